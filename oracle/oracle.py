@@ -1,0 +1,358 @@
+"""ctypes/numpy front end of liboracle.so plus the numpy/torch-CPU restatements
+of the parts of the path that are pure tensor algebra in the reference.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Citations are relative to
+/root/reference/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    """Compile liboracle.so (gcc, -ffp-contract=off).  Building the checker is
+    not using it; __graft_entry__.build() calls this."""
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+    return _LIB
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# --------------------------------------------------------------------------- a1
+def knn(xyz_bn3, k, return_pd=False):
+    """utils/model_common_utils.py:3-9 on xyz [B,N,3] -> int64 [B,N,k]."""
+    x = _f(xyz_bn3)
+    B, N, _ = x.shape
+    idx = np.empty((B, N, k), np.int64)
+    pd = np.empty((B, N, k), np.float32)
+    lib().orc_knn(_p(x), B, N, k, _p(idx), _p(pd))
+    return (idx, pd) if return_pd else idx
+
+
+def knn_pd(xyz_bn3):
+    """Full [B,N,N] matrix of the negated expanded distances knn() ranks."""
+    x = _f(xyz_bn3)
+    B, N, _ = x.shape
+    pd = np.empty((B, N, N), np.float32)
+    lib().orc_knn_pd(_p(x), B, N, _p(pd))
+    return pd
+
+
+def assert_knn_equal_modulo_ties(idx, ref_idx, xyz_bn3):
+    """Bit-identical indices wherever the ranked values are distinct; under exact fp32
+    ties (where the reference's topk order is unspecified) the
+    two index lists must still carry the identical value sequence."""
+    idx = np.asarray(idx).astype(np.int64)
+    ref_idx = np.asarray(ref_idx).astype(np.int64)
+    assert idx.shape == ref_idx.shape
+    pd = knn_pd(xyz_bn3)
+    va = np.take_along_axis(pd, idx, axis=2)
+    vb = np.take_along_axis(pd, ref_idx, axis=2)
+    assert np.array_equal(va, vb), "ranked value sequences differ"
+    diff = idx != ref_idx
+    if diff.any():
+        k = idx.shape[2]
+        # every differing slot must sit in a run of equal values (the k-th may tie with the (k+1)-th)
+        kth = np.sort(pd, axis=2)[:, :, ::-1][:, :, :min(k + 1, pd.shape[2])]
+        left = np.concatenate([np.zeros_like(diff[..., :1]), va[..., 1:] == va[..., :-1]], axis=2)
+        right = np.concatenate([va[..., :-1] == va[..., 1:], (va[..., -1:] == kth[..., -1:])], axis=2)
+        assert (~diff | left | right).all(), "indices differ outside exact ties"
+    return int(diff.sum())
+
+
+def get_graph_feature(x_b3n, k=20):
+    """utils/model_common_utils.py:132-156: [B,C,N] -> [B,2C,N,k] = cat(neighbour, centre)."""
+    x = _f(x_b3n)
+    B, Cc, N = x.shape
+    xt = np.ascontiguousarray(x.transpose(0, 2, 1))          # [B,N,C]
+    idx = knn(xt, k)
+    nb = np.stack([xt[b][idx[b]] for b in range(B)])         # [B,N,k,C]
+    ctr = np.broadcast_to(xt[:, :, None, :], nb.shape)
+    return np.ascontiguousarray(np.concatenate([nb, ctr], axis=3).transpose(0, 3, 1, 2))
+
+
+# --------------------------------------------------------------------------- a3
+def square_distance(src, dst):
+    s, d = _f(src), _f(dst)
+    B, N, _ = s.shape
+    M = d.shape[1]
+    out = np.empty((B, N, M), np.float32)
+    lib().orc_square_distance(_p(s), _p(d), B, N, M, _p(out))
+    return out
+
+
+# --------------------------------------------------------------------------- a4
+def query_ball_point(radius, nsample, xyz, new_xyz, get_cnt=False):
+    x, q = _f(xyz), _f(new_xyz)
+    B, N, _ = x.shape
+    S = q.shape[1]
+    idx = np.empty((B, S, nsample), np.int64)
+    cnt = np.empty((B, S), np.int64)
+    lib().orc_query_ball_point(C.c_float(radius), nsample, _p(x), _p(q), B, N, S, _p(idx), _p(cnt))
+    return (idx, cnt) if get_cnt else idx
+
+
+# --------------------------------------------------------------------------- a5
+def index_points(points, idx):
+    """utils/model_common_utils.py:40-56."""
+    points = np.asarray(points)
+    idx = np.asarray(idx)
+    B = points.shape[0]
+    return np.stack([points[b][idx[b]] for b in range(B)])
+
+
+# --------------------------------------------------------------------------- a6
+def farthest_point_sample(xyz, npoint):
+    """start_with_first_point=True variant (the random start is not testable)."""
+    x = _f(xyz)
+    B, N, _ = x.shape
+    out = np.empty((B, npoint), np.int64)
+    lib().orc_farthest_point_sample(_p(x), B, N, npoint, _p(out))
+    return out
+
+
+# --------------------------------------------------------------------------- a7
+def knn_point(k, pos1, pos2):
+    p1, p2 = _f(pos1), _f(pos2)
+    B, N, _ = p1.shape
+    M = p2.shape[1]
+    val = np.empty((B, M, k), np.float32)
+    idx = np.empty((B, M, k), np.int64)
+    lib().orc_knn_point(k, _p(p1), _p(p2), B, N, M, _p(val), _p(idx))
+    return val, idx
+
+
+# --------------------------------------------------------------------------- a9
+def chamfer_forward(xyz1, xyz2):
+    a, b = _f(xyz1), _f(xyz2)
+    B, N, _ = a.shape
+    M = b.shape[1]
+    d1 = np.empty((B, N), np.float32); d2 = np.empty((B, M), np.float32)
+    i1 = np.empty((B, N), np.int32); i2 = np.empty((B, M), np.int32)
+    lib().orc_chamfer_forward(_p(a), _p(b), B, N, M, _p(d1), _p(d2), _p(i1), _p(i2))
+    return d1, d2, i1, i2
+
+
+def chamfer_backward(xyz1, xyz2, gd1, gd2, idx1, idx2):
+    a, b = _f(xyz1), _f(xyz2)
+    B, N, _ = a.shape
+    M = b.shape[1]
+    g1 = np.empty_like(a); g2 = np.empty_like(b)
+    gd1, gd2, idx1, idx2 = _f(gd1), _f(gd2), _i32(idx1), _i32(idx2)
+    lib().orc_chamfer_backward(_p(a), _p(b), B, N, M, _p(gd1), _p(gd2), _p(idx1), _p(idx2), _p(g1), _p(g2))
+    return g1, g2
+
+
+def chamfer_loss(template, source):
+    """losses/chamfer_distance.py:34-43: (mean sqrt d1 + mean sqrt d2) / 2 over the whole batch."""
+    d1, d2, _, _ = chamfer_forward(template, source)
+    m1 = np.sqrt(d1).astype(np.float32).mean(dtype=np.float64)
+    m2 = np.sqrt(d2).astype(np.float32).mean(dtype=np.float64)
+    return np.float32((m1 + m2) / 2.0)
+
+
+# --------------------------------------------------------------------------- K7-K16
+def ball_query(radius, nsample, xyz, new_xyz):
+    x, q = _f(xyz), _f(new_xyz)
+    B, N, _ = x.shape
+    S = q.shape[1]
+    idx = np.zeros((B, S, nsample), np.int32)
+    lib().orc_ball_query(B, N, S, C.c_float(radius), nsample, _p(q), _p(x), _p(idx))
+    return idx
+
+
+def group_points(points_bcn, idx_bsk):
+    p, ix = _f(points_bcn), _i32(idx_bsk)
+    B, Cc, N = p.shape
+    _, S, K = ix.shape
+    out = np.empty((B, Cc, S, K), np.float32)
+    lib().orc_group_points(B, Cc, N, S, K, _p(p), _p(ix), _p(out))
+    return out
+
+
+def group_points_grad(grad_out, idx_bsk, N):
+    g, ix = _f(grad_out), _i32(idx_bsk)
+    B, Cc, S, K = g.shape
+    out = np.empty((B, Cc, N), np.float32)
+    lib().orc_group_points_grad(B, Cc, N, S, K, _p(g), _p(ix), _p(out))
+    return out
+
+
+def gather_points(points_bcn, idx_bs):
+    p, ix = _f(points_bcn), _i32(idx_bs)
+    B, Cc, N = p.shape
+    S = ix.shape[1]
+    out = np.empty((B, Cc, S), np.float32)
+    lib().orc_gather_points(B, Cc, N, S, _p(p), _p(ix), _p(out))
+    return out
+
+
+def gather_points_grad(grad_out, idx_bs, N):
+    g, ix = _f(grad_out), _i32(idx_bs)
+    B, Cc, S = g.shape
+    out = np.empty((B, Cc, N), np.float32)
+    lib().orc_gather_points_grad(B, Cc, N, S, _p(g), _p(ix), _p(out))
+    return out
+
+
+def furthest_point_sampling(xyz, npoint):
+    x = _f(xyz)
+    B, N, _ = x.shape
+    temp = np.full((B, N), 1e10, np.float32)
+    out = np.empty((B, npoint), np.int32)
+    lib().orc_furthest_point_sampling(B, N, npoint, _p(x), _p(temp), _p(out))
+    return out
+
+
+def knn_pair(k, unknown, known):
+    """pointnet2_utils.knn: returns (sqrt(dist2), idx) like pointnet2_utils.py:94-95."""
+    u, kn = _f(unknown), _f(known)
+    B, N, _ = u.shape
+    M = kn.shape[1]
+    d2 = np.empty((B, N, k), np.float32)
+    idx = np.empty((B, N, k), np.int32)
+    lib().orc_knn_pair(B, N, M, k, _p(u), _p(kn), _p(d2), _p(idx))
+    return np.sqrt(d2), idx
+
+
+def three_nn(unknown, known):
+    return knn_pair(3, unknown, known)
+
+
+def three_interpolate(points_bcm, idx_bn3, weight_bn3):
+    p, ix, w = _f(points_bcm), _i32(idx_bn3), _f(weight_bn3)
+    B, Cc, M = p.shape
+    N = ix.shape[1]
+    out = np.empty((B, Cc, N), np.float32)
+    lib().orc_three_interpolate(B, Cc, M, N, _p(p), _p(ix), _p(w), _p(out))
+    return out
+
+
+def three_interpolate_grad(grad_out, idx_bn3, weight_bn3, M):
+    g, ix, w = _f(grad_out), _i32(idx_bn3), _f(weight_bn3)
+    B, Cc, N = g.shape
+    out = np.empty((B, Cc, M), np.float32)
+    lib().orc_three_interpolate_grad(B, Cc, N, M, _p(g), _p(ix), _p(w), _p(out))
+    return out
+
+
+# --------------------------------------------------------------------------- a10
+def emd_forward(xyz1, xyz2):
+    a, b = _f(xyz1), _f(xyz2)
+    B, n, _ = a.shape
+    m = b.shape[1]
+    match = np.empty((B, n, m), np.float32)      # allocated [B,n,m], indexed [l*n+k] (emd.cu:18, emd.cuh:158)
+    cost = np.empty((B,), np.float32)
+    lib().orc_emd_approxmatch(B, n, m, _p(a), _p(b), _p(match))
+    lib().orc_emd_matchcost(B, n, m, _p(a), _p(b), _p(match), _p(cost))
+    return cost, match
+
+
+def emd_backward(xyz1, xyz2, match):
+    a, b, mt = _f(xyz1), _f(xyz2), _f(match)
+    B, n, _ = a.shape
+    m = b.shape[1]
+    g1 = np.empty_like(a); g2 = np.empty_like(b)
+    lib().orc_emd_matchcostgrad(B, n, m, _p(a), _p(b), _p(mt), _p(g1), _p(g2))
+    return g1, g2
+
+
+# --------------------------------------------------------------------------- a11
+def svd_head(src_emb, tgt_emb, src_bn3, tgt_bn3):
+    """utils/svd.py:13-59 in float32 numpy (np.linalg.svd = LAPACK gesdd, as torch.svd on CPU).
+
+    src_emb/tgt_emb [B,C,N]; src/tgt [B,N,3] ("bnc").  Returns R [B,3,3], t [B,3]."""
+    se, te = _f(src_emb), _f(tgt_emb)
+    src = _f(src_bn3).transpose(0, 2, 1)       # [B,3,N]
+    tgt = _f(tgt_bn3).transpose(0, 2, 1)
+    d_k = se.shape[1]
+    scores = np.matmul(se.transpose(0, 2, 1), te) / np.float32(np.sqrt(d_k))
+    scores = scores - scores.max(axis=2, keepdims=True)
+    e = np.exp(scores)
+    scores = (e / e.sum(axis=2, keepdims=True)).astype(np.float32)
+    src_corr = np.matmul(tgt, scores.transpose(0, 2, 1))
+    return kabsch(src, src_corr)
+
+
+def kabsch(src_b3n, corr_b3n):
+    """utils/svd.py:29-58: centre, H = src_c corr_c^T, R = V U^T (det-fixed), t."""
+    src, corr = _f(src_b3n), _f(corr_b3n)
+    sm = src.mean(axis=2, keepdims=True, dtype=np.float32)
+    cm = corr.mean(axis=2, keepdims=True, dtype=np.float32)
+    H = np.matmul(src - sm, (corr - cm).transpose(0, 2, 1))
+    R = rotation_from_H(H)
+    t = np.matmul(-R, sm) + cm
+    return R.astype(np.float32), t[:, :, 0].astype(np.float32)
+
+
+def rotation_from_H(H):
+    """utils/svd.py:38-49 per item: u,s,v = svd(H); r = v u^T; if det(r) < 0: v = v diag(1,1,-1)."""
+    H = np.asarray(H)
+    R = np.empty_like(H)
+    refl = np.diag([1.0, 1.0, -1.0]).astype(H.dtype)
+    for i in range(H.shape[0]):
+        u, s, vt = np.linalg.svd(H[i])
+        v = vt.T
+        r = v @ u.T
+        if np.linalg.det(r) < 0:
+            r = (v @ refl) @ u.T
+        R[i] = r
+    return R
+
+
+# --------------------------------------------------------------------------- a8
+def dgcnn_forward_torch(x_bn3, weights, k=20, eps=1e-5):
+    """models/dgcnn.py:25-49 in eval mode, restated with plain torch CPU ops.
+
+    `weights` is a dict with conv{1..5}.weight [Co,Ci,1,1] and bn{1..5}.{weight,bias,
+    running_mean,running_var}.  The graph comes from this oracle's own knn (C) so the
+    whole forward is independent of learning3d_amd."""
+    import torch
+    import torch.nn.functional as F
+    x = torch.as_tensor(np.asarray(x_bn3, dtype=np.float32))
+    B, N, _ = x.shape
+    idx = torch.from_numpy(knn(x.numpy(), k))                       # [B,N,k]
+    nb = torch.gather(x.unsqueeze(1).expand(B, N, N, 3), 2, idx.unsqueeze(-1).expand(B, N, k, 3))
+    feat = torch.cat([nb, x.unsqueeze(2).expand(B, N, k, 3)], dim=3).permute(0, 3, 1, 2)  # [B,6,N,k]
+
+    def block(h, i):
+        w = torch.as_tensor(weights[f"conv{i}.weight"])
+        h = F.conv2d(h, w)
+        h = F.batch_norm(h, torch.as_tensor(weights[f"bn{i}.running_mean"]),
+                         torch.as_tensor(weights[f"bn{i}.running_var"]),
+                         torch.as_tensor(weights[f"bn{i}.weight"]),
+                         torch.as_tensor(weights[f"bn{i}.bias"]), False, 0.0, eps)
+        return F.relu(h)
+
+    outs = []
+    h = feat
+    for i in (1, 2, 3, 4):
+        h = block(h, i)
+        outs.append(h.max(dim=-1, keepdim=True)[0])
+    h = block(torch.cat(outs, dim=1), 5)
+    return h.view(B, -1, N)

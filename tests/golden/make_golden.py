@@ -1,0 +1,177 @@
+"""Generate the golden fixtures in this directory by RUNNING THE REAL REFERENCE.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+What it does
+  * copies /root/reference to a scratch dir named `learning3d` (the reference is a
+    namespace package that must be imported under that name; importing it in place
+    would write __pycache__ into the read-only tree), stubs the unused `h5py`
+    import (utils/transformer.py:4), imports learning3d.{utils,models,losses};
+  * loads oracle/_ref/cd_ref*.so = the reference's own Chamfer C++ CPU path
+    (losses/cuda/chamfer_distance/chamfer_distance.cpp:59-177), built by
+    oracle/build_ref.py from the source where it lies;
+  * evaluates each hot-path function on small seeded inputs and stores
+    inputs + outputs as compressed .npz next to this script.
+
+The reference ships no tests / KATs; these vectors are what
+pins oracle/ (tests/test_oracle_golden.py) and, through it, the HIP kernels.
+Nothing here is read at run time on the GPU box except the .npz files.
+"""
+import glob
+import importlib.util
+import os
+import shutil
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+
+def import_reference():
+    tmp = tempfile.mkdtemp(prefix="l3d_ref_")
+    shutil.copytree(REF, os.path.join(tmp, "learning3d"),
+                    ignore=shutil.ignore_patterns("pretrained", "images", "build", "dist", "*.egg-info"))
+    sys.dont_write_bytecode = True
+    sys.modules.setdefault("h5py", types.ModuleType("h5py"))
+    sys.path.insert(0, tmp)
+    import learning3d.utils as U          # noqa
+    import learning3d.models as Mo        # noqa
+    import learning3d.losses.chamfer_distance as CD  # noqa
+    return tmp, U, Mo, CD
+
+
+def load_cd_ref():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import build_ref
+    so = build_ref.main(REF)
+    spec = importlib.util.spec_from_file_location("cd_ref", so)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def rand(shape, seed, lo=0.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(shape, generator=g) * (hi - lo) + lo
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  {name}.npz  {os.path.getsize(path)/1024:.1f} KiB")
+
+
+def main():
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+    tmp, U, Mo, CD = import_reference()
+    cd_ref = load_cd_ref()
+    from learning3d.utils.model_common_utils import (knn, get_graph_feature, square_distance, index_points,
+                                                     farthest_point_sample, knn_point, query_ball_point)
+    print("reference imported from", tmp)
+    with torch.no_grad():
+        # ---- a1 knn (c2 distribution: U(0,1)^3) ------------------------------------------
+        x = rand((2, 1024, 3), 0)                                   # [B,N,3]
+        idx = knn(x.permute(0, 2, 1), 20)
+        save("knn_n1024_k20", xyz=x, idx=idx.to(torch.int16))
+        x = rand((3, 200, 3), 1, -1.0, 1.0)
+        save("knn_n200_k7", xyz=x, idx=knn(x.permute(0, 2, 1), 7).to(torch.int16),
+             idx_plus1=knn(x.permute(0, 2, 1), 7, add_one_to_k=True).to(torch.int16))
+        # ---- a2 graph feature -----------------------------------------------------------
+        x = rand((2, 96, 3), 2)
+        save("graph_feature_n96", xyz=x, feat=get_graph_feature(x.permute(0, 2, 1), k=20, device="cpu").contiguous())
+        # ---- a3/a4/a5/a6/a7 -------------------------------------------------------------
+        src, dst = rand((2, 64, 3), 3, -1, 1), rand((2, 160, 3), 4, -1, 1)
+        save("square_distance", src=src, dst=dst, dist=square_distance(src, dst))
+        xyz = rand((2, 512, 3), 5, -1, 1)
+        new_xyz = xyz[:, :64, :].contiguous()
+        qi, qc = query_ball_point(0.3, 16, xyz, new_xyz, get_cnt=True)
+        far = rand((2, 4, 3), 6, 5, 6)                               # empty balls
+        qe = query_ball_point(0.3, 16, xyz, far)
+        save("query_ball_point", xyz=xyz, new_xyz=new_xyz, idx=qi.to(torch.int32), cnt=qc.to(torch.int32),
+             far=far, idx_far=qe.to(torch.int32), radius=np.float32(0.3), nsample=16)
+        pts = rand((2, 512, 5), 7)
+        save("index_points", points=pts, idx2=qi.to(torch.int32), out2=index_points(pts, qi),
+             idx1=qi[:, :, 0].to(torch.int32), out1=index_points(pts, qi[:, :, 0]))
+        save("farthest_point_sample", xyz=xyz,
+             idx=farthest_point_sample(xyz, 128, start_with_first_point=True).to(torch.int32))
+        pos1, pos2 = rand((2, 300, 3), 8), rand((2, 50, 3), 9)
+        v, i = knn_point(8, pos1, pos2)
+        save("knn_point", pos1=pos1, pos2=pos2, val=v, idx=i.to(torch.int32))
+        # ---- a9 chamfer: torch fallback + the reference's C++ nnsearch/backward ----------
+        a, b = rand((3, 256, 3), 10), rand((3, 320, 3), 11)
+        M = CD.pairwise_distances(a, b)
+        d1t, i1t = M.min(2)
+        d2t, i2t = M.min(1)
+        loss_t = CD.chamfer(a, b)
+        d1 = torch.zeros(3, 256); d2 = torch.zeros(3, 320)
+        i1 = torch.zeros(3, 256, dtype=torch.int); i2 = torch.zeros(3, 320, dtype=torch.int)
+        cd_ref.forward(a, b, d1, d2, i1, i2)
+        assert torch.equal(d1, d1t) and torch.equal(d2, d2t), "C++ nnsearch != torch fallback"
+        loss_c = (torch.mean(torch.sqrt(d1)) + torch.mean(torch.sqrt(d2))) / 2.0
+        gd1, gd2 = rand((3, 256), 12), rand((3, 320), 13)
+        g1 = torch.zeros_like(a); g2 = torch.zeros_like(b)
+        cd_ref.backward(a, b, g1, g2, gd1, gd2, i1, i2)
+        save("chamfer", xyz1=a, xyz2=b, dist1=d1, dist2=d2, idx1=i1, idx2=i2, loss_fallback=loss_t, loss_ext=loss_c,
+             graddist1=gd1, graddist2=gd2, gradxyz1=g1, gradxyz2=g2)
+        # ---- a8 DGCNN / PointNet / PCN forwards (eval, randomised BN statistics) ---------
+        torch.manual_seed(1)
+        net = Mo.DGCNN(emb_dims=64).eval()
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.2, 0.2); m.running_var.uniform_(0.5, 1.5)
+                m.weight.data.uniform_(0.5, 1.5); m.bias.data.uniform_(-0.2, 0.2)
+        x = rand((2, 128, 3), 14)
+        save("dgcnn_emb64", x=x, out=net(x), **{"w." + k: v for k, v in net.state_dict().items()})
+        torch.manual_seed(2)
+        pn = Mo.PointNet(emb_dims=64, use_bn=True).eval()
+        for m in pn.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.uniform_(-0.2, 0.2); m.running_var.uniform_(0.5, 1.5)
+        x = rand((2, 100, 3), 15, -1, 1)
+        save("pointnet_emb64", x=x, out=pn(x), **{"w." + k: v for k, v in pn.state_dict().items()})
+        # ---- a11 SVD head ----------------------------------------------------------------
+        from learning3d.utils.svd import SVDHead
+        head = SVDHead(emb_dims=32, input_shape="bnc")
+        se, te = rand((4, 32, 64), 16, -1, 1), rand((4, 32, 64), 17, -1, 1)
+        src = rand((4, 64, 3), 18, -0.5, 0.5)
+        ang = rand((4, 3), 19, 0, np.pi / 4)
+        Rs = []
+        for e in ang:
+            cx, cy, cz = torch.cos(e); sx, sy, sz = torch.sin(e)
+            Rx = torch.tensor([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+            Ry = torch.tensor([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+            Rz = torch.tensor([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+            Rs.append(Rz @ Ry @ Rx)
+        Rg = torch.stack(Rs)
+        tgt = torch.matmul(src, Rg.transpose(1, 2)) + rand((4, 1, 3), 20, -0.5, 0.5)
+        # sharpen the soft assignment so H is well conditioned (SURVEY.md section 7 "SVD tolerance")
+        te2 = se * 8.0
+        R, t = head(se * 8.0, te2, src, tgt)
+        save("svd_head", src_emb=se * 8.0, tgt_emb=te2, src=src, tgt=tgt, R=R, t=t)
+        Hs = torch.randn(256, 3, 3, generator=torch.Generator().manual_seed(21))
+        Rh = []
+        for i in range(Hs.shape[0]):
+            u, s, v = torch.svd(Hs[i]); r = v @ u.t()
+            if torch.det(r) < 0:
+                r = (v @ head.reflect) @ u.t()
+            Rh.append(r)
+        save("svd3x3", H=Hs, R=torch.stack(Rh))
+    shutil.rmtree(tmp, ignore_errors=True)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
