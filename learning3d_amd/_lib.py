@@ -1,0 +1,103 @@
+"""ctypes binding of libl3d_hip.so (the C ABI declared in include/l3d_hip.h).
+
+The product path has NO fallback: if the shared library is missing, fails to load, or a call
+returns a non-zero status, this module raises.  PyTorch is used only for device memory
+(`tensor.data_ptr()`), streams (`torch.cuda.current_stream()`) and torch.distributed.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libl3d_hip.so")
+_lib = None
+
+_P, _I, _F, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> argtypes (restype is int unless listed in _RESTYPE)
+SIGNATURES = {
+    "l3d_version": [],
+    "l3d_status_string": [_I],
+    "l3d_last_hip_error": [],
+    "l3d_knn_graph": [_P, _I, _I, _I, _P, _P],
+    "l3d_graph_feature": [_P, _P, _I, _I, _I, _I, _P, _P],
+    "l3d_chamfer_forward": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
+    "l3d_chamfer_backward": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "l3d_chamfer_sqrt_sums": [_P, _P, _I, _I, _I, _P, _P],
+    "l3d_ball_query": [_I, _I, _I, _F, _I, _P, _P, _P, _P],
+    "l3d_group_points": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "l3d_group_points_grad": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "l3d_gather_points": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "l3d_gather_points_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "l3d_furthest_point_sampling": [_I, _I, _I, _P, _P, _P, _P],
+    "l3d_knn": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "l3d_three_nn": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "l3d_three_interpolate": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "l3d_three_interpolate_grad": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "l3d_square_distance": [_P, _P, _I, _I, _I, _P, _P],
+    "l3d_query_ball_point": [_F, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "l3d_index_points": [_P, _P, _I, _I, _I, _I, _P, _P],
+    "l3d_farthest_point_sample": [_P, _I, _I, _I, _P, _P, _P, _P],
+    "l3d_knn_point": [_I, _P, _P, _I, _I, _I, _P, _P, _P],
+    "l3d_kabsch": [_P, _P, _I, _I, _P, _P, _P, _P],
+    "l3d_svd3x3_rotation": [_P, _I, _P, _P],
+    "l3d_edgeconv_packed_floats": [_I, _I, _I, _I],
+    "l3d_edgeconv_pack": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "l3d_edgeconv_forward": [_P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P],
+    "l3d_pointwise_conv": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "l3d_emd_forward": [_P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "l3d_emd_backward": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
+}
+_RESTYPE = {"l3d_status_string": C.c_char_p, "l3d_edgeconv_packed_floats": _SZ}
+
+
+class L3DError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libl3d_hip.so once.  Raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise L3DError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(python -m learning3d_amd.build, or __graft_entry__.build()). "
+                "learning3d_amd has no CPU / eager fallback by design.")
+        handle = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the ABI drifted
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPE.get(name, _I)
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        l = lib()
+        msg = l.l3d_status_string(status).decode()
+        raise L3DError(f"{what}: {msg} (status {status}, hipError {l.l3d_last_hip_error()})")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise L3DError("learning3d_amd operates on MI355X device tensors only "
+                           "(got a CPU tensor; there is no CPU fallback)")
+
+
+def f32c(t):
+    """contiguous fp32 view/copy of a device tensor"""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()

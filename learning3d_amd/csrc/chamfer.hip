@@ -1,0 +1,221 @@
+// chamfer.hip -- Chamfer nearest-neighbour search (fwd) and gradient (bwd) for gfx950.
+//
+// Replaces the pybind module `cd` of losses/cuda/chamfer_distance/ :
+//   K1  ChamferDistanceKernel      chamfer_distance.cu:6-137   (<<<dim3(32,16),512>>> x2)
+//   K2  ChamferDistanceGradKernel  chamfer_distance.cu:158-187 (fp32 atomicAdd scatter)
+// and matches the CPU twin `nnsearch` (chamfer_distance.cpp:59-87) bit for bit:
+//   d = (dx*dx + dy*dy) + dz*dz with dx = p2 - p1, no contraction, strict '<'.
+//
+// Design: both directions in ONE launch (blockIdx.z), one wave64 per workgroup, one or two
+// queries per lane, the other cloud streamed through LDS as float4 tiles and read back as
+// wave-uniform broadcasts.  No running-min merge through global memory (the reference merges
+// 512-point chunks through `result[]`, .cu:129-132): the running (min, argmin) lives in VGPRs.
+// Backward is deterministic: every output point owns its sum (direct term + an index-ordered
+// scan for the points that selected it), reproducing the CPU reference's accumulation order
+// (chamfer_distance.cpp:138-176) instead of racing fp32 atomics.
+#include "common.h"
+
+#define CTILE 2048
+
+template <int QPL>   // queries per lane
+__global__ __launch_bounds__(64) void chamfer_fwd_kernel(const float *__restrict__ xyz1,
+                                                         const float *__restrict__ xyz2, int N,
+                                                         int M, float *__restrict__ dist1,
+                                                         float *__restrict__ dist2,
+                                                         int32_t *__restrict__ idx1,
+                                                         int32_t *__restrict__ idx2)
+{
+    __shared__ float4 cand[CTILE];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.y;
+    const int dir = blockIdx.z;
+    const float *qs = dir == 0 ? xyz1 : xyz2;
+    const float *cs = dir == 0 ? xyz2 : xyz1;
+    const int Nq = dir == 0 ? N : M;
+    const int Nc = dir == 0 ? M : N;
+    float *dout = dir == 0 ? dist1 : dist2;
+    int32_t *iout = dir == 0 ? idx1 : idx2;
+    const int q0 = blockIdx.x * (64 * QPL);
+    if (q0 >= Nq) return;            // whole block out of range (grid is sized for max(N,M))
+
+    float qx[QPL], qy[QPL], qz[QPL], best[QPL];
+    int besti[QPL];
+#pragma unroll
+    for (int u = 0; u < QPL; u++) {
+        int q = min(q0 + u * 64 + lane, Nq - 1);
+        const float *p = qs + ((size_t)b * Nq + q) * 3;
+        qx[u] = p[0]; qy[u] = p[1]; qz[u] = p[2];
+        best[u] = INFINITY; besti[u] = 0;
+    }
+    const float *cbase = cs + (size_t)b * Nc * 3;
+    for (int c0 = 0; c0 < Nc; c0 += CTILE) {
+        const int tn = min(CTILE, Nc - c0);
+        __syncthreads();
+        for (int t = lane; t < tn; t += 64) {
+            const float *cp = cbase + (size_t)(c0 + t) * 3;
+            cand[t] = make_float4(cp[0], cp[1], cp[2], 0.f);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int t = 0; t < tn; t++) {
+            const float4 c = cand[t];
+#pragma unroll
+            for (int u = 0; u < QPL; u++) {
+                const float dx = c.x - qx[u], dy = c.y - qy[u], dz = c.z - qz[u];
+                const float d = (dx * dx + dy * dy) + dz * dz;
+                const bool lt = d < best[u];        // first candidate always wins vs +inf
+                best[u] = lt ? d : best[u];
+                besti[u] = lt ? c0 + t : besti[u];
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < QPL; u++) {
+        int q = q0 + u * 64 + lane;
+        if (q < Nq) {
+            dout[(size_t)b * Nq + q] = best[u];
+            iout[(size_t)b * Nq + q] = besti[u];
+        }
+    }
+}
+
+extern "C" int l3d_chamfer_forward(const float *xyz1, const float *xyz2, int B, int N, int M,
+                                   float *dist1, float *dist2, int32_t *idx1, int32_t *idx2,
+                                   l3d_stream_t stream)
+{
+    L3D_REQUIRE(xyz1 && xyz2 && dist1 && dist2 && idx1 && idx2 && B > 0 && N > 0 && M > 0);
+    const int mx = N > M ? N : M;
+    // enough waves to cover 256 CUs x 4 SIMDs a few times over before going to 2 queries/lane
+    const long waves1 = (long)l3d_divup(mx, 64) * B * 2;
+    if (waves1 >= 8192) {
+        dim3 grid(l3d_divup(mx, 128), B, 2);
+        hipLaunchKernelGGL(chamfer_fwd_kernel<2>, grid, dim3(64), 0, (hipStream_t)stream, xyz1, xyz2,
+                           N, M, dist1, dist2, idx1, idx2);
+    } else {
+        dim3 grid(l3d_divup(mx, 64), B, 2);
+        hipLaunchKernelGGL(chamfer_fwd_kernel<1>, grid, dim3(64), 0, (hipStream_t)stream, xyz1, xyz2,
+                           N, M, dist1, dist2, idx1, idx2);
+    }
+    return l3d_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward.  For output point i of cloud A (partner cloud C, A's own nn index ia, C's nn index ic):
+//   which == 0 (A = xyz1):  g = 0 + 2*gdA[i]*(a_i - c_ia[i])           (loop 1 of the CPU code)
+//                           then for j ascending with ic[j] == i:  g -= 2*gdC[j]*(c_j - a_i)
+//   which == 1 (A = xyz2):  g = 0; for j ascending with ic[j] == i: g -= 2*gdC[j]*(c_j - a_i)
+//                           then g += 2*gdA[i]*(a_i - c_ia[i])          (loop 2 comes second)
+// which is the exact accumulation order of chamfer_distance.cpp:138-176.
+// ---------------------------------------------------------------------------------------------
+#define BTILE 4096
+__global__ __launch_bounds__(64) void chamfer_bwd_kernel(const float *__restrict__ xyz1,
+                                                         const float *__restrict__ xyz2, int N,
+                                                         int M, const float *__restrict__ gd1,
+                                                         const float *__restrict__ gd2,
+                                                         const int32_t *__restrict__ idx1,
+                                                         const int32_t *__restrict__ idx2,
+                                                         float *__restrict__ g1,
+                                                         float *__restrict__ g2)
+{
+    __shared__ int32_t sel[BTILE];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.y;
+    const int which = blockIdx.z;
+    const float *A = which == 0 ? xyz1 : xyz2;
+    const float *C = which == 0 ? xyz2 : xyz1;
+    const int NA = which == 0 ? N : M;
+    const int NC = which == 0 ? M : N;
+    const float *gdA = which == 0 ? gd1 : gd2;
+    const float *gdC = which == 0 ? gd2 : gd1;
+    const int32_t *ia = which == 0 ? idx1 : idx2;
+    const int32_t *ic = which == 0 ? idx2 : idx1;
+    float *gout = which == 0 ? g1 : g2;
+    if (blockIdx.x * 64 >= NA) return;
+    const int i = blockIdx.x * 64 + lane;
+    const bool valid = i < NA;
+    const int iq = valid ? i : NA - 1;
+    const float *ap = A + ((size_t)b * NA + iq) * 3;
+    const float ax = ap[0], ay = ap[1], az = ap[2];
+    // direct term
+    const int j2 = ia[(size_t)b * NA + iq];
+    const float *cp = C + ((size_t)b * NC + j2) * 3;
+    const float g = gdA[(size_t)b * NA + iq] * 2;
+    const float dxd = g * (ax - cp[0]), dyd = g * (ay - cp[1]), dzd = g * (az - cp[2]);
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    if (which == 0) { gx += dxd; gy += dyd; gz += dzd; }
+    // scatter term, gathered: scan the partner cloud's selections in index order
+    const int32_t *icb = ic + (size_t)b * NC;
+    for (int c0 = 0; c0 < NC; c0 += BTILE) {
+        const int tn = min(BTILE, NC - c0);
+        __syncthreads();
+        for (int t = lane; t < tn; t += 64) sel[t] = icb[c0 + t];
+        __syncthreads();
+        for (int t = 0; t < tn; t++) {
+            if (sel[t] == iq) {          // rare, divergent branch: ~1 hit per lane per scan
+                const int j = c0 + t;
+                const float *pj = C + ((size_t)b * NC + j) * 3;
+                const float gj = gdC[(size_t)b * NC + j] * 2;
+                gx -= gj * (pj[0] - ax);
+                gy -= gj * (pj[1] - ay);
+                gz -= gj * (pj[2] - az);
+            }
+        }
+    }
+    if (which == 1) { gx += dxd; gy += dyd; gz += dzd; }
+    if (valid) {
+        float *o = gout + ((size_t)b * NA + i) * 3;
+        o[0] = gx; o[1] = gy; o[2] = gz;
+    }
+}
+
+extern "C" int l3d_chamfer_backward(const float *xyz1, const float *xyz2, int B, int N, int M,
+                                    const float *graddist1, const float *graddist2,
+                                    const int32_t *idx1, const int32_t *idx2, float *gradxyz1,
+                                    float *gradxyz2, l3d_stream_t stream)
+{
+    L3D_REQUIRE(xyz1 && xyz2 && graddist1 && graddist2 && idx1 && idx2 && gradxyz1 && gradxyz2 &&
+                B > 0 && N > 0 && M > 0);
+    const int mx = N > M ? N : M;
+    dim3 grid(l3d_divup(mx, 64), B, 2);
+    hipLaunchKernelGGL(chamfer_bwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, xyz1, xyz2, N, M,
+                       graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2);
+    return l3d_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// sums[0] = sum sqrt(dist1), sums[1] = sum sqrt(dist2)   (fp64 accumulation, one atomic/block)
+// ---------------------------------------------------------------------------------------------
+__global__ void zero2_kernel(double *s) { if (threadIdx.x < 2) s[threadIdx.x] = 0.0; }
+
+__global__ __launch_bounds__(256) void sqrt_sum_kernel(const float *__restrict__ d1, size_t n1,
+                                                       const float *__restrict__ d2, size_t n2,
+                                                       double *__restrict__ sums)
+{
+    __shared__ double part[4];
+    const int which = blockIdx.y;
+    const float *d = which == 0 ? d1 : d2;
+    const size_t n = which == 0 ? n1 : n2;
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (size_t)gridDim.x * blockDim.x)
+        acc += (double)sqrtf(d[i]);
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&sums[which], part[0] + part[1] + part[2] + part[3]);
+}
+
+extern "C" int l3d_chamfer_sqrt_sums(const float *dist1, const float *dist2, int B, int N, int M,
+                                     double *sums, l3d_stream_t stream)
+{
+    L3D_REQUIRE(dist1 && dist2 && sums && B > 0 && N > 0 && M > 0);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(zero2_kernel, dim3(1), dim3(64), 0, st, sums);
+    const size_t n1 = (size_t)B * N, n2 = (size_t)B * M;
+    const size_t mx = n1 > n2 ? n1 : n2;
+    int blocks = l3d_divup(mx, 256 * 8);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sqrt_sum_kernel, dim3(blocks, 2), dim3(256), 0, st, dist1, n1, dist2, n2, sums);
+    return l3d_check_launch();
+}

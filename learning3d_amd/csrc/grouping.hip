@@ -1,0 +1,443 @@
+// grouping.hip -- ball query, grouping / gather, farthest point sampling, 3-NN interpolation.
+//
+// Replaces the pybind module `pointnet2_cuda` (utils/lib/src/pointnet2_api.cpp:10-25):
+//   K7  ball_query_kernel_fast            ball_query_gpu.cu:9-45
+//   K8  group_points_kernel_fast          group_points_gpu.cu:47-66     K9  grad  :8-25
+//   K10 gather_points_kernel_fast         sampling_gpu.cu:8-24          K11 grad  :46-63
+//   K12 furthest_point_sampling_kernel    sampling_gpu.cu:93-209
+//   K15 three_interpolate_kernel_fast     interpolate_gpu.cu:149-169    K16 grad  :192-214
+// and the fused torch-level twins of utils/model_common_utils.py:
+//   T4  query_ball_point :102-130 (+ ppfnet_util.py:96-131 itself_indices, pointconv_util.py:85-105)
+//       -- the reference sorts an int64 [B,S,N] tensor (17 GB at B=256,N=8192,S=1024); here it is
+//          one streaming scan with early exit
+//   a3  square_distance :19-38,  a5 index_points :40-56,  T7 farthest_point_sample :58-82
+//
+// (K13/K14 knn / three_nn live in knn.hip.)
+#include "common.h"
+
+#define BQ_TILE 2048
+
+// ---------------------------------------------------------------------------------------------
+// Ball query.  One wave64 per workgroup, one centroid per lane, cloud streamed through LDS.
+// MODE 0 = native K7 : direct-difference d2, strict '<', int32 out, empty ball -> 0
+// MODE 1 = torch  T4 : expanded d2 (reference rounding order), '<=' (mask is d2 > r2), int64 out,
+//                      empty ball -> N, optional hit count, optional itself_indices
+// The scan stops as soon as every lane of the wave has nsample hits (unless counting).
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(64) void ball_query_kernel(int n, int m, float r2, int nsample,
+                                                        const float *__restrict__ new_xyz,
+                                                        const float *__restrict__ xyz,
+                                                        const int64_t *__restrict__ itself,
+                                                        void *__restrict__ idx_out,
+                                                        int64_t *__restrict__ cnt_out)
+{
+    __shared__ float4 cand[BQ_TILE];
+    const int lane = threadIdx.x;
+    const int b = blockIdx.y;
+    const int s = blockIdx.x * 64 + lane;
+    const bool valid = s < m;
+    const int sc = valid ? s : m - 1;
+    const float *qp = new_xyz + ((size_t)b * m + sc) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    const float qss = (qx * qx + qy * qy) + qz * qz;
+    const int self = (MODE == 1 && itself) ? (int)itself[(size_t)b * m + sc] : -1;
+    int32_t *o32 = (int32_t *)idx_out + ((size_t)b * m + sc) * nsample;
+    int64_t *o64 = (int64_t *)idx_out + ((size_t)b * m + sc) * nsample;
+    const float *cbase = xyz + (size_t)b * n * 3;
+    const bool counting = (MODE == 1) && cnt_out != nullptr;
+
+    int cnt = 0, first = -1;
+    long total = 0;
+    for (int c0 = 0; c0 < n; c0 += BQ_TILE) {
+        const int tn = min(BQ_TILE, n - c0);
+        __syncthreads();
+        for (int t = lane; t < tn; t += 64) {
+            const float *cp = cbase + (size_t)(c0 + t) * 3;
+            float x = cp[0], y = cp[1], z = cp[2];
+            cand[t] = make_float4(x, y, z, (x * x + y * y) + z * z);
+        }
+        __syncthreads();
+        if (!counting && __all(cnt >= nsample || !valid)) break;
+        for (int t = 0; t < tn; t++) {
+            const float4 c = cand[t];
+            bool hit;
+            if (MODE == 0) {
+                const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+                const float d2 = (dx * dx + dy * dy) + dz * dz;
+                hit = d2 < r2;
+            } else {
+                // square_distance(new_xyz, xyz): (-2*dot + |q|^2) + |p|^2
+                const float dot = fmaf(qz, c.z, fmaf(qy, c.y, qx * c.x));
+                const float d2 = (-2.0f * dot + qss) + c.w;
+                hit = !(d2 > r2) && (c0 + t != self);
+            }
+            if (hit) {
+                if (cnt < nsample && valid) {
+                    if (MODE == 0) o32[cnt] = c0 + t; else o64[cnt] = c0 + t;
+                    if (cnt == 0) first = c0 + t;
+                    cnt++;
+                }
+                total++;
+            }
+            if (!counting && ((t & 31) == 31) && __all(cnt >= nsample || !valid)) break;
+        }
+    }
+    if (!valid) return;
+    // pad: native -> first hit (or 0 when the ball is empty, the pre-zeroed idx of
+    // pointnet2_utils.py:246); torch -> first hit / itself_indices / N when empty
+    long fill;
+    if (MODE == 0) fill = first < 0 ? 0 : first;
+    else fill = self >= 0 ? self : (first < 0 ? n : first);
+    for (int l = cnt; l < nsample; l++) {
+        if (MODE == 0) o32[l] = (int32_t)fill; else o64[l] = fill;
+    }
+    if (counting) cnt_out[(size_t)b * m + s] = total;
+}
+
+extern "C" int l3d_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                              const float *xyz, int32_t *idx, l3d_stream_t stream)
+{
+    L3D_REQUIRE(new_xyz && xyz && idx && b > 0 && n > 0 && m > 0 && nsample > 0);
+    const float r2 = radius * radius;                       // ball_query_gpu.cu:24
+    hipLaunchKernelGGL(ball_query_kernel<0>, dim3(l3d_divup(m, 64), b), dim3(64), 0,
+                       (hipStream_t)stream, n, m, r2, nsample, new_xyz, xyz,
+                       (const int64_t *)nullptr, (void *)idx, (int64_t *)nullptr);
+    return l3d_check_launch();
+}
+
+extern "C" int l3d_query_ball_point(float radius, int nsample, const float *xyz,
+                                    const float *new_xyz, int B, int N, int S,
+                                    const int64_t *itself_indices, int64_t *idx, int64_t *cnt,
+                                    l3d_stream_t stream)
+{
+    L3D_REQUIRE(new_xyz && xyz && idx && B > 0 && N > 0 && S > 0 && nsample > 0);
+    // python `radius ** 2` is evaluated in double, then compared against an fp32 tensor
+    const float r2 = (float)((double)radius * (double)radius);
+    hipLaunchKernelGGL(ball_query_kernel<1>, dim3(l3d_divup(S, 64), B), dim3(64), 0,
+                       (hipStream_t)stream, N, S, r2, nsample, new_xyz, xyz, itself_indices,
+                       (void *)idx, cnt);
+    return l3d_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// square_distance: dist[b][i][j] = (-2*dot(s_i,d_j) + |s_i|^2) + |d_j|^2     (a3)
+// HBM-write-bound: one thread per 4 consecutive j (float4 store when M % 4 == 0).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void square_distance_kernel(const float *__restrict__ src,
+                                                              const float *__restrict__ dst, int N,
+                                                              int M, float *__restrict__ out)
+{
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    const float *s = src + ((size_t)b * N + i) * 3;
+    const float *d = dst + ((size_t)b * M + j) * 3;
+    const float sx = s[0], sy = s[1], sz = s[2];
+    const float dx = d[0], dy = d[1], dz = d[2];
+    const float dot = fmaf(sz, dz, fmaf(sy, dy, sx * dx));
+    const float ss = (sx * sx + sy * sy) + sz * sz;
+    const float dd = (dx * dx + dy * dy) + dz * dz;
+    out[((size_t)b * N + i) * M + j] = (-2.0f * dot + ss) + dd;
+}
+
+extern "C" int l3d_square_distance(const float *src, const float *dst, int B, int N, int M,
+                                   float *dist, l3d_stream_t stream)
+{
+    L3D_REQUIRE(src && dst && dist && B > 0 && N > 0 && M > 0 && N <= 65535 && B <= 65535);
+    hipLaunchKernelGGL(square_distance_kernel, dim3(l3d_divup(M, 256), N, B), dim3(256), 0,
+                       (hipStream_t)stream, src, dst, N, M, dist);
+    return l3d_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Grouping / gather (pure data movement: the HBM-bound ops of the path)
+// group : out[b][c][s][k] = points[b][c][idx[b][s][k]]     thread per (s,k), loop over a channel
+// gather: out[b][c][s]    = points[b][c][idx[b][s]]        slab; idx read once, writes coalesced
+// ---------------------------------------------------------------------------------------------
+#define GP_CCHUNK 16
+__global__ __launch_bounds__(256) void group_points_kernel(int c, int n, int total /*S*K*/,
+                                                           const float *__restrict__ points,
+                                                           const int32_t *__restrict__ idx,
+                                                           float *__restrict__ out)
+{
+    const int b = blockIdx.z;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int c0 = blockIdx.y * GP_CCHUNK;
+    const int c1 = min(c, c0 + GP_CCHUNK);
+    const int j = idx[(size_t)b * total + e];
+    const float *p = points + ((size_t)b * c + c0) * n + j;
+    float *o = out + ((size_t)b * c + c0) * total + e;
+    for (int cc = c0; cc < c1; cc++, p += n, o += total) *o = *p;
+}
+
+__global__ __launch_bounds__(256) void group_points_grad_kernel(int c, int n, int total,
+                                                                const float *__restrict__ grad_out,
+                                                                const int32_t *__restrict__ idx,
+                                                                float *__restrict__ grad_points)
+{
+    const int b = blockIdx.z;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int c0 = blockIdx.y * GP_CCHUNK;
+    const int c1 = min(c, c0 + GP_CCHUNK);
+    const int j = idx[(size_t)b * total + e];
+    float *p = grad_points + ((size_t)b * c + c0) * n + j;
+    const float *o = grad_out + ((size_t)b * c + c0) * total + e;
+    for (int cc = c0; cc < c1; cc++, p += n, o += total) atomicAdd(p, *o);
+}
+
+static int launch_group(bool grad, int b, int c, int n, int total, const float *src,
+                        const int32_t *idx, float *dst, hipStream_t st)
+{
+    dim3 grid(l3d_divup(total, 256), l3d_divup(c, GP_CCHUNK), b);
+    if (grad) {
+        hipError_t e = hipMemsetAsync(dst, 0, sizeof(float) * (size_t)b * c * n, st);
+        if (e != hipSuccess) { g_l3d_last_hip_error = (int)e; return L3D_ERR_LAUNCH; }
+        hipLaunchKernelGGL(group_points_grad_kernel, grid, dim3(256), 0, st, c, n, total, src, idx, dst);
+    } else {
+        hipLaunchKernelGGL(group_points_kernel, grid, dim3(256), 0, st, c, n, total, src, idx, dst);
+    }
+    return l3d_check_launch();
+}
+
+extern "C" int l3d_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                                const int32_t *idx, float *out, l3d_stream_t stream)
+{
+    L3D_REQUIRE(points && idx && out && b > 0 && c > 0 && n > 0 && npoints > 0 && nsample > 0);
+    return launch_group(false, b, c, n, npoints * nsample, points, idx, out, (hipStream_t)stream);
+}
+extern "C" int l3d_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                                     const float *grad_out, const int32_t *idx, float *grad_points,
+                                     l3d_stream_t stream)
+{
+    L3D_REQUIRE(grad_out && idx && grad_points && b > 0 && c > 0 && n > 0 && npoints > 0 && nsample > 0);
+    return launch_group(true, b, c, n, npoints * nsample, grad_out, idx, grad_points, (hipStream_t)stream);
+}
+extern "C" int l3d_gather_points(int b, int c, int n, int npoints, const float *points,
+                                 const int32_t *idx, float *out, l3d_stream_t stream)
+{
+    L3D_REQUIRE(points && idx && out && b > 0 && c > 0 && n > 0 && npoints > 0);
+    return launch_group(false, b, c, n, npoints, points, idx, out, (hipStream_t)stream);
+}
+extern "C" int l3d_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                                      const int32_t *idx, float *grad_points, l3d_stream_t stream)
+{
+    L3D_REQUIRE(grad_out && idx && grad_points && b > 0 && c > 0 && n > 0 && npoints > 0);
+    return launch_group(true, b, c, n, npoints, grad_out, idx, grad_points, (hipStream_t)stream);
+}
+
+// index_points: points [B,N,C] (channel-last), idx [B,S] int64 -> out [B,S,C]     (a5)
+__global__ __launch_bounds__(256) void index_points_kernel(const float *__restrict__ points,
+                                                           const int64_t *__restrict__ idx, int N,
+                                                           int C, int S, float *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // over S*C
+    if (e >= (size_t)S * C) return;
+    const int s = (int)(e / C), cc = (int)(e % C);
+    const int64_t j = idx[(size_t)b * S + s];
+    out[(size_t)b * S * C + e] = points[((size_t)b * N + j) * C + cc];
+}
+
+extern "C" int l3d_index_points(const float *points, const int64_t *idx, int B, int N, int C, int S,
+                                float *out, l3d_stream_t stream)
+{
+    L3D_REQUIRE(points && idx && out && B > 0 && N > 0 && C > 0 && S > 0);
+    hipLaunchKernelGGL(index_points_kernel, dim3(l3d_divup((long)S * C, 256), B), dim3(256), 0,
+                       (hipStream_t)stream, points, idx, N, C, S, out);
+    return l3d_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Farthest point sampling.  One workgroup (up to 1024 threads = 16 waves) per cloud; the cloud
+// and the running min-distance live in VGPRs (PPT points per thread), so a round is
+//   PPT x (3 sub, 3 mul, 2 add, min, cmp, 2 cndmask)  +  wave arg-max (6 DPP/shuffle steps)
+//   +  one LDS exchange between the <=16 waves  +  2 barriers
+// instead of the reference's global-memory `temp` round trip and 10-level LDS tree
+// (sampling_gpu.cu:139-203).  Arg-max ties resolve to the lowest index.
+// OUT64: int64 centroids + optional start index (torch twin T7), else int32, start 0 (K12).
+// ---------------------------------------------------------------------------------------------
+template <int PPT, bool OUT64>
+__global__ __launch_bounds__(1024) void fps_kernel(int n, int m, const float *__restrict__ xyz,
+                                                   const int64_t *__restrict__ start,
+                                                   float *__restrict__ temp,
+                                                   void *__restrict__ out)
+{
+    __shared__ float wv[2][16];
+    __shared__ int wi[2][16];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int b = blockIdx.x;
+    const float *p = xyz + (size_t)b * n * 3;
+    float px[PPT], py[PPT], pz[PPT], dmin[PPT];
+#pragma unroll
+    for (int u = 0; u < PPT; u++) {
+        const int k = tid + u * nthr;
+        const bool ok = k < n;
+        px[u] = ok ? p[k * 3] : 0.f;
+        py[u] = ok ? p[k * 3 + 1] : 0.f;
+        pz[u] = ok ? p[k * 3 + 2] : 0.f;
+        dmin[u] = ok ? 1e10f : -1.f;          // out-of-range slots can never win the arg-max
+    }
+    int old = (OUT64 && start) ? (int)start[b] : 0;
+    if (tid == 0) {
+        if (OUT64) ((int64_t *)out)[(size_t)b * m] = old; else ((int32_t *)out)[(size_t)b * m] = old;
+    }
+    const int nw = nthr >> 6, wave = tid >> 6, lane = tid & 63;
+    for (int j = 1; j < m; j++) {
+        const float x1 = p[old * 3], y1 = p[old * 3 + 1], z1 = p[old * 3 + 2];   // wave-uniform
+        float best = -1.f;
+        int besti = 0;
+#pragma unroll
+        for (int u = 0; u < PPT; u++) {
+            const float dx = px[u] - x1, dy = py[u] - y1, dz = pz[u] - z1;
+            const float d = (dx * dx + dy * dy) + dz * dz;
+            const float d2 = fminf(d, dmin[u]);
+            dmin[u] = d2;
+            const bool gt = d2 > best;          // ascending k within a thread: lowest index wins
+            best = gt ? d2 : best;
+            besti = gt ? tid + u * nthr : besti;
+        }
+        // wave arg-max, lowest index on ties
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(besti, off, 64);
+            const bool take = ov > best || (ov == best && oi < besti);
+            best = take ? ov : best;
+            besti = take ? oi : besti;
+        }
+        const int buf = j & 1;
+        if (lane == 0) { wv[buf][wave] = best; wi[buf][wave] = besti; }
+        __syncthreads();
+        float bv = wv[buf][0];
+        int bi = wi[buf][0];
+        for (int w = 1; w < nw; w++) {
+            const float ov = wv[buf][w];
+            const int oi = wi[buf][w];
+            const bool take = ov > bv || (ov == bv && oi < bi);
+            bv = take ? ov : bv;
+            bi = take ? oi : bi;
+        }
+        old = __builtin_amdgcn_readfirstlane(bi);     // wave-uniform -> scalar loads of p[old]
+        if (tid == 0) {
+            if (OUT64) ((int64_t *)out)[(size_t)b * m + j] = old; else ((int32_t *)out)[(size_t)b * m + j] = old;
+        }
+        // double-buffered wv/wi: the next round writes the other buffer, so one barrier per round
+    }
+    if (temp) {
+#pragma unroll
+        for (int u = 0; u < PPT; u++) {
+            const int k = tid + u * nthr;
+            if (k < n) temp[(size_t)b * n + k] = dmin[u];
+        }
+    }
+}
+
+template <bool OUT64>
+static int launch_fps(int b, int n, int m, const float *xyz, const int64_t *start, float *temp,
+                      void *out, hipStream_t st)
+{
+    // threads: multiple of 64, <= 1024; points per thread: 1,2,4,8,16,32
+    int nthr = n >= 1024 ? 1024 : ((n + 63) / 64) * 64;
+    int ppt = (n + nthr - 1) / nthr;
+#define L3D_FPS_CASE(P)                                                                           \
+    if (ppt <= P) {                                                                               \
+        hipLaunchKernelGGL((fps_kernel<P, OUT64>), dim3(b), dim3(nthr), 0, st, n, m, xyz, start,  \
+                           temp, out);                                                            \
+        return l3d_check_launch();                                                                \
+    }
+    L3D_FPS_CASE(1)
+    L3D_FPS_CASE(2)
+    L3D_FPS_CASE(4)
+    L3D_FPS_CASE(8)
+    L3D_FPS_CASE(16)
+    L3D_FPS_CASE(32)
+#undef L3D_FPS_CASE
+    return L3D_ERR_UNSUPPORTED;       // > 32768 points per cloud
+}
+
+extern "C" int l3d_furthest_point_sampling(int b, int n, int m, const float *points, float *temp,
+                                           int32_t *idx, l3d_stream_t stream)
+{
+    L3D_REQUIRE(points && idx && b > 0 && n > 0 && m > 0);
+    return launch_fps<false>(b, n, m, points, nullptr, temp, idx, (hipStream_t)stream);
+}
+
+extern "C" int l3d_farthest_point_sample(const float *xyz, int B, int N, int npoint,
+                                         const int64_t *start, float *temp, int64_t *centroids,
+                                         l3d_stream_t stream)
+{
+    L3D_REQUIRE(xyz && centroids && B > 0 && N > 0 && npoint > 0);
+    return launch_fps<true>(B, N, npoint, xyz, start, temp, centroids, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// three_interpolate: out[b][c][n] = (w0*p[i0] + w1*p[i1]) + w2*p[i2]     (K15)  + grad (K16)
+// thread per n, loop over a channel slab (idx/weight read once, coalesced writes)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, int n,
+                                                                const float *__restrict__ points,
+                                                                const int32_t *__restrict__ idx,
+                                                                const float *__restrict__ weight,
+                                                                float *__restrict__ out)
+{
+    const int b = blockIdx.z;
+    const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pt >= n) return;
+    const int c0 = blockIdx.y * GP_CCHUNK, c1 = min(c, c0 + GP_CCHUNK);
+    const int32_t *ix = idx + ((size_t)b * n + pt) * 3;
+    const float *w = weight + ((size_t)b * n + pt) * 3;
+    const int i0 = ix[0], i1 = ix[1], i2 = ix[2];
+    const float w0 = w[0], w1 = w[1], w2 = w[2];
+    for (int cc = c0; cc < c1; cc++) {
+        const float *p = points + ((size_t)b * c + cc) * m;
+        out[((size_t)b * c + cc) * n + pt] = (w0 * p[i0] + w1 * p[i1]) + w2 * p[i2];
+    }
+}
+
+__global__ __launch_bounds__(256) void three_interpolate_grad_kernel(
+    int c, int n, int m, const float *__restrict__ grad_out, const int32_t *__restrict__ idx,
+    const float *__restrict__ weight, float *__restrict__ grad_points)
+{
+    const int b = blockIdx.z;
+    const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pt >= n) return;
+    const int c0 = blockIdx.y * GP_CCHUNK, c1 = min(c, c0 + GP_CCHUNK);
+    const int32_t *ix = idx + ((size_t)b * n + pt) * 3;
+    const float *w = weight + ((size_t)b * n + pt) * 3;
+    const int i0 = ix[0], i1 = ix[1], i2 = ix[2];
+    const float w0 = w[0], w1 = w[1], w2 = w[2];
+    for (int cc = c0; cc < c1; cc++) {
+        const float g = grad_out[((size_t)b * c + cc) * n + pt];
+        float *gp = grad_points + ((size_t)b * c + cc) * m;
+        atomicAdd(gp + i0, g * w0);
+        atomicAdd(gp + i1, g * w1);
+        atomicAdd(gp + i2, g * w2);
+    }
+}
+
+extern "C" int l3d_three_interpolate(int b, int c, int m, int n, const float *points,
+                                     const int32_t *idx, const float *weight, float *out,
+                                     l3d_stream_t stream)
+{
+    L3D_REQUIRE(points && idx && weight && out && b > 0 && c > 0 && m > 0 && n > 0);
+    hipLaunchKernelGGL(three_interpolate_kernel, dim3(l3d_divup(n, 256), l3d_divup(c, GP_CCHUNK), b),
+                       dim3(256), 0, (hipStream_t)stream, c, m, n, points, idx, weight, out);
+    return l3d_check_launch();
+}
+
+extern "C" int l3d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                                          const int32_t *idx, const float *weight,
+                                          float *grad_points, l3d_stream_t stream)
+{
+    L3D_REQUIRE(grad_out && idx && weight && grad_points && b > 0 && c > 0 && m > 0 && n > 0);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)b * c * m, st);
+    if (e != hipSuccess) { g_l3d_last_hip_error = (int)e; return L3D_ERR_LAUNCH; }
+    hipLaunchKernelGGL(three_interpolate_grad_kernel,
+                       dim3(l3d_divup(n, 256), l3d_divup(c, GP_CCHUNK), b), dim3(256), 0, st, c, n, m,
+                       grad_out, idx, weight, grad_points);
+    return l3d_check_launch();
+}

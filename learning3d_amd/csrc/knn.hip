@@ -1,0 +1,221 @@
+// knn.hip -- fused pairwise-distance + top-k selection for gfx950 (wave64).
+//
+// Replaces, without ever materialising an [N,M] distance matrix:
+//   T1  knn()          utils/model_common_utils.py:3-9     (expanded metric, self cloud, int64)
+//   K13 knn_kernel_fast   utils/lib/src/interpolate_gpu.cu:9-57   (direct metric, int32, dist2)
+//   K14 three_nn_kernel_fast  interpolate_gpu.cu:81-124            (k = 3)
+//   T8  knn_point()    utils/model_common_utils.py:84-100  (direct metric, int64, sqrt)
+//
+// Kernel shape (MI355X-first, not the reference's thread-per-query + scratch arrays):
+//   * one wave64 per workgroup, one query per lane; >= 512 workgroups at B=32,N=1024 so all
+//     256 CUs get work;
+//   * candidates are staged as float4 (x,y,z,w) tiles in LDS with one coalesced pass over the
+//     [M,3] cloud, then read back as wave-uniform ds_read_b128 broadcasts (one LDS access per
+//     candidate per wave, no bank conflicts);
+//   * each lane keeps its sorted top-K in VGPRs (TopK<K>, common.h).  To avoid running the
+//     K-slot insertion network for every candidate just because one of 64 lanes needs it,
+//     candidates that beat the lane's current K-th best are appended to a small per-lane LDS
+//     queue; the insertion network runs only when some lane's queue is full (and once at the
+//     end), on all queued entries at once.
+//   * arithmetic replays the reference's fp32 rounding sequence (file is built with
+//     -ffp-contract=off; the only fused ops are the explicit fmaf()s of the MKL dot product).
+#include "common.h"
+
+#define TILE 1024   // candidates per LDS tile (16 KiB)
+#define QCAP 16     // per-lane queue depth (8 KiB per wave)
+#define CHUNK 8     // candidates scanned between queue-occupancy checks
+
+enum { METRIC_EXPANDED = 0, METRIC_DIRECT = 1 };
+enum { OUT_KNN_GRAPH = 0, OUT_KNN_PAIR = 1, OUT_KNN_POINT = 2 };
+
+template <int K, int METRIC>
+__global__ __launch_bounds__(64) void topk_scan_kernel(
+    const float *__restrict__ qxyz, const float *__restrict__ cxyz, int Nq, int Nc, int k,
+    int out_mode, void *__restrict__ idx_out, float *__restrict__ val_out)
+{
+    __shared__ float4 cand[TILE];
+    __shared__ float qkey[QCAP][64];
+    __shared__ int qidx[QCAP][64];
+
+    const int lane = threadIdx.x;
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * 64 + lane;
+    const bool valid = q < Nq;
+    const int qc = valid ? q : Nq - 1;
+    const float *qp = qxyz + ((size_t)b * Nq + qc) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    const float qxx = (qx * qx + qy * qy) + qz * qz;       // torch.sum(x**2): sequential rounding
+    const float *cbase = cxyz + (size_t)b * Nc * 3;
+
+    TopK<K> top;
+    top.init();
+    float thr = -INFINITY;
+    int cnt = 0;
+
+    auto flush = [&]() {
+#pragma unroll 1
+        for (int s = 0; s < QCAP; s++) {
+            const bool has = s < cnt;
+            if (!__any(has)) break;
+            const float key = has ? qkey[s][lane] : -INFINITY;
+            const int j = qidx[s][lane];
+            top.insert(key, j);
+        }
+        cnt = 0;
+        thr = top.worst();
+    };
+
+    auto eval = [&](const float4 c) -> float {
+        if (METRIC == METRIC_EXPANDED) {
+            // inner = -2 * dot (MKL sgemm K=3: fma chain); pd = (-xx_j - inner) - xx_i
+            const float dot = fmaf(qz, c.z, fmaf(qy, c.y, qx * c.x));
+            const float tt = fmaf(2.0f, dot, c.w);      // == rn(-xx_j + 2*dot): 2*dot is exact
+            return tt - qxx;
+        } else {
+            const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+            return -((dx * dx + dy * dy) + dz * dz);
+        }
+    };
+
+    for (int c0 = 0; c0 < Nc; c0 += TILE) {
+        const int tn = min(TILE, Nc - c0);
+        __syncthreads();
+        for (int t = lane; t < tn; t += 64) {
+            const float *cp = cbase + (size_t)(c0 + t) * 3;
+            float x = cp[0], y = cp[1], z = cp[2];
+            float w = 0.f;
+            if (METRIC == METRIC_EXPANDED) w = -((x * x + y * y) + z * z);   // -xx[j]
+            cand[t] = make_float4(x, y, z, w);
+        }
+        __syncthreads();
+        // main loop: CHUNK candidates between queue checks (queue has room for CHUNK more
+        // whenever every lane holds <= QCAP - CHUNK entries)
+        int t = 0;
+        for (; t + CHUNK <= tn; t += CHUNK) {
+            if (__any(cnt > QCAP - CHUNK)) flush();
+#pragma unroll
+            for (int u = 0; u < CHUNK; u++) {
+                const float key = eval(cand[t + u]);
+                if (key > thr) {
+                    qkey[cnt][lane] = key;
+                    qidx[cnt][lane] = c0 + t + u;
+                    cnt++;
+                }
+            }
+        }
+        for (; t < tn; t++) {
+            if (__any(cnt >= QCAP)) flush();
+            const float key = eval(cand[t]);
+            if (key > thr) {
+                qkey[cnt][lane] = key;
+                qidx[cnt][lane] = c0 + t;
+                cnt++;
+            }
+        }
+    }
+    flush();
+
+    if (!valid) return;
+    const size_t o = ((size_t)b * Nq + q) * k;
+    if (out_mode == OUT_KNN_GRAPH) {
+        int64_t *dst = (int64_t *)idx_out + o;
+#pragma unroll
+        for (int i = 0; i < K; i++)
+            if (i < k) dst[i] = top.id[i];
+    } else if (out_mode == OUT_KNN_PAIR) {
+        int32_t *dst = (int32_t *)idx_out + o;
+#pragma unroll
+        for (int i = 0; i < K; i++)
+            if (i < k) { dst[i] = top.id[i]; val_out[o + i] = -top.v[i]; }
+    } else {
+        int64_t *dst = (int64_t *)idx_out + o;
+#pragma unroll
+        for (int i = 0; i < K; i++)
+            if (i < k) { dst[i] = top.id[i]; val_out[o + i] = sqrtf(-top.v[i]); }
+    }
+}
+
+template <int METRIC>
+static int launch_topk(const float *q, const float *c, int B, int Nq, int Nc, int k, int out_mode,
+                       void *idx, float *val, hipStream_t st)
+{
+    dim3 grid(l3d_divup(Nq, 64), B), block(64);
+#define L3D_TOPK_CASE(KK)                                                                    \
+    if (k <= KK) {                                                                           \
+        hipLaunchKernelGGL((topk_scan_kernel<KK, METRIC>), grid, block, 0, st, q, c, Nq, Nc, \
+                           k, out_mode, idx, val);                                           \
+        return l3d_check_launch();                                                           \
+    }
+    L3D_TOPK_CASE(4)
+    L3D_TOPK_CASE(8)
+    L3D_TOPK_CASE(16)
+    L3D_TOPK_CASE(20)
+    L3D_TOPK_CASE(32)
+    L3D_TOPK_CASE(64)
+    L3D_TOPK_CASE(128)
+    L3D_TOPK_CASE(200)
+#undef L3D_TOPK_CASE
+    return L3D_ERR_UNSUPPORTED;
+}
+
+extern "C" int l3d_knn_graph(const float *xyz, int B, int N, int k, int64_t *idx, l3d_stream_t stream)
+{
+    L3D_REQUIRE(xyz && idx && B > 0 && N > 0 && k > 0 && k <= N && k <= L3D_KNN_MAX_K);
+    return launch_topk<METRIC_EXPANDED>(xyz, xyz, B, N, N, k, OUT_KNN_GRAPH, idx, nullptr,
+                                        (hipStream_t)stream);
+}
+
+extern "C" int l3d_knn(int b, int n, int m, int k, const float *unknown, const float *known,
+                       float *dist2, int32_t *idx, l3d_stream_t stream)
+{
+    L3D_REQUIRE(unknown && known && dist2 && idx && b > 0 && n > 0 && m > 0 && k > 0 &&
+                k <= L3D_KNN_MAX_K);
+    return launch_topk<METRIC_DIRECT>(unknown, known, b, n, m, k, OUT_KNN_PAIR, idx, dist2,
+                                      (hipStream_t)stream);
+}
+
+extern "C" int l3d_three_nn(int b, int n, int m, const float *unknown, const float *known,
+                            float *dist2, int32_t *idx, l3d_stream_t stream)
+{
+    return l3d_knn(b, n, m, 3, unknown, known, dist2, idx, stream);
+}
+
+extern "C" int l3d_knn_point(int k, const float *pos1, const float *pos2, int B, int N, int M,
+                             float *val, int64_t *idx, l3d_stream_t stream)
+{
+    L3D_REQUIRE(pos1 && pos2 && val && idx && B > 0 && N > 0 && M > 0 && k > 0 && k <= N &&
+                k <= L3D_KNN_MAX_K);
+    return launch_topk<METRIC_DIRECT>(pos2, pos1, B, M, N, k, OUT_KNN_POINT, idx, val,
+                                      (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// get_graph_feature gather: out[b][n][j] = (x[b][idx[b][n][j]], x[b][n])   [B,N,k,2C]
+// one thread per (b,n,j); 2C consecutive floats written per thread (C=3: 24 B).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void graph_feature_kernel(const float *__restrict__ x,
+                                                            const int64_t *__restrict__ idx, int N,
+                                                            int C, int k, size_t total,
+                                                            float *__restrict__ out)
+{
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    size_t bn = e / k;
+    size_t b = bn / N;
+    int64_t j = idx[e];
+    const float *nb = x + ((size_t)b * N + j) * C;
+    const float *ct = x + bn * C;
+    float *o = out + e * (size_t)(2 * C);
+    for (int c = 0; c < C; c++) o[c] = nb[c];
+    for (int c = 0; c < C; c++) o[C + c] = ct[c];
+}
+
+extern "C" int l3d_graph_feature(const float *x, const int64_t *idx, int B, int N, int C, int k,
+                                 float *out, l3d_stream_t stream)
+{
+    L3D_REQUIRE(x && idx && out && B > 0 && N > 0 && C > 0 && k > 0);
+    size_t total = (size_t)B * N * k;
+    hipLaunchKernelGGL(graph_feature_kernel, dim3(l3d_divup(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, idx, N, C, k, total, out);
+    return l3d_check_launch();
+}

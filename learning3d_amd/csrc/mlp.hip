@@ -1,0 +1,377 @@
+// mlp.hip -- the per-point shared-MLP (1x1 conv + folded BN + ReLU [+ max over k]) on gfx950's
+// fp32 MFMA (v_mfma_f32_16x16x4_f32 / v_mfma_f32_32x32x2_f32: exact fp32, 157 TFLOP/s dense).
+//
+// Replaces the chains of ATen ops in
+//   models/dgcnn.py:32-46   get_graph_feature -> 4 x relu(bn(conv2d 1x1)) -> max over k -> cat
+//   models/dgcnn.py:48      conv5 512 -> emb_dims
+//   models/pointnet.py:22-49, models/pcn.py:111-125   Conv1d stacks
+// which, un-fused, write and re-read the [B,C,N,k] activations through HBM (1.34 GB per forward
+// at B=32, N=1024, k=20).
+//
+// Kernel 1: edgeconv_kernel.  One 256-thread workgroup owns 4 points x k neighbours = 4k rows of
+// the [B*N*k, C] activation matrix and carries them through all four layers without leaving the
+// CU: layer outputs go VGPR(acc) -> bias/ReLU -> LDS -> next layer's A operand.  The 4 waves split
+// the OUTPUT channels of each layer (each wave streams only its own slice of the weights, as
+// pre-packed MFMA B fragments, straight from L2 into VGPRs), and share the activation tile in LDS.
+// The row order inside the tile is chosen so that a point's k neighbours are exactly the
+// (M-tile, accumulator-register) pairs of ONE 16-lane group: max-over-k is 4*MT v_max in
+// registers, no cross-lane traffic.        row = mt*16 + p*4 + r   <->   (point p, neighbour mt*4+r)
+//
+// Kernel 2: pointwise_conv_kernel.  Y[b] = act(scale * (W X[b]) + shift), a 128x128x16-tiled fp32
+// GEMM on v_mfma_f32_32x32x2_f32 with the point index on the MFMA column axis so the [B,Cout,N]
+// store is 128 B-coalesced, register-staged global->LDS prefetch of the next K chunk.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// packed parameter block (see l3d_edgeconv_pack)
+//   layer L fragment order: [nt = Cout/16][kq][lane 64][KV]  holding  W'[k][n]  with
+//     k = (kq*KV + s)*4 + (lane>>4),  n = nt*16 + (lane&15),   W'[k][n] = scale[n]*conv.weight[n][k]
+//   layer 1: Cin 6 padded to 8, KV = 2;  layers 2-4: KV = 4
+//   then the four bias (= BN shift) vectors.
+// ---------------------------------------------------------------------------------------------
+#define EC_C1 64
+#define EC_C2 64
+#define EC_C3 128
+#define EC_C4 256
+#define EC_OFF_W1 0
+#define EC_OFF_W2 (EC_OFF_W1 + 8 * EC_C1)
+#define EC_OFF_W3 (EC_OFF_W2 + EC_C1 * EC_C2)
+#define EC_OFF_W4 (EC_OFF_W3 + EC_C2 * EC_C3)
+#define EC_OFF_B1 (EC_OFF_W4 + EC_C3 * EC_C4)
+#define EC_OFF_B2 (EC_OFF_B1 + EC_C1)
+#define EC_OFF_B3 (EC_OFF_B2 + EC_C2)
+#define EC_OFF_B4 (EC_OFF_B3 + EC_C3)
+#define EC_PACKED_FLOATS (EC_OFF_B4 + EC_C4)
+
+extern "C" size_t l3d_edgeconv_packed_floats(int c1, int c2, int c3, int c4)
+{
+    if (c1 != EC_C1 || c2 != EC_C2 || c3 != EC_C3 || c4 != EC_C4) return 0;
+    return EC_PACKED_FLOATS;
+}
+
+static void pack_layer(const float *w /*[cout][cin]*/, const float *scale, int cin, int cin_pad,
+                       int cout, int kv, float *dst)
+{
+    const int kq_n = cin_pad / (4 * kv);
+    for (int nt = 0; nt < cout / 16; nt++)
+        for (int kq = 0; kq < kq_n; kq++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int s = 0; s < kv; s++) {
+                    const int k = (kq * kv + s) * 4 + (lane >> 4);
+                    const int n = nt * 16 + (lane & 15);
+                    float v = k < cin ? w[(size_t)n * cin + k] : 0.f;
+                    if (scale) v *= scale[n];
+                    dst[(((size_t)nt * kq_n + kq) * 64 + lane) * kv + s] = v;
+                }
+}
+
+extern "C" int l3d_edgeconv_pack(const float *const w[4], const float *const scale[4],
+                                 const float *const shift[4], int c1, int c2, int c3, int c4,
+                                 float *packed)
+{
+    L3D_REQUIRE(w && packed && w[0] && w[1] && w[2] && w[3]);
+    if (c1 != EC_C1 || c2 != EC_C2 || c3 != EC_C3 || c4 != EC_C4) return L3D_ERR_UNSUPPORTED;
+    pack_layer(w[0], scale ? scale[0] : nullptr, 6, 8, EC_C1, 2, packed + EC_OFF_W1);
+    pack_layer(w[1], scale ? scale[1] : nullptr, EC_C1, EC_C1, EC_C2, 4, packed + EC_OFF_W2);
+    pack_layer(w[2], scale ? scale[2] : nullptr, EC_C2, EC_C2, EC_C3, 4, packed + EC_OFF_W3);
+    pack_layer(w[3], scale ? scale[3] : nullptr, EC_C3, EC_C3, EC_C4, 4, packed + EC_OFF_W4);
+    const int cs[4] = {EC_C1, EC_C2, EC_C3, EC_C4};
+    const int off[4] = {EC_OFF_B1, EC_OFF_B2, EC_OFF_B3, EC_OFF_B4};
+    for (int l = 0; l < 4; l++)
+        for (int c = 0; c < cs[l]; c++) packed[off[l] + c] = (shift && shift[l]) ? shift[l][c] : 0.f;
+    return L3D_OK;
+}
+
+// One layer for one wave: acc[mt][i] += A(act rows) x B(weight fragments of this wave's N-tiles)
+//   act   : LDS, [4*MT*4 rows][CIN + 2] (the +2 skew makes the 16-row x 2-k ds_read_b32 pattern
+//           hit 32 distinct banks)
+//   wfrag : global, this layer's packed fragments
+template <int MT, int CIN, int KV, int NT>
+__device__ __forceinline__ void ec_layer_mma(const float *__restrict__ act,
+                                             const float *__restrict__ wfrag, int wave, int lane,
+                                             f32x4 (&acc)[MT][NT])
+{
+    constexpr int S = CIN + 2;
+    constexpr int KQ = CIN / (4 * KV);
+    typedef float vecT __attribute__((ext_vector_type(KV)));
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int i = 0; i < NT; i++) acc[mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const vecT *wp = (const vecT *)wfrag + ((size_t)(wave * NT) * KQ) * 64 + lane;
+    vecT bcur[NT], bnext[NT];
+#pragma unroll
+    for (int i = 0; i < NT; i++) bcur[i] = wp[(size_t)(i * KQ) * 64];
+#pragma unroll
+    for (int kq = 0; kq < KQ; kq++) {
+        if (kq + 1 < KQ) {
+#pragma unroll
+            for (int i = 0; i < NT; i++) bnext[i] = wp[(size_t)(i * KQ + kq + 1) * 64];
+        }
+#pragma unroll
+        for (int s = 0; s < KV; s++) {
+            const int k = (kq * KV + s) * 4 + g;
+            float a[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) a[mt] = act[(mt * 16 + r) * S + k];
+#pragma unroll
+            for (int i = 0; i < NT; i++)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+                    acc[mt][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bcur[i][s], acc[mt][i], 0, 0, 0);
+        }
+        if (kq + 1 < KQ) {
+#pragma unroll
+            for (int i = 0; i < NT; i++) bcur[i] = bnext[i];
+        }
+    }
+}
+
+// bias + ReLU, max over the point's k neighbours (registers only), optional write of the
+// activations for the next layer, and the pooled [B*N, CTOT] (channel-last) store.
+template <int MT, int NT, int COUT_STRIDE, bool WRITE_NEXT>
+__device__ __forceinline__ void ec_layer_epilogue(f32x4 (&acc)[MT][NT],
+                                                  const float *__restrict__ bias, int wave, int lane,
+                                                  float *__restrict__ act_out,
+                                                  float *__restrict__ pooled_row, bool store_ok)
+{
+    const int c16 = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+        const int ch = (wave * NT + i) * 16 + c16;
+        const float bv = bias[ch];
+        float mx = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) {
+                const float v = fmaxf(acc[mt][i][rr] + bv, 0.f);
+                mx = fmaxf(mx, v);
+                if (WRITE_NEXT) act_out[(mt * 16 + g * 4 + rr) * COUT_STRIDE + ch] = v;
+            }
+        if (store_ok) pooled_row[ch] = mx;
+    }
+}
+
+template <int MT>
+__global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float *__restrict__ xyz,
+                                                          const int64_t *__restrict__ idx, int N,
+                                                          int k, const float *__restrict__ packed,
+                                                          float *__restrict__ pooled /*[B*N][512]*/)
+{
+    constexpr int ROWS = MT * 16;
+    constexpr int CTOT = EC_C1 + EC_C2 + EC_C3 + EC_C4;
+    // P0: feature tile (8 ch) then h2 (64 ch);  P1: h1 (64 ch) then h3 (128 ch)
+    __shared__ float P0[ROWS * (EC_C2 + 2)];
+    __shared__ float P1[ROWS * (EC_C3 + 2)];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.y;
+    const int n0 = blockIdx.x * 4;
+
+    // ---- stage the graph feature rows: (neighbour xyz, centre xyz, 0, 0)   dgcnn.py:32 ----
+    if (tid < ROWS) {
+        const int row = tid;
+        const int p = (row >> 2) & 3;
+        const int j = (row >> 4) * 4 + (row & 3);
+        const int n = min(n0 + p, N - 1);
+        const int jj = j < k ? j : 0;                      // pad k up to 4*MT with a duplicate
+        const int64_t nb = idx[((size_t)b * N + n) * k + jj];
+        const float *pn = xyz + ((size_t)b * N + nb) * 3;
+        const float *pc = xyz + ((size_t)b * N + n) * 3;
+        float *f = P0 + row * 10;
+        f[0] = pn[0]; f[1] = pn[1]; f[2] = pn[2];
+        f[3] = pc[0]; f[4] = pc[1]; f[5] = pc[2];
+        f[6] = 0.f; f[7] = 0.f;
+    }
+    __syncthreads();
+
+    const int g = lane >> 4;
+    const bool store_ok = (n0 + g) < N;
+    float *prow = pooled + ((size_t)b * N + min(n0 + g, N - 1)) * CTOT;
+
+    {   // layer 1: 6(8) -> 64
+        f32x4 acc[MT][1];
+        ec_layer_mma<MT, 8, 2, 1>(P0, packed + EC_OFF_W1, wave, lane, acc);
+        ec_layer_epilogue<MT, 1, EC_C1 + 2, true>(acc, packed + EC_OFF_B1, wave, lane, P1, prow, store_ok);
+    }
+    __syncthreads();
+    {   // layer 2: 64 -> 64
+        f32x4 acc[MT][1];
+        ec_layer_mma<MT, EC_C1, 4, 1>(P1, packed + EC_OFF_W2, wave, lane, acc);
+        ec_layer_epilogue<MT, 1, EC_C2 + 2, true>(acc, packed + EC_OFF_B2, wave, lane, P0, prow + EC_C1, store_ok);
+    }
+    __syncthreads();
+    {   // layer 3: 64 -> 128
+        f32x4 acc[MT][2];
+        ec_layer_mma<MT, EC_C2, 4, 2>(P0, packed + EC_OFF_W3, wave, lane, acc);
+        ec_layer_epilogue<MT, 2, EC_C3 + 2, true>(acc, packed + EC_OFF_B3, wave, lane, P1, prow + EC_C1 + EC_C2, store_ok);
+    }
+    __syncthreads();
+    {   // layer 4: 128 -> 256 (activations are only max-pooled, never stored)
+        f32x4 acc[MT][4];
+        ec_layer_mma<MT, EC_C3, 4, 4>(P1, packed + EC_OFF_W4, wave, lane, acc);
+        ec_layer_epilogue<MT, 4, 0, false>(acc, packed + EC_OFF_B4, wave, lane, nullptr, prow + EC_C1 + EC_C2 + EC_C3, store_ok);
+    }
+}
+
+extern "C" int l3d_edgeconv_forward(const float *xyz, const int64_t *idx, int B, int N, int k,
+                                    const float *packed, int c1, int c2, int c3, int c4,
+                                    float *pooled, l3d_stream_t stream)
+{
+    L3D_REQUIRE(xyz && idx && packed && pooled && B > 0 && N > 0 && k > 0);
+    if (c1 != EC_C1 || c2 != EC_C2 || c3 != EC_C3 || c4 != EC_C4) return L3D_ERR_UNSUPPORTED;
+    if (B > 65535) return L3D_ERR_UNSUPPORTED;
+    dim3 grid(l3d_divup(N, 4), B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (k <= 8)       hipLaunchKernelGGL(edgeconv_kernel<2>, grid, block, 0, st, xyz, idx, N, k, packed, pooled);
+    else if (k <= 16) hipLaunchKernelGGL(edgeconv_kernel<4>, grid, block, 0, st, xyz, idx, N, k, packed, pooled);
+    else if (k <= 20) hipLaunchKernelGGL(edgeconv_kernel<5>, grid, block, 0, st, xyz, idx, N, k, packed, pooled);
+    else if (k <= 32) hipLaunchKernelGGL(edgeconv_kernel<8>, grid, block, 0, st, xyz, idx, N, k, packed, pooled);
+    else return L3D_ERR_UNSUPPORTED;
+    return l3d_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// pointwise conv:  y[b][co][n] = act(scale[co] * sum_ci w[co][ci] * X[b](ci,n) + shift[co])
+//   shift is indexed [b*shift_bstride + co] (shift_bstride = 0: shared by the batch; = Cout: one
+//   vector per cloud -- how a broadcast global feature concatenated to every point is folded away)
+//   X channel-first  [B,Cin,N]   (x_channel_last = 0, torch Conv1d layout)   or
+//   X channel-last   [B,N,Cin]   (x_channel_last = 1, the EdgeConv kernel's pooled output)
+// Workgroup tile 128 (co) x 128 (n), K chunk 16; 4 waves as 2x2, each 64x64 = 2x2 MFMA 32x32x2.
+// ---------------------------------------------------------------------------------------------
+#define PW_TM 128
+#define PW_TN 128
+#define PW_TK 16
+#define PW_LD (128 + 4)      // LDS row stride (floats) of the k-major tiles; 16 B aligned
+
+template <bool XCL>
+__global__ __launch_bounds__(256, 2) void pointwise_conv_kernel(
+    const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ scale,
+    const float *__restrict__ shift, int shift_bstride, int Cin, int Cout, int N, int relu,
+    float *__restrict__ y)
+{
+    __shared__ __attribute__((aligned(16))) float As[PW_TK][PW_LD];     // As[k][co]
+    __shared__ __attribute__((aligned(16))) float Bs[PW_TK][PW_LD];     // Bs[k][n]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.z;
+    const int co0 = blockIdx.y * PW_TM, n0 = blockIdx.x * PW_TN;
+    const int wm = wave >> 1, wn = wave & 1;          // wave tile origin (64x64) inside the WG tile
+    const float *xb = x + (size_t)b * Cin * N;
+
+    // global->register staging assignment
+    //   A: thread -> (co = tid/2, 8 consecutive k at (tid&1)*8)
+    //   B (channel-first): thread -> (k = tid/16, 8 consecutive n at (tid&15)*8)
+    //   B (channel-last) : thread -> (n = tid/2,  8 consecutive k at (tid&1)*8)
+    float ra[8], rb[8];
+    const bool cin_vec = (Cin & 3) == 0, n_vec = (N & 3) == 0;
+    auto load8 = [](float (&r)[8], const float *src, int pos, int limit, bool row_ok, bool vec) {
+        if (row_ok && vec && pos + 8 <= limit) {
+            const float4 v0 = *(const float4 *)(src + pos), v1 = *(const float4 *)(src + pos + 4);
+            r[0] = v0.x; r[1] = v0.y; r[2] = v0.z; r[3] = v0.w;
+            r[4] = v1.x; r[5] = v1.y; r[6] = v1.z; r[7] = v1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) r[e] = (row_ok && pos + e < limit) ? src[pos + e] : 0.f;
+        }
+    };
+    auto load_chunk = [&](int k0) {
+        {
+            const int co = co0 + (tid >> 1);
+            const bool rok = co < Cout;
+            load8(ra, w + (size_t)(rok ? co : 0) * Cin, k0 + (tid & 1) * 8, Cin, rok, cin_vec);
+        }
+        if (XCL) {
+            const int n = n0 + (tid >> 1);
+            const bool nok = n < N;
+            load8(rb, xb + (size_t)(nok ? n : 0) * Cin, k0 + (tid & 1) * 8, Cin, nok, cin_vec);
+        } else {
+            const int kk = k0 + (tid >> 4);
+            const bool kok = kk < Cin;
+            load8(rb, xb + (size_t)(kok ? kk : 0) * N, n0 + (tid & 15) * 8, N, kok, n_vec);
+        }
+    };
+    auto store_chunk = [&]() {
+        {
+            const int m = tid >> 1, kb = (tid & 1) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; e++) As[kb + e][m] = ra[e];
+        }
+        if (XCL) {
+            const int n = tid >> 1, kb = (tid & 1) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; e++) Bs[kb + e][n] = rb[e];
+        } else {
+            const int kk = tid >> 4, nb = (tid & 15) * 8;
+            *(float4 *)&Bs[kk][nb] = make_float4(rb[0], rb[1], rb[2], rb[3]);
+            *(float4 *)&Bs[kk][nb + 4] = make_float4(rb[4], rb[5], rb[6], rb[7]);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    const int l31 = lane & 31, kh = lane >> 5;
+    load_chunk(0);
+    for (int k0 = 0; k0 < Cin; k0 += PW_TK) {
+        __syncthreads();                 // previous chunk's MFMA reads are done
+        store_chunk();
+        __syncthreads();
+        if (k0 + PW_TK < Cin) load_chunk(k0 + PW_TK);     // overlaps with the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < PW_TK; ks += 2) {
+            float a[2], bb[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) a[i] = As[ks + kh][wm * 64 + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < 2; j++) bb[j] = Bs[ks + kh][wn * 64 + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // epilogue: D[row = co][col = n]; col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    float *yb = y + (size_t)b * Cout * N;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int co = co0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+            if (co >= Cout) continue;
+            const float sc = scale ? scale[co] : 1.f;
+            const float sh = shift ? shift[(size_t)b * shift_bstride + co] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int n = n0 + wn * 64 + j * 32 + l31;
+                float v = acc[i][j][e] * sc + sh;
+                if (relu) v = fmaxf(v, 0.f);
+                if (n < N) yb[(size_t)co * N + n] = v;
+            }
+        }
+}
+
+extern "C" int l3d_pointwise_conv(const float *x, int x_channel_last, const float *w,
+                                  const float *scale, const float *shift, int shift_bstride, int B,
+                                  int Cin, int Cout, int N, int relu, float *y, l3d_stream_t stream)
+{
+    L3D_REQUIRE(x && w && y && B > 0 && Cin > 0 && Cout > 0 && N > 0);
+    if (B > 65535) return L3D_ERR_UNSUPPORTED;
+    dim3 grid(l3d_divup(N, PW_TN), l3d_divup(Cout, PW_TM), B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (x_channel_last)
+        hipLaunchKernelGGL(pointwise_conv_kernel<true>, grid, block, 0, st, x, w, scale, shift, shift_bstride, Cin, Cout, N, relu, y);
+    else
+        hipLaunchKernelGGL(pointwise_conv_kernel<false>, grid, block, 0, st, x, w, scale, shift, shift_bstride, Cin, Cout, N, relu, y);
+    return l3d_check_launch();
+}

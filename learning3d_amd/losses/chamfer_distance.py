@@ -1,0 +1,87 @@
+"""Drop-in for learning3d/losses/chamfer_distance.py + losses/cuda/chamfer_distance/ on MI355X.
+
+reference: losses/chamfer_distance.py:34-51 (chamfer_distance / ChamferDistanceLoss) and
+losses/cuda/chamfer_distance/chamfer_distance.py:14-66 (ChamferDistanceFunction / ChamferDistance).
+The reference JIT-compiles a CUDA extension on first use and silently falls back to an O(B*N*M*3)
+torch broadcast when that fails (:36-42); here the native path is the only path.
+"""
+import torch
+import torch.nn as nn
+
+from .._lib import check, f32c, lib, ptr, require_gpu, stream_ptr
+
+
+class ChamferDistanceFunction(torch.autograd.Function):
+    """dist1 [B,N], dist2 [B,M] squared NN distances; backward == cd.backward_cuda (deterministic)."""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        require_gpu(xyz1, xyz2)
+        batchsize, n, _ = xyz1.size()
+        _, m, _ = xyz2.size()
+        xyz1 = f32c(xyz1)
+        xyz2 = f32c(xyz2)
+        dev = xyz1.device
+        dist1 = torch.empty(batchsize, n, dtype=torch.float32, device=dev)
+        dist2 = torch.empty(batchsize, m, dtype=torch.float32, device=dev)
+        idx1 = torch.empty(batchsize, n, dtype=torch.int32, device=dev)
+        idx2 = torch.empty(batchsize, m, dtype=torch.int32, device=dev)
+        check(lib().l3d_chamfer_forward(ptr(xyz1), ptr(xyz2), batchsize, n, m, ptr(dist1), ptr(dist2),
+                                        ptr(idx1), ptr(idx2), stream_ptr()), "l3d_chamfer_forward")
+        ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
+        return dist1, dist2
+
+    @staticmethod
+    def backward(ctx, graddist1, graddist2):
+        xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
+        graddist1 = f32c(graddist1)
+        graddist2 = f32c(graddist2)
+        b, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        gradxyz1 = torch.empty_like(xyz1)
+        gradxyz2 = torch.empty_like(xyz2)
+        check(lib().l3d_chamfer_backward(ptr(xyz1), ptr(xyz2), b, n, m, ptr(graddist1), ptr(graddist2),
+                                         ptr(idx1), ptr(idx2), ptr(gradxyz1), ptr(gradxyz2), stream_ptr()),
+              "l3d_chamfer_backward")
+        return gradxyz1, gradxyz2
+
+
+class ChamferDistance(torch.nn.Module):
+    def forward(self, xyz1, xyz2):
+        return ChamferDistanceFunction.apply(xyz1, xyz2)
+
+
+def chamfer_sqrt_sums(dist1, dist2):
+    """(sum sqrt(dist1), sum sqrt(dist2)) as a device fp64 tensor [2] -- the per-shard partial sums
+    the multi-GPU path all-gathers (forward-only helper; no autograd)."""
+    B, N = dist1.shape
+    M = dist2.shape[1]
+    sums = torch.empty(2, dtype=torch.float64, device=dist1.device)
+    check(lib().l3d_chamfer_sqrt_sums(ptr(dist1), ptr(dist2), B, N, M, ptr(sums), stream_ptr()),
+          "l3d_chamfer_sqrt_sums")
+    return sums
+
+
+def chamfer_distance(template: torch.Tensor, source: torch.Tensor):
+    """reference: losses/chamfer_distance.py:34-43 -- (mean sqrt d1 + mean sqrt d2) / 2, one scalar
+    over the whole batch."""
+    cost_p0_p1, cost_p1_p0 = ChamferDistance()(template, source)
+    if torch.is_grad_enabled() and (template.requires_grad or source.requires_grad):
+        cost_p0_p1 = torch.mean(torch.sqrt(cost_p0_p1))
+        cost_p1_p0 = torch.mean(torch.sqrt(cost_p1_p0))
+        return (cost_p0_p1 + cost_p1_p0) / 2.0
+    s = chamfer_sqrt_sums(cost_p0_p1, cost_p1_p0)
+    return ((s[0] / cost_p0_p1.numel() + s[1] / cost_p1_p0.numel()) / 2.0).to(torch.float32)
+
+
+def chamfer(a, b):
+    """reference: losses/chamfer_distance.py:21-31 (the torch fallback): same value, native path."""
+    return chamfer_distance(a, b)
+
+
+class ChamferDistanceLoss(nn.Module):
+    def __init__(self):
+        super(ChamferDistanceLoss, self).__init__()
+
+    def forward(self, template, source):
+        return chamfer_distance(template, source)

@@ -1,0 +1,61 @@
+"""Drop-in for learning3d/losses/emd.py + losses/cuda/emd_torch/ on MI355X.
+
+reference: losses/cuda/emd_torch/pkg/layer/emd_loss_layer.py:7-45 (EMDFunction / EMDLoss over the
+`_emd_ext._emd` pybind module, emd.h:47-50) and losses/emd.py:11-15 (whose free function `emd`
+is broken in the reference: it refers to `self`; the intended value
+mean(cost)/N is what is implemented here).
+"""
+import torch
+import torch.nn as nn
+
+from .._lib import check, f32c, lib, ptr, require_gpu, stream_ptr
+
+
+class EMDFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        require_gpu(xyz1, xyz2)
+        xyz1, xyz2 = f32c(xyz1), f32c(xyz2)
+        B, n, d = xyz1.shape
+        m = xyz2.shape[1]
+        assert d == 3 and xyz2.shape[2] == 3, "EMD kernels are built for 3-D points"
+        dev = xyz1.device
+        match = torch.empty((B, n, m), dtype=torch.float32, device=dev)
+        cost = torch.empty((B,), dtype=torch.float32, device=dev)
+        temp = torch.empty((B, 2 * (n + m)), dtype=torch.float32, device=dev)
+        check(lib().l3d_emd_forward(ptr(xyz1), ptr(xyz2), B, n, m, ptr(match), ptr(cost), ptr(temp), stream_ptr()),
+              "l3d_emd_forward")
+        ctx.save_for_backward(xyz1, xyz2, match)
+        return cost
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        # like the reference (emd_loss_layer.py:16-19) the incoming grad_output is NOT applied
+        xyz1, xyz2, match = ctx.saved_tensors
+        B, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        g1 = torch.empty_like(xyz1)
+        g2 = torch.empty_like(xyz2)
+        check(lib().l3d_emd_backward(ptr(xyz1), ptr(xyz2), ptr(match), B, n, m, ptr(g1), ptr(g2), stream_ptr()),
+              "l3d_emd_backward")
+        return g1, g2
+
+
+class EMDLossLayer(nn.Module):
+    """reference: pkg/layer/emd_loss_layer.py:24-45 (there also named EMDLoss): per-cloud cost [B]."""
+
+    def forward(self, xyz1, xyz2):
+        assert xyz1.shape[-1] == xyz2.shape[-1], 'Both point sets must have the same dimensionality'
+        return EMDFunction.apply(xyz1, xyz2)
+
+
+def emd(template: torch.Tensor, source: torch.Tensor):
+    return torch.mean(EMDLossLayer()(template, source)) / (template.size()[1])
+
+
+class EMDLoss(nn.Module):
+    def __init__(self):
+        super(EMDLoss, self).__init__()
+
+    def forward(self, template, source):
+        return emd(template, source)

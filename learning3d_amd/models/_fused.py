@@ -1,0 +1,105 @@
+"""Host-side glue for the fp32-MFMA shared-MLP kernels (mlp.hip): BatchNorm folding, parameter
+packing (cached per parameter version) and the two launches.  Inference / no-grad only: with
+autograd or train-mode BatchNorm (batch statistics) the modules route the 1x1 convs through torch
+(rocBLAS/MIOpen) on top of the HIP kNN / grouping kernels -- the training path is ranked under
+"next" in SURVEY.md 8(f)."""
+import ctypes as C
+
+import torch
+
+from .._lib import check, f32c, lib, ptr, require_gpu, stream_ptr
+
+
+def bn_affine(bn):
+    """eval-mode BatchNorm as y = scale * x + shift"""
+    scale = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
+    shift = bn.bias.detach() - bn.running_mean.detach() * scale
+    return scale, shift
+
+
+def fold_conv_bn(conv, bn=None):
+    """conv (1x1 Conv1d/Conv2d or Linear) followed by optional eval-mode BN ->
+    (w [Cout,Cin], scale [Cout] or None, shift [Cout] or None) with y = scale*(w x) + shift"""
+    w = conv.weight.detach().reshape(conv.weight.shape[0], -1)
+    bias = conv.bias.detach() if conv.bias is not None else None
+    if bn is None:
+        return w, None, bias
+    scale, shift = bn_affine(bn)
+    if bias is not None:
+        shift = shift + scale * bias
+    return w, scale, shift
+
+
+def can_fuse(module, *tensors):
+    """Fused MFMA path: inference semantics only (no grad, BatchNorm in eval mode)."""
+    if module.training and any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in module.modules()):
+        return False
+    if torch.is_grad_enabled() and (any(t.requires_grad for t in tensors) or
+                                    any(p.requires_grad for p in module.parameters())):
+        return False
+    return True
+
+
+def pointwise_conv(x, w, scale=None, shift=None, relu=False, channel_last=False):
+    """y[b,co,n] = act(scale[co] * sum_ci w[co,ci] x[b,ci,n] + shift[(b,)co]);  x [B,Cin,N] (or
+    [B,N,Cin] when channel_last) -> [B,Cout,N].   == Conv1d(k=1) (+BN eval) (+ReLU).
+    shift may be [Cout] or per-cloud [B,Cout]."""
+    require_gpu(x)
+    x = f32c(x)
+    w = f32c(w)
+    if channel_last:
+        B, N, Cin = x.shape
+    else:
+        B, Cin, N = x.shape
+    Cout = w.shape[0]
+    assert w.shape[1] == Cin
+    scale = f32c(scale) if scale is not None else None
+    shift = f32c(shift) if shift is not None else None
+    bstride = Cout if (shift is not None and shift.dim() == 2) else 0
+    y = torch.empty((B, Cout, N), dtype=torch.float32, device=x.device)
+    check(lib().l3d_pointwise_conv(ptr(x), int(channel_last), ptr(w), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N,
+                                   int(relu), ptr(y), stream_ptr()), "l3d_pointwise_conv")
+    return y
+
+
+class EdgeConvParams:
+    """Folded + fragment-packed parameters of a 4-layer EdgeConv stack, cached on the module and
+    rebuilt only when a parameter / running statistic changes (tensor._version) or moves device."""
+
+    def __init__(self):
+        self.key = None
+        self.packed = None
+
+    def get(self, convs, bns, device):
+        tensors = []
+        for c, b in zip(convs, bns):
+            tensors += [c.weight, b.weight, b.bias, b.running_mean, b.running_var]
+        key = (str(device),) + tuple((t.data_ptr(), t._version) for t in tensors)
+        if key != self.key:
+            ws, scs, shs = [], [], []
+            for c, b in zip(convs, bns):
+                w, sc, sh = fold_conv_bn(c, b)
+                ws.append(w.float().cpu().contiguous())
+                scs.append(sc.float().cpu().contiguous())
+                shs.append(sh.float().cpu().contiguous())
+            cs = [w.shape[0] for w in ws]
+            nfl = lib().l3d_edgeconv_packed_floats(*cs)
+            if nfl == 0:
+                raise NotImplementedError(f"EdgeConv channel widths {cs} are not built (64/64/128/256 only)")
+            packed = torch.empty(nfl, dtype=torch.float32)
+            arr = lambda ts: (C.c_void_p * 4)(*[t.data_ptr() for t in ts])
+            check(lib().l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), *cs, ptr(packed)), "l3d_edgeconv_pack")
+            self.packed = packed.to(device)
+            self.key = key
+        return self.packed
+
+
+def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256)):
+    """xyz [B,N,3], idx int64 [B,N,k] -> pooled [B,N,sum(widths)] (channel-last)."""
+    require_gpu(xyz_bn3, idx, packed)
+    B, N, _ = xyz_bn3.shape
+    k = idx.shape[2]
+    pooled = torch.empty((B, N, sum(widths)), dtype=torch.float32, device=xyz_bn3.device)
+    check(lib().l3d_edgeconv_forward(ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), *widths, ptr(pooled),
+                                     stream_ptr()), "l3d_edgeconv_forward")
+    return pooled

@@ -1,0 +1,61 @@
+"""Drop-in for learning3d/models/dgcnn.py on MI355X (reference: models/dgcnn.py:6-49).
+
+Same constructor, attribute / parameter names (state_dict compatible) and output layout.
+Inference (eval + no grad): 3 launches -- fused kNN graph, fused 4-layer EdgeConv stack on fp32 MFMA
+(activations never leave the CU), conv5 as an MFMA GEMM writing [B, emb, N].
+Training: HIP kNN + graph-feature gather, convs/BN through torch (batch statistics)."""
+import torch
+import torch.nn.functional as F
+
+from ..utils.model_common_utils import get_graph_feature, knn, _as_bn3
+from . import _fused
+
+
+class DGCNN(torch.nn.Module):
+    def __init__(self, emb_dims=1024, input_shape="bnc"):
+        super(DGCNN, self).__init__()
+        if input_shape not in ["bcn", "bnc"]:
+            raise ValueError("Allowed shapes are 'bcn' (batch * channels * num_in_points), 'bnc' ")
+        self.input_shape = input_shape
+        self.emb_dims = emb_dims
+
+        self.conv1 = torch.nn.Conv2d(6, 64, kernel_size=1, bias=False)
+        self.conv2 = torch.nn.Conv2d(64, 64, kernel_size=1, bias=False)
+        self.conv3 = torch.nn.Conv2d(64, 128, kernel_size=1, bias=False)
+        self.conv4 = torch.nn.Conv2d(128, 256, kernel_size=1, bias=False)
+        self.conv5 = torch.nn.Conv2d(512, emb_dims, kernel_size=1, bias=False)
+        self.bn1 = torch.nn.BatchNorm2d(64)
+        self.bn2 = torch.nn.BatchNorm2d(64)
+        self.bn3 = torch.nn.BatchNorm2d(128)
+        self.bn4 = torch.nn.BatchNorm2d(256)
+        self.bn5 = torch.nn.BatchNorm2d(emb_dims)
+        self._packed = _fused.EdgeConvParams()
+
+    def forward(self, input_data):
+        if self.input_shape == "bnc":
+            input_data = input_data.permute(0, 2, 1)
+        if input_data.shape[1] != 3:
+            raise RuntimeError("shape of x must be of [Batch x 3 x NumInPoints]")
+        batch_size, num_dims, num_points = input_data.size()
+
+        if _fused.can_fuse(self, input_data):
+            xyz = _as_bn3(input_data)                                   # [B,N,3] (no copy for "bnc")
+            idx = knn(input_data, k=20)                                 # dgcnn.py:32 (k=20 default)
+            packed = self._packed.get([self.conv1, self.conv2, self.conv3, self.conv4],
+                                      [self.bn1, self.bn2, self.bn3, self.bn4], xyz.device)
+            pooled = _fused.edgeconv_forward(xyz, idx, packed)          # dgcnn.py:34-46
+            w5, s5, b5 = _fused.fold_conv_bn(self.conv5, self.bn5)
+            return _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True)  # dgcnn.py:48
+
+        output = get_graph_feature(input_data)
+        output = F.relu(self.bn1(self.conv1(output)))
+        output1 = output.max(dim=-1, keepdim=True)[0]
+        output = F.relu(self.bn2(self.conv2(output)))
+        output2 = output.max(dim=-1, keepdim=True)[0]
+        output = F.relu(self.bn3(self.conv3(output)))
+        output3 = output.max(dim=-1, keepdim=True)[0]
+        output = F.relu(self.bn4(self.conv4(output)))
+        output4 = output.max(dim=-1, keepdim=True)[0]
+        output = torch.cat((output1, output2, output3, output4), dim=1)
+        output = F.relu(self.bn5(self.conv5(output))).view(batch_size, -1, num_points)
+        return output

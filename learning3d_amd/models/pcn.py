@@ -1,0 +1,119 @@
+"""Drop-in for learning3d/models/pcn.py on MI355X (reference: models/pcn.py:8-153).
+
+Inference path: every Conv1d(k=1) is an fp32-MFMA GEMM launch.  Two algebraic fusions remove the
+reference's largest temporaries:
+  * encoder (:117-119) concatenates the per-cloud global feature to every point before conv3; here
+    W3 is split and the global half becomes a per-cloud shift:  W3 [h ; g] = W3a h + (W3b g);
+  * fine decoder (:84-101) materialises a [B, 16384, 1029] feature (4.3 GB at B=64) of which 1024
+    channels are the same per-cloud vector; conv5 is applied to the 5 varying channels (grid 2 +
+    coarse point 3) and W5[:,5:] global_feature goes into the per-cloud shift.
+The FC decoder (3 Linear layers on [B, emb]) stays torch (rocBLAS)."""
+import torch
+
+from . import _fused
+from .pooling import Pooling
+
+
+class PCN(torch.nn.Module):
+    def __init__(self, emb_dims=1024, input_shape="bnc", num_coarse=1024, grid_size=4, detailed_output=False):
+        super(PCN, self).__init__()
+        if input_shape not in ["bcn", "bnc"]:
+            raise ValueError("Allowed shapes are 'bcn' (batch * channels * num_in_points), 'bnc' ")
+        self.input_shape = input_shape
+        self.emb_dims = emb_dims
+        self.num_coarse = num_coarse
+        self.detailed_output = detailed_output
+        self.grid_size = grid_size
+        self.num_fine = self.grid_size ** 2 * self.num_coarse
+        self.pooling = Pooling('max')
+        self.relu = torch.nn.ReLU()
+        # encoder (pcn.py:26-50)
+        self.conv1 = torch.nn.Conv1d(3, 128, 1)
+        self.conv2 = torch.nn.Conv1d(128, 256, 1)
+        self.conv3 = torch.nn.Conv1d(2 * 256, 512, 1)
+        self.conv4 = torch.nn.Conv1d(512, self.emb_dims, 1)
+        # decoder (pcn.py:56-70)
+        self.linear1 = torch.nn.Linear(self.emb_dims, 1024)
+        self.linear2 = torch.nn.Linear(1024, 1024)
+        self.linear3 = torch.nn.Linear(1024, self.num_coarse * 3)
+        if detailed_output:        # folding (pcn.py:72-82)
+            self.conv5 = torch.nn.Conv1d(1029, 512, 1)
+            self.conv6 = torch.nn.Conv1d(512, 512, 1)
+            self.conv7 = torch.nn.Conv1d(512, 3, 1)
+
+    # -- reference-order torch path (training / autograd) ------------------------------------------
+    def _encode_torch(self, x):
+        out = self.conv2(self.relu(self.conv1(x)))
+        g = self.pooling(out).unsqueeze(2).repeat(1, 1, self.num_points)
+        out = torch.cat([out, g], dim=1)
+        out = self.conv4(self.relu(self.conv3(out)))
+        return self.pooling(out)
+
+    def _grid_center(self, coarse):
+        B = coarse.shape[0]
+        linspace = torch.linspace(-0.05, 0.05, steps=self.grid_size, device=coarse.device)
+        grid = torch.meshgrid(linspace, linspace, indexing="ij")
+        grid = torch.reshape(torch.stack(grid, dim=2), (-1, 2)).unsqueeze(0)         # 1 x g^2 x 2
+        grid_feature = grid.repeat([B, self.num_coarse, 1])                           # B x fine x 2
+        center = coarse.unsqueeze(2).repeat([1, 1, self.grid_size ** 2, 1]).reshape(-1, self.num_fine, 3)
+        return grid_feature, center
+
+    def _fine_torch(self, coarse, gfeat):
+        grid_feature, center = self._grid_center(coarse)
+        global_feature = gfeat.unsqueeze(1).repeat([1, self.num_fine, 1])
+        feature = torch.cat([grid_feature, center, global_feature], dim=2).permute(0, 2, 1)
+        out = self.conv7(self.relu(self.conv6(self.relu(self.conv5(feature)))))
+        return out.permute(0, 2, 1) + center
+
+    # -- fused inference path ----------------------------------------------------------------------
+    def _encode_fused(self, x, channel_last):
+        pc = _fused.pointwise_conv
+        w, _, b = _fused.fold_conv_bn(self.conv1)
+        h = pc(x, w, None, b, relu=True, channel_last=channel_last)
+        w, _, b = _fused.fold_conv_bn(self.conv2)
+        h = pc(h, w, None, b, relu=False)
+        g = self.pooling(h)                                                # [B,256]
+        w3 = self.conv3.weight.detach().reshape(512, 512)
+        shift = torch.addmm(self.conv3.bias.detach(), g, w3[:, 256:].t())  # per-cloud [B,512]
+        h = pc(h, w3[:, :256], None, shift, relu=True)
+        w, _, b = _fused.fold_conv_bn(self.conv4)
+        h = pc(h, w, None, b, relu=False)
+        return self.pooling(h)
+
+    def _fine_fused(self, coarse, gfeat):
+        pc = _fused.pointwise_conv
+        grid_feature, center = self._grid_center(coarse)
+        x5 = torch.cat([grid_feature, center], dim=2)                      # [B, fine, 5] channel-last
+        w5 = self.conv5.weight.detach().reshape(512, 1029)
+        shift = torch.addmm(self.conv5.bias.detach(), gfeat, w5[:, 5:].t())
+        h = pc(x5, w5[:, :5], None, shift, relu=True, channel_last=True)
+        w, _, b = _fused.fold_conv_bn(self.conv6)
+        h = pc(h, w, None, b, relu=True)
+        w, _, b = _fused.fold_conv_bn(self.conv7)
+        h = pc(h, w, None, b, relu=False)
+        return h.permute(0, 2, 1) + center
+
+    def forward(self, input_data):
+        if self.input_shape == "bnc":
+            self.num_points = input_data.shape[1]
+            input_data = input_data.permute(0, 2, 1)
+        else:
+            self.num_points = input_data.shape[2]
+        if input_data.shape[1] != 3:
+            raise RuntimeError("shape of x must be of [Batch x 3 x NumInPoints]")
+
+        fused = _fused.can_fuse(self, input_data)
+        if fused:
+            cl = self.input_shape == "bnc"
+            self.global_feature_v = self._encode_fused(input_data.permute(0, 2, 1) if cl else input_data, cl)
+        else:
+            self.global_feature_v = self._encode_torch(input_data)
+        out = self.linear3(self.relu(self.linear2(self.relu(self.linear1(self.global_feature_v)))))
+        self.coarse_output = out.view(self.global_feature_v.shape[0], self.num_coarse, 3)
+        result = {'coarse_output': self.coarse_output}
+        if self.detailed_output:
+            if fused:
+                result['fine_output'] = self._fine_fused(self.coarse_output, self.global_feature_v)
+            else:
+                result['fine_output'] = self._fine_torch(self.coarse_output, self.global_feature_v)
+        return result

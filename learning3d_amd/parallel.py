@@ -1,0 +1,71 @@
+"""Multi-GPU layer of the hot path: one process per GPU (torch.distributed, backend "nccl" = RCCL over
+xGMI; "gloo" in the CPU tests), batch sharded contiguously, weights replicated, NO collective on the
+data path.  The only exchange is the one the maths needs: ChamferDistanceLoss is a mean over the
+WHOLE batch (losses/chamfer_distance.py:38-40), so every rank contributes its partial sums
+(sum sqrt d1, sum sqrt d2, point counts) through one all_gather of 4 fp64 values and forms the same
+global scalar.  The reference has no distributed layer at all (one nn.DataParallel call,
+examples/train_flownet.py:243-245); this replaces its scatter/gather.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract).
+    Returns (rank, world_size, local_rank).  Single-process when WORLD_SIZE is unset or 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_bounds(global_batch, rank, world):
+    """Contiguous [lo, hi) slice of the batch owned by `rank` (remainder spread over the first ranks)."""
+    base, rem = divmod(global_batch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard(tensor, rank, world):
+    lo, hi = shard_bounds(tensor.shape[0], rank, world)
+    return tensor[lo:hi]
+
+
+def combine_chamfer(partials):
+    """partials: [world, 4] fp64 rows (sum sqrt d1, sum sqrt d2, n1, n2) -> global loss scalar."""
+    tot = partials.sum(dim=0)
+    return (tot[0] / tot[2] + tot[1] / tot[3]) / 2.0
+
+
+def allgather_chamfer_loss(sums, n1, n2):
+    """sums: fp64 tensor [2] = (sum sqrt dist1, sum sqrt dist2) of this rank's shard (device tensor for
+    nccl, CPU tensor for gloo); n1/n2: number of dist1/dist2 entries on this rank.
+    Returns the whole-batch Chamfer loss, identical on every rank."""
+    local = torch.cat([sums.to(torch.float64), torch.tensor([n1, n2], dtype=torch.float64, device=sums.device)])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        world = dist.get_world_size()
+        flat = torch.empty(world * 4, dtype=torch.float64, device=sums.device)
+        dist.all_gather_into_tensor(flat, local)          # 32 B per rank: pure latency over xGMI
+        gathered = flat.view(world, 4)
+    else:
+        gathered = local.unsqueeze(0)
+    return combine_chamfer(gathered)
+
+
+def sharded_chamfer_loss(template_shard, source_shard):
+    """ChamferDistanceLoss over a batch that is sharded across ranks (forward / evaluation)."""
+    from .losses.chamfer_distance import ChamferDistance, chamfer_sqrt_sums
+    with torch.no_grad():
+        d1, d2 = ChamferDistance()(template_shard, source_shard)
+        sums = chamfer_sqrt_sums(d1, d2)
+    return allgather_chamfer_loss(sums, d1.numel(), d2.numel())

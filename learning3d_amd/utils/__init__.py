@@ -1,0 +1,12 @@
+"""Mirror of learning3d/utils/__init__.py:1-23 for the hot-path symbols."""
+from .svd import SVDHead, kabsch, svd3x3_rotation
+from .model_common_utils import (
+    knn,
+    get_graph_feature,
+    square_distance,
+    index_points,
+    farthest_point_sample,
+    knn_point,
+    query_ball_point,
+)
+from . import pointnet2_utils

@@ -1,0 +1,114 @@
+"""CPU model of edgeconv_kernel's data flow (mlp.hip): replays, lane by lane, the packed-fragment
+layout produced by l3d_edgeconv_pack (a HOST function of libl3d_hip.so, callable without a GPU),
+the MFMA 16x16x4 operand/accumulator lane maps, the row <-> (point, neighbour) mapping and the
+epilogue, and checks the pooled output against a direct numpy evaluation of
+models/dgcnn.py:32-46 (eval mode, BN folded).  Guards the index algebra that cannot be executed
+here for lack of a GPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from learning3d_amd import _lib
+
+C1, C2, C3, C4 = 64, 64, 128, 256
+MT = 5
+
+
+def mfma_16x16x4(a, b, acc):
+    """a, b: [64] per-lane operands; acc: [64,4].  A[i][k]=a[16k+i], B[k][j]=b[16k+j],
+    D[i][j] -> lane 16*(i//4)+j, reg i%4 (cdna_hip_programming.md section 3)."""
+    A = a.reshape(4, 16).T          # [i, k]
+    Bm = b.reshape(4, 16)           # [k, j]
+    D = A.astype(np.float64) @ Bm.astype(np.float64)
+    out = acc.copy()
+    for i in range(16):
+        for j in range(16):
+            out[16 * (i // 4) + j, i % 4] += D[i, j]
+    return out
+
+
+def run_layer(act, S, wfrag, cin, kv, nt_per_wave, cout_total, bias):
+    """act: flat LDS image with row stride S.  Returns (next_act rows x cout, pooled [4, cout])."""
+    kq_n = cin // (4 * kv)
+    rows = MT * 16
+    nxt = np.zeros((rows, cout_total), np.float64)
+    pooled = np.zeros((4, cout_total), np.float64)
+    lanes = np.arange(64)
+    r, g = lanes & 15, lanes >> 4
+    for wave in range(4):
+        for i in range(nt_per_wave):
+            nt = wave * nt_per_wave + i
+            accs = [np.zeros((64, 4)) for _ in range(MT)]
+            for kq in range(kq_n):
+                frag = wfrag[((nt * kq_n + kq) * 64) * kv:((nt * kq_n + kq) * 64 + 64) * kv].reshape(64, kv)
+                for s in range(kv):
+                    k = (kq * kv + s) * 4 + g
+                    for mt in range(MT):
+                        a = act[(mt * 16 + r) * S + k]
+                        accs[mt] = mfma_16x16x4(a, frag[:, s], accs[mt])
+            ch = nt * 16 + (lanes & 15)
+            for mt in range(MT):
+                v = np.maximum(accs[mt] + bias[ch][:, None], 0.0)       # [64 lanes, 4 regs]
+                for rr in range(4):
+                    nxt[mt * 16 + g * 4 + rr, ch] = v[:, rr]
+                    np.maximum.at(pooled, (g, ch), v[:, rr])
+    return nxt, pooled
+
+
+def to_lds(mat, S):
+    rows, c = mat.shape
+    img = np.zeros(rows * S)
+    for row in range(rows):
+        img[row * S:row * S + c] = mat[row]
+    return img
+
+
+def test_edgeconv_fragment_layout_and_row_mapping():
+    lib = _lib.lib()
+    rng = np.random.default_rng(0)
+    ws = [rng.standard_normal((C1, 6)).astype(np.float32), rng.standard_normal((C2, C1)).astype(np.float32) * 0.2,
+          rng.standard_normal((C3, C2)).astype(np.float32) * 0.2, rng.standard_normal((C4, C3)).astype(np.float32) * 0.1]
+    scs = [rng.uniform(0.5, 1.5, c).astype(np.float32) for c in (C1, C2, C3, C4)]
+    shs = [rng.uniform(-0.2, 0.2, c).astype(np.float32) for c in (C1, C2, C3, C4)]
+    n = lib.l3d_edgeconv_packed_floats(C1, C2, C3, C4)
+    assert n == 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4 + C1 + C2 + C3 + C4
+    packed = np.zeros(n, np.float32)
+    arr = lambda xs: (C.c_void_p * 4)(*[x.ctypes.data for x in xs])
+    assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), C1, C2, C3, C4, packed.ctypes.data) == 0
+    assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), 32, 32, 64, 128, packed.ctypes.data) == -2
+
+    # one tile: 4 points, 20 neighbours each
+    N, k = 16, 20
+    xyz = rng.uniform(0, 1, (N, 3)).astype(np.float32)
+    idx = rng.integers(0, N, (N, k))
+    n0 = 4
+    feat = np.zeros((MT * 16, 8))
+    for row in range(MT * 16):
+        p, j = (row >> 2) & 3, (row >> 4) * 4 + (row & 3)
+        feat[row, 0:3] = xyz[idx[n0 + p, j]]
+        feat[row, 3:6] = xyz[n0 + p]
+    o_w1, o_w2 = 0, 8 * C1
+    o_w3 = o_w2 + C1 * C2
+    o_w4 = o_w3 + C2 * C3
+    o_b1 = o_w4 + C3 * C4
+    o_b2, o_b3, o_b4 = o_b1 + C1, o_b1 + C1 + C2, o_b1 + C1 + C2 + C3
+    pk = packed.astype(np.float64)
+    h1, p1 = run_layer(to_lds(feat, 10), 10, pk[o_w1:o_w2], 8, 2, 1, C1, pk[o_b1:o_b2])
+    h2, p2 = run_layer(to_lds(h1, C1 + 2), C1 + 2, pk[o_w2:o_w3], C1, 4, 1, C2, pk[o_b2:o_b3])
+    h3, p3 = run_layer(to_lds(h2, C2 + 2), C2 + 2, pk[o_w3:o_w4], C2, 4, 2, C3, pk[o_b3:o_b4])
+    _, p4 = run_layer(to_lds(h3, C3 + 2), C3 + 2, pk[o_w4:o_b1], C3, 4, 4, C4, pk[o_b4:o_b4 + C4])
+    got = np.concatenate([p1, p2, p3, p4], axis=1)                 # [4 points, 512]
+
+    # direct evaluation
+    want = []
+    for p in range(4):
+        f = np.concatenate([xyz[idx[n0 + p]], np.repeat(xyz[n0 + p][None], k, 0)], axis=1).astype(np.float64)  # [k,6]
+        outs = []
+        h = f
+        for w, sc, sh in zip(ws, scs, shs):
+            h = np.maximum((h @ (w.astype(np.float64) * sc[:, None].astype(np.float64)).T) + sh, 0.0)
+            outs.append(h.max(axis=0))
+        want.append(np.concatenate(outs))
+    want = np.stack(want)
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
