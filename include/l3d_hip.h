@@ -74,11 +74,14 @@ int l3d_chamfer_forward(const float *xyz1, const float *xyz2, int B, int N, int 
 int l3d_chamfer_backward(const float *xyz1, const float *xyz2, int B, int N, int M,
                          const float *graddist1, const float *graddist2, const int32_t *idx1,
                          const int32_t *idx2, float *gradxyz1, float *gradxyz2, l3d_stream_t stream);
-/* fused loss partial sums: sums[0] = sum sqrt(dist1), sums[1] = sum sqrt(dist2) over the whole
- * batch (losses/chamfer_distance.py:38-40 takes the two means); fp64 accumulators, device memory,
- * ZEROED BY THE CALLEE.  This is the per-shard quantity the multi-GPU path all-gathers. */
-int l3d_chamfer_sqrt_sums(const float *dist1, const float *dist2, int B, int N, int M, double *sums,
-                          l3d_stream_t stream);
+/* Loss tail of losses/chamfer_distance.py:38-40, kept on the device (no host sync per step):
+ *   l3d_chamfer_partials: partial[0..3] = (sum sqrt(dist1), sum sqrt(dist2), #dist1, #dist2), fp64,
+ *       for this rank's shard -- the 32 bytes the multi-GPU path all-gathers over RCCL;
+ *   l3d_chamfer_combine : loss[0] = (S1/N1 + S2/N2) / 2 over `world` gathered partial rows
+ *       ([world][4] fp64) -> fp32 scalar, identical on every rank. */
+int l3d_chamfer_partials(const float *dist1, const float *dist2, int B, int N, int M, double *partial,
+                         l3d_stream_t stream);
+int l3d_chamfer_combine(const double *partials, int world, float *loss, l3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * PointNet++ native ops  == utils/lib/src/pointnet2_api.cpp:10-25 (pybind `pointnet2_cuda`)

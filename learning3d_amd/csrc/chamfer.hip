@@ -6,27 +6,32 @@
 // and matches the CPU twin `nnsearch` (chamfer_distance.cpp:59-87) bit for bit:
 //   d = (dx*dx + dy*dy) + dz*dz with dx = p2 - p1, no contraction, strict '<'.
 //
-// Design: both directions in ONE launch (blockIdx.z), one wave64 per workgroup, one or two
-// queries per lane, the other cloud streamed through LDS as float4 tiles and read back as
-// wave-uniform broadcasts.  No running-min merge through global memory (the reference merges
+// Design: both directions in ONE launch (blockIdx.z); a 4-wave workgroup owns 64 (or 128) queries,
+// one (or two) per lane, and the 4 waves split every LDS tile of the other cloud between them
+// (4 waves/SIMD hide the LDS latency; the (min, argmin) pairs are merged once through LDS).
+// Candidates are float4 tiles read back as wave-uniform ds_read_b128 broadcasts, 8 in flight.  No running-min merge through global memory (the reference merges
 // 512-point chunks through `result[]`, .cu:129-132): the running (min, argmin) lives in VGPRs.
 // Backward is deterministic: every output point owns its sum (direct term + an index-ordered
 // scan for the points that selected it), reproducing the CPU reference's accumulation order
 // (chamfer_distance.cpp:138-176) instead of racing fp32 atomics.
 #include "common.h"
 
-#define CTILE 2048
+#define CTILE 2048      // candidates per LDS tile, shared by the 4 waves (32 KiB)
+#define CWAVES 4        // waves per workgroup: each scans 1/4 of every tile for the SAME 64*QPL queries
+#define CUNROLL 8
 
 template <int QPL>   // queries per lane
-__global__ __launch_bounds__(64) void chamfer_fwd_kernel(const float *__restrict__ xyz1,
-                                                         const float *__restrict__ xyz2, int N,
-                                                         int M, float *__restrict__ dist1,
-                                                         float *__restrict__ dist2,
-                                                         int32_t *__restrict__ idx1,
-                                                         int32_t *__restrict__ idx2)
+__global__ __launch_bounds__(64 * CWAVES) void chamfer_fwd_kernel(const float *__restrict__ xyz1,
+                                                                  const float *__restrict__ xyz2, int N,
+                                                                  int M, float *__restrict__ dist1,
+                                                                  float *__restrict__ dist2,
+                                                                  int32_t *__restrict__ idx1,
+                                                                  int32_t *__restrict__ idx2)
 {
     __shared__ float4 cand[CTILE];
-    const int lane = threadIdx.x;
+    __shared__ float rbest[CWAVES][QPL][64];
+    __shared__ int rbesti[CWAVES][QPL][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     const int dir = blockIdx.z;
     const float *qs = dir == 0 ? xyz1 : xyz2;
@@ -45,36 +50,71 @@ __global__ __launch_bounds__(64) void chamfer_fwd_kernel(const float *__restrict
         int q = min(q0 + u * 64 + lane, Nq - 1);
         const float *p = qs + ((size_t)b * Nq + q) * 3;
         qx[u] = p[0]; qy[u] = p[1]; qz[u] = p[2];
-        best[u] = INFINITY; besti[u] = 0;
+        best[u] = INFINITY; besti[u] = 0x7fffffff;
     }
     const float *cbase = cs + (size_t)b * Nc * 3;
     for (int c0 = 0; c0 < Nc; c0 += CTILE) {
         const int tn = min(CTILE, Nc - c0);
         __syncthreads();
-        for (int t = lane; t < tn; t += 64) {
+        for (int t = tid; t < tn; t += 64 * CWAVES) {
             const float *cp = cbase + (size_t)(c0 + t) * 3;
             cand[t] = make_float4(cp[0], cp[1], cp[2], 0.f);
         }
         __syncthreads();
-#pragma unroll 4
-        for (int t = 0; t < tn; t++) {
+        // this wave's slice of the tile
+        const int per = (tn + CWAVES - 1) / CWAVES;
+        const int t0 = wave * per, t1 = min(tn, t0 + per);
+        int t = t0;
+        for (; t + CUNROLL <= t1; t += CUNROLL) {
+            float4 c[CUNROLL];
+#pragma unroll
+            for (int v = 0; v < CUNROLL; v++) c[v] = cand[t + v];
+#pragma unroll
+            for (int v = 0; v < CUNROLL; v++)
+#pragma unroll
+                for (int u = 0; u < QPL; u++) {
+                    const float dx = c[v].x - qx[u], dy = c[v].y - qy[u], dz = c[v].z - qz[u];
+                    const float d = (dx * dx + dy * dy) + dz * dz;
+                    const bool lt = d < best[u];        // ascending index inside a slice: strict '<'
+                    best[u] = lt ? d : best[u];
+                    besti[u] = lt ? c0 + t + v : besti[u];
+                }
+        }
+        for (; t < t1; t++) {
             const float4 c = cand[t];
 #pragma unroll
             for (int u = 0; u < QPL; u++) {
                 const float dx = c.x - qx[u], dy = c.y - qy[u], dz = c.z - qz[u];
                 const float d = (dx * dx + dy * dy) + dz * dz;
-                const bool lt = d < best[u];        // first candidate always wins vs +inf
+                const bool lt = d < best[u];
                 best[u] = lt ? d : best[u];
                 besti[u] = lt ? c0 + t : besti[u];
             }
         }
     }
+    // combine the 4 waves: smaller d wins, equal d -> lower index (what one sequential strict-'<'
+    // scan over all candidates returns).  NaN/inf-only rows keep index 0 like the reference.
 #pragma unroll
-    for (int u = 0; u < QPL; u++) {
-        int q = q0 + u * 64 + lane;
-        if (q < Nq) {
-            dout[(size_t)b * Nq + q] = best[u];
-            iout[(size_t)b * Nq + q] = besti[u];
+    for (int u = 0; u < QPL; u++) { rbest[wave][u][lane] = best[u]; rbesti[wave][u][lane] = besti[u]; }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int u = 0; u < QPL; u++) {
+            float bv = rbest[0][u][lane];
+            int bi = rbesti[0][u][lane];
+#pragma unroll
+            for (int w = 1; w < CWAVES; w++) {
+                const float ov = rbest[w][u][lane];
+                const int oi = rbesti[w][u][lane];
+                const bool take = ov < bv || (ov == bv && oi < bi);
+                bv = take ? ov : bv;
+                bi = take ? oi : bi;
+            }
+            const int q = q0 + u * 64 + lane;
+            if (q < Nq) {
+                dout[(size_t)b * Nq + q] = bv;
+                iout[(size_t)b * Nq + q] = bi == 0x7fffffff ? 0 : bi;
+            }
         }
     }
 }
@@ -85,16 +125,16 @@ extern "C" int l3d_chamfer_forward(const float *xyz1, const float *xyz2, int B, 
 {
     L3D_REQUIRE(xyz1 && xyz2 && dist1 && dist2 && idx1 && idx2 && B > 0 && N > 0 && M > 0);
     const int mx = N > M ? N : M;
-    // enough waves to cover 256 CUs x 4 SIMDs a few times over before going to 2 queries/lane
-    const long waves1 = (long)l3d_divup(mx, 64) * B * 2;
-    if (waves1 >= 8192) {
+    // enough workgroups to cover 256 CUs several times over before going to 2 queries/lane
+    const long wgs1 = (long)l3d_divup(mx, 64) * B * 2;
+    if (wgs1 >= 8192) {
         dim3 grid(l3d_divup(mx, 128), B, 2);
-        hipLaunchKernelGGL(chamfer_fwd_kernel<2>, grid, dim3(64), 0, (hipStream_t)stream, xyz1, xyz2,
-                           N, M, dist1, dist2, idx1, idx2);
+        hipLaunchKernelGGL(chamfer_fwd_kernel<2>, grid, dim3(64 * CWAVES), 0, (hipStream_t)stream, xyz1,
+                           xyz2, N, M, dist1, dist2, idx1, idx2);
     } else {
         dim3 grid(l3d_divup(mx, 64), B, 2);
-        hipLaunchKernelGGL(chamfer_fwd_kernel<1>, grid, dim3(64), 0, (hipStream_t)stream, xyz1, xyz2,
-                           N, M, dist1, dist2, idx1, idx2);
+        hipLaunchKernelGGL(chamfer_fwd_kernel<1>, grid, dim3(64 * CWAVES), 0, (hipStream_t)stream, xyz1,
+                           xyz2, N, M, dist1, dist2, idx1, idx2);
     }
     return l3d_check_launch();
 }
@@ -183,39 +223,57 @@ extern "C" int l3d_chamfer_backward(const float *xyz1, const float *xyz2, int B,
 }
 
 // ---------------------------------------------------------------------------------------------
-// sums[0] = sum sqrt(dist1), sums[1] = sum sqrt(dist2)   (fp64 accumulation, one atomic/block)
+// Loss tail, kept on the device so a step never synchronises with the host:
+//   partial[0..3] = (sum sqrt(dist1), sum sqrt(dist2), #dist1, #dist2) of this rank's shard  (fp64)
+//   loss = (sum_r p[r][0] / sum_r p[r][2] + sum_r p[r][1] / sum_r p[r][3]) / 2   over the gathered
+//          per-rank partials  == losses/chamfer_distance.py:38-40 on the whole batch.
+// One 1024-thread workgroup per direction, no atomics, no pre-zeroing (deterministic).
 // ---------------------------------------------------------------------------------------------
-__global__ void zero2_kernel(double *s) { if (threadIdx.x < 2) s[threadIdx.x] = 0.0; }
-
-__global__ __launch_bounds__(256) void sqrt_sum_kernel(const float *__restrict__ d1, size_t n1,
-                                                       const float *__restrict__ d2, size_t n2,
-                                                       double *__restrict__ sums)
+__global__ __launch_bounds__(1024) void sqrt_sum_kernel(const float *__restrict__ d1, size_t n1,
+                                                        const float *__restrict__ d2, size_t n2,
+                                                        double *__restrict__ partial)
 {
-    __shared__ double part[4];
-    const int which = blockIdx.y;
+    __shared__ double part[16];
+    const int which = blockIdx.x;
     const float *d = which == 0 ? d1 : d2;
     const size_t n = which == 0 ? n1 : n2;
     double acc = 0.0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (size_t)gridDim.x * blockDim.x)
-        acc += (double)sqrtf(d[i]);
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) acc += (double)sqrtf(d[i]);
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&sums[which], part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; w++) t += part[w];
+        partial[which] = t;
+        partial[2 + which] = (double)n;
+    }
 }
 
-extern "C" int l3d_chamfer_sqrt_sums(const float *dist1, const float *dist2, int B, int N, int M,
-                                     double *sums, l3d_stream_t stream)
+extern "C" int l3d_chamfer_partials(const float *dist1, const float *dist2, int B, int N, int M,
+                                    double *partial, l3d_stream_t stream)
 {
-    L3D_REQUIRE(dist1 && dist2 && sums && B > 0 && N > 0 && M > 0);
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(zero2_kernel, dim3(1), dim3(64), 0, st, sums);
-    const size_t n1 = (size_t)B * N, n2 = (size_t)B * M;
-    const size_t mx = n1 > n2 ? n1 : n2;
-    int blocks = l3d_divup(mx, 256 * 8);
-    if (blocks > 1024) blocks = 1024;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(sqrt_sum_kernel, dim3(blocks, 2), dim3(256), 0, st, dist1, n1, dist2, n2, sums);
+    L3D_REQUIRE(dist1 && dist2 && partial && B > 0 && N > 0 && M > 0);
+    hipLaunchKernelGGL(sqrt_sum_kernel, dim3(2), dim3(1024), 0, (hipStream_t)stream, dist1,
+                       (size_t)B * N, dist2, (size_t)B * M, partial);
+    return l3d_check_launch();
+}
+
+__global__ void chamfer_combine_kernel(const double *__restrict__ partials, int world,
+                                       float *__restrict__ loss)
+{
+    if (threadIdx.x != 0) return;
+    double s1 = 0, s2 = 0, n1 = 0, n2 = 0;
+    for (int r = 0; r < world; r++) {
+        s1 += partials[r * 4 + 0]; s2 += partials[r * 4 + 1];
+        n1 += partials[r * 4 + 2]; n2 += partials[r * 4 + 3];
+    }
+    loss[0] = (float)((s1 / n1 + s2 / n2) / 2.0);
+}
+
+extern "C" int l3d_chamfer_combine(const double *partials, int world, float *loss, l3d_stream_t stream)
+{
+    L3D_REQUIRE(partials && loss && world > 0);
+    hipLaunchKernelGGL(chamfer_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partials, world, loss);
     return l3d_check_launch();
 }

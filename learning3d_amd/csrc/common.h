@@ -35,6 +35,23 @@ static inline int l3d_divup(long a, long b) { return (int)((a + b - 1) / b); }
 //   insert(): v[i] <- med3(v[i-1], v[i], key) is exactly the sorted-insert update when
 //   v[i-1] >= v[i]; one v_med3_f32 per slot for the keys, cmp+2 cndmask for the payloads.
 // -------------------------------------------------------------------------------------------
+// Values-only variant: one v_med3_f32 per slot and nothing else.  Used for the first pass of the
+// two-pass selection (find the exact K-th best key), where indices are not needed yet.
+template <int K>
+struct TopKV {
+    float v[K];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int i = 0; i < K; i++) v[i] = -INFINITY;
+    }
+    __device__ __forceinline__ float worst() const { return v[K - 1]; }
+    __device__ __forceinline__ void insert(float key) {
+#pragma unroll
+        for (int i = K - 1; i > 0; i--) v[i] = __builtin_amdgcn_fmed3f(v[i - 1], v[i], key);
+        v[0] = fmaxf(v[0], key);
+    }
+};
+
 template <int K>
 struct TopK {
     float v[K];

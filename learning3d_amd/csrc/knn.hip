@@ -93,11 +93,19 @@ __global__ __launch_bounds__(64) void topk_scan_kernel(
         int t = 0;
         for (; t + CHUNK <= tn; t += CHUNK) {
             if (__any(cnt > QCAP - CHUNK)) flush();
+            // read the whole chunk first (independent ds_read_b128 in flight together), evaluate,
+            // THEN append: the queue stores may alias `cand` as far as the compiler knows, and
+            // interleaving them serialises every candidate behind an LDS round trip.
+            float4 c[CHUNK];
+            float key[CHUNK];
+#pragma unroll
+            for (int u = 0; u < CHUNK; u++) c[u] = cand[t + u];
+#pragma unroll
+            for (int u = 0; u < CHUNK; u++) key[u] = eval(c[u]);
 #pragma unroll
             for (int u = 0; u < CHUNK; u++) {
-                const float key = eval(cand[t + u]);
-                if (key > thr) {
-                    qkey[cnt][lane] = key;
+                if (key[u] > thr) {
+                    qkey[cnt][lane] = key[u];
                     qidx[cnt][lane] = c0 + t + u;
                     cnt++;
                 }
@@ -135,23 +143,235 @@ __global__ __launch_bounds__(64) void topk_scan_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-pass variant (K <= 64): what makes the single-pass kernel above slow is the index half of
+// the insertion network (cmp + 2 cndmask per slot, plus spurious moves) running on every queue
+// entry of the busiest lane.  Here
+//   pass 1 keeps VALUES ONLY (one v_med3_f32 per slot) and ends with the exact K-th best key;
+//   pass 2 rescans (the cloud is L2/LDS resident) and collects the (< K) candidates strictly above
+//          that key plus the first K candidates equal to it, in index order;
+//   the full (value, index) network then runs on ~K entries once.
+// W waves per workgroup split the candidate range into W contiguous slices for the SAME 64
+// queries (all SIMDs busy at B=32, N=1024; ties still resolve to the lower index because slice
+// w's indices all precede slice w+1's), and wave 0 merges the W sorted lists through LDS.
+// ---------------------------------------------------------------------------------------------
+#define T2 256          // candidates per per-wave LDS tile (4 KiB)
+
+template <int K, int METRIC, int W>
+__global__ __launch_bounds__(64 * W) void topk2_kernel(
+    const float *__restrict__ qxyz, const float *__restrict__ cxyz, int Nq, int Nc, int k,
+    int out_mode, void *__restrict__ idx_out, float *__restrict__ val_out)
+{
+    // per-wave LDS: a candidate tile and one scratch area that is the pass-1 key queue
+    // ([QCAP][64]), then the pass-2 collection (akey | aidx | bidx, [K][64] each), then the merge
+    // mailbox (akey | aidx).  19 KiB per wave at K=20 -> two 4-wave workgroups per CU.
+    constexpr int SCR = (3 * K > QCAP ? 3 * K : QCAP) * 64;
+    __shared__ float4 cand[W][T2];
+    __shared__ float scratch[W][SCR];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * 64 + lane;
+    const bool valid = q < Nq;
+    const int qc = valid ? q : Nq - 1;
+    const float *qp = qxyz + ((size_t)b * Nq + qc) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    const float qxx = (qx * qx + qy * qy) + qz * qz;
+    const float *cbase = cxyz + (size_t)b * Nc * 3;
+
+    float *qkey = scratch[wave];                       // [QCAP][64]
+    float *akey = scratch[wave];                       // [K][64]
+    int *aidx = (int *)scratch[wave] + K * 64;         // [K][64]
+    int *bidx = (int *)scratch[wave] + 2 * K * 64;     // [K][64]
+
+    const int per = (Nc + W - 1) / W;                 // slice length (uniform)
+    const int lo = wave * per, hi = min(Nc, lo + per);
+    const int ntiles = (per + T2 - 1) / T2;           // uniform trip count -> barriers are safe
+
+    auto eval = [&](const float4 c) -> float {
+        if (METRIC == METRIC_EXPANDED) {
+            const float dot = fmaf(qz, c.z, fmaf(qy, c.y, qx * c.x));
+            const float tt = fmaf(2.0f, dot, c.w);
+            return tt - qxx;
+        } else {
+            const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+            return -((dx * dx + dy * dy) + dz * dz);
+        }
+    };
+    auto stage = [&](int c0, int tn) {
+        __syncthreads();
+        for (int t = lane; t < tn; t += 64) {
+            const float *cp = cbase + (size_t)(c0 + t) * 3;
+            float x = cp[0], y = cp[1], z = cp[2];
+            float w = 0.f;
+            if (METRIC == METRIC_EXPANDED) w = -((x * x + y * y) + z * z);
+            cand[wave][t] = make_float4(x, y, z, w);
+        }
+        __syncthreads();
+    };
+
+    // ------------------------------------------------------------------ pass 1: K-th best key
+    float thrF;
+    {
+        TopKV<K> tv;
+        tv.init();
+        float thr = -INFINITY;
+        int cnt = 0;
+        auto flushv = [&]() {
+#pragma unroll 1
+            for (int s = 0; s < QCAP; s++) {
+                const bool has = s < cnt;
+                if (!__any(has)) break;
+                tv.insert(has ? qkey[s * 64 + lane] : -INFINITY);
+            }
+            cnt = 0;
+            thr = tv.worst();
+        };
+        for (int tile = 0; tile < ntiles; tile++) {
+            const int c0 = lo + tile * T2;
+            const int tn = max(0, min(T2, hi - c0));
+            stage(c0, tn);
+            int t = 0;
+            for (; t + CHUNK <= tn; t += CHUNK) {
+                if (__any(cnt > QCAP - CHUNK)) flushv();
+                float4 c[CHUNK];
+                float key[CHUNK];
+#pragma unroll
+                for (int u = 0; u < CHUNK; u++) c[u] = cand[wave][t + u];
+#pragma unroll
+                for (int u = 0; u < CHUNK; u++) key[u] = eval(c[u]);
+#pragma unroll
+                for (int u = 0; u < CHUNK; u++)
+                    if (key[u] > thr) { qkey[cnt * 64 + lane] = key[u]; cnt++; }
+            }
+            for (; t < tn; t++) {
+                if (__any(cnt >= QCAP)) flushv();
+                const float key = eval(cand[wave][t]);
+                if (key > thr) { qkey[cnt * 64 + lane] = key; cnt++; }
+            }
+        }
+        flushv();
+        thrF = tv.worst();
+    }
+
+    // -------------------------------------------- pass 2: collect (key > thrF) and first K (key == thrF)
+    int cntA = 0, cntB = 0;
+    for (int tile = 0; tile < ntiles; tile++) {
+        const int c0 = lo + tile * T2;
+        const int tn = max(0, min(T2, hi - c0));
+        if (ntiles > 1) stage(c0, tn);            // single-tile slices are still resident from pass 1
+        int t = 0;
+        for (; t + CHUNK <= tn; t += CHUNK) {
+            float4 c[CHUNK];
+            float key[CHUNK];
+#pragma unroll
+            for (int u = 0; u < CHUNK; u++) c[u] = cand[wave][t + u];
+#pragma unroll
+            for (int u = 0; u < CHUNK; u++) key[u] = eval(c[u]);
+#pragma unroll
+            for (int u = 0; u < CHUNK; u++) {
+                if (key[u] > thrF) {
+                    if (cntA < K) { akey[cntA * 64 + lane] = key[u]; aidx[cntA * 64 + lane] = c0 + t + u; cntA++; }
+                } else if (key[u] == thrF) {
+                    if (cntB < K) { bidx[cntB * 64 + lane] = c0 + t + u; cntB++; }
+                }
+            }
+        }
+        for (; t < tn; t++) {
+            const float key = eval(cand[wave][t]);
+            if (key > thrF) {
+                if (cntA < K) { akey[cntA * 64 + lane] = key; aidx[cntA * 64 + lane] = c0 + t; cntA++; }
+            } else if (key == thrF) {
+                if (cntB < K) { bidx[cntB * 64 + lane] = c0 + t; cntB++; }
+            }
+        }
+    }
+
+    // ------------------------------------------------ full (value, index) list of this wave's slice
+    TopK<K> top;
+    top.init();
+#pragma unroll 1
+    for (int s = 0; s < K; s++) {
+        const bool has = s < cntA;
+        if (!__any(has)) break;
+        top.insert(has ? akey[s * 64 + lane] : -INFINITY, aidx[s * 64 + lane]);
+    }
+#pragma unroll 1
+    for (int s = 0; s < K; s++) {
+        const bool has = s < cntB;
+        if (!__any(has)) break;
+        top.insert(has ? thrF : -INFINITY, bidx[s * 64 + lane]);
+    }
+
+    // ------------------------------------- tree-merge the W sorted lists: (1->0, 3->2), then (2->0)
+    // a sender's slice always FOLLOWS the receiver's in index order, so strict '>' insertion keeps
+    // lowest-index-first under ties.
+#pragma unroll 1
+    for (int step = 1; step < W; step <<= 1) {
+        const bool sender = (wave & (2 * step - 1)) == step;
+        const bool receiver = (wave & (2 * step - 1)) == 0 && wave + step < W;
+        __syncthreads();
+        if (sender) {
+#pragma unroll
+            for (int i = 0; i < K; i++) { akey[i * 64 + lane] = top.v[i]; aidx[i * 64 + lane] = top.id[i]; }
+        }
+        __syncthreads();
+        if (receiver) {
+            const float *mk = scratch[wave + step];
+            const int *mi = (const int *)scratch[wave + step] + K * 64;
+#pragma unroll 1
+            for (int i = 0; i < K; i++) {
+                const float kv = mk[i * 64 + lane];
+                if (!__any(kv > top.worst())) break;          // sorted: nothing further can enter
+                top.insert(kv, mi[i * 64 + lane]);
+            }
+        }
+    }
+
+    if (wave != 0 || !valid) return;
+    const size_t o = ((size_t)b * Nq + q) * k;
+    if (out_mode == OUT_KNN_GRAPH) {
+        int64_t *dst = (int64_t *)idx_out + o;
+#pragma unroll
+        for (int i = 0; i < K; i++)
+            if (i < k) dst[i] = top.id[i];
+    } else if (out_mode == OUT_KNN_PAIR) {
+        int32_t *dst = (int32_t *)idx_out + o;
+#pragma unroll
+        for (int i = 0; i < K; i++)
+            if (i < k) { dst[i] = top.id[i]; val_out[o + i] = -top.v[i]; }
+    } else {
+        int64_t *dst = (int64_t *)idx_out + o;
+#pragma unroll
+        for (int i = 0; i < K; i++)
+            if (i < k) { dst[i] = top.id[i]; val_out[o + i] = sqrtf(-top.v[i]); }
+    }
+}
+
 template <int METRIC>
 static int launch_topk(const float *q, const float *c, int B, int Nq, int Nc, int k, int out_mode,
                        void *idx, float *val, hipStream_t st)
 {
     dim3 grid(l3d_divup(Nq, 64), B), block(64);
+#define L3D_TOPK2_CASE(KK, WW)                                                                   \
+    if (k <= KK) {                                                                               \
+        hipLaunchKernelGGL((topk2_kernel<KK, METRIC, WW>), grid, dim3(64 * WW), 0, st, q, c, Nq, \
+                           Nc, k, out_mode, idx, val);                                           \
+        return l3d_check_launch();                                                               \
+    }
+    L3D_TOPK2_CASE(4, 4)
+    L3D_TOPK2_CASE(8, 4)
+    L3D_TOPK2_CASE(16, 4)
+    L3D_TOPK2_CASE(20, 4)
+    L3D_TOPK2_CASE(32, 4)
+    L3D_TOPK2_CASE(64, 2)
+#undef L3D_TOPK2_CASE
 #define L3D_TOPK_CASE(KK)                                                                    \
     if (k <= KK) {                                                                           \
         hipLaunchKernelGGL((topk_scan_kernel<KK, METRIC>), grid, block, 0, st, q, c, Nq, Nc, \
                            k, out_mode, idx, val);                                           \
         return l3d_check_launch();                                                           \
     }
-    L3D_TOPK_CASE(4)
-    L3D_TOPK_CASE(8)
-    L3D_TOPK_CASE(16)
-    L3D_TOPK_CASE(20)
-    L3D_TOPK_CASE(32)
-    L3D_TOPK_CASE(64)
     L3D_TOPK_CASE(128)
     L3D_TOPK_CASE(200)
 #undef L3D_TOPK_CASE

@@ -51,15 +51,24 @@ class ChamferDistance(torch.nn.Module):
         return ChamferDistanceFunction.apply(xyz1, xyz2)
 
 
-def chamfer_sqrt_sums(dist1, dist2):
-    """(sum sqrt(dist1), sum sqrt(dist2)) as a device fp64 tensor [2] -- the per-shard partial sums
-    the multi-GPU path all-gathers (forward-only helper; no autograd)."""
+def chamfer_partials(dist1, dist2):
+    """Device fp64 tensor [4] = (sum sqrt(dist1), sum sqrt(dist2), #dist1, #dist2): the per-shard
+    partial sums the multi-GPU path all-gathers (forward-only helper; no autograd, no host sync)."""
     B, N = dist1.shape
     M = dist2.shape[1]
-    sums = torch.empty(2, dtype=torch.float64, device=dist1.device)
-    check(lib().l3d_chamfer_sqrt_sums(ptr(dist1), ptr(dist2), B, N, M, ptr(sums), stream_ptr()),
-          "l3d_chamfer_sqrt_sums")
-    return sums
+    part = torch.empty(4, dtype=torch.float64, device=dist1.device)
+    check(lib().l3d_chamfer_partials(ptr(dist1), ptr(dist2), B, N, M, ptr(part), stream_ptr()),
+          "l3d_chamfer_partials")
+    return part
+
+
+def chamfer_combine(partials):
+    """partials: fp64 [world,4] (or [4]) device tensor -> fp32 scalar loss tensor (on device)."""
+    partials = partials.contiguous().view(-1, 4)
+    loss = torch.empty((), dtype=torch.float32, device=partials.device)
+    check(lib().l3d_chamfer_combine(ptr(partials), partials.shape[0], ptr(loss), stream_ptr()),
+          "l3d_chamfer_combine")
+    return loss
 
 
 def chamfer_distance(template: torch.Tensor, source: torch.Tensor):
@@ -70,8 +79,7 @@ def chamfer_distance(template: torch.Tensor, source: torch.Tensor):
         cost_p0_p1 = torch.mean(torch.sqrt(cost_p0_p1))
         cost_p1_p0 = torch.mean(torch.sqrt(cost_p1_p0))
         return (cost_p0_p1 + cost_p1_p0) / 2.0
-    s = chamfer_sqrt_sums(cost_p0_p1, cost_p1_p0)
-    return ((s[0] / cost_p0_p1.numel() + s[1] / cost_p1_p0.numel()) / 2.0).to(torch.float32)
+    return chamfer_combine(chamfer_partials(cost_p0_p1, cost_p1_p0))
 
 
 def chamfer(a, b):

@@ -10,6 +10,54 @@ import torch
 from .._lib import check, f32c, lib, ptr, require_gpu, stream_ptr
 
 
+class _NullSpan:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL = _NullSpan()
+
+
+class StageTimer:
+    """Optional per-stage HIP-event timing (bench.py sets `_fused.TIMER = StageTimer()`).  Events are
+    recorded on torch's current stream, which is the stream every l3d_* launch is issued on."""
+
+    def __init__(self, only=None):
+        self.spans = {}
+        self.only = only          # restrict to these span names (None = all)
+        self.enabled = True       # flip per step to sample a subset of steps
+
+    def span(self, name):
+        if not self.enabled or (self.only is not None and name not in self.only):
+            return _NULL
+        timer = self
+
+        class _Span:
+            def __enter__(self_inner):
+                self_inner.e0 = torch.cuda.Event(enable_timing=True)
+                self_inner.e1 = torch.cuda.Event(enable_timing=True)
+                self_inner.e0.record()
+
+            def __exit__(self_inner, *exc):
+                self_inner.e1.record()
+                timer.spans.setdefault(name, []).append((self_inner.e0, self_inner.e1))
+        return _Span()
+
+    def mean_ms(self):
+        """call after torch.cuda.synchronize()"""
+        return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in self.spans.items()}
+
+
+TIMER = None
+
+
+def stage(name):
+    return TIMER.span(name) if TIMER is not None else _NULL
+
+
 def bn_affine(bn):
     """eval-mode BatchNorm as y = scale * x + shift"""
     scale = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)

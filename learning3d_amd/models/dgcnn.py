@@ -31,6 +31,15 @@ class DGCNN(torch.nn.Module):
         self.bn5 = torch.nn.BatchNorm2d(emb_dims)
         self._packed = _fused.EdgeConvParams()
 
+    def _conv5_folded(self):
+        ts = [self.conv5.weight, self.bn5.weight, self.bn5.bias, self.bn5.running_mean, self.bn5.running_var]
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        if getattr(self, "_c5key", None) != key:
+            w, s, b = _fused.fold_conv_bn(self.conv5, self.bn5)
+            self._c5 = (w.float().contiguous(), s.float().contiguous(), b.float().contiguous())
+            self._c5key = key
+        return self._c5
+
     def forward(self, input_data):
         if self.input_shape == "bnc":
             input_data = input_data.permute(0, 2, 1)
@@ -40,12 +49,16 @@ class DGCNN(torch.nn.Module):
 
         if _fused.can_fuse(self, input_data):
             xyz = _as_bn3(input_data)                                   # [B,N,3] (no copy for "bnc")
-            idx = knn(input_data, k=20)                                 # dgcnn.py:32 (k=20 default)
+            with _fused.stage("knn"):
+                idx = knn(input_data, k=20)                             # dgcnn.py:32 (k=20 default)
             packed = self._packed.get([self.conv1, self.conv2, self.conv3, self.conv4],
                                       [self.bn1, self.bn2, self.bn3, self.bn4], xyz.device)
-            pooled = _fused.edgeconv_forward(xyz, idx, packed)          # dgcnn.py:34-46
-            w5, s5, b5 = _fused.fold_conv_bn(self.conv5, self.bn5)
-            return _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True)  # dgcnn.py:48
+            with _fused.stage("edgeconv"):
+                pooled = _fused.edgeconv_forward(xyz, idx, packed)      # dgcnn.py:34-46
+            w5, s5, b5 = self._conv5_folded()
+            with _fused.stage("conv5"):
+                out = _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True)  # dgcnn.py:48
+            return out
 
         output = get_graph_feature(input_data)
         output = F.relu(self.bn1(self.conv1(output)))

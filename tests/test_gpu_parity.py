@@ -348,7 +348,7 @@ def test_pointwise_conv_ragged_shapes():
 def test_pcn_fused_matches_reference_order_path():
     from learning3d_amd.models import PCN
     torch.manual_seed(3)
-    net = PCN(emb_dims=256, num_coarse=64, grid_size=2, detailed_output=True).cuda().eval()
+    net = PCN(emb_dims=1024, num_coarse=64, grid_size=2, detailed_output=True).cuda().eval()   # conv5 is 1029-wide: emb must be 1024 (pcn.py:73)
     x = dev(rand((2, 300, 3), 4, -0.5, 0.5))
     with torch.no_grad():
         fused = net(x)

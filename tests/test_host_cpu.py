@@ -104,8 +104,8 @@ g = torch.Generator().manual_seed(0)
 a = torch.rand((6, 64, 3), generator=g).numpy(); b = torch.rand((6, 80, 3), generator=g).numpy()
 lo, hi = parallel.shard_bounds(6, rank, world)
 d1, d2, _, _ = oracle.chamfer_forward(a[lo:hi], b[lo:hi])          # stands in for the HIP kernel on this rank
-sums = torch.tensor([np.sqrt(d1).astype(np.float64).sum(), np.sqrt(d2).astype(np.float64).sum()], dtype=torch.float64)
-loss = parallel.allgather_chamfer_loss(sums, d1.size, d2.size)
+part = torch.tensor([np.sqrt(d1).astype(np.float64).sum(), np.sqrt(d2).astype(np.float64).sum(), d1.size, d2.size], dtype=torch.float64)
+loss = parallel.allgather_chamfer_loss(part)
 want = float(oracle.chamfer_loss(a, b))
 assert abs(float(loss) - want) < 1e-6, (float(loss), want)
 print("RANK", rank, "OK", float(loss))

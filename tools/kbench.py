@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmarks at the BASELINE shapes (HIP-event timing on torch's current stream,
+which is the stream the l3d_* launches use).  Prints one line per kernel:
+    name  avg_us  achieved  unit  (algorithmic work / time)
+Not a product path; used while tuning and for DESIGN.md's tables."""
+import json
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def timeit(fn, warm=5, iters=30):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3       # us
+
+
+def main():
+    import learning3d_amd.utils as U
+    from learning3d_amd.utils import pointnet2_utils as P
+    from learning3d_amd.losses.chamfer_distance import ChamferDistance
+    from learning3d_amd.models import DGCNN, _fused, PCN
+    res = {}
+    dev = "cuda"
+    g = torch.Generator().manual_seed(0)
+    B, N, k = 32, 1024, 20
+    x = torch.rand((B, N, 3), generator=g).to(dev)
+    a = torch.rand((B, N, 3), generator=g).to(dev)
+    b = torch.rand((B, N, 3), generator=g).to(dev)
+    xt = x.permute(0, 2, 1)
+    with torch.no_grad():
+        t = timeit(lambda: U.knn(xt, k))
+        res["knn_c2"] = (t, B * N * N / t / 1e3, "Gpair/s")
+        cd = ChamferDistance()
+        t = timeit(lambda: cd(a, b))
+        res["chamfer_c2"] = (t, 2 * B * N * N / t / 1e3, "Gpair/s")
+        net = DGCNN(emb_dims=1024).to(dev).eval()
+        idx = U.knn(xt, k)
+        packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
+        t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed))
+        res["edgeconv_c2"] = (t, B * N * k * 2 * 45440 / t / 1e6, "TFLOP/s")
+        pooled = _fused.edgeconv_forward(x, idx, packed)
+        w5, s5, b5 = net._conv5_folded()
+        t = timeit(lambda: _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True))
+        res["conv5_c2"] = (t, B * N * 2 * 512 * 1024 / t / 1e6, "TFLOP/s")
+        t = timeit(lambda: net(x))
+        res["dgcnn_fwd_c2"] = (t, B / t * 1e6, "clouds/s")
+        # c4 slice: Chamfer 2048 x 16384 (B=8 of 64) -- O(N^2) stress
+        a4 = torch.rand((8, 16384, 3), generator=g).to(dev)
+        b4 = torch.rand((8, 16384, 3), generator=g).to(dev)
+        t = timeit(lambda: cd(a4, b4), warm=2, iters=5)
+        res["chamfer_c4_B8_16k"] = (t, 2 * 8 * 16384 * 16384 / t / 1e3, "Gpair/s")
+        # c5 per-GPU slice: FlowNet3D set-conv grouping, B=32, N=8192, S=1024, r=0.5, K=16
+        xyz = torch.clamp(torch.randn((32, 8192, 3), generator=g), -2, 2).to(dev)
+        feat = torch.rand((32, 3, 8192), generator=g).to(dev)
+        t = timeit(lambda: P.furthest_point_sample(xyz, 1024), warm=1, iters=3)
+        res["fps_c5"] = (t, 32 * 1024 * 8192 / t / 1e3, "Gpair/s")
+        fps = P.furthest_point_sample(xyz, 1024)
+        new_xyz = P.gather_operation(xyz.transpose(1, 2).contiguous(), fps).transpose(1, 2).contiguous()
+        t = timeit(lambda: P.ball_query(0.5, 16, xyz, new_xyz))
+        res["ball_query_c5"] = (t, 32 * 1024 * 8192 / t / 1e3, "Gpair/s(max)")
+        bidx = P.ball_query(0.5, 16, xyz, new_xyz)
+        feat6 = torch.cat([xyz.transpose(1, 2).contiguous(), feat], 1).contiguous()
+        t = timeit(lambda: P.grouping_operation(feat6, bidx))
+        res["group_c5"] = (t, 27262976 / t / 1e3, "GB/s(alg)")
+        t = timeit(lambda: P.knn(64, new_xyz, xyz), warm=1, iters=3)
+        res["knn_pair_k64_c5"] = (t, 32 * 1024 * 8192 / t / 1e3, "Gpair/s")
+    for name, (t, v, u) in res.items():
+        print(f"{name:22s} {t:10.1f} us   {v:10.2f} {u}")
+    print(json.dumps({k: {"us": v[0], "rate": v[1], "unit": v[2]} for k, v in res.items()}))
+
+
+if __name__ == "__main__":
+    main()

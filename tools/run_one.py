@@ -1,0 +1,23 @@
+"""Run one kernel a few times (for rocprofv3 --pmc passes).  usage: run_one.py knn|chamfer|edgeconv|conv5"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import learning3d_amd.utils as U
+from learning3d_amd.losses.chamfer_distance import ChamferDistance
+from learning3d_amd.models import DGCNN, _fused
+what = sys.argv[1]
+g = torch.Generator().manual_seed(0)
+x = torch.rand((32, 1024, 3), generator=g).cuda(); a = torch.rand((32, 1024, 3), generator=g).cuda(); b = torch.rand((32, 1024, 3), generator=g).cuda()
+net = DGCNN(emb_dims=1024).cuda().eval()
+with torch.no_grad():
+    idx = U.knn(x.permute(0, 2, 1), 20)
+    packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
+    pooled = _fused.edgeconv_forward(x, idx, packed)
+    w5, s5, b5 = net._conv5_folded()
+    torch.cuda.synchronize()
+    for _ in range(5):
+        if what == "knn": U.knn(x.permute(0, 2, 1), 20)
+        elif what == "chamfer": ChamferDistance()(a, b)
+        elif what == "edgeconv": _fused.edgeconv_forward(x, idx, packed)
+        elif what == "conv5": _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True)
+    torch.cuda.synchronize()
