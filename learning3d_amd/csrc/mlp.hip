@@ -104,31 +104,44 @@ __device__ __forceinline__ void ec_layer_mma(const float *__restrict__ act,
         for (int i = 0; i < NT; i++) acc[mt][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const vecT *wp = (const vecT *)wfrag + ((size_t)(wave * NT) * KQ) * 64 + lane;
-    vecT bcur[NT], bnext[NT];
+    // Software pipeline, two register sets each (no copies), order pinned with sched_barrier:
+    //   A operands: the ds_reads of k-step pair p+1 are in flight while pair p's MFMAs run;
+    //   B fragments: the global loads of weight block kq+1 are issued when block kq starts.
+    constexpr int NP = CIN / 8;                 // pairs of k-steps
+    vecT bf[2][NT];
+    float av[2][MT][2];
 #pragma unroll
-    for (int i = 0; i < NT; i++) bcur[i] = wp[(size_t)(i * KQ) * 64];
+    for (int i = 0; i < NT; i++) bf[0][i] = wp[(size_t)(i * KQ) * 64];
 #pragma unroll
-    for (int kq = 0; kq < KQ; kq++) {
-        if (kq + 1 < KQ) {
+    for (int mt = 0; mt < MT; mt++) {
+        av[0][mt][0] = act[(mt * 16 + r) * S + g];
+        av[0][mt][1] = act[(mt * 16 + r) * S + 4 + g];
+    }
 #pragma unroll
-            for (int i = 0; i < NT; i++) bnext[i] = wp[(size_t)(i * KQ + kq + 1) * 64];
+    for (int p = 0; p < NP; p++) {
+        const int cur = p & 1, nxt = cur ^ 1;
+        const int kq = (2 * p) / KV, s0 = (2 * p) % KV;
+        if (s0 == 0 && kq + 1 < KQ) {
+#pragma unroll
+            for (int i = 0; i < NT; i++) bf[(kq + 1) & 1][i] = wp[(size_t)(i * KQ + kq + 1) * 64];
         }
+        if (p + 1 < NP) {
 #pragma unroll
-        for (int s = 0; s < KV; s++) {
-            const int k = (kq * KV + s) * 4 + g;
-            float a[MT];
+            for (int mt = 0; mt < MT; mt++) {
+                av[nxt][mt][0] = act[(mt * 16 + r) * S + (2 * p + 2) * 4 + g];
+                av[nxt][mt][1] = act[(mt * 16 + r) * S + (2 * p + 3) * 4 + g];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) a[mt] = act[(mt * 16 + r) * S + k];
+        for (int e = 0; e < 2; e++)
 #pragma unroll
             for (int i = 0; i < NT; i++)
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
-                    acc[mt][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bcur[i][s], acc[mt][i], 0, 0, 0);
-        }
-        if (kq + 1 < KQ) {
-#pragma unroll
-            for (int i = 0; i < NT; i++) bcur[i] = bnext[i];
-        }
+                    acc[mt][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][mt][e], bf[kq & 1][i][s0 + e],
+                                                                      acc[mt][i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -159,16 +172,22 @@ __device__ __forceinline__ void ec_layer_epilogue(f32x4 (&acc)[MT][NT],
 }
 
 template <int MT>
-__global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float *__restrict__ xyz,
+__global__ __launch_bounds__(256, MT <= 5 ? 3 : 1) void edgeconv_kernel(const float *__restrict__ xyz,
                                                           const int64_t *__restrict__ idx, int N,
                                                           int k, const float *__restrict__ packed,
                                                           float *__restrict__ pooled /*[B*N][512]*/)
 {
     constexpr int ROWS = MT * 16;
     constexpr int CTOT = EC_C1 + EC_C2 + EC_C3 + EC_C4;
-    // P0: feature tile (8 ch) then h2 (64 ch);  P1: h1 (64 ch) then h3 (128 ch)
-    __shared__ float P0[ROWS * (EC_C2 + 2)];
-    __shared__ float P1[ROWS * (EC_C3 + 2)];
+    // One LDS arena of 2 x ROWS x 66 floats (42 KiB at MT=5 -> three workgroups per CU):
+    //   X = first half : feature tile (8 ch, stride 10), later h2 (64 ch, stride 66)
+    //   Y = second half: h1 (64 ch, stride 66)
+    //   h3 (128 ch, stride 130 = ROWS x 130 <= 2 x ROWS x 66) overlays X and Y once h2 is dead.
+    __shared__ float arena[2 * ROWS * (EC_C2 + 2)];
+    float *const P0 = arena;
+    float *const P1 = arena + ROWS * (EC_C2 + 2);
+    float *const P3 = arena;
+    static_assert(ROWS * (EC_C3 + 2) <= 2 * ROWS * (EC_C2 + 2), "h3 must fit the arena");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = blockIdx.y;
     const int n0 = blockIdx.x * 4;
@@ -209,12 +228,13 @@ __global__ __launch_bounds__(256, 2) void edgeconv_kernel(const float *__restric
     {   // layer 3: 64 -> 128
         f32x4 acc[MT][2];
         ec_layer_mma<MT, EC_C2, 4, 2>(P0, packed + EC_OFF_W3, wave, lane, acc);
-        ec_layer_epilogue<MT, 2, EC_C3 + 2, true>(acc, packed + EC_OFF_B3, wave, lane, P1, prow + EC_C1 + EC_C2, store_ok);
+        __syncthreads();                 // every wave is done reading h2 before h3 overlays it
+        ec_layer_epilogue<MT, 2, EC_C3 + 2, true>(acc, packed + EC_OFF_B3, wave, lane, P3, prow + EC_C1 + EC_C2, store_ok);
     }
     __syncthreads();
     {   // layer 4: 128 -> 256 (activations are only max-pooled, never stored)
         f32x4 acc[MT][4];
-        ec_layer_mma<MT, EC_C3, 4, 4>(P1, packed + EC_OFF_W4, wave, lane, acc);
+        ec_layer_mma<MT, EC_C3, 4, 4>(P3, packed + EC_OFF_W4, wave, lane, acc);
         ec_layer_epilogue<MT, 4, 0, false>(acc, packed + EC_OFF_B4, wave, lane, nullptr, prow + EC_C1 + EC_C2 + EC_C3, store_ok);
     }
 }
@@ -327,18 +347,32 @@ __global__ __launch_bounds__(256, 2) void pointwise_conv_kernel(
         store_chunk();
         __syncthreads();
         if (k0 + PW_TK < Cin) load_chunk(k0 + PW_TK);     // overlaps with the MFMAs below
+        // software-pipelined operand fetch: the ds_reads of k-step s+1 are in flight while the four
+        // 64-cycle MFMAs of k-step s occupy the matrix pipe (otherwise each k-step exposes one LDS
+        // round trip: measured 73 % MFMA-busy before, see profiles/)
+        float av[2][2], bv[2][2];          // [k-step parity][tile]: two register sets, no copies
 #pragma unroll
-        for (int ks = 0; ks < PW_TK; ks += 2) {
-            float a[2], bb[2];
+        for (int i = 0; i < 2; i++) av[0][i] = As[kh][wm * 64 + i * 32 + l31];
 #pragma unroll
-            for (int i = 0; i < 2; i++) a[i] = As[ks + kh][wm * 64 + i * 32 + l31];
+        for (int j = 0; j < 2; j++) bv[0][j] = Bs[kh][wn * 64 + j * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < 2; j++) bb[j] = Bs[ks + kh][wn * 64 + j * 32 + l31];
+        for (int st = 0; st < PW_TK / 2; st++) {
+            const int cur = st & 1, nxt = cur ^ 1;
+            if (st + 1 < PW_TK / 2) {
+#pragma unroll
+                for (int i = 0; i < 2; i++) av[nxt][i] = As[2 * (st + 1) + kh][wm * 64 + i * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < 2; j++) bv[nxt][j] = Bs[2 * (st + 1) + kh][wn * 64 + j * 32 + l31];
+            }
+            // pin the order "reads of step s+1, then MFMAs of step s" (hipcc otherwise sinks the reads
+            // below the MFMAs and waits on them immediately)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // epilogue: D[row = co][col = n]; col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
