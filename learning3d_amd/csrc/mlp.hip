@@ -266,7 +266,9 @@ extern "C" int l3d_edgeconv_forward(const float *xyz, const int64_t *idx, int B,
 // ---------------------------------------------------------------------------------------------
 #define PW_TM 128
 #define PW_TN 128
-#define PW_TK 16
+#ifndef PW_TK
+#define PW_TK 16       // K chunk per LDS stage (tools/probe_mlp.hip overrides it to explore)
+#endif
 #define PW_LD (128 + 4)      // LDS row stride (floats) of the k-major tiles; 16 B aligned
 
 template <bool XCL>
@@ -346,7 +348,9 @@ __global__ __launch_bounds__(256, 2) void pointwise_conv_kernel(
         __syncthreads();                 // previous chunk's MFMA reads are done
         store_chunk();
         __syncthreads();
+#ifndef PW_PROBE_NO_GLOBAL
         if (k0 + PW_TK < Cin) load_chunk(k0 + PW_TK);     // overlaps with the MFMAs below
+#endif
         // software-pipelined operand fetch: the ds_reads of k-step s+1 are in flight while the four
         // 64-cycle MFMAs of k-step s occupy the matrix pipe (otherwise each k-step exposes one LDS
         // round trip: measured 73 % MFMA-busy before, see profiles/)
@@ -390,6 +394,9 @@ __global__ __launch_bounds__(256, 2) void pointwise_conv_kernel(
                 const int n = n0 + wn * 64 + j * 32 + l31;
                 float v = acc[i][j][e] * sc + sh;
                 if (relu) v = fmaxf(v, 0.f);
+#ifdef PW_PROBE_NO_STORE
+                if (v == 123.456f)
+#endif
                 if (n < N) yb[(size_t)co * N + n] = v;
             }
         }

@@ -4,3 +4,5 @@ from .dgcnn import DGCNN
 from .pooling import Pooling
 from .classifier import Classifier
 from .pcn import PCN
+from .dcp import DCP
+from .flownet3d import FlowNet3D, PointNetSetAbstraction, FlowEmbedding, PointNetSetUpConv, PointNetFeaturePropogation

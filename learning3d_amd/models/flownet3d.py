@@ -1,0 +1,189 @@
+"""Drop-in for learning3d/models/flownet3d.py (reference: models/flownet3d.py:73-328) on MI355X.
+
+The reference needs the separately built `pointnet2_cuda` extension (and raises NameError without
+it); here the same layers run on libl3d_hip.so: FPS, gather, ball query / kNN, grouping are the HIP
+kernels of grouping.hip / knn.hip, and every Conv2d/Conv1d(k=1)+BN+ReLU stack is the fp32-MFMA GEMM
+of mlp.hip with BN folded (inference).  Parameter names match the reference."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..utils import pointnet2_utils as pointutils
+from ..utils.model_common_utils import query_ball_point
+from . import _fused
+
+
+def _mlp_stack(x, convs, bns, module):
+    """x [B,C,S,K] (or [B,C,N]) through [conv1x1 + BN + ReLU]*; fused MFMA path at inference."""
+    if len(convs) == 0:
+        return x
+    if _fused.can_fuse(module, x):
+        shp = x.shape
+        h = x.reshape(shp[0], shp[1], -1)
+        for conv, bn in zip(convs, bns):
+            w, sc, sh = _fused.fold_conv_bn(conv, bn)
+            h = _fused.pointwise_conv(h, w, sc, sh, relu=True)
+        return h.view(shp[0], h.shape[1], *shp[2:])
+    for conv, bn in zip(convs, bns):
+        x = F.relu(bn(conv(x)))
+    return x
+
+
+class PointNetSetAbstraction(nn.Module):
+    """reference :73-123.  xyz [B,3,N], points [B,D,N] -> new_xyz [B,3,S], new_points [B,D',S]."""
+
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all):
+        super().__init__()
+        self.npoint, self.radius, self.nsample, self.group_all = npoint, radius, nsample, group_all
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last_channel = in_channel + 3
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv2d(last_channel, out_channel, 1, bias=False))
+            self.mlp_bns.append(nn.BatchNorm2d(out_channel))
+            last_channel = out_channel
+        self.queryandgroup = pointutils.GroupAll() if group_all else pointutils.QueryAndGroup(radius, nsample)
+
+    def forward(self, xyz, points):
+        xyz_t = xyz.permute(0, 2, 1).contiguous()
+        if not self.group_all:
+            fps_idx = pointutils.furthest_point_sample(xyz_t, self.npoint)
+            new_xyz = pointutils.gather_operation(xyz.contiguous(), fps_idx)          # [B,3,S]
+        else:
+            new_xyz = xyz
+        new_points = self.queryandgroup(xyz_t, new_xyz.transpose(2, 1).contiguous(), points)   # [B,3+D,S,K]
+        new_points = _mlp_stack(new_points, self.mlp_convs, self.mlp_bns, self)
+        return new_xyz, torch.max(new_points, -1)[0]
+
+
+class FlowEmbedding(nn.Module):
+    """reference :125-180."""
+
+    def __init__(self, radius, nsample, in_channel, mlp, pooling='max', corr_func='concat', knn=True):
+        super().__init__()
+        self.radius, self.nsample, self.knn = radius, nsample, knn
+        self.pooling, self.corr_func = pooling, corr_func
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last_channel = in_channel * 2 + 3
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv2d(last_channel, out_channel, 1, bias=False))
+            self.mlp_bns.append(nn.BatchNorm2d(out_channel))
+            last_channel = out_channel
+
+    def forward(self, pos1, pos2, feature1, feature2):
+        pos1_t = pos1.permute(0, 2, 1).contiguous()
+        pos2_t = pos2.permute(0, 2, 1).contiguous()
+        B, N, C = pos1_t.shape
+        if self.knn:
+            _, idx = pointutils.knn(self.nsample, pos1_t, pos2_t)
+        else:
+            idx, cnt = query_ball_point(self.radius, self.nsample, pos2_t, pos1_t, get_cnt=True)
+            _, idx_knn = pointutils.knn(self.nsample, pos1_t, pos2_t)
+            cnt = cnt.view(B, -1, 1).repeat(1, 1, self.nsample)
+            idx = idx_knn[cnt > (self.nsample - 1)]
+        pos2_grouped = pointutils.grouping_operation(pos2.contiguous(), idx)           # [B,3,N,S]
+        pos_diff = pos2_grouped - pos1.view(B, -1, N, 1)
+        feat2_grouped = pointutils.grouping_operation(feature2.contiguous(), idx)
+        feat_diff = torch.cat([feat2_grouped, feature1.view(B, -1, N, 1).repeat(1, 1, 1, self.nsample)], dim=1)
+        feat1_new = torch.cat([pos_diff, feat_diff], dim=1)
+        feat1_new = _mlp_stack(feat1_new, self.mlp_convs, self.mlp_bns, self)
+        return pos1, torch.max(feat1_new, -1)[0]
+
+
+class PointNetSetUpConv(nn.Module):
+    """reference :182-242."""
+
+    def __init__(self, nsample, radius, f1_channel, f2_channel, mlp, mlp2, knn=True):
+        super().__init__()
+        self.nsample, self.radius, self.knn = nsample, radius, knn
+        self.mlp1_convs = nn.ModuleList()
+        self.mlp2_convs = nn.ModuleList()
+        last_channel = f2_channel + 3
+        for out_channel in mlp:
+            self.mlp1_convs.append(nn.Sequential(nn.Conv2d(last_channel, out_channel, 1, bias=False),
+                                                 nn.BatchNorm2d(out_channel), nn.ReLU(inplace=False)))
+            last_channel = out_channel
+        last_channel = (mlp[-1] if len(mlp) != 0 else last_channel) + f1_channel
+        for out_channel in mlp2:
+            self.mlp2_convs.append(nn.Sequential(nn.Conv1d(last_channel, out_channel, 1, bias=False),
+                                                 nn.BatchNorm1d(out_channel), nn.ReLU(inplace=False)))
+            last_channel = out_channel
+
+    def forward(self, pos1, pos2, feature1, feature2):
+        pos1_t = pos1.permute(0, 2, 1).contiguous()
+        pos2_t = pos2.permute(0, 2, 1).contiguous()
+        B, C, N = pos1.shape
+        if self.knn:
+            _, idx = pointutils.knn(self.nsample, pos1_t, pos2_t)
+        else:
+            idx = query_ball_point(self.radius, self.nsample, pos2_t, pos1_t)
+        pos2_grouped = pointutils.grouping_operation(pos2.contiguous(), idx)
+        pos_diff = pos2_grouped - pos1.view(B, -1, N, 1)
+        feat2_grouped = pointutils.grouping_operation(feature2.contiguous(), idx)
+        feat_new = torch.cat([feat2_grouped, pos_diff], dim=1)
+        feat_new = _mlp_stack(feat_new, [s[0] for s in self.mlp1_convs], [s[1] for s in self.mlp1_convs], self)
+        feat_new = feat_new.max(-1)[0]
+        if feature1 is not None:
+            feat_new = torch.cat([feat_new, feature1], dim=1)
+        return _mlp_stack(feat_new, [s[0] for s in self.mlp2_convs], [s[1] for s in self.mlp2_convs], self)
+
+
+class PointNetFeaturePropogation(nn.Module):
+    """reference :244-286 (3-NN inverse-distance interpolation + Conv1d stack)."""
+
+    def __init__(self, in_channel, mlp):
+        super().__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last_channel = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv1d(last_channel, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(out_channel))
+            last_channel = out_channel
+
+    def forward(self, pos1, pos2, feature1, feature2):
+        pos1_t = pos1.permute(0, 2, 1).contiguous()
+        pos2_t = pos2.permute(0, 2, 1).contiguous()
+        B, C, N = pos1.shape
+        dists, idx = pointutils.three_nn(pos1_t, pos2_t)
+        dists = dists.clamp_min(1e-10)
+        weight = 1.0 / dists
+        weight = weight / torch.sum(weight, -1, keepdim=True)
+        interpolated_feat = torch.sum(pointutils.grouping_operation(feature2.contiguous(), idx) * weight.view(B, 1, N, 3), dim=-1)
+        feat_new = torch.cat([interpolated_feat, feature1], 1) if feature1 is not None else interpolated_feat
+        return _mlp_stack(feat_new, self.mlp_convs, self.mlp_bns, self)
+
+
+class FlowNet3D(nn.Module):
+    """reference :289-328 (layer hyper-parameters :293-303)."""
+
+    def __init__(self):
+        super().__init__()
+        self.sa1 = PointNetSetAbstraction(npoint=1024, radius=0.5, nsample=16, in_channel=3, mlp=[32, 32, 64], group_all=False)
+        self.sa2 = PointNetSetAbstraction(npoint=256, radius=1.0, nsample=16, in_channel=64, mlp=[64, 64, 128], group_all=False)
+        self.sa3 = PointNetSetAbstraction(npoint=64, radius=2.0, nsample=8, in_channel=128, mlp=[128, 128, 256], group_all=False)
+        self.sa4 = PointNetSetAbstraction(npoint=16, radius=4.0, nsample=8, in_channel=256, mlp=[256, 256, 512], group_all=False)
+        self.fe_layer = FlowEmbedding(radius=10.0, nsample=64, in_channel=128, mlp=[128, 128, 128], pooling='max', corr_func='concat')
+        self.su1 = PointNetSetUpConv(nsample=8, radius=2.4, f1_channel=256, f2_channel=512, mlp=[], mlp2=[256, 256])
+        self.su2 = PointNetSetUpConv(nsample=8, radius=1.2, f1_channel=128 + 128, f2_channel=256, mlp=[128, 128, 256], mlp2=[256])
+        self.su3 = PointNetSetUpConv(nsample=8, radius=0.6, f1_channel=64, f2_channel=256, mlp=[128, 128, 256], mlp2=[256])
+        self.fp = PointNetFeaturePropogation(in_channel=256 + 3, mlp=[256, 256])
+        self.conv1 = nn.Conv1d(256, 128, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm1d(128)
+        self.conv2 = nn.Conv1d(128, 3, kernel_size=1, bias=True)
+
+    def forward(self, pc1, pc2, feature1, feature2):
+        l1_pc1, l1_feature1 = self.sa1(pc1, feature1)
+        l2_pc1, l2_feature1 = self.sa2(l1_pc1, l1_feature1)
+        l1_pc2, l1_feature2 = self.sa1(pc2, feature2)
+        l2_pc2, l2_feature2 = self.sa2(l1_pc2, l1_feature2)
+        _, l2_feature1_new = self.fe_layer(l2_pc1, l2_pc2, l2_feature1, l2_feature2)
+        l3_pc1, l3_feature1 = self.sa3(l2_pc1, l2_feature1_new)
+        l4_pc1, l4_feature1 = self.sa4(l3_pc1, l3_feature1)
+        l3_fnew1 = self.su1(l3_pc1, l4_pc1, l3_feature1, l4_feature1)
+        l2_fnew1 = self.su2(l2_pc1, l3_pc1, torch.cat([l2_feature1, l2_feature1_new], dim=1), l3_fnew1)
+        l1_fnew1 = self.su3(l1_pc1, l2_pc1, l1_feature1, l2_fnew1)
+        l0_fnew1 = self.fp(pc1, l1_pc1, feature1, l1_fnew1)
+        x = _mlp_stack(l0_fnew1, [self.conv1], [self.bn1], self)
+        return self.conv2(x)

@@ -1,5 +1,6 @@
 """Mirror of learning3d/utils/__init__.py:1-23 for the hot-path symbols."""
 from .svd import SVDHead, kabsch, svd3x3_rotation
+from .transformer import Transformer, Identity
 from .model_common_utils import (
     knn,
     get_graph_feature,

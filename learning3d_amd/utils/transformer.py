@@ -1,0 +1,173 @@
+"""DCP's pointer network (reference: utils/transformer.py:14-243), kept in torch (rocBLAS GEMMs):
+SURVEY.md section 2 row 9 marks the Transformer itself out of scope for hand kernels; it is here so
+that `learning3d_amd.models.DCP` is a drop-in.  Module / parameter names follow the reference so its
+checkpoints load unchanged (model.encoder.layers.0.self_attn.linears.0.weight, ... .norm.a_2, ...)."""
+import copy
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def clones(module, N):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
+
+
+def attention(query, key, value, mask=None, dropout=None):
+    d_k = query.size(-1)
+    scores = torch.matmul(query, key.transpose(-2, -1)) / math.sqrt(d_k)
+    if mask is not None:
+        scores = scores.masked_fill(mask == 0, -1e9)
+    p_attn = F.softmax(scores, dim=-1)
+    return torch.matmul(p_attn, value), p_attn
+
+
+class LayerNorm(nn.Module):
+    """reference :109-119 -- note: unbiased std and eps added to std, not nn.LayerNorm."""
+
+    def __init__(self, features, eps=1e-6):
+        super().__init__()
+        self.a_2 = nn.Parameter(torch.ones(features))
+        self.b_2 = nn.Parameter(torch.zeros(features))
+        self.eps = eps
+
+    def forward(self, x):
+        mean = x.mean(-1, keepdim=True)
+        std = x.std(-1, keepdim=True)
+        return self.a_2 * (x - mean) / (std + self.eps) + self.b_2
+
+
+class SublayerConnection(nn.Module):
+    def __init__(self, size, dropout=None):
+        super().__init__()
+        self.norm = LayerNorm(size)
+
+    def forward(self, x, sublayer):
+        return x + sublayer(self.norm(x))
+
+
+class MultiHeadedAttention(nn.Module):
+    def __init__(self, h, d_model, dropout=0.1):
+        super().__init__()
+        assert d_model % h == 0
+        self.d_k = d_model // h
+        self.h = h
+        self.linears = clones(nn.Linear(d_model, d_model), 4)
+        self.attn = None
+        self.dropout = None
+
+    def forward(self, query, key, value, mask=None):
+        if mask is not None:
+            mask = mask.unsqueeze(1)
+        nb = query.size(0)
+        q, k, v = [lin(x).view(nb, -1, self.h, self.d_k).transpose(1, 2)
+                   for lin, x in zip(self.linears, (query, key, value))]
+        x, self.attn = attention(q, k, v, mask=mask, dropout=self.dropout)
+        x = x.transpose(1, 2).contiguous().view(nb, -1, self.h * self.d_k)
+        return self.linears[-1](x)
+
+
+class PositionwiseFeedForward(nn.Module):
+    def __init__(self, d_model, d_ff, dropout=0.1):
+        super().__init__()
+        self.w_1 = nn.Linear(d_model, d_ff)
+        self.norm = nn.Sequential()
+        self.w_2 = nn.Linear(d_ff, d_model)
+        self.dropout = None
+
+    def forward(self, x):
+        return self.w_2(F.relu(self.w_1(x)))
+
+
+class EncoderLayer(nn.Module):
+    def __init__(self, size, self_attn, feed_forward, dropout):
+        super().__init__()
+        self.self_attn = self_attn
+        self.feed_forward = feed_forward
+        self.sublayer = clones(SublayerConnection(size, dropout), 2)
+        self.size = size
+
+    def forward(self, x, mask):
+        x = self.sublayer[0](x, lambda y: self.self_attn(y, y, y, mask))
+        return self.sublayer[1](x, self.feed_forward)
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, size, self_attn, src_attn, feed_forward, dropout):
+        super().__init__()
+        self.size = size
+        self.self_attn = self_attn
+        self.src_attn = src_attn
+        self.feed_forward = feed_forward
+        self.sublayer = clones(SublayerConnection(size, dropout), 3)
+
+    def forward(self, x, memory, src_mask, tgt_mask):
+        x = self.sublayer[0](x, lambda y: self.self_attn(y, y, y, tgt_mask))
+        x = self.sublayer[1](x, lambda y: self.src_attn(y, memory, memory, src_mask))
+        return self.sublayer[2](x, self.feed_forward)
+
+
+class Encoder(nn.Module):
+    def __init__(self, layer, N):
+        super().__init__()
+        self.layers = clones(layer, N)
+        self.norm = LayerNorm(layer.size)
+
+    def forward(self, x, mask):
+        for layer in self.layers:
+            x = layer(x, mask)
+        return self.norm(x)
+
+
+class Decoder(nn.Module):
+    def __init__(self, layer, N):
+        super().__init__()
+        self.layers = clones(layer, N)
+        self.norm = LayerNorm(layer.size)
+
+    def forward(self, x, memory, src_mask, tgt_mask):
+        for layer in self.layers:
+            x = layer(x, memory, src_mask, tgt_mask)
+        return self.norm(x)
+
+
+class EncoderDecoder(nn.Module):
+    def __init__(self, encoder, decoder, src_embed, tgt_embed, generator):
+        super().__init__()
+        self.encoder = encoder
+        self.decoder = decoder
+        self.src_embed = src_embed
+        self.tgt_embed = tgt_embed
+        self.generator = generator
+
+    def forward(self, src, tgt, src_mask, tgt_mask):
+        memory = self.encoder(self.src_embed(src), src_mask)
+        return self.generator(self.decoder(self.tgt_embed(tgt), memory, src_mask, tgt_mask))
+
+
+class Identity(nn.Module):
+    def forward(self, *input):
+        return input
+
+
+class Transformer(nn.Module):
+    """reference :219-243.  forward(src [B,C,N], tgt [B,C,N]) -> (src_embedding, tgt_embedding)."""
+
+    def __init__(self, emb_dims, n_blocks, dropout, ff_dims, n_heads):
+        super().__init__()
+        self.emb_dims, self.N, self.dropout = emb_dims, n_blocks, dropout
+        self.ff_dims, self.n_heads = ff_dims, n_heads
+        c = copy.deepcopy
+        attn = MultiHeadedAttention(n_heads, emb_dims)
+        ff = PositionwiseFeedForward(emb_dims, ff_dims, dropout)
+        self.model = EncoderDecoder(Encoder(EncoderLayer(emb_dims, c(attn), c(ff), dropout), n_blocks),
+                                    Decoder(DecoderLayer(emb_dims, c(attn), c(attn), c(ff), dropout), n_blocks),
+                                    nn.Sequential(), nn.Sequential(), nn.Sequential())
+
+    def forward(self, *input):
+        src = input[0].transpose(2, 1).contiguous()
+        tgt = input[1].transpose(2, 1).contiguous()
+        tgt_embedding = self.model(src, tgt, None, None).transpose(2, 1).contiguous()
+        src_embedding = self.model(tgt, src, None, None).transpose(2, 1).contiguous()
+        return src_embedding, tgt_embedding

@@ -169,6 +169,19 @@ def main():
                 r = (v @ head.reflect) @ u.t()
             Rh.append(r)
         save("svd3x3", H=Hs, R=torch.stack(Rh))
+        # ---- config 3: DCP-v2 (DGCNN embed + Transformer pointer + SVD head) ---------------
+        torch.manual_seed(5)
+        dcp = Mo.DCP(feature_model=Mo.DGCNN(emb_dims=64), cycle=False).eval()
+        for m in dcp.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.2, 0.2); m.running_var.uniform_(0.5, 1.5)
+        template = rand((2, 128, 3), 22, -0.5, 0.5)
+        source = torch.matmul(template, Rg[:2].transpose(1, 2)) + rand((2, 1, 3), 23, -0.5, 0.5)
+        out = dcp(template, source)
+        Hs_ = None
+        save("dcp_emb64", template=template, source=source, est_R=out["est_R"], est_t=out["est_t"], r=out["r"],
+             transformed_source=out["transformed_source"], est_T=out["est_T"],
+             **{"w." + k: v for k, v in dcp.state_dict().items()})
     shutil.rmtree(tmp, ignore_errors=True)
     print("done")
 

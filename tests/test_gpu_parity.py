@@ -376,3 +376,66 @@ def test_native_library_is_what_ran():
     from learning3d_amd._lib import LIB_PATH
     with open("/proc/self/maps") as f:
         assert any(LIB_PATH in line for line in f)
+
+
+# ------------------------------------------------------------------- model-level configs (3 and 5)
+def test_dcp_golden(golden):
+    """BASELINE config 3 (DCP-v2) on the reference-generated fixture: reference state_dict loads
+    unchanged; features, rotation and translation match."""
+    from learning3d_amd.models import DCP, DGCNN
+    g = golden("dcp_emb64")
+    net = _load(DCP(DGCNN(emb_dims=64)), g)
+    with torch.no_grad():
+        out = net(dev(g["template"]), dev(g["source"]))
+    np.testing.assert_allclose(out["r"].cpu().numpy(), g["r"], rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(out["est_R"].cpu().numpy(), g["est_R"], atol=1e-4)
+    np.testing.assert_allclose(out["est_t"].cpu().numpy(), g["est_t"], atol=1e-4)
+    np.testing.assert_allclose(out["est_T"].cpu().numpy(), g["est_T"], atol=1e-4)
+    np.testing.assert_allclose(out["transformed_source"].cpu().numpy(), g["transformed_source"], atol=1e-4)
+
+
+def test_flownet3d_set_abstraction_vs_oracle():
+    """BASELINE config 5's layer (sa1: npoint=1024 -> here 128, r=0.5, K=16, mlp [32,32,64]) against the
+    oracle composition FPS -> gather -> ball query -> group -> torch-CPU conv stack."""
+    from learning3d_amd.models import PointNetSetAbstraction
+    rng = np.random.default_rng(11)
+    B, N, S = 2, 1024, 128
+    xyz = np.clip(rng.standard_normal((B, 3, N)), -2, 2).astype(np.float32)
+    feat = rng.uniform(0, 1, (B, 3, N)).astype(np.float32)
+    torch.manual_seed(7)
+    sa = PointNetSetAbstraction(npoint=S, radius=0.5, nsample=16, in_channel=3, mlp=[32, 32, 64], group_all=False).eval()
+    for m in sa.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.uniform_(-0.1, 0.1); m.running_var.uniform_(0.8, 1.2)
+    # oracle composition on CPU
+    xyz_t = np.ascontiguousarray(xyz.transpose(0, 2, 1))
+    fps = oracle.furthest_point_sampling(xyz_t, S)
+    new_xyz = oracle.gather_points(xyz, fps)                                       # [B,3,S]
+    idx = oracle.ball_query(0.5, 16, xyz_t, np.ascontiguousarray(new_xyz.transpose(0, 2, 1)))
+    g_xyz = oracle.group_points(xyz, idx) - new_xyz[:, :, :, None]
+    h = torch.from_numpy(np.concatenate([g_xyz, oracle.group_points(feat, idx)], axis=1))
+    with torch.no_grad():
+        for conv, bn in zip(sa.mlp_convs, sa.mlp_bns):
+            h = torch.relu(bn(conv(h)))
+        want = h.max(-1)[0].numpy()
+        sa = sa.cuda()
+        got_xyz, got = sa(dev(xyz), dev(feat))
+    assert np.array_equal(got_xyz.cpu().numpy(), new_xyz)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
+
+
+def test_flownet3d_forward_runs():
+    from learning3d_amd.models import FlowNet3D
+    torch.manual_seed(0)
+    net = FlowNet3D().cuda().eval()
+    g = torch.Generator().manual_seed(3)
+    pc1 = torch.clamp(torch.randn((2, 3, 2048), generator=g), -2, 2).cuda()
+    pc2 = (pc1 + 0.05 * torch.randn((2, 3, 2048), generator=g).cuda()).contiguous()
+    f1 = torch.rand((2, 3, 2048), generator=g).cuda()
+    f2 = torch.rand((2, 3, 2048), generator=g).cuda()
+    with torch.no_grad():
+        sf = net(pc1, pc2, f1, f2)
+    assert sf.shape == (2, 3, 2048) and torch.isfinite(sf).all()
+    # fused (inference) and torch-conv (autograd) routes agree
+    sf2 = net(pc1, pc2, f1.clone().requires_grad_(), f2)
+    np.testing.assert_allclose(sf.cpu().numpy(), sf2.detach().cpu().numpy(), rtol=2e-3, atol=2e-4)
