@@ -182,6 +182,11 @@ int l3d_edgeconv_pack(const float *const w[4], const float *const scale[4], cons
 int l3d_edgeconv_forward(const float *xyz, const int64_t *idx, int B, int N, int k,
                          const float *packed, int c1, int c2, int c3, int c4, float *pooled,
                          l3d_stream_t stream);
+/* Same computation, same packed block, same output; a second kernel design (edgeconv2.hip) that
+ * keeps the activations in registers through all four layers (no LDS, no barriers) by chaining the
+ * MFMA accumulator layout of one layer into the B operand of the next.  k <= 20. */
+int l3d_edgeconv_forward_chained(const float *xyz, const int64_t *idx, int B, int N, int k,
+                                 const float *packed, float *pooled, l3d_stream_t stream);
 /* Per-point linear layer (Conv1d/Conv2d 1x1 + folded BN + optional ReLU):
  *   y[b][co][n] = act(scale[co] * sum_ci w[co][ci] x[b][ci][n] + shift[co])
  *   x [B,Cin,N] (x_channel_last = 0, torch Conv1d layout) or [B,N,Cin] (x_channel_last = 1),

@@ -32,19 +32,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   layer 1: Cin 6 padded to 8, KV = 2;  layers 2-4: KV = 4
 //   then the four bias (= BN shift) vectors.
 // ---------------------------------------------------------------------------------------------
-#define EC_C1 64
-#define EC_C2 64
-#define EC_C3 128
-#define EC_C4 256
-#define EC_OFF_W1 0
-#define EC_OFF_W2 (EC_OFF_W1 + 8 * EC_C1)
-#define EC_OFF_W3 (EC_OFF_W2 + EC_C1 * EC_C2)
-#define EC_OFF_W4 (EC_OFF_W3 + EC_C2 * EC_C3)
-#define EC_OFF_B1 (EC_OFF_W4 + EC_C3 * EC_C4)
-#define EC_OFF_B2 (EC_OFF_B1 + EC_C1)
-#define EC_OFF_B3 (EC_OFF_B2 + EC_C2)
-#define EC_OFF_B4 (EC_OFF_B3 + EC_C3)
-#define EC_PACKED_FLOATS (EC_OFF_B4 + EC_C4)
+#include "edgeconv_layout.h"
 
 extern "C" size_t l3d_edgeconv_packed_floats(int c1, int c2, int c3, int c4)
 {
@@ -82,6 +70,37 @@ extern "C" int l3d_edgeconv_pack(const float *const w[4], const float *const sca
     const int off[4] = {EC_OFF_B1, EC_OFF_B2, EC_OFF_B3, EC_OFF_B4};
     for (int l = 0; l < 4; l++)
         for (int c = 0; c < cs[l]; c++) packed[off[l] + c] = (shift && shift[l]) ? shift[l][c] : 0.f;
+    // second copy of the weights in the layout of the register-chained kernel (edgeconv2.hip):
+    //   layer 1: [m][lane][2]    = W'[16m + (lane&15)][4s + (lane>>4)],            s = 0,1 (Cin 6 -> 8)
+    //   layer L: [m][q][lane][4] = W'[16m + (lane&15)][16q + 4(lane>>4) + e],      e = 0..3
+    const int cin[4] = {6, EC_C1, EC_C2, EC_C3};
+    const int o2[4] = {EC2_OFF_W1, EC2_OFF_W2, EC2_OFF_W3, EC2_OFF_W4};
+    for (int l = 0; l < 4; l++) {
+        const float *wl = w[l];
+        const float *sc = scale ? scale[l] : nullptr;
+        float *dst = packed + o2[l];
+        for (int m = 0; m < cs[l] / 16; m++) {
+            if (l == 0) {
+                for (int lane = 0; lane < 64; lane++)
+                    for (int sidx = 0; sidx < 2; sidx++) {
+                        const int oc = 16 * m + (lane & 15), ic = 4 * sidx + (lane >> 4);
+                        float v = ic < 6 ? wl[(size_t)oc * 6 + ic] : 0.f;
+                        if (sc) v *= sc[oc];
+                        dst[(m * 64 + lane) * 2 + sidx] = v;
+                    }
+            } else {
+                const int nq = cin[l] / 16;
+                for (int q = 0; q < nq; q++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int e = 0; e < 4; e++) {
+                            const int oc = 16 * m + (lane & 15), ic = 16 * q + 4 * (lane >> 4) + e;
+                            float v = wl[(size_t)oc * cin[l] + ic];
+                            if (sc) v *= sc[oc];
+                            dst[(((size_t)m * nq + q) * 64 + lane) * 4 + e] = v;
+                        }
+            }
+        }
+    }
     return L3D_OK;
 }
 
@@ -172,7 +191,7 @@ __device__ __forceinline__ void ec_layer_epilogue(f32x4 (&acc)[MT][NT],
 }
 
 template <int MT>
-__global__ __launch_bounds__(256, MT <= 5 ? 3 : 1) void edgeconv_kernel(const float *__restrict__ xyz,
+__global__ __launch_bounds__(256, MT <= 5 ? 3 : 1) __attribute__((aligned(1024))) void edgeconv_kernel(const float *__restrict__ xyz,
                                                           const int64_t *__restrict__ idx, int N,
                                                           int k, const float *__restrict__ packed,
                                                           float *__restrict__ pooled /*[B*N][512]*/)
@@ -272,7 +291,7 @@ extern "C" int l3d_edgeconv_forward(const float *xyz, const int64_t *idx, int B,
 #define PW_LD (128 + 4)      // LDS row stride (floats) of the k-major tiles; 16 B aligned
 
 template <bool XCL>
-__global__ __launch_bounds__(256, 2) void pointwise_conv_kernel(
+__global__ __launch_bounds__(256, 2) __attribute__((aligned(1024))) void pointwise_conv_kernel(
     const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ scale,
     const float *__restrict__ shift, int shift_bstride, int Cin, int Cout, int N, int relu,
     float *__restrict__ y)

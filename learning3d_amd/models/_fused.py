@@ -142,12 +142,21 @@ class EdgeConvParams:
         return self.packed
 
 
-def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256)):
+EDGECONV_CHAINED = True     # register-chained kernel (edgeconv2.hip) for k <= 20; LDS kernel otherwise
+
+
+def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256), chained=None):
     """xyz [B,N,3], idx int64 [B,N,k] -> pooled [B,N,sum(widths)] (channel-last)."""
     require_gpu(xyz_bn3, idx, packed)
     B, N, _ = xyz_bn3.shape
     k = idx.shape[2]
     pooled = torch.empty((B, N, sum(widths)), dtype=torch.float32, device=xyz_bn3.device)
-    check(lib().l3d_edgeconv_forward(ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), *widths, ptr(pooled),
-                                     stream_ptr()), "l3d_edgeconv_forward")
+    if chained is None:
+        chained = EDGECONV_CHAINED
+    if chained and k <= 20 and tuple(widths) == (64, 64, 128, 256):
+        check(lib().l3d_edgeconv_forward_chained(ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), ptr(pooled),
+                                                 stream_ptr()), "l3d_edgeconv_forward_chained")
+    else:
+        check(lib().l3d_edgeconv_forward(ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), *widths, ptr(pooled),
+                                         stream_ptr()), "l3d_edgeconv_forward")
     return pooled

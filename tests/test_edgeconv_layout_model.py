@@ -72,7 +72,7 @@ def test_edgeconv_fragment_layout_and_row_mapping():
     scs = [rng.uniform(0.5, 1.5, c).astype(np.float32) for c in (C1, C2, C3, C4)]
     shs = [rng.uniform(-0.2, 0.2, c).astype(np.float32) for c in (C1, C2, C3, C4)]
     n = lib.l3d_edgeconv_packed_floats(C1, C2, C3, C4)
-    assert n == 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4 + C1 + C2 + C3 + C4
+    assert n == 2 * (8 * C1 + C1 * C2 + C2 * C3 + C3 * C4) + C1 + C2 + C3 + C4     # v1 + chained layouts + biases
     packed = np.zeros(n, np.float32)
     arr = lambda xs: (C.c_void_p * 4)(*[x.ctypes.data for x in xs])
     assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), C1, C2, C3, C4, packed.ctypes.data) == 0
@@ -112,3 +112,105 @@ def test_edgeconv_fragment_layout_and_row_mapping():
         want.append(np.concatenate(outs))
     want = np.stack(want)
     np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6)
+
+
+def test_edgeconv_chained_register_layout():
+    """CPU model of edgeconv2_kernel (edgeconv2.hip): weights are the MFMA A operand, activations the
+    B operand taken DIRECTLY from the previous layer's accumulator registers; checks the k-order
+    permutation (k-step (q,e), lane group g <-> channel 16q+4g+e), the second packed weight copy,
+    the row <-> (point, neighbour) map and the quad max."""
+    lib = _lib.lib()
+    rng = np.random.default_rng(1)
+    ws = [rng.standard_normal((C1, 6)).astype(np.float32), rng.standard_normal((C2, C1)).astype(np.float32) * 0.2,
+          rng.standard_normal((C3, C2)).astype(np.float32) * 0.2, rng.standard_normal((C4, C3)).astype(np.float32) * 0.1]
+    scs = [rng.uniform(0.5, 1.5, c).astype(np.float32) for c in (C1, C2, C3, C4)]
+    shs = [rng.uniform(-0.2, 0.2, c).astype(np.float32) for c in (C1, C2, C3, C4)]
+    n = lib.l3d_edgeconv_packed_floats(C1, C2, C3, C4)
+    v1 = 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4 + C1 + C2 + C3 + C4
+    assert n == v1 + 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4
+    packed = np.zeros(n, np.float32)
+    arr = lambda xs: (C.c_void_p * 4)(*[x.ctypes.data for x in xs])
+    assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), C1, C2, C3, C4, packed.ctypes.data) == 0
+    pk = packed.astype(np.float64)
+    o_b = [8 * C1 + C1 * C2 + C2 * C3 + C3 * C4]
+    o_b += [o_b[0] + C1, o_b[0] + C1 + C2, o_b[0] + C1 + C2 + C3]
+    o2 = [v1, v1 + 8 * C1, v1 + 8 * C1 + C1 * C2, v1 + 8 * C1 + C1 * C2 + C2 * C3]
+
+    N, k = 16, 20
+    xyz = rng.uniform(0, 1, (N, 3)).astype(np.float32)
+    idx = rng.integers(0, N, (N, k))
+    n0 = 8                                          # this wave's 4 points
+    lanes = np.arange(64)
+    j, g = lanes & 15, lanes >> 4
+
+    def mfma(a, b, acc):                            # A[i][k]=a[16k+i] (weights), B[k][j]=b[16k+j] (acts)
+        A = a.reshape(4, 16).T
+        Bm = b.reshape(4, 16)
+        D = A @ Bm                                  # [i=out ch in tile][j=row in tile]
+        out = acc.copy()
+        for i in range(16):
+            for jj in range(16):
+                out[16 * (i // 4) + jj, i % 4] += D[i, jj]
+        return out
+
+    # layer-1 B operands
+    b1 = np.zeros((MT, 2, 64))
+    for t in range(MT):
+        for l in range(64):
+            p, nbr = n0 + (j[l] >> 2), 4 * t + (j[l] & 3)
+            f = np.concatenate([xyz[idx[p, nbr]], xyz[p], [0, 0]])
+            b1[t, 0, l] = f[g[l]]
+            b1[t, 1, l] = f[4 + g[l]]
+    def bias_init(off, m):
+        acc = np.zeros((64, 4))
+        for r in range(4):
+            acc[:, r] = pk[off + 16 * m + 4 * g + r]
+        return acc
+    pooled = {}
+    def pool(h_m, choff, m):                       # h_m: [MT][64,4] after relu
+        mx = np.max(np.stack(h_m), axis=0)         # over row tiles
+        for l in range(64):
+            q0 = l & ~3
+            val = mx[q0:q0 + 4].max(axis=0)        # quad max
+            p = n0 + (j[l] >> 2)
+            for r in range(4):
+                pooled[(p, choff + 16 * m + 4 * g[l] + r)] = val[r]
+    # layer 1
+    h = []
+    w1 = pk[o2[0]:o2[0] + 8 * C1].reshape(C1 // 16, 64, 2)
+    for m in range(C1 // 16):
+        row = []
+        for t in range(MT):
+            acc = bias_init(o_b[0], m)
+            for s in range(2):
+                acc = mfma(w1[m, :, s], b1[t, s], acc)
+            row.append(np.maximum(acc, 0))
+        pool(row, 0, m)
+        h.append(row)
+    choff = C1
+    for li, (cin, cout) in enumerate([(C1, C2), (C2, C3), (C3, C4)], start=1):
+        nq = cin // 16
+        wl = pk[o2[li]:o2[li] + cin * cout].reshape(cout // 16, nq, 64, 4)
+        hn = []
+        for m in range(cout // 16):
+            row = []
+            for t in range(MT):
+                acc = bias_init(o_b[li], m)
+                for q in range(nq):
+                    for e in range(4):
+                        acc = mfma(wl[m, q, :, e], h[q][t][:, e], acc)
+                row.append(np.maximum(acc, 0))
+            pool(row, choff, m)
+            hn.append(row)
+        h = hn
+        choff += cout
+    got = np.array([[pooled[(n0 + p, c)] for c in range(C1 + C2 + C3 + C4)] for p in range(4)])
+    want = []
+    for p in range(4):
+        f = np.concatenate([xyz[idx[n0 + p]], np.repeat(xyz[n0 + p][None], k, 0)], axis=1).astype(np.float64)
+        outs, hh = [], f
+        for w, sc, sh in zip(ws, scs, shs):
+            hh = np.maximum((hh @ (w.astype(np.float64) * sc[:, None].astype(np.float64)).T) + sh, 0.0)
+            outs.append(hh.max(axis=0))
+        want.append(np.concatenate(outs))
+    np.testing.assert_allclose(got, np.stack(want), rtol=1e-6, atol=1e-6)

@@ -320,6 +320,36 @@ def test_dgcnn_full_size_vs_oracle_port():
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
 
 
+def test_edgeconv_both_kernels_agree_and_ragged():
+    """LDS-staged (mlp.hip) and register-chained (edgeconv2.hip) EdgeConv kernels against a torch fp64
+    evaluation, including N not a multiple of 16 and k < 20."""
+    from learning3d_amd.models import DGCNN, _fused
+    import learning3d_amd.utils as U
+    torch.manual_seed(4)
+    net = DGCNN(emb_dims=64).cuda().eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.uniform_(-0.1, 0.1); m.running_var.uniform_(0.8, 1.2)
+    for (B, N, k) in [(2, 1024, 20), (3, 203, 20), (2, 77, 16), (1, 50, 7)]:
+        x = dev(rand((B, N, 3), 30 + N))
+        with torch.no_grad():
+            idx = U.knn(x.permute(0, 2, 1), k)
+            packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
+            a = _fused.edgeconv_forward(x, idx, packed, chained=False)
+            c = _fused.edgeconv_forward(x, idx, packed, chained=True)
+            # fp64 torch evaluation of dgcnn.py:32-46 on the same graph
+            nb = torch.gather(x.unsqueeze(1).expand(B, N, N, 3), 2, idx.unsqueeze(-1).expand(B, N, k, 3))
+            h = torch.cat([nb, x.unsqueeze(2).expand(B, N, k, 3)], dim=3).permute(0, 3, 1, 2).double()
+            outs = []
+            for conv, bn in [(net.conv1, net.bn1), (net.conv2, net.bn2), (net.conv3, net.bn3), (net.conv4, net.bn4)]:
+                w, sc, sh = _fused.fold_conv_bn(conv, bn)
+                h = torch.relu(torch.einsum("oc,bcnk->bonk", w.double(), h) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+                outs.append(h.max(dim=-1)[0])
+            want = torch.cat(outs, dim=1).permute(0, 2, 1).float().cpu().numpy()
+        np.testing.assert_allclose(a.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(c.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
+
+
 def test_pointnet_golden(golden):
     from learning3d_amd.models import PointNet
     g = golden("pointnet_emb64")

@@ -47,8 +47,10 @@ def main():
         net = DGCNN(emb_dims=1024).to(dev).eval()
         idx = U.knn(xt, k)
         packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
-        t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed))
-        res["edgeconv_c2"] = (t, B * N * k * 2 * 45440 / t / 1e6, "TFLOP/s")
+        t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, chained=False))
+        res["edgeconv_lds_c2"] = (t, B * N * k * 2 * 45440 / t / 1e6, "TFLOP/s")
+        t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, chained=True))
+        res["edgeconv_chained_c2"] = (t, B * N * k * 2 * 45440 / t / 1e6, "TFLOP/s")
         pooled = _fused.edgeconv_forward(x, idx, packed)
         w5, s5, b5 = net._conv5_folded()
         t = timeit(lambda: _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True))

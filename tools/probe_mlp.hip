@@ -1,7 +1,9 @@
 // Stand-alone timing probe for the two MFMA kernels of mlp.hip (not part of the product).
 // Build variants with -DPW_TK=32, -DPW_PROBE_NO_STORE, -DPW_PROBE_NO_GLOBAL ... and compare.
 #include "../learning3d_amd/csrc/mlp.hip"
+#include "../learning3d_amd/csrc/edgeconv2.hip"
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 thread_local int g_l3d_last_hip_error = 0;
 int main(int argc, char **argv)
@@ -13,7 +15,8 @@ int main(int argc, char **argv)
     hipMalloc(&xyz, 4 * B * N * 3); hipMalloc(&idx, 8 * B * N * K); hipMalloc(&packed, 4 * EC_PACKED_FLOATS);
     hipMalloc(&pooled, 4 * (size_t)B * N * 512);
     std::vector<float> h((size_t)B * N * CIN);
-    for (size_t i = 0; i < h.size(); i++) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
+    const bool zero = getenv("ZERO") != nullptr;
+    for (size_t i = 0; i < h.size(); i++) h[i] = zero ? 0.f : (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
     hipMemcpy(x, h.data(), 4 * h.size(), hipMemcpyHostToDevice);
     hipMemcpy(w, h.data(), 4 * COUT * CIN, hipMemcpyHostToDevice);
     hipMemcpy(sc, h.data(), 4 * COUT, hipMemcpyHostToDevice); hipMemcpy(sh, h.data(), 4 * COUT, hipMemcpyHostToDevice);
@@ -23,19 +26,21 @@ int main(int argc, char **argv)
     for (size_t i = 0; i < hi.size(); i++) hi[i] = (i * 40503u) % N;
     hipMemcpy(idx, hi.data(), 8 * hi.size(), hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int which = 0; which < 2; which++) {
+    for (int which = 0; which < 3; which++) {
         auto run = [&]() {
             if (which == 0) l3d_pointwise_conv(x, 1, w, sc, sh, 0, B, CIN, COUT, N, 1, y, nullptr);
-            else l3d_edgeconv_forward(xyz, idx, B, N, K, packed, 64, 64, 128, 256, pooled, nullptr);
+            else if (which == 1) l3d_edgeconv_forward(xyz, idx, B, N, K, packed, 64, 64, 128, 256, pooled, nullptr);
+            else l3d_edgeconv_forward_chained(xyz, idx, B, N, K, packed, pooled, nullptr);
         };
         for (int i = 0; i < 5; i++) run();
         hipDeviceSynchronize();
+        const int reps = getenv("REPS") ? atoi(getenv("REPS")) : 20;
         hipEventRecord(e0);
-        for (int i = 0; i < 20; i++) run();
+        for (int i = 0; i < reps; i++) run();
         hipEventRecord(e1); hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 20;
+        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
         const double flop = which == 0 ? 2.0 * B * N * CIN * COUT : 2.0 * B * N * K * 45440.0;
-        printf("%s %s: %.1f us  %.1f TFLOP/s\n", argv[0], which == 0 ? "conv5" : "edgeconv", ms * 1e3, flop / ms / 1e9);
+        printf("%s %s: %.1f us  %.1f TFLOP/s\n", argv[0], which == 0 ? "conv5" : which == 1 ? "edgeconv" : "edgeconv_chained", ms * 1e3, flop / ms / 1e9);
     }
     return 0;
 }
