@@ -36,6 +36,18 @@ EDGECONV_FLOP_PER_CLOUD = NPTS * KNN * 2 * (6 * 64 + 64 * 64 + 64 * 128 + 128 * 
 CONV5_FLOP_PER_CLOUD = NPTS * 2 * 512 * EMB
 
 
+def pmc_traffic(tag):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/round1_traffic.json,
+    produced by tools/pmc.sh on the GPU box: FETCH_SIZE doubled per the guide's gfx950 correction for
+    wide coalesced reads, + WRITE_SIZE, both KB -> bytes).  bench.py cannot run rocprofv3 on itself,
+    so this is the measured figure of the same kernel at the same shapes; None if not collected."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_traffic.json")) as f:
+            return json.load(f).get(tag, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(sample_clouds=8, repeats=2):
     """The oracle port of the reference's CPU path (torch CPU ops for the conv stack exactly as
     models/dgcnn.py does them, C restatement of knn / nnsearch), timed on this box's host cores."""
@@ -170,13 +182,14 @@ def main():
                        "global_batch": world * B_PER_GPU, "num_points": NPTS, "k": KNN, "emb_dims": EMB,
                        "parallelism": f"batch-sharded x{world}, all_gather of loss partials only"},
             # dominant kernel by time: the fused 4-layer EdgeConv stack on fp32 MFMA
-            "roofline": {"kernel": "edgeconv_kernel<5>", "bound": "mfma", "achieved": ec_tf,
+            "roofline": {"kernel": "edgeconv2_kernel<5>", "bound": "mfma", "achieved": ec_tf,
                          "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ec_tf / MFMA_F32_PEAK_TF,
-                         "traffic": None, "avg_launch_ms": stage_ms["edgeconv"],
+                         "traffic": pmc_traffic("edgeconv"), "avg_launch_ms": stage_ms["edgeconv"],
                          "algorithmic_flop_per_launch": B_PER_GPU * EDGECONV_FLOP_PER_CLOUD},
             # the metric's second half: kNN (and Chamfer) HBM rate on ALGORITHMIC bytes
             "roofline_knn": {"kernel": "topk_scan_kernel<20,expanded>", "bound": "hbm", "achieved": knn_gbs,
-                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": knn_gbs / HBM_PEAK_GBS, "traffic": None,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": knn_gbs / HBM_PEAK_GBS,
+                             "traffic": pmc_traffic("knn"),
                              "avg_launch_ms": stage_ms["knn"],
                              "algorithmic_bytes_per_launch": B_PER_GPU * KNN_BYTES_PER_CLOUD,
                              "note": "VALU-bound by construction (33.5 M pair evaluations per 5.6 MB), see DESIGN.md"},

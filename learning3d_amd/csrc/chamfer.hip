@@ -238,7 +238,12 @@ __global__ __launch_bounds__(1024) void sqrt_sum_kernel(const float *__restrict_
     const float *d = which == 0 ? d1 : d2;
     const size_t n = which == 0 ? n1 : n2;
     double acc = 0.0;
-    for (size_t i = threadIdx.x; i < n; i += blockDim.x) acc += (double)sqrtf(d[i]);
+    const size_t n4 = n >> 2;                          // 16-byte loads, 4 independent sqrt per trip
+    for (size_t i = threadIdx.x; i < n4; i += blockDim.x) {
+        const float4 v = ((const float4 *)d)[i];
+        acc += ((double)sqrtf(v.x) + (double)sqrtf(v.y)) + ((double)sqrtf(v.z) + (double)sqrtf(v.w));
+    }
+    for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) acc += (double)sqrtf(d[i]);
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();

@@ -191,7 +191,7 @@ __device__ __forceinline__ void ec_layer_epilogue(f32x4 (&acc)[MT][NT],
 }
 
 template <int MT>
-__global__ __launch_bounds__(256, MT <= 5 ? 3 : 1) __attribute__((aligned(1024))) void edgeconv_kernel(const float *__restrict__ xyz,
+__global__ __launch_bounds__(256, MT <= 5 ? 3 : 1) void edgeconv_kernel(const float *__restrict__ xyz,
                                                           const int64_t *__restrict__ idx, int N,
                                                           int k, const float *__restrict__ packed,
                                                           float *__restrict__ pooled /*[B*N][512]*/)
@@ -291,7 +291,7 @@ extern "C" int l3d_edgeconv_forward(const float *xyz, const int64_t *idx, int B,
 #define PW_LD (128 + 4)      // LDS row stride (floats) of the k-major tiles; 16 B aligned
 
 template <bool XCL>
-__global__ __launch_bounds__(256, 2) __attribute__((aligned(1024))) void pointwise_conv_kernel(
+__global__ __launch_bounds__(256, 2) void pointwise_conv_kernel(
     const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ scale,
     const float *__restrict__ shift, int shift_bstride, int Cin, int Cout, int N, int relu,
     float *__restrict__ y)

@@ -25,4 +25,4 @@ PY
   fi
 done
 rm -rf $R/gpurun_out/pmc_tmp
-cat $R/gpurun_out/pmc_${TAG}_*.txt
+cat $R/gpurun_out/pmc_${TAG}_*.txt > $R/gpurun_out/pmc_${TAG}.txt; cat $R/gpurun_out/pmc_${TAG}.txt
