@@ -163,9 +163,11 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
     int out_mode, void *__restrict__ idx_out, float *__restrict__ val_out)
 {
     // per-wave LDS: a candidate tile and one scratch area that is the pass-1 key queue
-    // ([QCAP][64]), then the pass-2 collection (akey | aidx | bidx, [K][64] each), then the merge
-    // mailbox (akey | aidx).  19 KiB per wave at K=20 -> two 4-wave workgroups per CU.
-    constexpr int SCR = (3 * K > QCAP ? 3 * K : QCAP) * 64;
+    // ([QCAP][64]), the value-merge mailbox ([K][64]), then the pass-2 collection (akey | aidx | bidx,
+    // [K+1][64] each).  20 KiB per wave at K=20 -> two 4-wave workgroups per CU.
+    constexpr int KR = K + 1;                          // list rows: K entries + one dummy row the branch-free
+                                                       // append may scribble on when a list is full
+    constexpr int SCR = (2 * K + KR > QCAP ? 2 * K + KR : QCAP) * 64;   // A lists never fill (< K keys beat the K-th best)
     __shared__ float4 cand[W][T2];
     __shared__ float scratch[W][SCR];
 
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
     float *qkey = scratch[wave];                       // [QCAP][64]
     float *akey = scratch[wave];                       // [K][64]
     int *aidx = (int *)scratch[wave] + K * 64;         // [K][64]
-    int *bidx = (int *)scratch[wave] + 2 * K * 64;     // [K][64]
+    int *bidx = (int *)scratch[wave] + 2 * K * 64;     // [KR][64]
 
     const int per = (Nc + W - 1) / W;                 // slice length (uniform)
     const int lo = wave * per, hi = min(Nc, lo + per);
@@ -210,6 +212,12 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
         __syncthreads();
     };
 
+#ifdef KNN_TIMING
+#define KT(i) if (lane == 0) ((long long *)val_out)[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * W + wave) * 8 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define KT(i)
+#endif
+    KT(0)
     // ------------------------------------------------------------------ pass 1: K-th best key
     float thrF;
     {
@@ -240,9 +248,15 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
                 for (int u = 0; u < CHUNK; u++) c[u] = cand[wave][t + u];
 #pragma unroll
                 for (int u = 0; u < CHUNK; u++) key[u] = eval(c[u]);
+                // branch-free append: store unconditionally at the queue head, advance it only when the
+                // candidate beats the threshold (a rejected key is simply overwritten by the next one).
+                // Measured with s_memtime: the exec-mask branch per candidate made this loop cost
+                // ~240 cycles per candidate; the head never exceeds QCAP-1 inside a chunk (<= 8 + 7).
 #pragma unroll
-                for (int u = 0; u < CHUNK; u++)
-                    if (key[u] > thr) { qkey[cnt * 64 + lane] = key[u]; cnt++; }
+                for (int u = 0; u < CHUNK; u++) {
+                    qkey[cnt * 64 + lane] = key[u];
+                    cnt += key[u] > thr ? 1 : 0;
+                }
             }
             for (; t < tn; t++) {
                 if (__any(cnt >= QCAP)) flushv();
@@ -251,10 +265,41 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
             }
         }
         flushv();
-        thrF = tv.worst();
+        KT(1)
+        // ---- global K-th best key: tree-merge the W value lists (one v_med3 per slot and entry),
+        //      then wave 0 broadcasts its K-th value.  With the GLOBAL threshold pass 2 collects only
+        //      the ~K winners (plus exact ties) over all slices, and the expensive (value, index)
+        //      network runs once, on wave 0, instead of once per slice plus once per merge.
+        float *mail = scratch[wave];
+#pragma unroll 1
+        for (int step = 1; step < W; step <<= 1) {
+            const bool sender = (wave & (2 * step - 1)) == step;
+            const bool receiver = (wave & (2 * step - 1)) == 0 && wave + step < W;
+            __syncthreads();
+            if (sender) {
+#pragma unroll
+                for (int i = 0; i < K; i++) mail[i * 64 + lane] = tv.v[i];
+            }
+            __syncthreads();
+            if (receiver) {
+                const float *mk = scratch[wave + step];
+#pragma unroll 1
+                for (int i = 0; i < K; i++) {
+                    const float kv = mk[i * 64 + lane];
+                    if (!__any(kv > tv.worst())) break;      // sorted: nothing further can enter
+                    tv.insert(kv);
+                }
+            }
+        }
+        __syncthreads();
+        if (wave == 0) scratch[0][lane] = tv.worst();
+        __syncthreads();
+        thrF = scratch[0][lane];
+        __syncthreads();                                     // everyone has read it before scratch is reused
     }
 
-    // -------------------------------------------- pass 2: collect (key > thrF) and first K (key == thrF)
+    KT(2)
+    // ------------------ pass 2: collect (key > thrF) and the first K (key == thrF), thrF GLOBAL now
     int cntA = 0, cntB = 0;
     for (int tile = 0; tile < ntiles; tile++) {
         const int c0 = lo + tile * T2;
@@ -268,13 +313,16 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
             for (int u = 0; u < CHUNK; u++) c[u] = cand[wave][t + u];
 #pragma unroll
             for (int u = 0; u < CHUNK; u++) key[u] = eval(c[u]);
+            // branch-free collection (same reasoning as pass 1): write at the clamped list heads,
+            // advance a head only on a hit and only while the list has room
 #pragma unroll
             for (int u = 0; u < CHUNK; u++) {
-                if (key[u] > thrF) {
-                    if (cntA < K) { akey[cntA * 64 + lane] = key[u]; aidx[cntA * 64 + lane] = c0 + t + u; cntA++; }
-                } else if (key[u] == thrF) {
-                    if (cntB < K) { bidx[cntB * 64 + lane] = c0 + t + u; cntB++; }
-                }
+                const int pa = min(cntA, K - 1), pb = min(cntB, K);   // A never fills; B's row K is the dummy row
+                akey[pa * 64 + lane] = key[u];
+                aidx[pa * 64 + lane] = c0 + t + u;
+                bidx[pb * 64 + lane] = c0 + t + u;
+                cntA += (key[u] > thrF && cntA < K) ? 1 : 0;
+                cntB += (key[u] == thrF && cntB < K) ? 1 : 0;
             }
         }
         for (; t < tn; t++) {
@@ -287,47 +335,47 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
         }
     }
 
-    // ------------------------------------------------ full (value, index) list of this wave's slice
+    KT(3)
+    // ---------------- wave 0 builds the (value, index) list from every slice's collected entries,
+    // slices in index order, entries in index order within a slice: strict '>' insertion therefore
+    // keeps lowest-index-first under exact ties.
+    __shared__ int cnts[W][2][64];
+    cnts[wave][0][lane] = cntA;
+    cnts[wave][1][lane] = cntB;
+    __syncthreads();
     TopK<K> top;
     top.init();
-#pragma unroll 1
-    for (int s = 0; s < K; s++) {
-        const bool has = s < cntA;
-        if (!__any(has)) break;
-        top.insert(has ? akey[s * 64 + lane] : -INFINITY, aidx[s * 64 + lane]);
-    }
-#pragma unroll 1
-    for (int s = 0; s < K; s++) {
-        const bool has = s < cntB;
-        if (!__any(has)) break;
-        top.insert(has ? thrF : -INFINITY, bidx[s * 64 + lane]);
-    }
-
-    // ------------------------------------- tree-merge the W sorted lists: (1->0, 3->2), then (2->0)
-    // a sender's slice always FOLLOWS the receiver's in index order, so strict '>' insertion keeps
-    // lowest-index-first under ties.
-#pragma unroll 1
-    for (int step = 1; step < W; step <<= 1) {
-        const bool sender = (wave & (2 * step - 1)) == step;
-        const bool receiver = (wave & (2 * step - 1)) == 0 && wave + step < W;
-        __syncthreads();
-        if (sender) {
+    if (wave == 0) {
+        // walk each lane's entries as ONE list (slice 0's, then slice 1's, ...): the trip count is the
+        // busiest lane's TOTAL (about K), not the sum over slices of the busiest lane per slice
 #pragma unroll
-            for (int i = 0; i < K; i++) { akey[i * 64 + lane] = top.v[i]; aidx[i * 64 + lane] = top.id[i]; }
-        }
-        __syncthreads();
-        if (receiver) {
-            const float *mk = scratch[wave + step];
-            const int *mi = (const int *)scratch[wave + step] + K * 64;
+        for (int which = 0; which < 2; which++) {            // 0: keys > thrF (akey/aidx), 1: keys == thrF (bidx)
+            int tot = 0;
+#pragma unroll
+            for (int w = 0; w < W; w++) tot += cnts[w][which][lane];
+            int w_cur = 0, s_cur = 0, rem = cnts[0][which][lane];
 #pragma unroll 1
-            for (int i = 0; i < K; i++) {
-                const float kv = mk[i * 64 + lane];
-                if (!__any(kv > top.worst())) break;          // sorted: nothing further can enter
-                top.insert(kv, mi[i * 64 + lane]);
+            for (int it = 0; it < 2 * K; it++) {
+                const bool has = it < tot;
+                if (!__any(has)) break;
+#pragma unroll
+                for (int hop = 1; hop < W; hop++) {           // skip exhausted / empty slices
+                    const bool adv = rem == 0 && w_cur < W - 1;
+                    w_cur += adv ? 1 : 0;
+                    s_cur = adv ? 0 : s_cur;
+                    rem = adv ? cnts[w_cur][which][lane] : rem;
+                }
+                const float *ak = scratch[0] + (size_t)w_cur * SCR;
+                const int *ai = (const int *)ak + (which == 0 ? K * 64 : 2 * K * 64);
+                const float key = which == 0 ? ak[s_cur * 64 + lane] : thrF;
+                top.insert(has ? key : -INFINITY, ai[s_cur * 64 + lane]);
+                s_cur++;
+                rem--;
             }
         }
     }
 
+    KT(4)
     if (wave != 0 || !valid) return;
     const size_t o = ((size_t)b * Nq + q) * k;
     if (out_mode == OUT_KNN_GRAPH) {

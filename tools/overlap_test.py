@@ -1,0 +1,36 @@
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from learning3d_amd.models import DGCNN
+from learning3d_amd.losses.chamfer_distance import ChamferDistance, chamfer_partials, chamfer_combine
+dev = "cuda"
+g = torch.Generator().manual_seed(0)
+x = torch.rand((32, 1024, 3), generator=g).to(dev); a = torch.rand((32, 1024, 3), generator=g).to(dev); b = torch.rand((32, 1024, 3), generator=g).to(dev)
+net = DGCNN(emb_dims=1024).to(dev).eval(); cd = ChamferDistance()
+def dg():
+    with torch.no_grad(): return net(x)
+def ch():
+    with torch.no_grad():
+        d1, d2 = cd(a, b); return chamfer_combine(chamfer_partials(d1, d2))
+def run(mode, steps=60):
+    S = [torch.cuda.Stream() for _ in range(4)]
+    cur = torch.cuda.current_stream()
+    for s in S: s.wait_stream(cur)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    keep = []
+    for i in range(steps):
+        if mode == "seq":
+            f = dg(); l = ch()
+        elif mode == "branch":          # DGCNN on S0, Chamfer on S1 (within a step)
+            with torch.cuda.stream(S[0]): f = dg()
+            with torch.cuda.stream(S[1]): l = ch()
+        elif mode == "pipe2":           # alternate whole steps on two streams
+            with torch.cuda.stream(S[i % 2]): f = dg(); l = ch()
+        elif mode == "pipe4":           # both
+            with torch.cuda.stream(S[i % 2]): f = dg()
+            with torch.cuda.stream(S[2 + i % 2]): l = ch()
+        keep = [f, l]
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"{mode:8s} {dt / steps * 1e3:.3f} ms/step  {32 * steps / dt:.0f} clouds/s")
+for m in ("seq", "branch", "pipe2", "pipe4", "seq"):
+    run(m, 10); run(m)
