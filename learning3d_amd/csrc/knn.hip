@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64) void topk_scan_kernel(
 // queries (all SIMDs busy at B=32, N=1024; ties still resolve to the lower index because slice
 // w's indices all precede slice w+1's), and wave 0 merges the W sorted lists through LDS.
 // ---------------------------------------------------------------------------------------------
-#define T2 256          // candidates per per-wave LDS tile (4 KiB)
+#define T2 256          // candidates per per-wave LDS tile (4 KiB); multiple of 32
 
 template <int K, int METRIC, int W>
 __global__ __launch_bounds__(64 * W) void topk2_kernel(
@@ -202,12 +202,18 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
     };
     auto stage = [&](int c0, int tn) {
         __syncthreads();
-        for (int t = lane; t < tn; t += 64) {
-            const float *cp = cbase + (size_t)(c0 + t) * 3;
-            float x = cp[0], y = cp[1], z = cp[2];
-            float w = 0.f;
-            if (METRIC == METRIC_EXPANDED) w = -((x * x + y * y) + z * z);
-            cand[wave][t] = make_float4(x, y, z, w);
+        const int tp = (tn + 31) & ~31;               // padded with sentinels whose key is -inf
+        for (int t = lane; t < tp; t += 64) {
+            float4 v;
+            if (t < tn) {
+                const float *cp = cbase + (size_t)(c0 + t) * 3;
+                const float x = cp[0], y = cp[1], z = cp[2];
+                v = make_float4(x, y, z, METRIC == METRIC_EXPANDED ? -((x * x + y * y) + z * z) : 0.f);
+            } else {
+                v = METRIC == METRIC_EXPANDED ? make_float4(0.f, 0.f, 0.f, -INFINITY)
+                                              : make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
+            }
+            cand[wave][t] = v;
         }
         __syncthreads();
     };
@@ -224,47 +230,43 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
         TopKV<K> tv;
         tv.init();
         float thr = -INFINITY;
-        int cnt = 0;
-        auto flushv = [&]() {
-#pragma unroll 1
-            for (int s = 0; s < QCAP; s++) {
-                const bool has = s < cnt;
-                if (!__any(has)) break;
-                tv.insert(has ? qkey[s * 64 + lane] : -INFINITY);
-            }
-            cnt = 0;
-            thr = tv.worst();
-        };
+        // Scan 32 candidates at a time; a candidate that beats the lane's current K-th best only sets
+        // a bit in a VGPR mask (no LDS write, no exec-mask branch per candidate -- with 8 waves per CU
+        // hammering the LDS, per-candidate queue writes made this loop LDS-bound).  After the 32, the
+        // lanes pop their bits together and re-evaluate just those candidates for the value network.
         for (int tile = 0; tile < ntiles; tile++) {
             const int c0 = lo + tile * T2;
             const int tn = max(0, min(T2, hi - c0));
             stage(c0, tn);
-            int t = 0;
-            for (; t + CHUNK <= tn; t += CHUNK) {
-                if (__any(cnt > QCAP - CHUNK)) flushv();
-                float4 c[CHUNK];
-                float key[CHUNK];
+            for (int g0 = 0; g0 < tn; g0 += 32) {
+                unsigned mask = 0;
 #pragma unroll
-                for (int u = 0; u < CHUNK; u++) c[u] = cand[wave][t + u];
+                for (int ch = 0; ch < 32; ch += CHUNK) {
+                    float4 c[CHUNK];
 #pragma unroll
-                for (int u = 0; u < CHUNK; u++) key[u] = eval(c[u]);
-                // branch-free append: store unconditionally at the queue head, advance it only when the
-                // candidate beats the threshold (a rejected key is simply overwritten by the next one).
-                // Measured with s_memtime: the exec-mask branch per candidate made this loop cost
-                // ~240 cycles per candidate; the head never exceeds QCAP-1 inside a chunk (<= 8 + 7).
+                    for (int u = 0; u < CHUNK; u++) c[u] = cand[wave][g0 + ch + u];
 #pragma unroll
-                for (int u = 0; u < CHUNK; u++) {
-                    qkey[cnt * 64 + lane] = key[u];
-                    cnt += key[u] > thr ? 1 : 0;
+                    for (int u = 0; u < CHUNK; u++) mask |= eval(c[u]) > thr ? (1u << (ch + u)) : 0u;
                 }
-            }
-            for (; t < tn; t++) {
-                if (__any(cnt >= QCAP)) flushv();
-                const float key = eval(cand[wave][t]);
-                if (key > thr) { qkey[cnt * 64 + lane] = key; cnt++; }
+                // pop 4 bits per trip: the 4 per-lane LDS reads are independent, so one LDS round trip
+                // is paid per 4 insertions instead of per insertion (a -inf key is a no-op insertion)
+#pragma unroll 1
+                while (__any(mask != 0)) {
+                    float4 cc[4];
+                    bool has[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        has[e] = mask != 0;
+                        const int bpos = has[e] ? __builtin_ctz(mask) : 0;
+                        mask &= mask - 1;
+                        cc[e] = cand[wave][g0 + bpos];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) tv.insert(has[e] ? eval(cc[e]) : -INFINITY);
+                }
+                thr = tv.worst();
             }
         }
-        flushv();
         KT(1)
         // ---- global K-th best key: tree-merge the W value lists (one v_med3 per slot and entry),
         //      then wave 0 broadcasts its K-th value.  With the GLOBAL threshold pass 2 collects only
@@ -305,32 +307,38 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
         const int c0 = lo + tile * T2;
         const int tn = max(0, min(T2, hi - c0));
         if (ntiles > 1) stage(c0, tn);            // single-tile slices are still resident from pass 1
-        int t = 0;
-        for (; t + CHUNK <= tn; t += CHUNK) {
-            float4 c[CHUNK];
-            float key[CHUNK];
+        for (int g0 = 0; g0 < tn; g0 += 32) {
+            unsigned ma = 0, mb = 0;
 #pragma unroll
-            for (int u = 0; u < CHUNK; u++) c[u] = cand[wave][t + u];
+            for (int ch = 0; ch < 32; ch += CHUNK) {
+                float4 c[CHUNK];
 #pragma unroll
-            for (int u = 0; u < CHUNK; u++) key[u] = eval(c[u]);
-            // branch-free collection (same reasoning as pass 1): write at the clamped list heads,
-            // advance a head only on a hit and only while the list has room
+                for (int u = 0; u < CHUNK; u++) c[u] = cand[wave][g0 + ch + u];
 #pragma unroll
-            for (int u = 0; u < CHUNK; u++) {
-                const int pa = min(cntA, K - 1), pb = min(cntB, K);   // A never fills; B's row K is the dummy row
-                akey[pa * 64 + lane] = key[u];
-                aidx[pa * 64 + lane] = c0 + t + u;
-                bidx[pb * 64 + lane] = c0 + t + u;
-                cntA += (key[u] > thrF && cntA < K) ? 1 : 0;
-                cntB += (key[u] == thrF && cntB < K) ? 1 : 0;
+                for (int u = 0; u < CHUNK; u++) {
+                    const float key = eval(c[u]);
+                    ma |= key > thrF ? (1u << (ch + u)) : 0u;
+                    mb |= key == thrF ? (1u << (ch + u)) : 0u;
+                }
             }
-        }
-        for (; t < tn; t++) {
-            const float key = eval(cand[wave][t]);
-            if (key > thrF) {
-                if (cntA < K) { akey[cntA * 64 + lane] = key; aidx[cntA * 64 + lane] = c0 + t; cntA++; }
-            } else if (key == thrF) {
-                if (cntB < K) { bidx[cntB * 64 + lane] = c0 + t; cntB++; }
+            // hits are rare (~K in total over all slices): pop them in index order
+#pragma unroll 1
+            while (__any(ma != 0)) {
+                const bool has = ma != 0 && cntA < K;
+                const int bpos = ma != 0 ? __builtin_ctz(ma) : 0;
+                ma &= ma - 1;
+                const int pa = min(cntA, K - 1);
+                akey[pa * 64 + lane] = eval(cand[wave][g0 + bpos]);
+                aidx[pa * 64 + lane] = c0 + g0 + bpos;
+                cntA += has ? 1 : 0;
+            }
+#pragma unroll 1
+            while (__any(mb != 0)) {
+                const bool has = mb != 0 && cntB < K;
+                const int bpos = mb != 0 ? __builtin_ctz(mb) : 0;
+                mb &= mb - 1;
+                bidx[min(cntB, K) * 64 + lane] = c0 + g0 + bpos;      // row K is the dummy row
+                cntB += has ? 1 : 0;
             }
         }
     }
