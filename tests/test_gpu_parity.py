@@ -469,3 +469,64 @@ def test_flownet3d_forward_runs():
     # fused (inference) and torch-conv (autograd) routes agree
     sf2 = net(pc1, pc2, f1.clone().requires_grad_(), f2)
     np.testing.assert_allclose(sf.cpu().numpy(), sf2.detach().cpu().numpy(), rtol=2e-3, atol=2e-4)
+
+
+def test_config4_pcn_chamfer_full_size():
+    """BASELINE config 4: PCN(detailed) on partial [64,2048,3] -> fine [64,16384,3]; Chamfer loss against
+    gt [64,16384,3] (17.2 G pair evaluations per direction).  Full size through properties + one cloud
+    against the oracle (the reference's own fallback would need 3 x 206 GB here)."""
+    from learning3d_amd.models import PCN
+    from learning3d_amd.losses import ChamferDistanceLoss
+    from learning3d_amd.losses.chamfer_distance import ChamferDistanceFunction
+    torch.manual_seed(0)
+    net = PCN(emb_dims=1024, num_coarse=1024, grid_size=4, detailed_output=True).cuda().eval()
+    g = torch.Generator().manual_seed(0)
+    partial = (torch.rand((64, 2048, 3), generator=g) - 0.5).cuda()
+    gt = (torch.rand((64, 16384, 3), generator=g) - 0.5).cuda()
+    with torch.no_grad():
+        out = net(partial)
+        fine = out["fine_output"]
+        assert fine.shape == (64, 16384, 3) and torch.isfinite(fine).all()
+        loss = ChamferDistanceLoss()(gt, fine)
+        d1, d2 = ChamferDistanceFunction.apply(gt, fine.contiguous())
+    assert loss.ndim == 0 and torch.isfinite(loss)
+    o1, o2, _, _ = oracle.chamfer_forward(gt[:1].cpu().numpy(), fine[:1].contiguous().cpu().numpy())
+    assert np.array_equal(d1[:1].cpu().numpy(), o1) and np.array_equal(d2[:1].cpu().numpy(), o2)
+    want = (torch.sqrt(d1).double().mean() + torch.sqrt(d2).double().mean()) / 2
+    assert abs(float(loss) - float(want)) < 1e-6
+
+
+def test_edge_cases_small_and_degenerate():
+    """Ragged / degenerate inputs: single point clouds, k == N, nsample > N, duplicate points (exact
+    ties), M != N Chamfer with one-point clouds."""
+    import learning3d_amd.utils as U
+    from learning3d_amd.utils import pointnet2_utils as P
+    from learning3d_amd.losses.chamfer_distance import ChamferDistanceFunction
+    # k == N == 1 .. small
+    x = dev(rand((2, 1, 3), 1))
+    assert (U.knn(x.permute(0, 2, 1), 1) == 0).all()
+    x = dev(rand((1, 5, 3), 2))
+    idx = U.knn(x.permute(0, 2, 1), 5).cpu().numpy()
+    assert sorted(idx[0, 0].tolist()) == [0, 1, 2, 3, 4] and np.array_equal(idx, oracle.knn(x.cpu().numpy(), 5))
+    # duplicate points: exact ties resolve to the lower index, like the oracle's contract
+    pts = rand((1, 40, 3), 3)
+    pts[0, 20:] = pts[0, :20]
+    idx = U.knn(dev(pts).permute(0, 2, 1), 6).cpu().numpy()
+    assert np.array_equal(idx, oracle.knn(pts, 6))
+    # ball query: nsample > N, radius covering everything / nothing
+    xyz = dev(rand((1, 7, 3), 4))
+    bq = P.ball_query(10.0, 16, xyz, xyz[:, :3].contiguous()).cpu().numpy()
+    assert np.array_equal(bq, oracle.ball_query(10.0, 16, xyz.cpu().numpy(), xyz[:, :3].cpu().numpy()))
+    q = U.query_ball_point(1e-6, 4, xyz, xyz[:, :2].contiguous()).cpu().numpy()      # only the point itself
+    assert np.array_equal(q, oracle.query_ball_point(1e-6, 4, xyz.cpu().numpy(), xyz[:, :2].cpu().numpy()))
+    # FPS with npoint == N
+    f = P.furthest_point_sample(xyz, 7).cpu().numpy()
+    assert sorted(f[0].tolist()) == list(range(7))
+    # Chamfer with one-point clouds and M != N
+    a, b = dev(rand((2, 1, 3), 5)), dev(rand((2, 9, 3), 6))
+    d1, d2 = ChamferDistanceFunction.apply(a, b)
+    o1, o2, _, _ = oracle.chamfer_forward(a.cpu().numpy(), b.cpu().numpy())
+    assert np.array_equal(d1.cpu().numpy(), o1) and np.array_equal(d2.cpu().numpy(), o2)
+    # K13 with k > m: slots beyond m hold (+inf -> sqrt inf, index 0) like best[]=1e40, besti[]=0
+    d, i = P.knn(5, dev(rand((1, 4, 3), 7)), dev(rand((1, 3, 3), 8)))
+    assert torch.isinf(d[..., 3:]).all() and (i[..., 3:] == 0).all()
