@@ -51,36 +51,59 @@ __global__ __launch_bounds__(64) void ball_query_kernel(int n, int m, float r2, 
     long total = 0;
     for (int c0 = 0; c0 < n; c0 += BQ_TILE) {
         const int tn = min(BQ_TILE, n - c0);
+        const int tp = (tn + 31) & ~31;              // padded with far-away sentinels (never inside a ball)
         __syncthreads();
-        for (int t = lane; t < tn; t += 64) {
-            const float *cp = cbase + (size_t)(c0 + t) * 3;
-            float x = cp[0], y = cp[1], z = cp[2];
-            cand[t] = make_float4(x, y, z, (x * x + y * y) + z * z);
+        for (int t = lane; t < tp; t += 64) {
+            float4 v = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 2.7e37f);
+            if (t < tn) {
+                const float *cp = cbase + (size_t)(c0 + t) * 3;
+                const float x = cp[0], y = cp[1], z = cp[2];
+                v = make_float4(x, y, z, (x * x + y * y) + z * z);
+            }
+            cand[t] = v;
         }
         __syncthreads();
         if (!counting && __all(cnt >= nsample || !valid)) break;
-        for (int t = 0; t < tn; t++) {
-            const float4 c = cand[t];
-            bool hit;
-            if (MODE == 0) {
-                const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
-                const float d2 = (dx * dx + dy * dy) + dz * dz;
-                hit = d2 < r2;
-            } else {
-                // square_distance(new_xyz, xyz): (-2*dot + |q|^2) + |p|^2
-                const float dot = fmaf(qz, c.z, fmaf(qy, c.y, qx * c.x));
-                const float d2 = (-2.0f * dot + qss) + c.w;
-                hit = !(d2 > r2) && (c0 + t != self);
-            }
-            if (hit) {
-                if (cnt < nsample && valid) {
-                    if (MODE == 0) o32[cnt] = c0 + t; else o64[cnt] = c0 + t;
-                    if (cnt == 0) first = c0 + t;
-                    cnt++;
+        // 32 candidates per trip: the in-ball test only sets a bit (no exec-mask branch, no store per
+        // candidate); hits are popped afterwards in index order.  The wave leaves the scan as soon as
+        // every lane holds nsample hits.
+        for (int g0 = 0; g0 < tn; g0 += 32) {
+            unsigned mask = 0;
+#pragma unroll
+            for (int ch = 0; ch < 32; ch += 8) {
+                float4 c[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) c[u] = cand[g0 + ch + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    bool hit;
+                    if (MODE == 0) {
+                        const float dx = qx - c[u].x, dy = qy - c[u].y, dz = qz - c[u].z;
+                        const float d2 = (dx * dx + dy * dy) + dz * dz;
+                        hit = d2 < r2;
+                    } else {
+                        // square_distance(new_xyz, xyz): (-2*dot + |q|^2) + |p|^2
+                        const float dot = fmaf(qz, c[u].z, fmaf(qy, c[u].y, qx * c[u].x));
+                        const float d2 = (-2.0f * dot + qss) + c[u].w;
+                        hit = !(d2 > r2) && (c0 + g0 + ch + u != self);
+                    }
+                    mask |= hit ? (1u << (ch + u)) : 0u;
                 }
-                total++;
             }
-            if (!counting && ((t & 31) == 31) && __all(cnt >= nsample || !valid)) break;
+            if (counting) total += __builtin_popcount(mask);
+            if (cnt >= nsample || !valid) mask = 0;
+#pragma unroll 1
+            while (__any(mask != 0)) {
+                if (mask != 0) {
+                    const int hit_idx = c0 + g0 + __builtin_ctz(mask);
+                    mask &= mask - 1;
+                    if (MODE == 0) o32[cnt] = hit_idx; else o64[cnt] = hit_idx;
+                    if (cnt == 0) first = hit_idx;
+                    cnt++;
+                    if (cnt >= nsample) mask = 0;
+                }
+            }
+            if (!counting && __all(cnt >= nsample || !valid)) break;
         }
     }
     if (!valid) return;
@@ -259,13 +282,48 @@ extern "C" int l3d_index_points(const float *points, const int64_t *idx, int B, 
 // (sampling_gpu.cu:139-203).  Arg-max ties resolve to the lowest index.
 // OUT64: int64 centroids + optional start index (torch twin T7), else int32, start 0 (K12).
 // ---------------------------------------------------------------------------------------------
-template <int PPT, bool OUT64>
+// 16-lane (DPP row) reductions on integer keys: non-negative fp32 values order like their bit
+// patterns, so the arg-max runs on the integer pipe with quad_perm / row_half_mirror / row_mirror
+// DPP modifiers -- no ds_bpermute, no LDS round trip.
+__device__ __forceinline__ int row16_max_i(int v)
+{
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));    // quad_perm(1,0,3,2)
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));    // quad_perm(2,3,0,1)
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));   // row_half_mirror
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));   // row_mirror
+    return v;
+}
+__device__ __forceinline__ int row16_min_i(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+    v = row16_max_i(v);
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_min_i(int v)
+{
+    v = row16_min_i(v);
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// LDS_XYZ: the cloud is also kept in LDS (12 B/point, n <= 12288) so the coordinates of the point
+// picked in the previous round come from a wave-uniform LDS read instead of a dependent global load.
+template <int PPT, bool OUT64, bool LDS_XYZ>
 __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, const float *__restrict__ xyz,
                                                    const int64_t *__restrict__ start,
                                                    float *__restrict__ temp,
                                                    void *__restrict__ out)
 {
-    __shared__ float wv[2][16];
+    extern __shared__ float sxyz[];              // [3][n] when LDS_XYZ
+    __shared__ int wv[2][16];
     __shared__ int wi[2][16];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int b = blockIdx.x;
@@ -279,15 +337,20 @@ __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, const float *__
         py[u] = ok ? p[k * 3 + 1] : 0.f;
         pz[u] = ok ? p[k * 3 + 2] : 0.f;
         dmin[u] = ok ? 1e10f : -1.f;          // out-of-range slots can never win the arg-max
+        if (LDS_XYZ && ok) { sxyz[k] = px[u]; sxyz[n + k] = py[u]; sxyz[2 * n + k] = pz[u]; }
     }
+    if (tid < 32) { wv[tid >> 4][tid & 15] = (int)0x80000000; wi[tid >> 4][tid & 15] = 0x7fffffff; }
     int old = (OUT64 && start) ? (int)start[b] : 0;
     if (tid == 0) {
         if (OUT64) ((int64_t *)out)[(size_t)b * m] = old; else ((int32_t *)out)[(size_t)b * m] = old;
     }
-    const int nw = nthr >> 6, wave = tid >> 6, lane = tid & 63;
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
     for (int j = 1; j < m; j++) {
-        const float x1 = p[old * 3], y1 = p[old * 3 + 1], z1 = p[old * 3 + 2];   // wave-uniform
-        float best = -1.f;
+        float x1, y1, z1;                       // wave-uniform
+        if (LDS_XYZ) { x1 = sxyz[old]; y1 = sxyz[n + old]; z1 = sxyz[2 * n + old]; }
+        else { x1 = p[old * 3]; y1 = p[old * 3 + 1]; z1 = p[old * 3 + 2]; }
+        int best = (int)0x80000000;             // bit pattern of the running max (d2 >= 0, or -1 for padding)
         int besti = 0;
 #pragma unroll
         for (int u = 0; u < PPT; u++) {
@@ -295,32 +358,21 @@ __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, const float *__
             const float d = (dx * dx + dy * dy) + dz * dz;
             const float d2 = fminf(d, dmin[u]);
             dmin[u] = d2;
-            const bool gt = d2 > best;          // ascending k within a thread: lowest index wins
-            best = gt ? d2 : best;
+            const int key = __builtin_bit_cast(int, d2);
+            const bool gt = key > best;         // ascending k within a thread: lowest index wins
+            best = gt ? key : best;
             besti = gt ? tid + u * nthr : besti;
         }
-        // wave arg-max, lowest index on ties
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(best, off, 64);
-            const int oi = __shfl_xor(besti, off, 64);
-            const bool take = ov > best || (ov == best && oi < besti);
-            best = take ? ov : best;
-            besti = take ? oi : besti;
-        }
+        // wave arg-max (lowest index among equal maxima), then the <= 16 waves through LDS
+        const int wmax = wave_max_i(best);
+        const int widx = wave_min_i(best == wmax ? besti : 0x7fffffff);
         const int buf = j & 1;
-        if (lane == 0) { wv[buf][wave] = best; wi[buf][wave] = besti; }
+        if (lane == 0) { wv[buf][wave] = wmax; wi[buf][wave] = widx; }
         __syncthreads();
-        float bv = wv[buf][0];
-        int bi = wi[buf][0];
-        for (int w = 1; w < nw; w++) {
-            const float ov = wv[buf][w];
-            const int oi = wi[buf][w];
-            const bool take = ov > bv || (ov == bv && oi < bi);
-            bv = take ? ov : bv;
-            bi = take ? oi : bi;
-        }
-        old = __builtin_amdgcn_readfirstlane(bi);     // wave-uniform -> scalar loads of p[old]
+        const int ev = wv[buf][lane & 15], ei = wi[buf][lane & 15];      // every 16-lane row sees all waves
+        const int bmax = row16_max_i(ev);
+        const int bidx = row16_min_i(ev == bmax ? ei : 0x7fffffff);
+        old = __builtin_amdgcn_readfirstlane(bidx);
         if (tid == 0) {
             if (OUT64) ((int64_t *)out)[(size_t)b * m + j] = old; else ((int32_t *)out)[(size_t)b * m + j] = old;
         }
@@ -344,8 +396,12 @@ static int launch_fps(int b, int n, int m, const float *xyz, const int64_t *star
     int ppt = (n + nthr - 1) / nthr;
 #define L3D_FPS_CASE(P)                                                                           \
     if (ppt <= P) {                                                                               \
-        hipLaunchKernelGGL((fps_kernel<P, OUT64>), dim3(b), dim3(nthr), 0, st, n, m, xyz, start,  \
-                           temp, out);                                                            \
+        if (n <= 12288)                                                                           \
+            hipLaunchKernelGGL((fps_kernel<P, OUT64, true>), dim3(b), dim3(nthr),                 \
+                               sizeof(float) * 3 * (size_t)n, st, n, m, xyz, start, temp, out);   \
+        else                                                                                      \
+            hipLaunchKernelGGL((fps_kernel<P, OUT64, false>), dim3(b), dim3(nthr), 0, st, n, m,   \
+                               xyz, start, temp, out);                                            \
         return l3d_check_launch();                                                                \
     }
     L3D_FPS_CASE(1)
