@@ -190,14 +190,28 @@ __global__ __launch_bounds__(64) void chamfer_bwd_kernel(const float *__restrict
         __syncthreads();
         for (int t = lane; t < tn; t += 64) sel[t] = icb[c0 + t];
         __syncthreads();
-        for (int t = 0; t < tn; t++) {
-            if (sel[t] == iq) {          // rare, divergent branch: ~1 hit per lane per scan
-                const int j = c0 + t;
-                const float *pj = C + ((size_t)b * NC + j) * 3;
-                const float gj = gdC[(size_t)b * NC + j] * 2;
-                gx -= gj * (pj[0] - ax);
-                gy -= gj * (pj[1] - ay);
-                gz -= gj * (pj[2] - az);
+        // 32 selections per trip into a bit mask (a per-candidate branch costs an exec-mask round trip
+        // even when no lane takes it); the rare matches are popped in index order afterwards
+        for (int g0 = 0; g0 < tn; g0 += 32) {
+            unsigned mask = 0;
+            const int gn = min(32, tn - g0);
+            if (gn == 32) {
+#pragma unroll
+                for (int u = 0; u < 32; u++) mask |= sel[g0 + u] == iq ? (1u << u) : 0u;
+            } else {
+                for (int u = 0; u < gn; u++) mask |= sel[g0 + u] == iq ? (1u << u) : 0u;
+            }
+#pragma unroll 1
+            while (__any(mask != 0)) {
+                if (mask != 0) {
+                    const int j = c0 + g0 + __builtin_ctz(mask);
+                    mask &= mask - 1;
+                    const float *pj = C + ((size_t)b * NC + j) * 3;
+                    const float gj = gdC[(size_t)b * NC + j] * 2;
+                    gx -= gj * (pj[0] - ax);
+                    gy -= gj * (pj[1] - ay);
+                    gz -= gj * (pj[2] - az);
+                }
             }
         }
     }

@@ -44,6 +44,14 @@ def main():
         cd = ChamferDistance()
         t = timeit(lambda: cd(a, b))
         res["chamfer_c2"] = (t, 2 * B * N * N / t / 1e3, "Gpair/s")
+        from learning3d_amd.losses.chamfer_distance import ChamferDistanceFunction
+        ag, bg = a.clone().requires_grad_(), b.clone().requires_grad_()
+        def fwdbwd():
+            with torch.enable_grad():
+                d1, d2 = ChamferDistanceFunction.apply(ag, bg)
+                (d1.sum() + d2.sum()).backward()
+        t = timeit(fwdbwd)
+        res["chamfer_fwd+bwd_c2"] = (t, 2 * B * N * N / t / 1e3, "Gpair/s(fwd)")
         net = DGCNN(emb_dims=1024).to(dev).eval()
         idx = U.knn(xt, k)
         packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
