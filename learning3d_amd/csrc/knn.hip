@@ -181,7 +181,6 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
     const float qxx = (qx * qx + qy * qy) + qz * qz;
     const float *cbase = cxyz + (size_t)b * Nc * 3;
 
-    float *qkey = scratch[wave];                       // [QCAP][64]
     float *akey = scratch[wave];                       // [K][64]
     int *aidx = (int *)scratch[wave] + K * 64;         // [K][64]
     int *bidx = (int *)scratch[wave] + 2 * K * 64;     // [KR][64]
