@@ -290,7 +290,11 @@ extern "C" int l3d_edgeconv_forward(const float *xyz, const int64_t *idx, int B,
 #endif
 #define PW_LD (128 + 4)      // LDS row stride (floats) of the k-major tiles; 16 B aligned
 
-template <bool XCL>
+// FULL: every tile is complete and every row is 16-byte addressable (Cout, N multiples of 128, Cin of
+// 16): the staging loads are then unconditional.  The guarded variant wraps each 16-byte load in an
+// exec-mask branch -- 26 s_and_saveexec / s_cbranch_execz per K chunk, which sat in front of every
+// chunk's MFMAs and cost ~11 % at the conv5 shape.
+template <bool XCL, bool FULL>
 __global__ __launch_bounds__(256, 2) void pointwise_conv_kernel(
     const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ scale,
     const float *__restrict__ shift, int shift_bstride, int Cin, int Cout, int N, int relu,
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_conv_kernel(
     float ra[8], rb[8];
     const bool cin_vec = (Cin & 3) == 0, n_vec = (N & 3) == 0;
     auto load8 = [](float (&r)[8], const float *src, int pos, int limit, bool row_ok, bool vec) {
-        if (row_ok && vec && pos + 8 <= limit) {
+        if (FULL || (row_ok && vec && pos + 8 <= limit)) {
             const float4 v0 = *(const float4 *)(src + pos), v1 = *(const float4 *)(src + pos + 4);
             r[0] = v0.x; r[1] = v0.y; r[2] = v0.z; r[3] = v0.w;
             r[4] = v1.x; r[5] = v1.y; r[6] = v1.z; r[7] = v1.w;
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_conv_kernel(
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const int co = co0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-            if (co >= Cout) continue;
+            if (!FULL && co >= Cout) continue;
             const float sc = scale ? scale[co] : 1.f;
             const float sh = shift ? shift[(size_t)b * shift_bstride + co] : 0.f;
 #pragma unroll
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_conv_kernel(
 #ifdef PW_PROBE_NO_STORE
                 if (v == 123.456f)
 #endif
-                if (n < N) yb[(size_t)co * N + n] = v;
+                if (FULL || n < N) yb[(size_t)co * N + n] = v;
             }
         }
 }
@@ -429,9 +433,14 @@ extern "C" int l3d_pointwise_conv(const float *x, int x_channel_last, const floa
     if (B > 65535) return L3D_ERR_UNSUPPORTED;
     dim3 grid(l3d_divup(N, PW_TN), l3d_divup(Cout, PW_TM), B), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (x_channel_last)
-        hipLaunchKernelGGL(pointwise_conv_kernel<true>, grid, block, 0, st, x, w, scale, shift, shift_bstride, Cin, Cout, N, relu, y);
-    else
-        hipLaunchKernelGGL(pointwise_conv_kernel<false>, grid, block, 0, st, x, w, scale, shift, shift_bstride, Cin, Cout, N, relu, y);
+    const bool full = (Cout % PW_TM) == 0 && (N % PW_TN) == 0 && (Cin % PW_TK) == 0 &&
+                      ((((size_t)x) | ((size_t)w)) & 15) == 0;
+    if (x_channel_last) {
+        if (full) hipLaunchKernelGGL((pointwise_conv_kernel<true, true>), grid, block, 0, st, x, w, scale, shift, shift_bstride, Cin, Cout, N, relu, y);
+        else      hipLaunchKernelGGL((pointwise_conv_kernel<true, false>), grid, block, 0, st, x, w, scale, shift, shift_bstride, Cin, Cout, N, relu, y);
+    } else {
+        if (full) hipLaunchKernelGGL((pointwise_conv_kernel<false, true>), grid, block, 0, st, x, w, scale, shift, shift_bstride, Cin, Cout, N, relu, y);
+        else      hipLaunchKernelGGL((pointwise_conv_kernel<false, false>), grid, block, 0, st, x, w, scale, shift, shift_bstride, Cin, Cout, N, relu, y);
+    }
     return l3d_check_launch();
 }
