@@ -425,14 +425,76 @@ __global__ __launch_bounds__(256, 2) void pointwise_conv_kernel(
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Narrow heads (Cout <= 8, e.g. PCN's folding conv7 512 -> 3, FlowNet3D's conv2 128 -> 3): a 128-wide
+// MFMA tile would be > 90 % padding.  HBM-bound instead: one thread per point reads its Cin inputs
+// (coalesced over points for channel-first x, float4 runs for channel-last x), weights are
+// wave-uniform (scalar loads), COUT accumulators in registers.
+// ---------------------------------------------------------------------------------------------
+template <int COUT, bool XCL>
+__global__ __launch_bounds__(256) void pointwise_conv_narrow_kernel(
+    const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ scale,
+    const float *__restrict__ shift, int shift_bstride, int Cin, int N, int relu, float *__restrict__ y)
+{
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float *xb = x + (size_t)b * Cin * N;
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; c++) acc[c] = 0.f;
+    if (XCL) {
+        const float *xr = xb + (size_t)n * Cin;
+        for (int k = 0; k < Cin; k++) {
+            const float v = xr[k];
+#pragma unroll
+            for (int c = 0; c < COUT; c++) acc[c] = fmaf(w[c * Cin + k], v, acc[c]);
+        }
+    } else {
+#pragma unroll 4
+        for (int k = 0; k < Cin; k++) {
+            const float v = xb[(size_t)k * N + n];
+#pragma unroll
+            for (int c = 0; c < COUT; c++) acc[c] = fmaf(w[c * Cin + k], v, acc[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < COUT; c++) {
+        float v = acc[c] * (scale ? scale[c] : 1.f) + (shift ? shift[(size_t)b * shift_bstride + c] : 0.f);
+        if (relu) v = fmaxf(v, 0.f);
+        y[((size_t)b * COUT + c) * N + n] = v;
+    }
+}
+
+template <bool XCL>
+static int launch_narrow(const float *x, const float *w, const float *scale, const float *shift,
+                         int shift_bstride, int B, int Cin, int Cout, int N, int relu, float *y, hipStream_t st)
+{
+    dim3 grid(l3d_divup(N, 256), B), block(256);
+#define L3D_NARROW(CO)                                                                                  \
+    case CO:                                                                                            \
+        hipLaunchKernelGGL((pointwise_conv_narrow_kernel<CO, XCL>), grid, block, 0, st, x, w, scale,    \
+                           shift, shift_bstride, Cin, N, relu, y);                                      \
+        break;
+    switch (Cout) {
+        L3D_NARROW(1) L3D_NARROW(2) L3D_NARROW(3) L3D_NARROW(4) L3D_NARROW(5) L3D_NARROW(6) L3D_NARROW(7) L3D_NARROW(8)
+        default: return L3D_ERR_UNSUPPORTED;
+    }
+#undef L3D_NARROW
+    return l3d_check_launch();
+}
+
 extern "C" int l3d_pointwise_conv(const float *x, int x_channel_last, const float *w,
                                   const float *scale, const float *shift, int shift_bstride, int B,
                                   int Cin, int Cout, int N, int relu, float *y, l3d_stream_t stream)
 {
     L3D_REQUIRE(x && w && y && B > 0 && Cin > 0 && Cout > 0 && N > 0);
     if (B > 65535) return L3D_ERR_UNSUPPORTED;
-    dim3 grid(l3d_divup(N, PW_TN), l3d_divup(Cout, PW_TM), B), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (Cout <= 8 && B <= 65535)
+        return x_channel_last ? launch_narrow<true>(x, w, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, st)
+                              : launch_narrow<false>(x, w, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, st);
+    dim3 grid(l3d_divup(N, PW_TN), l3d_divup(Cout, PW_TM), B), block(256);
     const bool full = (Cout % PW_TM) == 0 && (N % PW_TN) == 0 && (Cin % PW_TK) == 0 &&
                       ((((size_t)x) | ((size_t)w)) & 15) == 0;
     if (x_channel_last) {

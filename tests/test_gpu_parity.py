@@ -362,7 +362,8 @@ def test_pointnet_golden(golden):
 def test_pointwise_conv_ragged_shapes():
     from learning3d_amd.models._fused import pointwise_conv
     rng = np.random.default_rng(9)
-    for (B, Cin, Cout, N) in [(2, 3, 64, 100), (1, 130, 70, 257), (3, 512, 256, 128), (2, 5, 512, 1000)]:
+    for (B, Cin, Cout, N) in [(2, 3, 64, 100), (1, 130, 70, 257), (3, 512, 256, 128), (2, 5, 512, 1000),
+                              (2, 512, 3, 1000), (1, 128, 8, 77)]:
         x = rng.standard_normal((B, Cin, N)).astype(np.float32)
         w = (rng.standard_normal((Cout, Cin)) / np.sqrt(Cin)).astype(np.float32)
         sc = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
