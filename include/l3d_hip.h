@@ -200,6 +200,25 @@ int l3d_pointwise_conv(const float *x, int x_channel_last, const float *w, const
                        int relu, float *y, l3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The same per-point linear layer on the bf16 matrix cores with fp32-equivalent results ("bf16x3"):
+ * every fp32 operand is split exactly into three bf16 planes (x = h + m + l) and six bf16 MFMA
+ * products (hh, hm, mh, hl, lh, mm) are accumulated in fp32 -- product error ~2^-24 relative, the
+ * level of an fp32 FMA chain, at 6/16 of the fp32-MFMA cost (conv_split.hip).
+ *   l3d_split_bytes(rows, cols): size of the split + tiled image of an fp32 [rows][cols] matrix,
+ *     layout [ceil(cols/16)][plane 3][kg 2][rows][8] bf16 (cols zero-padded to 16).
+ *   l3d_split_rows: device fp32 [rows][cols] -> that image (weights: rows = Cout, cols = Cin).
+ *   l3d_pointwise_conv_split: x_mode 0 = x [B,Cin,N] fp32, 1 = x [B,N,Cin] fp32,
+ *     2 = x already split as l3d_split_rows would split the [B*N][Cin] matrix.
+ *     Needs Cout % 256 == 0, N % 256 == 0, Cin % 16 == 0, else L3D_ERR_UNSUPPORTED (callers then use
+ *     l3d_pointwise_conv).  Other arguments as l3d_pointwise_conv.
+ * ------------------------------------------------------------------------------------------- */
+size_t l3d_split_bytes(int rows, int cols);
+int l3d_split_rows(const float *src, int rows, int cols, void *dst, l3d_stream_t stream);
+int l3d_pointwise_conv_split(const void *x, int x_mode, const void *w_split, const float *scale,
+                             const float *shift, int shift_bstride, int B, int Cin, int Cout, int N,
+                             int relu, float *y, l3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Approximate EMD  == losses/cuda/emd_torch/pkg/include/emd.h:47-50 (pybind `_emd_ext._emd`)
  *   emd_forward(xyz1,xyz2) -> cost [B], match [B,n,m] (indexed [l*n+k], emd.cuh:158);
  *   temp: scratch of B*2*(n+m) floats.   emd_backward(xyz1,xyz2,match) -> grad1, grad2.

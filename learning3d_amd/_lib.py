@@ -48,10 +48,13 @@ SIGNATURES = {
     "l3d_edgeconv_forward": [_P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P],
     "l3d_edgeconv_forward_chained": [_P, _P, _I, _I, _I, _P, _P, _P],
     "l3d_pointwise_conv": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "l3d_split_bytes": [_I, _I],
+    "l3d_split_rows": [_P, _I, _I, _P, _P],
+    "l3d_pointwise_conv_split": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_emd_forward": [_P, _P, _I, _I, _I, _P, _P, _P, _P],
     "l3d_emd_backward": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
 }
-_RESTYPE = {"l3d_status_string": C.c_char_p, "l3d_edgeconv_packed_floats": _SZ}
+_RESTYPE = {"l3d_status_string": C.c_char_p, "l3d_edgeconv_packed_floats": _SZ, "l3d_split_bytes": _SZ}
 
 
 class L3DError(RuntimeError):

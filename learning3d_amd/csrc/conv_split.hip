@@ -1,0 +1,248 @@
+// conv_split.hip -- per-point linear layer (1x1 conv + folded BN + ReLU) with fp32 operands split
+// into three bf16 planes and multiplied on the bf16 matrix cores ("bf16x3", 6 products).
+//
+// Why.  v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate (157 TFLOP/s); v_mfma_f32_32x32x16_bf16
+// runs 16x faster.  An fp32 value x is EXACTLY h + m + l with h = bf16(x), m = bf16(x - h),
+// l = bf16(x - h - m) (8 + 8 + 8 significand bits, every remainder exact in fp32).  Then
+//     w * x = wh*xh + (wh*xm + wm*xh) + (wh*xl + wl*xh + wm*xm) + O(2^-26 |w x|)
+// and each bf16 x bf16 product is exact in the fp32 accumulator, so six bf16 MFMAs reproduce the fp32
+// product to ~2^-24 relative -- the rounding level of an fp32 FMA chain -- at 6/16 of the cost of the
+// fp32 MFMA.  (tests/test_gpu_parity.py::test_conv_split_accuracy checks the error against an fp64
+// reference and against the fp32-MFMA kernel's own error.)  models/dgcnn.py:48, pointnet.py:22-49,
+// pcn.py:84-125 are the layers this serves.
+//
+// Shape of the kernel.  y[b][co][n] = act(scale[co] * sum_k W[co][k] x[b][n][k] + shift[b][co]).
+//   * workgroup tile 256 (co) x 256 (n), 512 threads = 8 waves (2 x 4), wave tile 128 x 64 =
+//     4 x 2 MFMA tiles of 32x32 (128 accumulator registers).  A 256x256 tile keeps the L2 -> LDS
+//     operand stream at ~13 B/clk/CU (~8 TB/s chip-wide, L2 gives ~34): with 2.7x less MFMA time per
+//     FLOP than the fp32 kernel the 128x128 tile of mlp.hip would be operand-bound.
+//   * K chunks of 16 (one MFMA k-step), double-buffered in LDS (2 x 48.75 KB), ONE barrier per chunk.
+//   * both operands are "K-contiguous rows": lane (i = l&31, kg = l>>5) of the 32x32x16 MFMA needs
+//     8 consecutive k of row i = one ds_read_b128.  LDS layout per plane: [kg][row][8 bf16], so the
+//     16 lanes one b128 read cycle serves touch 16 distinct 4-bank slots (no padding needed).
+//   * W arrives pre-split and pre-tiled ([k-chunk][plane][kg][Cout][8], l3d_conv_split_weights):
+//     each (chunk, plane, kg) block of a tile is one contiguous 4 KB run.
+//   * x arrives as fp32 (channel-last or channel-first) and is split while it is staged
+//     (11 VALU per pair of elements, once per element per workgroup), or pre-split in the same tiled
+//     layout as W (XMODE 2; written by the split EdgeConv kernel's epilogue).
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CS_TM 256
+#define CS_TN 256
+#define CS_TK 16
+#define CS_REGION (256 * 16 + 64)           // bytes of one (plane, kg) region (+64: write-side bank skew)
+#define CS_BUF (12 * CS_REGION)             // W: 6 regions, X: 6 regions
+#define CS_LDS (2 * CS_BUF)
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b)
+{
+    f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));     // v_cvt_pk_bf16_f32 (RNE)
+}
+__device__ __forceinline__ float bf16_lo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// two fp32 -> packed (h, m, l) bf16 pairs, x = h + m + l exactly
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t &h, uint32_t &m, uint32_t &l)
+{
+    h = cvt_pk_bf16(a, b);
+    const float ra = a - bf16_lo(h), rb = b - bf16_hi(h);
+    m = cvt_pk_bf16(ra, rb);
+    l = cvt_pk_bf16(ra - bf16_lo(m), rb - bf16_hi(m));
+}
+
+// 8 fp32 -> three uint4 of 8 bf16
+__device__ __forceinline__ void split8(const float (&v)[8], uint4 &h, uint4 &m, uint4 &l)
+{
+    split_pair(v[0], v[1], h.x, m.x, l.x);
+    split_pair(v[2], v[3], h.y, m.y, l.y);
+    split_pair(v[4], v[5], h.z, m.z, l.z);
+    split_pair(v[6], v[7], h.w, m.w, l.w);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight (or activation) splitter: src [R][C] fp32 row-major -> dst [ceil(C/16)][3][2][R][8] bf16.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ src, int R, int C,
+                                                         uint4 *__restrict__ dst)
+{
+    const int nkc = (C + 15) / 16;
+    const long total = (long)R * nkc * 2;
+    const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= total) return;
+    const int row = (int)(id % R);
+    const int oct = (int)(id / R);                 // kc*2 + kg
+    const int k0 = oct * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = (k0 + e < C) ? src[(size_t)row * C + k0 + e] : 0.f;
+    uint4 h, m, l;
+    split8(v, h, m, l);
+    const int kc = oct >> 1, kg = oct & 1;
+    dst[(((size_t)kc * 3 + 0) * 2 + kg) * R + row] = h;
+    dst[(((size_t)kc * 3 + 1) * 2 + kg) * R + row] = m;
+    dst[(((size_t)kc * 3 + 2) * 2 + kg) * R + row] = l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// XMODE 0: x [B][Cin][N] fp32   1: x [B][N][Cin] fp32   2: x pre-split [Cin/16][3][2][B*N][8] bf16
+// Requires Cout % 256 == 0, N % 256 == 0, Cin % 16 == 0 (dispatcher checks).
+// ---------------------------------------------------------------------------------------------
+template <int XMODE>
+__global__ __launch_bounds__(512) void conv_split_kernel(const void *__restrict__ xin,
+                                                         const uint4 *__restrict__ wsplit,
+                                                         const float *__restrict__ scale,
+                                                         const float *__restrict__ shift, int shift_bstride,
+                                                         int Bn, int Cin, int Cout, int N, int relu,
+                                                         float *__restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int n0 = blockIdx.x * CS_TN, co0 = blockIdx.y * CS_TM, b = blockIdx.z;
+    const int nk = Cin / CS_TK;
+
+    // ---- staging assignments
+    const int wrow = t & 255, wkg = t >> 8;                           // W (and pre-split X): 3 planes each
+    const int xrow = (XMODE == 1) ? (t >> 1) : (t & 255);             // fp32 X: one octet of one row
+    const int xkg = (XMODE == 1) ? (t & 1) : (t >> 8);
+    const uint4 *wsrc = wsplit + (size_t)wkg * Cout + co0 + wrow;      // + ((kc*3 + p)*2) * Cout
+    const size_t BN = (size_t)Bn * N;
+    const uint4 *xsrc2 = (const uint4 *)xin + (size_t)wkg * BN + (size_t)b * N + n0 + wrow;
+    const float *xsrc1 = (const float *)xin + ((size_t)b * N + n0 + xrow) * Cin + xkg * 8;
+    const float *xsrc0 = (const float *)xin + ((size_t)b * Cin + xkg * 8) * N + n0 + xrow;
+    const int w_lds = wkg * CS_REGION + wrow * 16;                     // + p * 2 * CS_REGION
+    const int x_lds = 6 * CS_REGION + ((XMODE == 2) ? w_lds : (xkg * CS_REGION + xrow * 16));
+
+    uint4 wreg[3], xs[3];
+    float xv[8];
+
+    auto load_global = [&](int kc) {
+#pragma unroll
+        for (int p = 0; p < 3; p++) wreg[p] = wsrc[((size_t)kc * 3 + p) * 2 * Cout];
+        if (XMODE == 2) {
+#pragma unroll
+            for (int p = 0; p < 3; p++) xs[p] = xsrc2[((size_t)kc * 3 + p) * 2 * BN];
+        } else if (XMODE == 1) {
+            const f32x4 a = *(const f32x4 *)(xsrc1 + kc * CS_TK);
+            const f32x4 c = *(const f32x4 *)(xsrc1 + kc * CS_TK + 4);
+            xv[0] = a[0]; xv[1] = a[1]; xv[2] = a[2]; xv[3] = a[3];
+            xv[4] = c[0]; xv[5] = c[1]; xv[6] = c[2]; xv[7] = c[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) xv[e] = xsrc0[((size_t)kc * CS_TK + e) * N];
+        }
+    };
+    auto store_lds = [&](int buf) {
+        unsigned char *base = lds + buf * CS_BUF;
+        if (XMODE != 2) split8(xv, xs[0], xs[1], xs[2]);
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            *(uint4 *)(base + w_lds + p * 2 * CS_REGION) = wreg[p];
+            *(uint4 *)(base + x_lds + p * 2 * CS_REGION) = xs[p];
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][c][r] = 0.f;
+
+    const int frag_kg = (lane >> 5) * CS_REGION;
+    const int a_off = frag_kg + (wm * 128 + (lane & 31)) * 16;                       // + a*32*16 + p*2*REGION
+    const int b_off = 6 * CS_REGION + frag_kg + (wn * 64 + (lane & 31)) * 16;        // + c*32*16 + p*2*REGION
+
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+
+    for (int kc = 0; kc < nk; kc++) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) load_global(kc + 1);
+        const unsigned char *base = lds + buf * CS_BUF;
+        bf16x8 A[4][3], Bf[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) A[a][p] = *(const bf16x8 *)(base + a_off + a * 512 + p * 2 * CS_REGION);
+#pragma unroll
+            for (int c = 0; c < 2; c++) Bf[c][p] = *(const bf16x8 *)(base + b_off + c * 512 + p * 2 * CS_REGION);
+        }
+        // six products per tile, smallest terms first
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                f32x16 d = acc[a][c];
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][2], Bf[c][0], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], Bf[c][2], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][1], Bf[c][1], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][1], Bf[c][0], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], Bf[c][1], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], Bf[c][0], d, 0, 0, 0);
+                acc[a][c] = d;
+            }
+        if (kc + 1 < nk) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[co = 32a + (r&3) + 8(r>>2) + 4(lane>>5)][n = 32c + (lane&31)]
+    float *yb = y + (size_t)b * Cout * N;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int co = co0 + wm * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float sc = scale ? scale[co] : 1.f;
+            const float sh = shift ? shift[(size_t)b * shift_bstride + co] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                float v = acc[a][c][r] * sc + sh;
+                if (relu) v = fmaxf(v, 0.f);
+                yb[(size_t)co * N + n0 + wn * 64 + c * 32 + (lane & 31)] = v;
+            }
+        }
+}
+
+extern "C" size_t l3d_split_bytes(int rows, int cols)
+{
+    return (size_t)((cols + 15) / 16) * 3 * 2 * (size_t)rows * 16;
+}
+
+extern "C" int l3d_split_rows(const float *src, int rows, int cols, void *dst, l3d_stream_t stream)
+{
+    L3D_REQUIRE(src && dst && rows > 0 && cols > 0);
+    const long total = (long)rows * ((cols + 15) / 16) * 2;
+    hipLaunchKernelGGL(split_rows_kernel, dim3(l3d_divup(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       rows, cols, (uint4 *)dst);
+    return l3d_check_launch();
+}
+
+extern "C" int l3d_pointwise_conv_split(const void *x, int x_mode, const void *w_split, const float *scale,
+                                        const float *shift, int shift_bstride, int B, int Cin, int Cout,
+                                        int N, int relu, float *y, l3d_stream_t stream)
+{
+    L3D_REQUIRE(x && w_split && y && B > 0 && Cin > 0 && Cout > 0 && N > 0 && x_mode >= 0 && x_mode <= 2);
+    if (Cout % CS_TM || N % CS_TN || Cin % CS_TK || B > 65535 || (((size_t)x) & 15)) return L3D_ERR_UNSUPPORTED;
+    dim3 grid(N / CS_TN, Cout / CS_TM, B), block(512);
+    hipStream_t st = (hipStream_t)stream;
+    if (x_mode == 0)
+        hipLaunchKernelGGL(conv_split_kernel<0>, grid, block, CS_LDS, st, x, (const uint4 *)w_split, scale, shift,
+                           shift_bstride, B, Cin, Cout, N, relu, y);
+    else if (x_mode == 1)
+        hipLaunchKernelGGL(conv_split_kernel<1>, grid, block, CS_LDS, st, x, (const uint4 *)w_split, scale, shift,
+                           shift_bstride, B, Cin, Cout, N, relu, y);
+    else
+        hipLaunchKernelGGL(conv_split_kernel<2>, grid, block, CS_LDS, st, x, (const uint4 *)w_split, scale, shift,
+                           shift_bstride, B, Cin, Cout, N, relu, y);
+    return l3d_check_launch();
+}

@@ -88,10 +88,30 @@ def can_fuse(module, *tensors):
     return True
 
 
-def pointwise_conv(x, w, scale=None, shift=None, relu=False, channel_last=False):
+# fp32 products as six bf16 MFMA products (conv_split.hip): fp32-equivalent results at 6/16 of the
+# fp32-MFMA cost.  False routes every 1x1 conv through the fp32-MFMA kernel of mlp.hip.
+SPLIT_BF16 = True
+
+
+def split_rows(m):
+    """fp32 [rows, cols] (device) -> split + tiled bf16x3 image (uint8 tensor) for l3d_pointwise_conv_split"""
+    require_gpu(m)
+    m = f32c(m)
+    rows, cols = m.shape
+    out = torch.empty(lib().l3d_split_bytes(rows, cols), dtype=torch.uint8, device=m.device)
+    check(lib().l3d_split_rows(ptr(m), rows, cols, ptr(out), stream_ptr()), "l3d_split_rows")
+    return out
+
+
+def split_eligible(Cin, Cout, N):
+    return SPLIT_BF16 and Cout % 256 == 0 and N % 256 == 0 and Cin % 16 == 0 and Cin >= 32
+
+
+def pointwise_conv(x, w, scale=None, shift=None, relu=False, channel_last=False, w_split=None, split=None):
     """y[b,co,n] = act(scale[co] * sum_ci w[co,ci] x[b,ci,n] + shift[(b,)co]);  x [B,Cin,N] (or
     [B,N,Cin] when channel_last) -> [B,Cout,N].   == Conv1d(k=1) (+BN eval) (+ReLU).
-    shift may be [Cout] or per-cloud [B,Cout]."""
+    shift may be [Cout] or per-cloud [B,Cout].  w_split: cached split_rows(w) (else split per call,
+    a ~3 us kernel); split=False forces the fp32-MFMA kernel."""
     require_gpu(x)
     x = f32c(x)
     w = f32c(w)
@@ -105,6 +125,14 @@ def pointwise_conv(x, w, scale=None, shift=None, relu=False, channel_last=False)
     shift = f32c(shift) if shift is not None else None
     bstride = Cout if (shift is not None and shift.dim() == 2) else 0
     y = torch.empty((B, Cout, N), dtype=torch.float32, device=x.device)
+    use_split = split_eligible(Cin, Cout, N) if split is None else (split and split_eligible(Cin, Cout, N))
+    if use_split:
+        if w_split is None:
+            w_split = split_rows(w)
+        check(lib().l3d_pointwise_conv_split(ptr(x), int(channel_last), ptr(w_split), ptr(scale), ptr(shift), bstride,
+                                             B, Cin, Cout, N, int(relu), ptr(y), stream_ptr()),
+              "l3d_pointwise_conv_split")
+        return y
     check(lib().l3d_pointwise_conv(ptr(x), int(channel_last), ptr(w), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N,
                                    int(relu), ptr(y), stream_ptr()), "l3d_pointwise_conv")
     return y

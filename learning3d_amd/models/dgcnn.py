@@ -36,7 +36,9 @@ class DGCNN(torch.nn.Module):
         key = tuple((t.data_ptr(), t._version) for t in ts)
         if getattr(self, "_c5key", None) != key:
             w, s, b = _fused.fold_conv_bn(self.conv5, self.bn5)
-            self._c5 = (w.float().contiguous(), s.float().contiguous(), b.float().contiguous())
+            w = w.float().contiguous()
+            w_split = _fused.split_rows(w) if (_fused.SPLIT_BF16 and w.is_cuda) else None
+            self._c5 = (w, s.float().contiguous(), b.float().contiguous(), w_split)
             self._c5key = key
         return self._c5
 
@@ -55,9 +57,10 @@ class DGCNN(torch.nn.Module):
                                       [self.bn1, self.bn2, self.bn3, self.bn4], xyz.device)
             with _fused.stage("edgeconv"):
                 pooled = _fused.edgeconv_forward(xyz, idx, packed)      # dgcnn.py:34-46
-            w5, s5, b5 = self._conv5_folded()
+            w5, s5, b5, w5_split = self._conv5_folded()
             with _fused.stage("conv5"):
-                out = _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True)  # dgcnn.py:48
+                out = _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True,
+                                            w_split=w5_split)                                   # dgcnn.py:48
             return out
 
         output = get_graph_feature(input_data)

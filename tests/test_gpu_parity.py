@@ -376,6 +376,38 @@ def test_pointwise_conv_ragged_shapes():
         np.testing.assert_allclose(got_cl, want, rtol=1e-4, atol=1e-5)
 
 
+def test_conv_split_accuracy():
+    """bf16x3 (six bf16 MFMA products) vs an fp64 reference: its error must be at the fp32 level --
+    no worse than 1.5x the fp32-MFMA kernel's own error on the same inputs -- in all three x modes."""
+    from learning3d_amd.models import _fused
+    from learning3d_amd._lib import lib, check, ptr, stream_ptr
+    rng = np.random.default_rng(21)
+    for (B, Cin, Cout, N, scale_x) in [(2, 512, 1024, 1024, 1.0), (1, 64, 256, 256, 1e-3), (3, 320, 512, 512, 50.0)]:
+        x = (np.maximum(rng.standard_normal((B, N, Cin)), 0) * scale_x).astype(np.float32)     # post-ReLU like
+        w = (rng.standard_normal((Cout, Cin)) / np.sqrt(Cin)).astype(np.float32)
+        sc = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+        sh = (rng.uniform(-0.5, 0.5, (B, Cout)) * scale_x).astype(np.float32)
+        want = np.einsum("oc,bnc->bon", w.astype(np.float64), x.astype(np.float64)) * sc[None, :, None] + sh[:, :, None]
+        xd, wd, scd, shd = dev(x), dev(w), dev(sc), dev(sh)
+        f32 = _fused.pointwise_conv(xd, wd, scd, shd, channel_last=True, split=False).cpu().numpy()
+        spl = _fused.pointwise_conv(xd, wd, scd, shd, channel_last=True, split=True).cpu().numpy()
+        xcf = dev(np.ascontiguousarray(x.transpose(0, 2, 1)))
+        spl_cf = _fused.pointwise_conv(xcf, wd, scd, shd, channel_last=False, split=True).cpu().numpy()
+        # x_mode 2: x pre-split with the same splitter
+        xs = _fused.split_rows(xd.reshape(B * N, Cin))
+        ws = _fused.split_rows(wd)
+        y2 = torch.empty((B, Cout, N), dtype=torch.float32, device="cuda")
+        check(lib().l3d_pointwise_conv_split(ptr(xs), 2, ptr(ws), ptr(scd), ptr(shd), Cout, B, Cin, Cout, N, 0, ptr(y2),
+                                             stream_ptr()), "l3d_pointwise_conv_split")
+        e32 = np.abs(f32 - want)
+        for name, got in (("channel_last", spl), ("channel_first", spl_cf), ("presplit", y2.cpu().numpy())):
+            es = np.abs(got - want)
+            assert es.max() <= 1.5 * e32.max() + 1e-30, (name, B, Cin, Cout, N, es.max(), e32.max())
+            assert np.sqrt((es ** 2).mean()) <= 1.5 * np.sqrt((e32 ** 2).mean()), (name, "rms")
+        np.testing.assert_array_equal(spl, spl_cf)          # same products, same order
+        np.testing.assert_array_equal(spl, y2.cpu().numpy())
+
+
 def test_pcn_fused_matches_reference_order_path():
     from learning3d_amd.models import PCN
     torch.manual_seed(3)

@@ -60,9 +60,13 @@ def main():
         t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, chained=True))
         res["edgeconv_chained_c2"] = (t, B * N * k * 2 * 45440 / t / 1e6, "TFLOP/s")
         pooled = _fused.edgeconv_forward(x, idx, packed)
-        w5, s5, b5 = net._conv5_folded()
-        t = timeit(lambda: _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True))
-        res["conv5_c2"] = (t, B * N * 2 * 512 * 1024 / t / 1e6, "TFLOP/s")
+        w5, s5, b5, w5s = net._conv5_folded()
+        t = timeit(lambda: _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True, split=False))
+        res["conv5_f32mfma_c2"] = (t, B * N * 2 * 512 * 1024 / t / 1e6, "TFLOP/s")
+        t = timeit(lambda: _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True, w_split=w5s))
+        res["conv5_bf16x3_c2"] = (t, B * N * 2 * 512 * 1024 / t / 1e6, "TFLOP/s(fp32-equiv)")
+        t = timeit(lambda: _fused.split_rows(w5))
+        res["split_w5"] = (t, 1024 * 512 * 10 / t / 1e3, "GB/s")
         t = timeit(lambda: net(x))
         res["dgcnn_fwd_c2"] = (t, B / t * 1e6, "clouds/s")
         # c4 slice: Chamfer 2048 x 16384 (B=8 of 64) -- O(N^2) stress

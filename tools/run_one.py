@@ -13,7 +13,7 @@ with torch.no_grad():
     idx = U.knn(x.permute(0, 2, 1), 20)
     packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
     pooled = _fused.edgeconv_forward(x, idx, packed)
-    w5, s5, b5 = net._conv5_folded()
+    w5, s5, b5, w5s = net._conv5_folded()
     torch.cuda.synchronize()
     for _ in range(5):
         if what == "knn": U.knn(x.permute(0, 2, 1), 20)
