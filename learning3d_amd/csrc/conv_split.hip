@@ -33,6 +33,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef CS_PROBE
+#define CS_PROBE 0          // tools/probe_conv_split.hip: bit 0 no global loads, 1 no LDS stores, 2 no MFMA, 3 no LDS reads, 4 no barrier
+#endif
 #define CS_TM 256
 #define CS_TN 256
 #define CS_TK 16
@@ -107,6 +110,14 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const void *__restrict_
     const int wm = wave & 1, wn = wave >> 1;
     const int n0 = blockIdx.x * CS_TN, co0 = blockIdx.y * CS_TM, b = blockIdx.z;
     const int nk = Cin / CS_TK;
+    // Every workgroup walks the K chunks in a different rotation: otherwise all ~256 resident
+    // workgroups request the SAME 24 KB of W from L2 in the same microsecond (measured: W loads
+    // 3x slower than the x loads).  Workgroups that share an x tile (same blockIdx.x/z) share the
+    // rotation, so their x reads still coincide in L2.
+#ifndef CS_ROT
+#define CS_ROT 0
+#endif
+    const int rot = ((blockIdx.x + gridDim.x * blockIdx.z) * CS_ROT) % nk;
 
     // ---- staging assignments
     const int wrow = t & 255, wkg = t >> 8;                           // W (and pre-split X): 3 planes each
@@ -120,34 +131,46 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const void *__restrict_
     const int w_lds = wkg * CS_REGION + wrow * 16;                     // + p * 2 * CS_REGION
     const int x_lds = 6 * CS_REGION + ((XMODE == 2) ? w_lds : (xkg * CS_REGION + xrow * 16));
 
-    uint4 wreg[3], xs[3];
-    float xv[8];
+    // staging registers (plain scalars: arrays captured by lambdas ended up in scratch memory)
+    uint4 w0, w1, w2, x0, x1, x2;
+    f32x4 xa, xb;
 
-    auto load_global = [&](int kc) {
-#pragma unroll
-        for (int p = 0; p < 3; p++) wreg[p] = wsrc[((size_t)kc * 3 + p) * 2 * Cout];
-        if (XMODE == 2) {
-#pragma unroll
-            for (int p = 0; p < 3; p++) xs[p] = xsrc2[((size_t)kc * 3 + p) * 2 * BN];
-        } else if (XMODE == 1) {
-            const f32x4 a = *(const f32x4 *)(xsrc1 + kc * CS_TK);
-            const f32x4 c = *(const f32x4 *)(xsrc1 + kc * CS_TK + 4);
-            xv[0] = a[0]; xv[1] = a[1]; xv[2] = a[2]; xv[3] = a[3];
-            xv[4] = c[0]; xv[5] = c[1]; xv[6] = c[2]; xv[7] = c[3];
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; e++) xv[e] = xsrc0[((size_t)kc * CS_TK + e) * N];
-        }
-    };
-    auto store_lds = [&](int buf) {
-        unsigned char *base = lds + buf * CS_BUF;
-        if (XMODE != 2) split8(xv, xs[0], xs[1], xs[2]);
-#pragma unroll
-        for (int p = 0; p < 3; p++) {
-            *(uint4 *)(base + w_lds + p * 2 * CS_REGION) = wreg[p];
-            *(uint4 *)(base + x_lds + p * 2 * CS_REGION) = xs[p];
-        }
-    };
+#define CS_LOAD_GLOBAL(KCI)                                                                          \
+    do {                                                                                             \
+        const int kc_ = ((KCI) + rot >= nk) ? (KCI) + rot - nk : (KCI) + rot;                        \
+        w0 = wsrc[((size_t)kc_ * 3 + 0) * 2 * Cout];                                                 \
+        w1 = wsrc[((size_t)kc_ * 3 + 1) * 2 * Cout];                                                 \
+        w2 = wsrc[((size_t)kc_ * 3 + 2) * 2 * Cout];                                                 \
+        if (XMODE == 2) {                                                                            \
+            x0 = xsrc2[((size_t)kc_ * 3 + 0) * 2 * BN];                                              \
+            x1 = xsrc2[((size_t)kc_ * 3 + 1) * 2 * BN];                                              \
+            x2 = xsrc2[((size_t)kc_ * 3 + 2) * 2 * BN];                                              \
+        } else if (XMODE == 1) {                                                                     \
+            xa = *(const f32x4 *)(xsrc1 + kc_ * CS_TK);                                              \
+            xb = *(const f32x4 *)(xsrc1 + kc_ * CS_TK + 4);                                          \
+        } else {                                                                                     \
+            const float *q_ = xsrc0 + (size_t)kc_ * CS_TK * N;                                       \
+            xa[0] = q_[0]; xa[1] = q_[(size_t)N]; xa[2] = q_[(size_t)2 * N]; xa[3] = q_[(size_t)3 * N];                   \
+            xb[0] = q_[(size_t)4 * N]; xb[1] = q_[(size_t)5 * N]; xb[2] = q_[(size_t)6 * N]; xb[3] = q_[(size_t)7 * N];   \
+        }                                                                                            \
+    } while (0)
+
+#define CS_STORE_LDS(BUF)                                                                            \
+    do {                                                                                             \
+        unsigned char *base_ = lds + (BUF) * CS_BUF;                                                 \
+        if (XMODE != 2) {                                                                            \
+            split_pair(xa[0], xa[1], x0.x, x1.x, x2.x);                                              \
+            split_pair(xa[2], xa[3], x0.y, x1.y, x2.y);                                              \
+            split_pair(xb[0], xb[1], x0.z, x1.z, x2.z);                                              \
+            split_pair(xb[2], xb[3], x0.w, x1.w, x2.w);                                              \
+        }                                                                                            \
+        *(uint4 *)(base_ + w_lds) = w0;                                                              \
+        *(uint4 *)(base_ + w_lds + 2 * CS_REGION) = w1;                                              \
+        *(uint4 *)(base_ + w_lds + 4 * CS_REGION) = w2;                                              \
+        *(uint4 *)(base_ + x_lds) = x0;                                                              \
+        *(uint4 *)(base_ + x_lds + 2 * CS_REGION) = x1;                                              \
+        *(uint4 *)(base_ + x_lds + 4 * CS_REGION) = x2;                                              \
+    } while (0)
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -161,17 +184,19 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const void *__restrict_
     const int a_off = frag_kg + (wm * 128 + (lane & 31)) * 16;                       // + a*32*16 + p*2*REGION
     const int b_off = 6 * CS_REGION + frag_kg + (wn * 64 + (lane & 31)) * 16;        // + c*32*16 + p*2*REGION
 
-    load_global(0);
-    store_lds(0);
+    CS_LOAD_GLOBAL(0);
+    CS_STORE_LDS(0);
     __syncthreads();
 
     for (int kc = 0; kc < nk; kc++) {
         const int buf = kc & 1;
-        if (kc + 1 < nk) load_global(kc + 1);
+        const bool more = kc + 1 < nk;
+        if (!(CS_PROBE & 1) && more) CS_LOAD_GLOBAL(kc + 1);
         const unsigned char *base = lds + buf * CS_BUF;
         bf16x8 A[4][3], Bf[2][3];
 #pragma unroll
         for (int p = 0; p < 3; p++) {
+            if ((CS_PROBE & 8) && kc > 0) break;
 #pragma unroll
             for (int a = 0; a < 4; a++) A[a][p] = *(const bf16x8 *)(base + a_off + a * 512 + p * 2 * CS_REGION);
 #pragma unroll
@@ -183,6 +208,10 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const void *__restrict_
 #pragma unroll
             for (int c = 0; c < 2; c++) {
                 f32x16 d = acc[a][c];
+                if (CS_PROBE & 4) {
+                    asm volatile("" ::"v"(A[a][0]), "v"(A[a][1]), "v"(A[a][2]), "v"(Bf[c][0]), "v"(Bf[c][1]), "v"(Bf[c][2]));
+                    continue;
+                }
                 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][2], Bf[c][0], d, 0, 0, 0);
                 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], Bf[c][2], d, 0, 0, 0);
                 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][1], Bf[c][1], d, 0, 0, 0);
@@ -191,9 +220,11 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const void *__restrict_
                 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a][0], Bf[c][0], d, 0, 0, 0);
                 acc[a][c] = d;
             }
-        if (kc + 1 < nk) store_lds(buf ^ 1);
-        __syncthreads();
+        if (!(CS_PROBE & 2) && more) CS_STORE_LDS(buf ^ 1);
+        if (!(CS_PROBE & 16)) __syncthreads();
     }
+#undef CS_LOAD_GLOBAL
+#undef CS_STORE_LDS
 
     // ---- epilogue: D[co = 32a + (r&3) + 8(r>>2) + 4(lane>>5)][n = 32c + (lane&31)]
     float *yb = y + (size_t)b * Cout * N;

@@ -19,5 +19,5 @@ with torch.no_grad():
         if what == "knn": U.knn(x.permute(0, 2, 1), 20)
         elif what == "chamfer": ChamferDistance()(a, b)
         elif what == "edgeconv": _fused.edgeconv_forward(x, idx, packed)
-        elif what == "conv5": _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True)
+        elif what == "conv5": _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True, w_split=w5s)
     torch.cuda.synchronize()
