@@ -29,6 +29,8 @@ sys.path.insert(0, ROOT)
 B_PER_GPU, NPTS, KNN, EMB = 32, 1024, 20, 1024
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
 MFMA_F32_PEAK_TF = 157.3         # MI355X_MICROARCH.md: dense fp32 MFMA peak
+MFMA_BF16_PEAK_TF = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA peak (2.17 PF sustained in tools/probe_mfma_bf16.hip)
+SPLIT_PRODUCTS = 6               # bf16 MFMA products per fp32 product in the bf16x3 kernels
 # algorithmic work per cloud (restated in DESIGN.md)
 KNN_BYTES_PER_CLOUD = NPTS * 3 * 4 + NPTS * KNN * 8                 # 176 128 B
 CHAMFER_BYTES_PER_CLOUD = 2 * NPTS * 3 * 4 + 2 * NPTS * (4 + 4)     # 40 960 B
@@ -46,6 +48,26 @@ def pmc_traffic(tag):
             return json.load(f).get(tag, {}).get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         return None
+
+
+def edgeconv_roofline(ec_tf, ec_ms, split):
+    """MFMA roofline of the EdgeConv kernel on ALGORITHMIC fp32 flops.  fp32-MFMA kernel: peak = the
+    dense fp32 MFMA rate.  bf16x3 kernel: every algorithmic product is executed as 6 bf16 MFMA products,
+    so the ceiling for algorithmic flops is the dense bf16 MFMA peak / 6."""
+    alg = B_PER_GPU * EDGECONV_FLOP_PER_CLOUD
+    if not split:
+        return {"kernel": "edgeconv2_kernel<5>", "bound": "mfma", "achieved": ec_tf, "peak": MFMA_F32_PEAK_TF,
+                "unit": "TFLOP/s", "frac": ec_tf / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("edgeconv"),
+                "avg_launch_ms": ec_ms, "algorithmic_flop_per_launch": alg}
+    peak = MFMA_BF16_PEAK_TF / SPLIT_PRODUCTS
+    l1 = B_PER_GPU * NPTS * KNN * 2 * 6 * 64                       # layer 1 stays on the fp32 MFMA
+    return {"kernel": "edgeconv_split_kernel<5>", "bound": "mfma", "achieved": ec_tf, "peak": peak,
+            "unit": "TFLOP/s", "frac": ec_tf / peak, "traffic": pmc_traffic("edgeconv_split"),
+            "avg_launch_ms": ec_ms, "algorithmic_flop_per_launch": alg,
+            "peak_note": "fp32-equivalent ceiling = dense bf16 MFMA peak 2500 TFLOP/s / 6 products per fp32 product "
+                         "(the fp32 MFMA peak is 157.3 TFLOP/s)",
+            "executed_bf16_tflops": SPLIT_PRODUCTS * (alg - l1) / (ec_ms * 1e-3) / 1e12,
+            "bf16_dense_peak": MFMA_BF16_PEAK_TF}
 
 
 def cpu_baseline(sample_clouds=8, repeats=2):
@@ -94,10 +116,14 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp32-mfma", action="store_true",
+                    help="run the shared-MLP GEMMs on the fp32 MFMA (157 TF peak) instead of the bf16x3 kernels")
     args = ap.parse_args()
 
     from learning3d_amd import parallel
     from learning3d_amd.models import DGCNN, _fused
+    if args.fp32_mfma:
+        _fused.SPLIT_BF16 = False
     from learning3d_amd.losses.chamfer_distance import ChamferDistance, chamfer_partials
     import torch.distributed as dist
 
@@ -172,20 +198,21 @@ def main():
         knn_gbs = B_PER_GPU * KNN_BYTES_PER_CLOUD / (stage_ms["knn"] * 1e-3) / 1e9
         ch_gbs = B_PER_GPU * CHAMFER_BYTES_PER_CLOUD / (stage_ms["chamfer"] * 1e-3) / 1e9
         c5_tf = B_PER_GPU * CONV5_FLOP_PER_CLOUD / (stage_ms["conv5"] * 1e-3) / 1e12
+        split = _fused.SPLIT_BF16
+        dtype = ("f32 (shared-MLP GEMMs as bf16x3: fp32 operands split exactly into 3 bf16 planes, 6 bf16 MFMA "
+                 "products per fp32 product, f32 accumulate, fp32-level error; distances/top-k/Chamfer plain f32)"
+                 if split else "f32")
         out = {
             "metric": "clouds/sec DGCNN-fwd+Chamfer B=32 N=1024; kNN HBM GB/s vs peak at 1/2/4/8 GPU",
             "value": clouds_per_s, "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "configs[1]: DGCNN k=20 kNN + EdgeConv forward (emb_dims=1024, eval, random-init "
                                    "weights) + ChamferDistanceLoss, B=32 clouds per GPU, N=1024, inputs resident in HBM",
                        "global_batch": world * B_PER_GPU, "num_points": NPTS, "k": KNN, "emb_dims": EMB,
                        "parallelism": f"batch-sharded x{world}, all_gather of loss partials only"},
-            # dominant kernel by time: the fused 4-layer EdgeConv stack on fp32 MFMA
-            "roofline": {"kernel": "edgeconv2_kernel<5>", "bound": "mfma", "achieved": ec_tf,
-                         "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": ec_tf / MFMA_F32_PEAK_TF,
-                         "traffic": pmc_traffic("edgeconv"), "avg_launch_ms": stage_ms["edgeconv"],
-                         "algorithmic_flop_per_launch": B_PER_GPU * EDGECONV_FLOP_PER_CLOUD},
+            # dominant kernel by time: the fused 4-layer EdgeConv stack
+            "roofline": edgeconv_roofline(ec_tf, stage_ms["edgeconv"], split),
             # the metric's second half: kNN (and Chamfer) HBM rate on ALGORITHMIC bytes
             "roofline_knn": {"kernel": "topk_scan_kernel<20,expanded>", "bound": "hbm", "achieved": knn_gbs,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": knn_gbs / HBM_PEAK_GBS,

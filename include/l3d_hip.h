@@ -187,6 +187,12 @@ int l3d_edgeconv_forward(const float *xyz, const int64_t *idx, int B, int N, int
  * MFMA accumulator layout of one layer into the B operand of the next.  k <= 20. */
 int l3d_edgeconv_forward_chained(const float *xyz, const int64_t *idx, int B, int N, int k,
                                  const float *packed, float *pooled, l3d_stream_t stream);
+/* Same computation, same packed block (its third weight copy), same output layout; layers 2-4 run on
+ * the bf16 matrix cores with every fp32 operand split exactly into three bf16 planes and six bf16
+ * products per fp32 product ("bf16x3", fp32 accumulate; edgeconv_split.hip) -- fp32-level error at a
+ * fraction of the fp32-MFMA time.  k <= 20; packed must be 16-byte aligned. */
+int l3d_edgeconv_forward_split(const float *xyz, const int64_t *idx, int B, int N, int k,
+                               const float *packed, float *pooled, l3d_stream_t stream);
 /* Per-point linear layer (Conv1d/Conv2d 1x1 + folded BN + optional ReLU):
  *   y[b][co][n] = act(scale[co] * sum_ci w[co][ci] x[b][ci][n] + shift[co])
  *   x [B,Cin,N] (x_channel_last = 0, torch Conv1d layout) or [B,N,Cin] (x_channel_last = 1),

@@ -32,12 +32,37 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   layer 1: Cin 6 padded to 8, KV = 2;  layers 2-4: KV = 4
 //   then the four bias (= BN shift) vectors.
 // ---------------------------------------------------------------------------------------------
+#include <string.h>
 #include "edgeconv_layout.h"
 
 extern "C" size_t l3d_edgeconv_packed_floats(int c1, int c2, int c3, int c4)
 {
     if (c1 != EC_C1 || c2 != EC_C2 || c3 != EC_C3 || c4 != EC_C4) return 0;
     return EC_PACKED_FLOATS;
+}
+
+// host-side fp32 -> three bf16 (round-to-nearest-even), v = h + m + l exactly for finite v
+static inline uint16_t l3d_f2bf_host(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);      // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float l3d_bf2f_host(uint16_t h)
+{
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline void l3d_split3_host(float v, uint16_t (&pl)[3])
+{
+    pl[0] = l3d_f2bf_host(v);
+    const float r = v - l3d_bf2f_host(pl[0]);
+    pl[1] = l3d_f2bf_host(r);
+    pl[2] = l3d_f2bf_host(r - l3d_bf2f_host(pl[1]));
 }
 
 static void pack_layer(const float *w /*[cout][cin]*/, const float *scale, int cin, int cin_pad,
@@ -100,6 +125,29 @@ extern "C" int l3d_edgeconv_pack(const float *const w[4], const float *const sca
                         }
             }
         }
+    }
+    // third copy (layers 2-4) for the bf16x3 kernel (edgeconv_split.hip): W' = h + m + l exactly,
+    //   block [step = m*S + s][plane][lane][slot 8]:
+    //   slot e (0..3) = W'[16m + (lane&15)][32s + 4(lane>>4) + e],  slot 4+e = W'[..][32s + 16 + 4(lane>>4) + e]
+    const int o3[4] = {0, EC3_OFF_W2, EC3_OFF_W3, EC3_OFF_W4};
+    for (int l = 1; l < 4; l++) {
+        const float *wl = w[l];
+        const float *sc = scale ? scale[l] : nullptr;
+        uint16_t *dst = (uint16_t *)(packed + o3[l]);
+        const int S = cin[l] / 32;
+        for (int m = 0; m < cs[l] / 16; m++)
+            for (int sidx = 0; sidx < S; sidx++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int slot = 0; slot < 8; slot++) {
+                        const int oc = 16 * m + (lane & 15);
+                        const int ic = 32 * sidx + 16 * (slot >> 2) + 4 * (lane >> 4) + (slot & 3);
+                        float v = wl[(size_t)oc * cin[l] + ic];
+                        if (sc) v *= sc[oc];
+                        uint16_t pl[3];
+                        l3d_split3_host(v, pl);
+                        for (int p = 0; p < 3; p++)
+                            dst[((((size_t)m * S + sidx) * 3 + p) * 64 + lane) * 8 + slot] = pl[p];
+                    }
     }
     return L3D_OK;
 }

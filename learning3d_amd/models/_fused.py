@@ -170,18 +170,28 @@ class EdgeConvParams:
         return self.packed
 
 
-EDGECONV_CHAINED = True     # register-chained kernel (edgeconv2.hip) for k <= 20; LDS kernel otherwise
+# EdgeConv kernel choice: "split" = register-chained, layers 2-4 as bf16x3 on the bf16 matrix cores
+# (edgeconv_split.hip); "chained" = register-chained on the fp32 MFMA (edgeconv2.hip); "lds" = the
+# LDS-staged fp32-MFMA kernel (mlp.hip, any k <= 32).  The first two need k <= 20.
+EDGECONV_KERNEL = "split"
 
 
-def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256), chained=None):
+def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256), kernel=None):
     """xyz [B,N,3], idx int64 [B,N,k] -> pooled [B,N,sum(widths)] (channel-last)."""
     require_gpu(xyz_bn3, idx, packed)
     B, N, _ = xyz_bn3.shape
     k = idx.shape[2]
     pooled = torch.empty((B, N, sum(widths)), dtype=torch.float32, device=xyz_bn3.device)
-    if chained is None:
-        chained = EDGECONV_CHAINED
-    if chained and k <= 20 and tuple(widths) == (64, 64, 128, 256):
+    if kernel is None:
+        kernel = EDGECONV_KERNEL if SPLIT_BF16 or EDGECONV_KERNEL != "split" else "chained"
+    if kernel not in ("split", "chained", "lds"):
+        raise ValueError(f"unknown EdgeConv kernel {kernel!r}")
+    if kernel != "lds" and (k > 20 or tuple(widths) != (64, 64, 128, 256)):
+        kernel = "lds"
+    if kernel == "split":
+        check(lib().l3d_edgeconv_forward_split(ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), ptr(pooled),
+                                               stream_ptr()), "l3d_edgeconv_forward_split")
+    elif kernel == "chained":
         check(lib().l3d_edgeconv_forward_chained(ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), ptr(pooled),
                                                  stream_ptr()), "l3d_edgeconv_forward_chained")
     else:

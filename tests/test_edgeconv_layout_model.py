@@ -12,6 +12,8 @@ import pytest
 from learning3d_amd import _lib
 
 C1, C2, C3, C4 = 64, 64, 128, 256
+# third weight copy (layers 2-4) for the bf16x3 kernel: [m][s][plane 3][lane 64][8 bf16] = 4 floats per fragment
+SPLIT_FLOATS = ((C2 // 16) * (C1 // 32) + (C3 // 16) * (C2 // 32) + (C4 // 16) * (C3 // 32)) * 3 * 64 * 4
 MT = 5
 
 
@@ -72,7 +74,7 @@ def test_edgeconv_fragment_layout_and_row_mapping():
     scs = [rng.uniform(0.5, 1.5, c).astype(np.float32) for c in (C1, C2, C3, C4)]
     shs = [rng.uniform(-0.2, 0.2, c).astype(np.float32) for c in (C1, C2, C3, C4)]
     n = lib.l3d_edgeconv_packed_floats(C1, C2, C3, C4)
-    assert n == 2 * (8 * C1 + C1 * C2 + C2 * C3 + C3 * C4) + C1 + C2 + C3 + C4     # v1 + chained layouts + biases
+    assert n == 2 * (8 * C1 + C1 * C2 + C2 * C3 + C3 * C4) + C1 + C2 + C3 + C4 + SPLIT_FLOATS   # v1 + chained + biases + bf16x3
     packed = np.zeros(n, np.float32)
     arr = lambda xs: (C.c_void_p * 4)(*[x.ctypes.data for x in xs])
     assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), C1, C2, C3, C4, packed.ctypes.data) == 0
@@ -127,7 +129,7 @@ def test_edgeconv_chained_register_layout():
     shs = [rng.uniform(-0.2, 0.2, c).astype(np.float32) for c in (C1, C2, C3, C4)]
     n = lib.l3d_edgeconv_packed_floats(C1, C2, C3, C4)
     v1 = 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4 + C1 + C2 + C3 + C4
-    assert n == v1 + 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4
+    assert n == v1 + 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4 + SPLIT_FLOATS
     packed = np.zeros(n, np.float32)
     arr = lambda xs: (C.c_void_p * 4)(*[x.ctypes.data for x in xs])
     assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), C1, C2, C3, C4, packed.ctypes.data) == 0
@@ -214,3 +216,156 @@ def test_edgeconv_chained_register_layout():
             outs.append(hh.max(axis=0))
         want.append(np.concatenate(outs))
     np.testing.assert_allclose(got, np.stack(want), rtol=1e-6, atol=1e-6)
+
+
+
+def _bf16_round(x):
+    """fp32 -> nearest-even bf16, returned as float32 (numpy model of v_cvt_pk_bf16_f32)"""
+    u = np.asarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7fff + ((u >> 16) & 1)) >> 16) << 16
+    return u.astype(np.uint32).view(np.float32)
+
+
+def _split3(x):
+    x = np.asarray(x, np.float32)
+    h = _bf16_round(x)
+    r = x - h
+    m = _bf16_round(r)
+    return h, m, _bf16_round(r - m)
+
+
+def test_edgeconv_split_bf16x3_layout():
+    """CPU model of edgeconv_split_kernel (edgeconv_split.hip): layers 2-4 as v_mfma_f32_16x16x32_bf16
+    with weights (A) from the third packed copy and activations (B) built in-lane from PAIRS of
+    previous-layer accumulators: k-step s, lane group g, slot 4u+e <-> channel 16(2s+u) + 4g + e.
+    Checks that packing, the host-side split (planes sum EXACTLY to the folded fp32 weight), the slot
+    permutation and the six-product sum reproduce the layer stack."""
+    lib = _lib.lib()
+    rng = np.random.default_rng(2)
+    ws = [rng.standard_normal((C1, 6)).astype(np.float32), rng.standard_normal((C2, C1)).astype(np.float32) * 0.2,
+          rng.standard_normal((C3, C2)).astype(np.float32) * 0.2, rng.standard_normal((C4, C3)).astype(np.float32) * 0.1]
+    scs = [rng.uniform(0.5, 1.5, c).astype(np.float32) for c in (C1, C2, C3, C4)]
+    shs = [rng.uniform(-0.2, 0.2, c).astype(np.float32) for c in (C1, C2, C3, C4)]
+    n = lib.l3d_edgeconv_packed_floats(C1, C2, C3, C4)
+    packed = np.zeros(n, np.float32)
+    arr = lambda xs: (C.c_void_p * 4)(*[x.ctypes.data for x in xs])
+    assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), C1, C2, C3, C4, packed.ctypes.data) == 0
+    v1 = 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4 + C1 + C2 + C3 + C4
+    o_b = [8 * C1 + C1 * C2 + C2 * C3 + C3 * C4]
+    o_b += [o_b[0] + C1, o_b[0] + C1 + C2, o_b[0] + C1 + C2 + C3]
+    o2_w1 = v1
+    o3 = v1 + 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4
+    lanes = np.arange(64)
+    j, g = lanes & 15, lanes >> 4
+
+    # ---- the split weight copy: decode, check exactness and the slot permutation
+    planes = {}
+    off = o3
+    for li, (cin, cout) in enumerate([(C1, C2), (C2, C3), (C3, C4)], start=1):
+        S, M = cin // 32, cout // 16
+        cnt = M * S * 3 * 64 * 4
+        raw = packed[off:off + cnt].view(np.uint16).reshape(M, S, 3, 64, 8)
+        f = (raw.astype(np.uint32) << 16).view(np.float32)                 # bf16 -> fp32
+        planes[li] = f
+        folded = (ws[li] * scs[li][:, None]).astype(np.float32)
+        for m in range(M):
+            for s_ in range(S):
+                for slot in range(8):
+                    oc = 16 * m + j
+                    ic = 32 * s_ + 16 * (slot >> 2) + 4 * g + (slot & 3)
+                    tot = f[m, s_, 0, :, slot].astype(np.float64) + f[m, s_, 1, :, slot] + f[m, s_, 2, :, slot]
+                    np.testing.assert_array_equal(tot.astype(np.float32), folded[oc, ic])
+        off += cnt
+    assert off == n
+
+    # ---- lane-level forward for one wave (4 points x 20 neighbours)
+    N, k = 16, 20
+    xyz = rng.uniform(0, 1, (N, 3)).astype(np.float32)
+    idx = rng.integers(0, N, (N, k))
+    n0 = 4
+    pk = packed.astype(np.float64)
+
+    def mfma_f32(a, b, acc):                       # 16x16x4 fp32, as in the chained model above
+        D = a.reshape(4, 16).T @ b.reshape(4, 16)
+        out = acc.copy()
+        for i in range(16):
+            out[16 * (i // 4) + np.arange(16), i % 4] += D[i]
+        return out
+
+    def mfma_bf16(a, b, acc):                      # a, b: [64 lanes][8 slots]; k index = 8*(lane>>4) + slot
+        A = np.zeros((16, 32)); Bm = np.zeros((32, 16))
+        for l in range(64):
+            A[l & 15, 8 * (l >> 4):8 * (l >> 4) + 8] = a[l]
+            Bm[8 * (l >> 4):8 * (l >> 4) + 8, l & 15] = b[l]
+        D = A @ Bm
+        out = acc.copy()
+        for i in range(16):
+            out[16 * (i // 4) + np.arange(16), i % 4] += D[i]
+        return out
+
+    def bias_init(off_b, m):
+        acc = np.zeros((64, 4))
+        for r in range(4):
+            acc[:, r] = pk[off_b + 16 * m + 4 * g + r]
+        return acc
+
+    pooled = {}
+    def pool(h_m, choff, m):
+        mx = np.max(np.stack(h_m), axis=0)
+        for l in range(64):
+            q0 = l & ~3
+            val = mx[q0:q0 + 4].max(axis=0)
+            for r in range(4):
+                pooled[(n0 + (j[l] >> 2), choff + 16 * m + 4 * g[l] + r)] = val[r]
+
+    # layer 1 (fp32 MFMA)
+    w1 = pk[o2_w1:o2_w1 + 8 * C1].reshape(C1 // 16, 64, 2)
+    h = []
+    for m in range(C1 // 16):
+        row = []
+        for t in range(MT):
+            b1 = np.zeros((2, 64))
+            for l in range(64):
+                p, nbr = n0 + (j[l] >> 2), 4 * t + (j[l] & 3)
+                f = np.concatenate([xyz[idx[p, nbr]], xyz[p], [0, 0]])
+                b1[0, l], b1[1, l] = f[g[l]], f[4 + g[l]]
+            acc = bias_init(o_b[0], m)
+            for s_ in range(2):
+                acc = mfma_f32(w1[m, :, s_], b1[s_], acc)
+            row.append(np.maximum(acc, 0).astype(np.float32))
+        pool(row, 0, m)
+        h.append(row)
+    choff = C1
+    for li, (cin, cout) in enumerate([(C1, C2), (C2, C3), (C3, C4)], start=1):
+        S, M = cin // 32, cout // 16
+        # B planes per k-step: slots 0..3 = M-tile 2s regs, 4..7 = M-tile 2s+1 regs (in-lane)
+        bpl = [[None] * MT for _ in range(S)]
+        for s_ in range(S):
+            for t in range(MT):
+                v = np.concatenate([h[2 * s_][t], h[2 * s_ + 1][t]], axis=1)       # [64, 8]
+                bpl[s_][t] = _split3(v)
+        hn = []
+        for m in range(M):
+            row = []
+            for t in range(MT):
+                acc = bias_init(o_b[li], m)
+                for s_ in range(S):
+                    a = planes[li][m, s_]                                          # [3][64][8]
+                    xh, xm, xl = bpl[s_][t]
+                    for (pa, xb) in ((2, xh), (0, xl), (1, xm), (1, xh), (0, xm), (0, xh)):
+                        acc = mfma_bf16(a[pa].astype(np.float64), xb.astype(np.float64), acc)
+                row.append(np.maximum(acc, 0).astype(np.float32))
+            pool(row, choff, m)
+            hn.append(row)
+        h = hn
+        choff += cout
+    got = np.array([[pooled[(n0 + p, c)] for c in range(C1 + C2 + C3 + C4)] for p in range(4)])
+    want = []
+    for p in range(4):
+        f = np.concatenate([xyz[idx[n0 + p]], np.repeat(xyz[n0 + p][None], k, 0)], axis=1).astype(np.float64)
+        outs, hh = [], f
+        for w, sc, sh in zip(ws, scs, shs):
+            hh = np.maximum((hh @ (w * sc[:, None]).astype(np.float32).astype(np.float64).T) + sh, 0.0)
+            outs.append(hh.max(axis=0))
+        want.append(np.concatenate(outs))
+    np.testing.assert_allclose(got, np.stack(want), rtol=2e-6, atol=2e-6)

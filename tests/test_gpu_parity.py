@@ -320,9 +320,10 @@ def test_dgcnn_full_size_vs_oracle_port():
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
 
 
-def test_edgeconv_both_kernels_agree_and_ragged():
-    """LDS-staged (mlp.hip) and register-chained (edgeconv2.hip) EdgeConv kernels against a torch fp64
-    evaluation, including N not a multiple of 16 and k < 20."""
+def test_edgeconv_all_kernels_agree_and_ragged():
+    """LDS-staged (mlp.hip), register-chained fp32-MFMA (edgeconv2.hip) and register-chained bf16x3
+    (edgeconv_split.hip) EdgeConv kernels against a torch fp64 evaluation, including N not a multiple
+    of 16 and k < 20.  The bf16x3 kernel must be as close to fp64 as the fp32-MFMA kernels are."""
     from learning3d_amd.models import DGCNN, _fused
     import learning3d_amd.utils as U
     torch.manual_seed(4)
@@ -335,8 +336,9 @@ def test_edgeconv_both_kernels_agree_and_ragged():
         with torch.no_grad():
             idx = U.knn(x.permute(0, 2, 1), k)
             packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
-            a = _fused.edgeconv_forward(x, idx, packed, chained=False)
-            c = _fused.edgeconv_forward(x, idx, packed, chained=True)
+            a = _fused.edgeconv_forward(x, idx, packed, kernel="lds")
+            c = _fused.edgeconv_forward(x, idx, packed, kernel="chained")
+            sp = _fused.edgeconv_forward(x, idx, packed, kernel="split")
             # fp64 torch evaluation of dgcnn.py:32-46 on the same graph
             nb = torch.gather(x.unsqueeze(1).expand(B, N, N, 3), 2, idx.unsqueeze(-1).expand(B, N, k, 3))
             h = torch.cat([nb, x.unsqueeze(2).expand(B, N, k, 3)], dim=3).permute(0, 3, 1, 2).double()
@@ -346,8 +348,14 @@ def test_edgeconv_both_kernels_agree_and_ragged():
                 h = torch.relu(torch.einsum("oc,bcnk->bonk", w.double(), h) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
                 outs.append(h.max(dim=-1)[0])
             want = torch.cat(outs, dim=1).permute(0, 2, 1).float().cpu().numpy()
+            want64 = torch.cat(outs, dim=1).permute(0, 2, 1).cpu().numpy()
         np.testing.assert_allclose(a.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(c.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(sp.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
+        e_c = np.abs(c.cpu().numpy() - want64)
+        e_s = np.abs(sp.cpu().numpy() - want64)
+        assert e_s.max() <= 2.0 * e_c.max() + 1e-30, (B, N, k, e_s.max(), e_c.max())
+        assert np.sqrt((e_s ** 2).mean()) <= 1.5 * np.sqrt((e_c ** 2).mean()), (B, N, k)
 
 
 def test_pointnet_golden(golden):

@@ -55,10 +55,12 @@ def main():
         net = DGCNN(emb_dims=1024).to(dev).eval()
         idx = U.knn(xt, k)
         packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
-        t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, chained=False))
+        t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, kernel="lds"))
         res["edgeconv_lds_c2"] = (t, B * N * k * 2 * 45440 / t / 1e6, "TFLOP/s")
-        t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, chained=True))
+        t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, kernel="chained"))
         res["edgeconv_chained_c2"] = (t, B * N * k * 2 * 45440 / t / 1e6, "TFLOP/s")
+        t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, kernel="split"))
+        res["edgeconv_bf16x3_c2"] = (t, B * N * k * 2 * 45440 / t / 1e6, "TFLOP/s(fp32-equiv)")
         pooled = _fused.edgeconv_forward(x, idx, packed)
         w5, s5, b5, w5s = net._conv5_folded()
         t = timeit(lambda: _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True, split=False))

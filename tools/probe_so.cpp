@@ -13,7 +13,7 @@ int main(int argc, char **argv)
     if (!h) { printf("dlopen failed %s\n", dlerror()); return 1; }
     chained_t chained = (chained_t)dlsym(h, "l3d_edgeconv_forward_chained");
     lds_t lds = (lds_t)dlsym(h, "l3d_edgeconv_forward");
-    const int B = 32, N = 1024, K = 20, NP = 46080 + 45568;
+    const int B = 32, N = 1024, K = 20, NP = 46080 + 45568 + 67584;
     float *xyz, *packed, *pooled; int64_t *idx;
     hipMalloc(&xyz, 4 * B * N * 3); hipMalloc(&idx, 8 * B * N * K); hipMalloc(&packed, 4 * NP); hipMalloc(&pooled, 4 * (size_t)B * N * 512);
     std::vector<float> hv(B * N * 3 + NP);
