@@ -71,82 +71,207 @@ __device__ __forceinline__ void es_finish_pair(f32x4 (&h0)[MT], f32x4 (&h1)[MT],
 }
 
 #define ES_BF(u) __builtin_bit_cast(bf16x8, (u))
+#ifndef ES_VPM
+#define ES_VPM 4            // VALU instructions the scheduler may place after each MFMA of a group
+#endif
 
 // One output M-tile pair of a dense layer: 2 x S steps of {prefetch fragment step+2, 6 x MT MFMAs}.
-template <int MT, int S, int NSTEP, bool LAST>
-__device__ __forceinline__ void es_pair(int mp, const uint4 (&pin)[S][3][MT], uint4 (&po)[3][MT],
-                                        const uint4 *__restrict__ wp, uint4 (&a0)[3], uint4 (&a1)[3],
-                                        const float *__restrict__ bias, float *__restrict__ prow, bool writer, int g)
+// ---------------------------------------------------------------------------------------------
+// The finish work of a completed M-tile pair (ReLU, max-pool, three-way split) cut into small units so
+// that it can be issued BETWEEN the MFMAs of the next pair: with one wave per SIMD nothing else hides
+// VALU work, and a VALU instruction issued in the shadow of a 16-cycle MFMA is free.
+//   per row tile t:  [relu+max of h0[t]] [relu+max of h1[t]] ([split h0[t]] [split h1[t]] unless LAST)
+//   then [quad max + store of M-tile 2s] [same for 2s+1]
+// ---------------------------------------------------------------------------------------------
+template <bool LAST> struct EsUnits { static constexpr int PER_T = LAST ? 2 : 4; };
+
+// Home a freshly split fragment word in the accumulation half of the register file: the layer-4
+// input planes (240 registers for MT = 5) are only ever read as MFMA B operands, which may be AGPRs;
+// left to itself the allocator keeps them in VGPRs, runs out, and reloads spilled words before every use.
+__device__ __forceinline__ uint32_t es_to_agpr(uint32_t v)
 {
-    f32x4 acc[2][MT];
+    uint32_t r;
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(r) : "v"(v));
+    return r;
+}
+
+template <int MT, bool LAST, bool AGPR_OUT = false>
+__device__ __forceinline__ void es_finish_unit(int u, f32x4 (&h)[2][MT], uint4 (&pl)[3][MT], f32x4 (&mx)[2],
+                                               float *__restrict__ dst, bool writer)
+{
+    constexpr int PER_T = EsUnits<LAST>::PER_T;
+    const int t = u / PER_T, k = u % PER_T;
+    if (t < MT) {
+        if (k < 2) {                                         // relu + running max of M-tile k
 #pragma unroll
-    for (int mm = 0; mm < 2; mm++) {
-        const f32x4 bv = *(const f32x4 *)(bias + 16 * (2 * mp + mm) + 4 * g);
+            for (int r = 0; r < 4; r++) {
+                h[k][t][r] = fmaxf(h[k][t][r], 0.f);
+                mx[k][r] = t == 0 ? h[k][t][r] : fmaxf(mx[k][r], h[k][t][r]);
+            }
+        } else {
+            uint32_t q[2][3];
+            split_pair(h[k - 2][t][0], h[k - 2][t][1], q[0][0], q[0][1], q[0][2]);
+            split_pair(h[k - 2][t][2], h[k - 2][t][3], q[1][0], q[1][1], q[1][2]);
 #pragma unroll
-        for (int t = 0; t < MT; t++) acc[mm][t] = bv;
+            for (int p = 0; p < 3; p++) {
+                const uint32_t lo = AGPR_OUT ? es_to_agpr(q[0][p]) : q[0][p];
+                const uint32_t hi = AGPR_OUT ? es_to_agpr(q[1][p]) : q[1][p];
+                if (k == 2) { pl[p][t].x = lo; pl[p][t].y = hi; } else { pl[p][t].z = lo; pl[p][t].w = hi; }
+            }
+        }
+    } else {                                                 // u = MT*PER_T + k, k = 0, 1: pooled store
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = es_quad_max(mx[k][r]);
+        if (writer) *(f32x4 *)(dst + 16 * k) = v;
     }
+}
+template <int MT, bool LAST> struct EsN { static constexpr int UNITS = MT * EsUnits<LAST>::PER_T + 2; };
+
+template <int MT, bool LAST, bool AGPR_OUT = false>
+__device__ __forceinline__ void es_finish_all(f32x4 (&h)[2][MT], uint4 (&pl)[3][MT], float *__restrict__ dst, bool writer)
+{
+    f32x4 mx[2];
+#pragma unroll
+    for (int u = 0; u < EsN<MT, LAST>::UNITS; u++) es_finish_unit<MT, LAST, AGPR_OUT>(u, h, pl, mx, dst, writer);
+}
+
+// ES_PIN: the compiler's IR passes sink a load towards its first use (two steps later) regardless of
+// sched_barrier, which collapses the prefetch distance; a memory clobber right after the issue pins it
+// (the fragment pointer is deliberately NOT __restrict__, or the clobber would not order the load).
+#define ES_PIN() asm volatile("" ::: "memory")
+
+// One output M-tile pair of a dense layer: 2 x S steps of {prefetch fragment step+2, 6 groups of MT
+// MFMAs}, with the finish units of the PREVIOUS pair (hp, if HAS_PREV) spread over the groups.
+// mp = this pair, mp_next = the pair executed after it (fragment and bias prefetches cross the pair
+// boundary); pairs may be executed in any order.  bv: this pair's bias, loaded during the previous
+// pair; replaced by the next pair's on return.
+template <int MT, int S, bool LAST, bool HAS_PREV, bool AGPR_OUT>
+__device__ __forceinline__ void es_pair(int mp, int mp_next, const uint4 (&pin)[S][3][MT], const uint4 *wp,
+                                        uint4 (&a0)[3], uint4 (&a1)[3], f32x4 (&bv)[2], const float *__restrict__ bias,
+                                        f32x4 (&acc)[2][MT], f32x4 (&hp)[2][MT], uint4 (&po_prev)[3][MT],
+                                        float *__restrict__ dst_prev, bool writer_prev, int g)
+{
+    constexpr int NG = 2 * S * 6;                              // MFMA groups in this pair
+    constexpr int NU = HAS_PREV ? EsN<MT, LAST>::UNITS : 0;    // finish units to hide among them
+#pragma unroll
+    for (int mm = 0; mm < 2; mm++)
+#pragma unroll
+        for (int t = 0; t < MT; t++) acc[mm][t] = bv[mm];
+    bv[0] = *(const f32x4 *)(bias + 32 * mp_next + 4 * g);
+    bv[1] = *(const f32x4 *)(bias + 32 * mp_next + 16 + 4 * g);
+    f32x4 mx[2];
 #pragma unroll
     for (int mm = 0; mm < 2; mm++)
 #pragma unroll
         for (int s = 0; s < S; s++) {
-            const int step = (2 * mp + mm) * S + s;
-            const int nxt = step + 2 < NSTEP ? step + 2 : NSTEP - 1;
+            // fragment two execution steps ahead: inside this pair, or the first two of the next pair
+            const int r = mm * S + s;
+            const int nxt = r + 2 < 2 * S ? mp * 2 * S + r + 2 : mp_next * 2 * S + (r + 2 - 2 * S);
             uint4 a2[3];
 #pragma unroll
             for (int p = 0; p < 3; p++) a2[p] = wp[(size_t)(nxt * 3 + p) * 64];
+            ES_PIN();
             __builtin_amdgcn_sched_barrier(0);
             // six products, smallest first; MT independent accumulators between dependent MFMAs
 #pragma unroll
-            for (int t = 0; t < MT; t++) acc[mm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ES_BF(a0[2]), ES_BF(pin[s][0][t]), acc[mm][t], 0, 0, 0);
+            for (int prod = 0; prod < 6; prod++) {
+                const int pa = prod == 0 ? 2 : (prod == 2 || prod == 3) ? 1 : 0;      // W plane: l h m m h h
+                const int pb = prod == 1 ? 2 : (prod == 2 || prod == 4) ? 1 : 0;      // x plane: h l m h m h
 #pragma unroll
-            for (int t = 0; t < MT; t++) acc[mm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ES_BF(a0[0]), ES_BF(pin[s][2][t]), acc[mm][t], 0, 0, 0);
+                for (int t = 0; t < MT; t++)
+                    acc[mm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ES_BF(a0[pa]), ES_BF(pin[s][pb][t]), acc[mm][t], 0, 0, 0);
+                if (HAS_PREV) {
+                    const int gi = r * 6 + prod;
 #pragma unroll
-            for (int t = 0; t < MT; t++) acc[mm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ES_BF(a0[1]), ES_BF(pin[s][1][t]), acc[mm][t], 0, 0, 0);
+                    for (int u = gi * NU / NG; u < (gi + 1) * NU / NG; u++)
+                        es_finish_unit<MT, LAST, AGPR_OUT>(u, hp, po_prev, mx, dst_prev, writer_prev);
+                    // issue order inside the group: one MFMA, then a few of the unit's VALU instructions
 #pragma unroll
-            for (int t = 0; t < MT; t++) acc[mm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ES_BF(a0[1]), ES_BF(pin[s][0][t]), acc[mm][t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < MT; t++) acc[mm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ES_BF(a0[0]), ES_BF(pin[s][1][t]), acc[mm][t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < MT; t++) acc[mm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ES_BF(a0[0]), ES_BF(pin[s][0][t]), acc[mm][t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int t = 0; t < MT; t++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, ES_VPM, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int p = 0; p < 3; p++) { a0[p] = a1[p]; a1[p] = a2[p]; }
         }
-    es_finish_pair<MT, LAST>(acc[0], acc[1], po, prow + 32 * mp, writer);
 }
 
-// One dense layer: S input k-steps (32 channels each, planes in pin), NPAIR output M-tile pairs.
-// wl: [step = m*S + s][plane][lane] fragments, read strictly in order, prefetched two steps ahead.
-template <int MT, int S, int NPAIR, bool LAST, bool UNROLL>
+// One dense layer: S input k-steps (32 channels each, planes in pin), NPAIR output M-tile pairs,
+// software-pipelined over pairs (accumulators double-buffered: pair i's MFMAs hide pair i-1's finish).
+// wl: [step = m*S + s][plane][lane] fragments, prefetched two steps ahead.  rot (only for the rolled
+// LAST layer, where no register array is indexed by the pair): this workgroup starts at pair `rot`.
+template <int MT, int S, int NPAIR, bool LAST, bool UNROLL, bool AGPR_OUT = false>
 __device__ __forceinline__ void es_layer(const uint4 (&pin)[S][3][MT], uint4 (&pout)[LAST ? 1 : NPAIR][3][MT],
-                                         const uint4 *__restrict__ wl, const float *__restrict__ bias,
-                                         float *__restrict__ prow, bool writer, int lane, int g)
+                                         const uint4 *wl, const float *__restrict__ bias,
+                                         float *__restrict__ prow, bool writer, int lane, int g, int rot)
 {
-    constexpr int NSTEP = NPAIR * 2 * S;
+    static_assert(NPAIR % 2 == 0, "pairs are processed two at a time");
     const uint4 *wp = wl + lane;
+    const int first = UNROLL ? 0 : rot;
     uint4 a0[3], a1[3];
+    f32x4 bv[2];
 #pragma unroll
     for (int p = 0; p < 3; p++) {
-        a0[p] = wp[p * 64];
-        a1[p] = wp[(3 + p) * 64];
+        a0[p] = wp[(size_t)((first * 2 * S) * 3 + p) * 64];
+        a1[p] = wp[(size_t)((first * 2 * S + 1) * 3 + p) * 64];
     }
+    bv[0] = *(const f32x4 *)(bias + 32 * first + 4 * g);
+    bv[1] = *(const f32x4 *)(bias + 32 * first + 16 + 4 * g);
+    ES_PIN();
+    f32x4 accA[2][MT], accB[2][MT];
     if (UNROLL) {
 #pragma unroll
-        for (int mp = 0; mp < NPAIR; mp++)
-            es_pair<MT, S, NSTEP, LAST>(mp, pin, pout[LAST ? 0 : mp], wp, a0, a1, bias, prow, writer, g);
+        for (int i = 0; i < NPAIR; i += 2) {
+            const int nx = i + 2 < NPAIR ? i + 2 : i + 1;
+            if (i == 0)
+                es_pair<MT, S, LAST, false, AGPR_OUT>(0, 1, pin, wp, a0, a1, bv, bias, accA, accB, pout[0], prow, false, g);
+            else
+                es_pair<MT, S, LAST, true, AGPR_OUT>(i, i + 1, pin, wp, a0, a1, bv, bias, accA, accB, pout[LAST ? 0 : i - 1],
+                                           prow + 32 * (i - 1), writer, g);
+            es_pair<MT, S, LAST, true, AGPR_OUT>(i + 1, nx, pin, wp, a0, a1, bv, bias, accB, accA, pout[LAST ? 0 : i],
+                                       prow + 32 * i, writer, g);
+        }
+        es_finish_all<MT, LAST, AGPR_OUT>(accB, pout[LAST ? 0 : NPAIR - 1], prow + 32 * (NPAIR - 1), writer);
     } else {
+#pragma unroll
+        for (int mm = 0; mm < 2; mm++)
+#pragma unroll
+            for (int t = 0; t < MT; t++) accB[mm][t] = bv[mm];          // defined contents for the first (discarded) finish
+        int mpB = first;                                                // pair whose results sit in accB
 #pragma unroll 1
-        for (int mp = 0; mp < NPAIR; mp++)
-            es_pair<MT, S, NSTEP, LAST>(mp, pin, pout[0], wp, a0, a1, bias, prow, writer, g);
+        for (int i = 0; i < NPAIR; i += 2) {
+            const int m0 = (i + rot) % NPAIR, m1 = (i + 1 + rot) % NPAIR, m2 = (i + 2 + rot) % NPAIR;
+            es_pair<MT, S, LAST, true, AGPR_OUT>(m0, m1, pin, wp, a0, a1, bv, bias, accA, accB, pout[0], prow + 32 * mpB,
+                                       writer && i > 0, g);
+            es_pair<MT, S, LAST, true, AGPR_OUT>(m1, i + 2 < NPAIR ? m2 : m1, pin, wp, a0, a1, bv, bias, accB, accA, pout[0],
+                                       prow + 32 * m0, writer, g);
+            mpB = m1;
+        }
+        es_finish_all<MT, LAST>(accB, pout[0], prow + 32 * mpB, writer);
     }
 }
 
 template <int MT>
 __global__ __launch_bounds__(256, 1) void edgeconv_split_kernel(const float *__restrict__ xyz,
                                                                 const int64_t *__restrict__ idx, int N, int k,
-                                                                const float *__restrict__ packed,
-                                                                float *__restrict__ pooled /*[B*N][512]*/)
+                                                                const float *packed,
+                                                                float *__restrict__ pooled /*[B*N][512]*/
+#ifdef ES_TIMING
+                                                                , unsigned long long *tdbg
+#endif
+)
 {
+#ifdef ES_TIMING
+    unsigned long long tk[6];
+#define ES_T(i) tk[i] = __builtin_amdgcn_s_memtime()
+#else
+#define ES_T(i)
+#endif
+    ES_T(0);
     constexpr int CTOT = EC_C1 + EC_C2 + EC_C3 + EC_C4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
@@ -170,6 +295,7 @@ __global__ __launch_bounds__(256, 1) void edgeconv_split_kernel(const float *__r
         b1[t][0] = g == 0 ? nx : (g == 1 ? ny : (g == 2 ? nz : cx));
         b1[t][1] = g == 0 ? cy : (g == 1 ? cz : 0.f);
     }
+    ES_T(1);
     uint4 p1[EC_C1 / 32][3][MT];
     {
         const f32x2 *w1 = (const f32x2 *)(packed + EC2_OFF_W1);
@@ -189,24 +315,37 @@ __global__ __launch_bounds__(256, 1) void edgeconv_split_kernel(const float *__r
                     for (int t = 0; t < MT; t++)
                         h[mm][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[t][s], h[mm][t], 0, 0, 0);
             }
-            es_finish_pair<MT, false>(h[0], h[1], p1[mp], prow + 32 * mp, writer);
+            es_finish_all<MT, false>(h, p1[mp], prow + 32 * mp, writer);
         }
     }
 
+    ES_T(2);
     // ---- layer 2: 64 -> 64
     uint4 p2[EC_C2 / 32][3][MT];
     es_layer<MT, EC_C1 / 32, EC_C2 / 32, false, true>(p1, p2, (const uint4 *)(packed + EC3_OFF_W2), packed + EC_OFF_B2,
-                                                      prow + EC_C1, writer, lane, g);
+                                                      prow + EC_C1, writer, lane, g, 0);
+    ES_T(3);
     // ---- layer 3: 64 -> 128
     uint4 p3[EC_C3 / 32][3][MT];
-    es_layer<MT, EC_C2 / 32, EC_C3 / 32, false, true>(p2, p3, (const uint4 *)(packed + EC3_OFF_W3), packed + EC_OFF_B3,
-                                                      prow + EC_C1 + EC_C2, writer, lane, g);
+    es_layer<MT, EC_C2 / 32, EC_C3 / 32, false, true, (MT > 4)>(p2, p3, (const uint4 *)(packed + EC3_OFF_W3), packed + EC_OFF_B3,
+                                                      prow + EC_C1 + EC_C2, writer, lane, g, 0);
+    ES_T(4);
     // ---- layer 4: 128 -> 256, only max-pooled
     uint4 dummy[1][3][MT];
+#ifndef ES_ROT
+#define ES_ROT 1
+#endif
+    const int rot = ES_ROT ? (int)(((blockIdx.x + gridDim.x * blockIdx.y) >> 3) % (EC_C4 / 32)) : 0;   // >>3: ids = XCD mod 8
     es_layer<MT, EC_C3 / 32, EC_C4 / 32, true, false>(p3, dummy, (const uint4 *)(packed + EC3_OFF_W4), packed + EC_OFF_B4,
-                                                      prow + EC_C1 + EC_C2 + EC_C3, writer, lane, g);
+                                                      prow + EC_C1 + EC_C2 + EC_C3, writer, lane, g, rot);
+    ES_T(5);
+#ifdef ES_TIMING
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 6; i++) tdbg[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 6 + i] = tk[i];
+#endif
 }
 
+#ifndef ES_TIMING
 extern "C" int l3d_edgeconv_forward_split(const float *xyz, const int64_t *idx, int B, int N, int k,
                                           const float *packed, float *pooled, l3d_stream_t stream)
 {
@@ -214,8 +353,8 @@ extern "C" int l3d_edgeconv_forward_split(const float *xyz, const int64_t *idx, 
     if (k > 20 || B > 65535 || (((size_t)packed) & 15)) return L3D_ERR_UNSUPPORTED;
     dim3 grid(l3d_divup(N, 16), B), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (k <= 8)       hipLaunchKernelGGL(edgeconv_split_kernel<2>, grid, block, 0, st, xyz, idx, N, k, packed, pooled);
-    else if (k <= 16) hipLaunchKernelGGL(edgeconv_split_kernel<4>, grid, block, 0, st, xyz, idx, N, k, packed, pooled);
+    if (k <= 16) hipLaunchKernelGGL(edgeconv_split_kernel<4>, grid, block, 0, st, xyz, idx, N, k, packed, pooled);
     else              hipLaunchKernelGGL(edgeconv_split_kernel<5>, grid, block, 0, st, xyz, idx, N, k, packed, pooled);
     return l3d_check_launch();
 }
+#endif
