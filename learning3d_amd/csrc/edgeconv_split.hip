@@ -95,7 +95,18 @@ __device__ __forceinline__ uint32_t es_to_agpr(uint32_t v)
     return r;
 }
 
-template <int MT, bool LAST, bool AGPR_OUT = false>
+// v_max_f32 written out: fmaxf() on an MFMA result costs a second, canonicalising v_max x,x,x.  Only
+// used where the accumulator was written hundreds of cycles earlier (the pipelined units): the
+// compiler does not pad MFMA -> VALU hazards around inline asm.
+template <bool RAW> __device__ __forceinline__ float es_max(float a, float b)
+{
+    if (!RAW) return fmaxf(a, b);
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+template <int MT, bool LAST, bool AGPR_OUT = false, bool RAW = false>
 __device__ __forceinline__ void es_finish_unit(int u, f32x4 (&h)[2][MT], uint4 (&pl)[3][MT], f32x4 (&mx)[2],
                                                float *__restrict__ dst, bool writer)
 {
@@ -105,8 +116,8 @@ __device__ __forceinline__ void es_finish_unit(int u, f32x4 (&h)[2][MT], uint4 (
         if (k < 2) {                                         // relu + running max of M-tile k
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                h[k][t][r] = fmaxf(h[k][t][r], 0.f);
-                mx[k][r] = t == 0 ? h[k][t][r] : fmaxf(mx[k][r], h[k][t][r]);
+                h[k][t][r] = es_max<RAW>(h[k][t][r], 0.f);
+                mx[k][r] = t == 0 ? h[k][t][r] : es_max<RAW>(mx[k][r], h[k][t][r]);
             }
         } else {
             uint32_t q[2][3];
@@ -185,7 +196,7 @@ __device__ __forceinline__ void es_pair(int mp, int mp_next, const uint4 (&pin)[
                     const int gi = r * 6 + prod;
 #pragma unroll
                     for (int u = gi * NU / NG; u < (gi + 1) * NU / NG; u++)
-                        es_finish_unit<MT, LAST, AGPR_OUT>(u, hp, po_prev, mx, dst_prev, writer_prev);
+                        es_finish_unit<MT, LAST, AGPR_OUT, true>(u, hp, po_prev, mx, dst_prev, writer_prev);
                     // issue order inside the group: one MFMA, then a few of the unit's VALU instructions
 #pragma unroll
                     for (int t = 0; t < MT; t++) {
