@@ -215,7 +215,7 @@ int l3d_pointwise_conv(const float *x, int x_channel_last, const float *w, const
  *   l3d_split_rows: device fp32 [rows][cols] -> that image (weights: rows = Cout, cols = Cin).
  *   l3d_pointwise_conv_split: x_mode 0 = x [B,Cin,N] fp32, 1 = x [B,N,Cin] fp32,
  *     2 = x already split as l3d_split_rows would split the [B*N][Cin] matrix.
- *     Needs Cout % 256 == 0, N % 256 == 0, Cin % 16 == 0, else L3D_ERR_UNSUPPORTED (callers then use
+ *     Needs Cout % 256 == 0, N % 128 == 0, Cin % 16 == 0, else L3D_ERR_UNSUPPORTED (callers then use
  *     l3d_pointwise_conv).  Other arguments as l3d_pointwise_conv.
  * ------------------------------------------------------------------------------------------- */
 size_t l3d_split_bytes(int rows, int cols);

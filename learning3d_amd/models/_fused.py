@@ -104,7 +104,7 @@ def split_rows(m):
 
 
 def split_eligible(Cin, Cout, N):
-    return SPLIT_BF16 and Cout % 256 == 0 and N % 256 == 0 and Cin % 16 == 0 and Cin >= 32
+    return SPLIT_BF16 and Cout % 256 == 0 and N % 128 == 0 and Cin % 16 == 0 and Cin >= 32
 
 
 def pointwise_conv(x, w, scale=None, shift=None, relu=False, channel_last=False, w_split=None, split=None):

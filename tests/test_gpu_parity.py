@@ -390,7 +390,8 @@ def test_conv_split_accuracy():
     from learning3d_amd.models import _fused
     from learning3d_amd._lib import lib, check, ptr, stream_ptr
     rng = np.random.default_rng(21)
-    for (B, Cin, Cout, N, scale_x) in [(2, 512, 1024, 1024, 1.0), (1, 64, 256, 256, 1e-3), (3, 320, 512, 512, 50.0)]:
+    for (B, Cin, Cout, N, scale_x) in [(2, 512, 1024, 1024, 1.0), (1, 64, 256, 256, 1e-3), (3, 320, 512, 512, 50.0),
+                                      (2, 128, 256, 384, 1.0)]:
         x = (np.maximum(rng.standard_normal((B, N, Cin)), 0) * scale_x).astype(np.float32)     # post-ReLU like
         w = (rng.standard_normal((Cout, Cin)) / np.sqrt(Cin)).astype(np.float32)
         sc = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
