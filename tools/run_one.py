@@ -1,4 +1,4 @@
-"""Run one kernel a few times (for rocprofv3 --pmc passes).  usage: run_one.py knn|chamfer|edgeconv|conv5"""
+"""Run one kernel a few times (for rocprofv3 --pmc passes).  usage: run_one.py knn|chamfer|edgeconv|edgeconv_split|conv5|conv5_split"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,6 +18,8 @@ with torch.no_grad():
     for _ in range(5):
         if what == "knn": U.knn(x.permute(0, 2, 1), 20)
         elif what == "chamfer": ChamferDistance()(a, b)
-        elif what == "edgeconv": _fused.edgeconv_forward(x, idx, packed)
-        elif what == "conv5": _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True, w_split=w5s)
+        elif what == "edgeconv": _fused.edgeconv_forward(x, idx, packed, kernel="chained")            # fp32 MFMA
+        elif what == "edgeconv_split": _fused.edgeconv_forward(x, idx, packed, kernel="split")        # bf16x3
+        elif what == "conv5": _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True, split=False)
+        elif what == "conv5_split": _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True, w_split=w5s)
     torch.cuda.synchronize()

@@ -2,7 +2,7 @@
 import json, os, re, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {}
-for tag in ("edgeconv", "conv5", "knn", "chamfer"):
+for tag in ("edgeconv", "edgeconv_split", "conv5", "conv5_split", "knn", "chamfer"):
     path = os.path.join(root, "profiles", f"round1_pmc_{tag}.txt")
     if not os.path.exists(path):
         continue
