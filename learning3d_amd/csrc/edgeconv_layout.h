@@ -23,8 +23,9 @@
 
 // third copy, layers 2-4 only, for the bf16x3 kernel (edgeconv_split.hip): every weight split into
 // three bf16 planes, fragment-ordered for v_mfma_f32_16x16x32_bf16 as the A operand.  Offsets and
-// sizes in floats (one 16-byte fragment = 4 floats); block [step = m*S + s][plane 3][lane 64][8 bf16]
-// with S = Cin/32 k-steps, m = output M-tile of 16 channels.
+// sizes in floats (one 16-byte fragment = 4 floats); block [step][plane 3][lane 64][8 bf16] with
+// step = ((m/2)*S + s)*2 + (m&1), S = Cin/32 k-steps, m = output M-tile of 16 channels (the order the
+// kernel consumes them: M-tile pair, k-step, M-tile of the pair).
 #define EC3_OFF_W2 EC2_END
 #define EC3_OFF_W3 (EC3_OFF_W2 + (EC_C2 / 16) * (EC_C1 / 32) * 3 * 64 * 4)
 #define EC3_OFF_W4 (EC3_OFF_W3 + (EC_C3 / 16) * (EC_C2 / 32) * 3 * 64 * 4)

@@ -19,6 +19,7 @@
 // registers) are live, so the dominant register cost is the split input planes (layer 4: 128
 // channels x 3 planes = 240 VGPRs for MT = 5) and the kernel fits one wave per SIMD.  Layer 1
 // (6 -> 64, K padded to 8) stays on the fp32 MFMA: a K=32 bf16 step would be 3/4 padding.
+#include <type_traits>
 #include "common.h"
 #include "edgeconv_layout.h"
 #include "split_bf16.h"
@@ -49,7 +50,7 @@ __device__ __forceinline__ f32x4 es_relu_pool(f32x4 (&h)[MT])
 
 // Two finished M-tiles (2s, 2s+1) -> pooled output + (unless LAST) the three bf16 planes of k-step s
 template <int MT, bool LAST>
-__device__ __forceinline__ void es_finish_pair(f32x4 (&h0)[MT], f32x4 (&h1)[MT], uint4 (&pl)[3][MT],
+__device__ __forceinline__ void es_finish_pair(f32x4 (&h0)[MT], f32x4 (&h1)[MT], bf16x8 (&pl)[3][MT],
                                                float *__restrict__ dst /* channel 16(2s) + 4g of this point */,
                                                bool writer)
 {
@@ -70,6 +71,7 @@ __device__ __forceinline__ void es_finish_pair(f32x4 (&h0)[MT], f32x4 (&h1)[MT],
     }
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define ES_BF(u) __builtin_bit_cast(bf16x8, (u))
 #ifndef ES_VPM
 #define ES_VPM 4            // VALU instructions the scheduler may place after each MFMA of a group
@@ -80,10 +82,10 @@ __device__ __forceinline__ void es_finish_pair(f32x4 (&h0)[MT], f32x4 (&h1)[MT],
 // The finish work of a completed M-tile pair (ReLU, max-pool, three-way split) cut into small units so
 // that it can be issued BETWEEN the MFMAs of the next pair: with one wave per SIMD nothing else hides
 // VALU work, and a VALU instruction issued in the shadow of a 16-cycle MFMA is free.
-//   per row tile t:  [relu+max of h0[t]] [relu+max of h1[t]] ([split h0[t]] [split h1[t]] unless LAST)
+//   per row tile t:  [relu+max of h0[t]] [relu+max of h1[t]] ([split h0[t], h1[t]] unless LAST)
 //   then [quad max + store of M-tile 2s] [same for 2s+1]
 // ---------------------------------------------------------------------------------------------
-template <bool LAST> struct EsUnits { static constexpr int PER_T = LAST ? 2 : 4; };
+template <bool LAST> struct EsUnits { static constexpr int PER_T = LAST ? 2 : 3; };
 
 // Home a freshly split fragment word in the accumulation half of the register file: the layer-4
 // input planes (240 registers for MT = 5) are only ever read as MFMA B operands, which may be AGPRs;
@@ -106,31 +108,33 @@ template <bool RAW> __device__ __forceinline__ float es_max(float a, float b)
     return r;
 }
 
-template <int MT, bool LAST, bool AGPR_OUT = false, bool RAW = false>
-__device__ __forceinline__ void es_finish_unit(int u, f32x4 (&h)[2][MT], uint4 (&pl)[3][MT], f32x4 (&mx)[2],
-                                               float *__restrict__ dst, bool writer)
+template <int MT, bool LAST, bool AGPR_OUT, bool RAW, int U>
+__device__ __forceinline__ void es_finish_unit_c(f32x4 (&h)[2][MT], bf16x8 (&pl)[3][MT], f32x4 (&mx)[2],
+                                                 float *__restrict__ dst, bool writer)
 {
     constexpr int PER_T = EsUnits<LAST>::PER_T;
-    const int t = u / PER_T, k = u % PER_T;
-    if (t < MT) {
-        if (k < 2) {                                         // relu + running max of M-tile k
+    constexpr int t = U / PER_T, k = U % PER_T;
+    if constexpr (t < MT && k < 2) {                         // relu + running max of M-tile k
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                h[k][t][r] = es_max<RAW>(h[k][t][r], 0.f);
-                mx[k][r] = t == 0 ? h[k][t][r] : es_max<RAW>(mx[k][r], h[k][t][r]);
-            }
-        } else {
-            uint32_t q[2][3];
-            split_pair(h[k - 2][t][0], h[k - 2][t][1], q[0][0], q[0][1], q[0][2]);
-            split_pair(h[k - 2][t][2], h[k - 2][t][3], q[1][0], q[1][1], q[1][2]);
-#pragma unroll
-            for (int p = 0; p < 3; p++) {
-                const uint32_t lo = AGPR_OUT ? es_to_agpr(q[0][p]) : q[0][p];
-                const uint32_t hi = AGPR_OUT ? es_to_agpr(q[1][p]) : q[1][p];
-                if (k == 2) { pl[p][t].x = lo; pl[p][t].y = hi; } else { pl[p][t].z = lo; pl[p][t].w = hi; }
-            }
+        for (int r = 0; r < 4; r++) {
+            h[k][t][r] = es_max<RAW>(h[k][t][r], 0.f);
+            mx[k][r] = t == 0 ? h[k][t][r] : es_max<RAW>(mx[k][r], h[k][t][r]);
         }
-    } else {                                                 // u = MT*PER_T + k, k = 0, 1: pooled store
+    } else if constexpr (t < MT) {                           // split both M-tiles of row tile t
+        // whole 16-byte fragments are written at once: component-wise stores into the plane arrays
+        // defeat their promotion to registers (the MFMA reads them back as one 8 x bf16 vector)
+        uint32_t q[4][3];
+        split_pair(h[0][t][0], h[0][t][1], q[0][0], q[0][1], q[0][2]);
+        split_pair(h[0][t][2], h[0][t][3], q[1][0], q[1][1], q[1][2]);
+        split_pair(h[1][t][0], h[1][t][1], q[2][0], q[2][1], q[2][2]);
+        split_pair(h[1][t][2], h[1][t][3], q[3][0], q[3][1], q[3][2]);
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const u32x4 v = {AGPR_OUT ? es_to_agpr(q[0][p]) : q[0][p], AGPR_OUT ? es_to_agpr(q[1][p]) : q[1][p],
+                             AGPR_OUT ? es_to_agpr(q[2][p]) : q[2][p], AGPR_OUT ? es_to_agpr(q[3][p]) : q[3][p]};
+            pl[p][t] = __builtin_bit_cast(bf16x8, v);        // one 16-byte value: the type the MFMA reads
+        }
+    } else {                                                 // U = MT*PER_T + k, k = 0, 1: pooled store
         f32x4 v;
 #pragma unroll
         for (int r = 0; r < 4; r++) v[r] = es_quad_max(mx[k][r]);
@@ -139,12 +143,25 @@ __device__ __forceinline__ void es_finish_unit(int u, f32x4 (&h)[2][MT], uint4 (
 }
 template <int MT, bool LAST> struct EsN { static constexpr int UNITS = MT * EsUnits<LAST>::PER_T + 2; };
 
+// Compile-time loops: every register-array index in this file must be a constant, and `#pragma unroll`
+// is only a request (bodies this large exceed the unroller's pragma threshold, the loop stays rolled,
+// the index becomes dynamic and the accumulators / planes land in scratch memory).
+template <int I0, int I1, class F>
+__device__ __forceinline__ void es_static_for(F &&f)
+{
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        es_static_for<I0 + 1, I1>(f);
+    }
+}
+
 template <int MT, bool LAST, bool AGPR_OUT = false>
-__device__ __forceinline__ void es_finish_all(f32x4 (&h)[2][MT], uint4 (&pl)[3][MT], float *__restrict__ dst, bool writer)
+__device__ __forceinline__ void es_finish_all(f32x4 (&h)[2][MT], bf16x8 (&pl)[3][MT], float *__restrict__ dst, bool writer)
 {
     f32x4 mx[2];
-#pragma unroll
-    for (int u = 0; u < EsN<MT, LAST>::UNITS; u++) es_finish_unit<MT, LAST, AGPR_OUT>(u, h, pl, mx, dst, writer);
+    es_static_for<0, EsN<MT, LAST>::UNITS>([&](auto u) {
+        es_finish_unit_c<MT, LAST, AGPR_OUT, false, decltype(u)::value>(h, pl, mx, dst, writer);
+    });
 }
 
 // ES_PIN: the compiler's IR passes sink a load towards its first use (two steps later) regardless of
@@ -152,19 +169,23 @@ __device__ __forceinline__ void es_finish_all(f32x4 (&h)[2][MT], uint4 (&pl)[3][
 // (the fragment pointer is deliberately NOT __restrict__, or the clobber would not order the load).
 #define ES_PIN() asm volatile("" ::: "memory")
 
-// One output M-tile pair of a dense layer: 2 x S steps of {prefetch fragment step+2, 6 groups of MT
-// MFMAs}, with the finish units of the PREVIOUS pair (hp, if HAS_PREV) spread over the groups.
+// One output M-tile pair of a dense layer: 2 x S steps (k-step outer, M-tile inner -- the order the
+// fragments are packed in) of {prefetch fragment step+2, 6 groups of MT MFMAs}, with the finish units
+// of a PREVIOUS pair (hp, if HAS_PREV) spread over the first NGU groups.  That previous pair is the
+// preceding pair of this layer (NGU = all groups) or, for a layer's first pair, the LAST pair of the
+// previous layer, whose planes are this layer's k-step S-1: its units then ride on the groups of
+// k-steps 0 .. S-2 only (NGU = (S-1)*12) and are complete before the first MFMA that reads them.
 // mp = this pair, mp_next = the pair executed after it (fragment and bias prefetches cross the pair
 // boundary); pairs may be executed in any order.  bv: this pair's bias, loaded during the previous
 // pair; replaced by the next pair's on return.
-template <int MT, int S, bool LAST, bool HAS_PREV, bool AGPR_OUT>
-__device__ __forceinline__ void es_pair(int mp, int mp_next, const uint4 (&pin)[S][3][MT], const uint4 *wp,
+template <int MT, int S, bool HAS_PREV, bool PREV_LAST, bool PREV_AGPR, int NGU>
+__device__ __forceinline__ void es_pair(int mp, int mp_next, const bf16x8 (&pin)[S][3][MT], const bf16x8 (&pin_last)[3][MT],
+                                        const uint4 *wp,
                                         uint4 (&a0)[3], uint4 (&a1)[3], f32x4 (&bv)[2], const float *__restrict__ bias,
-                                        f32x4 (&acc)[2][MT], f32x4 (&hp)[2][MT], uint4 (&po_prev)[3][MT],
+                                        f32x4 (&acc)[2][MT], f32x4 (&hp)[2][MT], bf16x8 (&po_prev)[3][MT],
                                         float *__restrict__ dst_prev, bool writer_prev, int g)
 {
-    constexpr int NG = 2 * S * 6;                              // MFMA groups in this pair
-    constexpr int NU = HAS_PREV ? EsN<MT, LAST>::UNITS : 0;    // finish units to hide among them
+    constexpr int NU = HAS_PREV ? EsN<MT, PREV_LAST>::UNITS : 0;    // finish units to hide
 #pragma unroll
     for (int mm = 0; mm < 2; mm++)
 #pragma unroll
@@ -172,55 +193,59 @@ __device__ __forceinline__ void es_pair(int mp, int mp_next, const uint4 (&pin)[
     bv[0] = *(const f32x4 *)(bias + 32 * mp_next + 4 * g);
     bv[1] = *(const f32x4 *)(bias + 32 * mp_next + 16 + 4 * g);
     f32x4 mx[2];
+    es_static_for<0, 2 * S>([&](auto rc) {
+        // execution step r = 2 s + mm; fragment two steps ahead: inside this pair, or the first two of the next
+        constexpr int r = decltype(rc)::value, s = r >> 1, mm = r & 1;
+        const int nxt = r + 2 < 2 * S ? mp * 2 * S + r + 2 : mp_next * 2 * S + (r + 2 - 2 * S);
+        uint4 a2[3];
 #pragma unroll
-    for (int mm = 0; mm < 2; mm++)
+        for (int p = 0; p < 3; p++) a2[p] = wp[(size_t)(nxt * 3 + p) * 64];
+        ES_PIN();
+        __builtin_amdgcn_sched_barrier(0);
+        // six products, smallest first; MT independent accumulators between dependent MFMAs
+        es_static_for<0, 6>([&](auto pc) {
+            constexpr int prod = decltype(pc)::value;
+            constexpr int pa = prod == 0 ? 2 : (prod == 2 || prod == 3) ? 1 : 0;      // W plane: l h m m h h
+            constexpr int pb = prod == 1 ? 2 : (prod == 2 || prod == 4) ? 1 : 0;      // x plane: h l m h m h
 #pragma unroll
-        for (int s = 0; s < S; s++) {
-            // fragment two execution steps ahead: inside this pair, or the first two of the next pair
-            const int r = mm * S + s;
-            const int nxt = r + 2 < 2 * S ? mp * 2 * S + r + 2 : mp_next * 2 * S + (r + 2 - 2 * S);
-            uint4 a2[3];
+            for (int t = 0; t < MT; t++)
+                acc[mm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ES_BF(a0[pa]), (s == S - 1 ? pin_last[pb][t] : pin[s][pb][t]),
+                                                                     acc[mm][t], 0, 0, 0);
+            constexpr int gi = r * 6 + prod;
+            if constexpr (HAS_PREV && gi < NGU) {
+                es_static_for<gi * NU / NGU, (gi + 1) * NU / NGU>([&](auto u) {
+                    es_finish_unit_c<MT, PREV_LAST, PREV_AGPR, true, decltype(u)::value>(hp, po_prev, mx, dst_prev, writer_prev);
+                });
+                // issue order inside the group: one MFMA, then a few of the unit's VALU instructions
 #pragma unroll
-            for (int p = 0; p < 3; p++) a2[p] = wp[(size_t)(nxt * 3 + p) * 64];
-            ES_PIN();
-            __builtin_amdgcn_sched_barrier(0);
-            // six products, smallest first; MT independent accumulators between dependent MFMAs
-#pragma unroll
-            for (int prod = 0; prod < 6; prod++) {
-                const int pa = prod == 0 ? 2 : (prod == 2 || prod == 3) ? 1 : 0;      // W plane: l h m m h h
-                const int pb = prod == 1 ? 2 : (prod == 2 || prod == 4) ? 1 : 0;      // x plane: h l m h m h
-#pragma unroll
-                for (int t = 0; t < MT; t++)
-                    acc[mm][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ES_BF(a0[pa]), ES_BF(pin[s][pb][t]), acc[mm][t], 0, 0, 0);
-                if (HAS_PREV) {
-                    const int gi = r * 6 + prod;
-#pragma unroll
-                    for (int u = gi * NU / NG; u < (gi + 1) * NU / NG; u++)
-                        es_finish_unit<MT, LAST, AGPR_OUT, true>(u, hp, po_prev, mx, dst_prev, writer_prev);
-                    // issue order inside the group: one MFMA, then a few of the unit's VALU instructions
-#pragma unroll
-                    for (int t = 0; t < MT; t++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, ES_VPM, 0);
-                    }
+                for (int t = 0; t < MT; t++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, ES_VPM, 0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+        });
 #pragma unroll
-            for (int p = 0; p < 3; p++) { a0[p] = a1[p]; a1[p] = a2[p]; }
-        }
+        for (int p = 0; p < 3; p++) { a0[p] = a1[p]; a1[p] = a2[p]; }
+    });
 }
 
 // One dense layer: S input k-steps (32 channels each, planes in pin), NPAIR output M-tile pairs,
 // software-pipelined over pairs (accumulators double-buffered: pair i's MFMAs hide pair i-1's finish).
-// wl: [step = m*S + s][plane][lane] fragments, prefetched two steps ahead.  rot (only for the rolled
-// LAST layer, where no register array is indexed by the pair): this workgroup starts at pair `rot`.
-template <int MT, int S, int NPAIR, bool LAST, bool UNROLL, bool AGPR_OUT = false>
-__device__ __forceinline__ void es_layer(const uint4 (&pin)[S][3][MT], uint4 (&pout)[LAST ? 1 : NPAIR][3][MT],
-                                         const uint4 *wl, const float *__restrict__ bias,
-                                         float *__restrict__ prow, bool writer, int lane, int g, int rot)
+// On entry accB holds the previous layer's last, unfinished pair (its planes are pin[S-1], its pooled
+// output goes to dst_in); on return accB holds THIS layer's last unfinished pair (pair index *mp_out).
+// wl: [step = (pair*S + s)*2 + mm][plane][lane] fragments, prefetched two steps ahead.  rot (only for
+// the rolled LAST layer, where no register array is indexed by the pair): this workgroup starts at pair
+// `rot`.  IN_AGPR: pin's planes are homed in AGPRs; OUT_AGPR: this layer's output planes are.
+template <int MT, int S, int NPAIR, bool LAST, bool UNROLL, bool IN_AGPR, bool OUT_AGPR>
+__device__ __forceinline__ void es_layer(const bf16x8 (&pin)[S][3][MT], bf16x8 (&pout)[LAST ? 1 : NPAIR][3][MT],
+                                         const uint4 *wl, const float *__restrict__ bias, float *__restrict__ prow,
+                                         f32x4 (&accA)[2][MT], f32x4 (&accB)[2][MT], float *__restrict__ dst_in,
+                                         int *mp_out, bool writer, int lane, int g, int rot)
 {
-    static_assert(NPAIR % 2 == 0, "pairs are processed two at a time");
+    static_assert(NPAIR % 2 == 0 && S >= 2, "pairs are processed two at a time; deferred finish needs S >= 2");
+    constexpr int NG = 2 * S * 6, NGD = (S - 1) * 12;
+    bf16x8 last[3][MT];             // planes of k-step S-1: produced here by the deferred finish (pin[S-1] is never written)
     const uint4 *wp = wl + lane;
     const int first = UNROLL ? 0 : rot;
     uint4 a0[3], a1[3];
@@ -233,36 +258,31 @@ __device__ __forceinline__ void es_layer(const uint4 (&pin)[S][3][MT], uint4 (&p
     bv[0] = *(const f32x4 *)(bias + 32 * first + 4 * g);
     bv[1] = *(const f32x4 *)(bias + 32 * first + 16 + 4 * g);
     ES_PIN();
-    f32x4 accA[2][MT], accB[2][MT];
-    if (UNROLL) {
-#pragma unroll
-        for (int i = 0; i < NPAIR; i += 2) {
-            const int nx = i + 2 < NPAIR ? i + 2 : i + 1;
-            if (i == 0)
-                es_pair<MT, S, LAST, false, AGPR_OUT>(0, 1, pin, wp, a0, a1, bv, bias, accA, accB, pout[0], prow, false, g);
-            else
-                es_pair<MT, S, LAST, true, AGPR_OUT>(i, i + 1, pin, wp, a0, a1, bv, bias, accA, accB, pout[LAST ? 0 : i - 1],
-                                           prow + 32 * (i - 1), writer, g);
-            es_pair<MT, S, LAST, true, AGPR_OUT>(i + 1, nx, pin, wp, a0, a1, bv, bias, accB, accA, pout[LAST ? 0 : i],
-                                       prow + 32 * i, writer, g);
+    if constexpr (UNROLL) {
+        // written out (NPAIR is 2 or 4): a `#pragma unroll` loop over this much code is not always
+        // unrolled, and a rolled loop indexes pout dynamically, which sends the planes to scratch
+        static_assert(NPAIR == 2 || NPAIR == 4, "unrolled layers have 2 or 4 output pairs");
+        es_pair<MT, S, true, false, IN_AGPR, NGD>(0, 1, pin, last, wp, a0, a1, bv, bias, accA, accB, last, dst_in, writer, g);
+        es_pair<MT, S, true, LAST, OUT_AGPR, NG>(1, NPAIR > 2 ? 2 : 1, pin, last, wp, a0, a1, bv, bias, accB, accA, pout[0], prow, writer, g);
+        if constexpr (NPAIR == 4) {
+            es_pair<MT, S, true, LAST, OUT_AGPR, NG>(2, 3, pin, last, wp, a0, a1, bv, bias, accA, accB, pout[1], prow + 32, writer, g);
+            es_pair<MT, S, true, LAST, OUT_AGPR, NG>(3, 3, pin, last, wp, a0, a1, bv, bias, accB, accA, pout[2], prow + 64, writer, g);
         }
-        es_finish_all<MT, LAST, AGPR_OUT>(accB, pout[LAST ? 0 : NPAIR - 1], prow + 32 * (NPAIR - 1), writer);
+        *mp_out = NPAIR - 1;
     } else {
-#pragma unroll
-        for (int mm = 0; mm < 2; mm++)
-#pragma unroll
-            for (int t = 0; t < MT; t++) accB[mm][t] = bv[mm];          // defined contents for the first (discarded) finish
-        int mpB = first;                                                // pair whose results sit in accB
+        const int q0 = rot % NPAIR, q1 = (1 + rot) % NPAIR, q2 = (2 + rot) % NPAIR;
+        es_pair<MT, S, true, false, IN_AGPR, NGD>(q0, q1, pin, last, wp, a0, a1, bv, bias, accA, accB, last, dst_in, writer, g);
+        es_pair<MT, S, true, LAST, OUT_AGPR, NG>(q1, q2, pin, last, wp, a0, a1, bv, bias, accB, accA, pout[0], prow + 32 * q0, writer, g);
+        int mpB = q1;                                                   // pair whose results sit in accB
 #pragma unroll 1
-        for (int i = 0; i < NPAIR; i += 2) {
+        for (int i = 2; i < NPAIR; i += 2) {
             const int m0 = (i + rot) % NPAIR, m1 = (i + 1 + rot) % NPAIR, m2 = (i + 2 + rot) % NPAIR;
-            es_pair<MT, S, LAST, true, AGPR_OUT>(m0, m1, pin, wp, a0, a1, bv, bias, accA, accB, pout[0], prow + 32 * mpB,
-                                       writer && i > 0, g);
-            es_pair<MT, S, LAST, true, AGPR_OUT>(m1, i + 2 < NPAIR ? m2 : m1, pin, wp, a0, a1, bv, bias, accB, accA, pout[0],
-                                       prow + 32 * m0, writer, g);
+            es_pair<MT, S, true, LAST, OUT_AGPR, NG>(m0, m1, pin, last, wp, a0, a1, bv, bias, accA, accB, pout[0], prow + 32 * mpB, writer, g);
+            es_pair<MT, S, true, LAST, OUT_AGPR, NG>(m1, i + 2 < NPAIR ? m2 : m1, pin, last, wp, a0, a1, bv, bias, accB, accA, pout[0],
+                                                    prow + 32 * m0, writer, g);
             mpB = m1;
         }
-        es_finish_all<MT, LAST>(accB, pout[0], prow + 32 * mpB, writer);
+        *mp_out = mpB;
     }
 }
 
@@ -307,48 +327,53 @@ __global__ __launch_bounds__(256, 1) void edgeconv_split_kernel(const float *__r
         b1[t][1] = g == 0 ? cy : (g == 1 ? cz : 0.f);
     }
     ES_T(1);
-    uint4 p1[EC_C1 / 32][3][MT];
+    bf16x8 p1[EC_C1 / 32][3][MT];
+    f32x4 accA[2][MT], accB[2][MT];                    // accB: the pair whose finish is pending
     {
         const f32x2 *w1 = (const f32x2 *)(packed + EC2_OFF_W1);
 #pragma unroll
         for (int mp = 0; mp < EC_C1 / 32; mp++) {
-            f32x4 h[2][MT];
 #pragma unroll
             for (int mm = 0; mm < 2; mm++) {
                 const int m = 2 * mp + mm;
                 const f32x4 bv = *(const f32x4 *)(packed + EC_OFF_B1 + 16 * m + 4 * g);
                 const f32x2 a = w1[m * 64 + lane];
 #pragma unroll
-                for (int t = 0; t < MT; t++) h[mm][t] = bv;
+                for (int t = 0; t < MT; t++) accB[mm][t] = bv;
 #pragma unroll
                 for (int s = 0; s < 2; s++)
 #pragma unroll
                     for (int t = 0; t < MT; t++)
-                        h[mm][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[t][s], h[mm][t], 0, 0, 0);
+                        accB[mm][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[t][s], accB[mm][t], 0, 0, 0);
             }
-            es_finish_all<MT, false>(h, p1[mp], prow + 32 * mp, writer);
+            if (mp + 1 < EC_C1 / 32) es_finish_all<MT, false>(accB, p1[mp], prow + 32 * mp, writer);
         }
     }
+    int mp_last;
 
     ES_T(2);
-    // ---- layer 2: 64 -> 64
-    uint4 p2[EC_C2 / 32][3][MT];
-    es_layer<MT, EC_C1 / 32, EC_C2 / 32, false, true>(p1, p2, (const uint4 *)(packed + EC3_OFF_W2), packed + EC_OFF_B2,
-                                                      prow + EC_C1, writer, lane, g, 0);
+    // ---- layer 2: 64 -> 64   (its first pair hides the finish of layer 1's last pair, and so on down)
+    bf16x8 p2[EC_C2 / 32][3][MT];
+    es_layer<MT, EC_C1 / 32, EC_C2 / 32, false, true, false, false>(
+        p1, p2, (const uint4 *)(packed + EC3_OFF_W2), packed + EC_OFF_B2, prow + EC_C1, accA, accB,
+        prow + 32 * (EC_C1 / 32 - 1), &mp_last, writer, lane, g, 0);
     ES_T(3);
     // ---- layer 3: 64 -> 128
-    uint4 p3[EC_C3 / 32][3][MT];
-    es_layer<MT, EC_C2 / 32, EC_C3 / 32, false, true, (MT > 4)>(p2, p3, (const uint4 *)(packed + EC3_OFF_W3), packed + EC_OFF_B3,
-                                                      prow + EC_C1 + EC_C2, writer, lane, g, 0);
+    bf16x8 p3[EC_C3 / 32][3][MT];
+    es_layer<MT, EC_C2 / 32, EC_C3 / 32, false, true, false, (MT > 4)>(
+        p2, p3, (const uint4 *)(packed + EC3_OFF_W3), packed + EC_OFF_B3, prow + EC_C1 + EC_C2, accA, accB,
+        prow + EC_C1 + 32 * (EC_C2 / 32 - 1), &mp_last, writer, lane, g, 0);
     ES_T(4);
     // ---- layer 4: 128 -> 256, only max-pooled
-    uint4 dummy[1][3][MT];
+    bf16x8 dummy[1][3][MT];
 #ifndef ES_ROT
 #define ES_ROT 1
 #endif
     const int rot = ES_ROT ? (int)(((blockIdx.x + gridDim.x * blockIdx.y) >> 3) % (EC_C4 / 32)) : 0;   // >>3: ids = XCD mod 8
-    es_layer<MT, EC_C3 / 32, EC_C4 / 32, true, false>(p3, dummy, (const uint4 *)(packed + EC3_OFF_W4), packed + EC_OFF_B4,
-                                                      prow + EC_C1 + EC_C2 + EC_C3, writer, lane, g, rot);
+    es_layer<MT, EC_C3 / 32, EC_C4 / 32, true, false, (MT > 4), false>(
+        p3, dummy, (const uint4 *)(packed + EC3_OFF_W4), packed + EC_OFF_B4, prow + EC_C1 + EC_C2 + EC_C3, accA, accB,
+        prow + EC_C1 + EC_C2 + 32 * (EC_C3 / 32 - 1), &mp_last, writer, lane, g, rot);
+    es_finish_all<MT, true>(accB, dummy[0], prow + EC_C1 + EC_C2 + EC_C3 + 32 * mp_last, writer);
     ES_T(5);
 #ifdef ES_TIMING
     if (threadIdx.x == 0)

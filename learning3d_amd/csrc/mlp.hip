@@ -127,7 +127,7 @@ extern "C" int l3d_edgeconv_pack(const float *const w[4], const float *const sca
         }
     }
     // third copy (layers 2-4) for the bf16x3 kernel (edgeconv_split.hip): W' = h + m + l exactly,
-    //   block [step = m*S + s][plane][lane][slot 8]:
+    //   block [step = ((m/2)*S + s)*2 + (m&1)][plane][lane][slot 8]  (M-tile pair outer, k-step, M-tile inner):
     //   slot e (0..3) = W'[16m + (lane&15)][32s + 4(lane>>4) + e],  slot 4+e = W'[..][32s + 16 + 4(lane>>4) + e]
     const int o3[4] = {0, EC3_OFF_W2, EC3_OFF_W3, EC3_OFF_W4};
     for (int l = 1; l < 4; l++) {
@@ -146,7 +146,7 @@ extern "C" int l3d_edgeconv_pack(const float *const w[4], const float *const sca
                         uint16_t pl[3];
                         l3d_split3_host(v, pl);
                         for (int p = 0; p < 3; p++)
-                            dst[((((size_t)m * S + sidx) * 3 + p) * 64 + lane) * 8 + slot] = pl[p];
+                            dst[(((((size_t)(m >> 1) * S + sidx) * 2 + (m & 1)) * 3 + p) * 64 + lane) * 8 + slot] = pl[p];
                     }
     }
     return L3D_OK;

@@ -264,8 +264,9 @@ def test_edgeconv_split_bf16x3_layout():
     for li, (cin, cout) in enumerate([(C1, C2), (C2, C3), (C3, C4)], start=1):
         S, M = cin // 32, cout // 16
         cnt = M * S * 3 * 64 * 4
-        raw = packed[off:off + cnt].view(np.uint16).reshape(M, S, 3, 64, 8)
-        f = (raw.astype(np.uint32) << 16).view(np.float32)                 # bf16 -> fp32
+        raw = packed[off:off + cnt].view(np.uint16).reshape(M // 2, S, 2, 3, 64, 8)     # [pair][k-step][m&1][plane][lane][slot]
+        raw = raw.transpose(0, 2, 1, 3, 4, 5).reshape(M, S, 3, 64, 8)                  # -> [m][k-step][plane][lane][slot]
+        f = (np.ascontiguousarray(raw).astype(np.uint32) << 16).view(np.float32)       # bf16 -> fp32
         planes[li] = f
         folded = (ws[li] * scs[li][:, None]).astype(np.float32)
         for m in range(M):
