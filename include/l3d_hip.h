@@ -163,6 +163,16 @@ int l3d_kabsch(const float *src, const float *corr, int B, int N, float *R, floa
 /* rotation only, from given H [B,3,3] (utils/svd.py:38-49) */
 int l3d_svd3x3_rotation(const float *H, int B, float *R, l3d_stream_t stream);
 
+/* Soft correspondences of SVDHead == utils/svd.py:22-27, flash-style (softcorr.hip):
+ *   scores[i][j] = softmax_j( <src_emb[b][:,i], tgt_emb[b][:,j]> * scale ),  scale = 1/sqrt(C) in the reference
+ *   src_corr[b][:,i] = sum_j scores[i][j] * tgt[b][:,j]
+ * src_emb [B,C,N], tgt_emb [B,C,M], tgt [B,3,M] -> src_corr [B,3,N], all fp32, channel-first (the
+ * reference's layouts).  The [B,N,M] score matrix is never materialised.  workspace: scratch of
+ * l3d_soft_correspondence_workspace_floats(B,N,M) floats.  C % 16 != 0 -> L3D_ERR_UNSUPPORTED. */
+size_t l3d_soft_correspondence_workspace_floats(int B, int N, int M);
+int l3d_soft_correspondence(const float *src_emb, const float *tgt_emb, const float *tgt, int B, int C, int N,
+                            int M, float scale, float *workspace, float *src_corr, l3d_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Shared-MLP (1x1 conv) stack on fp32 MFMA  (a8)
  * ------------------------------------------------------------------------------------------- */

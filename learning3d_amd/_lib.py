@@ -43,6 +43,8 @@ SIGNATURES = {
     "l3d_knn_point": [_I, _P, _P, _I, _I, _I, _P, _P, _P],
     "l3d_kabsch": [_P, _P, _I, _I, _P, _P, _P, _P],
     "l3d_svd3x3_rotation": [_P, _I, _P, _P],
+    "l3d_soft_correspondence_workspace_floats": [_I, _I, _I],
+    "l3d_soft_correspondence": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
     "l3d_edgeconv_packed_floats": [_I, _I, _I, _I],
     "l3d_edgeconv_pack": [_P, _P, _P, _I, _I, _I, _I, _P],
     "l3d_edgeconv_forward": [_P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P],
@@ -55,7 +57,8 @@ SIGNATURES = {
     "l3d_emd_forward": [_P, _P, _I, _I, _I, _P, _P, _P, _P],
     "l3d_emd_backward": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
 }
-_RESTYPE = {"l3d_status_string": C.c_char_p, "l3d_edgeconv_packed_floats": _SZ, "l3d_split_bytes": _SZ}
+_RESTYPE = {"l3d_status_string": C.c_char_p, "l3d_edgeconv_packed_floats": _SZ, "l3d_split_bytes": _SZ,
+            "l3d_soft_correspondence_workspace_floats": _SZ}
 
 
 class L3DError(RuntimeError):

@@ -1,0 +1,235 @@
+// softcorr.hip -- the soft-correspondence step of SVDHead (utils/svd.py:22-27) as ONE flash-style pass:
+//     scores = softmax_j( <src_emb[:, i], tgt_emb[:, j]> / sqrt(C) ),   src_corr[:, i] = sum_j scores[i][j] * tgt[:, j]
+// The reference materialises scores [B,N,M] (134 MB at B=32, N=M=1024), reads it for the softmax,
+// writes it, transposes it and reads it again for the second matmul.  Here the score tile lives in MFMA
+// accumulators, the softmax is online (running max / sum per query) and the "value" matrix is just the
+// three target coordinates, so nothing of size N x M ever leaves the CU.  SURVEY.md 8(f) rank 1.
+//
+// The score GEMM (2 B N M C FLOP = 34 GFLOP at C = 512) runs as bf16x3 on the bf16 matrix cores
+// (split_bf16.h: fp32 operands split exactly into three bf16 planes, six products, fp32 accumulate).
+// D[j][i] = sum_c K[j][c] Q[i][c] with the KEYS on the MFMA row axis: a lane then holds 64 keys of ONE
+// query per accumulator column, so max / exp / sum / weighted coordinate sums are in-lane.
+//
+// Workgroup = 128 queries x (M / KS) keys of one cloud, 256 threads = 4 waves (2 over keys x 2 over
+// queries, wave tile 128 keys x 64 queries), key tiles of 256, channel chunks of 16 double-buffered in
+// LDS exactly as conv_split.hip (both operands staged from the channel-first [B,C,N] embeddings with
+// per-lane coalesced dword loads and split in flight).  Every lane keeps its own running (m, l, o[3])
+// per query column; the 4 x KS partial states of a query (2 lane halves x 2 key waves x KS key splits)
+// go to a small workspace and a second kernel merges them -- no cross-wave traffic inside the loop.
+#include "common.h"
+#include "split_bf16.h"
+
+#define SC_TQ 128
+#define SC_TK 256
+#define SC_KREG (256 * 16)
+#define SC_QREG (128 * 16 + 64)
+#define SC_BUF (6 * SC_KREG + 6 * SC_QREG)
+#define SC_VOFF (2 * SC_BUF)
+#define SC_LDS (SC_VOFF + SC_TK * 16)
+#define SC_NEG (-1.0e30f)
+
+// partial state layout in the workspace: [B][N][parts][5] = (m, l, o0, o1, o2)
+template <int DUMMY>
+__global__ __launch_bounds__(256, 2) void softcorr_kernel(const float *__restrict__ src_emb,
+                                                          const float *__restrict__ tgt_emb,
+                                                          const float *__restrict__ tgt, int C, int N, int M,
+                                                          float scale, int ksplit, float *__restrict__ ws)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int i0 = blockIdx.x * SC_TQ, b = blockIdx.y, ks = blockIdx.z;
+    const int nk = C / 16;
+    const int keys_per_split = ((M + ksplit * SC_TK - 1) / (ksplit * SC_TK)) * SC_TK;
+    const int j_begin = ks * keys_per_split, j_end = min(M, j_begin + keys_per_split);
+    const int parts = 4 * ksplit;
+
+    // staging: K rows t (both octets), Q row t & 127, octet t >> 7
+    const float *kbase = tgt_emb + (size_t)b * C * M;
+    const float *qbase = src_emb + (size_t)b * C * N;
+    const int qrow = t & 127, qkg = t >> 7;
+    const int qn = min(i0 + qrow, N - 1);
+    const int k_lds = t * 16;                                        // + kg * SC_KREG + p * 2 * SC_KREG
+    const int q_lds = 6 * SC_KREG + qkg * SC_QREG + qrow * 16;       // + p * 2 * SC_QREG
+
+    // running softmax state: 2 query columns per lane
+    float m_run[2] = {SC_NEG, SC_NEG}, l_run[2] = {0.f, 0.f}, o_run[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    const float sl2 = scale * 1.44269504088896340736f;               // scores are compared / exponentiated in log2 units
+
+    const int a_off = (lane >> 5) * SC_KREG + (wm * 128 + (lane & 31)) * 16;                  // + a*512 + p*2*SC_KREG
+    const int b_off = 6 * SC_KREG + (lane >> 5) * SC_QREG + (wn * 64 + (lane & 31)) * 16;     // + c*512 + p*2*SC_QREG
+
+    for (int j0 = j_begin; j0 < j_end; j0 += SC_TK) {
+        const int kn = min(j0 + t, M - 1);
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[a][c][r] = 0.f;
+
+        float kv[2][8], qv[8];
+#define SC_LOAD(KC)                                                                                   \
+        do {                                                                                          \
+            _Pragma("unroll") for (int kg = 0; kg < 2; kg++)                                          \
+                _Pragma("unroll") for (int e = 0; e < 8; e++)                                         \
+                    kv[kg][e] = kbase[(size_t)((KC) * 16 + kg * 8 + e) * M + kn];                     \
+            _Pragma("unroll") for (int e = 0; e < 8; e++)                                             \
+                qv[e] = qbase[(size_t)((KC) * 16 + qkg * 8 + e) * N + qn];                            \
+        } while (0)
+#define SC_STORE(BUF)                                                                                 \
+        do {                                                                                          \
+            unsigned char *base_ = lds + (BUF) * SC_BUF;                                              \
+            uint4 h_, m_, l_;                                                                         \
+            _Pragma("unroll") for (int kg = 0; kg < 2; kg++) {                                        \
+                split8(kv[kg], h_, m_, l_);                                                           \
+                *(uint4 *)(base_ + k_lds + kg * SC_KREG) = h_;                                        \
+                *(uint4 *)(base_ + k_lds + kg * SC_KREG + 2 * SC_KREG) = m_;                          \
+                *(uint4 *)(base_ + k_lds + kg * SC_KREG + 4 * SC_KREG) = l_;                          \
+            }                                                                                         \
+            split8(qv, h_, m_, l_);                                                                   \
+            *(uint4 *)(base_ + q_lds) = h_;                                                           \
+            *(uint4 *)(base_ + q_lds + 2 * SC_QREG) = m_;                                             \
+            *(uint4 *)(base_ + q_lds + 4 * SC_QREG) = l_;                                             \
+        } while (0)
+
+        __syncthreads();                 // previous key tile's LDS reads (operands and V) are done
+        {                                // V tile: target coordinates of this key tile
+            const float *tb = tgt + (size_t)b * 3 * M;
+            const float4 v = {tb[kn], tb[(size_t)M + kn], tb[(size_t)2 * M + kn], 0.f};
+            *(float4 *)(lds + SC_VOFF + t * 16) = v;
+        }
+        SC_LOAD(0);
+        SC_STORE(0);
+        __syncthreads();
+        for (int kc = 0; kc < nk; kc++) {
+            const int buf = kc & 1;
+            const bool more = kc + 1 < nk;
+            if (more) SC_LOAD(kc + 1);
+            const unsigned char *base = lds + buf * SC_BUF;
+            // operand fragments: the 6 query fragments stay live, the key fragments are fetched one
+            // plane at a time (l, m, h) so that 10 fragments are live instead of 18 (register budget:
+            // 128 accumulators + staging + softmax state must fit 256 for two workgroups per CU)
+            bf16x8 Bf[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; p++)
+#pragma unroll
+                for (int c = 0; c < 2; c++) Bf[c][p] = *(const bf16x8 *)(base + b_off + c * 512 + p * 2 * SC_QREG);
+#pragma unroll
+            for (int pa = 2; pa >= 0; pa--) {
+                bf16x8 A[4];
+#pragma unroll
+                for (int a = 0; a < 4; a++) A[a] = *(const bf16x8 *)(base + a_off + a * 512 + pa * 2 * SC_KREG);
+                // products with this key plane, smallest first: l*h | m*m, m*h | h*l, h*m, h*h
+#pragma unroll
+                for (int pb = 2; pb >= 0; pb--) {
+                    if (pa + pb > 2) continue;
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int c = 0; c < 2; c++)
+                            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a], Bf[c][pb], acc[a][c], 0, 0, 0);
+                }
+            }
+            if (more) SC_STORE(buf ^ 1);
+            __syncthreads();
+        }
+#undef SC_LOAD
+#undef SC_STORE
+
+        // ---- online softmax update.  This lane's keys: j0 + wm*128 + a*32 + (r&3) + 8(r>>2) + 4(lane>>5)
+        float m_new[2], alpha[2], lsum[2] = {0.f, 0.f}, osum[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            float smax = SC_NEG;
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int j = j0 + wm * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float s = j < j_end ? acc[a][c][r] * sl2 : SC_NEG;
+                    acc[a][c][r] = s;
+                    smax = fmaxf(smax, s);
+                }
+            m_new[c] = fmaxf(m_run[c], smax);
+            alpha[c] = exp2f(m_run[c] - m_new[c]);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int jl = wm * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float4 v = *(const float4 *)(lds + SC_VOFF + jl * 16);
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const float p = acc[a][c][r] > 0.5f * SC_NEG ? exp2f(acc[a][c][r] - m_new[c]) : 0.f;
+                    lsum[c] += p;
+                    osum[c][0] = fmaf(p, v.x, osum[c][0]);
+                    osum[c][1] = fmaf(p, v.y, osum[c][1]);
+                    osum[c][2] = fmaf(p, v.z, osum[c][2]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);       // keep the 64 V reads from being hoisted into one 256-register burst
+        }
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            m_run[c] = m_new[c];
+            l_run[c] = l_run[c] * alpha[c] + lsum[c];
+#pragma unroll
+            for (int d = 0; d < 3; d++) o_run[c][d] = o_run[c][d] * alpha[c] + osum[c][d];
+        }
+    }
+
+    // ---- partial states out: part index = (ks*2 + wm)*2 + (lane>>5)
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int i = i0 + wn * 64 + c * 32 + (lane & 31);
+        if (i < N) {
+            float *dst = ws + (((size_t)b * N + i) * parts + (ks * 2 + wm) * 2 + (lane >> 5)) * 5;
+            dst[0] = m_run[c]; dst[1] = l_run[c];
+            dst[2] = o_run[c][0]; dst[3] = o_run[c][1]; dst[4] = o_run[c][2];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void softcorr_merge_kernel(const float *__restrict__ ws, int N, int parts,
+                                                             float *__restrict__ src_corr /*[B][3][N]*/)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i >= N) return;
+    const float *p = ws + ((size_t)b * N + i) * parts * 5;
+    float m = SC_NEG;
+    for (int q = 0; q < parts; q++) m = fmaxf(m, p[q * 5]);
+    float l = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    for (int q = 0; q < parts; q++) {
+        const float w = exp2f(p[q * 5] - m);
+        l = fmaf(p[q * 5 + 1], w, l);
+        o0 = fmaf(p[q * 5 + 2], w, o0); o1 = fmaf(p[q * 5 + 3], w, o1); o2 = fmaf(p[q * 5 + 4], w, o2);
+    }
+    float *out = src_corr + (size_t)b * 3 * N + i;
+    out[0] = o0 / l; out[(size_t)N] = o1 / l; out[(size_t)2 * N] = o2 / l;
+}
+
+static int sc_ksplit(int M) { return M >= 2 * SC_TK ? 2 : 1; }
+
+extern "C" size_t l3d_soft_correspondence_workspace_floats(int B, int N, int M)
+{
+    return (size_t)B * N * 4 * sc_ksplit(M) * 5;
+}
+
+extern "C" int l3d_soft_correspondence(const float *src_emb, const float *tgt_emb, const float *tgt, int B, int C,
+                                       int N, int M, float scale, float *workspace, float *src_corr,
+                                       l3d_stream_t stream)
+{
+    L3D_REQUIRE(src_emb && tgt_emb && tgt && workspace && src_corr && B > 0 && C > 0 && N > 0 && M > 0);
+    if (C % 16 || B > 65535) return L3D_ERR_UNSUPPORTED;
+    const int ksplit = sc_ksplit(M);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(l3d_divup(N, SC_TQ), B, ksplit), block(256);
+    hipLaunchKernelGGL(softcorr_kernel<0>, grid, block, SC_LDS, st, src_emb, tgt_emb, tgt, C, N, M, scale, ksplit, workspace);
+    int rc = l3d_check_launch();
+    if (rc != L3D_OK) return rc;
+    hipLaunchKernelGGL(softcorr_merge_kernel, dim3(l3d_divup(N, 256), B), dim3(256), 0, st, workspace, N, 4 * ksplit, src_corr);
+    return l3d_check_launch();
+}

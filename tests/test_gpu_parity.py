@@ -429,6 +429,34 @@ def test_pcn_fused_matches_reference_order_path():
         np.testing.assert_allclose(fused[k].cpu().numpy(), ref[k].detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
+def test_soft_correspondence_flash_vs_fp64():
+    """Fused score-GEMM + softmax + weighted target sum (softcorr.hip) against an fp64 evaluation of
+    utils/svd.py:22-27, ragged N / M included; and the SVDHead built on it against the oracle."""
+    from learning3d_amd.utils.svd import soft_correspondence, SVDHead
+    rng = np.random.default_rng(33)
+    for (B, C, N, M) in [(2, 512, 1024, 1024), (3, 64, 200, 333), (1, 128, 128, 700), (2, 32, 77, 64)]:
+        q = rng.standard_normal((B, C, N)).astype(np.float32)
+        k = rng.standard_normal((B, C, M)).astype(np.float32)
+        v = rng.uniform(-1, 1, (B, 3, M)).astype(np.float32)
+        s = np.einsum("bcn,bcm->bnm", q.astype(np.float64), k.astype(np.float64)) / np.sqrt(C)
+        s = np.exp(s - s.max(axis=2, keepdims=True))
+        s /= s.sum(axis=2, keepdims=True)
+        want = np.einsum("bdm,bnm->bdn", v.astype(np.float64), s)
+        got = soft_correspondence(dev(q), dev(k), dev(v)).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-6)
+    # SVD head end to end (R, t within 1e-5 of the oracle's torch.svd-based restatement)
+    B, C, N = 4, 64, 256
+    src = rng.uniform(-0.5, 0.5, (B, N, 3)).astype(np.float32)
+    tgt = rng.uniform(-0.5, 0.5, (B, N, 3)).astype(np.float32)
+    se = rng.standard_normal((B, C, N)).astype(np.float32)
+    te = rng.standard_normal((B, C, N)).astype(np.float32)
+    R_want, t_want = oracle.svd_head(se, te, src, tgt)
+    with torch.no_grad():
+        R, t = SVDHead(C).cuda()(dev(se), dev(te), dev(src), dev(tgt))
+    np.testing.assert_allclose(R.cpu().numpy(), R_want, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(t.cpu().numpy(), t_want, rtol=0, atol=1e-5)
+
+
 # --------------------------------------------------------------------------------------------- EMD
 def test_emd_vs_oracle():
     from learning3d_amd.losses.emd import EMDFunction

@@ -71,6 +71,19 @@ def main():
         res["split_w5"] = (t, 1024 * 512 * 10 / t / 1e3, "GB/s")
         t = timeit(lambda: net(x))
         res["dgcnn_fwd_c2"] = (t, B / t * 1e6, "clouds/s")
+        # c3: SVDHead soft correspondences, B=32, C=512, N=M=1024 (flash-style kernel vs the torch-op composition)
+        from learning3d_amd.utils.svd import soft_correspondence
+        se = torch.randn((32, 512, 1024), generator=g).to(dev)
+        te = torch.randn((32, 512, 1024), generator=g).to(dev)
+        tg = (torch.rand((32, 3, 1024), generator=g) - 0.5).to(dev)
+        t = timeit(lambda: soft_correspondence(se, te, tg), warm=3, iters=10)
+        res["softcorr_c3"] = (t, 2 * 32 * 1024 * 1024 * 512 / t / 1e6, "TFLOP/s(fp32-equiv)")
+        def torch_corr():
+            sc = torch.matmul(se.transpose(2, 1).contiguous(), te) / (512 ** 0.5)
+            sc = torch.softmax(sc, dim=2)
+            return torch.matmul(tg, sc.transpose(2, 1).contiguous())
+        t = timeit(torch_corr, warm=3, iters=10)
+        res["softcorr_c3_torch_ops"] = (t, 2 * 32 * 1024 * 1024 * 512 / t / 1e6, "TFLOP/s")
         # c4 slice: Chamfer 2048 x 16384 (B=8 of 64) -- O(N^2) stress
         a4 = torch.rand((8, 16384, 3), generator=g).to(dev)
         b4 = torch.rand((8, 16384, 3), generator=g).to(dev)
