@@ -173,6 +173,11 @@ size_t l3d_soft_correspondence_workspace_floats(int B, int N, int M);
 int l3d_soft_correspondence(const float *src_emb, const float *tgt_emb, const float *tgt, int B, int C, int N,
                             int M, float scale, float *workspace, float *src_corr, l3d_stream_t stream);
 
+/* LayerNorm of DCP's pointer network == utils/transformer.py:109-119 (unbiased std, eps added to std):
+ *   y[r][:] = a * (x[r][:] - mean_r) / (std_r + eps) + b,   x, y [rows][C] fp32, C % 4 == 0, C <= 2048. */
+int l3d_layernorm_ref(const float *x, const float *a, const float *b, float eps, long rows, int C, float *y,
+                      l3d_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Shared-MLP (1x1 conv) stack on fp32 MFMA  (a8)
  * ------------------------------------------------------------------------------------------- */

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libl3d_hip.so")
 _lib = None
 
-_P, _I, _F, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_P, _I, _F, _SZ, _L = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long
 
 # name -> argtypes (restype is int unless listed in _RESTYPE)
 SIGNATURES = {
@@ -45,6 +45,7 @@ SIGNATURES = {
     "l3d_svd3x3_rotation": [_P, _I, _P, _P],
     "l3d_soft_correspondence_workspace_floats": [_I, _I, _I],
     "l3d_soft_correspondence": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
+    "l3d_layernorm_ref": [_P, _P, _P, _F, _L, _I, _P, _P],
     "l3d_edgeconv_packed_floats": [_I, _I, _I, _I],
     "l3d_edgeconv_pack": [_P, _P, _P, _I, _I, _I, _I, _P],
     "l3d_edgeconv_forward": [_P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P],

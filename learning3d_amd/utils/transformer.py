@@ -1,13 +1,41 @@
-"""DCP's pointer network (reference: utils/transformer.py:14-243), kept in torch (rocBLAS GEMMs):
-SURVEY.md section 2 row 9 marks the Transformer itself out of scope for hand kernels; it is here so
-that `learning3d_amd.models.DCP` is a drop-in.  Module / parameter names follow the reference so its
-checkpoints load unchanged (model.encoder.layers.0.self_attn.linears.0.weight, ... .norm.a_2, ...)."""
+"""DCP's pointer network (reference: utils/transformer.py:14-243).  Module / parameter names follow the
+reference so its checkpoints load unchanged (model.encoder.layers.0.self_attn.linears.0.weight, ...
+.norm.a_2, ...).  Without autograd, on the GPU and at tileable shapes the twelve Linear layers and the
+two feed-forward blocks of a pass (62 % of its FLOPs) run on the bf16x3 1x1-conv kernel
+(`l3d_pointwise_conv_split`: a Linear over points IS a 1x1 conv) with bias and ReLU folded into its
+epilogue; its [B,Cout,N] output layout is consumed as is (heads become [B,h,d_k,N] views, the attention
+matmuls take the transposes for free).  LayerNorm, softmax and the attention matmuls stay torch ops."""
 import copy
 import math
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+
+def _fast_linear_ok(lin, x, n_points):
+    """bf16x3 conv kernel applicable: inference, GPU, Cout % 256 == 0, points % 128 == 0, Cin % 16 == 0"""
+    from ..models import _fused
+    return (x.is_cuda and not (torch.is_grad_enabled() and (x.requires_grad or lin.weight.requires_grad))
+            and _fused.split_eligible(lin.in_features, lin.out_features, n_points))
+
+
+def _linear_cf(lin, x, channel_last, relu=False, out_scale=None):
+    """Linear over points as a 1x1 conv: x [B,N,Cin] (channel_last) or [B,Cin,N] -> [B,Cout,N];
+    out_scale multiplies the whole result (weights and bias) in the kernel's epilogue."""
+    from ..models import _fused
+    key = (lin.weight.data_ptr(), lin.weight._version, str(lin.weight.device))
+    cache = getattr(lin, "_l3d_split", None)
+    if cache is None or cache[0] != key:
+        w = lin.weight.detach().float().contiguous()
+        cache = (key, w, _fused.split_rows(w))
+        lin._l3d_split = cache
+    bias = lin.bias.detach() if lin.bias is not None else None
+    scale = None
+    if out_scale is not None:
+        scale = torch.full((lin.out_features,), float(out_scale), dtype=torch.float32, device=x.device)
+        bias = bias * float(out_scale) if bias is not None else None
+    return _fused.pointwise_conv(x, cache[1], scale, bias, relu=relu, channel_last=channel_last, w_split=cache[2])
 
 
 def clones(module, N):
@@ -33,6 +61,15 @@ class LayerNorm(nn.Module):
         self.eps = eps
 
     def forward(self, x):
+        C = x.size(-1)
+        if (x.is_cuda and x.dtype == torch.float32 and C % 4 == 0 and 1 < C <= 2048
+                and not (torch.is_grad_enabled() and (x.requires_grad or self.a_2.requires_grad))):
+            from .._lib import check, lib, ptr, stream_ptr
+            xc = x.contiguous()
+            y = torch.empty_like(xc)
+            check(lib().l3d_layernorm_ref(ptr(xc), ptr(self.a_2.detach().contiguous()), ptr(self.b_2.detach().contiguous()),
+                                          float(self.eps), xc.numel() // C, C, ptr(y), stream_ptr()), "l3d_layernorm_ref")
+            return y
         mean = x.mean(-1, keepdim=True)
         std = x.std(-1, keepdim=True)
         return self.a_2 * (x - mean) / (std + self.eps) + self.b_2
@@ -61,6 +98,15 @@ class MultiHeadedAttention(nn.Module):
         if mask is not None:
             mask = mask.unsqueeze(1)
         nb = query.size(0)
+        if mask is None and all(_fast_linear_ok(self.linears[0], t, t.size(1)) for t in (query, key, value)):
+            # channel-first projections: [B, h*d_k, N] viewed as [B, h, d_k, N] -- no head transposes
+            # the 1/sqrt(d_k) of the scores rides in the q projection's epilogue (a [B,h,N,M] pass saved)
+            q, k, v = [_linear_cf(lin, x, True, out_scale=sc).view(nb, self.h, self.d_k, x.size(1))
+                       for lin, x, sc in zip(self.linears, (query, key, value), (1.0 / math.sqrt(self.d_k), None, None))]
+            p = F.softmax(torch.matmul(q.transpose(-2, -1), k), dim=-1)                           # [B,h,N,M]
+            self.attn = p
+            ctx = torch.matmul(v, p.transpose(-2, -1)).view(nb, self.h * self.d_k, query.size(1))  # [B,C,N]
+            return _linear_cf(self.linears[-1], ctx, False).transpose(1, 2)                       # [B,N,C] view
         q, k, v = [lin(x).view(nb, -1, self.h, self.d_k).transpose(1, 2)
                    for lin, x in zip(self.linears, (query, key, value))]
         x, self.attn = attention(q, k, v, mask=mask, dropout=self.dropout)
@@ -77,6 +123,9 @@ class PositionwiseFeedForward(nn.Module):
         self.dropout = None
 
     def forward(self, x):
+        if x.dim() == 3 and _fast_linear_ok(self.w_1, x, x.size(1)) and _fast_linear_ok(self.w_2, x, x.size(1)):
+            h = _linear_cf(self.w_1, x, True, relu=True)                  # [B,d_ff,N]
+            return _linear_cf(self.w_2, h, False).transpose(1, 2)         # [B,N,d_model] view
         return self.w_2(F.relu(self.w_1(x)))
 
 

@@ -494,6 +494,27 @@ def test_dcp_golden(golden):
     np.testing.assert_allclose(out["transformed_source"].cpu().numpy(), g["transformed_source"], atol=1e-4)
 
 
+def test_transformer_fast_linear_path_matches_torch_path():
+    """DCP's pointer network: the no-grad GPU path (Linear / feed-forward layers on the bf16x3 conv kernel,
+    channel-first projections) against the same module evaluated in fp64 on the CPU
+    (utils/transformer.py:14-243 op order)."""
+    import copy
+    from learning3d_amd.utils.transformer import Transformer
+    torch.manual_seed(12)
+    net = Transformer(256, 1, 0.0, 512, 4).eval()
+    ref = copy.deepcopy(net).double()
+    rng = np.random.default_rng(13)
+    a = rng.standard_normal((2, 256, 128)).astype(np.float32)
+    b = rng.standard_normal((2, 256, 128)).astype(np.float32)
+    with torch.no_grad():
+        want = ref(torch.from_numpy(a).double(), torch.from_numpy(b).double())
+        got = net.cuda()(dev(a), dev(b))
+    lin = net.model.encoder.layers[0].self_attn.linears[0]
+    assert getattr(lin, "_l3d_split", None) is not None, "fast path not taken"
+    for g_, w_ in zip(got, want):
+        np.testing.assert_allclose(g_.cpu().numpy(), w_.numpy(), rtol=1e-4, atol=1e-5)
+
+
 def test_flownet3d_set_abstraction_vs_oracle():
     """BASELINE config 5's layer (sa1: npoint=1024 -> here 128, r=0.5, K=16, mlp [32,32,64]) against the
     oracle composition FPS -> gather -> ball query -> group -> torch-CPU conv stack."""
