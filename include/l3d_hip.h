@@ -173,6 +173,15 @@ size_t l3d_soft_correspondence_workspace_floats(int B, int N, int M);
 int l3d_soft_correspondence(const float *src_emb, const float *tgt_emb, const float *tgt, int B, int C, int N,
                             int M, float scale, float *workspace, float *src_corr, l3d_stream_t stream);
 
+/* Scaled-dot-product attention of DCP's pointer network == utils/transformer.py:17-25 (mask = None, no
+ * dropout), flash-style (attention.hip):  q [B, H*D, N], k, v [B, H*D, M] (channel-first: head h is rows
+ * h*D .. h*D+D-1) -> ctx [B, H*D, N],
+ *   ctx[b][h*D+d][i] = sum_j softmax_j(scale * <q[b][h*D+:][i], k[b][h*D+:][j]>) * v[b][h*D+d][j].
+ * The [B,H,N,M] scores are never materialised; both GEMMs run as bf16x3 (fp32-level error).
+ * D must be 32, 64 or 128, else L3D_ERR_UNSUPPORTED. */
+int l3d_attention_forward(const float *q, const float *k, const float *v, int B, int H, int D, int N, int M,
+                          float scale, float *ctx, l3d_stream_t stream);
+
 /* LayerNorm of DCP's pointer network == utils/transformer.py:109-119 (unbiased std, eps added to std):
  *   y[r][:] = a * (x[r][:] - mean_r) / (std_r + eps) + b,   x, y [rows][C] fp32, C % 4 == 0, C <= 2048. */
 int l3d_layernorm_ref(const float *x, const float *a, const float *b, float eps, long rows, int C, float *y,

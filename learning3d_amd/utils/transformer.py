@@ -4,13 +4,17 @@ reference so its checkpoints load unchanged (model.encoder.layers.0.self_attn.li
 two feed-forward blocks of a pass (62 % of its FLOPs) run on the bf16x3 1x1-conv kernel
 (`l3d_pointwise_conv_split`: a Linear over points IS a 1x1 conv) with bias and ReLU folded into its
 epilogue; its [B,Cout,N] output layout is consumed as is (heads become [B,h,d_k,N] views, the attention
-matmuls take the transposes for free).  LayerNorm, softmax and the attention matmuls stay torch ops."""
+matmuls take the transposes for free), the attention itself is one flash-style kernel
+(`l3d_attention_forward`, no [B,h,N,N] score tensor) and LayerNorm one fused kernel (`l3d_layernorm_ref`)."""
 import copy
 import math
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+
+FLASH_ATTENTION = True      # l3d_attention_forward for d_k in {32, 64, 128}; False: torch matmul + softmax + matmul
 
 
 def _fast_linear_ok(lin, x, n_points):
@@ -100,12 +104,17 @@ class MultiHeadedAttention(nn.Module):
         nb = query.size(0)
         if mask is None and all(_fast_linear_ok(self.linears[0], t, t.size(1)) for t in (query, key, value)):
             # channel-first projections: [B, h*d_k, N] viewed as [B, h, d_k, N] -- no head transposes
-            # the 1/sqrt(d_k) of the scores rides in the q projection's epilogue (a [B,h,N,M] pass saved)
-            q, k, v = [_linear_cf(lin, x, True, out_scale=sc).view(nb, self.h, self.d_k, x.size(1))
-                       for lin, x, sc in zip(self.linears, (query, key, value), (1.0 / math.sqrt(self.d_k), None, None))]
-            p = F.softmax(torch.matmul(q.transpose(-2, -1), k), dim=-1)                           # [B,h,N,M]
-            self.attn = p
-            ctx = torch.matmul(v, p.transpose(-2, -1)).view(nb, self.h * self.d_k, query.size(1))  # [B,C,N]
+            q, k, v = [_linear_cf(lin, x, True) for lin, x in zip(self.linears, (query, key, value))]   # [B,C,N]
+            self.attn = None                                   # the [B,h,N,M] map is never formed
+            if FLASH_ATTENTION and self.d_k in (32, 64, 128):
+                from .._lib import check, lib, ptr, stream_ptr
+                ctx = torch.empty_like(q)
+                check(lib().l3d_attention_forward(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, query.size(1), key.size(1),
+                                                  1.0 / math.sqrt(self.d_k), ptr(ctx), stream_ptr()), "l3d_attention_forward")
+            else:
+                qh, kh, vh = [z.view(nb, self.h, self.d_k, z.size(2)) for z in (q, k, v)]
+                p = F.softmax(torch.matmul(qh.transpose(-2, -1), kh) / math.sqrt(self.d_k), dim=-1)   # [B,h,N,M]
+                ctx = torch.matmul(vh, p.transpose(-2, -1)).view(nb, self.h * self.d_k, query.size(1))
             return _linear_cf(self.linears[-1], ctx, False).transpose(1, 2)                       # [B,N,C] view
         q, k, v = [lin(x).view(nb, -1, self.h, self.d_k).transpose(1, 2)
                    for lin, x in zip(self.linears, (query, key, value))]

@@ -494,6 +494,26 @@ def test_dcp_golden(golden):
     np.testing.assert_allclose(out["transformed_source"].cpu().numpy(), g["transformed_source"], atol=1e-4)
 
 
+def test_flash_attention_vs_fp64():
+    """l3d_attention_forward (attention.hip) against an fp64 evaluation of utils/transformer.py:17-25 on
+    channel-first q, k, v, all three head widths, ragged N / M."""
+    from learning3d_amd._lib import lib, check, ptr, stream_ptr
+    rng = np.random.default_rng(41)
+    for (B, H, D, N, M) in [(2, 4, 128, 256, 256), (1, 2, 64, 200, 333), (2, 1, 32, 128, 100), (1, 4, 128, 1024, 1024)]:
+        q = rng.standard_normal((B, H, D, N)).astype(np.float32)
+        k = rng.standard_normal((B, H, D, M)).astype(np.float32)
+        v = rng.standard_normal((B, H, D, M)).astype(np.float32)
+        s = np.einsum("bhdn,bhdm->bhnm", q.astype(np.float64), k.astype(np.float64)) / np.sqrt(D)
+        s = np.exp(s - s.max(axis=-1, keepdims=True))
+        s /= s.sum(axis=-1, keepdims=True)
+        want = np.einsum("bhdm,bhnm->bhdn", v.astype(np.float64), s)
+        qd, kd, vd = dev(q.reshape(B, H * D, N)), dev(k.reshape(B, H * D, M)), dev(v.reshape(B, H * D, M))
+        out = torch.empty_like(qd)
+        check(lib().l3d_attention_forward(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, float(1 / np.sqrt(D)), ptr(out),
+                                          stream_ptr()), "l3d_attention_forward")
+        np.testing.assert_allclose(out.cpu().numpy().reshape(B, H, D, N), want, rtol=1e-5, atol=2e-6)
+
+
 def test_transformer_fast_linear_path_matches_torch_path():
     """DCP's pointer network: the no-grad GPU path (Linear / feed-forward layers on the bf16x3 conv kernel,
     channel-first projections) against the same module evaluated in fp64 on the CPU

@@ -26,3 +26,16 @@ with torch.no_grad():
     print("residual add (strided view) %8.1f us" % timeit(lambda: x + v.view(B, 512, N).transpose(1, 2)))
     qq = q.transpose(-2, -1).contiguous()
     print("sdpa fused          %8.1f us" % timeit(lambda: F.scaled_dot_product_attention(qq, k.transpose(-2, -1).contiguous(), v.transpose(-2, -1).contiguous())))
+    from learning3d_amd._lib import lib, check, ptr, stream_ptr
+    qc, kc, vc = [z.reshape(B, H * D, N).contiguous() for z in (q, k, v)]
+    out = torch.empty_like(qc)
+    def flash():
+        check(lib().l3d_attention_forward(ptr(qc), ptr(kc), ptr(vc), B, H, D, N, N, 1 / math.sqrt(D), ptr(out), stream_ptr()), "att")
+    print("flash attention (l3d)  %8.1f us" % timeit(flash))
+    from learning3d_amd.models import _fused
+    w = torch.randn(512, 512, device="cuda"); bias = torch.randn(512, device="cuda")
+    ws = _fused.split_rows(w)
+    print("linear 512->512 (conv_split, cl in) %8.1f us" % timeit(lambda: _fused.pointwise_conv(x, w, None, bias, channel_last=True, w_split=ws)))
+    xcf = x.transpose(1, 2).contiguous()
+    print("linear 512->512 (conv_split, cf in) %8.1f us" % timeit(lambda: _fused.pointwise_conv(xcf, w, None, bias, channel_last=False, w_split=ws)))
+    print("linear 512->512 (torch)             %8.1f us" % timeit(lambda: F.linear(x, w, bias)))
