@@ -21,6 +21,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL needs it)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -157,7 +159,7 @@ def main():
 
     def sync():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local])           # RCCL barrier on this rank's own device
         torch.cuda.synchronize()
 
     # Live HIP-event timing of the dominant kernel inside the timed region, on the stream it is
@@ -230,7 +232,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local])
         dist.destroy_process_group()
 
 
