@@ -33,6 +33,9 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 T
 MFMA_F32_PEAK_TF = 157.3         # MI355X_MICROARCH.md: dense fp32 MFMA peak
 MFMA_BF16_PEAK_TF = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA peak (2.17 PF sustained in tools/probe_mfma_bf16.hip)
 SPLIT_PRODUCTS = 6               # bf16 MFMA products per fp32 product in the bf16x3 kernels
+VALU_PEAK_LANEOPS = 256 * 4 * 16 * 2.4e9     # 39.3 T lane-ops/s: 256 CUs x 4 SIMD16 x 2.4 GHz (an fma counts once)
+KNN_LANEOPS_PER_PAIR = 7         # 2 fma + 1 mul + 2 sub + compare/insert
+CHAMFER_LANEOPS_PER_PAIR = 8
 # algorithmic work per cloud (restated in DESIGN.md)
 KNN_BYTES_PER_CLOUD = NPTS * 3 * 4 + NPTS * KNN * 8                 # 176 128 B
 CHAMFER_BYTES_PER_CLOUD = 2 * NPTS * 3 * 4 + 2 * NPTS * (4 + 4)     # 40 960 B
@@ -221,9 +224,14 @@ def main():
                              "traffic": pmc_traffic("knn"),
                              "avg_launch_ms": stage_ms["knn"],
                              "algorithmic_bytes_per_launch": B_PER_GPU * KNN_BYTES_PER_CLOUD,
-                             "note": "VALU-bound by construction (33.5 M pair evaluations per 5.6 MB), see DESIGN.md"},
+                             "note": "VALU-bound by construction (33.5 M pair evaluations per 5.6 MB), see DESIGN.md",
+                             "pair_evals_per_s": B_PER_GPU * NPTS * NPTS / (stage_ms["knn"] * 1e-3),
+                             "valu_frac": B_PER_GPU * NPTS * NPTS * KNN_LANEOPS_PER_PAIR /
+                             (stage_ms["knn"] * 1e-3) / VALU_PEAK_LANEOPS},
             "kernels": {"knn_ms": stage_ms["knn"], "edgeconv_ms": stage_ms["edgeconv"], "conv5_ms": stage_ms["conv5"],
                         "chamfer_ms": stage_ms["chamfer"], "conv5_tflops": c5_tf, "chamfer_alg_gbs": ch_gbs,
+                        "chamfer_valu_frac": 2 * B_PER_GPU * NPTS * NPTS * CHAMFER_LANEOPS_PER_PAIR /
+                        (stage_ms["chamfer"] * 1e-3) / VALU_PEAK_LANEOPS,
                         "knn_chamfer_alg_gbs": B_PER_GPU * (KNN_BYTES_PER_CLOUD + CHAMFER_BYTES_PER_CLOUD) /
                         ((stage_ms["knn"] + stage_ms["chamfer"]) * 1e-3) / 1e9},
             "loss": float(loss),

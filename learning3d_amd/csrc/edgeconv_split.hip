@@ -31,46 +31,6 @@ __device__ __forceinline__ float es_quad_max(float v)
     return v;
 }
 
-// ReLU in place + max over the wave's neighbours of each point (all 4 lanes of a quad get it)
-template <int MT>
-__device__ __forceinline__ f32x4 es_relu_pool(f32x4 (&h)[MT])
-{
-    f32x4 mx = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < MT; t++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            h[t][r] = fmaxf(h[t][r], 0.f);
-            mx[r] = fmaxf(mx[r], h[t][r]);
-        }
-#pragma unroll
-    for (int r = 0; r < 4; r++) mx[r] = es_quad_max(mx[r]);
-    return mx;
-}
-
-// Two finished M-tiles (2s, 2s+1) -> pooled output + (unless LAST) the three bf16 planes of k-step s
-template <int MT, bool LAST>
-__device__ __forceinline__ void es_finish_pair(f32x4 (&h0)[MT], f32x4 (&h1)[MT], bf16x8 (&pl)[3][MT],
-                                               float *__restrict__ dst /* channel 16(2s) + 4g of this point */,
-                                               bool writer)
-{
-    const f32x4 m0 = es_relu_pool<MT>(h0);
-    const f32x4 m1 = es_relu_pool<MT>(h1);
-    if (writer) {
-        *(f32x4 *)dst = m0;
-        *(f32x4 *)(dst + 16) = m1;
-    }
-    if (!LAST) {
-#pragma unroll
-        for (int t = 0; t < MT; t++) {
-            split_pair(h0[t][0], h0[t][1], pl[0][t].x, pl[1][t].x, pl[2][t].x);
-            split_pair(h0[t][2], h0[t][3], pl[0][t].y, pl[1][t].y, pl[2][t].y);
-            split_pair(h1[t][0], h1[t][1], pl[0][t].z, pl[1][t].z, pl[2][t].z);
-            split_pair(h1[t][2], h1[t][3], pl[0][t].w, pl[1][t].w, pl[2][t].w);
-        }
-    }
-}
-
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define ES_BF(u) __builtin_bit_cast(bf16x8, (u))
 #ifndef ES_VPM
