@@ -179,16 +179,33 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     stage_ms = timer.mean_ms()
-    # untimed diagnostic pass: every stage, 8 steps (reported under "kernels", not part of `value`)
-    diag = _fused.StageTimer()
-    _fused.TIMER = diag
-    for _ in range(8):
-        step()
-    torch.cuda.synchronize()
-    diag_ms = diag.mean_ms()
-    for k_, v_ in diag_ms.items():
-        stage_ms.setdefault(k_, v_)
+    # untimed diagnostics (reported under "kernels" / "roofline_knn", not part of `value`): the short
+    # kernels are timed as 20 back-to-back launches between two events -- a per-launch event pair adds
+    # ~15 us of its own to a 25-70 us kernel.
     _fused.TIMER = None
+
+    def per_launch_ms(fn, iters=20):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    import learning3d_amd.utils as U
+    with torch.no_grad():
+        xt = x.permute(0, 2, 1)
+        stage_ms["knn"] = per_launch_ms(lambda: U.knn(xt, KNN))
+        stage_ms["chamfer"] = per_launch_ms(lambda: cd(a, b))
+        idx_ = U.knn(xt, KNN)
+        packed_ = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
+        pooled_ = _fused.edgeconv_forward(x, idx_, packed_)
+        w5_, s5_, b5_, w5s_ = net._conv5_folded()
+        stage_ms["conv5"] = per_launch_ms(lambda: _fused.pointwise_conv(pooled_, w5_, s5_, b5_, relu=True, channel_last=True,
+                                                                          w_split=w5s_))
+        stage_ms.setdefault("edgeconv", per_launch_ms(lambda: _fused.edgeconv_forward(x, idx_, packed_)))
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -219,7 +236,7 @@ def main():
             # dominant kernel by time: the fused 4-layer EdgeConv stack
             "roofline": edgeconv_roofline(ec_tf, stage_ms["edgeconv"], split),
             # the metric's second half: kNN (and Chamfer) HBM rate on ALGORITHMIC bytes
-            "roofline_knn": {"kernel": "topk_scan_kernel<20,expanded>", "bound": "hbm", "achieved": knn_gbs,
+            "roofline_knn": {"kernel": "topk2_kernel<20,EXPANDED,4>", "bound": "hbm", "achieved": knn_gbs,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": knn_gbs / HBM_PEAK_GBS,
                              "traffic": pmc_traffic("knn"),
                              "avg_launch_ms": stage_ms["knn"],
