@@ -10,4 +10,5 @@ from .model_common_utils import (
     knn_point,
     query_ball_point,
 )
+from .ppfnet_util import angle_difference, pc_normalize, sample_and_group, sample_and_group_multi
 from . import pointnet2_utils
