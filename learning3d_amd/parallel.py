@@ -66,6 +66,41 @@ def allgather_chamfer_loss(partial):
     return combine_chamfer(gathered)
 
 
+class PipelinedChamferLoss:
+    """The same exchange with the collective taken off the critical path: `submit(partial)` starts this
+    step's 32-byte all_gather asynchronously (RCCL runs it on its own stream) and returns the loss of
+    the PREVIOUS submission, whose gather has had a whole step to complete, so the compute stream never
+    waits for xGMI latency or for the slowest rank of the step; `flush()` returns the last one.  Every
+    step's loss is still produced, one step late (what asynchronous gradient all-reduce does for
+    training).  With one rank there is nothing to hide and `submit` returns the current loss."""
+
+    def __init__(self):
+        self._pending = None
+        self._multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def submit(self, partial):
+        if not self._multi:
+            return combine_chamfer(partial.view(1, 4))
+        world = dist.get_world_size()
+        flat = torch.empty(world * 4, dtype=torch.float64, device=partial.device)
+        src = partial.contiguous()
+        work = dist.all_gather_into_tensor(flat, src, async_op=True)
+        prev, self._pending = self._pending, (work, flat, src)
+        return self._finish(prev)
+
+    def flush(self):
+        prev, self._pending = self._pending, None
+        return self._finish(prev)
+
+    @staticmethod
+    def _finish(pending):
+        if pending is None:
+            return None
+        work, flat, _src = pending
+        work.wait()                      # device tensors: orders the current stream after the collective
+        return combine_chamfer(flat.view(-1, 4))
+
+
 def sharded_chamfer_loss(template_shard, source_shard):
     """ChamferDistanceLoss over a batch that is sharded across ranks (forward / evaluation)."""
     from .losses.chamfer_distance import ChamferDistance, chamfer_partials

@@ -108,6 +108,18 @@ part = torch.tensor([np.sqrt(d1).astype(np.float64).sum(), np.sqrt(d2).astype(np
 loss = parallel.allgather_chamfer_loss(part)
 want = float(oracle.chamfer_loss(a, b))
 assert abs(float(loss) - want) < 1e-6, (float(loss), want)
+# pipelined exchange: step i's loss comes back from submit(i+1) / flush(), values scaled per step
+pipe = parallel.PipelinedChamferLoss()
+got = []
+for step in range(4):
+    scaled = part.clone(); scaled[:2] *= (step + 1)
+    out = pipe.submit(scaled)
+    assert (out is None) == (step == 0)
+    if out is not None: got.append(float(out))
+got.append(float(pipe.flush()))
+assert pipe.flush() is None
+for step, v in enumerate(got):
+    assert abs(v - want * (step + 1)) < 1e-5 * (step + 1), (step, v, want)
 print("RANK", rank, "OK", float(loss))
 dist.barrier(); dist.destroy_process_group()
 """
