@@ -367,6 +367,24 @@ def test_pointnet_golden(golden):
     np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-4, atol=1e-5)
 
 
+def test_knn_feature_space_matches_exact_topk():
+    """C != 3 (feature-space graphs): every returned neighbour is within rounding of the exact k nearest."""
+    from learning3d_amd.utils import knn, get_graph_feature
+    rng = np.random.default_rng(61)
+    x = rng.standard_normal((2, 64, 300)).astype(np.float32)
+    idx = knn(dev(x), 16).cpu().numpy()
+    assert idx.shape == (2, 300, 16) and idx.dtype == np.int64
+    xd = x.astype(np.float64)
+    d = ((xd[:, :, :, None] - xd[:, :, None, :]) ** 2).sum(axis=1)                 # [B,N,N]
+    kth = np.sort(d, axis=-1)[:, :, 15]
+    got = np.take_along_axis(d, idx, axis=-1).max(axis=-1)
+    assert np.all(got <= kth * (1 + 1e-5) + 1e-6)
+    assert np.all(idx[:, :, 0] == np.arange(300)[None])                           # self first
+    feat = get_graph_feature(dev(x), k=16)
+    assert feat.shape == (2, 128, 300, 16)
+    np.testing.assert_array_equal(feat[:, 64:, :, 3].cpu().numpy(), x)             # centre half = the point itself
+
+
 def test_pointwise_conv_ragged_shapes():
     from learning3d_amd.models._fused import pointwise_conv
     rng = np.random.default_rng(9)
