@@ -37,6 +37,9 @@
 #define CS_TK 16
 #define CS_REGION (256 * 16 + 64)           // bytes of one (plane, kg) region (+64: write-side bank skew)
 #define CS_BUF (12 * CS_REGION)             // W: 6 regions, X: 6 regions
+#ifndef CS_INTERLEAVE
+#define CS_INTERLEAVE 1
+#endif
 #ifndef CS_STAGES
 #define CS_STAGES 3                        // LDS chunk buffers of the 256x256 kernel (2: staging after the MFMAs; 3: inside them)
 #endif
@@ -196,9 +199,19 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const void *__restrict_
                     for (int c = 0; c < 2; c++)
                         acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[a], Bf[c][pb], acc[a][c], 0, 0, 0);
             }
-            if (pa == 1) {                  // after the l and m planes (24 of 48 MFMAs): stage chunk kc+2
+            if (pa == 1) {                  // after the l and m planes (24 of 48 MFMAs): stage chunk kc+2 ...
                 __builtin_amdgcn_sched_barrier(0);
                 if (more) CS_STORE_LDS(wbuf);
+            }
+            if (pa == 0) {                  // ... its split VALU / LDS stores issued between the h plane's 24 MFMAs
+#if CS_INTERLEAVE
+#pragma unroll
+                for (int i = 0; i < 24; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    if (i % 4 == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
