@@ -118,8 +118,8 @@ def cpu_baseline(sample_clouds=8, repeats=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-loss", action="store_true",
                     help="N>1: wait for each step's loss all_gather inside the step instead of one step later")
