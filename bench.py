@@ -140,6 +140,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    local = local % torch.cuda.device_count()     # a launcher that narrows visibility leaves one device at index 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
