@@ -229,6 +229,14 @@ int l3d_pointwise_conv(const float *x, int x_channel_last, const float *w, const
                        const float *shift, int shift_bstride, int B, int Cin, int Cout, int N,
                        int relu, float *y, l3d_stream_t stream);
 
+/* l3d_pointwise_conv with a fused max over every `pool` consecutive points (pool = 8, 16, 32, 64;
+ * N % pool == 0): y [B, Cout, N / pool].  With x = the grouped features [B, Cin, S*K] of a PointNet++ layer
+ * and pool = K this is the last conv + BN + ReLU + max-over-neighbours of models/flownet3d.py:118-122 /
+ * :170-176 / :231-232 without the [B,Cout,S,K] activation or a reduction launch. */
+int l3d_pointwise_conv_maxpool(const float *x, int x_channel_last, const float *w, const float *scale,
+                               const float *shift, int shift_bstride, int B, int Cin, int Cout, int N, int relu,
+                               int pool, float *y, l3d_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * The same per-point linear layer on the bf16 matrix cores with fp32-equivalent results ("bf16x3"):
  * every fp32 operand is split exactly into three bf16 planes (x = h + m + l) and six bf16 MFMA

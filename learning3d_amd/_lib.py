@@ -53,6 +53,7 @@ SIGNATURES = {
     "l3d_edgeconv_forward_chained": [_P, _P, _I, _I, _I, _P, _P, _P],
     "l3d_edgeconv_forward_split": [_P, _P, _I, _I, _I, _P, _P, _P],
     "l3d_pointwise_conv": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "l3d_pointwise_conv_maxpool": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_split_bytes": [_I, _I],
     "l3d_split_rows": [_P, _I, _I, _P, _P],
     "l3d_pointwise_conv_split": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],

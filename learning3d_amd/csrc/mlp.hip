@@ -342,11 +342,15 @@ extern "C" int l3d_edgeconv_forward(const float *xyz, const int64_t *idx, int B,
 // 16): the staging loads are then unconditional.  The guarded variant wraps each 16-byte load in an
 // exec-mask branch -- 26 s_and_saveexec / s_cbranch_execz per K chunk, which sat in front of every
 // chunk's MFMAs and cost ~11 % at the conv5 shape.
-template <bool XCL, bool FULL>
+// POOL: the epilogue additionally takes the max over every `pool` (8, 16, 32 or 64) consecutive points
+// and writes y [B, Cout, N / pool]: the "shared MLP over [B,C,S,K] then max over K" tail of a PointNet++
+// set-abstraction / flow-embedding layer (models/flownet3d.py:118-122, :170-176) without materialising
+// the [B,Cout,S,K] activation or launching a reduction over it.
+template <bool XCL, bool FULL, bool POOL>
 __global__ __launch_bounds__(256, 2) void pointwise_conv_kernel(
     const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ scale,
     const float *__restrict__ shift, int shift_bstride, int Cin, int Cout, int N, int relu,
-    float *__restrict__ y)
+    float *__restrict__ y, int pool)
 {
     __shared__ __attribute__((aligned(16))) float As[PW_TK][PW_LD];     // As[k][co]
     __shared__ __attribute__((aligned(16))) float Bs[PW_TK][PW_LD];     // Bs[k][n]
@@ -451,6 +455,45 @@ __global__ __launch_bounds__(256, 2) void pointwise_conv_kernel(
         }
     }
     // epilogue: D[row = co][col = n]; col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    if (POOL) {
+        const int Np = N / pool;
+        float *yb = y + (size_t)b * Cout * Np;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int co = co0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                const bool co_ok = FULL || co < Cout;
+                const float sc = (scale && co_ok) ? scale[co] : 1.f;
+                const float sh = (shift && co_ok) ? shift[(size_t)b * shift_bstride + co] : 0.f;
+                float v[2];
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int n = n0 + wn * 64 + j * 32 + l31;
+                    v[j] = acc[i][j][e] * sc + sh;
+                    if (relu) v[j] = fmaxf(v[j], 0.f);
+                    if (!FULL && n >= N) v[j] = -INFINITY;          // N % pool == 0: a group is all in or all out
+                }
+                if (pool == 64) v[0] = fmaxf(v[0], v[1]);
+                const int span = pool < 32 ? pool : 32;             // lanes to reduce over (xor masks stay inside the 32-lane half)
+#pragma unroll
+                for (int m = 1; m < 32; m <<= 1)
+                    if (m < span) {
+                        v[0] = fmaxf(v[0], __shfl_xor(v[0], m, 64));
+                        v[1] = fmaxf(v[1], __shfl_xor(v[1], m, 64));
+                    }
+                if (co_ok && (l31 & (span - 1)) == 0) {
+                    const int nb = n0 + wn * 64 + l31;
+                    if (pool == 64) {
+                        if (nb < N) yb[(size_t)co * Np + nb / 64] = v[0];
+                    } else {
+                        if (nb < N) yb[(size_t)co * Np + nb / pool] = v[0];
+                        if (nb + 32 < N) yb[(size_t)co * Np + (nb + 32) / pool] = v[1];
+                    }
+                }
+            }
+        return;
+    }
     float *yb = y + (size_t)b * Cout * N;
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -532,6 +575,26 @@ static int launch_narrow(const float *x, const float *w, const float *scale, con
     return l3d_check_launch();
 }
 
+template <bool POOL>
+static int launch_pointwise_conv(const float *x, int x_channel_last, const float *w, const float *scale,
+                                 const float *shift, int shift_bstride, int B, int Cin, int Cout, int N, int relu,
+                                 float *y, int pool, hipStream_t st)
+{
+    dim3 grid(l3d_divup(N, PW_TN), l3d_divup(Cout, PW_TM), B), block(256);
+    const bool full = (Cout % PW_TM) == 0 && (N % PW_TN) == 0 && (Cin % PW_TK) == 0 &&
+                      ((((size_t)x) | ((size_t)w)) & 15) == 0;
+#define L3D_PW(XCL_, FULL_)                                                                                  \
+    hipLaunchKernelGGL((pointwise_conv_kernel<XCL_, FULL_, POOL>), grid, block, 0, st, x, w, scale, shift,   \
+                       shift_bstride, Cin, Cout, N, relu, y, pool)
+    if (x_channel_last) {
+        if (full) L3D_PW(true, true); else L3D_PW(true, false);
+    } else {
+        if (full) L3D_PW(false, true); else L3D_PW(false, false);
+    }
+#undef L3D_PW
+    return l3d_check_launch();
+}
+
 extern "C" int l3d_pointwise_conv(const float *x, int x_channel_last, const float *w,
                                   const float *scale, const float *shift, int shift_bstride, int B,
                                   int Cin, int Cout, int N, int relu, float *y, l3d_stream_t stream)
@@ -542,15 +605,15 @@ extern "C" int l3d_pointwise_conv(const float *x, int x_channel_last, const floa
     if (Cout <= 8 && B <= 65535)
         return x_channel_last ? launch_narrow<true>(x, w, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, st)
                               : launch_narrow<false>(x, w, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, st);
-    dim3 grid(l3d_divup(N, PW_TN), l3d_divup(Cout, PW_TM), B), block(256);
-    const bool full = (Cout % PW_TM) == 0 && (N % PW_TN) == 0 && (Cin % PW_TK) == 0 &&
-                      ((((size_t)x) | ((size_t)w)) & 15) == 0;
-    if (x_channel_last) {
-        if (full) hipLaunchKernelGGL((pointwise_conv_kernel<true, true>), grid, block, 0, st, x, w, scale, shift, shift_bstride, Cin, Cout, N, relu, y);
-        else      hipLaunchKernelGGL((pointwise_conv_kernel<true, false>), grid, block, 0, st, x, w, scale, shift, shift_bstride, Cin, Cout, N, relu, y);
-    } else {
-        if (full) hipLaunchKernelGGL((pointwise_conv_kernel<false, true>), grid, block, 0, st, x, w, scale, shift, shift_bstride, Cin, Cout, N, relu, y);
-        else      hipLaunchKernelGGL((pointwise_conv_kernel<false, false>), grid, block, 0, st, x, w, scale, shift, shift_bstride, Cin, Cout, N, relu, y);
-    }
-    return l3d_check_launch();
+    return launch_pointwise_conv<false>(x, x_channel_last, w, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, 0, st);
+}
+
+extern "C" int l3d_pointwise_conv_maxpool(const float *x, int x_channel_last, const float *w, const float *scale,
+                                          const float *shift, int shift_bstride, int B, int Cin, int Cout, int N,
+                                          int relu, int pool, float *y, l3d_stream_t stream)
+{
+    L3D_REQUIRE(x && w && y && B > 0 && Cin > 0 && Cout > 0 && N > 0);
+    if (B > 65535 || (pool != 8 && pool != 16 && pool != 32 && pool != 64) || N % pool) return L3D_ERR_UNSUPPORTED;
+    return launch_pointwise_conv<true>(x, x_channel_last, w, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, pool,
+                                       (hipStream_t)stream);
 }

@@ -107,6 +107,24 @@ def split_eligible(Cin, Cout, N):
     return SPLIT_BF16 and Cout % 256 == 0 and N % 128 == 0 and Cin % 16 == 0 and Cin >= 32
 
 
+def pointwise_conv_maxpool(x, w, scale, shift, relu, pool):
+    """pointwise_conv followed by max over every `pool` consecutive points, in one launch:
+    x [B,Cin,S*pool] -> [B,Cout,S].  pool in (8, 16, 32, 64); returns None if the kernel does not take the shape."""
+    require_gpu(x)
+    x, w = f32c(x), f32c(w)
+    B, Cin, N = x.shape
+    Cout = w.shape[0]
+    if pool not in (8, 16, 32, 64) or N % pool or Cout <= 8:
+        return None
+    scale = f32c(scale) if scale is not None else None
+    shift = f32c(shift) if shift is not None else None
+    bstride = Cout if (shift is not None and shift.dim() == 2) else 0
+    y = torch.empty((B, Cout, N // pool), dtype=torch.float32, device=x.device)
+    check(lib().l3d_pointwise_conv_maxpool(ptr(x), 0, ptr(w), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N, int(relu),
+                                           pool, ptr(y), stream_ptr()), "l3d_pointwise_conv_maxpool")
+    return y
+
+
 def pointwise_conv(x, w, scale=None, shift=None, relu=False, channel_last=False, w_split=None, split=None):
     """y[b,co,n] = act(scale[co] * sum_ci w[co,ci] x[b,ci,n] + shift[(b,)co]);  x [B,Cin,N] (or
     [B,N,Cin] when channel_last) -> [B,Cout,N].   == Conv1d(k=1) (+BN eval) (+ReLU).

@@ -13,20 +13,28 @@ from ..utils.model_common_utils import query_ball_point
 from . import _fused
 
 
-def _mlp_stack(x, convs, bns, module):
-    """x [B,C,S,K] (or [B,C,N]) through [conv1x1 + BN + ReLU]*; fused MFMA path at inference."""
+def _mlp_stack(x, convs, bns, module, pool=False):
+    """x [B,C,S,K] (or [B,C,N]) through [conv1x1 + BN + ReLU]*; fused MFMA path at inference.
+    pool=True (x 4-D): also take the max over K, i.e. return [B,C',S] -- at inference the last layer's
+    kernel does it in its epilogue (no [B,C',S,K] activation, no reduction launch)."""
     if len(convs) == 0:
-        return x
+        return torch.max(x, -1)[0] if pool else x
     if _fused.can_fuse(module, x):
         shp = x.shape
         h = x.reshape(shp[0], shp[1], -1)
-        for conv, bn in zip(convs, bns):
+        last = len(convs) - 1
+        for i, (conv, bn) in enumerate(zip(convs, bns)):
             w, sc, sh = _fused.fold_conv_bn(conv, bn)
+            if pool and i == last and x.dim() == 4:
+                y = _fused.pointwise_conv_maxpool(h, w, sc, sh, True, shp[3])
+                if y is not None:
+                    return y
             h = _fused.pointwise_conv(h, w, sc, sh, relu=True)
-        return h.view(shp[0], h.shape[1], *shp[2:])
+        h = h.view(shp[0], h.shape[1], *shp[2:])
+        return torch.max(h, -1)[0] if pool else h
     for conv, bn in zip(convs, bns):
         x = F.relu(bn(conv(x)))
-    return x
+    return torch.max(x, -1)[0] if pool else x
 
 
 class PointNetSetAbstraction(nn.Module):
@@ -52,8 +60,7 @@ class PointNetSetAbstraction(nn.Module):
         else:
             new_xyz = xyz
         new_points = self.queryandgroup(xyz_t, new_xyz.transpose(2, 1).contiguous(), points)   # [B,3+D,S,K]
-        new_points = _mlp_stack(new_points, self.mlp_convs, self.mlp_bns, self)
-        return new_xyz, torch.max(new_points, -1)[0]
+        return new_xyz, _mlp_stack(new_points, self.mlp_convs, self.mlp_bns, self, pool=True)
 
 
 class FlowEmbedding(nn.Module):
@@ -87,8 +94,7 @@ class FlowEmbedding(nn.Module):
         feat2_grouped = pointutils.grouping_operation(feature2.contiguous(), idx)
         feat_diff = torch.cat([feat2_grouped, feature1.view(B, -1, N, 1).repeat(1, 1, 1, self.nsample)], dim=1)
         feat1_new = torch.cat([pos_diff, feat_diff], dim=1)
-        feat1_new = _mlp_stack(feat1_new, self.mlp_convs, self.mlp_bns, self)
-        return pos1, torch.max(feat1_new, -1)[0]
+        return pos1, _mlp_stack(feat1_new, self.mlp_convs, self.mlp_bns, self, pool=True)
 
 
 class PointNetSetUpConv(nn.Module):
@@ -122,8 +128,7 @@ class PointNetSetUpConv(nn.Module):
         pos_diff = pos2_grouped - pos1.view(B, -1, N, 1)
         feat2_grouped = pointutils.grouping_operation(feature2.contiguous(), idx)
         feat_new = torch.cat([feat2_grouped, pos_diff], dim=1)
-        feat_new = _mlp_stack(feat_new, [s[0] for s in self.mlp1_convs], [s[1] for s in self.mlp1_convs], self)
-        feat_new = feat_new.max(-1)[0]
+        feat_new = _mlp_stack(feat_new, [s[0] for s in self.mlp1_convs], [s[1] for s in self.mlp1_convs], self, pool=True)
         if feature1 is not None:
             feat_new = torch.cat([feat_new, feature1], dim=1)
         return _mlp_stack(feat_new, [s[0] for s in self.mlp2_convs], [s[1] for s in self.mlp2_convs], self)

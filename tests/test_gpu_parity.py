@@ -435,6 +435,24 @@ def test_conv_split_accuracy():
         np.testing.assert_array_equal(spl, y2.cpu().numpy())
 
 
+def test_pointwise_conv_maxpool_epilogue():
+    """conv + BN + ReLU + max over K consecutive points in one launch vs the two-step composition,
+    K in {8,16,32,64}, ragged Cout / S."""
+    from learning3d_amd.models._fused import pointwise_conv, pointwise_conv_maxpool
+    rng = np.random.default_rng(71)
+    for (B, Cin, Cout, S, K) in [(2, 6, 64, 100, 16), (1, 131, 70, 33, 8), (2, 64, 128, 40, 32), (1, 259, 128, 24, 64),
+                                 (2, 128, 256, 128, 16)]:
+        x = rng.standard_normal((B, Cin, S * K)).astype(np.float32)
+        w = (rng.standard_normal((Cout, Cin)) / np.sqrt(Cin)).astype(np.float32)
+        sc = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+        sh = rng.uniform(-0.5, 0.5, Cout).astype(np.float32)
+        full = pointwise_conv(dev(x), dev(w), dev(sc), dev(sh), relu=True, split=False)
+        want = full.view(B, Cout, S, K).max(dim=-1)[0].cpu().numpy()
+        got = pointwise_conv_maxpool(dev(x), dev(w), dev(sc), dev(sh), True, K)
+        assert got is not None and got.shape == (B, Cout, S)
+        np.testing.assert_array_equal(got.cpu().numpy(), want)               # same kernel arithmetic, only the epilogue differs
+
+
 def test_pcn_fused_matches_reference_order_path():
     from learning3d_amd.models import PCN
     torch.manual_seed(3)
