@@ -152,6 +152,12 @@ int l3d_farthest_point_sample(const float *xyz, int B, int N, int npoint, const 
 int l3d_knn_point(int k, const float *pos1, const float *pos2, int B, int N, int M, float *val,
                   int64_t *idx, l3d_stream_t stream);
 
+/* QueryAndGroup's tail == utils/lib/pointnet2_utils.py:274-292 in one pass: centred neighbour coordinates
+ * (if use_xyz) concatenated with the gathered features.  xyz [B,N,3], new_xyz [B,S,3], features [B,C,N]
+ * (NULL if C == 0), idx int32 [B,S,K] -> out [B, 3*use_xyz + C, S, K]. */
+int l3d_group_concat(const float *xyz, const float *new_xyz, const float *features, const int32_t *idx, int B,
+                     int N, int S, int K, int C, int use_xyz, float *out, l3d_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Batched 3x3 SVD head  == utils/svd.py:29-58 (T6, without the B host syncs)
  *   src, corr [B,3,N]: centre both, H = src_c corr_c^T, H = U S V^T, R = V U^T with the

@@ -497,3 +497,45 @@ extern "C" int l3d_three_interpolate_grad(int b, int c, int n, int m, const floa
                        grad_out, idx, weight, grad_points);
     return l3d_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------
+// QueryAndGroup's tail in one pass (pointnet2_utils.py:274-292): out [B, 3+C, S, K] with
+//   out[b][c][s][k] = xyz[b][idx[b][s][k]][c] - new_xyz[b][s][c]          (c < 3, use_xyz)
+//   out[b][3+c][s][k] = features[b][c][idx[b][s][k]]
+// instead of two grouping launches, a broadcast subtraction and a torch.cat copy of the result.
+// One thread per (s, k); channels in a loop: every store is coalesced over (s, k).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void group_concat_kernel(const float *__restrict__ xyz /*[B,N,3]*/,
+                                                           const float *__restrict__ new_xyz /*[B,S,3]*/,
+                                                           const float *__restrict__ feat /*[B,C,N] or null*/,
+                                                           const int32_t *__restrict__ idx /*[B,S,K]*/, int N, int S,
+                                                           int K, int C, int use_xyz, float *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;                 // s*K + k
+    if (e >= S * K) return;
+    const int s_ = e / K;
+    const int j = idx[((size_t)b * S) * K + e];
+    const size_t SK = (size_t)S * K;
+    const int c0 = use_xyz ? 3 : 0;
+    float *ob = out + (size_t)b * (c0 + C) * SK + e;
+    if (use_xyz) {
+        const float *p = xyz + ((size_t)b * N + j) * 3, *q = new_xyz + ((size_t)b * S + s_) * 3;
+        ob[0] = p[0] - q[0];
+        ob[SK] = p[1] - q[1];
+        ob[2 * SK] = p[2] - q[2];
+    }
+    const float *fb = feat + (size_t)b * C * N + j;
+    for (int c = 0; c < C; c++) ob[(size_t)(c0 + c) * SK] = fb[(size_t)c * N];
+}
+
+extern "C" int l3d_group_concat(const float *xyz, const float *new_xyz, const float *features, const int32_t *idx,
+                                int B, int N, int S, int K, int C, int use_xyz, float *out, l3d_stream_t stream)
+{
+    L3D_REQUIRE(xyz && new_xyz && idx && out && B > 0 && N > 0 && S > 0 && K > 0 && C >= 0 && (C == 0 || features) &&
+                (use_xyz || C > 0));
+    if (B > 65535) return L3D_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(group_concat_kernel, dim3(l3d_divup((long)S * K, 256), B), dim3(256), 0, (hipStream_t)stream, xyz,
+                       new_xyz, features, idx, N, S, K, C, use_xyz, out);
+    return l3d_check_launch();
+}

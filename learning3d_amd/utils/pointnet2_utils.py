@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 from torch.autograd import Function
 
-from .._lib import check, lib, ptr, require_gpu, stream_ptr
+from .._lib import check, f32c, lib, ptr, require_gpu, stream_ptr
 
 
 class FurthestPointSampling(Function):
@@ -213,6 +213,19 @@ class QueryAndGroup(nn.Module):
 
     def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None):
         idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        needs_grad = torch.is_grad_enabled() and (xyz.requires_grad or (features is not None and features.requires_grad))
+        if not needs_grad and (self.use_xyz or features is not None):
+            # one pass: gather + centring + concat (no grouped temporaries, no torch.cat copy)
+            assert self.use_xyz or features is not None
+            B, N, _ = xyz.shape
+            S = new_xyz.shape[1]
+            Cf = features.shape[1] if features is not None else 0
+            x_, q_ = f32c(xyz), f32c(new_xyz)
+            f_ = f32c(features) if features is not None else None
+            out = torch.empty((B, (3 if self.use_xyz else 0) + Cf, S, self.nsample), dtype=torch.float32, device=xyz.device)
+            check(lib().l3d_group_concat(ptr(x_), ptr(q_), ptr(f_), ptr(idx), B, N, S, self.nsample, Cf, int(self.use_xyz),
+                                         ptr(out), stream_ptr()), "l3d_group_concat")
+            return out
         xyz_trans = xyz.transpose(1, 2).contiguous()
         grouped_xyz = grouping_operation(xyz_trans, idx)                  # (B, 3, npoint, nsample)
         grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)

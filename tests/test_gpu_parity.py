@@ -453,6 +453,23 @@ def test_pointwise_conv_maxpool_epilogue():
         np.testing.assert_array_equal(got.cpu().numpy(), want)               # same kernel arithmetic, only the epilogue differs
 
 
+def test_query_and_group_fused_matches_composition():
+    """QueryAndGroup's one-pass gather + centring + concat (l3d_group_concat) against the autograd route
+    (two grouping launches, subtraction, torch.cat) on the same ball-query indices."""
+    from learning3d_amd.utils.pointnet2_utils import QueryAndGroup
+    rng = np.random.default_rng(81)
+    B, N, S, K, Cf = 2, 500, 70, 16, 5
+    xyz = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    new_xyz = xyz[:, :S].copy()
+    feat = rng.standard_normal((B, Cf, N)).astype(np.float32)
+    for use_xyz, f in ((True, feat), (True, None), (False, feat)):
+        qg = QueryAndGroup(0.4, K, use_xyz=use_xyz)
+        with torch.no_grad():
+            fused = qg(dev(xyz), dev(new_xyz), dev(f) if f is not None else None)
+        ref = qg(dev(xyz).requires_grad_(), dev(new_xyz), dev(f) if f is not None else None)   # composition route
+        np.testing.assert_array_equal(fused.cpu().numpy(), ref.detach().cpu().numpy())
+
+
 def test_pcn_fused_matches_reference_order_path():
     from learning3d_amd.models import PCN
     torch.manual_seed(3)
