@@ -155,7 +155,9 @@ class PointNetFeaturePropogation(nn.Module):
         dists = dists.clamp_min(1e-10)
         weight = 1.0 / dists
         weight = weight / torch.sum(weight, -1, keepdim=True)
-        interpolated_feat = torch.sum(pointutils.grouping_operation(feature2.contiguous(), idx) * weight.view(B, 1, N, 3), dim=-1)
+        # reference :268: sum(grouping_operation(feature2, idx) * weight, -1) -- the same three-term weighted
+        # sum as pointnet2's three_interpolate, which is one fused kernel (no [B,C,N,3] temporary)
+        interpolated_feat = pointutils.three_interpolate(feature2.contiguous(), idx, weight.contiguous())
         feat_new = torch.cat([interpolated_feat, feature1], 1) if feature1 is not None else interpolated_feat
         return _mlp_stack(feat_new, self.mlp_convs, self.mlp_bns, self)
 
