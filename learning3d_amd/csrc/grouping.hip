@@ -365,14 +365,25 @@ __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, const float *__
         }
         // wave arg-max (lowest index among equal maxima), then the <= 16 waves through LDS
         const int wmax = wave_max_i(best);
-        const int widx = wave_min_i(best == wmax ? besti : 0x7fffffff);
+        // index of the maximum: almost always ONE lane holds it -- then its index is a ballot + find-first
+        // + readlane (3 instructions) instead of a second 6-step DPP reduction; only an exact tie between
+        // lanes takes the reduction (lowest index among equal maxima, as before)
+        const unsigned long long hit = __ballot(best == wmax);
+        int widx;
+        if (__builtin_popcountll(hit) == 1)
+            widx = __builtin_amdgcn_readlane(besti, __builtin_ctzll(hit));
+        else
+            widx = wave_min_i(best == wmax ? besti : 0x7fffffff);
         const int buf = j & 1;
         if (lane == 0) { wv[buf][wave] = wmax; wi[buf][wave] = widx; }
         __syncthreads();
         const int ev = wv[buf][lane & 15], ei = wi[buf][lane & 15];      // every 16-lane row sees all waves
         const int bmax = row16_max_i(ev);
-        const int bidx = row16_min_i(ev == bmax ? ei : 0x7fffffff);
-        old = __builtin_amdgcn_readfirstlane(bidx);
+        const unsigned hit16 = (unsigned)(__ballot(ev == bmax) & 0xffffull);      // row 0 sees all 16 waves
+        if (__builtin_popcount(hit16) == 1)
+            old = __builtin_amdgcn_readlane(ei, __builtin_ctz(hit16));
+        else
+            old = __builtin_amdgcn_readfirstlane(row16_min_i(ev == bmax ? ei : 0x7fffffff));
         if (tid == 0) {
             if (OUT64) ((int64_t *)out)[(size_t)b * m + j] = old; else ((int32_t *)out)[(size_t)b * m + j] = old;
         }
