@@ -1,0 +1,65 @@
+"""Randomised shape sweep of the fused kernels against torch / fp64 evaluations (run on a GPU box).
+Complements tests/test_gpu_parity.py (fixed shapes); prints the worst error per kernel family."""
+import os, sys, math
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from learning3d_amd.models import DGCNN, _fused
+import learning3d_amd.utils as U
+from learning3d_amd.utils.svd import soft_correspondence
+from learning3d_amd._lib import lib, check, ptr, stream_ptr
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+worst = {}
+def rec(name, got, want, rtol, atol):
+    err = np.abs(got - want) - rtol * np.abs(want)
+    worst[name] = max(worst.get(name, -1), float(err.max()))
+    assert err.max() <= atol, (name, err.max())
+torch.manual_seed(0)
+net = DGCNN(emb_dims=64).cuda().eval()
+for m in net.modules():
+    if isinstance(m, torch.nn.BatchNorm2d):
+        m.running_mean.uniform_(-0.1, 0.1); m.running_var.uniform_(0.8, 1.2)
+with torch.no_grad():
+    for it in range(12):                                            # EdgeConv: all three kernels agree
+        B, N, k = int(rng.integers(1, 5)), int(rng.integers(21, 700)), int(rng.integers(1, 21))
+        x = dev(rng.uniform(0, 1, (B, N, 3)).astype(np.float32))
+        idx = U.knn(x.permute(0, 2, 1), k)
+        packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
+        a = _fused.edgeconv_forward(x, idx, packed, kernel="lds").cpu().numpy()
+        s = _fused.edgeconv_forward(x, idx, packed, kernel="split").cpu().numpy()
+        c = _fused.edgeconv_forward(x, idx, packed, kernel="chained").cpu().numpy()
+        rec("edgeconv split vs lds", s, a, 1e-5, 2e-6); rec("edgeconv chained vs lds", c, a, 1e-5, 2e-6)
+    for it in range(12):                                            # 1x1 conv: bf16x3 vs fp32-MFMA vs fp64
+        B = int(rng.integers(1, 4)); Cin = 16 * int(rng.integers(2, 40)); Cout = 256 * int(rng.integers(1, 4)); N = 128 * int(rng.integers(1, 9))
+        x = rng.standard_normal((B, Cin, N)).astype(np.float32); w = (rng.standard_normal((Cout, Cin)) / math.sqrt(Cin)).astype(np.float32)
+        sh = rng.standard_normal((B, Cout)).astype(np.float32)
+        want = np.maximum(np.einsum("oc,bcn->bon", w.astype(np.float64), x) + sh[:, :, None], 0)
+        for cl in (False, True):
+            xin = dev(x.transpose(0, 2, 1)) if cl else dev(x)
+            got = _fused.pointwise_conv(xin, dev(w), None, dev(sh), relu=True, channel_last=cl, split=True).cpu().numpy()
+            rec("conv_split vs fp64", got, want, 1e-5, 5e-6)
+        K = int(rng.choice([8, 16, 32, 64]))
+        if N % K == 0:
+            full = _fused.pointwise_conv(dev(x), dev(w), None, dev(sh), relu=True, split=False)
+            pooled = _fused.pointwise_conv_maxpool(dev(x), dev(w), None, dev(sh), True, K)
+            rec("conv maxpool", pooled.cpu().numpy(), full.view(B, Cout, N // K, K).max(-1)[0].cpu().numpy(), 0, 0)
+    for it in range(10):                                            # soft correspondence + attention, ragged
+        B = int(rng.integers(1, 3)); C = 16 * int(rng.integers(2, 20)); N = int(rng.integers(1, 600)); M = int(rng.integers(1, 600))
+        q = rng.standard_normal((B, C, N)).astype(np.float32); k_ = rng.standard_normal((B, C, M)).astype(np.float32)
+        v = rng.uniform(-1, 1, (B, 3, M)).astype(np.float32)
+        s = np.einsum("bcn,bcm->bnm", q.astype(np.float64), k_.astype(np.float64)) / math.sqrt(C)
+        s = np.exp(s - s.max(2, keepdims=True)); s /= s.sum(2, keepdims=True)
+        rec("softcorr vs fp64", soft_correspondence(dev(q), dev(k_), dev(v)).cpu().numpy(), np.einsum("bdm,bnm->bdn", v.astype(np.float64), s), 1e-5, 4e-6)
+        H = int(rng.choice([1, 2, 4])); D = int(rng.choice([32, 64, 128]))
+        qa = rng.standard_normal((B, H, D, N)).astype(np.float32); ka = rng.standard_normal((B, H, D, M)).astype(np.float32)
+        va = rng.standard_normal((B, H, D, M)).astype(np.float32)
+        s = np.einsum("bhdn,bhdm->bhnm", qa.astype(np.float64), ka.astype(np.float64)) / math.sqrt(D)
+        s = np.exp(s - s.max(-1, keepdims=True)); s /= s.sum(-1, keepdims=True)
+        want = np.einsum("bhdm,bhnm->bhdn", va.astype(np.float64), s)
+        qd, kd, vd = dev(qa.reshape(B, H * D, N)), dev(ka.reshape(B, H * D, M)), dev(va.reshape(B, H * D, M))
+        out = torch.empty_like(qd)
+        check(lib().l3d_attention_forward(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, 1 / math.sqrt(D), ptr(out), stream_ptr()), "att")
+        rec("attention vs fp64", out.cpu().numpy().reshape(B, H, D, N), want, 1e-5, 4e-6)
+for k_, v_ in worst.items():
+    print(f"{k_:28s} worst (|err| - rtol|want|) = {v_:.3e}")
+print("fuzz OK")
