@@ -262,6 +262,15 @@ int l3d_pointwise_conv_split(const void *x, int x_mode, const void *w_split, con
                              const float *shift, int shift_bstride, int B, int Cin, int Cout, int N,
                              int relu, float *y, l3d_stream_t stream);
 
+/* PCN's folding decoder == models/pcn.py:84-101 (conv5 -> ReLU -> conv6 -> ReLU -> conv7, + centre) in one
+ * kernel (fold_mlp.hip): g [B,N,5] = (grid u, v, centre x, y, z) per fine point, w5g [512,5] = conv5's
+ * columns for those five inputs, s5 [B,512] = conv5.bias + conv5.weight[:, 5:] . global_feature (per cloud),
+ * w6_split = l3d_split_rows(conv6.weight [512,512]), b6 [512], w7 [3,512], b7 [3], centre [B,N,3]
+ * -> out [B,N,3].  The two [B,512,N] activations (2.1 GB each at B=64, N=16384) are never formed. */
+int l3d_fold_mlp(const float *g, int CG, const float *w5g, const float *s5, const void *w6_split,
+                 const float *b6, const float *w7, const float *b7, const float *centre, int B, int N,
+                 float *out, l3d_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Approximate EMD  == losses/cuda/emd_torch/pkg/include/emd.h:47-50 (pybind `_emd_ext._emd`)
  *   emd_forward(xyz1,xyz2) -> cost [B], match [B,n,m] (indexed [l*n+k], emd.cuh:158);

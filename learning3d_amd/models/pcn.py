@@ -14,6 +14,9 @@ from . import _fused
 from .pooling import Pooling
 
 
+FOLD_FUSED = True       # folding decoder as one kernel (l3d_fold_mlp); False: three 1x1-conv launches
+
+
 class PCN(torch.nn.Module):
     def __init__(self, emb_dims=1024, input_shape="bnc", num_coarse=1024, grid_size=4, detailed_output=False):
         super(PCN, self).__init__()
@@ -86,6 +89,20 @@ class PCN(torch.nn.Module):
         x5 = torch.cat([grid_feature, center], dim=2)                      # [B, fine, 5] channel-last
         w5 = self.conv5.weight.detach().reshape(512, 1029)
         shift = torch.addmm(self.conv5.bias.detach(), gfeat, w5[:, 5:].t())
+        if _fused.SPLIT_BF16 and FOLD_FUSED:
+            # conv5 -> conv6 -> conv7 (+ centre) as one kernel: the two [B,512,fine] activations never exist
+            from .._lib import check, f32c, lib, ptr, stream_ptr
+            w6 = self.conv6.weight.detach().reshape(512, 512)
+            key = (w6.data_ptr(), self.conv6.weight._version, str(w6.device))
+            if getattr(self, "_w6_split", (None,))[0] != key:
+                self._w6_split = (key, _fused.split_rows(w6.float().contiguous()))
+            g_, ce = f32c(x5), f32c(center)
+            B, Nf, _ = g_.shape
+            out = torch.empty((B, Nf, 3), dtype=torch.float32, device=g_.device)
+            check(lib().l3d_fold_mlp(ptr(g_), 5, ptr(f32c(w5[:, :5])), ptr(f32c(shift)), ptr(self._w6_split[1]),
+                                     ptr(f32c(self.conv6.bias.detach())), ptr(f32c(self.conv7.weight.detach().reshape(3, 512))),
+                                     ptr(f32c(self.conv7.bias.detach())), ptr(ce), B, Nf, ptr(out), stream_ptr()), "l3d_fold_mlp")
+            return out
         h = pc(x5, w5[:, :5], None, shift, relu=True, channel_last=True)
         w, _, b = _fused.fold_conv_bn(self.conv6)
         h = pc(h, w, None, b, relu=True)
