@@ -87,11 +87,11 @@ def main():
         # c4 slice: Chamfer 2048 x 16384 (B=8 of 64) -- O(N^2) stress
         a4 = torch.rand((8, 16384, 3), generator=g).to(dev)
         b4 = torch.rand((8, 16384, 3), generator=g).to(dev)
-        t = timeit(lambda: cd(a4, b4), warm=2, iters=5)
+        t = timeit(lambda: cd(a4, b4), warm=20, iters=10)          # long enough for the clocks to settle
         res["chamfer_c4_B8_16k"] = (t, 2 * 8 * 16384 * 16384 / t / 1e3, "Gpair/s")
         pcn = PCN(emb_dims=1024, num_coarse=1024, grid_size=4, detailed_output=True).to(dev).eval()
         part = (torch.rand((64, 2048, 3), generator=g) - 0.5).to(dev)
-        t = timeit(lambda: pcn(part), warm=2, iters=5)
+        t = timeit(lambda: pcn(part), warm=5, iters=10)
         res["pcn_fwd_c4_B64"] = (t, 64 / t * 1e6, "clouds/s")
         # c5 per-GPU slice: FlowNet3D set-conv grouping, B=32, N=8192, S=1024, r=0.5, K=16
         xyz = torch.clamp(torch.randn((32, 8192, 3), generator=g), -2, 2).to(dev)
