@@ -261,6 +261,12 @@ int l3d_split_rows(const float *src, int rows, int cols, void *dst, l3d_stream_t
 int l3d_pointwise_conv_split(const void *x, int x_mode, const void *w_split, const float *scale,
                              const float *shift, int shift_bstride, int B, int Cin, int Cout, int N,
                              int relu, float *y, l3d_stream_t stream);
+/* the same with the max over every `pool` (8/16/32/64) consecutive points in the epilogue: y [B,Cout,N/pool]
+ * (N % 256 == 0).  With pool = 64 and a tiny reduction over the N/64 partial maxima this is a conv followed
+ * by a GLOBAL max-pool (models/pcn.py:68-70, models/pooling.py) without the [B,Cout,N] activation. */
+int l3d_pointwise_conv_split_maxpool(const void *x, int x_mode, const void *w_split, const float *scale,
+                                     const float *shift, int shift_bstride, int B, int Cin, int Cout, int N,
+                                     int relu, int pool, float *y, l3d_stream_t stream);
 
 /* PCN's folding decoder == models/pcn.py:84-101 (conv5 -> ReLU -> conv6 -> ReLU -> conv7, + centre) in one
  * kernel (fold_mlp.hip): g [B,N,5] = (grid u, v, centre x, y, z) per fine point, w5g [512,5] = conv5's

@@ -58,6 +58,7 @@ SIGNATURES = {
     "l3d_split_bytes": [_I, _I],
     "l3d_split_rows": [_P, _I, _I, _P, _P],
     "l3d_pointwise_conv_split": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "l3d_pointwise_conv_split_maxpool": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_fold_mlp": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P],
     "l3d_emd_forward": [_P, _P, _I, _I, _I, _P, _P, _P, _P],
     "l3d_emd_backward": [_P, _P, _P, _I, _I, _I, _P, _P, _P],

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const void *__restrict_
                                                          const float *__restrict__ scale,
                                                          const float *__restrict__ shift, int shift_bstride,
                                                          int Bn, int Cin, int Cout, int N, int relu,
-                                                         float *__restrict__ y)
+                                                         float *__restrict__ y, int pool)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -282,6 +282,35 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const void *__restrict_
 #undef CS_STORE_LDS
 
     // ---- epilogue: D[co = 32a + (r&3) + 8(r>>2) + 4(lane>>5)][n = 32c + (lane&31)]
+    if (pool) {
+        // max over every `pool` (8 / 16 / 32 / 64) consecutive points: y [B][Cout][N / pool]  (as mlp.hip's POOL epilogue)
+        const int Np = N / pool;
+        float *yp = y + (size_t)b * Cout * Np;
+        const int span = pool < 32 ? pool : 32;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int co = co0 + wm * 128 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float sc = scale ? scale[co] : 1.f;
+                const float sh = shift ? shift[(size_t)b * shift_bstride + co] : 0.f;
+                float v0 = acc[a][0][r] * sc + sh, v1 = acc[a][1][r] * sc + sh;
+                if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                if (pool == 64) v0 = fmaxf(v0, v1);
+#pragma unroll
+                for (int m = 1; m < 32; m <<= 1)
+                    if (m < span) {
+                        v0 = fmaxf(v0, __shfl_xor(v0, m, 64));
+                        v1 = fmaxf(v1, __shfl_xor(v1, m, 64));
+                    }
+                if (((lane & 31) & (span - 1)) == 0) {
+                    const int nb = n0 + wn * 64 + (lane & 31);
+                    yp[(size_t)co * Np + nb / pool] = v0;
+                    if (pool != 64) yp[(size_t)co * Np + (nb + 32) / pool] = v1;
+                }
+            }
+        return;
+    }
     float *yb = y + (size_t)b * Cout * N;
 #pragma unroll
     for (int a = 0; a < 4; a++)
@@ -481,13 +510,12 @@ extern "C" int l3d_split_rows(const float *src, int rows, int cols, void *dst, l
     return l3d_check_launch();
 }
 
-extern "C" int l3d_pointwise_conv_split(const void *x, int x_mode, const void *w_split, const float *scale,
-                                        const float *shift, int shift_bstride, int B, int Cin, int Cout,
-                                        int N, int relu, float *y, l3d_stream_t stream)
+static int launch_conv_split(const void *x, int x_mode, const void *w_split, const float *scale, const float *shift,
+                             int shift_bstride, int B, int Cin, int Cout, int N, int relu, int pool, float *y,
+                             hipStream_t st)
 {
-    L3D_REQUIRE(x && w_split && y && B > 0 && Cin > 0 && Cout > 0 && N > 0 && x_mode >= 0 && x_mode <= 2);
     if (Cout % CS_TM || N % CD_TN || Cin % CS_TK || B > 65535 || (((size_t)x) & 15)) return L3D_ERR_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
+    if (pool && N % CS_TN) return L3D_ERR_UNSUPPORTED;          // the pooled epilogue lives in the 256x256 kernel only
     // Both shapes run conv5 in ~170 us (tools/probe_conv_split.hip ablations: the 256x128 shape moves
     // 1.6x the bytes per FLOP through the CU's vector-memory path, which cancels what its two
     // out-of-phase workgroups gain); the 256x256 shape is the default, the 256x128 one takes
@@ -495,7 +523,7 @@ extern "C" int l3d_pointwise_conv_split(const void *x, int x_mode, const void *w
 #ifndef CS_USE_DMA
 #define CS_USE_DMA 0
 #endif
-    if (CS_USE_DMA || N % CS_TN) {
+    if (!pool && (CS_USE_DMA || N % CS_TN)) {
         dim3 grid2(N / CD_TN, Cout / CD_TM, B), block2(256);
         if (x_mode == 0)
             hipLaunchKernelGGL(conv_split_dma_kernel<0>, grid2, block2, CD_LDS, st, x, (const uint4 *)w_split, scale,
@@ -511,12 +539,29 @@ extern "C" int l3d_pointwise_conv_split(const void *x, int x_mode, const void *w
     dim3 grid(N / CS_TN, Cout / CS_TM, B), block(512);
     if (x_mode == 0)
         hipLaunchKernelGGL(conv_split_kernel<0>, grid, block, CS_LDS, st, x, (const uint4 *)w_split, scale, shift,
-                           shift_bstride, B, Cin, Cout, N, relu, y);
+                           shift_bstride, B, Cin, Cout, N, relu, y, pool);
     else if (x_mode == 1)
         hipLaunchKernelGGL(conv_split_kernel<1>, grid, block, CS_LDS, st, x, (const uint4 *)w_split, scale, shift,
-                           shift_bstride, B, Cin, Cout, N, relu, y);
+                           shift_bstride, B, Cin, Cout, N, relu, y, pool);
     else
         hipLaunchKernelGGL(conv_split_kernel<2>, grid, block, CS_LDS, st, x, (const uint4 *)w_split, scale, shift,
-                           shift_bstride, B, Cin, Cout, N, relu, y);
+                           shift_bstride, B, Cin, Cout, N, relu, y, pool);
     return l3d_check_launch();
+}
+
+extern "C" int l3d_pointwise_conv_split(const void *x, int x_mode, const void *w_split, const float *scale,
+                                        const float *shift, int shift_bstride, int B, int Cin, int Cout,
+                                        int N, int relu, float *y, l3d_stream_t stream)
+{
+    L3D_REQUIRE(x && w_split && y && B > 0 && Cin > 0 && Cout > 0 && N > 0 && x_mode >= 0 && x_mode <= 2);
+    return launch_conv_split(x, x_mode, w_split, scale, shift, shift_bstride, B, Cin, Cout, N, relu, 0, y, (hipStream_t)stream);
+}
+
+extern "C" int l3d_pointwise_conv_split_maxpool(const void *x, int x_mode, const void *w_split, const float *scale,
+                                                const float *shift, int shift_bstride, int B, int Cin, int Cout,
+                                                int N, int relu, int pool, float *y, l3d_stream_t stream)
+{
+    L3D_REQUIRE(x && w_split && y && B > 0 && Cin > 0 && Cout > 0 && N > 0 && x_mode >= 0 && x_mode <= 2);
+    if (pool != 8 && pool != 16 && pool != 32 && pool != 64) return L3D_ERR_UNSUPPORTED;
+    return launch_conv_split(x, x_mode, w_split, scale, shift, shift_bstride, B, Cin, Cout, N, relu, pool, y, (hipStream_t)stream);
 }

@@ -107,7 +107,7 @@ def split_eligible(Cin, Cout, N):
     return SPLIT_BF16 and Cout % 256 == 0 and N % 128 == 0 and Cin % 16 == 0 and Cin >= 32
 
 
-def pointwise_conv_maxpool(x, w, scale, shift, relu, pool):
+def pointwise_conv_maxpool(x, w, scale, shift, relu, pool, w_split=None):
     """pointwise_conv followed by max over every `pool` consecutive points, in one launch:
     x [B,Cin,S*pool] -> [B,Cout,S].  pool in (8, 16, 32, 64); returns None if the kernel does not take the shape."""
     require_gpu(x)
@@ -120,9 +120,26 @@ def pointwise_conv_maxpool(x, w, scale, shift, relu, pool):
     shift = f32c(shift) if shift is not None else None
     bstride = Cout if (shift is not None and shift.dim() == 2) else 0
     y = torch.empty((B, Cout, N // pool), dtype=torch.float32, device=x.device)
+    if split_eligible(Cin, Cout, N) and N % 256 == 0:
+        if w_split is None:
+            w_split = split_rows(w)
+        check(lib().l3d_pointwise_conv_split_maxpool(ptr(x), 0, ptr(w_split), ptr(scale), ptr(shift), bstride, B, Cin, Cout,
+                                                     N, int(relu), pool, ptr(y), stream_ptr()),
+              "l3d_pointwise_conv_split_maxpool")
+        return y
     check(lib().l3d_pointwise_conv_maxpool(ptr(x), 0, ptr(w), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N, int(relu),
                                            pool, ptr(y), stream_ptr()), "l3d_pointwise_conv_maxpool")
     return y
+
+
+def conv_global_max(x, w, scale, shift, relu):
+    """conv (+BN, +ReLU) followed by a max over ALL points: x [B,Cin,N] -> [B,Cout]; the [B,Cout,N] activation
+    is not formed when N % 64 == 0 (partial maxima over 64 points in the conv's epilogue, then a tiny reduce)."""
+    if x.shape[2] % 64 == 0:
+        part = pointwise_conv_maxpool(x, w, scale, shift, relu, 64)
+        if part is not None:
+            return part.max(dim=2)[0]
+    return pointwise_conv(x, w, scale, shift, relu=relu).max(dim=2)[0]
 
 
 def pointwise_conv(x, w, scale=None, shift=None, relu=False, channel_last=False, w_split=None, split=None):

@@ -80,6 +80,8 @@ class PCN(torch.nn.Module):
         shift = torch.addmm(self.conv3.bias.detach(), g, w3[:, 256:].t())  # per-cloud [B,512]
         h = pc(h, w3[:, :256], None, shift, relu=True)
         w, _, b = _fused.fold_conv_bn(self.conv4)
+        if self.pooling.pool_type == 'max':
+            return _fused.conv_global_max(h, w, None, b, False)             # conv4 + global max, no [B,1024,N] tensor
         h = pc(h, w, None, b, relu=False)
         return self.pooling(h)
 

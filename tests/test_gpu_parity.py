@@ -450,7 +450,16 @@ def test_pointwise_conv_maxpool_epilogue():
         want = full.view(B, Cout, S, K).max(dim=-1)[0].cpu().numpy()
         got = pointwise_conv_maxpool(dev(x), dev(w), dev(sc), dev(sh), True, K)
         assert got is not None and got.shape == (B, Cout, S)
+        if (Cout % 256 == 0 and (S * K) % 256 == 0 and Cin % 16 == 0 and Cin >= 32):   # bf16x3 kernel took it
+            full = pointwise_conv(dev(x), dev(w), dev(sc), dev(sh), relu=True, split=True)
+            want = full.view(B, Cout, S, K).max(dim=-1)[0].cpu().numpy()
         np.testing.assert_array_equal(got.cpu().numpy(), want)               # same kernel arithmetic, only the epilogue differs
+    from learning3d_amd.models._fused import conv_global_max
+    x = rng.standard_normal((3, 512, 2048)).astype(np.float32)
+    w = (rng.standard_normal((1024, 512)) / np.sqrt(512)).astype(np.float32)
+    b_ = rng.standard_normal(1024).astype(np.float32)
+    want = pointwise_conv(dev(x), dev(w), None, dev(b_), relu=False).max(dim=2)[0].cpu().numpy()
+    np.testing.assert_array_equal(conv_global_max(dev(x), dev(w), None, dev(b_), False).cpu().numpy(), want)
 
 
 def test_query_and_group_fused_matches_composition():
