@@ -187,6 +187,11 @@ int l3d_soft_correspondence(const float *src_emb, const float *tgt_emb, const fl
  * D must be 32, 64 or 128, else L3D_ERR_UNSUPPORTED. */
 int l3d_attention_forward(const float *q, const float *k, const float *v, int B, int H, int D, int N, int M,
                           float scale, float *ctx, l3d_stream_t stream);
+/* the same with explicit batch strides (in floats) for q, k, v: they may then be channel slices of ONE fused
+ * projection output [B, 3*H*D, N] (self-attention) or [B, 2*H*D, M] (keys + values of cross-attention). */
+int l3d_attention_forward_strided(const float *q, const float *k, const float *v, int B, int H, int D, int N,
+                                  int M, long q_bstride, long k_bstride, long v_bstride, float scale, float *ctx,
+                                  l3d_stream_t stream);
 
 /* LayerNorm of DCP's pointer network == utils/transformer.py:109-119 (unbiased std, eps added to std):
  *   y[r][:] = a * (x[r][:] - mean_r) / (std_r + eps) + b,   x, y [rows][C] fp32, C % 4 == 0, C <= 2048. */

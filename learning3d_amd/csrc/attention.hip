@@ -35,16 +35,18 @@
 template <int ND /* D / 32 */>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                            const float *__restrict__ v, int H, int N, int M,
-                                                           float scale, float *__restrict__ ctx)
+                                                           float scale, float *__restrict__ ctx, long q_bs, long k_bs,
+                                                           long v_bs)
 {
     constexpr int D = ND * 32;
     constexpr int NCH = D / 16;                        // QK^T chunks of 16 channels
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int i0 = blockIdx.x * AT_TQ, h = blockIdx.y, b = blockIdx.z;
-    const float *qb = q + ((size_t)b * H + h) * D * N;
-    const float *kb = k + ((size_t)b * H + h) * D * M;
-    const float *vb = v + ((size_t)b * H + h) * D * M;
+    // batch strides in floats: q, k, v may be channel slices of one fused projection output
+    const float *qb = q + (size_t)b * q_bs + (size_t)h * D * N;
+    const float *kb = k + (size_t)b * k_bs + (size_t)h * D * M;
+    const float *vb = v + (size_t)b * v_bs + (size_t)h * D * M;
 
     // staging roles: thread -> (row, kg) octet.  QK^T phase: K row = key, Q row = query (channel-first:
     // 8 dword loads strided by M resp. N, coalesced over rows).  PV phase: V row = d (keys contiguous).
@@ -242,15 +244,24 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float *__restri
     }
 }
 
+extern "C" int l3d_attention_forward_strided(const float *q, const float *k, const float *v, int B, int H, int D,
+                                             int N, int M, long q_bstride, long k_bstride, long v_bstride, float scale,
+                                             float *ctx, l3d_stream_t stream)
+{
+    L3D_REQUIRE(q && k && v && ctx && B > 0 && H > 0 && D > 0 && N > 0 && M > 0);
+    if ((D != 32 && D != 64 && D != 128) || B > 65535 || H > 65535 || (((size_t)v) & 15) || (v_bstride & 3))
+        return L3D_ERR_UNSUPPORTED;
+    dim3 grid(l3d_divup(N, AT_TQ), H, B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (D == 32)      hipLaunchKernelGGL(attention_kernel<1>, grid, block, AT_LDS, st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride);
+    else if (D == 64) hipLaunchKernelGGL(attention_kernel<2>, grid, block, AT_LDS, st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride);
+    else              hipLaunchKernelGGL(attention_kernel<4>, grid, block, AT_LDS, st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride);
+    return l3d_check_launch();
+}
+
 extern "C" int l3d_attention_forward(const float *q, const float *k, const float *v, int B, int H, int D, int N,
                                      int M, float scale, float *ctx, l3d_stream_t stream)
 {
-    L3D_REQUIRE(q && k && v && ctx && B > 0 && H > 0 && D > 0 && N > 0 && M > 0);
-    if ((D != 32 && D != 64 && D != 128) || B > 65535 || H > 65535 || (((size_t)v) & 15)) return L3D_ERR_UNSUPPORTED;
-    dim3 grid(l3d_divup(N, AT_TQ), H, B), block(256);
-    hipStream_t st = (hipStream_t)stream;
-    if (D == 32)      hipLaunchKernelGGL(attention_kernel<1>, grid, block, AT_LDS, st, q, k, v, H, N, M, scale, ctx);
-    else if (D == 64) hipLaunchKernelGGL(attention_kernel<2>, grid, block, AT_LDS, st, q, k, v, H, N, M, scale, ctx);
-    else              hipLaunchKernelGGL(attention_kernel<4>, grid, block, AT_LDS, st, q, k, v, H, N, M, scale, ctx);
-    return l3d_check_launch();
+    return l3d_attention_forward_strided(q, k, v, B, H, D, N, M, (long)H * D * N, (long)H * D * M, (long)H * D * M, scale,
+                                         ctx, stream);
 }

@@ -98,23 +98,53 @@ class MultiHeadedAttention(nn.Module):
         self.attn = None
         self.dropout = None
 
+    def _fused_linear(self, lo, hi):
+        """nn.Linear whose weight / bias are linears[lo:hi] stacked (cached per parameter version): the
+        projections of one input become a single 1x1-conv launch."""
+        ps = [p for l in self.linears[lo:hi] for p in (l.weight, l.bias)]
+        key = (lo, hi) + tuple((p.data_ptr(), p._version) for p in ps)
+        cache = getattr(self, "_l3d_fused", {})
+        if cache.get((lo, hi), (None,))[0] != key:
+            lin = nn.Linear(self.linears[lo].in_features, sum(l.out_features for l in self.linears[lo:hi]),
+                            device=self.linears[lo].weight.device)
+            with torch.no_grad():
+                lin.weight.copy_(torch.cat([l.weight for l in self.linears[lo:hi]], 0))
+                lin.bias.copy_(torch.cat([l.bias for l in self.linears[lo:hi]], 0))
+            lin.requires_grad_(False)
+            cache[(lo, hi)] = (key, lin)
+            object.__setattr__(self, "_l3d_fused", cache)          # not a registered submodule: state_dict unchanged
+        return cache[(lo, hi)][1]
+
     def forward(self, query, key, value, mask=None):
         if mask is not None:
             mask = mask.unsqueeze(1)
         nb = query.size(0)
         if mask is None and all(_fast_linear_ok(self.linears[0], t, t.size(1)) for t in (query, key, value)):
             # channel-first projections: [B, h*d_k, N] viewed as [B, h, d_k, N] -- no head transposes
-            q, k, v = [_linear_cf(lin, x, True) for lin, x in zip(self.linears, (query, key, value))]   # [B,C,N]
+            C_ = self.h * self.d_k
+            n_q, n_k = query.size(1), key.size(1)
+            # projections that share an input run as ONE conv with concatenated weights (q|k|v for
+            # self-attention, k|v for cross-attention); q, k, v are then channel slices of its [B, 3C, N] output
+            if query is key and key is value:
+                qkv = _linear_cf(self._fused_linear(0, 3), query, True)
+                q, k, v = qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:]
+            elif key is value:
+                q = _linear_cf(self.linears[0], query, True)
+                kv = _linear_cf(self._fused_linear(1, 3), key, True)
+                k, v = kv[:, :C_], kv[:, C_:]
+            else:
+                q, k, v = [_linear_cf(lin, x, True) for lin, x in zip(self.linears, (query, key, value))]   # [B,C,N]
             self.attn = None                                   # the [B,h,N,M] map is never formed
             if FLASH_ATTENTION and self.d_k in (32, 64, 128):
                 from .._lib import check, lib, ptr, stream_ptr
-                ctx = torch.empty_like(q)
-                check(lib().l3d_attention_forward(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, query.size(1), key.size(1),
-                                                  1.0 / math.sqrt(self.d_k), ptr(ctx), stream_ptr()), "l3d_attention_forward")
+                ctx = torch.empty((nb, C_, n_q), dtype=torch.float32, device=q.device)
+                check(lib().l3d_attention_forward_strided(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
+                                                          q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),
+                                                          ptr(ctx), stream_ptr()), "l3d_attention_forward_strided")
             else:
-                qh, kh, vh = [z.view(nb, self.h, self.d_k, z.size(2)) for z in (q, k, v)]
+                qh, kh, vh = [z.reshape(nb, self.h, self.d_k, z.size(2)) for z in (q, k, v)]
                 p = F.softmax(torch.matmul(qh.transpose(-2, -1), kh) / math.sqrt(self.d_k), dim=-1)   # [B,h,N,M]
-                ctx = torch.matmul(vh, p.transpose(-2, -1)).view(nb, self.h * self.d_k, query.size(1))
+                ctx = torch.matmul(vh, p.transpose(-2, -1)).reshape(nb, C_, n_q)
             return _linear_cf(self.linears[-1], ctx, False).transpose(1, 2)                       # [B,N,C] view
         q, k, v = [lin(x).view(nb, -1, self.h, self.d_k).transpose(1, 2)
                    for lin, x in zip(self.linears, (query, key, value))]

@@ -628,8 +628,9 @@ def test_transformer_fast_linear_path_matches_torch_path():
     with torch.no_grad():
         want = ref(torch.from_numpy(a).double(), torch.from_numpy(b).double())
         got = net.cuda()(dev(a), dev(b))
-    lin = net.model.encoder.layers[0].self_attn.linears[0]
-    assert getattr(lin, "_l3d_split", None) is not None, "fast path not taken"
+    att = net.model.encoder.layers[0].self_attn
+    assert getattr(att, "_l3d_fused", None), "fused q|k|v projection not taken"
+    assert getattr(att.linears[-1], "_l3d_split", None) is not None, "fast linear path not taken"
     for g_, w_ in zip(got, want):
         np.testing.assert_allclose(g_.cpu().numpy(), w_.numpy(), rtol=1e-4, atol=1e-5)
 
