@@ -54,6 +54,15 @@ int l3d_last_hip_error(void);
  * ------------------------------------------------------------------------------------------- */
 int l3d_knn_graph(const float *xyz, int B, int N, int k, int64_t *idx, l3d_stream_t stream);
 
+/* knn() of utils/model_common_utils.py:3-9 for FEATURE-space graphs, x [B,C,N] with C % 32 == 0 (PRNet's
+ * dynamic DGCNN graphs, models/prnet.py:76-97; C = 3 takes l3d_knn_graph): pd = -xx_j + 2 x_i.x_j - xx_i
+ * with the inner product on the matrix cores (bf16x3, fp32-level error) and top-k as the GEMM epilogue, no
+ * [B,N,N] tensor.  idx int64 [B,N,k], best first, exact ties -> lower index.  workspace: >=
+ * l3d_knn_feature_workspace_bytes(B,C,N) bytes, 16-byte aligned (holds the split copy of x).
+ * k > 20 or C % 32 != 0 -> L3D_ERR_UNSUPPORTED; k > N -> L3D_ERR_INVALID_ARG. */
+size_t l3d_knn_feature_workspace_bytes(int B, int C, int N);
+int l3d_knn_feature(const float *x, int B, int C, int N, int k, void *workspace, int64_t *idx, l3d_stream_t stream);
+
 /* get_graph_feature gather  == utils/model_common_utils.py:141-154
  *   out[b][n][j][0:C] = x[b][idx[b][n][j]][:], out[b][n][j][C:2C] = x[b][n][:]
  *   x [B,N,C], idx [B,N,k] int64, out [B,N,k,2C]  (the reference returns this memory

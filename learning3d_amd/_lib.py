@@ -21,6 +21,8 @@ SIGNATURES = {
     "l3d_status_string": [_I],
     "l3d_last_hip_error": [],
     "l3d_knn_graph": [_P, _I, _I, _I, _P, _P],
+    "l3d_knn_feature_workspace_bytes": [_I, _I, _I],
+    "l3d_knn_feature": [_P, _I, _I, _I, _I, _P, _P, _P],
     "l3d_graph_feature": [_P, _P, _I, _I, _I, _I, _P, _P],
     "l3d_chamfer_forward": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     "l3d_chamfer_backward": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
@@ -65,7 +67,7 @@ SIGNATURES = {
     "l3d_emd_backward": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
 }
 _RESTYPE = {"l3d_status_string": C.c_char_p, "l3d_edgeconv_packed_floats": _SZ, "l3d_split_bytes": _SZ,
-            "l3d_soft_correspondence_workspace_floats": _SZ}
+            "l3d_soft_correspondence_workspace_floats": _SZ, "l3d_knn_feature_workspace_bytes": _SZ}
 
 
 class L3DError(RuntimeError):
