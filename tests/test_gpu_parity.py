@@ -368,21 +368,46 @@ def test_pointnet_golden(golden):
 
 
 def test_knn_feature_space_matches_exact_topk():
-    """C != 3 (feature-space graphs): every returned neighbour is within rounding of the exact k nearest."""
+    """C != 3 (feature-space graphs): l3d_knn_feature = bf16x3 GEMM + top-k epilogue.
+    Its indices cannot be bit-pinned to the reference (MKL's sgemm summation order), so every returned
+    neighbour list is checked against exact fp64 distances: the set is the k nearest up to rounding, the
+    order is ascending, self comes first, no index repeats."""
     from learning3d_amd.utils import knn, get_graph_feature
-    rng = np.random.default_rng(61)
-    x = rng.standard_normal((2, 64, 300)).astype(np.float32)
-    idx = knn(dev(x), 16).cpu().numpy()
-    assert idx.shape == (2, 300, 16) and idx.dtype == np.int64
-    xd = x.astype(np.float64)
-    d = ((xd[:, :, :, None] - xd[:, :, None, :]) ** 2).sum(axis=1)                 # [B,N,N]
-    kth = np.sort(d, axis=-1)[:, :, 15]
-    got = np.take_along_axis(d, idx, axis=-1).max(axis=-1)
-    assert np.all(got <= kth * (1 + 1e-5) + 1e-6)
-    assert np.all(idx[:, :, 0] == np.arange(300)[None])                           # self first
+    from learning3d_amd import _lib
+    for (B, C, N, k, seed) in [(2, 64, 300, 16, 61), (2, 32, 128, 20, 62), (2, 128, 1000, 20, 63), (1, 256, 513, 7, 64),
+                               (1, 96, 77, 1, 65), (1, 64, 200, 24, 66), (1, 48, 150, 8, 67)]:   # last two: torch-op route
+        rng = np.random.default_rng(seed)
+        x = rng.standard_normal((B, C, N)).astype(np.float32)
+        idx = knn(dev(x), k).cpu().numpy()
+        assert idx.shape == (B, N, k) and idx.dtype == np.int64
+        xd = x.astype(np.float64)
+        sq = (xd ** 2).sum(axis=1)
+        d = sq[:, :, None] + sq[:, None, :] - 2 * np.einsum("bci,bcj->bij", xd, xd)  # [B,N,N]
+        kth = np.sort(d, axis=-1)[:, :, k - 1]
+        got = np.take_along_axis(d, idx, axis=-1)
+        tol = 4e-6 * sq.max()
+        assert np.all(got.max(axis=-1) <= kth + tol), (B, C, N, k)
+        assert np.all(np.diff(got, axis=-1) >= -tol), (B, C, N, k)
+        assert np.all(idx[:, :, 0] == np.arange(N)[None])                          # self first
+        srt = np.sort(idx, axis=-1)
+        assert np.all(srt[:, :, 1:] != srt[:, :, :-1])                             # no repeats
+    # exact ties (every point duplicated N/2 later): equal fp32 scores -> lower index first, as l3d_knn_graph
+    rng = np.random.default_rng(68)
+    half = rng.standard_normal((1, 64, 128)).astype(np.float32)
+    x = np.concatenate([half, half], axis=2)
+    idx = knn(dev(x), 20).cpu().numpy()[0]
+    assert np.all(idx[:, 0::2] + 128 == idx[:, 1::2]) and np.all(idx[:, 0::2] < 128)
+    # the caller: get_graph_feature on a feature map
+    x = np.random.default_rng(61).standard_normal((2, 64, 300)).astype(np.float32)
     feat = get_graph_feature(dev(x), k=16)
     assert feat.shape == (2, 128, 300, 16)
     np.testing.assert_array_equal(feat[:, 64:, :, 3].cpu().numpy(), x)             # centre half = the point itself
+    # unsupported shapes are refused by the C ABI, not silently mangled
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    out = torch.empty((1, 64, 8), dtype=torch.int64, device="cuda")
+    xx = torch.zeros((1, 48, 64), device="cuda")
+    assert _lib.lib().l3d_knn_feature(_lib.ptr(xx), 1, 48, 64, 8, _lib.ptr(ws), _lib.ptr(out), _lib.stream_ptr()) == -2
+    assert _lib.lib().l3d_knn_feature(_lib.ptr(xx), 1, 32, 64, 65, _lib.ptr(ws), _lib.ptr(out), _lib.stream_ptr()) == -1
 
 
 def test_pointwise_conv_ragged_shapes():

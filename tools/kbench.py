@@ -41,6 +41,10 @@ def main():
     with torch.no_grad():
         t = timeit(lambda: U.knn(xt, k))
         res["knn_c2"] = (t, B * N * N / t / 1e3, "Gpair/s")
+        for Cf in (64, 128):
+            xf = torch.randn((B, Cf, N), generator=g).to(dev)
+            t = timeit(lambda: U.knn(xf, k))
+            res[f"knn_feature_C{Cf}"] = (t, 2.0 * Cf * B * N * N / t / 1e6, "TFLOP/s(fp32-equiv GEMM)")
         cd = ChamferDistance()
         t = timeit(lambda: cd(a, b))
         res["chamfer_c2"] = (t, 2 * B * N * N / t / 1e3, "Gpair/s")
