@@ -54,6 +54,16 @@ int l3d_last_hip_error(void);
  * ------------------------------------------------------------------------------------------- */
 int l3d_knn_graph(const float *xyz, int B, int N, int k, int64_t *idx, l3d_stream_t stream);
 
+/* Second half of one dynamic-graph EdgeConv layer (PRNet's DGCNN, models/prnet.py:76-97) on linear
+ * pre-activations: the 1x1 conv over (neighbour ; centre) is two per-point products P, Q (one
+ * l3d_pointwise_conv with 2*Cout output rows, BN folded), and
+ *     out[b][co][i] = act(max_j pq[b][co][idx[b][i][j]] + pq[b][Cout+co][i])
+ * equals the reference's max_j act(bn(conv(cat(x_j, x_i)))) up to the rounding of the split sum.
+ * pq fp32 [B][2*Cout][N]; idx int64 [B][N][k] (k <= 40); act: activation code as l3d_pointwise_conv's relu;
+ * out fp32 [B][Cout][N] with batch stride out_bstride floats (a slice of a concat buffer). */
+int l3d_edge_gather_max(const float *pq, const int64_t *idx, int B, int Cout, int N, int k, int act, float *out,
+                        long out_bstride, l3d_stream_t stream);
+
 /* knn() of utils/model_common_utils.py:3-9 for FEATURE-space graphs, x [B,C,N] with C % 32 == 0 (PRNet's
  * dynamic DGCNN graphs, models/prnet.py:76-97; C = 3 takes l3d_knn_graph): pd = -xx_j + 2 x_i.x_j - xx_i
  * with the inner product on the matrix cores (bf16x3, fp32-level error) and top-k as the GEMM epilogue, no
@@ -244,7 +254,9 @@ int l3d_edgeconv_forward_split(const float *xyz, const int64_t *idx, int B, int 
  *   (identity / zero).  shift is read at [b*shift_bstride + co]: 0 = one vector for the batch,
  *   Cout = one per cloud (a broadcast per-cloud feature concatenated to every point, as in
  *   models/pcn.py:117-119,98-101, becomes a per-cloud shift instead of Cin extra channels).
- *   == models/dgcnn.py:48, models/pointnet.py:22-49, models/pcn.py:84-125 */
+ *   == models/dgcnn.py:48, models/pointnet.py:22-49, models/pcn.py:84-125 *
+ * relu is an activation code for every conv entry point below: 0 none, 1 ReLU, any value > 1 = the IEEE-754 bits
+ * of a LeakyReLU negative slope in (0,1) (0.2f -> 0x3E4CCCCD). */
 int l3d_pointwise_conv(const float *x, int x_channel_last, const float *w, const float *scale,
                        const float *shift, int shift_bstride, int B, int Cin, int Cout, int N,
                        int relu, float *y, l3d_stream_t stream);

@@ -32,6 +32,7 @@ SIGNATURES = {
     "l3d_group_points": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "l3d_group_points_grad": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "l3d_group_concat": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "l3d_edge_gather_max": [_P, _P, _I, _I, _I, _I, _I, _P, _L, _P],
     "l3d_gather_points": [_I, _I, _I, _I, _P, _P, _P, _P],
     "l3d_gather_points_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
     "l3d_furthest_point_sampling": [_I, _I, _I, _P, _P, _P, _P],

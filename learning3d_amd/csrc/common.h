@@ -75,3 +75,12 @@ struct TopK {
         v[0] = fmaxf(v[0], key);
     }
 };
+
+// Activation code of the conv entry points (their `relu` argument): 0 none, 1 ReLU, any value > 1 = the
+// IEEE-754 bits of a LeakyReLU negative slope in (0, 1) (models/prnet.py:79 uses 0.2).  Call only if act != 0.
+#ifdef __HIPCC__
+__device__ __forceinline__ float l3d_act(float v, int act)
+{
+    return act == 1 ? fmaxf(v, 0.f) : fmaxf(v, v * __int_as_float(act));
+}
+#endif

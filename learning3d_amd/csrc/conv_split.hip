@@ -295,7 +295,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const void *__restrict_
                 const float sc = scale ? scale[co] : 1.f;
                 const float sh = shift ? shift[(size_t)b * shift_bstride + co] : 0.f;
                 float v0 = acc[a][0][r] * sc + sh, v1 = acc[a][1][r] * sc + sh;
-                if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                if (relu) { v0 = l3d_act(v0, relu); v1 = l3d_act(v1, relu); }
                 if (pool == 64) v0 = fmaxf(v0, v1);
 #pragma unroll
                 for (int m = 1; m < 32; m <<= 1)
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const void *__restrict_
 #pragma unroll
             for (int c = 0; c < 2; c++) {
                 float v = acc[a][c][r] * sc + sh;
-                if (relu) v = fmaxf(v, 0.f);
+                if (relu) v = l3d_act(v, relu);
                 yb[(size_t)co * N + n0 + wn * 64 + c * 32 + (lane & 31)] = v;
             }
         }
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_dma_kernel(const void *__re
 #pragma unroll
             for (int c = 0; c < 2; c++) {
                 float v = acc[a][c][r] * sc + sh;
-                if (relu) v = fmaxf(v, 0.f);
+                if (relu) v = l3d_act(v, relu);
                 yb[(size_t)co * N + n0 + wn * 64 + c * 32 + (lane & 31)] = v;
             }
         }

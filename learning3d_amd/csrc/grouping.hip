@@ -550,3 +550,66 @@ extern "C" int l3d_group_concat(const float *xyz, const float *new_xyz, const fl
                        new_xyz, features, idx, N, S, K, C, use_xyz, out);
     return l3d_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------
+// One dynamic-graph EdgeConv layer on LINEAR pre-activations (PRNet's DGCNN, models/prnet.py:76-97:
+// get_graph_feature -> conv2d 1x1 (2C -> Cout, no bias) -> BN -> leaky_relu -> max over k).
+// The conv acts on (neighbour ; centre), so it splits into two per-POINT products
+//     P = (s * W[:, :C]) x,     Q = (s * W[:, C:]) x + t          (BN scale s, shift t folded in),
+// and  max_j lrelu(P[idx_ij] + Q_i)  ==  lrelu(max_j P[idx_ij] + Q_i)  exactly (x + c and lrelu are monotone,
+// rounding included): k times fewer conv flops and no [B,2C,N,k] tensor.  This kernel is the second half:
+//     out[b][co][i] = act(max_j pq[b][co][idx[b][i][j]] + pq[b][Cout + co][i]).
+// A workgroup stages CG channel rows of P (N floats each) in LDS and gathers from there (random 4-byte
+// LDS reads); a thread owns a point, its k indices stay in registers across the CG channels; stores are
+// coalesced over points.  `out` takes a batch stride so a layer can write its slice of the cat buffer.
+// (Tried, slower end to end: four channels interleaved per point for 16-byte LDS gathers; staging the
+// index tile through LDS -- both cut occupancy more than they saved.)
+// ---------------------------------------------------------------------------------------------
+template <int KMAX>
+__global__ __launch_bounds__(256) void edge_gather_max_kernel(const float *__restrict__ pq, const int64_t *__restrict__ idx,
+                                                              int Cout, int N, int k, int CG, int act,
+                                                              float *__restrict__ out, long out_bstride)
+{
+    extern __shared__ float prow[];                              // [CG][N]
+    const int b = blockIdx.y, co0 = blockIdx.x * CG;
+    const int cg = min(CG, Cout - co0);
+    const float *pb = pq + ((size_t)b * 2 * Cout + co0) * N;
+    for (int e = threadIdx.x; e < cg * N; e += 256) prow[e] = pb[e];
+    __syncthreads();
+    const float *qb = pq + ((size_t)b * 2 * Cout + Cout + co0) * N;
+    float *ob = out + (size_t)b * out_bstride + (size_t)co0 * N;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const int64_t *ip = idx + ((size_t)b * N + i) * k;
+        int nb[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; j++) nb[j] = (int)ip[j < k ? j : 0];
+        for (int c = 0; c < cg; c++) {
+            const float *pr = prow + c * N;
+            float m = pr[nb[0]];
+#pragma unroll
+            for (int j = 1; j < KMAX; j++) m = fmaxf(m, pr[nb[j]]);   // j >= k repeats neighbour 0
+            float v = m + qb[(size_t)c * N + i];
+            if (act) v = l3d_act(v, act);
+            ob[(size_t)c * N + i] = v;
+        }
+    }
+}
+
+extern "C" int l3d_edge_gather_max(const float *pq, const int64_t *idx, int B, int Cout, int N, int k, int act,
+                                   float *out, long out_bstride, l3d_stream_t stream)
+{
+    L3D_REQUIRE(pq && idx && out && B > 0 && Cout > 0 && N > 0 && k > 0 && out_bstride >= (long)Cout * N);
+    if (B > 65535 || k > 40 || (size_t)N * 4 > 128 * 1024) return L3D_ERR_UNSUPPORTED;
+    // channel rows per workgroup: as many as fit 64 KiB of LDS, fewer while the grid would leave CUs idle
+    int CG = 16;
+    while (CG > 1 && ((size_t)CG * N * 4 > 64 * 1024 || (long)l3d_divup(Cout, CG) * B < 1024)) CG >>= 1;
+    dim3 grid(l3d_divup(Cout, CG), B), block(256);
+    const size_t lds = (size_t)CG * N * 4;
+    hipStream_t st = (hipStream_t)stream;
+    if (k <= 20) {
+        hipLaunchKernelGGL(edge_gather_max_kernel<20>, grid, block, lds, st, pq, idx, Cout, N, k, CG, act, out, out_bstride);
+    } else {
+        hipLaunchKernelGGL(edge_gather_max_kernel<40>, grid, block, lds, st, pq, idx, Cout, N, k, CG, act, out, out_bstride);
+    }
+    return l3d_check_launch();
+}

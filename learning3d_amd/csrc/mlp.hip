@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_conv_kernel(
                 for (int j = 0; j < 2; j++) {
                     const int n = n0 + wn * 64 + j * 32 + l31;
                     v[j] = acc[i][j][e] * sc + sh;
-                    if (relu) v[j] = fmaxf(v[j], 0.f);
+                    if (relu) v[j] = l3d_act(v[j], relu);
                     if (!FULL && n >= N) v[j] = -INFINITY;          // N % pool == 0: a group is all in or all out
                 }
                 if (pool == 64) v[0] = fmaxf(v[0], v[1]);
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_conv_kernel(
             for (int j = 0; j < 2; j++) {
                 const int n = n0 + wn * 64 + j * 32 + l31;
                 float v = acc[i][j][e] * sc + sh;
-                if (relu) v = fmaxf(v, 0.f);
+                if (relu) v = l3d_act(v, relu);
 #ifdef PW_PROBE_NO_STORE
                 if (v == 123.456f)
 #endif
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256) void pointwise_conv_narrow_kernel(
 #pragma unroll
     for (int c = 0; c < COUT; c++) {
         float v = acc[c] * (scale ? scale[c] : 1.f) + (shift ? shift[(size_t)b * shift_bstride + c] : 0.f);
-        if (relu) v = fmaxf(v, 0.f);
+        if (relu) v = l3d_act(v, relu);
         y[((size_t)b * COUT + c) * N + n] = v;
     }
 }

@@ -127,6 +127,33 @@ def query_ball_point(radius, nsample, xyz, new_xyz, get_cnt=False, itself_indice
     return (idx, cnt) if get_cnt else idx
 
 
+class _GraphFeature(torch.autograd.Function):
+    """[B,N,k,2C] = (x[idx] ; x) through l3d_graph_feature; backward = the adjoint of the two gathers (the
+    reference's version is differentiable through its advanced indexing, model_common_utils.py:146-154, and
+    PRNet's layers 2-4 need that gradient: their graph features are built from learned features)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        B, Cc, N = x.shape
+        k = idx.shape[2]
+        xt = _as_bn3(x) if Cc == 3 else f32c(x.transpose(2, 1))
+        out = torch.empty((B, N, k, 2 * Cc), dtype=torch.float32, device=x.device)
+        check(lib().l3d_graph_feature(ptr(xt), ptr(idx), B, N, Cc, k, ptr(out), stream_ptr()), "l3d_graph_feature")
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, Cc, N)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        B, Cc, N = ctx.shape
+        g = grad_out.contiguous()
+        gx = g[..., Cc:].sum(dim=2)                                              # centre half: [B,N,C]
+        flat = (idx + torch.arange(B, device=idx.device).view(B, 1, 1) * N).reshape(-1)
+        gx = gx.reshape(B * N, Cc).index_add(0, flat, g[..., :Cc].reshape(-1, Cc)).view(B, N, Cc)
+        return gx.transpose(2, 1), None
+
+
 def get_graph_feature(x, k=20, device=None):
     """reference: utils/model_common_utils.py:132-156.  x [B,C,N] -> [B,2C,N,k] as a permuted view of
     [B,N,k,2C] memory (the reference returns the same non-contiguous view): channels 0..C-1 are the
@@ -134,11 +161,7 @@ def get_graph_feature(x, k=20, device=None):
     x = x.view(*x.size()[:3])
     require_gpu(x)
     idx = knn(x, k=k)
-    B, Cc, N = x.shape
-    xt = _as_bn3(x) if Cc == 3 else f32c(x.transpose(2, 1))
-    out = torch.empty((B, N, k, 2 * Cc), dtype=torch.float32, device=x.device)
-    check(lib().l3d_graph_feature(ptr(xt), ptr(idx), B, N, Cc, k, ptr(out), stream_ptr()), "l3d_graph_feature")
-    return out.permute(0, 3, 1, 2)
+    return _GraphFeature.apply(x, idx).permute(0, 3, 1, 2)
 
 
 __all__ = ["knn", "square_distance", "index_points", "farthest_point_sample", "knn_point",

@@ -63,7 +63,12 @@ def rand(shape, seed, lo=0.0, hi=1.0):
     return torch.rand(shape, generator=g) * (hi - lo) + lo
 
 
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]     # e.g. `make_golden.py prnet` rewrites only matching files
+
+
 def save(name, **arrs):
+    if ONLY and not any(o in name for o in ONLY):
+        return
     out = {}
     for k, v in arrs.items():
         if isinstance(v, torch.Tensor):
@@ -182,6 +187,16 @@ def main():
         save("dcp_emb64", template=template, source=source, est_R=out["est_R"], est_t=out["est_t"], r=out["r"],
              transformed_source=out["transformed_source"], est_T=out["est_T"],
              **{"w." + k: v for k, v in dcp.state_dict().items()})
+        # ---- 8(f) rank 2: PRNet's DGCNN, a k-NN graph in feature space per layer (models/prnet.py:62-97) --
+        from learning3d.models.prnet import DGCNN as PRNetDGCNN
+        torch.manual_seed(6)
+        pr = PRNetDGCNN(emb_dims=64).eval()
+        for m in pr.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.2, 0.2); m.running_var.uniform_(0.5, 1.5)
+                m.weight.data.uniform_(0.5, 1.5); m.bias.data.uniform_(-0.2, 0.2)
+        x = rand((2, 3, 128), 24)
+        save("prnet_dgcnn_emb64", x=x, out=pr(x), **{"w." + k: v for k, v in pr.state_dict().items()})
     shutil.rmtree(tmp, ignore_errors=True)
     print("done")
 
