@@ -74,103 +74,6 @@ __device__ __forceinline__ void fk_insert_lex(TopK<K> &t, float key, int j)
 #undef FK_BEFORE
 }
 
-// TopK<20>::insert written out as 4 instructions per slot (compare, two index selects, v_med3).  Left to the
-// compiler, the nested selects of common.h's insert() inside the candidate loop below became exec-mask branches
-// plus ~80 register copies per trip.  Slots are updated from the bottom up, so each reads its upper neighbour's
-// OLD value; mask i (= key > v[i]) is computed two slots before its first use: on gfx950 a VALU read of an SGPR
-// needs two other instructions after the VALU write, and the hazard recogniser does not look inside asm.  Two
-// blocks because an asm statement takes at most 30 operands.
-__device__ __forceinline__ void fk_insert20(TopK<20> &t, float key, int j)
-{
-    unsigned long long m0, m1, m2;
-    asm volatile(
-        "v_cmp_gt_f32_e64 %[m1], %[key], %[v19]\n\t"
-        "v_cmp_gt_f32_e64 %[m0], %[key], %[v18]\n\t"
-        "v_cmp_gt_f32_e64 %[m2], %[key], %[v17]\n\t"
-        "v_cndmask_b32_e64 %[i19], %[i19], %[j], %[m1]\n\t"
-        "v_med3_f32 %[v19], %[v18], %[v19], %[key]\n\t"
-        "v_cndmask_b32_e64 %[i19], %[i19], %[i18], %[m0]\n\t"
-        "v_cmp_gt_f32_e64 %[m1], %[key], %[v16]\n\t"
-        "v_cndmask_b32_e64 %[i18], %[i18], %[j], %[m0]\n\t"
-        "v_med3_f32 %[v18], %[v17], %[v18], %[key]\n\t"
-        "v_cndmask_b32_e64 %[i18], %[i18], %[i17], %[m2]\n\t"
-        "v_cmp_gt_f32_e64 %[m0], %[key], %[v15]\n\t"
-        "v_cndmask_b32_e64 %[i17], %[i17], %[j], %[m2]\n\t"
-        "v_med3_f32 %[v17], %[v16], %[v17], %[key]\n\t"
-        "v_cndmask_b32_e64 %[i17], %[i17], %[i16], %[m1]\n\t"
-        "v_cmp_gt_f32_e64 %[m2], %[key], %[v14]\n\t"
-        "v_cndmask_b32_e64 %[i16], %[i16], %[j], %[m1]\n\t"
-        "v_med3_f32 %[v16], %[v15], %[v16], %[key]\n\t"
-        "v_cndmask_b32_e64 %[i16], %[i16], %[i15], %[m0]\n\t"
-        "v_cmp_gt_f32_e64 %[m1], %[key], %[v13]\n\t"
-        "v_cndmask_b32_e64 %[i15], %[i15], %[j], %[m0]\n\t"
-        "v_med3_f32 %[v15], %[v14], %[v15], %[key]\n\t"
-        "v_cndmask_b32_e64 %[i15], %[i15], %[i14], %[m2]\n\t"
-        "v_cmp_gt_f32_e64 %[m0], %[key], %[v12]\n\t"
-        "v_cndmask_b32_e64 %[i14], %[i14], %[j], %[m2]\n\t"
-        "v_med3_f32 %[v14], %[v13], %[v14], %[key]\n\t"
-        "v_cndmask_b32_e64 %[i14], %[i14], %[i13], %[m1]\n\t"
-        "v_cmp_gt_f32_e64 %[m2], %[key], %[v11]\n\t"
-        "v_cndmask_b32_e64 %[i13], %[i13], %[j], %[m1]\n\t"
-        "v_med3_f32 %[v13], %[v12], %[v13], %[key]\n\t"
-        "v_cndmask_b32_e64 %[i13], %[i13], %[i12], %[m0]\n\t"
-        "v_cmp_gt_f32_e64 %[m1], %[key], %[v10]\n\t"
-        "v_cndmask_b32_e64 %[i12], %[i12], %[j], %[m0]\n\t"
-        "v_med3_f32 %[v12], %[v11], %[v12], %[key]\n\t"
-        "v_cndmask_b32_e64 %[i12], %[i12], %[i11], %[m2]\n\t"
-        "v_cmp_gt_f32_e64 %[m0], %[key], %[v9]\n\t"
-        "v_cndmask_b32_e64 %[i11], %[i11], %[j], %[m2]\n\t"
-        "v_med3_f32 %[v11], %[v10], %[v11], %[key]\n\t"
-        "v_cndmask_b32_e64 %[i11], %[i11], %[i10], %[m1]\n\t"
-        "v_cndmask_b32_e64 %[i10], %[i10], %[j], %[m1]\n\t"
-        "v_med3_f32 %[v10], %[v9], %[v10], %[key]\n\t"
-        "v_cndmask_b32_e64 %[i10], %[i10], %[i9], %[m0]\n\t"
-        : [v10] "+v"(t.v[10]), [v11] "+v"(t.v[11]), [v12] "+v"(t.v[12]), [v13] "+v"(t.v[13]), [v14] "+v"(t.v[14]), [v15] "+v"(t.v[15]), [v16] "+v"(t.v[16]), [v17] "+v"(t.v[17]), [v18] "+v"(t.v[18]), [v19] "+v"(t.v[19]), [i10] "+v"(t.id[10]), [i11] "+v"(t.id[11]), [i12] "+v"(t.id[12]), [i13] "+v"(t.id[13]), [i14] "+v"(t.id[14]), [i15] "+v"(t.id[15]), [i16] "+v"(t.id[16]), [i17] "+v"(t.id[17]), [i18] "+v"(t.id[18]), [i19] "+v"(t.id[19]), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2)
-        : [v9] "v"(t.v[9]), [i9] "v"(t.id[9]), [key] "v"(key), [j] "v"(j));
-    asm volatile(
-        "v_cmp_gt_f32_e64 %[m0], %[key], %[v9]\n\t"
-        "v_cmp_gt_f32_e64 %[m2], %[key], %[v8]\n\t"
-        "v_cmp_gt_f32_e64 %[m1], %[key], %[v7]\n\t"
-        "v_cndmask_b32_e64 %[i9], %[i9], %[j], %[m0]\n\t"
-        "v_med3_f32 %[v9], %[v8], %[v9], %[key]\n\t"
-        "v_cndmask_b32_e64 %[i9], %[i9], %[i8], %[m2]\n\t"
-        "v_cmp_gt_f32_e64 %[m0], %[key], %[v6]\n\t"
-        "v_cndmask_b32_e64 %[i8], %[i8], %[j], %[m2]\n\t"
-        "v_med3_f32 %[v8], %[v7], %[v8], %[key]\n\t"
-        "v_cndmask_b32_e64 %[i8], %[i8], %[i7], %[m1]\n\t"
-        "v_cmp_gt_f32_e64 %[m2], %[key], %[v5]\n\t"
-        "v_cndmask_b32_e64 %[i7], %[i7], %[j], %[m1]\n\t"
-        "v_med3_f32 %[v7], %[v6], %[v7], %[key]\n\t"
-        "v_cndmask_b32_e64 %[i7], %[i7], %[i6], %[m0]\n\t"
-        "v_cmp_gt_f32_e64 %[m1], %[key], %[v4]\n\t"
-        "v_cndmask_b32_e64 %[i6], %[i6], %[j], %[m0]\n\t"
-        "v_med3_f32 %[v6], %[v5], %[v6], %[key]\n\t"
-        "v_cndmask_b32_e64 %[i6], %[i6], %[i5], %[m2]\n\t"
-        "v_cmp_gt_f32_e64 %[m0], %[key], %[v3]\n\t"
-        "v_cndmask_b32_e64 %[i5], %[i5], %[j], %[m2]\n\t"
-        "v_med3_f32 %[v5], %[v4], %[v5], %[key]\n\t"
-        "v_cndmask_b32_e64 %[i5], %[i5], %[i4], %[m1]\n\t"
-        "v_cmp_gt_f32_e64 %[m2], %[key], %[v2]\n\t"
-        "v_cndmask_b32_e64 %[i4], %[i4], %[j], %[m1]\n\t"
-        "v_med3_f32 %[v4], %[v3], %[v4], %[key]\n\t"
-        "v_cndmask_b32_e64 %[i4], %[i4], %[i3], %[m0]\n\t"
-        "v_cmp_gt_f32_e64 %[m1], %[key], %[v1]\n\t"
-        "v_cndmask_b32_e64 %[i3], %[i3], %[j], %[m0]\n\t"
-        "v_med3_f32 %[v3], %[v2], %[v3], %[key]\n\t"
-        "v_cndmask_b32_e64 %[i3], %[i3], %[i2], %[m2]\n\t"
-        "v_cmp_gt_f32_e64 %[m0], %[key], %[v0]\n\t"
-        "v_cndmask_b32_e64 %[i2], %[i2], %[j], %[m2]\n\t"
-        "v_med3_f32 %[v2], %[v1], %[v2], %[key]\n\t"
-        "v_cndmask_b32_e64 %[i2], %[i2], %[i1], %[m1]\n\t"
-        "v_cndmask_b32_e64 %[i1], %[i1], %[j], %[m1]\n\t"
-        "v_med3_f32 %[v1], %[v0], %[v1], %[key]\n\t"
-        "v_cndmask_b32_e64 %[i1], %[i1], %[i0], %[m0]\n\t"
-        "v_cndmask_b32_e64 %[i0], %[i0], %[j], %[m0]\n\t"
-        "v_max_f32 %[v0], %[v0], %[key]\n\t"
-        : [v0] "+v"(t.v[0]), [v1] "+v"(t.v[1]), [v2] "+v"(t.v[2]), [v3] "+v"(t.v[3]), [v4] "+v"(t.v[4]), [v5] "+v"(t.v[5]), [v6] "+v"(t.v[6]), [v7] "+v"(t.v[7]), [v8] "+v"(t.v[8]), [v9] "+v"(t.v[9]), [i0] "+v"(t.id[0]), [i1] "+v"(t.id[1]), [i2] "+v"(t.id[2]), [i3] "+v"(t.id[3]), [i4] "+v"(t.id[4]), [i5] "+v"(t.id[5]), [i6] "+v"(t.id[6]), [i7] "+v"(t.id[7]), [i8] "+v"(t.id[8]), [i9] "+v"(t.id[9]), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2)
-        : [key] "v"(key), [j] "v"(j));
-}
-
 template <int K>
 __global__ __launch_bounds__(256, 2) void featknn_kernel(const uint4 *__restrict__ xs, const float *__restrict__ nxx,
                                                          int C, int N, int Np, int k, int64_t *__restrict__ idx_out)
@@ -236,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void featknn_kernel(const uint4 *__restrict
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
-    static_assert(K == 20, "fk_insert20 is written for K = 20");
+    static_assert(K == 20, "topk20_insert (common.h) is written for K = 20");
 #ifdef FK_COUNT
     int trips = 0;
 #endif
@@ -329,7 +232,7 @@ __global__ __launch_bounds__(256, 2) void featknn_kernel(const uint4 *__restrict
                         const unsigned bn = min((unsigned)(__ffs((int)mask) - 1), 16u);
                         mask &= mask - 1;
                         const float cn = scr[bn * 64 + lane];
-                        fk_insert20(top, cv, rbase + (int)((bp & 3) + 8 * (bp >> 2)));
+                        topk20_insert(top, cv, rbase + (int)((bp & 3) + 8 * (bp >> 2)));
                         bp = bn;
                         cv = cn;
                     } while (__builtin_amdgcn_ballot_w64(bp < 16u) != 0);

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
     constexpr int KR = K + 1;                          // list rows: K entries + one dummy row the branch-free
                                                        // append may scribble on when a list is full
     constexpr int SCR = (2 * K + KR > QCAP ? 2 * K + KR : QCAP) * 64;   // A lists never fill (< K keys beat the K-th best)
-    __shared__ float4 cand[W][T2];
+    __shared__ float4 cand[W][T2 + 1];                 // slot T2: a sentinel whose key is -inf
     __shared__ float scratch[W][SCR];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -180,6 +180,10 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
     const float qx = qp[0], qy = qp[1], qz = qp[2];
     const float qxx = (qx * qx + qy * qy) + qz * qz;
     const float *cbase = cxyz + (size_t)b * Nc * 3;
+
+    if (lane == 0)
+        cand[wave][T2] = METRIC == METRIC_EXPANDED ? make_float4(0.f, 0.f, 0.f, -INFINITY)
+                                                   : make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
 
     float *akey = scratch[wave];                       // [K][64]
     int *aidx = (int *)scratch[wave] + K * 64;         // [K][64]
@@ -248,20 +252,24 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
                     for (int u = 0; u < CHUNK; u++) mask |= eval(c[u]) > thr ? (1u << (ch + u)) : 0u;
                 }
                 // pop 4 bits per trip: the 4 per-lane LDS reads are independent, so one LDS round trip
-                // is paid per 4 insertions instead of per insertion (a -inf key is a no-op insertion)
+                // is paid per 4 insertions instead of per insertion.  A lane that has run out of bits reads the
+                // sentinel slot (key -inf = a no-op insertion): no per-lane boolean lives across the loop, and
+                // the loop is rotated by hand (if + do-while) because the compiler may not rotate a loop whose
+                // condition is a convergent ballot -- unrotated, every trip copied the whole value list twice
+                // and took four exec-mask branches (featknn.hip met the same problem).
+                if (__builtin_amdgcn_ballot_w64(mask != 0) != 0) {
 #pragma unroll 1
-                while (__any(mask != 0)) {
-                    float4 cc[4];
-                    bool has[4];
+                    do {
+                        float4 cc[4];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        has[e] = mask != 0;
-                        const int bpos = has[e] ? __builtin_ctz(mask) : 0;
-                        mask &= mask - 1;
-                        cc[e] = cand[wave][g0 + bpos];
-                    }
+                        for (int e = 0; e < 4; e++) {
+                            const int bpos = mask != 0 ? g0 + __builtin_ctz(mask) : T2;
+                            mask &= mask - 1;
+                            cc[e] = cand[wave][bpos];
+                        }
 #pragma unroll
-                    for (int e = 0; e < 4; e++) tv.insert(has[e] ? eval(cc[e]) : -INFINITY);
+                        for (int e = 0; e < 4; e++) tv.insert(eval(cc[e]));
+                    } while (__builtin_amdgcn_ballot_w64(mask != 0) != 0);
                 }
                 thr = tv.worst();
             }
@@ -284,11 +292,17 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
             __syncthreads();
             if (receiver) {
                 const float *mk = scratch[wave + step];
+                // sorted lists: once no lane's entry can enter, nothing further can.  Rotated by hand (see pass 1).
+                int i = 0;
+                float kv = mk[lane];
+                if (__builtin_amdgcn_ballot_w64(kv > tv.worst()) != 0) {
 #pragma unroll 1
-                for (int i = 0; i < K; i++) {
-                    const float kv = mk[i * 64 + lane];
-                    if (!__any(kv > tv.worst())) break;      // sorted: nothing further can enter
-                    tv.insert(kv);
+                    do {
+                        const float kn = mk[min(i + 1, K - 1) * 64 + lane];
+                        tv.insert(kv);
+                        kv = kn;
+                        i++;
+                    } while (i < K && __builtin_amdgcn_ballot_w64(kv > tv.worst()) != 0);
                 }
             }
         }
@@ -375,7 +389,8 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
                 const float *ak = scratch[0] + (size_t)w_cur * SCR;
                 const int *ai = (const int *)ak + (which == 0 ? K * 64 : 2 * K * 64);
                 const float key = which == 0 ? ak[s_cur * 64 + lane] : thrF;
-                top.insert(has ? key : -INFINITY, ai[s_cur * 64 + lane]);
+                if constexpr (K == 20) topk20_insert(top, has ? key : -INFINITY, ai[s_cur * 64 + lane]);
+                else top.insert(has ? key : -INFINITY, ai[s_cur * 64 + lane]);
                 s_cur++;
                 rem--;
             }

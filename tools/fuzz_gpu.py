@@ -42,7 +42,8 @@ with torch.no_grad():
         if N % K == 0:
             full = _fused.pointwise_conv(dev(x), dev(w), None, dev(sh), relu=True, split=False)
             pooled = _fused.pointwise_conv_maxpool(dev(x), dev(w), None, dev(sh), True, K)
-            rec("conv maxpool", pooled.cpu().numpy(), full.view(B, Cout, N // K, K).max(-1)[0].cpu().numpy(), 0, 0)
+            # the pooled epilogue exists in both GEMM arithmetics (bf16x3 when N % 256 == 0): fp32-level agreement
+            rec("conv maxpool", pooled.cpu().numpy(), full.view(B, Cout, N // K, K).max(-1)[0].cpu().numpy(), 1e-5, 5e-6)
     for it in range(10):                                            # soft correspondence + attention, ragged
         B = int(rng.integers(1, 3)); C = 16 * int(rng.integers(2, 20)); N = int(rng.integers(1, 600)); M = int(rng.integers(1, 600))
         q = rng.standard_normal((B, C, N)).astype(np.float32); k_ = rng.standard_normal((B, C, M)).astype(np.float32)

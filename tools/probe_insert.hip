@@ -10,7 +10,7 @@ __global__ __launch_bounds__(256) void ins_kernel(float *out, long long *cyc, in
     float key = (float)(s >> 8);
     long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; it++) {
-        if (MODE == 0) fk_insert20(top, key, it);
+        if (MODE == 0) topk20_insert(top, key, it);
         else top.insert(key, it);
         key = key * 1.0001f + 3.f;
     }
