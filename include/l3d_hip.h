@@ -54,6 +54,18 @@ int l3d_last_hip_error(void);
  * ------------------------------------------------------------------------------------------- */
 int l3d_knn_graph(const float *xyz, int B, int N, int k, int64_t *idx, l3d_stream_t stream);
 
+/* Deterministic backward of the gather-type ops (replaces the fp32-atomicAdd scatters of
+ * group_points_grad_kernel, group_points_gpu.cu:8-28; gather_points_grad, sampling_gpu.cu:37-52;
+ * three_interpolate_grad, interpolate_gpu.cu:185-205):
+ *     dst[b][c][t] = sum over entries e < E with idx[b][e] == t, in ascending e, of
+ *                    src[b][c][e / div] * (weight ? weight[b][e] : 1)
+ * src fp32 [B][C][E/div]; idx int32 [B][E] with values in [0,T); dst fp32 [B][C][T] (fully written).
+ * grouping: E = npoint*nsample, div 1;  gather: E = npoint, div 1;  three_interpolate: E = n*3, div 3, weight [B,n,3].
+ * workspace: >= l3d_scatter_add_det_workspace_bytes(B,T,E) bytes.  Same inputs -> same bits, every run. */
+size_t l3d_scatter_add_det_workspace_bytes(int B, int T, int E);
+int l3d_scatter_add_det(const float *src, const int32_t *idx, const float *weight, int B, int C, int T, int E, int div,
+                        void *workspace, float *dst, l3d_stream_t stream);
+
 /* Second half of one dynamic-graph EdgeConv layer (PRNet's DGCNN, models/prnet.py:76-97) on linear
  * pre-activations: the 1x1 conv over (neighbour ; centre) is two per-point products P, Q (one
  * l3d_pointwise_conv with 2*Cout output rows, BN folded), and

@@ -32,6 +32,8 @@ SIGNATURES = {
     "l3d_group_points": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "l3d_group_points_grad": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "l3d_group_concat": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "l3d_scatter_add_det_workspace_bytes": [_I, _I, _I],
+    "l3d_scatter_add_det": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "l3d_edge_gather_max": [_P, _P, _I, _I, _I, _I, _I, _P, _L, _P],
     "l3d_gather_points": [_I, _I, _I, _I, _P, _P, _P, _P],
     "l3d_gather_points_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
@@ -68,7 +70,8 @@ SIGNATURES = {
     "l3d_emd_backward": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
 }
 _RESTYPE = {"l3d_status_string": C.c_char_p, "l3d_edgeconv_packed_floats": _SZ, "l3d_split_bytes": _SZ,
-            "l3d_soft_correspondence_workspace_floats": _SZ, "l3d_knn_feature_workspace_bytes": _SZ}
+            "l3d_soft_correspondence_workspace_floats": _SZ, "l3d_knn_feature_workspace_bytes": _SZ,
+            "l3d_scatter_add_det_workspace_bytes": _SZ}
 
 
 class L3DError(RuntimeError):

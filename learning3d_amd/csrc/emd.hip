@@ -109,12 +109,14 @@ __global__ __launch_bounds__(1024) void emd_approxmatch_kernel(int n, int m,
     }
 }
 
-// cost[b] = sum_k sum_l sqrt(d2(k,l)) * match[l*n+k]; one wave per l-row, fp32 partials, one atomic per wave
+// cost[b] = sum_k sum_l sqrt(d2(k,l)) * match[l*n+k]; one wave per l-row writes its partial to rowcost[b][l]
+// (the approxmatch scratch, free by now), emd_costsum_kernel adds the rows in a fixed order: deterministic,
+// where the reference (emd.cuh:236-243) and the first version here raced fp32 atomics into cost[b].
 __global__ __launch_bounds__(256) void emd_matchcost_kernel(int n, int m,
                                                             const float *__restrict__ xyz1,
                                                             const float *__restrict__ xyz2,
                                                             const float *__restrict__ match,
-                                                            float *__restrict__ cost)
+                                                            float *__restrict__ rowcost, int row_bstride)
 {
     const int b = blockIdx.y;
     const int l = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -128,7 +130,21 @@ __global__ __launch_bounds__(256) void emd_matchcost_kernel(int n, int m,
         s += sqrtf((dx * dx + dy * dy) + dz * dz) * mt[k];
     }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) atomicAdd(&cost[b], s);
+    if (lane == 0) rowcost[(size_t)b * row_bstride + l] = s;
+}
+
+__global__ __launch_bounds__(256) void emd_costsum_kernel(int m, const float *__restrict__ rowcost, int row_bstride,
+                                                          float *__restrict__ cost)
+{
+    __shared__ float part[4];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float *r = rowcost + (size_t)b * row_bstride;
+    float s = 0.f;
+    for (int l = t; l < m; l += 256) s += r[l];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((t & 63) == 0) part[t >> 6] = s;
+    __syncthreads();
+    if (t == 0) cost[b] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
 // grad2[l] = sum_k (p2_l - p1_k) * match[l*n+k] * rsqrt(max(d2, 1e-20))        (K6)
@@ -188,9 +204,9 @@ extern "C" int l3d_emd_forward(const float *xyz1, const float *xyz2, int B, int 
     hipLaunchKernelGGL(emd_approxmatch_kernel, dim3(B), dim3(1024), 0, st, n, m, xyz1, xyz2, match, temp);
     int rc = l3d_check_launch();
     if (rc) return rc;
-    hipError_t e = hipMemsetAsync(cost, 0, sizeof(float) * B, st);
-    if (e != hipSuccess) { g_l3d_last_hip_error = (int)e; return L3D_ERR_LAUNCH; }
-    hipLaunchKernelGGL(emd_matchcost_kernel, dim3(l3d_divup(m, 4), B), dim3(256), 0, st, n, m, xyz1, xyz2, match, cost);
+    const int tstride = 2 * (n + m);                             // temp is [B][2 * (n + m)] floats, >= m per cloud
+    hipLaunchKernelGGL(emd_matchcost_kernel, dim3(l3d_divup(m, 4), B), dim3(256), 0, st, n, m, xyz1, xyz2, match, temp, tstride);
+    hipLaunchKernelGGL(emd_costsum_kernel, dim3(B), dim3(256), 0, st, m, (const float *)temp, tstride, cost);
     return l3d_check_launch();
 }
 

@@ -15,6 +15,24 @@ from torch.autograd import Function
 from .._lib import check, f32c, lib, ptr, require_gpu, stream_ptr
 
 
+# Backward of the gather-type ops: True = every target owns its sum and adds its contributions in ascending
+# entry order (l3d_scatter_add_det: stable sort of the indices, then segment sums) -- same bits every run;
+# False = the reference's scheme, fp32 atomicAdd scatter (group_points_gpu.cu:8-28 etc.): faster, run-to-run
+# different in the low bits.
+DETERMINISTIC_BACKWARD = True
+
+
+def _scatter_add_det(src, idx, weight, T, div):
+    """dst[b,c,t] = sum_{e: idx[b,e]==t, ascending e} src[b,c,e//div] * weight[b,e];  src [B,C,E/div], idx int32 [B,E]"""
+    B, Cc = src.shape[0], src.shape[1]
+    E = idx.numel() // B
+    dst = torch.empty((B, Cc, T), dtype=torch.float32, device=src.device)
+    ws = torch.empty(lib().l3d_scatter_add_det_workspace_bytes(B, T, E), dtype=torch.uint8, device=src.device)
+    check(lib().l3d_scatter_add_det(ptr(src), ptr(idx), ptr(weight), B, Cc, T, E, div, ptr(ws), ptr(dst), stream_ptr()),
+          "l3d_scatter_add_det")
+    return dst
+
+
 class FurthestPointSampling(Function):
     """reference: pointnet2_utils.py:10-33 -> K12 furthest_point_sampling_kernel."""
 
@@ -58,8 +76,10 @@ class GatherOperation(Function):
     def backward(ctx, grad_out):
         idx, Cc, N = ctx.for_backwards
         B, npoint = idx.size()
-        grad_features = torch.empty((B, Cc, N), dtype=torch.float32, device=grad_out.device)
         g = grad_out.contiguous()
+        if DETERMINISTIC_BACKWARD:
+            return _scatter_add_det(g, idx, None, N, 1), None
+        grad_features = torch.empty((B, Cc, N), dtype=torch.float32, device=grad_out.device)
         check(lib().l3d_gather_points_grad(B, Cc, N, npoint, ptr(g), ptr(idx), ptr(grad_features), stream_ptr()),
               "l3d_gather_points_grad")
         return grad_features, None
@@ -139,8 +159,10 @@ class ThreeInterpolate(Function):
     def backward(ctx, grad_out: torch.Tensor):
         idx, weight, m = ctx.three_interpolate_for_backward
         B, c, n = grad_out.size()
-        grad_features = torch.empty((B, c, m), dtype=torch.float32, device=grad_out.device)
         g = grad_out.contiguous()
+        if DETERMINISTIC_BACKWARD:
+            return _scatter_add_det(g, idx, weight, m, 3), None, None
+        grad_features = torch.empty((B, c, m), dtype=torch.float32, device=grad_out.device)
         check(lib().l3d_three_interpolate_grad(B, c, n, m, ptr(g), ptr(idx), ptr(weight), ptr(grad_features),
                                                stream_ptr()), "l3d_three_interpolate_grad")
         return grad_features, None, None
@@ -170,8 +192,10 @@ class GroupingOperation(Function):
     def backward(ctx, grad_out: torch.Tensor):
         idx, N = ctx.for_backwards
         B, Cc, npoint, nsample = grad_out.size()
-        grad_features = torch.empty((B, Cc, N), dtype=torch.float32, device=grad_out.device)
         g = grad_out.contiguous()
+        if DETERMINISTIC_BACKWARD:
+            return _scatter_add_det(g.view(B, Cc, npoint * nsample), idx, None, N, 1), None
+        grad_features = torch.empty((B, Cc, N), dtype=torch.float32, device=grad_out.device)
         check(lib().l3d_group_points_grad(B, Cc, N, npoint, nsample, ptr(g), ptr(idx), ptr(grad_features),
                                           stream_ptr()), "l3d_group_points_grad")
         return grad_features, None

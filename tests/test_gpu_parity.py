@@ -169,6 +169,56 @@ def test_chamfer_large_properties():
 
 
 # ---------------------------------------------------------------------------- PointNet++ native ops
+def test_gather_type_backward_is_deterministic_and_correct():
+    """grouping / gather / three_interpolate backward through l3d_scatter_add_det (stable
+    sort of the indices + per-target sums in ascending entry order) instead of fp32 atomics: the same bits on
+    every run, equal to an fp64 index_add within fp32 rounding, and to the atomic kernels within tolerance."""
+    from learning3d_amd.utils import pointnet2_utils as P
+    rng = np.random.default_rng(123)
+    B, C, N, S, K = 3, 20, 500, 64, 16
+    feat = dev(rng.standard_normal((B, C, N)).astype(np.float32))
+    idx_g = dev(rng.integers(0, 40, (B, S, K)).astype(np.int32))                 # heavy collisions: 40 targets
+    idx_s = dev(rng.integers(0, N, (B, S)).astype(np.int32))
+    idx_3 = dev(rng.integers(0, S, (B, N, 3)).astype(np.int32))
+    w3 = dev(rng.uniform(0, 1, (B, N, 3)).astype(np.float32))
+    known = dev(rng.standard_normal((B, C, S)).astype(np.float32))
+
+    def run(det):
+        P.DETERMINISTIC_BACKWARD = det
+        outs = []
+        f = feat.clone().requires_grad_()
+        go = dev(np.random.default_rng(5).standard_normal((B, C, S, K)).astype(np.float32))
+        (P.grouping_operation(f, idx_g) * go).sum().backward(); outs.append(f.grad.clone())
+        f = feat.clone().requires_grad_()
+        go = dev(np.random.default_rng(6).standard_normal((B, C, S)).astype(np.float32))
+        (P.gather_operation(f, idx_s) * go).sum().backward(); outs.append(f.grad.clone())
+        f = known.clone().requires_grad_()
+        go = dev(np.random.default_rng(7).standard_normal((B, C, N)).astype(np.float32))
+        (P.three_interpolate(f, idx_3, w3) * go).sum().backward(); outs.append(f.grad.clone())
+        return [o.cpu().numpy() for o in outs]
+
+    try:
+        d1, d2, atomic = run(True), run(True), run(False)
+    finally:
+        P.DETERMINISTIC_BACKWARD = True
+    for a, b_ in zip(d1, d2):
+        assert np.array_equal(a, b_)                                               # same bits, run to run
+    for a, b_ in zip(d1, atomic):
+        np.testing.assert_allclose(a, b_, rtol=1e-4, atol=1e-4)
+    # fp64 references
+    go = np.random.default_rng(5).standard_normal((B, C, S, K))
+    ref = np.zeros((B, C, N)); ig = idx_g.cpu().numpy()
+    for b in range(B):
+        np.add.at(ref[b], (slice(None), ig[b].reshape(-1)), go[b].astype(np.float32).reshape(C, -1))
+    np.testing.assert_allclose(d1[0], ref, rtol=1e-5, atol=1e-4)
+    go = np.random.default_rng(7).standard_normal((B, C, N)).astype(np.float32)
+    ref = np.zeros((B, C, S)); i3 = idx_3.cpu().numpy(); w = w3.cpu().numpy().astype(np.float64)
+    for b in range(B):
+        for t in range(3):
+            np.add.at(ref[b], (slice(None), i3[b, :, t]), go[b] * w[b, :, t][None, :])
+    np.testing.assert_allclose(d1[2], ref, rtol=1e-5, atol=1e-4)
+
+
 def test_pointnet2_ops_vs_oracle(golden):
     from learning3d_amd.utils import pointnet2_utils as P
     rng = np.random.default_rng(5)
