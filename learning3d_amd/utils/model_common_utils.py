@@ -148,10 +148,17 @@ class _GraphFeature(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         B, Cc, N = ctx.shape
         g = grad_out.contiguous()
-        gx = g[..., Cc:].sum(dim=2)                                              # centre half: [B,N,C]
-        flat = (idx + torch.arange(B, device=idx.device).view(B, 1, 1) * N).reshape(-1)
-        gx = gx.reshape(B * N, Cc).index_add(0, flat, g[..., :Cc].reshape(-1, Cc)).view(B, N, Cc)
-        return gx.transpose(2, 1), None
+        k = idx.shape[2]
+        centre = g[..., Cc:].sum(dim=2).transpose(2, 1)                          # [B,C,N]
+        # neighbour half: every point owns its sum, contributions added in ascending (n, j) order
+        # (l3d_scatter_add_det, scatter_det.hip) -- deterministic, unlike index_add's fp32 atomics
+        src = g[..., :Cc].permute(0, 3, 1, 2).reshape(B, Cc, N * k).contiguous()
+        idx32 = idx.to(torch.int32).reshape(B, N * k).contiguous()
+        dst = torch.empty((B, Cc, N), dtype=torch.float32, device=g.device)
+        ws = torch.empty(lib().l3d_scatter_add_det_workspace_bytes(B, N, N * k), dtype=torch.uint8, device=g.device)
+        check(lib().l3d_scatter_add_det(ptr(src), ptr(idx32), None, B, Cc, N, N * k, 1, ptr(ws), ptr(dst), stream_ptr()),
+              "l3d_scatter_add_det")
+        return dst + centre, None
 
 
 def get_graph_feature(x, k=20, device=None):
