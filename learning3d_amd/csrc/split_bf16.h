@@ -22,10 +22,15 @@ __device__ __forceinline__ float bf16_hi(uint32_t p) { return __builtin_bit_cast
 // two fp32 -> packed (h, m, l) bf16 pairs, x = h + m + l exactly
 __device__ __forceinline__ void split_pair(float a, float b, uint32_t &h, uint32_t &m, uint32_t &l)
 {
+    // the two remainders are formed as packed fp32 subtractions (v_pk_add_f32: one instruction per pair)
+    const f32x2 x = {a, b};
     h = cvt_pk_bf16(a, b);
-    const float ra = a - bf16_lo(h), rb = b - bf16_hi(h);
-    m = cvt_pk_bf16(ra, rb);
-    l = cvt_pk_bf16(ra - bf16_lo(m), rb - bf16_hi(m));
+    const f32x2 hf = {bf16_lo(h), bf16_hi(h)};
+    const f32x2 r = x - hf;
+    m = cvt_pk_bf16(r[0], r[1]);
+    const f32x2 mf = {bf16_lo(m), bf16_hi(m)};
+    const f32x2 r2 = r - mf;
+    l = cvt_pk_bf16(r2[0], r2[1]);
 }
 
 // 8 fp32 -> three uint4 of 8 bf16
