@@ -371,28 +371,43 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
         // busiest lane's TOTAL (about K), not the sum over slices of the busiest lane per slice
 #pragma unroll
         for (int which = 0; which < 2; which++) {            // 0: keys > thrF (akey/aidx), 1: keys == thrF (bidx)
+            // cumulative entry counts of the slices, in registers: entry `it` of the lane's virtual list sits in
+            // slice w = #(cum[.] <= it), slot it - cum[w-1] -- no LDS round trips to find it
+            int cum[W];
             int tot = 0;
 #pragma unroll
-            for (int w = 0; w < W; w++) tot += cnts[w][which][lane];
-            int w_cur = 0, s_cur = 0, rem = cnts[0][which][lane];
-#pragma unroll 1
-            for (int it = 0; it < 2 * K; it++) {
-                const bool has = it < tot;
-                if (!__any(has)) break;
+            for (int w = 0; w < W; w++) { tot += cnts[w][which][lane]; cum[w] = tot; }
+            int tmax = tot;                                   // uniform trip count = the busiest lane's total
 #pragma unroll
-                for (int hop = 1; hop < W; hop++) {           // skip exhausted / empty slices
-                    const bool adv = rem == 0 && w_cur < W - 1;
-                    w_cur += adv ? 1 : 0;
-                    s_cur = adv ? 0 : s_cur;
-                    rem = adv ? cnts[w_cur][which][lane] : rem;
+            for (int d = 32; d > 0; d >>= 1) tmax = max(tmax, __shfl_xor(tmax, d, 64));
+            tmax = __builtin_amdgcn_readfirstlane(tmax);
+            const int list_off = which == 0 ? K * 64 : 2 * K * 64;
+            auto fetch = [&](int it, float &key, int &id) {
+                int w = 0, base = 0;
+#pragma unroll
+                for (int u = 0; u < W - 1; u++) {
+                    const bool past = it >= cum[u];
+                    w += past ? 1 : 0;
+                    base = past ? cum[u] : base;
                 }
-                const float *ak = scratch[0] + (size_t)w_cur * SCR;
-                const int *ai = (const int *)ak + (which == 0 ? K * 64 : 2 * K * 64);
-                const float key = which == 0 ? ak[s_cur * 64 + lane] : thrF;
-                if constexpr (K == 20) topk20_insert(top, has ? key : -INFINITY, ai[s_cur * 64 + lane]);
-                else top.insert(has ? key : -INFINITY, ai[s_cur * 64 + lane]);
-                s_cur++;
-                rem--;
+                const int slot = min(it - base, K - 1);       // lanes past their total read a valid (ignored) slot
+                const float *ak = scratch[0] + (size_t)w * SCR;
+                const float kv = which == 0 ? ak[slot * 64 + lane] : thrF;
+                id = ((const int *)ak)[list_off + slot * 64 + lane];
+                key = it < tot ? kv : -INFINITY;               // a -inf key is a no-op insertion
+            };
+            float key_c;
+            int id_c;
+            fetch(0, key_c, id_c);
+#pragma unroll 1
+            for (int it = 0; it < tmax; it++) {
+                float key_n;
+                int id_n;
+                fetch(it + 1, key_n, id_n);                    // the next entry's LDS reads overlap this insertion
+                if constexpr (K == 20) topk20_insert(top, key_c, id_c);
+                else top.insert(key_c, id_c);
+                key_c = key_n;
+                id_c = id_n;
             }
         }
     }
