@@ -169,6 +169,11 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
                                                        // append may scribble on when a list is full
     constexpr int SCR = (2 * K + KR > QCAP ? 2 * K + KR : QCAP) * 64;   // A lists never fill (< K keys beat the K-th best)
     __shared__ float4 cand[W][T2 + 1];                 // slot T2: a sentinel whose key is -inf
+    __shared__ int cnts[W][2][64];                     // pass 2's per-slice entry counts; during pass 1 its first W*64
+                                                       // words hold each wave's current K-th best (sthr), shared
+                                                       // between the slices -- the workgroup sits 960 B under the
+                                                       // 80 KiB that let two of them share a CU, so nothing is added
+    volatile float *sthr = (volatile float *)&cnts[0][0][0];
     __shared__ float scratch[W][SCR];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -181,6 +186,7 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
     const float qxx = (qx * qx + qy * qy) + qz * qz;
     const float *cbase = cxyz + (size_t)b * Nc * 3;
 
+    sthr[wave * 64 + lane] = -INFINITY;                      // visible to the other waves after stage()'s first barrier
     if (lane == 0)
         cand[wave][T2] = METRIC == METRIC_EXPANDED ? make_float4(0.f, 0.f, 0.f, -INFINITY)
                                                    : make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
@@ -271,7 +277,17 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
                         for (int e = 0; e < 4; e++) tv.insert(eval(cc[e]));
                     } while (__builtin_amdgcn_ballot_w64(mask != 0) != 0);
                 }
+                // The K-th best of ANY slice is a lower bound of the global K-th best, and it only ever rises: publish
+                // this wave's, read the other waves' (whatever they have published so far -- no barrier needed, a
+                // stale value is still a valid bound) and filter with the maximum.  A candidate <= that bound cannot
+                // change the K-th largest value of the union, which is all pass 1 is after; it cuts the insertions
+                // of a quarter-cloud slice from ~K ln(N/4K)+K to roughly a quarter of the single-stream count.
                 thr = tv.worst();
+                if (W > 1) {
+                    sthr[wave * 64 + lane] = thr;
+#pragma unroll
+                    for (int w = 0; w < W; w++) thr = fmaxf(thr, sthr[w * 64 + lane]);
+                }
             }
         }
         KT(1)
@@ -360,7 +376,6 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
     // ---------------- wave 0 builds the (value, index) list from every slice's collected entries,
     // slices in index order, entries in index order within a slice: strict '>' insertion therefore
     // keeps lowest-index-first under exact ties.
-    __shared__ int cnts[W][2][64];
     cnts[wave][0][lane] = cntA;
     cnts[wave][1][lane] = cntB;
     __syncthreads();
