@@ -102,6 +102,10 @@ int l3d_graph_feature(const float *x, const int64_t *idx, int B, int N, int C, i
  * ------------------------------------------------------------------------------------------- */
 int l3d_chamfer_forward(const float *xyz1, const float *xyz2, int B, int N, int M, float *dist1,
                         float *dist2, int32_t *idx1, int32_t *idx2, l3d_stream_t stream);
+/* Kernel choice of l3d_chamfer_forward (results are bit-identical either way): 0 = one (query, candidate) pair per
+ * instruction sequence, 1 = auto (default), 2 = always the packed-fp32 kernel (two queries per lane, argmin per
+ * chunk of 8).  A process-wide tuning / test knob, not part of the call contract. */
+extern int l3d_chamfer_forward_mode;
 int l3d_chamfer_backward(const float *xyz1, const float *xyz2, int B, int N, int M,
                          const float *graddist1, const float *graddist2, const int32_t *idx1,
                          const int32_t *idx2, float *gradxyz1, float *gradxyz2, l3d_stream_t stream);

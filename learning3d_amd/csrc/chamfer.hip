@@ -119,15 +119,142 @@ __global__ __launch_bounds__(64 * CWAVES) void chamfer_fwd_kernel(const float *_
     }
 }
 
+// kernel choice of l3d_chamfer_forward: 0 = per-candidate kernels only, 1 = auto (default), 2 = packed kernel always
+// (tests and tools flip it to compare the two bit for bit)
+extern "C" { int l3d_chamfer_forward_mode = 1; }
+
+// ---------------------------------------------------------------------------------------------
+// Packed variant: two queries per lane evaluated with ONE packed-fp32 instruction each step (v_pk_add_f32 /
+// v_pk_mul_f32: the 157 TFLOP/s vector peak of this part exists only in packed form), and the argmin kept
+// per CHUNK of 8 candidates instead of per candidate: min3 tree over the chunk, one strict '<' against the
+// running best, remember the chunk's first index.  Which of the 8 it was is resolved once at the end by
+// re-evaluating that chunk (same arithmetic -> the same bits) and taking the first candidate whose distance
+// equals the best: exactly what one sequential strict-'<' scan returns.  Per (query, candidate): 4 packed + ~1
+// instructions instead of 11.  Same tiling / wave split / merge as chamfer_fwd_kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * CWAVES) void chamfer_fwd_packed_kernel(const float *__restrict__ xyz1,
+                                                                         const float *__restrict__ xyz2, int N, int M,
+                                                                         float *__restrict__ dist1,
+                                                                         float *__restrict__ dist2,
+                                                                         int32_t *__restrict__ idx1,
+                                                                         int32_t *__restrict__ idx2)
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    __shared__ float4 cand[CTILE];
+    __shared__ float rbest[CWAVES][2][64];
+    __shared__ int rbesti[CWAVES][2][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int dir = blockIdx.z;
+    const float *qs = dir == 0 ? xyz1 : xyz2;
+    const float *cs = dir == 0 ? xyz2 : xyz1;
+    const int Nq = dir == 0 ? N : M;
+    const int Nc = dir == 0 ? M : N;
+    float *dout = dir == 0 ? dist1 : dist2;
+    int32_t *iout = dir == 0 ? idx1 : idx2;
+    const int q0 = blockIdx.x * 128;
+    if (q0 >= Nq) return;
+
+    f32x2 qx, qy, qz;
+    {
+        const float *p0 = qs + ((size_t)b * Nq + min(q0 + lane, Nq - 1)) * 3;
+        const float *p1 = qs + ((size_t)b * Nq + min(q0 + 64 + lane, Nq - 1)) * 3;
+        qx = f32x2{p0[0], p1[0]}; qy = f32x2{p0[1], p1[1]}; qz = f32x2{p0[2], p1[2]};
+    }
+    float best0 = INFINITY, best1 = INFINITY;
+    int base0 = 0x7fffffff, base1 = 0x7fffffff;        // first candidate index of the chunk that holds the best
+    const float *cbase = cs + (size_t)b * Nc * 3;
+    for (int c0 = 0; c0 < Nc; c0 += CTILE) {
+        const int tn = min(CTILE, Nc - c0);
+        __syncthreads();
+        for (int t = tid; t < tn; t += 64 * CWAVES) {
+            const float *cp = cbase + (size_t)(c0 + t) * 3;
+            cand[t] = make_float4(cp[0], cp[1], cp[2], 0.f);
+        }
+        __syncthreads();
+        const int per = (tn + CWAVES - 1) / CWAVES;
+        const int t0 = wave * per, t1 = min(tn, t0 + per);
+        int t = t0;
+        for (; t + 8 <= t1; t += 8) {
+            float4 c[8];
+#pragma unroll
+            for (int v = 0; v < 8; v++) c[v] = cand[t + v];
+            f32x2 d[8];
+#pragma unroll
+            for (int v = 0; v < 8; v++) {
+                const f32x2 dx = f32x2{c[v].x, c[v].x} - qx, dy = f32x2{c[v].y, c[v].y} - qy, dz = f32x2{c[v].z, c[v].z} - qz;
+                d[v] = (dx * dx + dy * dy) + dz * dz;
+            }
+            float m0 = fminf(fminf(d[0][0], d[1][0]), d[2][0]), m1 = fminf(fminf(d[0][1], d[1][1]), d[2][1]);
+            m0 = fminf(fminf(m0, d[3][0]), d[4][0]); m1 = fminf(fminf(m1, d[3][1]), d[4][1]);
+            m0 = fminf(fminf(m0, d[5][0]), d[6][0]); m1 = fminf(fminf(m1, d[5][1]), d[6][1]);
+            m0 = fminf(m0, d[7][0]); m1 = fminf(m1, d[7][1]);
+            const bool lt0 = m0 < best0, lt1 = m1 < best1;           // strict: an equal later chunk does not replace
+            best0 = lt0 ? m0 : best0; base0 = lt0 ? c0 + t : base0;
+            best1 = lt1 ? m1 : best1; base1 = lt1 ? c0 + t : base1;
+        }
+        for (; t < t1; t++) {                                       // slice tail: chunks of one
+            const float4 c = cand[t];
+            const f32x2 dx = f32x2{c.x, c.x} - qx, dy = f32x2{c.y, c.y} - qy, dz = f32x2{c.z, c.z} - qz;
+            const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+            const bool lt0 = d[0] < best0, lt1 = d[1] < best1;
+            best0 = lt0 ? d[0] : best0; base0 = lt0 ? c0 + t : base0;
+            best1 = lt1 ? d[1] : best1; base1 = lt1 ? c0 + t : base1;
+        }
+    }
+    // which candidate of the winning chunk: the first whose distance equals the best (a chunk of one matches at once)
+    int bi0 = base0, bi1 = base1;
+    {
+        bool f0 = base0 == 0x7fffffff, f1 = base1 == 0x7fffffff;
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+            const int j0 = min(base0 == 0x7fffffff ? 0 : base0 + v, Nc - 1), j1 = min(base1 == 0x7fffffff ? 0 : base1 + v, Nc - 1);
+            const float *pa = cbase + (size_t)j0 * 3, *pb = cbase + (size_t)j1 * 3;
+            const f32x2 dx = f32x2{pa[0], pb[0]} - qx, dy = f32x2{pa[1], pb[1]} - qy, dz = f32x2{pa[2], pb[2]} - qz;
+            const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+            if (!f0 && d[0] == best0) { bi0 = j0; f0 = true; }
+            if (!f1 && d[1] == best1) { bi1 = j1; f1 = true; }
+        }
+    }
+    rbest[wave][0][lane] = best0; rbesti[wave][0][lane] = bi0;
+    rbest[wave][1][lane] = best1; rbesti[wave][1][lane] = bi1;
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            float bv = rbest[0][u][lane];
+            int bi = rbesti[0][u][lane];
+#pragma unroll
+            for (int w = 1; w < CWAVES; w++) {
+                const float ov = rbest[w][u][lane];
+                const int oi = rbesti[w][u][lane];
+                const bool take = ov < bv || (ov == bv && oi < bi);
+                bv = take ? ov : bv;
+                bi = take ? oi : bi;
+            }
+            const int q = q0 + u * 64 + lane;
+            if (q < Nq) {
+                dout[(size_t)b * Nq + q] = bv;
+                iout[(size_t)b * Nq + q] = bi == 0x7fffffff ? 0 : bi;
+            }
+        }
+    }
+}
+
 extern "C" int l3d_chamfer_forward(const float *xyz1, const float *xyz2, int B, int N, int M,
                                    float *dist1, float *dist2, int32_t *idx1, int32_t *idx2,
                                    l3d_stream_t stream)
 {
     L3D_REQUIRE(xyz1 && xyz2 && dist1 && dist2 && idx1 && idx2 && B > 0 && N > 0 && M > 0);
     const int mx = N > M ? N : M;
-    // enough workgroups to cover 256 CUs several times over before going to 2 queries/lane
-    const long wgs1 = (long)l3d_divup(mx, 64) * B * 2;
-    if (wgs1 >= 8192) {
+    // two queries per lane, packed fp32 (chamfer_fwd_packed_kernel) once that still gives every SIMD a wave;
+    // tiny problems keep one query per lane for the workgroup count
+    const long wgs2 = (long)l3d_divup(mx, 128) * B * 2;
+    if (l3d_chamfer_forward_mode == 2 || (l3d_chamfer_forward_mode == 1 && wgs2 * CWAVES >= 1024)) {
+        dim3 grid(l3d_divup(mx, 128), B, 2);
+        hipLaunchKernelGGL(chamfer_fwd_packed_kernel, grid, dim3(64 * CWAVES), 0, (hipStream_t)stream, xyz1, xyz2, N, M,
+                           dist1, dist2, idx1, idx2);
+    } else if (wgs2 * 2 >= 8192) {
         dim3 grid(l3d_divup(mx, 128), B, 2);
         hipLaunchKernelGGL(chamfer_fwd_kernel<2>, grid, dim3(64 * CWAVES), 0, (hipStream_t)stream, xyz1,
                            xyz2, N, M, dist1, dist2, idx1, idx2);

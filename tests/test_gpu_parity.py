@@ -143,6 +143,40 @@ def test_chamfer_golden_forward_backward(golden):
     assert abs(float(loss_g) - float(g["loss_ext"])) < 1e-6
 
 
+def test_chamfer_packed_kernel_bit_identical():
+    """The packed-fp32 forward (two queries per lane, argmin per chunk of 8 resolved at the end) against the
+    per-candidate kernels and the oracle: identical distances AND indices, including exact ties (duplicated
+    points -> the first index must win), ragged sizes and a collapsed cloud."""
+    import ctypes
+    from learning3d_amd._lib import lib, check, ptr, stream_ptr
+    mode = ctypes.c_int.in_dll(lib(), "l3d_chamfer_forward_mode")
+    rng = np.random.default_rng(33)
+    cases = [(rng.uniform(0, 1, (2, 77, 3)), rng.uniform(0, 1, (2, 130, 3))),
+             (rng.uniform(0, 1, (3, 1024, 3)), rng.uniform(0, 1, (3, 1000, 3))),
+             (rng.uniform(0, 1, (1, 2500, 3)), rng.uniform(0, 1, (1, 4099, 3)))]
+    dup = rng.uniform(0, 1, (1, 300, 3)); cases.append((rng.uniform(0, 1, (1, 200, 3)), np.concatenate([dup, dup, dup], 1)))
+    cases.append((rng.uniform(0, 1, (2, 500, 3)), np.full((2, 700, 3), 0.25)))
+    try:
+        for a, b in cases:
+            a, b = a.astype(np.float32), b.astype(np.float32)
+            B, N, M = a.shape[0], a.shape[1], b.shape[1]
+            ta, tb = dev(a), dev(b)
+            res = {}
+            for m in (0, 2):
+                mode.value = m
+                d1 = torch.empty(B, N, device="cuda"); d2 = torch.empty(B, M, device="cuda")
+                i1 = torch.empty(B, N, dtype=torch.int32, device="cuda"); i2 = torch.empty(B, M, dtype=torch.int32, device="cuda")
+                check(lib().l3d_chamfer_forward(ptr(ta), ptr(tb), B, N, M, ptr(d1), ptr(d2), ptr(i1), ptr(i2), stream_ptr()), "cd")
+                res[m] = [x.cpu().numpy() for x in (d1, d2, i1, i2)]
+            for x, y in zip(res[0], res[2]):
+                assert np.array_equal(x, y), (B, N, M)
+            o = oracle.chamfer_forward(a[:1], b[:1])
+            for x, y in zip(res[2], o):
+                assert np.array_equal(x[:1], y), (B, N, M)
+    finally:
+        mode.value = 1
+
+
 def test_chamfer_idx_and_ragged_vs_oracle():
     from learning3d_amd._lib import lib, check, ptr, stream_ptr
     for (B, N, M, seed) in [(2, 77, 130, 1), (1, 2500, 64, 2), (32, 1024, 1024, 3)]:
