@@ -61,6 +61,41 @@ with torch.no_grad():
         out = torch.empty_like(qd)
         check(lib().l3d_attention_forward(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, 1 / math.sqrt(D), ptr(out), stream_ptr()), "att")
         rec("attention vs fp64", out.cpu().numpy().reshape(B, H, D, N), want, 1e-5, 4e-6)
+    import ctypes
+    mode = ctypes.c_int.in_dll(lib(), "l3d_chamfer_forward_mode")
+    for it in range(10):                                            # Chamfer: packed kernel == per-candidate kernel, bit for bit
+        B = int(rng.integers(1, 4)); N = int(rng.integers(1, 3000)); M = int(rng.integers(1, 3000))
+        a = dev(rng.uniform(0, 1, (B, N, 3)).astype(np.float32)); b_ = dev(np.round(rng.uniform(0, 1, (B, M, 3)) * 8).astype(np.float32) / 8)   # ties
+        outs = []
+        for m_ in (0, 2):
+            mode.value = m_
+            d1 = torch.empty(B, N, device="cuda"); d2 = torch.empty(B, M, device="cuda")
+            i1 = torch.empty(B, N, dtype=torch.int32, device="cuda"); i2 = torch.empty(B, M, dtype=torch.int32, device="cuda")
+            check(lib().l3d_chamfer_forward(ptr(a), ptr(b_), B, N, M, ptr(d1), ptr(d2), ptr(i1), ptr(i2), stream_ptr()), "cd")
+            outs.append([t.cpu().numpy() for t in (d1, d2, i1, i2)])
+        mode.value = 1
+        for x_, y_ in zip(*outs):
+            assert np.array_equal(x_, y_), ("chamfer packed", B, N, M)
+    worst["chamfer packed == scalar"] = 0.0
+    for it in range(8):                                             # feature-space kNN vs exact fp64 distances
+        B = int(rng.integers(1, 3)); C = 32 * int(rng.integers(1, 9)); N = int(rng.integers(21, 1500)); k = int(rng.integers(1, 21))
+        x = rng.standard_normal((B, C, N)).astype(np.float32)
+        idx = U.knn(dev(x), k).cpu().numpy()
+        xd = x.astype(np.float64); sq = (xd ** 2).sum(1)
+        d = sq[:, :, None] + sq[:, None, :] - 2 * np.einsum("bci,bcj->bij", xd, xd)
+        kth = np.sort(d, axis=-1)[:, :, k - 1]
+        got = np.take_along_axis(d, idx, axis=-1)
+        rec("feature knn: k-th bound", got.max(-1), kth, 0, 4e-6 * sq.max())
+        assert np.all(np.diff(got, axis=-1) >= -4e-6 * sq.max()) and np.all(idx[:, :, 0] == np.arange(N)[None])
+    from learning3d_amd.utils import pointnet2_utils as P
+    for it in range(6):                                             # deterministic scatter-add vs fp64 index_add
+        B = int(rng.integers(1, 4)); C = int(rng.integers(1, 70)); T = int(rng.integers(1, 900)); E = int(rng.integers(1, 5000))
+        src = rng.standard_normal((B, C, E)).astype(np.float32); idx = rng.integers(0, T, (B, E)).astype(np.int32)
+        got = P._scatter_add_det(dev(src), dev(idx), None, T, 1).cpu().numpy()
+        ref = np.zeros((B, C, T))
+        for b in range(B):
+            np.add.at(ref[b], (slice(None), idx[b]), src[b].astype(np.float64))
+        rec("scatter_add_det vs fp64", got, ref, 1e-5, 2e-5)
 for k_, v_ in worst.items():
     print(f"{k_:28s} worst (|err| - rtol|want|) = {v_:.3e}")
 print("fuzz OK")
