@@ -181,10 +181,21 @@ class FlowNet3D(nn.Module):
         self.conv2 = nn.Conv1d(128, 3, kernel_size=1, bias=True)
 
     def forward(self, pc1, pc2, feature1, feature2):
-        l1_pc1, l1_feature1 = self.sa1(pc1, feature1)
-        l2_pc1, l2_feature1 = self.sa2(l1_pc1, l1_feature1)
-        l1_pc2, l1_feature2 = self.sa1(pc2, feature2)
-        l2_pc2, l2_feature2 = self.sa2(l1_pc2, l1_feature2)
+        if (_fused.can_fuse(self, pc1, pc2, feature1, feature2) and pc1.is_cuda and pc1.shape == pc2.shape
+                and feature1.shape == feature2.shape):
+            # sa1 / sa2 are applied to BOTH clouds with the same weights (reference :307-310) and every op in them
+            # is per cloud (eval-mode BN), so the two passes run as one over the concatenated batch: furthest
+            # point sampling is latency-bound with one workgroup per cloud -- 2B workgroups take as long as B.
+            B = pc1.shape[0]
+            l1_pc, l1_feature = self.sa1(torch.cat([pc1, pc2], 0), torch.cat([feature1, feature2], 0))
+            l2_pc, l2_feature = self.sa2(l1_pc, l1_feature)
+            l1_pc1, l1_feature1 = l1_pc[:B], l1_feature[:B]
+            l2_pc1, l2_feature1, l2_pc2, l2_feature2 = l2_pc[:B], l2_feature[:B], l2_pc[B:], l2_feature[B:]
+        else:
+            l1_pc1, l1_feature1 = self.sa1(pc1, feature1)
+            l2_pc1, l2_feature1 = self.sa2(l1_pc1, l1_feature1)
+            l1_pc2, l1_feature2 = self.sa1(pc2, feature2)
+            l2_pc2, l2_feature2 = self.sa2(l1_pc2, l1_feature2)
         _, l2_feature1_new = self.fe_layer(l2_pc1, l2_pc2, l2_feature1, l2_feature2)
         l3_pc1, l3_feature1 = self.sa3(l2_pc1, l2_feature1_new)
         l4_pc1, l4_feature1 = self.sa4(l3_pc1, l3_feature1)
