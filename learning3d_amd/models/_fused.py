@@ -67,15 +67,28 @@ def bn_affine(bn):
 
 def fold_conv_bn(conv, bn=None):
     """conv (1x1 Conv1d/Conv2d or Linear) followed by optional eval-mode BN ->
-    (w [Cout,Cin], scale [Cout] or None, shift [Cout] or None) with y = scale*(w x) + shift"""
-    w = conv.weight.detach().reshape(conv.weight.shape[0], -1)
-    bias = conv.bias.detach() if conv.bias is not None else None
+    (w [Cout,Cin], scale [Cout] or None, shift [Cout] or None) with y = scale*(w x) + shift.
+    The result is cached on the conv module per parameter / running-statistic version: folding is five tiny
+    elementwise launches per layer, ~0.65 ms per FlowNet3D forward before this cache.  Treat the returned
+    tensors as read-only."""
+    ts = [conv.weight, conv.bias]
+    if bn is not None:
+        ts += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in ts)
+    hit = conv.__dict__.get("_l3d_fold")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    w = conv.weight.detach().reshape(conv.weight.shape[0], -1).float().contiguous()
+    bias = conv.bias.detach().float() if conv.bias is not None else None
     if bn is None:
-        return w, None, bias
-    scale, shift = bn_affine(bn)
-    if bias is not None:
-        shift = shift + scale * bias
-    return w, scale, shift
+        out = (w, None, bias)
+    else:
+        scale, shift = bn_affine(bn)
+        if bias is not None:
+            shift = shift + scale * bias
+        out = (w, scale.float().contiguous(), shift.float().contiguous())
+    conv.__dict__["_l3d_fold"] = (key, out)
+    return out
 
 
 def can_fuse(module, *tensors):
