@@ -163,7 +163,8 @@ def main():
             if args.sync_loss:
                 loss = parallel.allgather_chamfer_loss(chamfer_partials(d1, d2))   # blocking RCCL all_gather if N>1
             else:
-                loss = loss_pipe.submit(chamfer_partials(d1, d2))                  # async all_gather; previous step's loss
+                loss = loss_pipe.submit_dists(d1, d2)     # N>1: partial sums + async all_gather (previous step's loss);
+                                                          # N=1: the whole loss tail in one launch
         return feat, loss
 
     # clock / cache pre-conditioning before the W official warm-up steps: the first ~50 ms after an idle

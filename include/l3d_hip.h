@@ -117,6 +117,10 @@ int l3d_chamfer_backward(const float *xyz1, const float *xyz2, int B, int N, int
 int l3d_chamfer_partials(const float *dist1, const float *dist2, int B, int N, int M, double *partial,
                          l3d_stream_t stream);
 int l3d_chamfer_combine(const double *partials, int world, float *loss, l3d_stream_t stream);
+/* The loss tail of ONE rank in one launch: partial[4] exactly as l3d_chamfer_partials writes it, and
+ * loss = (partial[0]/partial[2] + partial[1]/partial[3]) / 2 as l3d_chamfer_combine(partial, 1, loss) would. */
+int l3d_chamfer_loss_local(const float *dist1, const float *dist2, int B, int N, int M, double *partial, float *loss,
+                           l3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * PointNet++ native ops  == utils/lib/src/pointnet2_api.cpp:10-25 (pybind `pointnet2_cuda`)

@@ -405,6 +405,50 @@ extern "C" int l3d_chamfer_partials(const float *dist1, const float *dist2, int 
     return l3d_check_launch();
 }
 
+// Single-rank tail in ONE launch: both sqrt-sums (same thread mapping and summation order as sqrt_sum_kernel, so
+// the partials are bit-identical to l3d_chamfer_partials') and the combine, by one 1024-thread workgroup.
+__global__ __launch_bounds__(1024) void chamfer_loss_local_kernel(const float *__restrict__ d1, size_t n1,
+                                                                  const float *__restrict__ d2, size_t n2,
+                                                                  double *__restrict__ partial, float *__restrict__ loss)
+{
+    __shared__ double part[2][16];
+    double tot[2];
+#pragma unroll
+    for (int which = 0; which < 2; which++) {
+        const float *d = which == 0 ? d1 : d2;
+        const size_t n = which == 0 ? n1 : n2;
+        double acc = 0.0;
+        const size_t n4 = n >> 2;
+        for (size_t i = threadIdx.x; i < n4; i += blockDim.x) {
+            const float4 v = ((const float4 *)d)[i];
+            acc += ((double)sqrtf(v.x) + (double)sqrtf(v.y)) + ((double)sqrtf(v.z) + (double)sqrtf(v.w));
+        }
+        for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) acc += (double)sqrtf(d[i]);
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if ((threadIdx.x & 63) == 0) part[which][threadIdx.x >> 6] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int which = 0; which < 2; which++) {
+            double t = 0.0;
+            for (int w = 0; w < 16; w++) t += part[which][w];
+            tot[which] = t;
+        }
+        partial[0] = tot[0]; partial[1] = tot[1]; partial[2] = (double)n1; partial[3] = (double)n2;
+        loss[0] = (float)((tot[0] / (double)n1 + tot[1] / (double)n2) / 2.0);
+    }
+}
+
+extern "C" int l3d_chamfer_loss_local(const float *dist1, const float *dist2, int B, int N, int M, double *partial,
+                                      float *loss, l3d_stream_t stream)
+{
+    L3D_REQUIRE(dist1 && dist2 && partial && loss && B > 0 && N > 0 && M > 0);
+    hipLaunchKernelGGL(chamfer_loss_local_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dist1, (size_t)B * N,
+                       dist2, (size_t)B * M, partial, loss);
+    return l3d_check_launch();
+}
+
 __global__ void chamfer_combine_kernel(const double *__restrict__ partials, int world,
                                        float *__restrict__ loss)
 {

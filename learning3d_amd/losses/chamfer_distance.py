@@ -62,6 +62,17 @@ def chamfer_partials(dist1, dist2):
     return part
 
 
+def chamfer_loss_local(dist1, dist2):
+    """One rank, one launch: the same partial sums and the same combine as chamfer_combine(chamfer_partials(...))."""
+    B, N = dist1.shape
+    M = dist2.shape[1]
+    part = torch.empty(4, dtype=torch.float64, device=dist1.device)
+    loss = torch.empty((), dtype=torch.float32, device=dist1.device)
+    check(lib().l3d_chamfer_loss_local(ptr(dist1), ptr(dist2), B, N, M, ptr(part), ptr(loss), stream_ptr()),
+          "l3d_chamfer_loss_local")
+    return loss
+
+
 def chamfer_combine(partials):
     """partials: fp64 [world,4] (or [4]) device tensor -> fp32 scalar loss tensor (on device)."""
     partials = partials.contiguous().view(-1, 4)
@@ -79,7 +90,7 @@ def chamfer_distance(template: torch.Tensor, source: torch.Tensor):
         cost_p0_p1 = torch.mean(torch.sqrt(cost_p0_p1))
         cost_p1_p0 = torch.mean(torch.sqrt(cost_p1_p0))
         return (cost_p0_p1 + cost_p1_p0) / 2.0
-    return chamfer_combine(chamfer_partials(cost_p0_p1, cost_p1_p0))
+    return chamfer_loss_local(cost_p0_p1, cost_p1_p0)          # == chamfer_combine(chamfer_partials(...)), one launch
 
 
 def chamfer(a, b):

@@ -88,6 +88,14 @@ class PipelinedChamferLoss:
         prev, self._pending = self._pending, (work, flat, src)
         return self._finish(prev)
 
+    def submit_dists(self, dist1, dist2):
+        """submit() from the two distance tensors: with one rank the whole tail (both sqrt-sums + combine) is one
+        launch (l3d_chamfer_loss_local); with several, partial sums then the asynchronous exchange."""
+        from .losses.chamfer_distance import chamfer_loss_local, chamfer_partials
+        if not self._multi and dist1.is_cuda:
+            return chamfer_loss_local(dist1, dist2)
+        return self.submit(chamfer_partials(dist1, dist2))
+
     def flush(self):
         prev, self._pending = self._pending, None
         return self._finish(prev)

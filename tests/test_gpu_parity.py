@@ -177,6 +177,18 @@ def test_chamfer_packed_kernel_bit_identical():
         mode.value = 1
 
 
+def test_chamfer_loss_local_equals_partials_plus_combine():
+    from learning3d_amd.losses.chamfer_distance import chamfer_loss_local, chamfer_partials, chamfer_combine
+    rng = np.random.default_rng(44)
+    for (B, N, M) in [(32, 1024, 1024), (3, 77, 130), (1, 5, 2)]:
+        d1, d2 = dev(rng.uniform(0, 2, (B, N)).astype(np.float32)), dev(rng.uniform(0, 2, (B, M)).astype(np.float32))
+        a = chamfer_loss_local(d1, d2)
+        b = chamfer_combine(chamfer_partials(d1, d2))
+        assert a.item() == b.item()
+        want = (np.sqrt(d1.cpu().numpy().astype(np.float64)).mean() + np.sqrt(d2.cpu().numpy().astype(np.float64)).mean()) / 2
+        assert abs(a.item() - want) < 1e-6
+
+
 def test_chamfer_idx_and_ragged_vs_oracle():
     from learning3d_amd._lib import lib, check, ptr, stream_ptr
     for (B, N, M, seed) in [(2, 77, 130, 1), (1, 2500, 64, 2), (32, 1024, 1024, 3)]:
