@@ -118,11 +118,160 @@ __global__ __launch_bounds__(64) void ball_query_kernel(int n, int m, float r2, 
     if (counting) cnt_out[(size_t)b * m + s] = total;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sliced ball query (n >= 1024, nsample <= 64): the single-wave kernel above leaves half the SIMDs idle at
+// FlowNet3D's sa1 (512 waves on 1024 SIMDs) and each wave walks all n candidates.  Here 4 waves serve the SAME
+// 64 centroids, wave w scanning the w-th quarter of the cloud through its own LDS tile (no workgroup barrier
+// in the scan, so a wave can leave early) and collecting its first nsample hits in index order.  A wave may
+// stop once its own hits plus the hits of the EARLIER quarters reach nsample for every lane; the earlier waves'
+// counts are read from LDS without synchronisation -- they only grow, so a stale value just delays the exit.
+// Wave 0 then concatenates the four lists in slice order (= index order) and pads like the kernel above.
+// ---------------------------------------------------------------------------------------------
+#define BQ_W 4
+#define BQ_T4 512
+template <int MODE>
+__global__ __launch_bounds__(64 * BQ_W) void ball_query_sliced_kernel(int n, int m, float r2, int nsample,
+                                                                      const float *__restrict__ new_xyz,
+                                                                      const float *__restrict__ xyz,
+                                                                      const int64_t *__restrict__ itself,
+                                                                      void *__restrict__ idx_out,
+                                                                      int64_t *__restrict__ cnt_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char bq_lds[];
+    float4 *cand = (float4 *)bq_lds + (threadIdx.x >> 6) * BQ_T4;                       // this wave's tile
+    int *hits = (int *)(bq_lds + BQ_W * BQ_T4 * 16);                                    // [BQ_W][nsample][64]
+    volatile int *cnts = (volatile int *)(hits + BQ_W * nsample * 64);                  // [BQ_W][64]
+    long *totals = (long *)(hits + BQ_W * nsample * 64 + BQ_W * 64);                    // [BQ_W][64] (counting)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int s = blockIdx.x * 64 + lane;
+    const bool valid = s < m;
+    const int sc = valid ? s : m - 1;
+    const float *qp = new_xyz + ((size_t)b * m + sc) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    const float qss = (qx * qx + qy * qy) + qz * qz;
+    const int self = (MODE == 1 && itself) ? (int)itself[(size_t)b * m + sc] : -1;
+    const float *cbase = xyz + (size_t)b * n * 3;
+    const bool counting = (MODE == 1) && cnt_out != nullptr;
+    int *myhits = hits + wave * nsample * 64;
+
+    cnts[wave * 64 + lane] = 0;
+    __syncthreads();
+    const int per = ((n + BQ_W - 1) / BQ_W + 31) & ~31;         // slice length, multiple of 32
+    const int lo = wave * per, hi = min(n, lo + per);
+    int cnt = 0;
+    long total = 0;
+    for (int c0 = lo; c0 < hi; c0 += BQ_T4) {
+        const int tn = min(BQ_T4, hi - c0);
+        const int tp = (tn + 31) & ~31;
+        for (int t = lane; t < tp; t += 64) {
+            float4 v = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 2.7e37f);   // far-away sentinel, never inside a ball
+            if (t < tn) {
+                const float *cp = cbase + (size_t)(c0 + t) * 3;
+                const float x = cp[0], y = cp[1], z = cp[2];
+                v = make_float4(x, y, z, (x * x + y * y) + z * z);
+            }
+            cand[t] = v;
+        }
+        bool stop = false;
+        for (int g0 = 0; g0 < tn; g0 += 32) {
+            unsigned mask = 0;
+#pragma unroll
+            for (int ch = 0; ch < 32; ch += 8) {
+                float4 c[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) c[u] = cand[g0 + ch + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    bool hit;
+                    if (MODE == 0) {
+                        const float dx = qx - c[u].x, dy = qy - c[u].y, dz = qz - c[u].z;
+                        const float d2 = (dx * dx + dy * dy) + dz * dz;
+                        hit = d2 < r2;
+                    } else {
+                        const float dot = fmaf(qz, c[u].z, fmaf(qy, c[u].y, qx * c[u].x));
+                        const float d2 = (-2.0f * dot + qss) + c[u].w;
+                        hit = !(d2 > r2) && (c0 + g0 + ch + u != self);
+                    }
+                    mask |= hit ? (1u << (ch + u)) : 0u;
+                }
+            }
+            if (counting) total += __builtin_popcount(mask);
+            if (cnt >= nsample || !valid) mask = 0;
+            if (__builtin_amdgcn_ballot_w64(mask != 0) != 0) {
+#pragma unroll 1
+                do {
+                    if (mask != 0) {
+                        myhits[cnt * 64 + lane] = c0 + g0 + __builtin_ctz(mask);
+                        mask &= mask - 1;
+                        cnt++;
+                        if (cnt >= nsample) mask = 0;
+                    }
+                } while (__builtin_amdgcn_ballot_w64(mask != 0) != 0);
+            }
+            cnts[wave * 64 + lane] = cnt;
+            if (!counting) {
+                int before = 0;
+                for (int w = 0; w < wave; w++) before += cnts[w * 64 + lane];
+                if (__all(cnt + before >= nsample || !valid)) { stop = true; break; }
+            }
+        }
+        if (stop) break;
+    }
+    cnts[wave * 64 + lane] = cnt;
+    if (counting) totals[wave * 64 + lane] = total;
+    __syncthreads();
+    if (wave != 0 || !valid) return;
+    // concatenate the slices' lists in slice order
+    int cum[BQ_W], tot = 0;
+#pragma unroll
+    for (int w = 0; w < BQ_W; w++) { tot += cnts[w * 64 + lane]; cum[w] = tot; }
+    const int got = min(tot, nsample);
+    int32_t *o32 = (int32_t *)idx_out + ((size_t)b * m + s) * nsample;
+    int64_t *o64 = (int64_t *)idx_out + ((size_t)b * m + s) * nsample;
+    int first = -1;
+    for (int l = 0; l < got; l++) {
+        int w = 0, base = 0;
+#pragma unroll
+        for (int u = 0; u < BQ_W - 1; u++) {
+            const bool past = l >= cum[u];
+            w += past ? 1 : 0;
+            base = past ? cum[u] : base;
+        }
+        const int h = hits[(w * nsample + (l - base)) * 64 + lane];
+        if (l == 0) first = h;
+        if (MODE == 0) o32[l] = h; else o64[l] = h;
+    }
+    long fill;
+    if (MODE == 0) fill = first < 0 ? 0 : first;
+    else fill = self >= 0 ? self : (first < 0 ? n : first);
+    for (int l = got; l < nsample; l++) {
+        if (MODE == 0) o32[l] = (int32_t)fill; else o64[l] = fill;
+    }
+    if (counting) {
+        long t = 0;
+#pragma unroll
+        for (int w = 0; w < BQ_W; w++) t += totals[w * 64 + lane];
+        cnt_out[(size_t)b * m + s] = t;
+    }
+}
+
+static size_t bq_sliced_lds(int nsample)
+{
+    return (size_t)BQ_W * BQ_T4 * 16 + (size_t)BQ_W * nsample * 64 * 4 + (size_t)BQ_W * 64 * 4 + (size_t)BQ_W * 64 * 8 + 16;
+}
+
 extern "C" int l3d_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                               const float *xyz, int32_t *idx, l3d_stream_t stream)
 {
     L3D_REQUIRE(new_xyz && xyz && idx && b > 0 && n > 0 && m > 0 && nsample > 0);
     const float r2 = radius * radius;                       // ball_query_gpu.cu:24
+    if (n >= 1024 && nsample <= 64) {
+        hipLaunchKernelGGL(ball_query_sliced_kernel<0>, dim3(l3d_divup(m, 64), b), dim3(64 * BQ_W), bq_sliced_lds(nsample),
+                           (hipStream_t)stream, n, m, r2, nsample, new_xyz, xyz, (const int64_t *)nullptr, (void *)idx,
+                           (int64_t *)nullptr);
+        return l3d_check_launch();
+    }
     hipLaunchKernelGGL(ball_query_kernel<0>, dim3(l3d_divup(m, 64), b), dim3(64), 0,
                        (hipStream_t)stream, n, m, r2, nsample, new_xyz, xyz,
                        (const int64_t *)nullptr, (void *)idx, (int64_t *)nullptr);
@@ -137,6 +286,11 @@ extern "C" int l3d_query_ball_point(float radius, int nsample, const float *xyz,
     L3D_REQUIRE(new_xyz && xyz && idx && B > 0 && N > 0 && S > 0 && nsample > 0);
     // python `radius ** 2` is evaluated in double, then compared against an fp32 tensor
     const float r2 = (float)((double)radius * (double)radius);
+    if (N >= 1024 && nsample <= 64) {
+        hipLaunchKernelGGL(ball_query_sliced_kernel<1>, dim3(l3d_divup(S, 64), B), dim3(64 * BQ_W), bq_sliced_lds(nsample),
+                           (hipStream_t)stream, N, S, r2, nsample, new_xyz, xyz, itself_indices, (void *)idx, cnt);
+        return l3d_check_launch();
+    }
     hipLaunchKernelGGL(ball_query_kernel<1>, dim3(l3d_divup(S, 64), B), dim3(64), 0,
                        (hipStream_t)stream, N, S, r2, nsample, new_xyz, xyz, itself_indices,
                        (void *)idx, cnt);
