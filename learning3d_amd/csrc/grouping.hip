@@ -506,16 +506,37 @@ __global__ __launch_bounds__(1024) void fps_kernel(int n, int m, const float *__
         else { x1 = p[old * 3]; y1 = p[old * 3 + 1]; z1 = p[old * 3 + 2]; }
         int best = (int)0x80000000;             // bit pattern of the running max (d2 >= 0, or -1 for padding)
         int besti = 0;
+        if constexpr (PPT >= 2) {
+            // two points per packed-fp32 instruction (v_pk_add_f32 / v_pk_mul_f32; same IEEE results): the
+            // update of 8192 points is VALU-throughput-bound inside the one CU a cloud owns
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 x2 = {x1, x1}, y2 = {y1, y1}, z2 = {z1, z1};
 #pragma unroll
-        for (int u = 0; u < PPT; u++) {
-            const float dx = px[u] - x1, dy = py[u] - y1, dz = pz[u] - z1;
-            const float d = (dx * dx + dy * dy) + dz * dz;
-            const float d2 = fminf(d, dmin[u]);
-            dmin[u] = d2;
-            const int key = __builtin_bit_cast(int, d2);
-            const bool gt = key > best;         // ascending k within a thread: lowest index wins
-            best = gt ? key : best;
-            besti = gt ? tid + u * nthr : besti;
+            for (int u = 0; u < PPT; u += 2) {
+                const f32x2 dx = f32x2{px[u], px[u + 1]} - x2, dy = f32x2{py[u], py[u + 1]} - y2, dz = f32x2{pz[u], pz[u + 1]} - z2;
+                const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const float d2 = fminf(d[h], dmin[u + h]);
+                    dmin[u + h] = d2;
+                    const int key = __builtin_bit_cast(int, d2);
+                    const bool gt = key > best;         // ascending k within a thread: lowest index wins
+                    best = gt ? key : best;
+                    besti = gt ? tid + (u + h) * nthr : besti;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < PPT; u++) {
+                const float dx = px[u] - x1, dy = py[u] - y1, dz = pz[u] - z1;
+                const float d = (dx * dx + dy * dy) + dz * dz;
+                const float d2 = fminf(d, dmin[u]);
+                dmin[u] = d2;
+                const int key = __builtin_bit_cast(int, d2);
+                const bool gt = key > best;         // ascending k within a thread: lowest index wins
+                best = gt ? key : best;
+                besti = gt ? tid + u * nthr : besti;
+            }
         }
         // wave arg-max (lowest index among equal maxima), then the <= 16 waves through LDS
         const int wmax = wave_max_i(best);
@@ -557,7 +578,9 @@ static int launch_fps(int b, int n, int m, const float *xyz, const int64_t *star
                       void *out, hipStream_t st)
 {
     // threads: multiple of 64, <= 1024; points per thread: 1,2,4,8,16,32
-    int nthr = n >= 1024 ? 1024 : ((n + 63) / 64) * 64;
+    // large clouds: 512 threads x 16 points -- the per-wave arg-max reduction (~40 instructions) is amortised over
+    // twice the points and the second level sees 8 waves (the round is VALU-throughput-bound inside one CU)
+    int nthr = n >= 4096 ? 512 : (n >= 1024 ? 1024 : ((n + 63) / 64) * 64);      // (256 x 32 points: 2.2 ms -- one wave per SIMD)
     int ppt = (n + nthr - 1) / nthr;
 #define L3D_FPS_CASE(P)                                                                           \
     if (ppt <= P) {                                                                               \
