@@ -236,6 +236,9 @@ int l3d_attention_forward_strided(const float *q, const float *k, const float *v
  *   y[r][:] = a * (x[r][:] - mean_r) / (std_r + eps) + b,   x, y [rows][C] fp32, C % 4 == 0, C <= 2048. */
 int l3d_layernorm_ref(const float *x, const float *a, const float *b, float eps, long rows, int C, float *y,
                       l3d_stream_t stream);
+/* Residual connection x + sublayer(norm(x)) of utils/transformer.py:82-88 when the sublayer output is channel-first:
+ * out[b][n][c] = x[b][n][c] + y[b][c][n];  x, out fp32 [B,N,C], y fp32 [B,C,N] (tiled transpose through LDS). */
+int l3d_add_transposed(const float *x, const float *y, int B, int N, int C, float *out, l3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Shared-MLP (1x1 conv) stack on fp32 MFMA  (a8)

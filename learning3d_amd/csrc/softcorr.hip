@@ -302,3 +302,39 @@ extern "C" int l3d_layernorm_ref(const float *x, const float *a, const float *b,
     else               hipLaunchKernelGGL(layernorm_ref_kernel<8>, grid, block, 0, st, x, a, b, eps, rows, C, y);
     return l3d_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Residual connection of the pointer network's sublayers (utils/transformer.py:82-88, x + sublayer(norm(x))):
+// x is [B,N,C] (channel-last), the sublayer's output comes from a 1x1-conv kernel as [B,C,N].  torch adds the
+// two through a strided view at ~1/3 of the streaming rate; here 32x32 tiles go through LDS so that both
+// reads and the write are coalesced:   out[b][n][c] = x[b][n][c] + y[b][c][n].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void add_transposed_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                                             int N, int C, float *__restrict__ out)
+{
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const float *yb = y + (size_t)b * C * N;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {                           // y rows c0 + r, columns n0 + tx
+        const int c = c0 + r, n = n0 + tx;
+        tile[r][tx] = (c < C && n < N) ? yb[(size_t)c * N + n] : 0.f;
+    }
+    __syncthreads();
+    const size_t xb = (size_t)b * N * C;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {                           // x / out rows n0 + r, columns c0 + tx
+        const int n = n0 + r, c = c0 + tx;
+        if (n < N && c < C) out[xb + (size_t)n * C + c] = x[xb + (size_t)n * C + c] + tile[tx][r];
+    }
+}
+
+extern "C" int l3d_add_transposed(const float *x, const float *y, int B, int N, int C, float *out, l3d_stream_t stream)
+{
+    L3D_REQUIRE(x && y && out && B > 0 && N > 0 && C > 0);
+    if (B > 65535 || l3d_divup(C, 32) > 65535) return L3D_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(add_transposed_kernel, dim3(l3d_divup(N, 32), l3d_divup(C, 32), B), dim3(256), 0,
+                       (hipStream_t)stream, x, y, N, C, out);
+    return l3d_check_launch();
+}

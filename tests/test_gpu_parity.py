@@ -817,6 +817,16 @@ def test_flash_attention_vs_fp64():
         np.testing.assert_allclose(out.cpu().numpy().reshape(B, H, D, N), want, rtol=1e-5, atol=2e-6)
 
 
+def test_add_transposed_residual():
+    from learning3d_amd._lib import lib, check, ptr, stream_ptr
+    rng = np.random.default_rng(55)
+    for (B, N, C) in [(2, 1024, 512), (3, 77, 130), (1, 1, 1), (2, 33, 31)]:
+        x = dev(rng.standard_normal((B, N, C)).astype(np.float32)); y = dev(rng.standard_normal((B, C, N)).astype(np.float32))
+        out = torch.empty_like(x)
+        check(lib().l3d_add_transposed(ptr(x), ptr(y), B, N, C, ptr(out), stream_ptr()), "l3d_add_transposed")
+        assert torch.equal(out, x + y.transpose(1, 2))
+
+
 def test_transformer_fast_linear_path_matches_torch_path():
     """DCP's pointer network: the no-grad GPU path (Linear / feed-forward layers on the bf16x3 conv kernel,
     channel-first projections) against the same module evaluated in fp64 on the CPU
