@@ -196,6 +196,14 @@ int l3d_knn_point(int k, const float *pos1, const float *pos2, int B, int N, int
  * (NULL if C == 0), idx int32 [B,S,K] -> out [B, 3*use_xyz + C, S, K]. */
 int l3d_group_concat(const float *xyz, const float *new_xyz, const float *features, const int32_t *idx, int B,
                      int N, int S, int K, int C, int use_xyz, float *out, l3d_stream_t stream);
+/* The grouped conv input of FlowEmbedding / PointNetSetUpConv (models/flownet3d.py:125-180, :182-242) in one pass:
+ *   order 0: out = [xyz[idx] - new_xyz | features[idx] | centre broadcast over K]
+ *   order 1: out = [features[idx] | xyz[idx] - new_xyz | centre broadcast over K]
+ * xyz [B,N,3], new_xyz [B,S,3], features [B,C,N], centre [B,C1,S] (NULL when C1 == 0), idx int32 [B,S,K];
+ * out fp32 [B, 3+C+C1, S, K].  Replaces two grouping ops, a subtraction, a repeat and the torch.cat copies. */
+int l3d_group_concat2(const float *xyz, const float *new_xyz, const float *features, const float *centre,
+                      const int32_t *idx, int B, int N, int S, int K, int C, int C1, int order, float *out,
+                      l3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Batched 3x3 SVD head  == utils/svd.py:29-58 (T6, without the B host syncs)

@@ -729,6 +729,55 @@ extern "C" int l3d_group_concat(const float *xyz, const float *new_xyz, const fl
 }
 
 // ---------------------------------------------------------------------------------------------
+// The grouped conv input of FlowNet3D's FlowEmbedding / PointNetSetUpConv (models/flownet3d.py:125-180,
+// :182-242) in one pass: two grouping_operations, a broadcast subtraction, a repeat and one or two torch.cat
+// copies become
+//   order 0:  out = [ xyz[idx] - new_xyz | features[idx] | centre (broadcast over K) ]     (FlowEmbedding, concat)
+//   order 1:  out = [ features[idx] | xyz[idx] - new_xyz | centre ]                        (PointNetSetUpConv)
+// out [B, 3 + C + C1, S, K]; one thread per (s, k), channels in a loop, every store coalesced over (s, k).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void group_concat2_kernel(const float *__restrict__ xyz /*[B,N,3]*/,
+                                                            const float *__restrict__ new_xyz /*[B,S,3]*/,
+                                                            const float *__restrict__ feat /*[B,C,N]*/,
+                                                            const float *__restrict__ centre /*[B,C1,S] or null*/,
+                                                            const int32_t *__restrict__ idx /*[B,S,K]*/, int N, int S,
+                                                            int K, int C, int C1, int order, float *__restrict__ out)
+{
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;                 // s*K + k
+    if (e >= S * K) return;
+    const int s_ = e / K;
+    const int j = idx[((size_t)b * S) * K + e];
+    const size_t SK = (size_t)S * K;
+    float *ob = out + (size_t)b * (3 + C + C1) * SK + e;
+    const float *p = xyz + ((size_t)b * N + j) * 3, *q = new_xyz + ((size_t)b * S + s_) * 3;
+    float *oxyz = ob + (order == 0 ? 0 : (size_t)C * SK);
+    oxyz[0] = p[0] - q[0];
+    oxyz[SK] = p[1] - q[1];
+    oxyz[2 * SK] = p[2] - q[2];
+    float *of = ob + (order == 0 ? 3 * SK : 0);
+    const float *fb = feat + (size_t)b * C * N + j;
+    for (int c = 0; c < C; c++) of[(size_t)c * SK] = fb[(size_t)c * N];
+    if (C1 > 0) {
+        float *oc = ob + (size_t)(3 + C) * SK;
+        const float *cb = centre + (size_t)b * C1 * S + s_;
+        for (int c = 0; c < C1; c++) oc[(size_t)c * SK] = cb[(size_t)c * S];
+    }
+}
+
+extern "C" int l3d_group_concat2(const float *xyz, const float *new_xyz, const float *features, const float *centre,
+                                 const int32_t *idx, int B, int N, int S, int K, int C, int C1, int order, float *out,
+                                 l3d_stream_t stream)
+{
+    L3D_REQUIRE(xyz && new_xyz && features && idx && out && B > 0 && N > 0 && S > 0 && K > 0 && C > 0 && C1 >= 0 &&
+                (C1 == 0 || centre) && (order == 0 || order == 1));
+    if (B > 65535) return L3D_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(group_concat2_kernel, dim3(l3d_divup((long)S * K, 256), B), dim3(256), 0, (hipStream_t)stream, xyz,
+                       new_xyz, features, centre, idx, N, S, K, C, C1, order, out);
+    return l3d_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
 // One dynamic-graph EdgeConv layer on LINEAR pre-activations (PRNet's DGCNN, models/prnet.py:76-97:
 // get_graph_feature -> conv2d 1x1 (2C -> Cout, no bias) -> BN -> leaky_relu -> max over k).
 // The conv acts on (neighbour ; centre), so it splits into two per-POINT products

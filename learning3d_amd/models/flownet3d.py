@@ -37,6 +37,26 @@ def _mlp_stack(x, convs, bns, module, pool=False):
     return torch.max(x, -1)[0] if pool else x
 
 
+def _grouped_input(src_xyz_t, centre_xyz_t, src_feat, centre_feat, idx, order, module):
+    """[xyz[idx] - centre | feat[idx] | centre_feat] (order 0) or [feat[idx] | xyz[idx] - centre] (order 1) as ONE
+    kernel (l3d_group_concat2) at inference; None -> the caller composes it from grouping ops (autograd route)."""
+    if (not _fused.can_fuse(module, src_xyz_t, centre_xyz_t, src_feat) or not src_feat.is_cuda or idx.dtype != torch.int32
+            or (centre_feat is not None and not _fused.can_fuse(module, centre_feat))):
+        return None
+    from .._lib import check, lib, ptr, stream_ptr
+    B, N, _ = src_xyz_t.shape
+    S, K = idx.shape[1], idx.shape[2]
+    feat = src_feat.float().contiguous()
+    C = feat.shape[1]
+    cen = centre_feat.float().contiguous() if centre_feat is not None else None
+    C1 = cen.shape[1] if cen is not None else 0
+    out = torch.empty((B, 3 + C + C1, S, K), dtype=torch.float32, device=feat.device)
+    check(lib().l3d_group_concat2(ptr(src_xyz_t.contiguous()), ptr(centre_xyz_t.contiguous()), ptr(feat), ptr(cen),
+                                  ptr(idx.contiguous()), B, N, S, K, C, C1, order, ptr(out), stream_ptr()),
+          "l3d_group_concat2")
+    return out
+
+
 class PointNetSetAbstraction(nn.Module):
     """reference :73-123.  xyz [B,3,N], points [B,D,N] -> new_xyz [B,3,S], new_points [B,D',S]."""
 
@@ -89,6 +109,9 @@ class FlowEmbedding(nn.Module):
             _, idx_knn = pointutils.knn(self.nsample, pos1_t, pos2_t)
             cnt = cnt.view(B, -1, 1).repeat(1, 1, self.nsample)
             idx = idx_knn[cnt > (self.nsample - 1)]
+        fused = _grouped_input(pos2_t, pos1_t, feature2, feature1, idx, 0, self)
+        if fused is not None:
+            return pos1, _mlp_stack(fused, self.mlp_convs, self.mlp_bns, self, pool=True)
         pos2_grouped = pointutils.grouping_operation(pos2.contiguous(), idx)           # [B,3,N,S]
         pos_diff = pos2_grouped - pos1.view(B, -1, N, 1)
         feat2_grouped = pointutils.grouping_operation(feature2.contiguous(), idx)
@@ -124,10 +147,12 @@ class PointNetSetUpConv(nn.Module):
             _, idx = pointutils.knn(self.nsample, pos1_t, pos2_t)
         else:
             idx = query_ball_point(self.radius, self.nsample, pos2_t, pos1_t)
-        pos2_grouped = pointutils.grouping_operation(pos2.contiguous(), idx)
-        pos_diff = pos2_grouped - pos1.view(B, -1, N, 1)
-        feat2_grouped = pointutils.grouping_operation(feature2.contiguous(), idx)
-        feat_new = torch.cat([feat2_grouped, pos_diff], dim=1)
+        feat_new = _grouped_input(pos2_t, pos1_t, feature2, None, idx, 1, self)
+        if feat_new is None:
+            pos2_grouped = pointutils.grouping_operation(pos2.contiguous(), idx)
+            pos_diff = pos2_grouped - pos1.view(B, -1, N, 1)
+            feat2_grouped = pointutils.grouping_operation(feature2.contiguous(), idx)
+            feat_new = torch.cat([feat2_grouped, pos_diff], dim=1)
         feat_new = _mlp_stack(feat_new, [s[0] for s in self.mlp1_convs], [s[1] for s in self.mlp1_convs], self, pool=True)
         if feature1 is not None:
             feat_new = torch.cat([feat_new, feature1], dim=1)

@@ -879,6 +879,27 @@ def test_flownet3d_set_abstraction_vs_oracle():
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
 
 
+def test_group_concat2_matches_composition():
+    """l3d_group_concat2 == grouping_operation x2 + broadcast subtraction + repeat + torch.cat (flownet3d.py:125-180,
+    :182-242), both channel orders, with and without the broadcast centre features."""
+    from learning3d_amd.utils import pointnet2_utils as P
+    from learning3d_amd._lib import lib, check, ptr, stream_ptr
+    rng = np.random.default_rng(66)
+    B, N, S, K, C, C1 = 2, 300, 77, 9, 13, 5
+    xyz = dev(rng.standard_normal((B, N, 3)).astype(np.float32)); new = dev(rng.standard_normal((B, S, 3)).astype(np.float32))
+    feat = dev(rng.standard_normal((B, C, N)).astype(np.float32)); cen = dev(rng.standard_normal((B, C1, S)).astype(np.float32))
+    idx = dev(rng.integers(0, N, (B, S, K)).astype(np.int32))
+    pos_diff = P.grouping_operation(xyz.transpose(1, 2).contiguous(), idx) - new.transpose(1, 2).reshape(B, 3, S, 1)
+    fg = P.grouping_operation(feat, idx)
+    cb = cen.view(B, C1, S, 1).repeat(1, 1, 1, K)
+    for order, c1, want in [(0, C1, torch.cat([pos_diff, fg, cb], 1)), (1, 0, torch.cat([fg, pos_diff], 1)),
+                            (1, C1, torch.cat([fg, pos_diff, cb], 1))]:
+        out = torch.empty((B, 3 + C + c1, S, K), device="cuda")
+        check(lib().l3d_group_concat2(ptr(xyz), ptr(new), ptr(feat), ptr(cen) if c1 else None, ptr(idx), B, N, S, K, C, c1,
+                                      order, ptr(out), stream_ptr()), "l3d_group_concat2")
+        assert torch.equal(out, want)
+
+
 def test_flownet3d_forward_runs():
     from learning3d_amd.models import FlowNet3D
     torch.manual_seed(0)
