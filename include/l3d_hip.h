@@ -160,6 +160,10 @@ int l3d_three_nn(int b, int n, int m, const float *unknown, const float *known, 
 /* three_interpolate_wrapper(b,c,m,n,points,idx,weight,out)   K15 interpolate_gpu.cu:149-169 */
 int l3d_three_interpolate(int b, int c, int m, int n, const float *points, const int32_t *idx,
                           const float *weight, float *out, l3d_stream_t stream);
+/* three_interpolate followed by torch.cat([interpolated, skip], dim=1) (models/flownet3d.py:268-272):
+ * out fp32 [B, c + c1, n] = [interpolated (c) | skip (c1)]; skip fp32 [B, c1, n] (NULL when c1 == 0). */
+int l3d_three_interpolate_concat(int b, int c, int m, int n, const float *points, const int32_t *idx,
+                                 const float *weight, const float *skip, int c1, float *out, l3d_stream_t stream);
 /* three_interpolate_grad_wrapper(b,c,n,m,grad_out,idx,weight,grad_points)   K16 :192-214 */
 int l3d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
                                const int32_t *idx, const float *weight, float *grad_points,

@@ -43,6 +43,7 @@ SIGNATURES = {
     "l3d_knn": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "l3d_three_nn": [_I, _I, _I, _P, _P, _P, _P, _P],
     "l3d_three_interpolate": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "l3d_three_interpolate_concat": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
     "l3d_three_interpolate_grad": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "l3d_square_distance": [_P, _P, _I, _I, _I, _P, _P],
     "l3d_query_ball_point": [_F, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P],

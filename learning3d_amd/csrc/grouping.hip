@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, in
                                                                 const float *__restrict__ points,
                                                                 const int32_t *__restrict__ idx,
                                                                 const float *__restrict__ weight,
-                                                                float *__restrict__ out)
+                                                                float *__restrict__ out, long out_bstride)
 {
     const int b = blockIdx.z;
     const int pt = blockIdx.x * blockDim.x + threadIdx.x;
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, in
     const float w0 = w[0], w1 = w[1], w2 = w[2];
     for (int cc = c0; cc < c1; cc++) {
         const float *p = points + ((size_t)b * c + cc) * m;
-        out[((size_t)b * c + cc) * n + pt] = (w0 * p[i0] + w1 * p[i1]) + w2 * p[i2];
+        out[(size_t)b * out_bstride + (size_t)cc * n + pt] = (w0 * p[i0] + w1 * p[i1]) + w2 * p[i2];
     }
 }
 
@@ -668,7 +668,27 @@ extern "C" int l3d_three_interpolate(int b, int c, int m, int n, const float *po
 {
     L3D_REQUIRE(points && idx && weight && out && b > 0 && c > 0 && m > 0 && n > 0);
     hipLaunchKernelGGL(three_interpolate_kernel, dim3(l3d_divup(n, 256), l3d_divup(c, GP_CCHUNK), b),
-                       dim3(256), 0, (hipStream_t)stream, c, m, n, points, idx, weight, out);
+                       dim3(256), 0, (hipStream_t)stream, c, m, n, points, idx, weight, out, (long)c * n);
+    return l3d_check_launch();
+}
+
+// three_interpolate followed by torch.cat([interpolated, skip], dim=1) (PointNetFeaturePropogation,
+// models/flownet3d.py:268-272): the interpolation writes its channels of the [B, c + c1, n] result directly,
+// the skip features are one strided device copy.
+extern "C" int l3d_three_interpolate_concat(int b, int c, int m, int n, const float *points, const int32_t *idx,
+                                            const float *weight, const float *skip, int c1, float *out,
+                                            l3d_stream_t stream)
+{
+    L3D_REQUIRE(points && idx && weight && out && b > 0 && c > 0 && m > 0 && n > 0 && c1 >= 0 && (c1 == 0 || skip));
+    hipStream_t st = (hipStream_t)stream;
+    const long bs = (long)(c + c1) * n;
+    hipLaunchKernelGGL(three_interpolate_kernel, dim3(l3d_divup(n, 256), l3d_divup(c, GP_CCHUNK), b), dim3(256), 0, st, c,
+                       m, n, points, idx, weight, out, bs);
+    if (c1 > 0) {
+        hipError_t e = hipMemcpy2DAsync(out + (size_t)c * n, (size_t)bs * 4, skip, (size_t)c1 * n * 4, (size_t)c1 * n * 4, b,
+                                        hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) { g_l3d_last_hip_error = (int)e; return L3D_ERR_LAUNCH; }
+    }
     return l3d_check_launch();
 }
 

@@ -182,8 +182,17 @@ class PointNetFeaturePropogation(nn.Module):
         weight = weight / torch.sum(weight, -1, keepdim=True)
         # reference :268: sum(grouping_operation(feature2, idx) * weight, -1) -- the same three-term weighted
         # sum as pointnet2's three_interpolate, which is one fused kernel (no [B,C,N,3] temporary)
-        interpolated_feat = pointutils.three_interpolate(feature2.contiguous(), idx, weight.contiguous())
-        feat_new = torch.cat([interpolated_feat, feature1], 1) if feature1 is not None else interpolated_feat
+        if _fused.can_fuse(self, feature2, weight) and feature2.is_cuda and (feature1 is None or _fused.can_fuse(self, feature1)):
+            from .._lib import check, lib, ptr, stream_ptr
+            f2 = feature2.float().contiguous()
+            f1 = feature1.float().contiguous() if feature1 is not None else None
+            c, c1, m = f2.shape[1], (f1.shape[1] if f1 is not None else 0), f2.shape[2]
+            feat_new = torch.empty((B, c + c1, N), dtype=torch.float32, device=f2.device)
+            check(lib().l3d_three_interpolate_concat(B, c, m, N, ptr(f2), ptr(idx.contiguous()), ptr(weight.contiguous()),
+                                                     ptr(f1), c1, ptr(feat_new), stream_ptr()), "l3d_three_interpolate_concat")
+        else:
+            interpolated_feat = pointutils.three_interpolate(feature2.contiguous(), idx, weight.contiguous())
+            feat_new = torch.cat([interpolated_feat, feature1], 1) if feature1 is not None else interpolated_feat
         return _mlp_stack(feat_new, self.mlp_convs, self.mlp_bns, self)
 
 
