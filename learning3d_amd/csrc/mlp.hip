@@ -371,6 +371,11 @@ __global__ __launch_bounds__(256, 2) void pointwise_conv_kernel(
             const float4 v0 = *(const float4 *)(src + pos), v1 = *(const float4 *)(src + pos + 4);
             r[0] = v0.x; r[1] = v0.y; r[2] = v0.z; r[3] = v0.w;
             r[4] = v1.x; r[5] = v1.y; r[6] = v1.z; r[7] = v1.w;
+        } else if (row_ok && pos + 8 <= limit) {
+            // in range but not 16-byte addressable (row length not a multiple of 4, e.g. Cin = 259): eight plain
+            // loads, no per-element exec-mask branch -- only the last chunk of a row takes the guarded path below
+#pragma unroll
+            for (int e = 0; e < 8; e++) r[e] = src[pos + e];
         } else {
 #pragma unroll
             for (int e = 0; e < 8; e++) r[e] = (row_ok && pos + e < limit) ? src[pos + e] : 0.f;
