@@ -182,3 +182,21 @@ __device__ __forceinline__ float l3d_act(float v, int act)
     return act == 1 ? fmaxf(v, 0.f) : fmaxf(v, v * __int_as_float(act));
 }
 #endif
+
+// max over aligned groups of `span` (2..32, power of two) consecutive lanes, every lane of a group receiving it.
+// The first four levels are DPP modifiers on the VALU (quad_perm, row_half_mirror, row_mirror: no LDS crossbar, no
+// wait) -- the pooled conv epilogues ran 4-5 ds_bpermute round trips per accumulator value before and spent more
+// time there than in writing the un-pooled tensor; only the 16 <-> 16 exchange of span = 32 still goes through
+// ds_bpermute.
+#ifdef __HIPCC__
+#define L3D_DPP_FMAX(v, CTRL) fmaxf((v), __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (v)), __builtin_bit_cast(int, (v)), (CTRL), 0xF, 0xF, false)))
+__device__ __forceinline__ float l3d_group_max(float v, int span)
+{
+    if (span >= 2) v = L3D_DPP_FMAX(v, 0xB1);        // quad_perm(1,0,3,2)
+    if (span >= 4) v = L3D_DPP_FMAX(v, 0x4E);        // quad_perm(2,3,0,1)
+    if (span >= 8) v = L3D_DPP_FMAX(v, 0x141);       // row_half_mirror
+    if (span >= 16) v = L3D_DPP_FMAX(v, 0x140);      // row_mirror
+    if (span >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return v;
+}
+#endif

@@ -297,12 +297,8 @@ __global__ __launch_bounds__(512) void conv_split_kernel(const void *__restrict_
                 float v0 = acc[a][0][r] * sc + sh, v1 = acc[a][1][r] * sc + sh;
                 if (relu) { v0 = l3d_act(v0, relu); v1 = l3d_act(v1, relu); }
                 if (pool == 64) v0 = fmaxf(v0, v1);
-#pragma unroll
-                for (int m = 1; m < 32; m <<= 1)
-                    if (m < span) {
-                        v0 = fmaxf(v0, __shfl_xor(v0, m, 64));
-                        v1 = fmaxf(v1, __shfl_xor(v1, m, 64));
-                    }
+                v0 = l3d_group_max(v0, span);
+                v1 = l3d_group_max(v1, span);
                 if (((lane & 31) & (span - 1)) == 0) {
                     const int nb = n0 + wn * 64 + (lane & 31);
                     yp[(size_t)co * Np + nb / pool] = v0;

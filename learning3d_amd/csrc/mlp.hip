@@ -481,12 +481,8 @@ __global__ __launch_bounds__(256, 2) void pointwise_conv_kernel(
                 }
                 if (pool == 64) v[0] = fmaxf(v[0], v[1]);
                 const int span = pool < 32 ? pool : 32;             // lanes to reduce over (xor masks stay inside the 32-lane half)
-#pragma unroll
-                for (int m = 1; m < 32; m <<= 1)
-                    if (m < span) {
-                        v[0] = fmaxf(v[0], __shfl_xor(v[0], m, 64));
-                        v[1] = fmaxf(v[1], __shfl_xor(v[1], m, 64));
-                    }
+                v[0] = l3d_group_max(v[0], span);
+                v[1] = l3d_group_max(v[1], span);
                 if (co_ok && (l31 & (span - 1)) == 0) {
                     const int nb = n0 + wn * 64 + l31;
                     if (pool == 64) {
@@ -632,7 +628,8 @@ __global__ __launch_bounds__(256) void pointwise_conv_stream_kernel(
                 float v = acc[c2][h] * (scale ? scale[c] : 1.f) + (shift ? shift[(size_t)b * shift_bstride + c] : 0.f);
                 if (relu) v = l3d_act(v, relu);
                 if (POOL) {
-                    for (int d = 1; d < pool; d <<= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+                    v = l3d_group_max(v, pool < 32 ? pool : 32);
+                    if (pool == 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
                     if (n < N && (tid & (pool - 1)) == 0) y[((size_t)b * Cout + c) * np + n / pool] = v;
                 } else if (n < N) {
                     y[((size_t)b * Cout + c) * N + n] = v;
