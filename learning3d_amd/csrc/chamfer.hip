@@ -413,20 +413,24 @@ __global__ __launch_bounds__(1024) void chamfer_loss_local_kernel(const float *_
 {
     __shared__ double part[2][16];
     double tot[2];
-#pragma unroll
-    for (int which = 0; which < 2; which++) {
-        const float *d = which == 0 ? d1 : d2;
-        const size_t n = which == 0 ? n1 : n2;
-        double acc = 0.0;
-        const size_t n4 = n >> 2;
-        for (size_t i = threadIdx.x; i < n4; i += blockDim.x) {
-            const float4 v = ((const float4 *)d)[i];
-            acc += ((double)sqrtf(v.x) + (double)sqrtf(v.y)) + ((double)sqrtf(v.z) + (double)sqrtf(v.w));
+    // both directions in ONE loop (their loads overlap; each keeps sqrt_sum_kernel's per-thread order, so the
+    // partial sums are the same bits)
+    double acc1 = 0.0, acc2 = 0.0;
+    const size_t a4 = n1 >> 2, b4 = n2 >> 2, m4 = a4 > b4 ? a4 : b4;
+    for (size_t i = threadIdx.x; i < m4; i += blockDim.x) {
+        if (i < a4) {
+            const float4 v = ((const float4 *)d1)[i];
+            acc1 += ((double)sqrtf(v.x) + (double)sqrtf(v.y)) + ((double)sqrtf(v.z) + (double)sqrtf(v.w));
         }
-        for (size_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) acc += (double)sqrtf(d[i]);
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-        if ((threadIdx.x & 63) == 0) part[which][threadIdx.x >> 6] = acc;
+        if (i < b4) {
+            const float4 v = ((const float4 *)d2)[i];
+            acc2 += ((double)sqrtf(v.x) + (double)sqrtf(v.y)) + ((double)sqrtf(v.z) + (double)sqrtf(v.w));
+        }
     }
+    for (size_t i = (a4 << 2) + threadIdx.x; i < n1; i += blockDim.x) acc1 += (double)sqrtf(d1[i]);
+    for (size_t i = (b4 << 2) + threadIdx.x; i < n2; i += blockDim.x) acc2 += (double)sqrtf(d2[i]);
+    for (int off = 32; off > 0; off >>= 1) { acc1 += __shfl_down(acc1, off, 64); acc2 += __shfl_down(acc2, off, 64); }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = acc1; part[1][threadIdx.x >> 6] = acc2; }
     __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll
