@@ -356,3 +356,43 @@ def dgcnn_forward_torch(x_bn3, weights, k=20, eps=1e-5):
         outs.append(h.max(dim=-1, keepdim=True)[0])
     h = block(torch.cat(outs, dim=1), 5)
     return h.view(B, -1, N)
+
+
+def knn_feature(x_bcn, k):
+    """utils/model_common_utils.py:3-9 for a feature map x [B,C,N] (any C): the reference's own op sequence in
+    torch CPU fp32 (matmul -> MKL sgemm, topk) -- what models/prnet.py:76-97 calls per layer."""
+    import torch
+    x = torch.as_tensor(np.asarray(x_bcn, dtype=np.float32))
+    inner = -2 * torch.matmul(x.transpose(2, 1), x)
+    xx = torch.sum(x ** 2, dim=1, keepdim=True)
+    pd = -xx - inner - xx.transpose(2, 1)
+    return pd.topk(k=k, dim=-1)[1]
+
+
+def prnet_dgcnn_forward_torch(x_b3n, weights, k=20, eps=1e-5, slope=0.2):
+    """models/prnet.py:62-97 (class DGCNN) in eval mode, restated with plain torch CPU ops: every layer rebuilds
+    the k-NN graph in the feature space of the previous layer's output (get_graph_feature on x, x1, x2, x3)."""
+    import torch
+    import torch.nn.functional as F
+    x = torch.as_tensor(np.asarray(x_b3n, dtype=np.float32))
+    B, _, N = x.shape
+
+    def graph_feature(h):                                              # model_common_utils.py:132-156
+        C = h.shape[1]
+        idx = knn_feature(h.numpy(), k)                                # [B,N,k]
+        ht = h.transpose(2, 1)                                         # [B,N,C]
+        nb = torch.gather(ht.unsqueeze(1).expand(B, N, N, C), 2, idx.unsqueeze(-1).expand(B, N, k, C))
+        return torch.cat([nb, ht.unsqueeze(2).expand(B, N, k, C)], dim=3).permute(0, 3, 1, 2)
+
+    def block(h, i):
+        h = F.conv2d(h, torch.as_tensor(weights[f"conv{i}.weight"]))
+        h = F.batch_norm(h, torch.as_tensor(weights[f"bn{i}.running_mean"]), torch.as_tensor(weights[f"bn{i}.running_var"]),
+                         torch.as_tensor(weights[f"bn{i}.weight"]), torch.as_tensor(weights[f"bn{i}.bias"]), False, 0.0, eps)
+        return F.leaky_relu(h, negative_slope=slope)
+
+    outs, h = [], x
+    for i in (1, 2, 3, 4):
+        h = block(graph_feature(h), i).max(dim=-1, keepdim=True)[0]    # [B,Co,N,1]
+        outs.append(h)
+        h = h.view(B, -1, N)
+    return block(torch.cat(outs, dim=1), 5).view(B, -1, N)

@@ -570,6 +570,11 @@ def test_knn_feature_space_matches_exact_topk():
         assert np.all(idx[:, :, 0] == np.arange(N)[None])                          # self first
         srt = np.sort(idx, axis=-1)
         assert np.all(srt[:, :, 1:] != srt[:, :, :-1])                             # no repeats
+    # against the reference's own op sequence (oracle.knn_feature: MKL sgemm + topk in fp32 on the CPU): identical
+    # indices except where two candidates sit within fp32 rounding of each other
+    x = np.random.default_rng(69).standard_normal((2, 64, 1024)).astype(np.float32)
+    mine, ref = knn(dev(x), 20).cpu().numpy(), oracle.knn_feature(x, 20).numpy()
+    assert (mine == ref).mean() > 0.999, (mine == ref).mean()
     # exact ties (every point duplicated N/2 later): equal fp32 scores -> lower index first, as l3d_knn_graph
     rng = np.random.default_rng(68)
     half = rng.standard_normal((1, 64, 128)).astype(np.float32)

@@ -102,6 +102,15 @@ def test_dgcnn_forward(golden):
     np.testing.assert_allclose(out, g["out"], rtol=1e-5, atol=1e-6)
 
 
+def test_prnet_dgcnn_forward(golden):
+    """SURVEY.md 8(f) rank 2's caller: the oracle restatement of models/prnet.py:62-97 against the golden made by
+    running the reference class itself (tests/golden/make_golden.py)."""
+    g = golden("prnet_dgcnn_emb64")
+    w = {k[2:]: v for k, v in g.items() if k.startswith("w.")}
+    out = oracle.prnet_dgcnn_forward_torch(g["x"], w).numpy()
+    np.testing.assert_allclose(out, g["out"], rtol=1e-5, atol=1e-6)
+
+
 def test_svd(golden):
     g = golden("svd3x3")
     R = oracle.rotation_from_H(g["H"])
