@@ -595,9 +595,10 @@ __global__ __launch_bounds__(256) void pointwise_conv_stream_kernel(
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) float wT[];          // [Cin][COUT], zero-padded beyond Cout
     const int b = blockIdx.y, tid = threadIdx.x;
+    const int co_off = blockIdx.z * COUT;                               // Cout > COUT: one pass over x per COUT channels
     for (int e = tid; e < Cin * COUT; e += 256) {
         const int k = e / COUT, c = e - k * COUT;
-        wT[e] = c < Cout ? w[(size_t)c * Cin + k] : 0.f;
+        wT[e] = co_off + c < Cout ? w[(size_t)(co_off + c) * Cin + k] : 0.f;
     }
     __syncthreads();
     const int n = blockIdx.x * 256 + tid;
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(256) void pointwise_conv_stream_kernel(
     for (int c2 = 0; c2 < COUT / 2; c2++) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const int c = 2 * c2 + h;
+            const int c = co_off + 2 * c2 + h;
             if (c < Cout) {                                            // Cout is uniform: no divergence around the shuffles
                 float v = acc[c2][h] * (scale ? scale[c] : 1.f) + (shift ? shift[(size_t)b * shift_bstride + c] : 0.f);
                 if (relu) v = l3d_act(v, relu);
@@ -643,7 +644,7 @@ template <bool POOL>
 static int launch_stream(const float *x, const float *w, const float *scale, const float *shift, int shift_bstride,
                          int B, int Cin, int Cout, int N, int relu, float *y, int pool, hipStream_t st)
 {
-    dim3 grid(l3d_divup(N, 256), B), block(256);
+    dim3 grid(l3d_divup(N, 256), B, l3d_divup(Cout, 32)), block(256);
     hipLaunchKernelGGL((pointwise_conv_stream_kernel<32, POOL>), grid, block, (size_t)Cin * 32 * 4, st, x, w, scale, shift,
                        shift_bstride, Cin, Cout, N, relu, y, pool);
     return l3d_check_launch();
@@ -653,7 +654,9 @@ static int launch_stream(const float *x, const float *w, const float *scale, con
 static bool stream_shape(int x_channel_last, int Cin, int Cout, int N, int pool)
 {
     (void)pool;
-    return !x_channel_last && Cout > 8 && Cout <= 32 && Cin <= 128 && N >= 4096;
+    if (x_channel_last || N < 4096) return false;
+    if (Cout > 8 && Cout <= 32 && Cin <= 128) return true;
+    return Cout <= 64 && Cin <= 32 && N >= 16384;               // two passes of 32 channels still beat the tile kernel here
 }
 
 template <bool POOL>
