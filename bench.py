@@ -4,8 +4,9 @@
     + the kNN kernel's achieved HBM GB/s against peak.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-            --master-port P bench.py --gpus N --steps K --warmup W)
+    (N>1: either under a launcher -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+     127.0.0.1 --master-port P bench.py --gpus N ... -- or plainly as above: with WORLD_SIZE unset and N>1 the script
+     re-launches itself under torch.distributed.run on 127.0.0.1 with a free port, one rank per GPU.)
 
 A "step" is one pass of the hot path over one batch of synthetic clouds already resident in HBM:
 DGCNN(emb_dims=1024).eval() forward on x[32,1024,3] (fused kNN -> fused EdgeConv stack -> conv5 GEMM,
@@ -76,7 +77,18 @@ def edgeconv_roofline(ec_tf, ec_ms, split):
             "bf16_dense_peak": MFMA_BF16_PEAK_TF}
 
 
-def cpu_baseline(sample_clouds=8, repeats=2):
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sample_clouds=B_PER_GPU, repeats=2):
     """The oracle port of the reference's CPU path (torch CPU ops for the conv stack exactly as
     models/dgcnn.py does them, C restatement of knn / nnsearch), timed on this box's host cores."""
     import numpy as np
@@ -110,10 +122,58 @@ def cpu_baseline(sample_clouds=8, repeats=2):
         for _ in range(1 + repeats):              # first iteration is the warm-up
             best = min(best, run(x, a, b))
     return {"value": sample_clouds / best, "unit": "clouds/s", "cores": nthr, "kind": "port",
-            "host_cpus": ncores,
+            "host_cpus": ncores, "cpu_model": cpu_model(),
             "sample": f"{sample_clouds} clouds x N={NPTS} (DGCNN emb={EMB} fwd via torch-CPU ops + C kNN, "
                       f"Chamfer via C nnsearch restatement), min of {1 + repeats} runs, torch threads={nthr} "
                       f"(best of {sorted(tried)} on a 2-cloud probe; host has {ncores} logical CPUs)"}
+
+
+def relaunch_under_torchrun(ngpus):
+    """`python bench.py --gpus N` with no launcher around it: start N ranks of this very command under
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 with a free port) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd)
+
+
+def selftest_cpu(args, parallel, dist):
+    """Control flow only (tests/test_host_cpu.py drives it with --gpus 2): launcher -> init_from_env (gloo) -> rank-specific
+    partial sums -> the same all_gather + combine and the same barrier / max-over-ranks bracketing as the real run.
+    No HIP kernel and no oracle is involved; the JSON says so."""
+    rank, world, local = parallel.init_from_env(backend="gloo")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    part = torch.tensor([10.0 * (rank + 1), 20.0 * (rank + 1), 100.0, 200.0], dtype=torch.float64)
+    pipe = parallel.PipelinedChamferLoss()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss_sync = parallel.allgather_chamfer_loss(part)
+        pipe.submit(part)
+    loss_pipe = pipe.flush()
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    per_rank = [t.clone() for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank, t)
+    if rank == 0:
+        tot = sum(range(1, world + 1))
+        want = (10.0 * tot / (100.0 * world) + 20.0 * tot / (200.0 * world)) / 2.0
+        print(json.dumps({"metric": "SELFTEST (control flow only, not a measurement)", "n_gpus": world, "steps": args.steps,
+                          "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                          "dist_backend": dist.get_backend() if world > 1 else None,
+                          "loss_sync": float(loss_sync), "loss_pipelined": float(loss_pipe), "loss_expected": want,
+                          "per_rank_s": [float(v) for v in per_rank]}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -123,21 +183,29 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-loss", action="store_true",
-                    help="N>1: wait for each step's loss all_gather inside the step instead of one step later")
+                    help="N>1: make the blocking exchange the headline (default: pipelined; both are always reported)")
     ap.add_argument("--fp32-mfma", action="store_true",
                     help="run the shared-MLP GEMMs on the fp32 MFMA (157 TF peak) instead of the bf16x3 kernels")
+    ap.add_argument("--selftest-cpu", action="store_true",
+                    help="control-flow self test on CPU/gloo (launcher, sharding, collective, max-over-ranks, JSON): "
+                         "NO kernels run and the printed line is not a measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(relaunch_under_torchrun(args.gpus))
+
     from learning3d_amd import parallel
+    import torch.distributed as dist
+    if args.selftest_cpu:
+        return selftest_cpu(args, parallel, dist)
     from learning3d_amd.models import DGCNN, _fused
     if args.fp32_mfma:
         _fused.SPLIT_BF16 = False
     from learning3d_amd.losses.chamfer_distance import ChamferDistance, chamfer_partials
-    import torch.distributed as dist
 
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     local = local % torch.cuda.device_count()     # a launcher that narrows visibility leaves one device at index 0
@@ -155,12 +223,12 @@ def main():
 
     loss_pipe = parallel.PipelinedChamferLoss()
 
-    def step():
+    def step(sync_loss):
         with torch.no_grad():
             feat = net(x)                                   # knn -> edgeconv -> conv5
             with _fused.stage("chamfer"):
                 d1, d2 = cd(a, b)
-            if args.sync_loss:
+            if sync_loss:
                 loss = parallel.allgather_chamfer_loss(chamfer_partials(d1, d2))   # blocking RCCL all_gather if N>1
             else:
                 loss = loss_pipe.submit_dists(d1, d2)     # N>1: partial sums + async all_gather (previous step's loss);
@@ -170,36 +238,51 @@ def main():
     # clock / cache pre-conditioning before the W official warm-up steps: the first ~50 ms after an idle
     # period run at ramping clocks (measured: 0.545 ms/step over steps 10-60, 0.506 ms/step in steady state)
     for _ in range(PRECONDITION_STEPS):
-        step()
+        step(args.sync_loss)
     for _ in range(args.warmup):
-        step()
+        step(args.sync_loss)
 
     def sync():
         if world > 1:
             dist.barrier(device_ids=[local])           # RCCL barrier on this rank's own device
         torch.cuda.synchronize()
 
+    def timed(sync_loss, timer=None):
+        """K steps between two (barrier + device sync) brackets; returns (this rank's seconds, last loss)."""
+        stride = max(1, (args.steps + 31) // 32)
+        sync()
+        t0 = time.perf_counter()
+        loss = None
+        for i in range(args.steps):
+            if timer is not None:
+                timer.enabled = (i % stride == 0)
+            _, loss = step(sync_loss)
+        if not sync_loss:
+            last = loss_pipe.flush()                      # the last step's loss, still inside the timed region
+            loss = last if last is not None else loss
+        sync()
+        return time.perf_counter() - t0, loss
+
     # Live HIP-event timing of the dominant kernel inside the timed region, on the stream it is
     # launched on (torch's current stream).  Only <= 32 evenly spaced steps carry events: a few
     # hundred un-synchronised timing events exhaust the runtime's signal pool and stall the host.
-    stride = max(1, (args.steps + 31) // 32)
     timer = _fused.StageTimer(only=("edgeconv",))
     _fused.TIMER = timer
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        timer.enabled = (i % stride == 0)
-        feat, loss = step()
-    if not args.sync_loss:
-        last = loss_pipe.flush()                      # the last step's loss, still inside the timed region
-        loss = last if last is not None else loss
-    sync()
-    elapsed = time.perf_counter() - t0
+    elapsed, loss = timed(args.sync_loss, timer)          # THE timed region: `value` comes from this one
+    _fused.TIMER = None
+    # N>1: the other exchange mode over the same K steps, reported beside the headline (the pipelined mode hides
+    # exactly the collective latency a scaling curve is meant to show; --sync-loss swaps which one is `value`)
+    other = None
+    if world > 1:
+        for _ in range(args.warmup):
+            step(not args.sync_loss)
+        if args.sync_loss:
+            loss_pipe.flush()
+        other, _ = timed(not args.sync_loss)
     stage_ms = timer.mean_ms()
     # untimed diagnostics (reported under "kernels" / "roofline_knn", not part of `value`): the short
     # kernels are timed as 20 back-to-back launches between two events -- a per-launch event pair adds
     # ~15 us of its own to a 25-70 us kernel.
-    _fused.TIMER = None
 
     def per_launch_ms(fn, iters=20):
         fn()
@@ -224,10 +307,17 @@ def main():
                                                                           w_split=w5s_))
         stage_ms.setdefault("edgeconv", per_launch_ms(lambda: _fused.edgeconv_forward(x, idx_, packed_)))
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    # max over ranks (the contract), and every rank's own time for the record
+    t = torch.tensor([elapsed, other if other is not None else 0.0], dtype=torch.float64, device=dev)
+    per_rank = [t.clone() for _ in range(world)]
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        dist.all_gather(per_rank, t)
+    else:
+        per_rank = [t]
+    per_rank = torch.stack(per_rank).cpu()
+    elapsed = float(per_rank[:, 0].max())
+    other = float(per_rank[:, 1].max()) if other is not None else None
+    backend = dist.get_backend() if world > 1 else None
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -252,6 +342,15 @@ def main():
                        "untimed_precondition_steps": PRECONDITION_STEPS,
                        "parallelism": f"batch-sharded x{world}, all_gather of loss partials only"
                                       + ("" if args.sync_loss or world == 1 else " (asynchronous, consumed one step later)")},
+            # multi-GPU record: ranks that really joined the process group, its backend ("nccl" = RCCL on ROCm),
+            # each rank's own wall time for the K steps, and the OTHER loss-exchange mode timed over the same K steps
+            "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "dist_backend": backend,
+            "per_rank_ms_per_step": [float(v) / args.steps * 1e3 for v in per_rank[:, 0]],
+            "loss_exchange": ("blocking all_gather inside the step" if args.sync_loss else
+                              "asynchronous all_gather, consumed one step later") if world > 1 else "none (1 rank)",
+            "other_exchange_mode": None if other is None else {
+                "mode": "asynchronous all_gather, consumed one step later" if args.sync_loss else "blocking all_gather inside the step",
+                "ms_per_step": other / args.steps * 1e3, "value": world * B_PER_GPU * args.steps / other},
             # dominant kernel by time: the fused 4-layer EdgeConv stack
             "roofline": edgeconv_roofline(ec_tf, stage_ms["edgeconv"], split),
             # the metric's second half: kNN (and Chamfer) HBM rate on ALGORITHMIC bytes

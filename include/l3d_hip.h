@@ -102,10 +102,11 @@ int l3d_graph_feature(const float *x, const int64_t *idx, int B, int N, int C, i
  * ------------------------------------------------------------------------------------------- */
 int l3d_chamfer_forward(const float *xyz1, const float *xyz2, int B, int N, int M, float *dist1,
                         float *dist2, int32_t *idx1, int32_t *idx2, l3d_stream_t stream);
-/* Kernel choice of l3d_chamfer_forward (results are bit-identical either way): 0 = one (query, candidate) pair per
- * instruction sequence, 1 = auto (default), 2 = always the packed-fp32 kernel (two queries per lane, argmin per
- * chunk of 8).  A process-wide tuning / test knob, not part of the call contract. */
-extern int l3d_chamfer_forward_mode;
+/* The same with the kernel choice as an ARGUMENT (results are bit-identical either way; tests compare them):
+ * variant 0 = one (query, candidate) pair per instruction sequence, 1 = auto (what l3d_chamfer_forward does),
+ * 2 = always the packed-fp32 kernel (two queries per lane, argmin per chunk of 8). */
+int l3d_chamfer_forward_variant(const float *xyz1, const float *xyz2, int B, int N, int M, float *dist1,
+                                float *dist2, int32_t *idx1, int32_t *idx2, int variant, l3d_stream_t stream);
 int l3d_chamfer_backward(const float *xyz1, const float *xyz2, int B, int N, int M,
                          const float *graddist1, const float *graddist2, const int32_t *idx1,
                          const int32_t *idx2, float *gradxyz1, float *gradxyz2, l3d_stream_t stream);
@@ -175,6 +176,12 @@ int l3d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out
 /* square_distance(src,dst) :19-38 -> dist [B,N,M] (expanded form, reference rounding order) */
 int l3d_square_distance(const float *src, const float *dst, int B, int N, int M, float *dist,
                         l3d_stream_t stream);
+/* the same for C != 3 (the reference body is generic in C); dot product = fma chain over channels in order */
+int l3d_square_distance_c(const float *src, const float *dst, int B, int N, int M, int C, float *dist,
+                          l3d_stream_t stream);
+/* compute_density(xyz, bandwidth) utils/pointconv_util.py:194-203, fused (no [B,N,N] tensor):
+ *   density[b][i] = mean_j exp(-square_distance(xyz,xyz)[i][j] / (2 bw^2)) / (2.5 bw).  xyz [B,N,3] -> density [B,N] */
+int l3d_gaussian_density(const float *xyz, int B, int N, float bandwidth, float *density, l3d_stream_t stream);
 /* query_ball_point(radius,nsample,xyz,new_xyz,get_cnt) :102-130 (also ppfnet_util.py:96-131 with
  *   itself_indices, pointconv_util.py:85-105): first nsample indices with expanded d2 <= r^2 in
  *   index order, padded with the first (or with itself_indices[b][s] when given, in which case
@@ -194,6 +201,12 @@ int l3d_farthest_point_sample(const float *xyz, int B, int N, int npoint, const 
  *   val [B,M,k] = sqrt(d2) ascending, idx [B,M,k] int64. */
 int l3d_knn_point(int k, const float *pos1, const float *pos2, int B, int N, int M, float *val,
                   int64_t *idx, l3d_stream_t stream);
+/* pointconv_util.knn_point(nsample, xyz, new_xyz) utils/pointconv_util.py:107-118: the nsample smallest entries of
+ *   square_distance(new_xyz, xyz) = ((-2 q.c) + |q|^2) + |c|^2 (that fp32 rounding sequence) per query, indices only.
+ *   The reference calls torch.topk(sorted=False) -- row order unspecified; here nearest first, lowest index first
+ *   under exact ties.  xyz [B,N,3] searched, new_xyz [B,S,3] queries -> idx [B,S,nsample] int64. */
+int l3d_knn_point_expanded(int nsample, const float *xyz, const float *new_xyz, int B, int N, int S,
+                           int64_t *idx, l3d_stream_t stream);
 
 /* QueryAndGroup's tail == utils/lib/pointnet2_utils.py:274-292 in one pass: centred neighbour coordinates
  * (if use_xyz) concatenated with the gathered features.  xyz [B,N,3], new_xyz [B,S,3], features [B,C,N]

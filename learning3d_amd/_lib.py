@@ -25,6 +25,7 @@ SIGNATURES = {
     "l3d_knn_feature": [_P, _I, _I, _I, _I, _P, _P, _P],
     "l3d_graph_feature": [_P, _P, _I, _I, _I, _I, _P, _P],
     "l3d_chamfer_forward": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
+    "l3d_chamfer_forward_variant": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     "l3d_chamfer_backward": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "l3d_chamfer_partials": [_P, _P, _I, _I, _I, _P, _P],
     "l3d_chamfer_combine": [_P, _I, _P, _P],
@@ -46,10 +47,13 @@ SIGNATURES = {
     "l3d_three_interpolate_concat": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
     "l3d_three_interpolate_grad": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "l3d_square_distance": [_P, _P, _I, _I, _I, _P, _P],
+    "l3d_square_distance_c": [_P, _P, _I, _I, _I, _I, _P, _P],
+    "l3d_gaussian_density": [_P, _I, _I, _F, _P, _P],
     "l3d_query_ball_point": [_F, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "l3d_index_points": [_P, _P, _I, _I, _I, _I, _P, _P],
     "l3d_farthest_point_sample": [_P, _I, _I, _I, _P, _P, _P, _P],
     "l3d_knn_point": [_I, _P, _P, _I, _I, _I, _P, _P, _P],
+    "l3d_knn_point_expanded": [_I, _P, _P, _I, _I, _I, _P, _P],
     "l3d_kabsch": [_P, _P, _I, _I, _P, _P, _P, _P],
     "l3d_svd3x3_rotation": [_P, _I, _P, _P],
     "l3d_soft_correspondence_workspace_floats": [_I, _I, _I],

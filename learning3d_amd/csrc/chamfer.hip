@@ -119,9 +119,8 @@ __global__ __launch_bounds__(64 * CWAVES) void chamfer_fwd_kernel(const float *_
     }
 }
 
-// kernel choice of l3d_chamfer_forward: 0 = per-candidate kernels only, 1 = auto (default), 2 = packed kernel always
-// (tests and tools flip it to compare the two bit for bit)
-extern "C" { int l3d_chamfer_forward_mode = 1; }
+// kernel choice is an ARGUMENT of l3d_chamfer_forward_variant (0 = per-candidate kernels only, 1 = auto, 2 = packed
+// kernel always); there is no process-wide state.  l3d_chamfer_forward == variant 1.
 
 // ---------------------------------------------------------------------------------------------
 // Packed variant: two queries per lane evaluated with ONE packed-fp32 instruction each step (v_pk_add_f32 /
@@ -241,11 +240,12 @@ __global__ __launch_bounds__(64 * CWAVES) void chamfer_fwd_packed_kernel(const f
     }
 }
 
-extern "C" int l3d_chamfer_forward(const float *xyz1, const float *xyz2, int B, int N, int M,
-                                   float *dist1, float *dist2, int32_t *idx1, int32_t *idx2,
-                                   l3d_stream_t stream)
+extern "C" int l3d_chamfer_forward_variant(const float *xyz1, const float *xyz2, int B, int N, int M,
+                                           float *dist1, float *dist2, int32_t *idx1, int32_t *idx2,
+                                           int variant, l3d_stream_t stream)
 {
-    L3D_REQUIRE(xyz1 && xyz2 && dist1 && dist2 && idx1 && idx2 && B > 0 && N > 0 && M > 0);
+    L3D_REQUIRE(xyz1 && xyz2 && dist1 && dist2 && idx1 && idx2 && B > 0 && N > 0 && M > 0 && variant >= 0 && variant <= 2);
+    const int l3d_chamfer_forward_mode = variant;
     const int mx = N > M ? N : M;
     // two queries per lane, packed fp32 (chamfer_fwd_packed_kernel) once that still gives every SIMD a wave;
     // tiny problems keep one query per lane for the workgroup count
@@ -264,6 +264,13 @@ extern "C" int l3d_chamfer_forward(const float *xyz1, const float *xyz2, int B, 
                            xyz2, N, M, dist1, dist2, idx1, idx2);
     }
     return l3d_check_launch();
+}
+
+extern "C" int l3d_chamfer_forward(const float *xyz1, const float *xyz2, int B, int N, int M,
+                                   float *dist1, float *dist2, int32_t *idx1, int32_t *idx2,
+                                   l3d_stream_t stream)
+{
+    return l3d_chamfer_forward_variant(xyz1, xyz2, B, N, M, dist1, dist2, idx1, idx2, 1, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

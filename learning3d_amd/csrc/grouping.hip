@@ -327,6 +327,80 @@ extern "C" int l3d_square_distance(const float *src, const float *dst, int B, in
     return l3d_check_launch();
 }
 
+// square_distance for C != 3 (the reference body is generic in C, model_common_utils.py:34-37): the dot product is an
+// fma chain over the channels in ascending order (MKL's blocking for K > 3 is not restated: ~1 ulp of the dot).
+__global__ __launch_bounds__(256) void square_distance_c_kernel(const float *__restrict__ src,
+                                                                const float *__restrict__ dst, int N, int M, int C,
+                                                                float *__restrict__ out)
+{
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    const float *s = src + ((size_t)b * N + i) * C;
+    const float *d = dst + ((size_t)b * M + j) * C;
+    float dot = 0.f, ss = 0.f, dd = 0.f;
+    for (int c = 0; c < C; c++) {
+        const float a = s[c], e = d[c];
+        dot = c == 0 ? a * e : fmaf(a, e, dot);
+        ss = c == 0 ? a * a : ss + a * a;
+        dd = c == 0 ? e * e : dd + e * e;
+    }
+    out[((size_t)b * N + i) * M + j] = (-2.0f * dot + ss) + dd;
+}
+
+extern "C" int l3d_square_distance_c(const float *src, const float *dst, int B, int N, int M, int C,
+                                     float *dist, l3d_stream_t stream)
+{
+    L3D_REQUIRE(src && dst && dist && B > 0 && N > 0 && M > 0 && C > 0 && N <= 65535 && B <= 65535);
+    hipLaunchKernelGGL(square_distance_c_kernel, dim3(l3d_divup(M, 256), N, B), dim3(256), 0,
+                       (hipStream_t)stream, src, dst, N, M, C, dist);
+    return l3d_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// compute_density (utils/pointconv_util.py:194-203), fused: density[b][i] = mean_j exp(-d2_ij / (2 bw^2)) / (2.5 bw)
+// with d2 = square_distance(xyz, xyz) in the reference's expanded rounding order.  One query per thread, the cloud
+// streamed through LDS as (x, y, z, |p|^2); the [B,N,N] matrix of the reference never exists.  VALU/transcendental
+// bound: N^2 exps per cloud.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gaussian_density_kernel(const float *__restrict__ xyz, int N, float two_bw2,
+                                                               float norm, float *__restrict__ out)
+{
+    __shared__ float4 tile[1024];
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const float *base = xyz + (size_t)b * N * 3;
+    const int ic = min(i, N - 1);
+    const float qx = base[ic * 3], qy = base[ic * 3 + 1], qz = base[ic * 3 + 2];
+    const float qq = (qx * qx + qy * qy) + qz * qz;
+    float acc = 0.f;
+    for (int j0 = 0; j0 < N; j0 += 1024) {
+        const int tn = min(1024, N - j0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < tn; t += 256) {
+            const float x = base[(j0 + t) * 3], y = base[(j0 + t) * 3 + 1], z = base[(j0 + t) * 3 + 2];
+            tile[t] = make_float4(x, y, z, (x * x + y * y) + z * z);
+        }
+        __syncthreads();
+        for (int t = 0; t < tn; t++) {
+            const float4 c = tile[t];
+            const float dot = fmaf(qz, c.z, fmaf(qy, c.y, qx * c.x));
+            const float d2 = (-2.0f * dot + qq) + c.w;
+            acc += expf(-d2 / two_bw2) / norm;
+        }
+    }
+    if (i < N) out[(size_t)b * N + i] = acc / (float)N;
+}
+
+extern "C" int l3d_gaussian_density(const float *xyz, int B, int N, float bandwidth, float *density, l3d_stream_t stream)
+{
+    L3D_REQUIRE(xyz && density && B > 0 && N > 0 && bandwidth > 0.f && B <= 65535);
+    // the reference divides by the Python doubles 2.0*bw*bw and 2.5*bw, which torch converts to fp32 scalars
+    const float two_bw2 = (float)(2.0 * (double)bandwidth * (double)bandwidth), norm = (float)(2.5 * (double)bandwidth);
+    hipLaunchKernelGGL(gaussian_density_kernel, dim3(l3d_divup(N, 256), B), dim3(256), 0, (hipStream_t)stream, xyz, N,
+                       two_bw2, norm, density);
+    return l3d_check_launch();
+}
+
 // ---------------------------------------------------------------------------------------------
 // Grouping / gather (pure data movement: the HBM-bound ops of the path)
 // group : out[b][c][s][k] = points[b][c][idx[b][s][k]]     thread per (s,k), loop over a channel

@@ -25,7 +25,9 @@
 #define QCAP 16     // per-lane queue depth (8 KiB per wave)
 #define CHUNK 8     // candidates scanned between queue-occupancy checks
 
-enum { METRIC_EXPANDED = 0, METRIC_DIRECT = 1 };
+// METRIC_EXPANDED_SQ: pointconv_util.knn_point (utils/pointconv_util.py:107-118) ranks square_distance()'s
+// expanded form, dist = ((-2 * dot) + |q|^2) + |c|^2 with that rounding sequence, smallest first.
+enum { METRIC_EXPANDED = 0, METRIC_DIRECT = 1, METRIC_EXPANDED_SQ = 2 };
 enum { OUT_KNN_GRAPH = 0, OUT_KNN_PAIR = 1, OUT_KNN_POINT = 2 };
 
 template <int K, int METRIC>
@@ -71,6 +73,10 @@ __global__ __launch_bounds__(64) void topk_scan_kernel(
             const float dot = fmaf(qz, c.z, fmaf(qy, c.y, qx * c.x));
             const float tt = fmaf(2.0f, dot, c.w);      // == rn(-xx_j + 2*dot): 2*dot is exact
             return tt - qxx;
+        } else if (METRIC == METRIC_EXPANDED_SQ) {
+            const float dot = fmaf(qz, c.z, fmaf(qy, c.y, qx * c.x));
+            const float tt = fmaf(-2.0f, dot, qxx);     // == rn(-2*dot + |q|^2)
+            return -(tt + c.w);                         // c.w = +|c|^2; negated so that larger = nearer
         } else {
             const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
             return -((dx * dx + dy * dy) + dz * dz);
@@ -85,6 +91,7 @@ __global__ __launch_bounds__(64) void topk_scan_kernel(
             float x = cp[0], y = cp[1], z = cp[2];
             float w = 0.f;
             if (METRIC == METRIC_EXPANDED) w = -((x * x + y * y) + z * z);   // -xx[j]
+            if (METRIC == METRIC_EXPANDED_SQ) w = (x * x + y * y) + z * z;
             cand[t] = make_float4(x, y, z, w);
         }
         __syncthreads();
@@ -186,10 +193,14 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
     const float qxx = (qx * qx + qy * qy) + qz * qz;
     const float *cbase = cxyz + (size_t)b * Nc * 3;
 
+    auto sentinel = []() -> float4 {                         // a candidate whose key is -inf for every query
+        return METRIC == METRIC_EXPANDED      ? make_float4(0.f, 0.f, 0.f, -INFINITY)
+               : METRIC == METRIC_EXPANDED_SQ ? make_float4(0.f, 0.f, 0.f, INFINITY)
+                                              : make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
+    };
     sthr[wave * 64 + lane] = -INFINITY;                      // visible to the other waves after stage()'s first barrier
     if (lane == 0)
-        cand[wave][T2] = METRIC == METRIC_EXPANDED ? make_float4(0.f, 0.f, 0.f, -INFINITY)
-                                                   : make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
+        cand[wave][T2] = sentinel();
 
     float *akey = scratch[wave];                       // [K][64]
     int *aidx = (int *)scratch[wave] + K * 64;         // [K][64]
@@ -204,6 +215,10 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
             const float dot = fmaf(qz, c.z, fmaf(qy, c.y, qx * c.x));
             const float tt = fmaf(2.0f, dot, c.w);
             return tt - qxx;
+        } else if (METRIC == METRIC_EXPANDED_SQ) {
+            const float dot = fmaf(qz, c.z, fmaf(qy, c.y, qx * c.x));
+            const float tt = fmaf(-2.0f, dot, qxx);
+            return -(tt + c.w);
         } else {
             const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
             return -((dx * dx + dy * dy) + dz * dz);
@@ -217,10 +232,10 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
             if (t < tn) {
                 const float *cp = cbase + (size_t)(c0 + t) * 3;
                 const float x = cp[0], y = cp[1], z = cp[2];
-                v = make_float4(x, y, z, METRIC == METRIC_EXPANDED ? -((x * x + y * y) + z * z) : 0.f);
+                const float cc = (x * x + y * y) + z * z;
+                v = make_float4(x, y, z, METRIC == METRIC_EXPANDED ? -cc : METRIC == METRIC_EXPANDED_SQ ? cc : 0.f);
             } else {
-                v = METRIC == METRIC_EXPANDED ? make_float4(0.f, 0.f, 0.f, -INFINITY)
-                                              : make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.f);
+                v = sentinel();
             }
             cand[wave][t] = v;
         }
@@ -492,6 +507,18 @@ extern "C" int l3d_knn(int b, int n, int m, int k, const float *unknown, const f
                 k <= L3D_KNN_MAX_K);
     return launch_topk<METRIC_DIRECT>(unknown, known, b, n, m, k, OUT_KNN_PAIR, idx, dist2,
                                       (hipStream_t)stream);
+}
+
+// pointconv_util.knn_point (utils/pointconv_util.py:107-118): nsample smallest square_distance(new_xyz, xyz)
+// entries per query, indices only.  The reference asks torch.topk for sorted=False (order unspecified); the
+// rows here come out nearest first, lowest index first under exact ties.
+extern "C" int l3d_knn_point_expanded(int nsample, const float *xyz, const float *new_xyz, int B, int N, int S,
+                                      int64_t *idx, l3d_stream_t stream)
+{
+    L3D_REQUIRE(xyz && new_xyz && idx && B > 0 && N > 0 && S > 0 && nsample > 0 && nsample <= N &&
+                nsample <= L3D_KNN_MAX_K);
+    return launch_topk<METRIC_EXPANDED_SQ>(new_xyz, xyz, B, S, N, nsample, OUT_KNN_GRAPH, idx, nullptr,
+                                           (hipStream_t)stream);
 }
 
 extern "C" int l3d_three_nn(int b, int n, int m, const float *unknown, const float *known,

@@ -11,4 +11,5 @@ from .model_common_utils import (
     query_ball_point,
 )
 from .ppfnet_util import angle_difference, pc_normalize, sample_and_group, sample_and_group_multi
-from . import pointnet2_utils
+from .pointconv_util import PointConvDensitySetAbstraction
+from . import pointconv_util, pointnet2_utils

@@ -56,11 +56,14 @@ def square_distance(src, dst):
     require_gpu(src, dst)
     B, N, Cc = src.shape
     M = dst.shape[1]
-    if Cc != 3 or dst.shape[2] != 3:
-        raise NotImplementedError("square_distance: C=3 only on the accelerated path")
+    if dst.shape[2] != Cc:
+        raise RuntimeError(f"square_distance: channel mismatch {Cc} vs {dst.shape[2]}")
     s, d = f32c(src), f32c(dst)
     out = torch.empty((B, N, M), dtype=torch.float32, device=src.device)
-    check(lib().l3d_square_distance(ptr(s), ptr(d), B, N, M, ptr(out), stream_ptr()), "l3d_square_distance")
+    if Cc == 3:
+        check(lib().l3d_square_distance(ptr(s), ptr(d), B, N, M, ptr(out), stream_ptr()), "l3d_square_distance")
+    else:                                                   # the reference body is generic in C
+        check(lib().l3d_square_distance_c(ptr(s), ptr(d), B, N, M, Cc, ptr(out), stream_ptr()), "l3d_square_distance_c")
     return out
 
 

@@ -147,6 +147,14 @@ def knn_point(k, pos1, pos2):
     return val, idx
 
 
+def knn_point_expanded(nsample, xyz, new_xyz):
+    """utils/pointconv_util.py:107-118: the nsample smallest entries of square_distance(new_xyz, xyz) per query.
+    torch.topk(sorted=False) leaves the row order open; rows are returned nearest first, lowest index first
+    under exact ties (stable argsort), which is also what the HIP kernel emits."""
+    d = square_distance(new_xyz, xyz)                       # the reference's expanded fp32 rounding sequence
+    return np.argsort(d, axis=-1, kind="stable")[..., :nsample].astype(np.int64)
+
+
 # --------------------------------------------------------------------------- a9
 def chamfer_forward(xyz1, xyz2):
     a, b = _f(xyz1), _f(xyz2)
@@ -396,3 +404,60 @@ def prnet_dgcnn_forward_torch(x_b3n, weights, k=20, eps=1e-5, slope=0.2):
         outs.append(h)
         h = h.view(B, -1, N)
     return block(torch.cat(outs, dim=1), 5).view(B, -1, N)
+
+
+# ----------------------------------------------------------------- a8: PCN, PointNet classifier (config 1)
+def _t(a):
+    import torch
+    return torch.as_tensor(np.asarray(a))
+
+
+def pcn_forward_torch(x_bn3, w, num_coarse, grid_size):
+    """models/pcn.py:104-153 (encode :104-119, decode :121-126, fine_decoder :84-102) in eval mode, restated with
+    plain torch CPU functionals.  `w`: conv{1..7}.{weight,bias}, linear{1..3}.{weight,bias} (the reference's
+    state_dict keys)."""
+    import torch
+    import torch.nn.functional as F
+    x = _t(x_bn3).float().permute(0, 2, 1)                                        # [B,3,N]
+    B, _, N = x.shape
+    c = lambda h, i: F.conv1d(h, _t(w[f"conv{i}.weight"]), _t(w[f"conv{i}.bias"]))
+    l = lambda h, i: F.linear(h, _t(w[f"linear{i}.weight"]), _t(w[f"linear{i}.bias"]))
+    h = c(F.relu(c(x, 1)), 2)                                                      # encoder_1
+    g = h.max(dim=2)[0]
+    h = torch.cat([h, g.unsqueeze(2).repeat(1, 1, N)], dim=1)
+    h = c(F.relu(c(h, 3)), 4)                                                      # encoder_2
+    gv = h.max(dim=2)[0]                                                           # [B,1024]
+    coarse = l(F.relu(l(F.relu(l(gv, 1)), 2)), 3).view(B, num_coarse, 3)
+    num_fine = grid_size ** 2 * num_coarse
+    lin = torch.linspace(-0.05, 0.05, steps=grid_size)
+    grid = torch.reshape(torch.stack(torch.meshgrid(lin, lin, indexing="ij"), dim=2), (-1, 2)).unsqueeze(0)
+    grid_feature = grid.repeat([B, num_coarse, 1])
+    point_feature = coarse.unsqueeze(2).repeat([1, 1, grid_size ** 2, 1]).reshape(-1, num_fine, 3)
+    global_feature = gv.unsqueeze(1).repeat([1, num_fine, 1])
+    feature = torch.cat([grid_feature, point_feature, global_feature], dim=2).permute(0, 2, 1)
+    out = c(F.relu(c(F.relu(c(feature, 5)), 6)), 7)
+    return coarse.numpy(), (out.permute(0, 2, 1) + point_feature).numpy()
+
+
+def pointnet_classifier_forward_torch(x_bn3, w, eps=1e-5):
+    """models/pointnet.py:45-73 (use_bn=True) -> Pooling('max') -> models/classifier.py:22-29, eval mode (dropout is
+    the identity), restated with torch CPU functionals.  `w` has the checkpoint's keys (feature_model.*, linear*, bn*)."""
+    import torch.nn.functional as F
+    h = _t(x_bn3).float().permute(0, 2, 1)
+    bn = lambda h, p: F.batch_norm(h, _t(w[p + ".running_mean"]), _t(w[p + ".running_var"]), _t(w[p + ".weight"]),
+                                   _t(w[p + ".bias"]), False, 0.0, eps)
+    for i in range(1, 6):
+        h = F.relu(bn(F.conv1d(h, _t(w[f"feature_model.conv{i}.weight"]), _t(w[f"feature_model.conv{i}.bias"])),
+                      f"feature_model.bn{i}"))
+    h = h.max(dim=2)[0]
+    h = F.relu(bn(F.linear(h, _t(w["linear1.weight"]), _t(w["linear1.bias"])), "bn1"))
+    h = F.relu(bn(F.linear(h, _t(w["linear2.weight"]), _t(w["linear2.bias"])), "bn2"))
+    return F.linear(h, _t(w["linear3.weight"]), _t(w["linear3.bias"])).numpy()
+
+
+def gaussian_density(xyz, bandwidth):
+    """utils/pointconv_util.py:194-203: mean_j exp(-square_distance / (2 bw^2)) / (2.5 bw), fp32 like the reference
+    (the two divisors are Python doubles that torch narrows to fp32 scalars)."""
+    d = square_distance(xyz, xyz)
+    g = np.exp(-d / np.float32(2.0 * bandwidth * bandwidth)) / np.float32(2.5 * bandwidth)
+    return g.astype(np.float32).mean(axis=-1, dtype=np.float32)

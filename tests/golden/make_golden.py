@@ -13,7 +13,8 @@ What it does
     (losses/cuda/chamfer_distance/chamfer_distance.cpp:59-177), built by
     oracle/build_ref.py from the source where it lies;
   * evaluates each hot-path function on small seeded inputs and stores
-    inputs + outputs as compressed .npz next to this script.
+    inputs + outputs as compressed .npz next to this script;
+  * `make_golden.py <substring> ...` rewrites only the fixtures whose name contains a substring.
 
 The reference ships no tests / KATs; these vectors are what
 pins oracle/ (tests/test_oracle_golden.py) and, through it, the HIP kernels.
@@ -61,6 +62,10 @@ def load_cd_ref():
 def rand(shape, seed, lo=0.0, hi=1.0):
     g = torch.Generator().manual_seed(seed)
     return torch.rand(shape, generator=g) * (hi - lo) + lo
+
+
+sys.path.insert(0, HERE)
+from seeded import seeded_params  # noqa: E402  (shared with the tests)
 
 
 ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]     # e.g. `make_golden.py prnet` rewrites only matching files
@@ -197,6 +202,45 @@ def main():
                 m.weight.data.uniform_(0.5, 1.5); m.bias.data.uniform_(-0.2, 0.2)
         x = rand((2, 3, 128), 24)
         save("prnet_dgcnn_emb64", x=x, out=pr(x), **{"w." + k: v for k, v in pr.state_dict().items()})
+        # ---- a8 PCN (models/pcn.py:8-153): conv5 is 1029 wide, so emb_dims must be 1024 and the weights are 15 MB.
+        #      They are NOT stored: every parameter is overwritten, by state_dict key, with seeded_params() below, and
+        #      the tests apply the same function to their model -- only inputs and outputs live in the fixture.
+        torch.manual_seed(7)
+        pcn = Mo.PCN(emb_dims=1024, num_coarse=64, grid_size=2, detailed_output=True).eval()
+        seeded_params(pcn, 700)
+        x = rand((2, 300, 3), 25, -0.5, 0.5)
+        out = pcn(x)
+        save("pcn_seeded", x=x, coarse_output=out["coarse_output"], fine_output=out["fine_output"],
+             keys=np.array(sorted(pcn.state_dict().keys())), seed=700)
+        # ---- config 1: PointNet classifier with the reference's own trained checkpoint
+        #      (pretrained/exp_classifier/models/best_model.t7, examples/test_pointnet.py:98-118, B=8 N=1024) ----------
+        ckpt = torch.load(os.path.join(REF, "pretrained", "exp_classifier", "models", "best_model.t7"), map_location="cpu")
+        clf = Mo.Classifier(feature_model=Mo.PointNet(emb_dims=1024, use_bn=True)).eval()
+        clf.load_state_dict(ckpt)
+        x = rand((8, 1024, 3), 0, -1.0, 1.0)                        # U(-1,1), seed 0
+        save("classifier_best_model", x=x, logits=clf(x), **{"w." + k: v for k, v in ckpt.items()})
+        # ---- utils/pointconv_util.py (north_star names the file): FPS from index 0, smallest-k expanded-distance
+        #      kNN (unsorted in the reference -> stored sorted by (distance, index)), density, one density SA layer ----
+        import learning3d.utils.pointconv_util as PC
+        xyz = rand((2, 512, 3), 26, -1, 1)
+        fps = PC.farthest_point_sample(xyz, 64)
+        new_xyz = PC.index_points(xyz, fps)
+        kidx = PC.knn_point(16, xyz, new_xyz)
+        d = PC.square_distance(new_xyz, xyz)
+        order = np.lexsort((kidx.numpy(), torch.gather(d, 2, kidx).numpy()), axis=-1)        # by distance, then index
+        kidx_sorted = np.take_along_axis(kidx.numpy(), order, axis=-1)
+        dens = PC.compute_density(xyz, 0.1)
+        torch.manual_seed(8)
+        sa = PC.PointConvDensitySetAbstraction(npoint=64, nsample=16, in_channel=3 + 5, mlp=[16, 32], bandwidth=0.1,
+                                               group_all=False).eval()
+        for m in sa.modules():
+            if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
+                m.running_mean.uniform_(-0.2, 0.2); m.running_var.uniform_(0.5, 1.5)
+        feats = rand((2, 5, 512), 27)
+        sa_xyz, sa_pts = sa(xyz.permute(0, 2, 1), feats)
+        save("pointconv_util", xyz=xyz, fps=fps.to(torch.int32), knn_idx_sorted=kidx_sorted.astype(np.int32),
+             density=dens, feats=feats, sa_xyz=sa_xyz, sa_points=sa_pts,
+             **{"w." + k: v for k, v in sa.state_dict().items()})
     shutil.rmtree(tmp, ignore_errors=True)
     print("done")
 

@@ -159,3 +159,56 @@ def test_small_losses_match_their_definitions():
     want = F.cross_entropy(pred.reshape(B * Ns, Nt), lab.reshape(-1))
     got = CorrespondenceLoss()(torch.zeros(B, 3, Nt), torch.zeros(B, 3, Ns), pred, gt)
     assert torch.allclose(got, want)
+
+
+def test_kabsch_backward_matches_autograd_of_reference_sequence():
+    """SVDHead's analytic Kabsch backward (learning3d_amd/utils/svd.py) against torch autograd through the reference's
+    own op sequence (utils/svd.py:29-58: centring, H, torch.svd, V U^T, det fix with `reflect`, t), fp64, including
+    clouds whose best orthogonal fit is a reflection (the det < 0 branch)."""
+    import torch
+    from learning3d_amd.utils.svd import kabsch_backward
+    torch.manual_seed(0)
+    B, N = 6, 40
+    src = torch.randn(B, 3, N, dtype=torch.float64)
+    corr = torch.randn(B, 3, N, dtype=torch.float64)
+    mirror = torch.diag(torch.tensor([1.0, 1.0, -1.0], dtype=torch.float64))
+    corr[3:] = mirror @ src[3:] + 0.05 * torch.randn(3, 3, N, dtype=torch.float64)     # reflection is the best fit
+    src.requires_grad_(); corr.requires_grad_()
+    sc = src - src.mean(2, keepdim=True)
+    cc = corr - corr.mean(2, keepdim=True)
+    H = sc @ cc.transpose(2, 1)
+    Rs, dets = [], []
+    for i in range(B):
+        u, s, v = torch.svd(H[i])
+        r = v @ u.t()
+        dets.append(float(torch.det(r.detach())))
+        if dets[-1] < 0:
+            r = (v @ mirror) @ u.t()
+        Rs.append(r)
+    assert min(dets) < 0 < max(dets)                       # both branches exercised
+    R = torch.stack(Rs)
+    t = (torch.matmul(-R, src.mean(2, keepdim=True)) + corr.mean(2, keepdim=True)).view(B, 3)
+    gR, gt = torch.randn_like(R), torch.randn_like(t)
+    ((R * gR).sum() + (t * gt).sum()).backward()
+    g_src, g_corr = kabsch_backward(src.detach(), corr.detach(), R.detach(), gR, gt)
+    assert (g_src - src.grad).abs().max() < 1e-10 * max(1.0, float(src.grad.abs().max()))
+    assert (g_corr - corr.grad).abs().max() < 1e-10 * max(1.0, float(corr.grad.abs().max()))
+
+
+def test_bench_self_launches_two_ranks_gloo():
+    """`python bench.py --gpus 2` with no launcher around it must start its own ranks.  The
+    --selftest-cpu mode runs the launcher, init_from_env, the loss all_gather (blocking and pipelined), the barrier /
+    max-over-ranks bracket and the JSON line on gloo; no kernel and no oracle is involved."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--selftest-cpu"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and len(j["per_rank_s"]) == 2
+    assert abs(j["loss_sync"] - j["loss_expected"]) < 1e-6 and abs(j["loss_pipelined"] - j["loss_expected"]) < 1e-6

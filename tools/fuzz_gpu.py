@@ -61,19 +61,15 @@ with torch.no_grad():
         out = torch.empty_like(qd)
         check(lib().l3d_attention_forward(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, 1 / math.sqrt(D), ptr(out), stream_ptr()), "att")
         rec("attention vs fp64", out.cpu().numpy().reshape(B, H, D, N), want, 1e-5, 4e-6)
-    import ctypes
-    mode = ctypes.c_int.in_dll(lib(), "l3d_chamfer_forward_mode")
     for it in range(10):                                            # Chamfer: packed kernel == per-candidate kernel, bit for bit
         B = int(rng.integers(1, 4)); N = int(rng.integers(1, 3000)); M = int(rng.integers(1, 3000))
         a = dev(rng.uniform(0, 1, (B, N, 3)).astype(np.float32)); b_ = dev(np.round(rng.uniform(0, 1, (B, M, 3)) * 8).astype(np.float32) / 8)   # ties
         outs = []
         for m_ in (0, 2):
-            mode.value = m_
             d1 = torch.empty(B, N, device="cuda"); d2 = torch.empty(B, M, device="cuda")
             i1 = torch.empty(B, N, dtype=torch.int32, device="cuda"); i2 = torch.empty(B, M, dtype=torch.int32, device="cuda")
-            check(lib().l3d_chamfer_forward(ptr(a), ptr(b_), B, N, M, ptr(d1), ptr(d2), ptr(i1), ptr(i2), stream_ptr()), "cd")
+            check(lib().l3d_chamfer_forward_variant(ptr(a), ptr(b_), B, N, M, ptr(d1), ptr(d2), ptr(i1), ptr(i2), m_, stream_ptr()), "cd")
             outs.append([t.cpu().numpy() for t in (d1, d2, i1, i2)])
-        mode.value = 1
         for x_, y_ in zip(*outs):
             assert np.array_equal(x_, y_), ("chamfer packed", B, N, M)
     worst["chamfer packed == scalar"] = 0.0
