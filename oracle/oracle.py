@@ -461,3 +461,91 @@ def gaussian_density(xyz, bandwidth):
     d = square_distance(xyz, xyz)
     g = np.exp(-d / np.float32(2.0 * bandwidth * bandwidth)) / np.float32(2.5 * bandwidth)
     return g.astype(np.float32).mean(axis=-1, dtype=np.float32)
+
+
+# ----------------------------------------------------------------- config 3: DCP-v2 (DGCNN + Transformer + SVD head)
+def dcp_forward_torch(template, source, w, n_heads=4, k=20, dtype="float32"):
+    """models/dcp.py:30-56 with pointer_='transformer', head='svd', cycle=False, eval mode, restated as torch CPU
+    functionals: emb_nn = DGCNN (models/dgcnn.py:25-49), pointer = Transformer(emb, 1 block, ff 1024, 4 heads)
+    (utils/transformer.py:17-25, :94-216: unbiased-std LayerNorm with eps on the std, pre-norm residual sublayers,
+    encoder(src) -> decoder(tgt, memory), called twice with the roles swapped :238-245), head = SVDHead
+    (utils/svd.py:13-59).  `w` has the DCP state_dict keys (emb_nn.*, pointer.model.*, head.reflect).
+    dtype="float64" evaluates the same graph in double (kNN graph still from the fp32 oracle) -- used to measure how
+    far fp32 rounding alone moves R, t on a given input."""
+    import math
+    import torch
+    import torch.nn.functional as F
+    dt = getattr(torch, dtype)
+    W = lambda name: torch.as_tensor(np.asarray(w[name])).to(dt)
+
+    def dgcnn(x_bn3):
+        B, N, _ = x_bn3.shape
+        idx = torch.from_numpy(knn(np.asarray(x_bn3, dtype=np.float32), k))
+        x = torch.as_tensor(np.asarray(x_bn3)).to(dt)
+        nb = torch.gather(x.unsqueeze(1).expand(B, N, N, 3), 2, idx.unsqueeze(-1).expand(B, N, k, 3))
+        h = torch.cat([nb, x.unsqueeze(2).expand(B, N, k, 3)], dim=3).permute(0, 3, 1, 2)
+        outs = []
+        for i in (1, 2, 3, 4, 5):
+            if i == 5:
+                h = torch.cat(outs, dim=1)
+            h = F.conv2d(h, W(f"emb_nn.conv{i}.weight"))
+            h = F.relu(F.batch_norm(h, W(f"emb_nn.bn{i}.running_mean"), W(f"emb_nn.bn{i}.running_var"),
+                                    W(f"emb_nn.bn{i}.weight"), W(f"emb_nn.bn{i}.bias"), False, 0.0, 1e-5))
+            if i < 5:
+                outs.append(h.max(dim=-1, keepdim=True)[0])          # the un-pooled h feeds the next conv (:36-46)
+        return h.view(B, -1, N)
+
+    def layer_norm(x, p):
+        mean, std = x.mean(-1, keepdim=True), x.std(-1, keepdim=True)
+        return W(p + ".a_2") * (x - mean) / (std + 1e-6) + W(p + ".b_2")
+
+    def mha(q, k_, v, p):
+        nb = q.size(0)
+        lin = lambda x, i: F.linear(x, W(f"{p}.linears.{i}.weight"), W(f"{p}.linears.{i}.bias"))
+        d_model = q.size(-1)
+        d_k = d_model // n_heads
+        q, k_, v = [lin(x, i).view(nb, -1, n_heads, d_k).transpose(1, 2) for i, x in enumerate((q, k_, v))]
+        scores = torch.matmul(q, k_.transpose(-2, -1)) / math.sqrt(d_k)
+        x = torch.matmul(F.softmax(scores, dim=-1), v)
+        return lin(x.transpose(1, 2).contiguous().view(nb, -1, d_model), 3)
+
+    def ff(x, p):
+        return F.linear(F.relu(F.linear(x, W(p + ".w_1.weight"), W(p + ".w_1.bias"))), W(p + ".w_2.weight"), W(p + ".w_2.bias"))
+
+    def pointer_pass(src, tgt):                      # self.model(src, tgt, None, None)
+        e = "pointer.model.encoder"
+        x = src
+        x = x + mha(*([layer_norm(x, e + ".layers.0.sublayer.0.norm")] * 3), e + ".layers.0.self_attn")
+        x = x + ff(layer_norm(x, e + ".layers.0.sublayer.1.norm"), e + ".layers.0.feed_forward")
+        mem = layer_norm(x, e + ".norm")
+        d = "pointer.model.decoder"
+        x = tgt
+        x = x + mha(*([layer_norm(x, d + ".layers.0.sublayer.0.norm")] * 3), d + ".layers.0.self_attn")
+        x = x + mha(layer_norm(x, d + ".layers.0.sublayer.1.norm"), mem, mem, d + ".layers.0.src_attn")
+        x = x + ff(layer_norm(x, d + ".layers.0.sublayer.2.norm"), d + ".layers.0.feed_forward")
+        return layer_norm(x, d + ".norm")
+
+    sf, tf = dgcnn(source), dgcnn(template)                                    # [B,C,N]
+    s_t, t_t = sf.transpose(2, 1).contiguous(), tf.transpose(2, 1).contiguous()
+    tgt_emb = pointer_pass(s_t, t_t).transpose(2, 1)                           # Transformer.forward(src=sf, tgt=tf)
+    src_emb = pointer_pass(t_t, s_t).transpose(2, 1)
+    sf, tf = sf + src_emb, tf + tgt_emb
+    src = torch.as_tensor(np.asarray(source)).to(dt).permute(0, 2, 1)
+    tgt = torch.as_tensor(np.asarray(template)).to(dt).permute(0, 2, 1)
+    B = src.shape[0]
+    d_k = sf.size(1)
+    scores = torch.softmax(torch.matmul(sf.transpose(2, 1).contiguous(), tf) / math.sqrt(d_k), dim=2)
+    corr = torch.matmul(tgt, scores.transpose(2, 1).contiguous())
+    sc, cc = src - src.mean(dim=2, keepdim=True), corr - corr.mean(dim=2, keepdim=True)
+    H = torch.matmul(sc, cc.transpose(2, 1).contiguous())
+    refl = torch.diag(torch.tensor([1.0, 1.0, -1.0], dtype=dt))
+    Rs = []
+    for i in range(B):
+        u, s_, v = torch.svd(H[i])
+        r = torch.matmul(v, u.transpose(1, 0))
+        if torch.det(r) < 0:
+            r = torch.matmul(torch.matmul(v, refl), u.transpose(1, 0))
+        Rs.append(r)
+    R = torch.stack(Rs, dim=0)
+    t = (torch.matmul(-R, src.mean(dim=2, keepdim=True)) + corr.mean(dim=2, keepdim=True)).view(B, 3)
+    return {"est_R": R.numpy(), "est_t": t.numpy(), "r": (tf - sf).numpy(), "H": H.numpy()}

@@ -58,13 +58,13 @@ def test_knn_vs_oracle_ragged_sizes(U, B, N, k):
 
 
 def test_knn_full_baseline_size_properties(U):
-    """B=32, N=1024, k=20 (BASELINE config 2): self is the first neighbour, rows are sorted by the
-    ranked value, indices are unique; spot-check 2 clouds against the oracle."""
+    """B=32, N=1024, k=20 (BASELINE config 2, the bench shape): ALL 32 clouds bit-identical to the oracle
+    (which is pinned to the reference's golden on this very distribution), plus the structural properties."""
     xyz = rand((32, 1024, 3), 0)
     idx = U.knn(dev(xyz).permute(0, 2, 1), 20).cpu().numpy()
     assert (idx[:, :, 0] == np.arange(1024)[None]).mean() > 0.999
     assert all(len(np.unique(r)) == 20 for r in idx[0])
-    assert np.array_equal(idx[[0, 31]], oracle.knn(xyz[[0, 31]], 20))
+    assert np.array_equal(idx, oracle.knn(xyz, 20))
 
 
 def test_knn_rejects_bad_k(U):
@@ -331,7 +331,7 @@ def test_flownet_sized_ball_query_properties():
     fps = P.furthest_point_sample(txyz, 1024)
     new_xyz = P.gather_operation(txyz.transpose(1, 2).contiguous(), fps).transpose(1, 2).contiguous()
     idx = P.ball_query(0.5, 16, txyz, new_xyz)
-    sel = [0, 31]
+    sel = list(range(32))                                   # all 32 clouds of the per-GPU slice against the oracle
     ofps = oracle.furthest_point_sampling(xyz[sel].numpy(), 1024)
     assert np.array_equal(fps.cpu().numpy()[sel], ofps)
     oidx = oracle.ball_query(0.5, 16, xyz[sel].numpy(), new_xyz.cpu().numpy()[sel])
@@ -1103,3 +1103,44 @@ def test_svd_head_is_differentiable_like_the_reference():
     for got, want in ((a.grad, a64.grad), (b.grad, b64.grad)):
         scale = float(want.abs().max())
         np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-3, atol=1e-4 * scale)
+
+
+def test_config3_dcp_full_size_vs_oracle_port():
+    """BASELINE config 3 at full size: DCP-v2 (DGCNN emb 512 + Transformer + SVD head), B=32, N=1024, inputs as
+    SURVEY.md 8(d) c3 (template U(-0.5,0.5)^3 seed 0; source = R template + t, Euler angles in [0,45 deg]^3,
+    t in U(-0.5,0.5)^3), against oracle.dcp_forward_torch -- the fp32 CPU restatement that reproduces the reference's
+    golden bit for bit (tests/test_oracle_golden.py::test_dcp_oracle_port_is_the_reference).  R, t are compared where
+    the SVD is well conditioned ((s2 +- s3)/s1 >= 1e-2, the survey's criterion)."""
+    from learning3d_amd.models import DCP, DGCNN
+    torch.manual_seed(5)
+    net = DCP(feature_model=DGCNN(emb_dims=512), cycle=False).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.uniform_(-0.2, 0.2); m.running_var.uniform_(0.5, 1.5)
+    w = {k: v.numpy() for k, v in net.state_dict().items()}
+    B, N = 32, 1024
+    template = rand((B, N, 3), 0, -0.5, 0.5)
+    ang = rand((B, 3), 1, 0, np.pi / 4)
+    cx, cy, cz = np.cos(ang).T; sx, sy, sz = np.sin(ang).T
+    Rg = np.zeros((B, 3, 3), np.float32)
+    for i in range(B):
+        Rx = np.array([[1, 0, 0], [0, cx[i], -sx[i]], [0, sx[i], cx[i]]]); Ry = np.array([[cy[i], 0, sy[i]], [0, 1, 0], [-sy[i], 0, cy[i]]])
+        Rz = np.array([[cz[i], -sz[i], 0], [sz[i], cz[i], 0], [0, 0, 1]])
+        Rg[i] = (Rz @ Ry @ Rx).astype(np.float32)
+    source = (template @ Rg.transpose(0, 2, 1) + rand((B, 1, 3), 2, -0.5, 0.5)).astype(np.float32)
+    with torch.no_grad():
+        out = net.cuda()(dev(template), dev(source))
+    want = {k: [] for k in ("est_R", "est_t", "r", "H")}
+    for c in range(0, B, 8):                                 # bound the CPU side's [8,4,1024,1024] attention maps
+        o = oracle.dcp_forward_torch(template[c:c + 8], source[c:c + 8], w)
+        for k in want:
+            want[k].append(o[k])
+    want = {k: np.concatenate(v) for k, v in want.items()}
+    np.testing.assert_allclose(out["r"].cpu().numpy(), want["r"], rtol=1e-3, atol=2e-5)
+    s = np.linalg.svd(want["H"].astype(np.float64), compute_uv=False)
+    ok = ((s[:, 1] - s[:, 2]) / s[:, 0] >= 1e-2) & ((s[:, 1] + s[:, 2]) / s[:, 0] >= 1e-2)
+    assert ok.sum() >= B // 2, ok.sum()
+    eR = np.abs(out["est_R"].cpu().numpy() - want["est_R"])[ok].max()
+    et = np.abs(out["est_t"].cpu().numpy() - want["est_t"])[ok].max()
+    print(f"config 3 full size: max |dR| {eR:.2e}, max |dt| {et:.2e} over {ok.sum()} well-conditioned clouds")
+    assert eR <= 1e-4 and et <= 1e-4, (eR, et)

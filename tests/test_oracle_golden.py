@@ -165,3 +165,16 @@ def test_pointconv_util_oracle(golden):
     new_xyz = oracle.index_points(xyz, fps)
     assert np.array_equal(oracle.knn_point_expanded(16, xyz, new_xyz), g["knn_idx_sorted"])
     np.testing.assert_allclose(oracle.gaussian_density(xyz, 0.1), g["density"], rtol=2e-6, atol=0)
+
+
+def test_dcp_oracle_port_is_the_reference(golden):
+    """config 3: oracle.dcp_forward_torch (DGCNN + Transformer + SVD head restated as functionals) reproduces the
+    reference DCP's golden output; the fp64 evaluation of the same graph shows what fp32 rounding alone does to R, t
+    on this input (the floor any fp32 implementation with another summation order sits on)."""
+    g = golden("dcp_emb64")
+    w = {k[2:]: v for k, v in g.items() if k.startswith("w.")}
+    o = oracle.dcp_forward_torch(g["template"], g["source"], w)
+    for k in ("est_R", "est_t", "r"):
+        np.testing.assert_allclose(o[k], g[k], rtol=0, atol=1e-6)
+    o64 = oracle.dcp_forward_torch(g["template"], g["source"], w, dtype="float64")
+    assert np.abs(o64["est_R"] - g["est_R"]).max() < 1e-5 and np.abs(o64["est_t"] - g["est_t"]).max() < 1e-5
