@@ -15,7 +15,9 @@ names -> HIP) plus the C entry files oracle/ref_pointnet2_entry.hip / ref_emd_en
   oracle/_ref/libref_pointnet2.so      -ffp-contract=off  (the arithmetic as written: bit-exact pin)
   oracle/_ref/libref_pointnet2_fma.so  compiler-default contraction (what nvcc's default -fmad does)
   oracle/_ref/libref_chamfer.so        <ref>/losses/cuda/chamfer_distance/chamfer_distance.cu (K1/K2), -ffp-contract=off
-  oracle/_ref/libref_emd.so            compiler default (the kernels use __expf / rsqrtf anyway)
+  oracle/_ref/libref_emd.so            compiler-default contraction
+  oracle/_ref/libref_emd_nofma.so      -ffp-contract=off: the arithmetic as written (the auction amplifies rounding
+                                       differences chaotically at n = 1024, so this is the tight pin)
 These are the K3-K16 pins of tests/test_gpu_ref_kernels.py on the GPU box.
 
 usage: python build_ref.py [/root/reference]
@@ -79,6 +81,8 @@ def build_kernels(ref="/root/reference", force=False):
         (os.path.join(out, "libref_pointnet2_fma.so"), base + [f"-I{src}", *cu, pn_entry], cu + [pn_entry]),
         (os.path.join(out, "libref_chamfer.so"), base + ["-ffp-contract=off", cd_cu, cd_entry], [cd_cu, cd_entry]),
         (os.path.join(out, "libref_emd.so"), base + [f"-I{here}", f"-I{emd_inc}", emd_entry],
+         [emd_entry, os.path.join(emd_inc, "cuda", "emd.cuh")]),
+        (os.path.join(out, "libref_emd_nofma.so"), base + ["-ffp-contract=off", f"-I{here}", f"-I{emd_inc}", emd_entry],
          [emd_entry, os.path.join(emd_inc, "cuda", "emd.cuh")]),
     ]
     built = []

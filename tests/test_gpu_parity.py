@@ -794,10 +794,12 @@ def test_dcp_golden(golden):
     with torch.no_grad():
         out = net(dev(g["template"]), dev(g["source"]))
     np.testing.assert_allclose(out["r"].cpu().numpy(), g["r"], rtol=1e-3, atol=2e-5)
-    np.testing.assert_allclose(out["est_R"].cpu().numpy(), g["est_R"], atol=1e-4)
-    np.testing.assert_allclose(out["est_t"].cpu().numpy(), g["est_t"], atol=1e-4)
-    np.testing.assert_allclose(out["est_T"].cpu().numpy(), g["est_T"], atol=1e-4)
-    np.testing.assert_allclose(out["transformed_source"].cpu().numpy(), g["transformed_source"], atol=1e-4)
+    # north_star: "SVD rotations within 1e-5 fp32" -- held end to end (fp32 rounding alone moves R by 1.4e-6 on this
+    # fixture: tests/test_oracle_golden.py::test_dcp_oracle_port_is_the_reference)
+    np.testing.assert_allclose(out["est_R"].cpu().numpy(), g["est_R"], atol=1e-5)
+    np.testing.assert_allclose(out["est_t"].cpu().numpy(), g["est_t"], atol=1e-5)
+    np.testing.assert_allclose(out["est_T"].cpu().numpy(), g["est_T"], atol=1e-5)
+    np.testing.assert_allclose(out["transformed_source"].cpu().numpy(), g["transformed_source"], atol=1e-5)
 
 
 def test_flash_attention_vs_fp64():
@@ -1143,4 +1145,4 @@ def test_config3_dcp_full_size_vs_oracle_port():
     eR = np.abs(out["est_R"].cpu().numpy() - want["est_R"])[ok].max()
     et = np.abs(out["est_t"].cpu().numpy() - want["est_t"])[ok].max()
     print(f"config 3 full size: max |dR| {eR:.2e}, max |dt| {et:.2e} over {ok.sum()} well-conditioned clouds")
-    assert eR <= 1e-4 and et <= 1e-4, (eR, et)
+    assert eR <= 1e-5 and et <= 1e-5, (eR, et)

@@ -231,12 +231,15 @@ def test_chamfer_equals_reference_gpu_kernels(B, N, M):
 # ------------------------------------------------------------------------------------------ K3-K6 EMD
 @pytest.mark.parametrize("B,n,m", [(2, 256, 256), (4, 1024, 1024), (32, 1024, 1024), (2, 512, 256), (2, 300, 900)])
 def test_emd_equals_reference_kernels(B, n, m):
-    """EMD against the reference's own approxmatch / matchcost / matchcostgrad kernels run on this GPU.
-    Both sides evaluate exp through the hardware's v_exp_f32 (the reference's __expf) and rsqrtf; they differ in
-    the order of the long fp32 sums (one 1024-thread workgroup per cloud here, 512-thread blocks striding over
-    clouds there; cost via atomicAdd there).  Tolerances: match 2e-5 absolute (entries are <= 1), cost 1e-5
-    relative, gradients 1e-4 of the gradient scale."""
-    EMD = _load("libref_emd.so")
+    """EMD against the reference's own approxmatch / matchcost / matchcostgrad kernels (emd.cuh:7-323) run on this
+    GPU, n = m = 1024 at B = 32 (the c2-sized case) included.  Both sides evaluate exp through v_exp_f32 (__expf)
+    and rsqrtf.  The auction is a 10-level fixed-point iteration whose temperature reaches -4^7: it amplifies
+    last-bit differences of the long fp32 sums, so there are two bars:
+      * libref_emd_nofma.so (-ffp-contract=off, i.e. the arithmetic exactly as the source writes it, which is what
+        emd.hip implements): match within 1e-6 absolute (entries are <= 1), cost within 2e-6 relative (the reference
+        sums cost with atomicAdd in arbitrary order), gradients within 1e-5 of the gradient scale;
+      * libref_emd.so (the compiler's default FMA contraction, as nvcc would also apply): cost within 1e-4 relative,
+        99.99 % of the match entries within 2e-5, gradients within 1e-3 of the gradient scale."""
     from learning3d_amd._lib import check, lib, stream_ptr
     rng = np.random.default_rng(11)
     a = dev(rng.uniform(0, 1, (B, n, 3)).astype(np.float32))
@@ -245,20 +248,28 @@ def test_emd_equals_reference_kernels(B, n, m):
     cost = torch.empty((B,), device="cuda")
     temp = torch.empty((B, 2 * (n + m)), device="cuda")
     check(lib().l3d_emd_forward(p(a), p(b), B, n, m, p(match), p(cost), p(temp), stream_ptr()), "l3d_emd_forward")
-    wmatch = torch.zeros((B, m, n), device="cuda")                                  # emd.cu:18-22
-    wcost = torch.zeros((B,), device="cuda")
-    wtemp = torch.zeros((B, 2 * (n + m)), device="cuda")
-    torch.cuda.synchronize()
-    EMD.ref_emd_forward(B, n, m, p(a), p(b), p(wmatch), p(wtemp), p(wcost))
-    torch.cuda.synchronize()
-    np.testing.assert_allclose(match.cpu().numpy(), wmatch.cpu().numpy(), rtol=0, atol=2e-5)
-    np.testing.assert_allclose(cost.cpu().numpy(), wcost.cpu().numpy(), rtol=1e-5)
-    g1, g2 = torch.empty_like(a), torch.empty_like(b)
-    check(lib().l3d_emd_backward(p(a), p(b), p(wmatch), B, n, m, p(g1), p(g2), stream_ptr()), "l3d_emd_backward")
-    wg1, wg2 = torch.zeros_like(a), torch.zeros_like(b)                             # emd.cu:56-57
-    torch.cuda.synchronize()
-    EMD.ref_emd_backward(B, n, m, p(a), p(b), p(wmatch), p(wg1), p(wg2))
-    torch.cuda.synchronize()
-    for got, want in ((g1, wg1), (g2, wg2)):
-        scale = float(want.abs().max())
-        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-4 * scale)
+    for name, tight in (("libref_emd_nofma.so", True), ("libref_emd.so", False)):
+        EMD = _load(name)
+        wmatch = torch.zeros((B, m, n), device="cuda")                                  # emd.cu:18-22
+        wcost = torch.zeros((B,), device="cuda")
+        wtemp = torch.zeros((B, 2 * (n + m)), device="cuda")
+        torch.cuda.synchronize()
+        EMD.ref_emd_forward(B, n, m, p(a), p(b), p(wmatch), p(wtemp), p(wcost))
+        torch.cuda.synchronize()
+        dm = (match - wmatch).abs()
+        if tight:
+            assert float(dm.max()) <= 1e-6, float(dm.max())
+            np.testing.assert_allclose(cost.cpu().numpy(), wcost.cpu().numpy(), rtol=2e-6)
+        else:
+            assert float((dm <= 2e-5).float().mean()) >= 0.9999
+            np.testing.assert_allclose(cost.cpu().numpy(), wcost.cpu().numpy(), rtol=1e-4)
+        g1, g2 = torch.empty_like(a), torch.empty_like(b)
+        check(lib().l3d_emd_backward(p(a), p(b), p(wmatch), B, n, m, p(g1), p(g2), stream_ptr()), "l3d_emd_backward")
+        wg1, wg2 = torch.zeros_like(a), torch.zeros_like(b)                             # emd.cu:56-57
+        torch.cuda.synchronize()
+        EMD.ref_emd_backward(B, n, m, p(a), p(b), p(wmatch), p(wg1), p(wg2))
+        torch.cuda.synchronize()
+        for got, want in ((g1, wg1), (g2, wg2)):
+            scale = float(want.abs().max())
+            tol = 1e-5 if tight else 1e-3
+            np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=tol, atol=tol * scale)
