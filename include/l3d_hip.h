@@ -295,6 +295,15 @@ int l3d_edgeconv_forward_chained(const float *xyz, const int64_t *idx, int B, in
  * fraction of the fp32-MFMA time.  k <= 20; packed must be 16-byte aligned. */
 int l3d_edgeconv_forward_split(const float *xyz, const int64_t *idx, int B, int N, int k,
                                const float *packed, float *pooled, l3d_stream_t stream);
+/* Same computation, same packed block (its fourth weight copy), same output layout; layers 2-4 as "f16x2" on the
+ * fp16 matrix cores (edgeconv_f16.hip): activations x = h + m' 2^-12 (h = f16(x), m' = f16((x - h) 2^12)), weights
+ * scaled by a per-layer power of two and split the same way, THREE fp16 MFMA products per fp32 product into one fp32
+ * accumulator -- fp32-level error (tests hold it to the bf16x3 bar) at half of bf16x3's matrix-core work.
+ * Range contract: post-ReLU activations of layers 1-3 must stay below 65504 (fp16); the kernel watches the pooled
+ * maxima it writes anyway and stores 1 to *range_flag (device or mapped host memory, may be NULL) when one exceeds
+ * 60000 -- the outputs are then invalid and the caller re-runs l3d_edgeconv_forward_split.  k <= 20. */
+int l3d_edgeconv_forward_f16(const float *xyz, const int64_t *idx, int B, int N, int k,
+                             const float *packed, float *pooled, int *range_flag, l3d_stream_t stream);
 /* Per-point linear layer (Conv1d/Conv2d 1x1 + folded BN + optional ReLU):
  *   y[b][co][n] = act(scale[co] * sum_ci w[co][ci] x[b][ci][n] + shift[co])
  *   x [B,Cin,N] (x_channel_last = 0, torch Conv1d layout) or [B,N,Cin] (x_channel_last = 1),

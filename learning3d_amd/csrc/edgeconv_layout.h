@@ -29,4 +29,17 @@
 #define EC3_OFF_W2 EC2_END
 #define EC3_OFF_W3 (EC3_OFF_W2 + (EC_C2 / 16) * (EC_C1 / 32) * 3 * 64 * 4)
 #define EC3_OFF_W4 (EC3_OFF_W3 + (EC_C3 / 16) * (EC_C2 / 32) * 3 * 64 * 4)
-#define EC_PACKED_FLOATS (EC3_OFF_W4 + (EC_C4 / 16) * (EC_C3 / 32) * 3 * 64 * 4)
+#define EC3_END (EC3_OFF_W4 + (EC_C4 / 16) * (EC_C3 / 32) * 3 * 64 * 4)
+
+// fourth copy, layers 2-4, for the f16x2 kernel (edgeconv_f16.hip): W = w' 2^S (S per layer so that max|W| is in
+// [4,8)) as three fp16 planes H = f16(W), Hs = f16(H 2^-12), M = f16(W - H), same fragment order as the third copy
+// ([step][plane 3: H, Hs, M][lane 64][8 f16]); then the biases of layers 2-4 pre-multiplied by 2^S, then 2^-S of
+// layers 2, 3, 4 (+ one pad float).
+#define EC4_OFF_W2 EC3_END
+#define EC4_OFF_W3 (EC4_OFF_W2 + (EC_C2 / 16) * (EC_C1 / 32) * 3 * 64 * 4)
+#define EC4_OFF_W4 (EC4_OFF_W3 + (EC_C3 / 16) * (EC_C2 / 32) * 3 * 64 * 4)
+#define EC4_OFF_B2 (EC4_OFF_W4 + (EC_C4 / 16) * (EC_C3 / 32) * 3 * 64 * 4)
+#define EC4_OFF_B3 (EC4_OFF_B2 + EC_C2)
+#define EC4_OFF_B4 (EC4_OFF_B3 + EC_C3)
+#define EC4_OFF_SC (EC4_OFF_B4 + EC_C4)
+#define EC_PACKED_FLOATS (EC4_OFF_SC + 4)

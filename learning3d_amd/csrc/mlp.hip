@@ -149,6 +149,52 @@ extern "C" int l3d_edgeconv_pack(const float *const w[4], const float *const sca
                             dst[(((((size_t)(m >> 1) * S + sidx) * 2 + (m & 1)) * 3 + p) * 64 + lane) * 8 + slot] = pl[p];
                     }
     }
+    // fourth copy (layers 2-4) for the f16x2 kernel (edgeconv_f16.hip): W = w' 2^S, planes H = f16(W), Hs = f16(H 2^-12),
+    //   M = f16(W - H) in the fragment order of the third copy; biases times 2^S; 2^-S per layer.
+    const int o4[4] = {0, EC4_OFF_W2, EC4_OFF_W3, EC4_OFF_W4};
+    const int ob4[4] = {0, EC4_OFF_B2, EC4_OFF_B3, EC4_OFF_B4};
+    for (int l = 1; l < 4; l++) {
+        const float *wl = w[l];
+        const float *sc = scale ? scale[l] : nullptr;
+        float wmax = 0.f;
+        for (int oc = 0; oc < cs[l]; oc++)
+            for (int ic = 0; ic < cin[l]; ic++) {
+                float v = wl[(size_t)oc * cin[l] + ic];
+                if (sc) v *= sc[oc];
+                wmax = fmaxf(wmax, fabsf(v));
+            }
+        int S = 0;                                            // max|w| 2^S in [4, 8); all-zero weights: S = 0
+        if (wmax > 0.f && wmax < INFINITY) {
+            int e;
+            frexpf(wmax, &e);                                 // wmax = f 2^e, f in [0.5, 1)
+            S = 3 - e;
+        }
+        const float up = ldexpf(1.0f, S), down = ldexpf(1.0f, -S);
+        uint16_t *dst = (uint16_t *)(packed + o4[l]);
+        const int St = cin[l] / 32;
+        for (int m = 0; m < cs[l] / 16; m++)
+            for (int sidx = 0; sidx < St; sidx++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int slot = 0; slot < 8; slot++) {
+                        const int oc = 16 * m + (lane & 15);
+                        const int ic = 32 * sidx + 16 * (slot >> 2) + 4 * (lane >> 4) + (slot & 3);
+                        float v = wl[(size_t)oc * cin[l] + ic];
+                        if (sc) v *= sc[oc];
+                        v *= up;                               // exact
+                        const _Float16 H = (_Float16)v;        // round-to-nearest-even
+                        const _Float16 M = (_Float16)(v - (float)H);
+                        const _Float16 Hs = (_Float16)((float)H * 0x1p-12f);
+                        const _Float16 pl[3] = {H, Hs, M};
+                        for (int p = 0; p < 3; p++) {
+                            uint16_t bits;
+                            memcpy(&bits, &pl[p], 2);
+                            dst[(((((size_t)(m >> 1) * St + sidx) * 2 + (m & 1)) * 3 + p) * 64 + lane) * 8 + slot] = bits;
+                        }
+                    }
+        for (int c = 0; c < cs[l]; c++) packed[ob4[l] + c] = ((shift && shift[l]) ? shift[l][c] : 0.f) * up;
+        packed[EC4_OFF_SC + (l - 1)] = down;
+    }
+    packed[EC4_OFF_SC + 3] = 0.f;
     return L3D_OK;
 }
 

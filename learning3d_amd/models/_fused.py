@@ -218,10 +218,62 @@ class EdgeConvParams:
         return self.packed
 
 
-# EdgeConv kernel choice: "split" = register-chained, layers 2-4 as bf16x3 on the bf16 matrix cores
-# (edgeconv_split.hip); "chained" = register-chained on the fp32 MFMA (edgeconv2.hip); "lds" = the
-# LDS-staged fp32-MFMA kernel (mlp.hip, any k <= 32).  The first two need k <= 20.
-EDGECONV_KERNEL = "split"
+# ------------------------------------------------------------------------------------------------------------
+# GEMM arithmetic of the shared-MLP kernels (all three are fp32-in / fp32-out with fp32-level error; tests hold the
+# matrix-core variants to <= 2x max / 1.5x rms of the fp32-MFMA kernel's own error against fp64):
+#   "f16x2"  fp16 high part + 2^12-scaled fp16 residual, 3 fp16 MFMA products per fp32 product (edgeconv_f16.hip);
+#            needs |activation| < 65504 -- guarded by a range flag, see range_flag() below
+#   "bf16x3" exact three-way bf16 split, 6 bf16 MFMA products per fp32 product (edgeconv_split.hip, conv_split.hip);
+#            fp32's full exponent range
+#   "fp32"   the fp32 MFMA itself (edgeconv2.hip, mlp.hip)
+# SPLIT_BF16 = False (bench.py --fp32-mfma) forces "fp32" regardless.
+GEMM_ARITH = "f16x2"
+
+
+def gemm_arith():
+    return GEMM_ARITH if SPLIT_BF16 else "fp32"
+
+
+class L3DRangeError(RuntimeError):
+    pass
+
+
+_RANGE_FLAGS = {}
+
+
+def range_flag(device):
+    """One int32 in pinned (device-mapped) host memory per GPU.  A f16x2 kernel stores 1 into it when an activation
+    leaves fp16's range (never for BatchNorm'd networks); the host reads it without a device sync."""
+    key = torch.device(device).index or 0
+    f = _RANGE_FLAGS.get(key)
+    if f is None:
+        f = torch.zeros(1, dtype=torch.int32).pin_memory()
+        _RANGE_FLAGS[key] = f
+    return f
+
+
+def check_range(device=None, sync=False):
+    """Raise if a f16x2 kernel launched earlier on `device` (default: every device used) reported an out-of-range
+    activation: its outputs were invalid.  sync=True waits for the device first (tests, end of a bench run); the
+    default looks at what has already completed -- the models call it at the start of every fused forward, so an
+    overflow is reported at the next call at the latest."""
+    keys = list(_RANGE_FLAGS) if device is None else [torch.device(device).index or 0]
+    for key in keys:
+        f = _RANGE_FLAGS.get(key)
+        if f is None:
+            continue
+        if sync:
+            torch.cuda.synchronize(key)
+        if int(f[0]) != 0:
+            f[0] = 0
+            raise L3DRangeError("an activation left the fp16 range (|x| > 60000) inside a f16x2 matrix-core kernel; its "
+                                "outputs were invalid.  Set learning3d_amd.models._fused.GEMM_ARITH = 'bf16x3' (full "
+                                "fp32 exponent range) and run again.")
+
+
+# EdgeConv kernel choice: "f16" / "split" / "chained" are the register-chained kernels in the three arithmetics above
+# (k <= 20); "lds" = the LDS-staged fp32-MFMA kernel (mlp.hip, any k <= 32).  None: by gemm_arith().
+EDGECONV_KERNEL = None
 
 
 def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256), kernel=None):
@@ -231,12 +283,17 @@ def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256), kernel=Non
     k = idx.shape[2]
     pooled = torch.empty((B, N, sum(widths)), dtype=torch.float32, device=xyz_bn3.device)
     if kernel is None:
-        kernel = EDGECONV_KERNEL if SPLIT_BF16 or EDGECONV_KERNEL != "split" else "chained"
-    if kernel not in ("split", "chained", "lds"):
+        kernel = EDGECONV_KERNEL or {"f16x2": "f16", "bf16x3": "split", "fp32": "chained"}[gemm_arith()]
+    if kernel not in ("f16", "split", "chained", "lds"):
         raise ValueError(f"unknown EdgeConv kernel {kernel!r}")
     if kernel != "lds" and (k > 20 or tuple(widths) != (64, 64, 128, 256)):
         kernel = "lds"
-    if kernel == "split":
+    if kernel == "f16":
+        check_range(xyz_bn3.device)                      # a previous launch's verdict, if it has completed
+        flag = range_flag(xyz_bn3.device)
+        check(lib().l3d_edgeconv_forward_f16(ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), ptr(pooled), ptr(flag),
+                                             stream_ptr()), "l3d_edgeconv_forward_f16")
+    elif kernel == "split":
         check(lib().l3d_edgeconv_forward_split(ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), ptr(pooled),
                                                stream_ptr()), "l3d_edgeconv_forward_split")
     elif kernel == "chained":

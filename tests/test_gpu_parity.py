@@ -498,9 +498,12 @@ def test_dgcnn_full_size_vs_oracle_port():
 
 
 def test_edgeconv_all_kernels_agree_and_ragged():
-    """LDS-staged (mlp.hip), register-chained fp32-MFMA (edgeconv2.hip) and register-chained bf16x3
-    (edgeconv_split.hip) EdgeConv kernels against a torch fp64 evaluation, including N not a multiple
-    of 16 and k < 20.  The bf16x3 kernel must be as close to fp64 as the fp32-MFMA kernels are."""
+    """LDS-staged (mlp.hip), register-chained fp32-MFMA (edgeconv2.hip), register-chained bf16x3
+    (edgeconv_split.hip) and register-chained f16x2 (edgeconv_f16.hip) EdgeConv kernels against a torch fp64
+    evaluation, including N not a multiple of 16 and k < 20.  The matrix-core kernels (bf16x3: six bf16 products per
+    fp32 product; f16x2: three fp16 products) must be as close to fp64 as the fp32-MFMA kernels are: max error
+    <= 2x, rms error <= 1.5x the fp32-MFMA kernel's own.  Also with activations scaled down 1000x / up 100x through
+    the BatchNorm weights (the f16x2 residual scaling and the weight scaling have to hold there)."""
     from learning3d_amd.models import DGCNN, _fused
     import learning3d_amd.utils as U
     torch.manual_seed(4)
@@ -508,14 +511,18 @@ def test_edgeconv_all_kernels_agree_and_ragged():
     for m in net.modules():
         if isinstance(m, torch.nn.BatchNorm2d):
             m.running_mean.uniform_(-0.1, 0.1); m.running_var.uniform_(0.8, 1.2)
-    for (B, N, k) in [(2, 1024, 20), (3, 203, 20), (2, 77, 16), (1, 50, 7)]:
+    for (B, N, k, gain) in [(2, 1024, 20, 1.0), (3, 203, 20, 1.0), (2, 77, 16, 1.0), (1, 50, 7, 1.0),
+                            (2, 512, 20, 1e-3), (2, 512, 20, 30.0)]:
         x = dev(rand((B, N, 3), 30 + N))
         with torch.no_grad():
+            net.bn1.weight.fill_(gain)                     # scales every activation of the stack
             idx = U.knn(x.permute(0, 2, 1), k)
             packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
             a = _fused.edgeconv_forward(x, idx, packed, kernel="lds")
             c = _fused.edgeconv_forward(x, idx, packed, kernel="chained")
             sp = _fused.edgeconv_forward(x, idx, packed, kernel="split")
+            f16 = _fused.edgeconv_forward(x, idx, packed, kernel="f16")
+            _fused.check_range(x.device, sync=True)
             # fp64 torch evaluation of dgcnn.py:32-46 on the same graph
             nb = torch.gather(x.unsqueeze(1).expand(B, N, N, 3), 2, idx.unsqueeze(-1).expand(B, N, k, 3))
             h = torch.cat([nb, x.unsqueeze(2).expand(B, N, k, 3)], dim=3).permute(0, 3, 1, 2).double()
@@ -529,10 +536,36 @@ def test_edgeconv_all_kernels_agree_and_ragged():
         np.testing.assert_allclose(a.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(c.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(sp.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(f16.cpu().numpy(), want, rtol=1e-4, atol=1e-5 * max(1.0, gain))
         e_c = np.abs(c.cpu().numpy() - want64)
-        e_s = np.abs(sp.cpu().numpy() - want64)
-        assert e_s.max() <= 2.0 * e_c.max() + 1e-30, (B, N, k, e_s.max(), e_c.max())
-        assert np.sqrt((e_s ** 2).mean()) <= 1.5 * np.sqrt((e_c ** 2).mean()), (B, N, k)
+        for name, got in (("bf16x3", sp), ("f16x2", f16)):
+            e_s = np.abs(got.cpu().numpy() - want64)
+            print(f"edgeconv {name} B={B} N={N} k={k} gain={gain}: max err {e_s.max():.3e} ({e_s.max() / e_c.max():.2f}x fp32-MFMA), "
+                  f"rms {np.sqrt((e_s ** 2).mean()):.3e} ({np.sqrt((e_s ** 2).mean()) / np.sqrt((e_c ** 2).mean()):.2f}x)")
+            assert e_s.max() <= 2.0 * e_c.max() + 1e-30, (name, B, N, k, gain, e_s.max(), e_c.max())
+            assert np.sqrt((e_s ** 2).mean()) <= 1.5 * np.sqrt((e_c ** 2).mean()), (name, B, N, k, gain)
+
+
+def test_edgeconv_f16_range_flag():
+    """f16x2 range contract: an activation beyond fp16's range raises the flag (and check_range raises); normal inputs
+    never do.  The flag lives in pinned host memory the kernel writes directly."""
+    from learning3d_amd.models import DGCNN, _fused
+    import learning3d_amd.utils as U
+    torch.manual_seed(4)
+    net = DGCNN(emb_dims=64).cuda().eval()
+    x = dev(rand((2, 256, 3), 77))
+    with torch.no_grad():
+        idx = U.knn(x.permute(0, 2, 1), 20)
+        get = lambda: net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
+        _fused.edgeconv_forward(x, idx, get(), kernel="f16")
+        _fused.check_range(x.device, sync=True)                         # fine
+        net.bn2.weight.fill_(1e6)                                        # layer-2 outputs ~1e5: beyond fp16
+        _fused.edgeconv_forward(x, idx, get(), kernel="f16")
+        with pytest.raises(_fused.L3DRangeError):
+            _fused.check_range(x.device, sync=True)
+        _fused.check_range(x.device, sync=True)                         # the flag was cleared by the raise
+        sp = _fused.edgeconv_forward(x, idx, get(), kernel="split")      # the wide-range kernel takes the same input
+        assert torch.isfinite(sp).all()
 
 
 def test_pointnet_golden(golden):
