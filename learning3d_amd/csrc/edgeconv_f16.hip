@@ -32,48 +32,70 @@
 #include "split_bf16.h"      // f32x2 / f32x4 typedefs
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ float ef_quad_max(float v)
-{
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
-    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
-    return v;
-}
-
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-#define EF_BF(u) __builtin_bit_cast(f16x8, (u))
-#ifndef EF_VPM
-#define EF_VPM 4            // VALU instructions the scheduler may place after each MFMA of a group
+
+// ---------------------------------------------------------------------------------------------
+// Register homes.  With __launch_bounds__(256, 1) hipcc selects the AGPR form of every MFMA builtin: accumulators
+// live in AGPRs and each value the finish work touches costs a v_accvgpr_read first -- measured at ~15 cycles apiece
+// beside the MFMA stream (4.7 k of layer 4's 22 k cycles went on moving accumulators, tools/probe_ef.hip).  The dense
+// layers therefore issue their MFMAs as volatile inline asm with the homes fixed by constraints:
+//     accumulators  VGPRs ("+v")  -- the finish VALU reads and writes them in place, no copies;
+//     B operands    AGPRs ("a")   -- the split activation planes are only ever MFMA operands (<= 240 registers);
+//     A operands    VGPRs ("v")   -- weight fragments arrive by global_load.
+// Volatile asm statements keep their program order, so the interleave of finish work and MFMAs below is the issue
+// order; the compiler still places the fragment loads, address arithmetic and s_waitcnt (asm operands are uses).
+// What it no longer does is pad MFMA hazards: every read of an accumulator by VALU code is >= 5 MFMAs after the
+// MFMA that wrote it (see the unit order), and the two places where that does not hold by construction carry s_nop.
+// ---------------------------------------------------------------------------------------------
+#ifndef EF_AHOME
+#define EF_AHOME 0          // weight fragments (MFMA A operand): 0 = VGPRs, 1 = AGPRs (global_load writes them directly)
 #endif
-
-// One output M-tile pair of a dense layer: 2 x S steps of {prefetch fragment step+2, 6 x MT MFMAs}.
-// ---------------------------------------------------------------------------------------------
-// The finish work of a completed M-tile pair (ReLU, max-pool, three-way split) cut into small units so
-// that it can be issued BETWEEN the MFMAs of the next pair: with one wave per SIMD nothing else hides
-// VALU work, and a VALU instruction issued in the shadow of a 16-cycle MFMA is free.
-//   per row tile t:  [relu+max of h0[t]] [relu+max of h1[t]] ([split h0[t], h1[t]] unless LAST)
-//   then [quad max + store of M-tile 2s] [same for 2s+1]
-// ---------------------------------------------------------------------------------------------
-template <bool LAST> struct EfUnits { static constexpr int PER_T = LAST ? 2 : 3; };
-
-// Home a freshly split fragment word in the accumulation half of the register file: the layer-4
-// input planes (240 registers for MT = 5) are only ever read as MFMA B operands, which may be AGPRs;
-// left to itself the allocator keeps them in VGPRs, runs out, and reloads spilled words before every use.
-__device__ __forceinline__ uint32_t ef_to_agpr(uint32_t v)
+#if EF_AHOME
+#define EF_ACON "a"
+#else
+#define EF_ACON "v"
+#endif
+__device__ __forceinline__ void ef_mfma_init(f32x4 &d, const u32x4 &a, const f16x8 &b, const f32x4 &c)
 {
-    uint32_t r;
-    asm("v_accvgpr_write_b32 %0, %1" : "=a"(r) : "v"(v));
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(d) : EF_ACON(a), "a"(b), "v"(c));
+}
+__device__ __forceinline__ void ef_mfma_acc(f32x4 &d, const u32x4 &a, const f16x8 &b)
+{
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : EF_ACON(a), "a"(b));
+}
+// a freshly split 16-byte fragment -> an AGPR tuple, once, at its creation
+__device__ __forceinline__ f16x8 ef_home_agpr(u32x4 v)
+{
+    f16x8 r = __builtin_bit_cast(f16x8, v);
+    asm("" : "+a"(r));
     return r;
 }
 
-// v_max_f32 written out: fmaxf() on an MFMA result costs a second, canonicalising v_max x,x,x.  Only
-// used where the accumulator was written hundreds of cycles earlier (the pipelined units): the
-// compiler does not pad MFMA -> VALU hazards around inline asm.
-template <bool RAW> __device__ __forceinline__ float ef_max(float a, float b)
+// VALU written out (volatile: issue position = program position)
+__device__ __forceinline__ float ef_vmax(float a, float b)
 {
-    if (!RAW) return fmaxf(a, b);
     float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    asm volatile("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float ef_vmax3(float a, float b, float c)
+{
+    float r;
+    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// d[lane] = max(give[lane ^ 1], keep[lane]) / (lane ^ 2).  The s_nop covers the VALU-write -> DPP-read hazard (2 wait
+// states) that the compiler's hazard recogniser does not see inside inline asm.
+__device__ __forceinline__ float ef_dpp_max_x1(float give, float keep)
+{
+    float r;
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(give), "v"(keep));
+    return r;
+}
+__device__ __forceinline__ float ef_dpp_max_x2(float give, float keep)
+{
+    float r;
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(give), "v"(keep));
     return r;
 }
 
@@ -82,50 +104,94 @@ template <bool RAW> __device__ __forceinline__ float ef_max(float a, float b)
 __device__ __forceinline__ void ef_split_pair(float a0, float a1, float c, uint32_t &h, uint32_t &m)
 {
     float r0, r1;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a0), "v"(c));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(a1), "v"(c));
-    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a0), "v"(c), "v"(h));
-    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(a1), "v"(c), "v"(h));
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(m) : "v"(r0), "s"(4096.0f));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(m) : "v"(r1), "s"(4096.0f));
+    asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a0), "v"(c));
+    asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(a1), "v"(c));
+    asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a0), "v"(c), "v"(h));
+    asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(a1), "v"(c), "v"(h));
+    asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(m) : "v"(r0), "s"(4096.0f));
+    asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(m) : "v"(r1), "s"(4096.0f));
 }
 
-// c: 2^-S of the layer whose accumulators h holds (1 for layer 1); ovf: running maximum of the pooled outputs
-template <int MT, bool LAST, bool AGPR_OUT, bool RAW, int U>
-__device__ __forceinline__ void ef_finish_unit_c(f32x4 (&h)[2][MT], f16x8 (&pl)[2][MT], f32x4 (&mx)[2],
-                                                 float *__restrict__ dst, bool writer, float c, float &ovf)
+// Lane-constant context of the pooled stores.  q = lane & 3 (neighbour slot inside the quad); after the transposing
+// quad reduce lane q holds channel register {0,2,1,3}[q] of its point, and stores it to pooled[point][ch0 + 4g + that].
+struct EfLane {
+    bool odd, hi;            // q & 1, q & 2
+    float *prow;             // pooled + (b N + point) CTOT + 4 g + {0,2,1,3}[q]
+};
+
+// Scratch values that live from one micro-unit to the next
+struct EfTmp {
+    f32x4 mx[2];             // max over the row tiles, per M-tile
+    u32x4 qh, qm;            // the 16-byte h / m' fragments being assembled for one row tile
+    f32x2 xs[2];             // quad reduce, after its first step
+};
+
+// ---------------------------------------------------------------------------------------------
+// The finish work of a completed M-tile pair (ReLU, two-plane split, max-pool) as MICRO-UNITS of 2-8 VALU instructions,
+// issued one by one between the MFMAs of the next pair (with one wave per SIMD nothing else hides VALU work):
+//   not LAST:  per row tile t: [relu h0[t]] [relu h1[t]] [split pair 0] [1] [2] [3 + the two fragments -> AGPRs]
+//              then 8 x [pool one register of one M-tile], 2 x ([quad reduce, step 1] [step 2 + store])  = 6 MT + 12
+//   LAST:      the 8 pool and 4 quad units on the raw accumulators, ReLU on the one pooled value per lane      = 12
+// ORDER is the MFMA -> VALU hazard cover: the first units touch M-tile 0 only (finished a whole step earlier);
+// h1[MT-1], written by the pair's very last MFMA, is first read by unit 6 (MT-1) + 1 resp. pool unit 4.
+// The quad reduce is a transposing butterfly: 4 registers x 4 lanes -> ONE value per lane in 3 DPP max (+6 selects),
+// and every lane stores its dword -- no `if (writer)` exec-mask branch.
+// RAW = false (layer 1's accumulators come from MFMA builtins, straight after them): the first reader of every
+// accumulator is a compiler-visible instruction, so the compiler pads the hazard.
+// ---------------------------------------------------------------------------------------------
+template <int MT, bool LAST> struct EfN { static constexpr int UNITS = LAST ? 12 : 6 * MT + 12; };
+
+template <int MT, bool LAST, bool RAW, int U>
+__device__ __forceinline__ void ef_micro(f32x4 (&h)[2][MT], f16x8 (&pl)[2][MT], EfTmp &T, int ch0, const EfLane &L, float c, float &ovf)
 {
-    constexpr int PER_T = EfUnits<LAST>::PER_T;
-    constexpr int t = U / PER_T, k = U % PER_T;
-    if constexpr (t < MT && k < 2) {                         // relu + running max of M-tile k
+    constexpr int NT = LAST ? 0 : 6 * MT;                    // units before the pool units
+    if constexpr (U < NT) {
+        constexpr int t = U / 6, k = U % 6;
+        if constexpr (k < 2) {                               // relu of M-tile k, row tile t
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            h[k][t][r] = ef_max<RAW>(h[k][t][r], 0.f);
-            mx[k][r] = t == 0 ? h[k][t][r] : ef_max<RAW>(mx[k][r], h[k][t][r]);
+            for (int r = 0; r < 4; r++) h[k][t][r] = RAW ? ef_vmax(h[k][t][r], 0.f) : fmaxf(h[k][t][r], 0.f);
+        } else {                                             // split value pair k-2 of the (M-tile pair, row tile t) fragment
+            constexpr int i = k - 2;
+            uint32_t a, b;
+            ef_split_pair(h[i >> 1][t][2 * (i & 1)], h[i >> 1][t][2 * (i & 1) + 1], c, a, b);
+            T.qh[i] = a;
+            T.qm[i] = b;
+            if constexpr (i == 3) {                          // whole 16-byte fragments, homed in AGPRs: the type the MFMA reads
+                pl[0][t] = ef_home_agpr(T.qh);
+                pl[1][t] = ef_home_agpr(T.qm);
+            }
         }
-    } else if constexpr (t < MT) {                           // split both M-tiles of row tile t
-        // whole 16-byte fragments are written at once: component-wise stores into the plane arrays
-        // defeat their promotion to registers (the MFMA reads them back as one 8 x f16 vector)
-        uint32_t q[4][2];
-        ef_split_pair(h[0][t][0], h[0][t][1], c, q[0][0], q[0][1]);
-        ef_split_pair(h[0][t][2], h[0][t][3], c, q[1][0], q[1][1]);
-        ef_split_pair(h[1][t][0], h[1][t][1], c, q[2][0], q[2][1]);
-        ef_split_pair(h[1][t][2], h[1][t][3], c, q[3][0], q[3][1]);
+    } else if constexpr (U < NT + 8) {                       // max over the row tiles (= 4 MT neighbours), one register
+        constexpr int k = (U - NT) / 4, r = (U - NT) % 4;
+        static_assert(MT >= 3 && MT <= 5, "row tiles per wave");
+        if constexpr (RAW) {
+            float m = ef_vmax3(h[k][0][r], h[k][1][r], h[k][2][r]);
+            if constexpr (MT == 4) m = ef_vmax(m, h[k][3][r]);
+            if constexpr (MT == 5) m = ef_vmax3(m, h[k][3][r], h[k][4][r]);
+            T.mx[k][r] = m;
+        } else {
+            float m = h[k][0][r];
 #pragma unroll
-        for (int p = 0; p < 2; p++) {
-            const u32x4 v = {AGPR_OUT ? ef_to_agpr(q[0][p]) : q[0][p], AGPR_OUT ? ef_to_agpr(q[1][p]) : q[1][p],
-                             AGPR_OUT ? ef_to_agpr(q[2][p]) : q[2][p], AGPR_OUT ? ef_to_agpr(q[3][p]) : q[3][p]};
-            pl[p][t] = __builtin_bit_cast(f16x8, v);         // one 16-byte value: the type the MFMA reads
+            for (int t = 1; t < MT; t++) m = fmaxf(m, h[k][t][r]);
+            T.mx[k][r] = m;
         }
-    } else {                                                 // U = MT*PER_T + k, k = 0, 1: pooled store
-        f32x4 v;
-#pragma unroll
-        for (int r = 0; r < 4; r++) v[r] = ef_quad_max(mx[k][r]) * c;
-        if (!LAST) ovf = fmaxf(fmaxf(ovf, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));    // only split layers matter
-        if (writer) *(f32x4 *)(dst + 16 * k) = v;
+    } else {                                                 // transposing quad reduce, ReLU (LAST), scale, store
+        constexpr int k = (U - NT - 8) / 2, part = (U - NT - 8) % 2;
+        if constexpr (part == 0) {
+            const float k0 = L.odd ? T.mx[k][2] : T.mx[k][0], g0 = L.odd ? T.mx[k][0] : T.mx[k][2];
+            const float k1 = L.odd ? T.mx[k][3] : T.mx[k][1], g1 = L.odd ? T.mx[k][1] : T.mx[k][3];
+            T.xs[k][0] = ef_dpp_max_x1(g0, k0);
+            T.xs[k][1] = ef_dpp_max_x1(g1, k1);
+        } else {
+            const float kk = L.hi ? T.xs[k][1] : T.xs[k][0], gg = L.hi ? T.xs[k][0] : T.xs[k][1];
+            float v = ef_dpp_max_x2(gg, kk);
+            if constexpr (LAST) v = ef_vmax(v, 0.f);         // non-LAST values were ReLU'd before pooling
+            v *= c;
+            if constexpr (!LAST) ovf = ef_vmax(ovf, v);      // only layers whose output is split matter
+            L.prow[ch0 + 16 * k] = v;
+        }
     }
 }
-template <int MT, bool LAST> struct EfN { static constexpr int UNITS = MT * EfUnits<LAST>::PER_T + 2; };
 
 // Compile-time loops: every register-array index in this file must be a constant, and `#pragma unroll`
 // is only a request (bodies this large exceed the unroller's pragma threshold, the loop stays rolled,
@@ -139,14 +205,11 @@ __device__ __forceinline__ void ef_static_for(F &&f)
     }
 }
 
-template <int MT, bool LAST, bool AGPR_OUT = false>
-__device__ __forceinline__ void ef_finish_all(f32x4 (&h)[2][MT], f16x8 (&pl)[2][MT], float *__restrict__ dst, bool writer,
-                                              float c, float &ovf)
+template <int MT, bool LAST, bool RAW>
+__device__ __forceinline__ void ef_finish_all(f32x4 (&h)[2][MT], f16x8 (&pl)[2][MT], int ch0, const EfLane &L, float c, float &ovf)
 {
-    f32x4 mx[2];
-    ef_static_for<0, EfN<MT, LAST>::UNITS>([&](auto u) {
-        ef_finish_unit_c<MT, LAST, AGPR_OUT, false, decltype(u)::value>(h, pl, mx, dst, writer, c, ovf);
-    });
+    EfTmp T;
+    ef_static_for<0, EfN<MT, LAST>::UNITS>([&](auto u) { ef_micro<MT, LAST, RAW, decltype(u)::value>(h, pl, T, ch0, L, c, ovf); });
 }
 
 // EF_PIN: the compiler's IR passes sink a load towards its first use (two steps later) regardless of
@@ -155,62 +218,65 @@ __device__ __forceinline__ void ef_finish_all(f32x4 (&h)[2][MT], f16x8 (&pl)[2][
 #define EF_PIN() asm volatile("" ::: "memory")
 
 // One output M-tile pair of a dense layer: 2 x S steps (k-step outer, M-tile inner -- the order the
-// fragments are packed in) of {prefetch fragment step+2, 3 groups of MT MFMAs}, with the finish units
-// of a PREVIOUS pair (hp, if HAS_PREV) spread over the first NGU groups.  That previous pair is the
-// preceding pair of this layer (NGU = all groups) or, for a layer's first pair, the LAST pair of the
-// previous layer, whose planes are this layer's k-step S-1: its units then ride on the groups of
-// k-steps 0 .. S-2 only (NGU = (S-1)*6) and are complete before the first MFMA that reads them.
+// fragments are packed in) of {prefetch fragment step+2, 3 products x MT MFMAs}, with one micro-unit of the finish of a
+// PREVIOUS pair (hp) after each of the first NSL MFMAs.  That previous pair is the preceding pair of this layer
+// (NSL = every MFMA slot) or, for a layer's first pair, the LAST pair of the previous layer, whose planes are this
+// layer's k-step S-1: its units then ride on the MFMAs of k-steps 0 .. S-2 only and are complete (plus an s_nop for
+// the accvgpr-write -> MFMA-read hazard) before the first MFMA that reads them.
 // mp = this pair, mp_next = the pair executed after it (fragment and bias prefetches cross the pair
-// boundary); pairs may be executed in any order.  bv: this pair's bias, loaded during the previous
-// pair; replaced by the next pair's on return.  c_prev: 2^-S of the layer the previous pair belongs to.
-template <int MT, int S, bool HAS_PREV, bool PREV_LAST, bool PREV_AGPR, int NGU>
+// boundary); pairs may be executed in any order.  bv: this pair's bias (the MFMA C operand of each M-tile's first
+// product), loaded during the previous pair; replaced by the next pair's on return.  c_prev: 2^-S of hp's layer.
+template <int MT, int S, bool PREV_LAST, bool PREV_RAW, int NSL>
 __device__ __forceinline__ void ef_pair(int mp, int mp_next, const f16x8 (&pin)[S][2][MT], const f16x8 (&pin_last)[2][MT],
-                                        const uint4 *wp,
-                                        uint4 (&a0)[3], uint4 (&a1)[3], f32x4 (&bv)[2], const float *__restrict__ bias,
+                                        const u32x4 *wp,
+                                        u32x4 (&a0)[3], u32x4 (&a1)[3], f32x4 (&bv)[2], const float *__restrict__ bias,
                                         f32x4 (&acc)[2][MT], f32x4 (&hp)[2][MT], f16x8 (&po_prev)[2][MT],
-                                        float *__restrict__ dst_prev, bool writer_prev, int g, float c_prev, float &ovf)
+                                        int ch_prev, const EfLane &L, int g, float c_prev, float &ovf)
 {
-    constexpr int NU = HAS_PREV ? EfN<MT, PREV_LAST>::UNITS : 0;    // finish units to hide
-#pragma unroll
-    for (int mm = 0; mm < 2; mm++)
-#pragma unroll
-        for (int t = 0; t < MT; t++) acc[mm][t] = bv[mm];
-    bv[0] = *(const f32x4 *)(bias + 32 * mp_next + 4 * g);
-    bv[1] = *(const f32x4 *)(bias + 32 * mp_next + 16 + 4 * g);
-    f32x4 mx[2];
+    constexpr int NU = EfN<MT, PREV_LAST>::UNITS;                    // micro-units to hide
+    EfTmp T;
     ef_static_for<0, 2 * S>([&](auto rc) {
         // execution step r = 2 s + mm; fragment two steps ahead: inside this pair, or the first two of the next
         constexpr int r = decltype(rc)::value, s = r >> 1, mm = r & 1;
         const int nxt = r + 2 < 2 * S ? mp * 2 * S + r + 2 : mp_next * 2 * S + (r + 2 - 2 * S);
-        uint4 a2[3];
+        u32x4 a2[3];
 #pragma unroll
         for (int p = 0; p < 3; p++) a2[p] = wp[(size_t)(nxt * 3 + p) * 64];
         EF_PIN();
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (s == S - 1 && mm == 0 && NSL < 2 * S * 3 * MT)
+            asm volatile("s_nop 7");                                  // pin_last was written by v_accvgpr_write just now
         // three products, smallest first (M h, Hs m', H h); MT independent accumulators between dependent MFMAs
         ef_static_for<0, 3>([&](auto pc) {
             constexpr int prod = decltype(pc)::value;
             constexpr int pa = prod == 0 ? 2 : (prod == 1 ? 1 : 0);                   // W plane: M  Hs H   (packed H, Hs, M)
             constexpr int pb = prod == 1 ? 1 : 0;                                     // x plane: h  m' h
+            ef_static_for<0, MT>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                const f16x8 &bop = s == S - 1 ? pin_last[pb][t] : pin[s][pb][t];
+                if constexpr (s == 0 && prod == 0) ef_mfma_init(acc[mm][t], a0[pa], bop, bv[mm]);
+                else ef_mfma_acc(acc[mm][t], a0[pa], bop);
+                constexpr int slot = (r * 3 + prod) * MT + t;
+#ifdef EF_NOFINISH                                                     // timing experiment: accumulators kept alive, no finish work
+                if constexpr (slot == 0) {
 #pragma unroll
-            for (int t = 0; t < MT; t++)
-                acc[mm][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(EF_BF(a0[pa]), (s == S - 1 ? pin_last[pb][t] : pin[s][pb][t]),
-                                                                    acc[mm][t], 0, 0, 0);
-            constexpr int gi = r * 3 + prod;
-            if constexpr (HAS_PREV && gi < NGU) {
-                ef_static_for<gi * NU / NGU, (gi + 1) * NU / NGU>([&](auto u) {
-                    ef_finish_unit_c<MT, PREV_LAST, PREV_AGPR, true, decltype(u)::value>(hp, po_prev, mx, dst_prev, writer_prev,
-                                                                                          c_prev, ovf);
-                });
-                // issue order inside the group: one MFMA, then a few of the unit's VALU instructions
+                    for (int kk = 0; kk < 2; kk++)
 #pragma unroll
-                for (int t = 0; t < MT; t++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, EF_VPM, 0);
+                        for (int tt = 0; tt < MT; tt++) asm volatile("" ::"v"(hp[kk][tt]));
                 }
-            }
-            __builtin_amdgcn_sched_barrier(0);
+                if constexpr (false)
+#else
+                if constexpr (slot < NSL)
+#endif
+                    ef_static_for<slot * NU / NSL, (slot + 1) * NU / NSL>([&](auto u) {
+                        ef_micro<MT, PREV_LAST, PREV_RAW, decltype(u)::value>(hp, po_prev, T, ch_prev, L, c_prev, ovf);
+                    });
+            });
         });
+        if constexpr (r == 1) {                                       // both M-tiles have consumed their bias: fetch the next pair's
+            bv[0] = *(const f32x4 *)(bias + 32 * mp_next + 4 * g);
+            bv[1] = *(const f32x4 *)(bias + 32 * mp_next + 16 + 4 * g);
+            EF_PIN();
+        }
 #pragma unroll
         for (int p = 0; p < 3; p++) { a0[p] = a1[p]; a1[p] = a2[p]; }
     });
@@ -219,23 +285,23 @@ __device__ __forceinline__ void ef_pair(int mp, int mp_next, const f16x8 (&pin)[
 // One dense layer: S input k-steps (32 channels each, planes in pin), NPAIR output M-tile pairs,
 // software-pipelined over pairs (accumulators double-buffered: pair i's MFMAs hide pair i-1's finish).
 // On entry accB holds the previous layer's last, unfinished pair (its planes are pin[S-1], its pooled
-// output goes to dst_in); on return accB holds THIS layer's last unfinished pair (pair index *mp_out).
+// output goes to channel ch_in); on return accB holds THIS layer's last unfinished pair (pair index *mp_out).
 // wl: [step = (pair*S + s)*2 + mm][plane][lane] fragments, prefetched two steps ahead.  rot (only for
-// the rolled LAST layer, where no register array is indexed by the pair): this workgroup starts at pair
-// `rot`.  IN_AGPR: pin's planes are homed in AGPRs; OUT_AGPR: this layer's output planes are.
+// the rolled LAST layer, where no register array is indexed by the pair): this workgroup starts at pair `rot`.
+// IN_RAW: accB on entry was produced by asm MFMAs (layers >= 2) rather than builtins (layer 1).
 // c_in / c_own: 2^-S of the previous layer (whose last pair is finished here) and of this layer; bias is pre-scaled.
-template <int MT, int S, int NPAIR, bool LAST, bool UNROLL, bool IN_AGPR, bool OUT_AGPR>
+template <int MT, int S, int NPAIR, bool LAST, bool UNROLL, bool IN_RAW>
 __device__ __forceinline__ void ef_layer(const f16x8 (&pin)[S][2][MT], f16x8 (&pout)[LAST ? 1 : NPAIR][2][MT],
-                                         const uint4 *wl, const float *__restrict__ bias, float *__restrict__ prow,
-                                         f32x4 (&accA)[2][MT], f32x4 (&accB)[2][MT], float *__restrict__ dst_in,
-                                         int *mp_out, bool writer, int lane, int g, int rot, float c_in, float c_own, float &ovf)
+                                         const u32x4 *wl, const float *__restrict__ bias, int ch_own,
+                                         f32x4 (&accA)[2][MT], f32x4 (&accB)[2][MT], int ch_in,
+                                         int *mp_out, const EfLane &L, int lane, int g, int rot, float c_in, float c_own, float &ovf)
 {
     static_assert(NPAIR % 2 == 0 && S >= 2, "pairs are processed two at a time; deferred finish needs S >= 2");
-    constexpr int NG = 2 * S * 3, NGD = (S - 1) * 6;
-    f16x8 last[2][MT];             // planes of k-step S-1: produced here by the deferred finish (pin[S-1] is never written)
-    const uint4 *wp = wl + lane;
+    constexpr int NS = 2 * S * 3 * MT, NSD = (S - 1) * 6 * MT;      // MFMA slots of a pair; of its k-steps 0 .. S-2
+    f16x8 last[2][MT];              // planes of k-step S-1: produced here by the deferred finish (pin[S-1] is never written)
+    const u32x4 *wp = wl + lane;
     const int first = UNROLL ? 0 : rot;
-    uint4 a0[3], a1[3];
+    u32x4 a0[3], a1[3];
     f32x4 bv[2];
 #pragma unroll
     for (int p = 0; p < 3; p++) {
@@ -249,24 +315,24 @@ __device__ __forceinline__ void ef_layer(const f16x8 (&pin)[S][2][MT], f16x8 (&p
         // written out (NPAIR is 2 or 4): a `#pragma unroll` loop over this much code is not always
         // unrolled, and a rolled loop indexes pout dynamically, which sends the planes to scratch
         static_assert(NPAIR == 2 || NPAIR == 4, "unrolled layers have 2 or 4 output pairs");
-        ef_pair<MT, S, true, false, IN_AGPR, NGD>(0, 1, pin, last, wp, a0, a1, bv, bias, accA, accB, last, dst_in, writer, g, c_in, ovf);
-        ef_pair<MT, S, true, LAST, OUT_AGPR, NG>(1, NPAIR > 2 ? 2 : 1, pin, last, wp, a0, a1, bv, bias, accB, accA, pout[0], prow, writer, g, c_own, ovf);
+        ef_pair<MT, S, false, IN_RAW, NSD>(0, 1, pin, last, wp, a0, a1, bv, bias, accA, accB, last, ch_in, L, g, c_in, ovf);
+        ef_pair<MT, S, LAST, true, NS>(1, NPAIR > 2 ? 2 : 1, pin, last, wp, a0, a1, bv, bias, accB, accA, pout[0], ch_own, L, g, c_own, ovf);
         if constexpr (NPAIR == 4) {
-            ef_pair<MT, S, true, LAST, OUT_AGPR, NG>(2, 3, pin, last, wp, a0, a1, bv, bias, accA, accB, pout[1], prow + 32, writer, g, c_own, ovf);
-            ef_pair<MT, S, true, LAST, OUT_AGPR, NG>(3, 3, pin, last, wp, a0, a1, bv, bias, accB, accA, pout[2], prow + 64, writer, g, c_own, ovf);
+            ef_pair<MT, S, LAST, true, NS>(2, 3, pin, last, wp, a0, a1, bv, bias, accA, accB, pout[1], ch_own + 32, L, g, c_own, ovf);
+            ef_pair<MT, S, LAST, true, NS>(3, 3, pin, last, wp, a0, a1, bv, bias, accB, accA, pout[2], ch_own + 64, L, g, c_own, ovf);
         }
         *mp_out = NPAIR - 1;
     } else {
         const int q0 = rot % NPAIR, q1 = (1 + rot) % NPAIR, q2 = (2 + rot) % NPAIR;
-        ef_pair<MT, S, true, false, IN_AGPR, NGD>(q0, q1, pin, last, wp, a0, a1, bv, bias, accA, accB, last, dst_in, writer, g, c_in, ovf);
-        ef_pair<MT, S, true, LAST, OUT_AGPR, NG>(q1, q2, pin, last, wp, a0, a1, bv, bias, accB, accA, pout[0], prow + 32 * q0, writer, g, c_own, ovf);
+        ef_pair<MT, S, false, IN_RAW, NSD>(q0, q1, pin, last, wp, a0, a1, bv, bias, accA, accB, last, ch_in, L, g, c_in, ovf);
+        ef_pair<MT, S, LAST, true, NS>(q1, q2, pin, last, wp, a0, a1, bv, bias, accB, accA, pout[0], ch_own + 32 * q0, L, g, c_own, ovf);
         int mpB = q1;                                                   // pair whose results sit in accB
 #pragma unroll 1
         for (int i = 2; i < NPAIR; i += 2) {
             const int m0 = (i + rot) % NPAIR, m1 = (i + 1 + rot) % NPAIR, m2 = (i + 2 + rot) % NPAIR;
-            ef_pair<MT, S, true, LAST, OUT_AGPR, NG>(m0, m1, pin, last, wp, a0, a1, bv, bias, accA, accB, pout[0], prow + 32 * mpB, writer, g, c_own, ovf);
-            ef_pair<MT, S, true, LAST, OUT_AGPR, NG>(m1, i + 2 < NPAIR ? m2 : m1, pin, last, wp, a0, a1, bv, bias, accB, accA, pout[0],
-                                                    prow + 32 * m0, writer, g, c_own, ovf);
+            ef_pair<MT, S, LAST, true, NS>(m0, m1, pin, last, wp, a0, a1, bv, bias, accA, accB, pout[0], ch_own + 32 * mpB, L, g, c_own, ovf);
+            ef_pair<MT, S, LAST, true, NS>(m1, i + 2 < NPAIR ? m2 : m1, pin, last, wp, a0, a1, bv, bias, accB, accA, pout[0],
+                                           ch_own + 32 * m0, L, g, c_own, ovf);
             mpB = m1;
         }
         *mp_out = mpB;
@@ -297,8 +363,12 @@ __global__ __launch_bounds__(256, 1) void edgeconv_f16_kernel(const float *__res
     const int b = blockIdx.y;
     const int n = (blockIdx.x * 4 + wave) * 4 + (j >> 2);          // this lane's point
     const int nc = min(n, N - 1);
-    const bool writer = (n < N) && ((j & 3) == 0);
-    float *prow = pooled + ((size_t)b * N + nc) * CTOT + 4 * g;
+    // pooled stores: after the transposing quad reduce lane q = j & 3 holds channel register {0,2,1,3}[q] of its point;
+    // lanes past N recompute point N-1 and store the same bits to the same place
+    EfLane L;
+    L.odd = j & 1;
+    L.hi = j & 2;
+    L.prow = pooled + ((size_t)b * N + nc) * CTOT + 4 * g + ((j & 1) * 2 + ((j >> 1) & 1));
     // 2^-S of layers 2..4 (uniform: scalar loads)
     const float c2 = packed[EC4_OFF_SC], c3 = packed[EC4_OFF_SC + 1], c4 = packed[EC4_OFF_SC + 2];
     float ovf = 0.f;
@@ -337,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void edgeconv_f16_kernel(const float *__res
                     for (int t = 0; t < MT; t++)
                         accB[mm][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[t][s], accB[mm][t], 0, 0, 0);
             }
-            if (mp + 1 < EC_C1 / 32) ef_finish_all<MT, false>(accB, p1[mp], prow + 32 * mp, writer, 1.0f, ovf);
+            if (mp + 1 < EC_C1 / 32) ef_finish_all<MT, false, false>(accB, p1[mp], 32 * mp, L, 1.0f, ovf);
         }
     }
     int mp_last;
@@ -345,15 +415,15 @@ __global__ __launch_bounds__(256, 1) void edgeconv_f16_kernel(const float *__res
     EF_T(2);
     // ---- layer 2: 64 -> 64   (its first pair hides the finish of layer 1's last pair, and so on down)
     f16x8 p2[EC_C2 / 32][2][MT];
-    ef_layer<MT, EC_C1 / 32, EC_C2 / 32, false, true, false, false>(
-        p1, p2, (const uint4 *)(packed + EC4_OFF_W2), packed + EC4_OFF_B2, prow + EC_C1, accA, accB,
-        prow + 32 * (EC_C1 / 32 - 1), &mp_last, writer, lane, g, 0, 1.0f, c2, ovf);
+    ef_layer<MT, EC_C1 / 32, EC_C2 / 32, false, true, false>(
+        p1, p2, (const u32x4 *)(packed + EC4_OFF_W2), packed + EC4_OFF_B2, EC_C1, accA, accB,
+        32 * (EC_C1 / 32 - 1), &mp_last, L, lane, g, 0, 1.0f, c2, ovf);
     EF_T(3);
     // ---- layer 3: 64 -> 128
     f16x8 p3[EC_C3 / 32][2][MT];
-    ef_layer<MT, EC_C2 / 32, EC_C3 / 32, false, true, false, (MT > 4)>(
-        p2, p3, (const uint4 *)(packed + EC4_OFF_W3), packed + EC4_OFF_B3, prow + EC_C1 + EC_C2, accA, accB,
-        prow + EC_C1 + 32 * (EC_C2 / 32 - 1), &mp_last, writer, lane, g, 0, c2, c3, ovf);
+    ef_layer<MT, EC_C2 / 32, EC_C3 / 32, false, true, true>(
+        p2, p3, (const u32x4 *)(packed + EC4_OFF_W3), packed + EC4_OFF_B3, EC_C1 + EC_C2, accA, accB,
+        EC_C1 + 32 * (EC_C2 / 32 - 1), &mp_last, L, lane, g, 0, c2, c3, ovf);
     EF_T(4);
     // ---- layer 4: 128 -> 256, only max-pooled
     f16x8 dummy[1][2][MT];
@@ -361,10 +431,11 @@ __global__ __launch_bounds__(256, 1) void edgeconv_f16_kernel(const float *__res
 #define EF_ROT 1
 #endif
     const int rot = EF_ROT ? (int)(((blockIdx.x + gridDim.x * blockIdx.y) >> 3) % (EC_C4 / 32)) : 0;   // >>3: ids = XCD mod 8
-    ef_layer<MT, EC_C3 / 32, EC_C4 / 32, true, false, (MT > 4), false>(
-        p3, dummy, (const uint4 *)(packed + EC4_OFF_W4), packed + EC4_OFF_B4, prow + EC_C1 + EC_C2 + EC_C3, accA, accB,
-        prow + EC_C1 + EC_C2 + 32 * (EC_C3 / 32 - 1), &mp_last, writer, lane, g, rot, c3, c4, ovf);
-    ef_finish_all<MT, true>(accB, dummy[0], prow + EC_C1 + EC_C2 + EC_C3 + 32 * mp_last, writer, c4, ovf);
+    ef_layer<MT, EC_C3 / 32, EC_C4 / 32, true, false, true>(
+        p3, dummy, (const u32x4 *)(packed + EC4_OFF_W4), packed + EC4_OFF_B4, EC_C1 + EC_C2 + EC_C3, accA, accB,
+        EC_C1 + EC_C2 + 32 * (EC_C3 / 32 - 1), &mp_last, L, lane, g, rot, c3, c4, ovf);
+    asm volatile("s_nop 15\n\ts_nop 15");                       // the last asm MFMAs must have written accB (no compiler padding)
+    ef_finish_all<MT, true, true>(accB, dummy[0], EC_C1 + EC_C2 + EC_C3 + 32 * mp_last, L, c4, ovf);
     EF_T(5);
     // fp16 range guard: ovf = the largest layer-1..3 activation this lane pooled (post-ReLU, so the pooled maxima
     // are the maxima).  Never taken for BatchNorm'd networks; the host re-runs on the bf16x3 kernel if it is.
