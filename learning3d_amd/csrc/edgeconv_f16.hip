@@ -33,6 +33,8 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct EfBase { const char *p; };     // the packed parameter block
+typedef EfBase ef_rsrc_t;
 
 // ---------------------------------------------------------------------------------------------
 // Register homes.  With __launch_bounds__(256, 1) hipcc selects the AGPR form of every MFMA builtin: accumulators
@@ -48,7 +50,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // MFMA that wrote it (see the unit order), and the two places where that does not hold by construction carry s_nop.
 // ---------------------------------------------------------------------------------------------
 #ifndef EF_AHOME
-#define EF_AHOME 0          // weight fragments (MFMA A operand): 0 = VGPRs, 1 = AGPRs (global_load writes them directly)
+#define EF_AHOME 1          // weight fragments (MFMA A operand): 0 = VGPRs, 1 = AGPRs (global_load writes them directly)
 #endif
 #if EF_AHOME
 #define EF_ACON "a"
@@ -116,6 +118,8 @@ __device__ __forceinline__ void ef_split_pair(float a0, float a1, float c, uint3
 // quad reduce lane q holds channel register {0,2,1,3}[q] of its point, and stores it to pooled[point][ch0 + 4g + that].
 struct EfLane {
     bool odd, hi;            // q & 1, q & 2
+    unsigned laneoff;        // lane * 16: byte offset of the lane's 16 bytes inside a 1 KB fragment
+    ef_rsrc_t rs;            // the packed parameter block
     float *prow;             // pooled + (b N + point) CTOT + 4 g + {0,2,1,3}[q]
 };
 
@@ -217,31 +221,72 @@ __device__ __forceinline__ void ef_finish_all(f32x4 (&h)[2][MT], f16x8 (&pl)[2][
 // (the fragment pointer is deliberately NOT __restrict__, or the clobber would not order the load).
 #define EF_PIN() asm volatile("" ::: "memory")
 
+// Weight fragments are prefetched EF_PD execution steps ahead into a ring of registers that is handed from pair to
+// pair and from layer to layer.  A step is only 3 x MT MFMAs (~250 cycles): two steps ahead (what the bf16x3 kernel,
+// with 6 x MT MFMAs per step, gets away with) is less than an L2 hit under load and stalled every step.
+#ifndef EF_PD
+#define EF_PD 4
+#endif
+struct EfRing {
+    u32x4 a[EF_PD][3];       // fragments (H, Hs, M planes) of the next EF_PD steps
+    f32x4 bv[2];             // bias (pre-scaled) of the current pair's two M-tiles
+};
+struct EfNext {              // where the pair executed after this one finds its fragments / bias
+    int woff;                // byte offset of the layer's fragment block inside the packed parameters
+    const float *bias;       // layer's scaled bias + 4 g
+    int mp;                  // pair index inside that layer
+    int steps;               // 2 S of that layer
+};
+
+// fragment `frag` (1 KB each) of the layer block at byte offset `byte_off` of the packed parameters.
+// Measured alternatives for the addressing (tools/probe_ef.hip, layer 4): plain pointers as here 19.9 k cycles (the
+// compiler spends ~50 VALU per 240 MFMAs on 64-bit address arithmetic); a buffer descriptor with scalar offsets
+// (no VALU at all) 20.9 k -- the cost beside the MFMAs is the issue of the load itself (one global_load_dwordx4 per
+// 5 MFMAs costs the stream ~40 cycles, tools/probe_mfma_filler.hip), not its address.
+__device__ __forceinline__ u32x4 ef_ldfrag(ef_rsrc_t rs, int byte_off, int frag, unsigned laneoff)
+{
+    return *(const u32x4 *)(rs.p + (size_t)byte_off + (size_t)frag * 1024 + laneoff);
+}
+
+__device__ __forceinline__ void ef_ring_fill(EfRing &R, ef_rsrc_t rs, int woff, const float *bias4g, int mp, int steps, int lane)
+{
+#pragma unroll
+    for (int d = 0; d < EF_PD; d++)
+#pragma unroll
+        for (int p = 0; p < 3; p++) R.a[d][p] = ef_ldfrag(rs, woff, (mp * steps + d) * 3 + p, (unsigned)lane * 16u);
+    R.bv[0] = *(const f32x4 *)(bias4g + 32 * mp);
+    R.bv[1] = *(const f32x4 *)(bias4g + 32 * mp + 16);
+}
+
 // One output M-tile pair of a dense layer: 2 x S steps (k-step outer, M-tile inner -- the order the
-// fragments are packed in) of {prefetch fragment step+2, 3 products x MT MFMAs}, with one micro-unit of the finish of a
-// PREVIOUS pair (hp) after each of the first NSL MFMAs.  That previous pair is the preceding pair of this layer
+// fragments are packed in) of {prefetch fragment step+EF_PD, 3 products x MT MFMAs}, with one micro-unit of the finish
+// of a PREVIOUS pair (hp) after each of the first NSL MFMAs.  That previous pair is the preceding pair of this layer
 // (NSL = every MFMA slot) or, for a layer's first pair, the LAST pair of the previous layer, whose planes are this
 // layer's k-step S-1: its units then ride on the MFMAs of k-steps 0 .. S-2 only and are complete (plus an s_nop for
 // the accvgpr-write -> MFMA-read hazard) before the first MFMA that reads them.
-// mp = this pair, mp_next = the pair executed after it (fragment and bias prefetches cross the pair
-// boundary); pairs may be executed in any order.  bv: this pair's bias (the MFMA C operand of each M-tile's first
-// product), loaded during the previous pair; replaced by the next pair's on return.  c_prev: 2^-S of hp's layer.
+// mp = this pair; nx = the pair executed after it, in this layer or the first of the next (fragment and bias
+// prefetches cross both boundaries); pairs may be executed in any order.  R.bv: this pair's bias (the MFMA C operand of
+// each M-tile's first product); replaced by the next pair's on return.  c_prev: 2^-S of hp's layer.
 template <int MT, int S, bool PREV_LAST, bool PREV_RAW, int NSL>
-__device__ __forceinline__ void ef_pair(int mp, int mp_next, const f16x8 (&pin)[S][2][MT], const f16x8 (&pin_last)[2][MT],
-                                        const u32x4 *wp,
-                                        u32x4 (&a0)[3], u32x4 (&a1)[3], f32x4 (&bv)[2], const float *__restrict__ bias,
+__device__ __forceinline__ void ef_pair(int mp, const EfNext &nx, const f16x8 (&pin)[S][2][MT], const f16x8 (&pin_last)[2][MT],
+                                        int woff, EfRing &R,
                                         f32x4 (&acc)[2][MT], f32x4 (&hp)[2][MT], f16x8 (&po_prev)[2][MT],
-                                        int ch_prev, const EfLane &L, int g, float c_prev, float &ovf)
+                                        int ch_prev, const EfLane &L, float c_prev, float &ovf)
 {
+    static_assert(2 * S >= EF_PD, "a pair is at least EF_PD steps long");
     constexpr int NU = EfN<MT, PREV_LAST>::UNITS;                    // micro-units to hide
     EfTmp T;
     ef_static_for<0, 2 * S>([&](auto rc) {
-        // execution step r = 2 s + mm; fragment two steps ahead: inside this pair, or the first two of the next
+        // execution step r = 2 s + mm; fragment EF_PD steps ahead: inside this pair, or the first steps of the next
         constexpr int r = decltype(rc)::value, s = r >> 1, mm = r & 1;
-        const int nxt = r + 2 < 2 * S ? mp * 2 * S + r + 2 : mp_next * 2 * S + (r + 2 - 2 * S);
-        u32x4 a2[3];
+        u32x4 an[3];
+        if constexpr (r + EF_PD < 2 * S) {
 #pragma unroll
-        for (int p = 0; p < 3; p++) a2[p] = wp[(size_t)(nxt * 3 + p) * 64];
+            for (int p = 0; p < 3; p++) an[p] = ef_ldfrag(L.rs, woff, (mp * 2 * S + r + EF_PD) * 3 + p, L.laneoff);
+        } else {
+#pragma unroll
+            for (int p = 0; p < 3; p++) an[p] = ef_ldfrag(L.rs, nx.woff, (nx.mp * nx.steps + (r + EF_PD - 2 * S)) * 3 + p, L.laneoff);
+        }
         EF_PIN();
         if constexpr (s == S - 1 && mm == 0 && NSL < 2 * S * 3 * MT)
             asm volatile("s_nop 7");                                  // pin_last was written by v_accvgpr_write just now
@@ -253,8 +298,8 @@ __device__ __forceinline__ void ef_pair(int mp, int mp_next, const f16x8 (&pin)[
             ef_static_for<0, MT>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 const f16x8 &bop = s == S - 1 ? pin_last[pb][t] : pin[s][pb][t];
-                if constexpr (s == 0 && prod == 0) ef_mfma_init(acc[mm][t], a0[pa], bop, bv[mm]);
-                else ef_mfma_acc(acc[mm][t], a0[pa], bop);
+                if constexpr (s == 0 && prod == 0) ef_mfma_init(acc[mm][t], R.a[0][pa], bop, R.bv[mm]);
+                else ef_mfma_acc(acc[mm][t], R.a[0][pa], bop);
                 constexpr int slot = (r * 3 + prod) * MT + t;
 #ifdef EF_NOFINISH                                                     // timing experiment: accumulators kept alive, no finish work
                 if constexpr (slot == 0) {
@@ -273,66 +318,60 @@ __device__ __forceinline__ void ef_pair(int mp, int mp_next, const f16x8 (&pin)[
             });
         });
         if constexpr (r == 1) {                                       // both M-tiles have consumed their bias: fetch the next pair's
-            bv[0] = *(const f32x4 *)(bias + 32 * mp_next + 4 * g);
-            bv[1] = *(const f32x4 *)(bias + 32 * mp_next + 16 + 4 * g);
+            R.bv[0] = *(const f32x4 *)(nx.bias + 32 * nx.mp);
+            R.bv[1] = *(const f32x4 *)(nx.bias + 32 * nx.mp + 16);
             EF_PIN();
         }
 #pragma unroll
-        for (int p = 0; p < 3; p++) { a0[p] = a1[p]; a1[p] = a2[p]; }
+        for (int p = 0; p < 3; p++) {
+#pragma unroll
+            for (int d = 0; d + 1 < EF_PD; d++) R.a[d][p] = R.a[d + 1][p];
+            R.a[EF_PD - 1][p] = an[p];
+        }
     });
 }
 
 // One dense layer: S input k-steps (32 channels each, planes in pin), NPAIR output M-tile pairs,
 // software-pipelined over pairs (accumulators double-buffered: pair i's MFMAs hide pair i-1's finish).
 // On entry accB holds the previous layer's last, unfinished pair (its planes are pin[S-1], its pooled
-// output goes to channel ch_in); on return accB holds THIS layer's last unfinished pair (pair index *mp_out).
-// wl: [step = (pair*S + s)*2 + mm][plane][lane] fragments, prefetched two steps ahead.  rot (only for
-// the rolled LAST layer, where no register array is indexed by the pair): this workgroup starts at pair `rot`.
+// output goes to channel ch_in) and R the fragments / bias of this layer's first pair; on return accB holds THIS
+// layer's last unfinished pair (pair index *mp_out) and R what `after` (the next layer's first pair) needs.
+// wl: [step = (pair*S + s)*2 + mm][plane][lane] fragments.  rot (only for the rolled LAST layer, where no register
+// array is indexed by the pair): this workgroup starts at pair `rot`.
 // IN_RAW: accB on entry was produced by asm MFMAs (layers >= 2) rather than builtins (layer 1).
 // c_in / c_own: 2^-S of the previous layer (whose last pair is finished here) and of this layer; bias is pre-scaled.
 template <int MT, int S, int NPAIR, bool LAST, bool UNROLL, bool IN_RAW>
 __device__ __forceinline__ void ef_layer(const f16x8 (&pin)[S][2][MT], f16x8 (&pout)[LAST ? 1 : NPAIR][2][MT],
-                                         const u32x4 *wl, const float *__restrict__ bias, int ch_own,
+                                         int woff, const float *bias4g, const EfNext &after, EfRing &R, int ch_own,
                                          f32x4 (&accA)[2][MT], f32x4 (&accB)[2][MT], int ch_in,
-                                         int *mp_out, const EfLane &L, int lane, int g, int rot, float c_in, float c_own, float &ovf)
+                                         int *mp_out, const EfLane &L, int rot, float c_in, float c_own, float &ovf)
 {
     static_assert(NPAIR % 2 == 0 && S >= 2, "pairs are processed two at a time; deferred finish needs S >= 2");
     constexpr int NS = 2 * S * 3 * MT, NSD = (S - 1) * 6 * MT;      // MFMA slots of a pair; of its k-steps 0 .. S-2
     f16x8 last[2][MT];              // planes of k-step S-1: produced here by the deferred finish (pin[S-1] is never written)
-    const u32x4 *wp = wl + lane;
-    const int first = UNROLL ? 0 : rot;
-    u32x4 a0[3], a1[3];
-    f32x4 bv[2];
-#pragma unroll
-    for (int p = 0; p < 3; p++) {
-        a0[p] = wp[(size_t)((first * 2 * S) * 3 + p) * 64];
-        a1[p] = wp[(size_t)((first * 2 * S + 1) * 3 + p) * 64];
-    }
-    bv[0] = *(const f32x4 *)(bias + 32 * first + 4 * g);
-    bv[1] = *(const f32x4 *)(bias + 32 * first + 16 + 4 * g);
-    EF_PIN();
+    auto in_layer = [&](int mp) { return EfNext{woff, bias4g, mp, 2 * S}; };
     if constexpr (UNROLL) {
         // written out (NPAIR is 2 or 4): a `#pragma unroll` loop over this much code is not always
         // unrolled, and a rolled loop indexes pout dynamically, which sends the planes to scratch
         static_assert(NPAIR == 2 || NPAIR == 4, "unrolled layers have 2 or 4 output pairs");
-        ef_pair<MT, S, false, IN_RAW, NSD>(0, 1, pin, last, wp, a0, a1, bv, bias, accA, accB, last, ch_in, L, g, c_in, ovf);
-        ef_pair<MT, S, LAST, true, NS>(1, NPAIR > 2 ? 2 : 1, pin, last, wp, a0, a1, bv, bias, accB, accA, pout[0], ch_own, L, g, c_own, ovf);
+        ef_pair<MT, S, false, IN_RAW, NSD>(0, in_layer(1), pin, last, woff, R, accA, accB, last, ch_in, L, c_in, ovf);
+        ef_pair<MT, S, LAST, true, NS>(1, NPAIR > 2 ? in_layer(2) : after, pin, last, woff, R, accB, accA, pout[0], ch_own, L, c_own, ovf);
         if constexpr (NPAIR == 4) {
-            ef_pair<MT, S, LAST, true, NS>(2, 3, pin, last, wp, a0, a1, bv, bias, accA, accB, pout[1], ch_own + 32, L, g, c_own, ovf);
-            ef_pair<MT, S, LAST, true, NS>(3, 3, pin, last, wp, a0, a1, bv, bias, accB, accA, pout[2], ch_own + 64, L, g, c_own, ovf);
+            ef_pair<MT, S, LAST, true, NS>(2, in_layer(3), pin, last, woff, R, accA, accB, pout[1], ch_own + 32, L, c_own, ovf);
+            ef_pair<MT, S, LAST, true, NS>(3, after, pin, last, woff, R, accB, accA, pout[2], ch_own + 64, L, c_own, ovf);
         }
         *mp_out = NPAIR - 1;
     } else {
         const int q0 = rot % NPAIR, q1 = (1 + rot) % NPAIR, q2 = (2 + rot) % NPAIR;
-        ef_pair<MT, S, false, IN_RAW, NSD>(q0, q1, pin, last, wp, a0, a1, bv, bias, accA, accB, last, ch_in, L, g, c_in, ovf);
-        ef_pair<MT, S, LAST, true, NS>(q1, q2, pin, last, wp, a0, a1, bv, bias, accB, accA, pout[0], ch_own + 32 * q0, L, g, c_own, ovf);
+        ef_pair<MT, S, false, IN_RAW, NSD>(q0, in_layer(q1), pin, last, woff, R, accA, accB, last, ch_in, L, c_in, ovf);
+        ef_pair<MT, S, LAST, true, NS>(q1, in_layer(q2), pin, last, woff, R, accB, accA, pout[0], ch_own + 32 * q0, L, c_own, ovf);
         int mpB = q1;                                                   // pair whose results sit in accB
 #pragma unroll 1
         for (int i = 2; i < NPAIR; i += 2) {
             const int m0 = (i + rot) % NPAIR, m1 = (i + 1 + rot) % NPAIR, m2 = (i + 2 + rot) % NPAIR;
-            ef_pair<MT, S, LAST, true, NS>(m0, m1, pin, last, wp, a0, a1, bv, bias, accA, accB, pout[0], ch_own + 32 * mpB, L, g, c_own, ovf);
-            ef_pair<MT, S, LAST, true, NS>(m1, i + 2 < NPAIR ? m2 : m1, pin, last, wp, a0, a1, bv, bias, accB, accA, pout[0],
-                                           ch_own + 32 * m0, L, g, c_own, ovf);
+            ef_pair<MT, S, LAST, true, NS>(m0, in_layer(m1), pin, last, woff, R, accA, accB, pout[0], ch_own + 32 * mpB, L, c_own, ovf);
+            ef_pair<MT, S, LAST, true, NS>(m1, i + 2 < NPAIR ? in_layer(m2) : after, pin, last, woff, R, accB, accA, pout[0],
+                                           ch_own + 32 * m0, L, c_own, ovf);
             mpB = m1;
         }
         *mp_out = mpB;
@@ -366,12 +405,18 @@ __global__ __launch_bounds__(256, 1) void edgeconv_f16_kernel(const float *__res
     // pooled stores: after the transposing quad reduce lane q = j & 3 holds channel register {0,2,1,3}[q] of its point;
     // lanes past N recompute point N-1 and store the same bits to the same place
     EfLane L;
+    L.laneoff = (unsigned)lane * 16u;
+    L.rs.p = (const char *)packed;
     L.odd = j & 1;
     L.hi = j & 2;
     L.prow = pooled + ((size_t)b * N + nc) * CTOT + 4 * g + ((j & 1) * 2 + ((j >> 1) & 1));
     // 2^-S of layers 2..4 (uniform: scalar loads)
     const float c2 = packed[EC4_OFF_SC], c3 = packed[EC4_OFF_SC + 1], c4 = packed[EC4_OFF_SC + 2];
     float ovf = 0.f;
+    // layer 2's first fragments and bias: requested before the gather so that their latency hides behind it
+    EfRing R;
+    ef_ring_fill(R, L.rs, EC4_OFF_W2 * 4, packed + EC4_OFF_B2 + 4 * g, 0, 2 * (EC_C1 / 32), lane);
+    EF_PIN();
 
     // ---- layer 1 on the fp32 MFMA (as edgeconv2.hip): graph feature rows as B operands, k-step s,
     //      lane group g -> channel 4s + g of (neighbour xyz, centre xyz, 0, 0)          dgcnn.py:32
@@ -413,27 +458,29 @@ __global__ __launch_bounds__(256, 1) void edgeconv_f16_kernel(const float *__res
     int mp_last;
 
     EF_T(2);
-    // ---- layer 2: 64 -> 64   (its first pair hides the finish of layer 1's last pair, and so on down)
-    f16x8 p2[EC_C2 / 32][2][MT];
-    ef_layer<MT, EC_C1 / 32, EC_C2 / 32, false, true, false>(
-        p1, p2, (const u32x4 *)(packed + EC4_OFF_W2), packed + EC4_OFF_B2, EC_C1, accA, accB,
-        32 * (EC_C1 / 32 - 1), &mp_last, L, lane, g, 0, 1.0f, c2, ovf);
-    EF_T(3);
-    // ---- layer 3: 64 -> 128
-    f16x8 p3[EC_C3 / 32][2][MT];
-    ef_layer<MT, EC_C2 / 32, EC_C3 / 32, false, true, true>(
-        p2, p3, (const u32x4 *)(packed + EC4_OFF_W3), packed + EC4_OFF_B3, EC_C1 + EC_C2, accA, accB,
-        EC_C1 + 32 * (EC_C2 / 32 - 1), &mp_last, L, lane, g, 0, c2, c3, ovf);
-    EF_T(4);
-    // ---- layer 4: 128 -> 256, only max-pooled
-    f16x8 dummy[1][2][MT];
+    constexpr int w2 = EC4_OFF_W2 * 4, w3 = EC4_OFF_W3 * 4, w4 = EC4_OFF_W4 * 4;      // byte offsets inside the descriptor
+    const float *bs2 = packed + EC4_OFF_B2 + 4 * g, *bs3 = packed + EC4_OFF_B3 + 4 * g, *bs4 = packed + EC4_OFF_B4 + 4 * g;
 #ifndef EF_ROT
 #define EF_ROT 1
 #endif
     const int rot = EF_ROT ? (int)(((blockIdx.x + gridDim.x * blockIdx.y) >> 3) % (EC_C4 / 32)) : 0;   // >>3: ids = XCD mod 8
+    // ---- layer 2: 64 -> 64   (its first pair hides the finish of layer 1's last pair, and so on down)
+    f16x8 p2[EC_C2 / 32][2][MT];
+    ef_layer<MT, EC_C1 / 32, EC_C2 / 32, false, true, false>(
+        p1, p2, w2, bs2, EfNext{w3, bs3, 0, 2 * (EC_C2 / 32)}, R, EC_C1, accA, accB,
+        32 * (EC_C1 / 32 - 1), &mp_last, L, 0, 1.0f, c2, ovf);
+    EF_T(3);
+    // ---- layer 3: 64 -> 128
+    f16x8 p3[EC_C3 / 32][2][MT];
+    ef_layer<MT, EC_C2 / 32, EC_C3 / 32, false, true, true>(
+        p2, p3, w3, bs3, EfNext{w4, bs4, rot, 2 * (EC_C3 / 32)}, R, EC_C1 + EC_C2, accA, accB,
+        EC_C1 + 32 * (EC_C2 / 32 - 1), &mp_last, L, 0, c2, c3, ovf);
+    EF_T(4);
+    // ---- layer 4: 128 -> 256, only max-pooled
+    f16x8 dummy[1][2][MT];
     ef_layer<MT, EC_C3 / 32, EC_C4 / 32, true, false, true>(
-        p3, dummy, (const u32x4 *)(packed + EC4_OFF_W4), packed + EC4_OFF_B4, EC_C1 + EC_C2 + EC_C3, accA, accB,
-        EC_C1 + EC_C2 + 32 * (EC_C3 / 32 - 1), &mp_last, L, lane, g, rot, c3, c4, ovf);
+        p3, dummy, w4, bs4, EfNext{w4, bs4, 0, 2 * (EC_C3 / 32)}, R, EC_C1 + EC_C2 + EC_C3, accA, accB,
+        EC_C1 + EC_C2 + 32 * (EC_C3 / 32 - 1), &mp_last, L, rot, c3, c4, ovf);
     asm volatile("s_nop 15\n\ts_nop 15");                       // the last asm MFMAs must have written accB (no compiler padding)
     ef_finish_all<MT, true, true>(accB, dummy[0], EC_C1 + EC_C2 + EC_C3 + 32 * mp_last, L, c4, ovf);
     EF_T(5);

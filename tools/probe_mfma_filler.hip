@@ -21,6 +21,49 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         if (KIND == 12) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(d[i & 3]) : "v"(d[(i + 1) & 3]), "v"(d[(i + 2) & 3]));     \
     } while (0)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// one memory / LDS instruction per 5 MFMAs: 0 global_load_dwordx4, 1 ds_read_b128, 2 global_load_dwordx4 into AGPRs, 3 none
+template <int MK>
+__global__ __launch_bounds__(256, 1) void km(float *out, unsigned long long *cyc, int iters, const float4 *src)
+{
+    __shared__ float4 lds[1024];
+    f32x4 acc[5];
+    u32x4 a = {threadIdx.x, 1, 2, 3}, b[5];
+    lds[threadIdx.x] = src[threadIdx.x];
+    __syncthreads();
+    for (int i = 0; i < 5; i++) { acc[i] = (f32x4){0, 0, 0, 0}; b[i] = (u32x4){threadIdx.x + i, 5, 6, 7}; asm volatile("" : "+a"(b[i])); }
+    float4 sum = {0, 0, 0, 0};
+    const float4 *p = src + threadIdx.x;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int rep = 0; rep < 6; rep++) {
+            f32x4 v = {0, 0, 0, 0};
+            if (MK == 0 || MK == 2) v = *(const f32x4 *)&p[((it * 6 + rep) & 63) * 256];
+            if (MK == 1) v = *(const f32x4 *)&lds[(threadIdx.x + rep * 64) & 1023];
+            if (MK == 2) asm volatile("" : "+a"(v));
+#pragma unroll
+            for (int i = 0; i < 5; i++) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "a"(b[i]));
+            if (MK == 2) asm volatile("" : "+v"(v));
+            sum.x += v[0]; sum.y += v[1]; sum.z += v[2]; sum.w += v[3];
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float s = sum.x + sum.y + sum.z + sum.w;
+    for (int i = 0; i < 5; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+template <int MK> double runm()
+{
+    static float *out = nullptr; static unsigned long long *cyc = nullptr; static float4 *src = nullptr; const int nb = 256, iters = 500;
+    if (!out) { hipMalloc(&out, 4 * nb * 256); hipMalloc(&cyc, 8 * nb); hipMalloc(&src, 16 * 256 * 64 + 4096); hipMemset(src, 0, 16 * 256 * 64 + 4096); }
+    hipLaunchKernelGGL((km<MK>), dim3(nb), dim3(256), 0, 0, out, cyc, iters, src);
+    hipLaunchKernelGGL((km<MK>), dim3(nb), dim3(256), 0, 0, out, cyc, iters, src);
+    hipDeviceSynchronize();
+    unsigned long long h[256]; hipMemcpy(h, cyc, 8 * nb, hipMemcpyDeviceToHost);
+    return h[7] / ((double)iters * 30);
+}
+
 template <int KIND, int NF>
 __global__ __launch_bounds__(256, 1) void k(float *out, unsigned long long *cyc, int iters)
 {
@@ -70,5 +113,7 @@ int main()
     row<1>("v_fma_mix_f32"); row<2>("v_fma_mixlo_f16"); row<3>("v_cvt_pk_f16_f32");
     row<4>("v_cvt_f32_f16_sdwa"); row<5>("v_cvt_f32_f16"); row<6>("v_accvgpr_write"); row<7>("v_accvgpr_read");
     row<11>("s_nop1+v_max_f32_dpp"); row<12>("v_pk_mul_f32");
+    printf("one memory instruction per 5 MFMAs (ticks per MFMA): none %.2f  global_load_dwordx4 %.2f  -> AGPR %.2f  ds_read_b128 %.2f\n",
+           runm<3>(), runm<0>(), runm<2>(), runm<1>());
     return 0;
 }
