@@ -351,6 +351,32 @@ int l3d_pointwise_conv_split_maxpool(const void *x, int x_mode, const void *w_sp
                                      const float *shift, int shift_bstride, int B, int Cin, int Cout, int N,
                                      int relu, int pool, float *y, l3d_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The same 1x1 conv as "f16x2" on the fp16 matrix cores (conv_f16.hip): three fp16 MFMA products per fp32 product --
+ * activations x = h + m' 2^-12, weights scaled by a power of two and split into H, Hs = H 2^-12, M -- fp32-level
+ * error (tests hold it to the bf16x3 bar) at half of bf16x3's matrix-core work.  Both operands are PRE-SPLIT fp16
+ * planes in the tiled layout plane[k / 8][row][8 fp16] (rows = Cout for W, B*N for x), so the kernel moves them
+ * global -> LDS by DMA with no registers and no VALU.  Range contract: |x| < 65504 (producers raise *range_flag
+ * beyond 60000; results are then invalid and the caller falls back to l3d_pointwise_conv_split).
+ *   l3d_f16_plane_bytes(rows, cols)          bytes of one plane
+ *   l3d_f16_act_bytes(rows, cols)            bytes of an activation image (h | m' planes + 16 bytes: 2^-T, scratch), the
+ *                                            activations being stored times 2^T (T per tensor: see conv_f16.hip)
+ *   l3d_conv_f16_weight_bytes(Cout, Cin)     bytes of a split weight image (H | Hs | M planes + 16 bytes: 2^-S, scratch)
+ *   l3d_conv_f16_split_weights               w [Cout][Cin] fp32 (device) -> that image (device); two small launches
+ *   l3d_split_f16_rows                       x [rows][C] fp32, or [B][C][Npts] with channel_first -> activation image
+ *   l3d_pointwise_conv_f16                   y[b][co][n] = act(scale[co] sum_k w[co][k] x[b][n][k] + shift[(b,)co]);
+ *                                            Cout % 256 == 0, N % 256 == 0, Cin % 16 == 0, else L3D_ERR_UNSUPPORTED
+ * ------------------------------------------------------------------------------------------- */
+size_t l3d_f16_plane_bytes(long rows, int cols);
+size_t l3d_f16_act_bytes(long rows, int cols);
+size_t l3d_conv_f16_weight_bytes(int Cout, int Cin);
+int l3d_conv_f16_split_weights(const float *w, int Cout, int Cin, void *dst, l3d_stream_t stream);
+int l3d_split_f16_rows(const float *x, long rows, int C, int channel_first, int Npts, void *dst, int *range_flag,
+                       l3d_stream_t stream);
+int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
+                           int shift_bstride, int B, int Cin, int Cout, int N, int relu, float *y,
+                           l3d_stream_t stream);
+
 /* PCN's folding decoder == models/pcn.py:84-101 (conv5 -> ReLU -> conv6 -> ReLU -> conv7, + centre) in one
  * kernel (fold_mlp.hip): g [B,N,5] = (grid u, v, centre x, y, z) per fine point, w5g [512,5] = conv5's
  * columns for those five inputs, s5 [B,512] = conv5.bias + conv5.weight[:, 5:] . global_feature (per cloud),

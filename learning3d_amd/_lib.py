@@ -74,13 +74,19 @@ SIGNATURES = {
     "l3d_split_rows": [_P, _I, _I, _P, _P],
     "l3d_pointwise_conv_split": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_pointwise_conv_split_maxpool": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "l3d_f16_plane_bytes": [_L, _I],
+    "l3d_f16_act_bytes": [_L, _I],
+    "l3d_conv_f16_weight_bytes": [_I, _I],
+    "l3d_conv_f16_split_weights": [_P, _I, _I, _P, _P],
+    "l3d_split_f16_rows": [_P, _L, _I, _I, _I, _P, _P, _P],
+    "l3d_pointwise_conv_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_fold_mlp": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P],
     "l3d_emd_forward": [_P, _P, _I, _I, _I, _P, _P, _P, _P],
     "l3d_emd_backward": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
 }
 _RESTYPE = {"l3d_status_string": C.c_char_p, "l3d_edgeconv_packed_floats": _SZ, "l3d_split_bytes": _SZ,
             "l3d_soft_correspondence_workspace_floats": _SZ, "l3d_knn_feature_workspace_bytes": _SZ,
-            "l3d_scatter_add_det_workspace_bytes": _SZ}
+            "l3d_scatter_add_det_workspace_bytes": _SZ, "l3d_f16_plane_bytes": _SZ, "l3d_f16_act_bytes": _SZ, "l3d_conv_f16_weight_bytes": _SZ}
 
 
 class L3DError(RuntimeError):

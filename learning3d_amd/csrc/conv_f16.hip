@@ -1,0 +1,316 @@
+// conv_f16.hip -- per-point linear layer (1x1 conv + folded BN + ReLU) as "f16x2" on the fp16 matrix cores:
+// three fp16 MFMA products per fp32 product (half of bf16x3's six), fp32-level error.  models/dgcnn.py:48 (conv5,
+// 33 % of the benchmark step), pointnet.py:22-49, pcn.py:84-125.
+//
+// Arithmetic (see edgeconv_f16.hip for the derivation and the error measurements):
+//   activation x:  X = x 2^T (T per tensor),  h = f16(X),  m' = f16((X - h) 2^12)
+//   weight     w:  W = w 2^S (S per matrix, max|W| in [4,8)),  H = f16(W),  Hs = f16(H 2^-12),  M = f16(W - H)
+//   acc = sum_k ( M h + Hs m' + H h ) = 2^(S+T) w.x,     y = act(acc * (scale 2^-S 2^-T) + shift)
+// fp16 has 30 binades: T places the tensor's largest magnitude near 2^12 (16x headroom to 65504; values 2^-26 of the
+// maximum and larger keep full relative precision, smaller ones an absolute error of 2^-49 of the maximum).  The
+// generic splitter takes T from the tensor's own maximum (one extra read pass); a fused producer takes it from what it
+// knows about its output (the EdgeConv kernel: BatchNorm statistics) and raises the range flag if that was wrong.
+//
+// Both operands arrive PRE-SPLIT as fp16 planes in the tiled layout  plane[k / 8][row][8 fp16]  (one 16-byte cell per
+// (octet, row); rows = Cout for W, B*N for x): exactly the "8 consecutive k of row i" that a lane of
+// v_mfma_f32_32x32x16_f16 consumes, and 64 consecutive rows of one octet are 1 KB contiguous -- one
+// global_load_lds_dwordx4 per wave moves them global -> LDS with no registers, no VALU and no ds_write.  W is split
+// once per weight version (l3d_conv_f16_split_weights); x is written in this form by its producer (the EdgeConv f16
+// kernel's pooled epilogue, out_mode 1) or by l3d_split_f16_rows.  Measured beside the MFMAs (tools/probe_mfma_filler.hip):
+// a VALU instruction costs ~7.5 cycles, a packed-fp32 one 17+, a global load ~40 -- an in-kernel split of fp32 x
+// (conv_split.hip: 11 VALU per value pair, redone by the 4 workgroups that share an x tile) is what this layout removes.
+//
+// Kernel.  Workgroup tile 256 (co) x 256 (n), 512 threads = 8 waves (4 x 2), wave tile 64 (co) x 128 (n) = 2 x 4
+// MFMA tiles of 32x32 (128 accumulator registers, two waves per SIMD).  With three W planes and two x planes the
+// fragment reads per K chunk are 3a + 2c for an a x c wave tile: 14 for 2 x 4 (16 for 4 x 2).  K chunks of 16 (one MFMA
+// k-step), THREE LDS stages of 40 KB (W 24 KB + x 16 KB); per chunk every wave issues 5 DMA pieces for chunk kc+2,
+// waits for its own pieces of chunk kc (s_waitcnt vmcnt -- the loop has no other vector memory traffic), one barrier,
+// 14 ds_read_b128, 24 MFMAs.
+#include "common.h"
+#include "split_bf16.h"          // f32x4 / f32x16 typedefs
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define CF_TM 256
+#define CF_TN 256
+#define CF_WBYTES (6 * 4096)                 // 3 planes x 2 octets x 256 rows x 16 B
+#define CF_XBYTES (4 * 4096)                 // 2 planes x 2 octets x 256 rows x 16 B
+#define CF_STAGE (CF_WBYTES + CF_XBYTES)
+#define CF_NSTAGE 3
+#define CF_LDS (CF_NSTAGE * CF_STAGE)
+
+typedef __attribute__((address_space(3))) void *cf_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *cf_gbl_ptr_t;
+
+// ---------------------------------------------------------------------------------------------
+// Splitters.  src [R][C] fp32 row-major -> planes [ceil(C/8)][R][8] fp16 (C padded with zeros).
+//   weights: H, Hs, M of src * 2^S, S chosen on the device from max|src| (two launches: max, split); *inv = 2^-S
+//   activations: h, m' ; raises *range_flag if |x| > 60000
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cf_absmax_kernel(const float *__restrict__ src, size_t n, unsigned *__restrict__ out)
+{
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(src[i]));
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));          // non-negative floats order like their bits
+}
+
+__device__ __forceinline__ int cf_scale_exp(float wmax)
+{
+    if (!(wmax > 0.f) || !(wmax < INFINITY)) return 0;
+    int e;
+    frexpf(wmax, &e);                          // wmax = f 2^e, f in [0.5, 1)  ->  wmax 2^(3-e) in [4, 8)
+    return 3 - e;
+}
+
+__global__ __launch_bounds__(256) void cf_split_w_kernel(const float *__restrict__ src, int R, int C, const unsigned *__restrict__ amax,
+                                                         uint4 *__restrict__ pH, uint4 *__restrict__ pHs, uint4 *__restrict__ pM,
+                                                         float *__restrict__ inv)
+{
+    const int S = cf_scale_exp(__uint_as_float(*amax));
+    const float up = ldexpf(1.0f, S);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *inv = ldexpf(1.0f, -S);
+    const int noct = (C + 7) / 8;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (long)R * noct) return;
+    const int row = (int)(id % R), o = (int)(id / R);
+    _Float16 H[8], Hs[8], M[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int k = o * 8 + e;
+        const float v = (k < C ? src[(size_t)row * C + k] : 0.f) * up;
+        H[e] = (_Float16)v;
+        M[e] = (_Float16)(v - (float)H[e]);
+        Hs[e] = (_Float16)((float)H[e] * 0x1p-12f);
+    }
+    pH[(size_t)o * R + row] = *(const uint4 *)H;
+    pHs[(size_t)o * R + row] = *(const uint4 *)Hs;
+    pM[(size_t)o * R + row] = *(const uint4 *)M;
+}
+
+// x [R][C] (row-major, channel-last) or, with CFIRST, x [B][C][Npts] (R = B * Npts) -> h / m' planes
+__device__ __forceinline__ int cf_act_exp(float xmax)
+{
+    if (!(xmax > 0.f) || !(xmax < INFINITY)) return 0;
+    int e;
+    frexpf(xmax, &e);                          // xmax = f 2^e, f in [0.5, 1)  ->  xmax 2^(12-e) in [2^11, 2^12)
+    return 12 - e;
+}
+
+template <bool CFIRST>
+__global__ __launch_bounds__(256) void cf_split_x_kernel(const float *__restrict__ src, long R, int C, int Npts, const unsigned *__restrict__ amax,
+                                                         uint4 *__restrict__ ph, uint4 *__restrict__ pm, float *__restrict__ inv,
+                                                         int *__restrict__ range_flag)
+{
+    const int T = cf_act_exp(__uint_as_float(*amax));
+    const float up = ldexpf(1.0f, T);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *inv = ldexpf(1.0f, -T);
+    const int noct = (C + 7) / 8;
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= R * noct) return;
+    const long row = id % R;
+    const int o = (int)(id / R);
+    _Float16 h[8], m[8];
+    float big = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int k = o * 8 + e;
+        float v = 0.f;
+        if (k < C) v = (CFIRST ? src[((size_t)(row / Npts) * C + k) * Npts + row % Npts] : src[(size_t)row * C + k]) * up;
+        big = fmaxf(big, fabsf(v));
+        h[e] = (_Float16)v;
+        m[e] = (_Float16)((v - (float)h[e]) * 4096.0f);
+    }
+    ph[(size_t)o * R + row] = *(const uint4 *)h;
+    pm[(size_t)o * R + row] = *(const uint4 *)m;
+    if (!(big <= 60000.f) && range_flag) *(volatile int *)range_flag = 1;         // inf / NaN inputs land here too
+}
+
+// ---------------------------------------------------------------------------------------------
+// The GEMM.  Requires Cout % 256 == 0, N % 256 == 0, Cin % 16 == 0 (dispatcher checks).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__ xh, const uint4 *__restrict__ xm,
+                                                       const uint4 *__restrict__ wH, const uint4 *__restrict__ wHs,
+                                                       const uint4 *__restrict__ wM, const float *__restrict__ winv,
+                                                       const float *__restrict__ xinv, const float *__restrict__ scale, const float *__restrict__ shift,
+                                                       int shift_bstride, int Bn, int Cin, int Cout, int N, int relu,
+                                                       float *__restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave & 3, wn = wave >> 2;
+    const int n0 = blockIdx.x * CF_TN, co0 = blockIdx.y * CF_TM, b = blockIdx.z;
+    const int nk = Cin / 16;
+    const size_t BN = (size_t)Bn * N;
+
+    // ---- DMA pieces: 40 per chunk (W: 6 regions x 4 quarters of 64 rows, x: 4 regions x 4), 5 per wave
+    const uint4 *src[5];
+    size_t stride[5];
+    int dst[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const int q = wave * 5 + i;
+        if (q < 24) {
+            const int reg = q >> 2, p = reg >> 1, kg = reg & 1, quarter = q & 3;
+            const uint4 *pl = p == 0 ? wH : (p == 1 ? wHs : wM);
+            src[i] = pl + (size_t)kg * Cout + co0 + quarter * 64 + lane;
+            stride[i] = 2 * (size_t)Cout;
+            dst[i] = reg * 4096 + quarter * 1024;
+        } else {
+            const int q2 = q - 24, reg = q2 >> 2, p = reg >> 1, kg = reg & 1, quarter = q2 & 3;
+            const uint4 *pl = p == 0 ? xh : xm;
+            src[i] = pl + (size_t)kg * BN + (size_t)b * N + n0 + quarter * 64 + lane;
+            stride[i] = 2 * BN;
+            dst[i] = CF_WBYTES + reg * 4096 + quarter * 1024;
+        }
+    }
+    auto issue = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            __builtin_amdgcn_global_load_lds((cf_gbl_ptr_t)src[i], (cf_lds_ptr_t)(lds + stage * CF_STAGE + dst[i]), 16, 0, 0);
+            src[i] += stride[i];
+        }
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][c][r] = 0.f;
+
+    const int kgl = lane >> 5;
+    const int a_off = kgl * 4096 + (wm * 64 + (lane & 31)) * 16;                     // + a*512 + p*8192
+    const int b_off = CF_WBYTES + kgl * 4096 + (wn * 128 + (lane & 31)) * 16;        // + c*512 + p*8192
+
+    issue(0);
+    if (nk > 1) issue(1);
+    int stage = 0;
+    for (int kc = 0; kc < nk; kc++) {
+        // this wave's pieces of chunk kc have landed (chunk kc+1's five may still be in flight) ...
+        if (kc + 1 < nk) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // ... and so have everybody else's; stage (kc+2)%3 was last read in chunk kc-1
+        const int nst = stage == 0 ? 2 : stage - 1;                                   // (kc + 2) % 3
+        if (kc + 2 < nk) issue(nst);
+        const unsigned char *base = lds + stage * CF_STAGE;
+        f16x8 A[2][3], Bf[4][2];
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) Bf[c][p] = *(const f16x8 *)(base + b_off + c * 512 + p * 8192);
+#pragma unroll
+        for (int p = 2; p >= 0; p--)
+#pragma unroll
+            for (int a = 0; a < 2; a++) A[a][p] = *(const f16x8 *)(base + a_off + a * 512 + p * 8192);
+        // three products, smallest first: M h, Hs m', H h
+#pragma unroll
+        for (int prod = 0; prod < 3; prod++) {
+            const int pa = prod == 0 ? 2 : (prod == 1 ? 1 : 0), pb = prod == 1 ? 1 : 0;
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][pa], Bf[c][pb], acc[a][c], 0, 0, 0);
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+
+    // ---- epilogue: D[co = 32a + (r&3) + 8(r>>2) + 4(lane>>5)][n = 32c + (lane&31)]
+    const float inv = *winv * *xinv;             // 2^-S 2^-T: exact
+    float *yb = y + (size_t)b * Cout * N;
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int co = co0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float sc = (scale ? scale[co] : 1.f) * inv;
+            const float sh = shift ? shift[(size_t)b * shift_bstride + co] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                float v = acc[a][c][r] * sc + sh;
+                if (relu) v = l3d_act(v, relu);
+                yb[(size_t)co * N + n0 + wn * 128 + c * 32 + (lane & 31)] = v;
+            }
+        }
+}
+
+// bytes of ONE fp16 plane of a [rows][cols] matrix in the tiled layout
+extern "C" size_t l3d_f16_plane_bytes(long rows, int cols)
+{
+    return (size_t)((cols + 7) / 8) * (size_t)rows * 16;
+}
+
+// weights [Cout][Cin] fp32 -> dst = H | Hs | M planes (3 x l3d_f16_plane_bytes) followed by 16 bytes holding 2^-S (fp32)
+// and the |w| maximum's bits (scratch)
+extern "C" size_t l3d_conv_f16_weight_bytes(int Cout, int Cin)
+{
+    return 3 * l3d_f16_plane_bytes(Cout, Cin) + 16;
+}
+
+extern "C" int l3d_conv_f16_split_weights(const float *w, int Cout, int Cin, void *dst, l3d_stream_t stream)
+{
+    L3D_REQUIRE(w && dst && Cout > 0 && Cin > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t pb = l3d_f16_plane_bytes(Cout, Cin);
+    unsigned char *d = (unsigned char *)dst;
+    float *inv = (float *)(d + 3 * pb);
+    unsigned *amax = (unsigned *)(d + 3 * pb + 4);
+    hipMemsetAsync(amax, 0, 4, st);
+    const size_t n = (size_t)Cout * Cin;
+    const long nblk = l3d_divup((long)n, 256);
+    hipLaunchKernelGGL(cf_absmax_kernel, dim3((unsigned)(nblk > 256 ? 256 : nblk)), dim3(256), 0, st, w, n, amax);
+    const long cells = (long)Cout * ((Cin + 7) / 8);
+    hipLaunchKernelGGL(cf_split_w_kernel, dim3((unsigned)l3d_divup(cells, 256)), dim3(256), 0, st, w, Cout, Cin, (const unsigned *)amax,
+                       (uint4 *)d, (uint4 *)(d + pb), (uint4 *)(d + 2 * pb), inv);
+    return l3d_check_launch();
+}
+
+// an activation image: h | m' planes (2 x l3d_f16_plane_bytes) followed by 16 bytes holding 2^-T (fp32) and scratch
+extern "C" size_t l3d_f16_act_bytes(long rows, int cols)
+{
+    return 2 * l3d_f16_plane_bytes(rows, cols) + 16;
+}
+
+// activations: x [rows][C] (channel_first = 0) or [B][C][Npts] (channel_first = 1, rows = B*Npts) -> dst = activation image
+// (T from the tensor's own maximum: one read pass for the maximum, one for the split)
+extern "C" int l3d_split_f16_rows(const float *x, long rows, int C, int channel_first, int Npts, void *dst, int *range_flag,
+                                  l3d_stream_t stream)
+{
+    L3D_REQUIRE(x && dst && rows > 0 && C > 0 && (!channel_first || (Npts > 0 && rows % Npts == 0)));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t pb = l3d_f16_plane_bytes(rows, C);
+    unsigned char *d = (unsigned char *)dst;
+    float *inv = (float *)(d + 2 * pb);
+    unsigned *amax = (unsigned *)(d + 2 * pb + 4);
+    hipMemsetAsync(amax, 0, 4, st);
+    const size_t n = (size_t)rows * C;
+    const long nblk = l3d_divup((long)n, 1024);
+    hipLaunchKernelGGL(cf_absmax_kernel, dim3((unsigned)(nblk > 256 ? 256 : nblk)), dim3(256), 0, st, x, n, amax);
+    const long cells = rows * ((C + 7) / 8);
+    if (channel_first)
+        hipLaunchKernelGGL(cf_split_x_kernel<true>, dim3((unsigned)l3d_divup(cells, 256)), dim3(256), 0, st, x, rows, C,
+                           Npts, (const unsigned *)amax, (uint4 *)d, (uint4 *)(d + pb), inv, range_flag);
+    else
+        hipLaunchKernelGGL(cf_split_x_kernel<false>, dim3((unsigned)l3d_divup(cells, 256)), dim3(256), 0, st, x, rows, C,
+                           1, (const unsigned *)amax, (uint4 *)d, (uint4 *)(d + pb), inv, range_flag);
+    return l3d_check_launch();
+}
+
+// x_act: an activation image (l3d_f16_act_bytes), w_planes: a weight image (l3d_conv_f16_weight_bytes)
+extern "C" int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
+                                      int shift_bstride, int B, int Cin, int Cout, int N, int relu, float *y,
+                                      l3d_stream_t stream)
+{
+    L3D_REQUIRE(x_planes && w_planes && y && B > 0 && Cin > 0 && Cout > 0 && N > 0);
+    if (Cout % CF_TM || N % CF_TN || Cin % 16 || B > 65535 || (((size_t)x_planes) & 15) || (((size_t)w_planes) & 15))
+        return L3D_ERR_UNSUPPORTED;
+    const size_t xpb = l3d_f16_plane_bytes((long)B * N, Cin), wpb = l3d_f16_plane_bytes(Cout, Cin);
+    const unsigned char *xp = (const unsigned char *)x_planes, *wp = (const unsigned char *)w_planes;
+    dim3 grid(N / CF_TN, Cout / CF_TM, B), block(512);
+    hipLaunchKernelGGL(conv_f16_kernel, grid, block, CF_LDS, (hipStream_t)stream, (const uint4 *)xp, (const uint4 *)(xp + xpb),
+                       (const uint4 *)wp, (const uint4 *)(wp + wpb), (const uint4 *)(wp + 2 * wpb), (const float *)(wp + 3 * wpb),
+                       (const float *)(xp + 2 * xpb), scale, shift, shift_bstride, B, Cin, Cout, N, relu, y);
+    return l3d_check_launch();
+}

@@ -120,6 +120,47 @@ def split_eligible(Cin, Cout, N):
     return SPLIT_BF16 and Cout % 256 == 0 and N % 128 == 0 and Cin % 16 == 0 and Cin >= 32
 
 
+def split_weights_f16(w):
+    """fp32 [Cout, Cin] (device) -> f16x2 weight image (H | Hs | M planes + 2^-S) for l3d_pointwise_conv_f16"""
+    require_gpu(w)
+    w = f32c(w)
+    Cout, Cin = w.shape
+    out = torch.empty(lib().l3d_conv_f16_weight_bytes(Cout, Cin), dtype=torch.uint8, device=w.device)
+    check(lib().l3d_conv_f16_split_weights(ptr(w), Cout, Cin, ptr(out), stream_ptr()), "l3d_conv_f16_split_weights")
+    return out
+
+
+def split_rows_f16(x, channel_first=False):
+    """fp32 activations -> activation image (h | m' fp16 planes of x 2^T in the tiled layout of conv_f16.hip, then 2^-T);
+    T from the tensor's own maximum.  x [B,N,C] (or [B,C,N] with channel_first).  inf / NaN raise the range flag."""
+    require_gpu(x)
+    x = f32c(x)
+    if channel_first:
+        B, C, N = x.shape
+    else:
+        B, N, C = x.shape
+    rows = B * N
+    out = torch.empty(lib().l3d_f16_act_bytes(rows, C), dtype=torch.uint8, device=x.device)
+    check(lib().l3d_split_f16_rows(ptr(x), rows, C, int(channel_first), N, ptr(out), ptr(range_flag(x.device)), stream_ptr()),
+          "l3d_split_f16_rows")
+    return out
+
+
+def f16_eligible(Cin, Cout, N):
+    return Cout % 256 == 0 and N % 256 == 0 and Cin % 16 == 0 and Cin >= 32
+
+
+def pointwise_conv_f16(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=None, relu=False):
+    """l3d_pointwise_conv_f16 on pre-split operands -> y [B,Cout,N] fp32"""
+    scale = f32c(scale) if scale is not None else None
+    shift = f32c(shift) if shift is not None else None
+    bstride = Cout if (shift is not None and shift.dim() == 2) else 0
+    y = torch.empty((B, Cout, N), dtype=torch.float32, device=x_planes.device)
+    check(lib().l3d_pointwise_conv_f16(ptr(x_planes), ptr(w_planes), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N, int(relu),
+                                       ptr(y), stream_ptr()), "l3d_pointwise_conv_f16")
+    return y
+
+
 def pointwise_conv_maxpool(x, w, scale, shift, relu, pool, w_split=None):
     """pointwise_conv followed by max over every `pool` consecutive points, in one launch:
     x [B,Cin,S*pool] -> [B,Cout,S].  pool in (8, 16, 32, 64); returns None if the kernel does not take the shape."""

@@ -675,6 +675,40 @@ def test_conv_split_accuracy():
         np.testing.assert_array_equal(spl, y2.cpu().numpy())
 
 
+def test_conv_f16_accuracy():
+    """f16x2 1x1 conv (three fp16 MFMA products per fp32 product, conv_f16.hip) vs an fp64 reference: error at the fp32
+    level -- max <= 2x, rms <= 1.5x the fp32-MFMA kernel's own error on the same inputs -- for activations scaled 1e-3 ..
+    1e-6 .. 50 (the splitter scales the tensor by a power of two taken from its own maximum), weights x 0.01 .. 30,
+    channel-last and channel-first sources; non-finite inputs raise the range flag."""
+    from learning3d_amd.models import _fused
+    rng = np.random.default_rng(22)
+    for (B, Cin, Cout, N, scale_x) in [(2, 512, 1024, 1024, 1.0), (1, 64, 256, 256, 1e-3), (3, 320, 512, 512, 50.0),
+                                      (2, 128, 256, 768, 1.0), (1, 32, 256, 256, 1e-6)]:
+        x = (np.maximum(rng.standard_normal((B, N, Cin)), 0) * scale_x).astype(np.float32)     # post-ReLU like
+        w = (rng.standard_normal((Cout, Cin)) / np.sqrt(Cin)).astype(np.float32) * rng.choice([0.01, 1.0, 30.0])
+        sc = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+        sh = (rng.uniform(-0.5, 0.5, (B, Cout)) * scale_x).astype(np.float32)
+        want = np.einsum("oc,bnc->bon", w.astype(np.float64), x.astype(np.float64)) * sc[None, :, None] + sh[:, :, None]
+        xd, wd, scd, shd = dev(x), dev(w), dev(sc), dev(sh)
+        f32 = _fused.pointwise_conv(xd, wd, scd, shd, channel_last=True, split=False).cpu().numpy()
+        wp = _fused.split_weights_f16(wd)
+        y_cl = _fused.pointwise_conv_f16(_fused.split_rows_f16(xd), B, N, wp, Cin, Cout, scd, shd).cpu().numpy()
+        xcf = dev(np.ascontiguousarray(x.transpose(0, 2, 1)))
+        y_cf = _fused.pointwise_conv_f16(_fused.split_rows_f16(xcf, channel_first=True), B, N, wp, Cin, Cout, scd, shd).cpu().numpy()
+        _fused.check_range(xd.device, sync=True)
+        e32 = np.abs(f32 - want)
+        es = np.abs(y_cl - want)
+        print(f"conv f16x2 B={B} Cin={Cin} Cout={Cout} N={N} x-scale {scale_x}: max err {es.max():.3e} ({es.max() / e32.max():.2f}x fp32-MFMA), "
+              f"rms {np.sqrt((es ** 2).mean()):.3e} ({np.sqrt((es ** 2).mean()) / np.sqrt((e32 ** 2).mean()):.2f}x)")
+        assert es.max() <= 2.0 * e32.max() + 1e-30, (B, Cin, Cout, N, es.max(), e32.max())
+        assert np.sqrt((es ** 2).mean()) <= 1.5 * np.sqrt((e32 ** 2).mean()), (B, Cin, Cout, N, "rms")
+        np.testing.assert_array_equal(y_cl, y_cf)            # same planes, same products, same order
+    bad = np.ones((1, 256, 32), np.float32); bad[0, 3, 5] = np.inf
+    _fused.split_rows_f16(dev(bad))
+    with pytest.raises(_fused.L3DRangeError):
+        _fused.check_range(sync=True)
+
+
 def test_pointwise_conv_maxpool_epilogue():
     """conv + BN + ReLU + max over K consecutive points in one launch vs the two-step composition,
     K in {8,16,32,64}, ragged Cout / S."""
