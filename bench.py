@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 T
 MFMA_F32_PEAK_TF = 157.3         # MI355X_MICROARCH.md: dense fp32 MFMA peak
 MFMA_BF16_PEAK_TF = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA peak (2.17 PF sustained in tools/probe_mfma_bf16.hip)
 PRECONDITION_STEPS = 150         # untimed, before the --warmup steps (~80 ms of GPU work)
-SPLIT_PRODUCTS = 6               # bf16 MFMA products per fp32 product in the bf16x3 kernels
+SPLIT_PRODUCTS = {"f16x2": 3, "bf16x3": 6}    # low-precision MFMA products per fp32 product
 VALU_PEAK_LANEOPS = 256 * 4 * 16 * 2.4e9     # 39.3 T lane-ops/s: 256 CUs x 4 SIMD16 x 2.4 GHz (an fma counts once)
 KNN_LANEOPS_PER_PAIR = 7         # 2 fma + 1 mul + 2 sub + compare/insert
 CHAMFER_LANEOPS_PER_PAIR = 8
@@ -57,24 +57,26 @@ def pmc_traffic(tag):
         return None
 
 
-def edgeconv_roofline(ec_tf, ec_ms, split):
-    """MFMA roofline of the EdgeConv kernel on ALGORITHMIC fp32 flops.  fp32-MFMA kernel: peak = the
-    dense fp32 MFMA rate.  bf16x3 kernel: every algorithmic product is executed as 6 bf16 MFMA products,
-    so the ceiling for algorithmic flops is the dense bf16 MFMA peak / 6."""
+def edgeconv_roofline(ec_tf, ec_ms, arith):
+    """MFMA roofline of the EdgeConv kernel on ALGORITHMIC fp32 flops.  fp32-MFMA kernel: peak = the dense fp32 MFMA
+    rate.  Matrix-core split kernels execute every algorithmic product as P low-precision MFMA products (f16x2: 3 fp16,
+    bf16x3: 6 bf16), so the ceiling for algorithmic flops is the dense fp16 / bf16 MFMA peak / P."""
     alg = B_PER_GPU * EDGECONV_FLOP_PER_CLOUD
-    if not split:
+    if arith == "fp32":
         return {"kernel": "edgeconv2_kernel<5>", "bound": "mfma", "achieved": ec_tf, "peak": MFMA_F32_PEAK_TF,
                 "unit": "TFLOP/s", "frac": ec_tf / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("edgeconv"),
                 "avg_launch_ms": ec_ms, "algorithmic_flop_per_launch": alg}
-    peak = MFMA_BF16_PEAK_TF / SPLIT_PRODUCTS
+    prods = SPLIT_PRODUCTS[arith]
+    peak = MFMA_BF16_PEAK_TF / prods
     l1 = B_PER_GPU * NPTS * KNN * 2 * 6 * 64                       # layer 1 stays on the fp32 MFMA
-    return {"kernel": "edgeconv_split_kernel<5>", "bound": "mfma", "achieved": ec_tf, "peak": peak,
-            "unit": "TFLOP/s", "frac": ec_tf / peak, "traffic": pmc_traffic("edgeconv_split"),
+    name = "edgeconv_f16_kernel<5,true>" if arith == "f16x2" else "edgeconv_split_kernel<5>"
+    return {"kernel": name, "bound": "mfma", "achieved": ec_tf, "peak": peak,
+            "unit": "TFLOP/s", "frac": ec_tf / peak, "traffic": pmc_traffic("edgeconv_f16" if arith == "f16x2" else "edgeconv_split"),
             "avg_launch_ms": ec_ms, "algorithmic_flop_per_launch": alg,
-            "peak_note": "fp32-equivalent ceiling = dense bf16 MFMA peak 2500 TFLOP/s / 6 products per fp32 product "
+            "peak_note": f"fp32-equivalent ceiling = dense fp16/bf16 MFMA peak 2500 TFLOP/s / {prods} products per fp32 product "
                          "(the fp32 MFMA peak is 157.3 TFLOP/s)",
-            "executed_bf16_tflops": SPLIT_PRODUCTS * (alg - l1) / (ec_ms * 1e-3) / 1e12,
-            "bf16_dense_peak": MFMA_BF16_PEAK_TF}
+            "executed_lowprec_tflops": prods * (alg - l1) / (ec_ms * 1e-3) / 1e12,
+            "lowprec_dense_peak": MFMA_BF16_PEAK_TF}
 
 
 def cpu_model():
@@ -185,7 +187,10 @@ def main():
     ap.add_argument("--sync-loss", action="store_true",
                     help="N>1: make the blocking exchange the headline (default: pipelined; both are always reported)")
     ap.add_argument("--fp32-mfma", action="store_true",
-                    help="run the shared-MLP GEMMs on the fp32 MFMA (157 TF peak) instead of the bf16x3 kernels")
+                    help="run the shared-MLP GEMMs on the fp32 MFMA (157 TF peak) instead of the matrix-core split kernels")
+    ap.add_argument("--arith", choices=["f16x2", "bf16x3"], default=None,
+                    help="GEMM arithmetic of the shared-MLP kernels (default f16x2: 3 fp16 MFMA products per fp32 product; "
+                         "bf16x3: 6 bf16 products, full fp32 exponent range)")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="control-flow self test on CPU/gloo (launcher, sharding, collective, max-over-ranks, JSON): "
                          "NO kernels run and the printed line is not a measurement")
@@ -201,6 +206,8 @@ def main():
     from learning3d_amd.models import DGCNN, _fused
     if args.fp32_mfma:
         _fused.SPLIT_BF16 = False
+    if args.arith:
+        _fused.GEMM_ARITH = args.arith
     from learning3d_amd.losses.chamfer_distance import ChamferDistance, chamfer_partials
 
     rank, world, local = parallel.init_from_env()
@@ -301,11 +308,17 @@ def main():
         stage_ms["chamfer"] = per_launch_ms(lambda: cd(a, b))
         idx_ = U.knn(xt, KNN)
         packed_ = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
-        pooled_ = _fused.edgeconv_forward(x, idx_, packed_)
-        w5_, s5_, b5_, w5s_ = net._conv5_folded()
-        stage_ms["conv5"] = per_launch_ms(lambda: _fused.pointwise_conv(pooled_, w5_, s5_, b5_, relu=True, channel_last=True,
-                                                                          w_split=w5s_))
-        stage_ms.setdefault("edgeconv", per_launch_ms(lambda: _fused.edgeconv_forward(x, idx_, packed_)))
+        arith_ = _fused.gemm_arith()
+        w5_, s5_, b5_, w5s_, w5f_ = net._conv5_folded()
+        if arith_ == "f16x2":
+            img_ = _fused.edgeconv_forward(x, idx_, packed_, planes=True)
+            stage_ms["conv5"] = per_launch_ms(lambda: _fused.pointwise_conv_f16(img_, B_PER_GPU, NPTS, w5f_, 512, EMB, s5_, b5_, relu=True))
+        else:
+            pooled_ = _fused.edgeconv_forward(x, idx_, packed_)
+            stage_ms["conv5"] = per_launch_ms(lambda: _fused.pointwise_conv(pooled_, w5_, s5_, b5_, relu=True, channel_last=True,
+                                                                              w_split=w5s_))
+        stage_ms.setdefault("edgeconv", per_launch_ms(lambda: _fused.edgeconv_forward(x, idx_, packed_, planes=(arith_ == "f16x2"))))
+        _fused.check_range(sync=True)                 # no activation left the fp16 range during the run
 
     # max over ranks (the contract), and every rank's own time for the record
     t = torch.tensor([elapsed, other if other is not None else 0.0], dtype=torch.float64, device=dev)
@@ -327,10 +340,13 @@ def main():
         knn_gbs = B_PER_GPU * KNN_BYTES_PER_CLOUD / (stage_ms["knn"] * 1e-3) / 1e9
         ch_gbs = B_PER_GPU * CHAMFER_BYTES_PER_CLOUD / (stage_ms["chamfer"] * 1e-3) / 1e9
         c5_tf = B_PER_GPU * CONV5_FLOP_PER_CLOUD / (stage_ms["conv5"] * 1e-3) / 1e12
-        split = _fused.SPLIT_BF16
-        dtype = ("f32 (shared-MLP GEMMs as bf16x3: fp32 operands split exactly into 3 bf16 planes, 6 bf16 MFMA "
-                 "products per fp32 product, f32 accumulate, fp32-level error; distances/top-k/Chamfer plain f32)"
-                 if split else "f32")
+        arith = _fused.gemm_arith()
+        dtype = {"f16x2": "f32 (shared-MLP GEMMs as f16x2: fp32 operands carried as an fp16 high part + a 2^12-scaled fp16 residual, "
+                          "3 fp16 MFMA products per fp32 product, f32 accumulate, fp32-level error -- tests bound it by 2x the "
+                          "fp32-MFMA kernel's own error against fp64; distances/top-k/Chamfer plain f32)",
+                 "bf16x3": "f32 (shared-MLP GEMMs as bf16x3: fp32 operands split exactly into 3 bf16 planes, 6 bf16 MFMA "
+                           "products per fp32 product, f32 accumulate, fp32-level error; distances/top-k/Chamfer plain f32)",
+                 "fp32": "f32"}[arith]
         out = {
             "metric": "clouds/sec DGCNN-fwd+Chamfer B=32 N=1024; kNN HBM GB/s vs peak at 1/2/4/8 GPU",
             "value": clouds_per_s, "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
@@ -352,7 +368,7 @@ def main():
                 "mode": "asynchronous all_gather, consumed one step later" if args.sync_loss else "blocking all_gather inside the step",
                 "ms_per_step": other / args.steps * 1e3, "value": world * B_PER_GPU * args.steps / other},
             # dominant kernel by time: the fused 4-layer EdgeConv stack
-            "roofline": edgeconv_roofline(ec_tf, stage_ms["edgeconv"], split),
+            "roofline": edgeconv_roofline(ec_tf, stage_ms["edgeconv"], arith),
             # the metric's second half: kNN (and Chamfer) HBM rate on ALGORITHMIC bytes
             "roofline_knn": {"kernel": "topk2_kernel<20,EXPANDED,4>", "bound": "hbm", "achieved": knn_gbs,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": knn_gbs / HBM_PEAK_GBS,

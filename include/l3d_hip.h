@@ -295,15 +295,23 @@ int l3d_edgeconv_forward_chained(const float *xyz, const int64_t *idx, int B, in
  * fraction of the fp32-MFMA time.  k <= 20; packed must be 16-byte aligned. */
 int l3d_edgeconv_forward_split(const float *xyz, const int64_t *idx, int B, int N, int k,
                                const float *packed, float *pooled, l3d_stream_t stream);
-/* Same computation, same packed block (its fourth weight copy), same output layout; layers 2-4 as "f16x2" on the
- * fp16 matrix cores (edgeconv_f16.hip): activations x = h + m' 2^-12 (h = f16(x), m' = f16((x - h) 2^12)), weights
- * scaled by a per-layer power of two and split the same way, THREE fp16 MFMA products per fp32 product into one fp32
- * accumulator -- fp32-level error (tests hold it to the bf16x3 bar) at half of bf16x3's matrix-core work.
- * Range contract: post-ReLU activations of layers 1-3 must stay below 65504 (fp16); the kernel watches the pooled
- * maxima it writes anyway and stores 1 to *range_flag (device or mapped host memory, may be NULL) when one exceeds
- * 60000 -- the outputs are then invalid and the caller re-runs l3d_edgeconv_forward_split.  k <= 20. */
-int l3d_edgeconv_forward_f16(const float *xyz, const int64_t *idx, int B, int N, int k,
-                             const float *packed, float *pooled, int *range_flag, l3d_stream_t stream);
+/* Same computation, same packed block (its fourth weight copy); layers 2-4 as "f16x2" on the fp16 matrix cores
+ * (edgeconv_f16.hip): activations X = x 2^T as h = f16(X), m' = f16((X - h) 2^12), weights scaled by a per-layer power of
+ * two and split the same way, THREE fp16 MFMA products per fp32 product into one fp32 accumulator -- fp32-level error
+ * (tests hold it to the bf16x3 bar) at half of bf16x3's matrix-core work.  T per layer is fixed when the block is packed,
+ * from the activation magnitudes the caller expects (l3d_edgeconv_pack_mag; BatchNorm statistics give them).
+ *   out_mode 0: out = pooled [B,N,512] fp32, channel-last (as the other EdgeConv entry points)
+ *   out_mode 1: out = an fp16 activation image of the pooled values (l3d_f16_act_bytes(B*N, 512)), the x operand of
+ *               l3d_pointwise_conv_f16 -- conv5 then runs without any split pass
+ * Range contract: activations must stay below 16x the expected magnitude (fp16 tops out at 65504); the kernel watches
+ * the pooled maxima it forms anyway and stores 1 to *range_flag (device or mapped host memory, may be NULL) when a
+ * plane value exceeds 60000 -- the outputs are then invalid and the caller re-runs l3d_edgeconv_forward_split.  k <= 20. */
+int l3d_edgeconv_forward_f16(const float *xyz, const int64_t *idx, int B, int N, int k, const float *packed, void *out,
+                             int out_mode, int *range_flag, l3d_stream_t stream);
+/* l3d_edgeconv_pack with act_mag[4]: the magnitude (a few standard deviations) expected of each layer's post-ReLU
+ * activations; NULL or non-positive entries mean 1.  Only the f16x2 kernel uses it. */
+int l3d_edgeconv_pack_mag(const float *const w[4], const float *const scale[4], const float *const shift[4],
+                          const float *act_mag, int c1, int c2, int c3, int c4, float *packed);
 /* Per-point linear layer (Conv1d/Conv2d 1x1 + folded BN + optional ReLU):
  *   y[b][co][n] = act(scale[co] * sum_ci w[co][ci] x[b][ci][n] + shift[co])
  *   x [B,Cin,N] (x_channel_last = 0, torch Conv1d layout) or [B,N,Cin] (x_channel_last = 1),

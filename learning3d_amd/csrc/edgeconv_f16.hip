@@ -120,7 +120,14 @@ struct EfLane {
     bool odd, hi;            // q & 1, q & 2
     unsigned laneoff;        // lane * 16: byte offset of the lane's 16 bytes inside a 1 KB fragment
     ef_rsrc_t rs;            // the packed parameter block
-    float *prow;             // pooled + (b N + point) CTOT + 4 g + {0,2,1,3}[q]
+    float *prow;             // out_mode 0: pooled + (b N + point) CTOT + 4 g + {0,2,1,3}[q]
+    _Float16 *ph;            // out_mode 1: the h plane's cell of (this lane's channel within a 16-channel M-tile, its point)
+    size_t bn;               // B N: channel ch0 + 16 k lies (ch0 + 16 k) * bn halfs further, the m' plane 512 * bn beyond that
+};
+
+// Power-of-two scales of one layer's accumulators (edgeconv_layout.h): to its split planes, to the pooled output
+struct EfScale {
+    float split, pool;
 };
 
 // Scratch values that live from one micro-unit to the next
@@ -145,9 +152,10 @@ struct EfTmp {
 // ---------------------------------------------------------------------------------------------
 template <int MT, bool LAST> struct EfN { static constexpr int UNITS = LAST ? 12 : 6 * MT + 12; };
 
-template <int MT, bool LAST, bool RAW, int U>
-__device__ __forceinline__ void ef_micro(f32x4 (&h)[2][MT], f16x8 (&pl)[2][MT], EfTmp &T, int ch0, const EfLane &L, float c, float &ovf)
+template <int MT, bool LAST, bool RAW, bool PLANES, int U>
+__device__ __forceinline__ void ef_micro(f32x4 (&h)[2][MT], f16x8 (&pl)[2][MT], EfTmp &T, int ch0, const EfLane &L, const EfScale &sc, float &ovf)
 {
+    const float c = sc.split;
     constexpr int NT = LAST ? 0 : 6 * MT;                    // units before the pool units
     if constexpr (U < NT) {
         constexpr int t = U / 6, k = U % 6;
@@ -190,9 +198,18 @@ __device__ __forceinline__ void ef_micro(f32x4 (&h)[2][MT], f16x8 (&pl)[2][MT], 
             const float kk = L.hi ? T.xs[k][1] : T.xs[k][0], gg = L.hi ? T.xs[k][0] : T.xs[k][1];
             float v = ef_dpp_max_x2(gg, kk);
             if constexpr (LAST) v = ef_vmax(v, 0.f);         // non-LAST values were ReLU'd before pooling
-            v *= c;
-            if constexpr (!LAST) ovf = ef_vmax(ovf, v);      // only layers whose output is split matter
-            L.prow[ch0 + 16 * k] = v;
+            if constexpr (!LAST) ovf = ef_vmax(ovf, v * sc.split);   // in plane units: what the next layer's fp16 planes hold
+            v *= sc.pool;
+            if constexpr (PLANES) {                          // pooled output as fp16 planes (times 2^T_out) for conv_f16.hip
+                ovf = ef_vmax(ovf, v);
+                const _Float16 hh = (_Float16)v;
+                const _Float16 mm = (_Float16)((v - (float)hh) * 4096.0f);
+                _Float16 *d = L.ph + (size_t)(ch0 + 16 * k) * L.bn;
+                d[0] = hh;
+                d[(size_t)512 * L.bn] = mm;
+            } else {
+                L.prow[ch0 + 16 * k] = v;
+            }
         }
     }
 }
@@ -209,11 +226,11 @@ __device__ __forceinline__ void ef_static_for(F &&f)
     }
 }
 
-template <int MT, bool LAST, bool RAW>
-__device__ __forceinline__ void ef_finish_all(f32x4 (&h)[2][MT], f16x8 (&pl)[2][MT], int ch0, const EfLane &L, float c, float &ovf)
+template <int MT, bool LAST, bool RAW, bool PLANES>
+__device__ __forceinline__ void ef_finish_all(f32x4 (&h)[2][MT], f16x8 (&pl)[2][MT], int ch0, const EfLane &L, const EfScale &sc, float &ovf)
 {
     EfTmp T;
-    ef_static_for<0, EfN<MT, LAST>::UNITS>([&](auto u) { ef_micro<MT, LAST, RAW, decltype(u)::value>(h, pl, T, ch0, L, c, ovf); });
+    ef_static_for<0, EfN<MT, LAST>::UNITS>([&](auto u) { ef_micro<MT, LAST, RAW, PLANES, decltype(u)::value>(h, pl, T, ch0, L, sc, ovf); });
 }
 
 // EF_PIN: the compiler's IR passes sink a load towards its first use (two steps later) regardless of
@@ -267,11 +284,11 @@ __device__ __forceinline__ void ef_ring_fill(EfRing &R, ef_rsrc_t rs, int woff, 
 // mp = this pair; nx = the pair executed after it, in this layer or the first of the next (fragment and bias
 // prefetches cross both boundaries); pairs may be executed in any order.  R.bv: this pair's bias (the MFMA C operand of
 // each M-tile's first product); replaced by the next pair's on return.  c_prev: 2^-S of hp's layer.
-template <int MT, int S, bool PREV_LAST, bool PREV_RAW, int NSL>
+template <int MT, int S, bool PREV_LAST, bool PREV_RAW, bool PLANES, int NSL>
 __device__ __forceinline__ void ef_pair(int mp, const EfNext &nx, const f16x8 (&pin)[S][2][MT], const f16x8 (&pin_last)[2][MT],
                                         int woff, EfRing &R,
                                         f32x4 (&acc)[2][MT], f32x4 (&hp)[2][MT], f16x8 (&po_prev)[2][MT],
-                                        int ch_prev, const EfLane &L, float c_prev, float &ovf)
+                                        int ch_prev, const EfLane &L, const EfScale &c_prev, float &ovf)
 {
     static_assert(2 * S >= EF_PD, "a pair is at least EF_PD steps long");
     constexpr int NU = EfN<MT, PREV_LAST>::UNITS;                    // micro-units to hide
@@ -313,7 +330,7 @@ __device__ __forceinline__ void ef_pair(int mp, const EfNext &nx, const f16x8 (&
                 if constexpr (slot < NSL)
 #endif
                     ef_static_for<slot * NU / NSL, (slot + 1) * NU / NSL>([&](auto u) {
-                        ef_micro<MT, PREV_LAST, PREV_RAW, decltype(u)::value>(hp, po_prev, T, ch_prev, L, c_prev, ovf);
+                        ef_micro<MT, PREV_LAST, PREV_RAW, PLANES, decltype(u)::value>(hp, po_prev, T, ch_prev, L, c_prev, ovf);
                     });
             });
         });
@@ -340,11 +357,11 @@ __device__ __forceinline__ void ef_pair(int mp, const EfNext &nx, const f16x8 (&
 // array is indexed by the pair): this workgroup starts at pair `rot`.
 // IN_RAW: accB on entry was produced by asm MFMAs (layers >= 2) rather than builtins (layer 1).
 // c_in / c_own: 2^-S of the previous layer (whose last pair is finished here) and of this layer; bias is pre-scaled.
-template <int MT, int S, int NPAIR, bool LAST, bool UNROLL, bool IN_RAW>
+template <int MT, int S, int NPAIR, bool LAST, bool UNROLL, bool IN_RAW, bool PLANES>
 __device__ __forceinline__ void ef_layer(const f16x8 (&pin)[S][2][MT], f16x8 (&pout)[LAST ? 1 : NPAIR][2][MT],
                                          int woff, const float *bias4g, const EfNext &after, EfRing &R, int ch_own,
                                          f32x4 (&accA)[2][MT], f32x4 (&accB)[2][MT], int ch_in,
-                                         int *mp_out, const EfLane &L, int rot, float c_in, float c_own, float &ovf)
+                                         int *mp_out, const EfLane &L, int rot, const EfScale &c_in, const EfScale &c_own, float &ovf)
 {
     static_assert(NPAIR % 2 == 0 && S >= 2, "pairs are processed two at a time; deferred finish needs S >= 2");
     constexpr int NS = 2 * S * 3 * MT, NSD = (S - 1) * 6 * MT;      // MFMA slots of a pair; of its k-steps 0 .. S-2
@@ -354,23 +371,23 @@ __device__ __forceinline__ void ef_layer(const f16x8 (&pin)[S][2][MT], f16x8 (&p
         // written out (NPAIR is 2 or 4): a `#pragma unroll` loop over this much code is not always
         // unrolled, and a rolled loop indexes pout dynamically, which sends the planes to scratch
         static_assert(NPAIR == 2 || NPAIR == 4, "unrolled layers have 2 or 4 output pairs");
-        ef_pair<MT, S, false, IN_RAW, NSD>(0, in_layer(1), pin, last, woff, R, accA, accB, last, ch_in, L, c_in, ovf);
-        ef_pair<MT, S, LAST, true, NS>(1, NPAIR > 2 ? in_layer(2) : after, pin, last, woff, R, accB, accA, pout[0], ch_own, L, c_own, ovf);
+        ef_pair<MT, S, false, IN_RAW, PLANES, NSD>(0, in_layer(1), pin, last, woff, R, accA, accB, last, ch_in, L, c_in, ovf);
+        ef_pair<MT, S, LAST, true, PLANES, NS>(1, NPAIR > 2 ? in_layer(2) : after, pin, last, woff, R, accB, accA, pout[0], ch_own, L, c_own, ovf);
         if constexpr (NPAIR == 4) {
-            ef_pair<MT, S, LAST, true, NS>(2, in_layer(3), pin, last, woff, R, accA, accB, pout[1], ch_own + 32, L, c_own, ovf);
-            ef_pair<MT, S, LAST, true, NS>(3, after, pin, last, woff, R, accB, accA, pout[2], ch_own + 64, L, c_own, ovf);
+            ef_pair<MT, S, LAST, true, PLANES, NS>(2, in_layer(3), pin, last, woff, R, accA, accB, pout[1], ch_own + 32, L, c_own, ovf);
+            ef_pair<MT, S, LAST, true, PLANES, NS>(3, after, pin, last, woff, R, accB, accA, pout[2], ch_own + 64, L, c_own, ovf);
         }
         *mp_out = NPAIR - 1;
     } else {
         const int q0 = rot % NPAIR, q1 = (1 + rot) % NPAIR, q2 = (2 + rot) % NPAIR;
-        ef_pair<MT, S, false, IN_RAW, NSD>(q0, in_layer(q1), pin, last, woff, R, accA, accB, last, ch_in, L, c_in, ovf);
-        ef_pair<MT, S, LAST, true, NS>(q1, in_layer(q2), pin, last, woff, R, accB, accA, pout[0], ch_own + 32 * q0, L, c_own, ovf);
+        ef_pair<MT, S, false, IN_RAW, PLANES, NSD>(q0, in_layer(q1), pin, last, woff, R, accA, accB, last, ch_in, L, c_in, ovf);
+        ef_pair<MT, S, LAST, true, PLANES, NS>(q1, in_layer(q2), pin, last, woff, R, accB, accA, pout[0], ch_own + 32 * q0, L, c_own, ovf);
         int mpB = q1;                                                   // pair whose results sit in accB
 #pragma unroll 1
         for (int i = 2; i < NPAIR; i += 2) {
             const int m0 = (i + rot) % NPAIR, m1 = (i + 1 + rot) % NPAIR, m2 = (i + 2 + rot) % NPAIR;
-            ef_pair<MT, S, LAST, true, NS>(m0, in_layer(m1), pin, last, woff, R, accA, accB, pout[0], ch_own + 32 * mpB, L, c_own, ovf);
-            ef_pair<MT, S, LAST, true, NS>(m1, i + 2 < NPAIR ? in_layer(m2) : after, pin, last, woff, R, accB, accA, pout[0],
+            ef_pair<MT, S, LAST, true, PLANES, NS>(m0, in_layer(m1), pin, last, woff, R, accA, accB, pout[0], ch_own + 32 * mpB, L, c_own, ovf);
+            ef_pair<MT, S, LAST, true, PLANES, NS>(m1, i + 2 < NPAIR ? in_layer(m2) : after, pin, last, woff, R, accB, accA, pout[0],
                                            ch_own + 32 * m0, L, c_own, ovf);
             mpB = m1;
         }
@@ -378,11 +395,13 @@ __device__ __forceinline__ void ef_layer(const f16x8 (&pin)[S][2][MT], f16x8 (&p
     }
 }
 
-template <int MT>
+// PLANES = false: pooled [B*N][512] fp32 (channel-last).  PLANES = true: `pooled` is an fp16 activation image for
+// conv_f16.hip -- h | m' planes [512/8][B*N][8] of the pooled values times 2^T_out, then 2^-T_out (written here too).
+template <int MT, bool PLANES>
 __global__ __launch_bounds__(256, 1) void edgeconv_f16_kernel(const float *__restrict__ xyz,
                                                               const int64_t *__restrict__ idx, int N, int k,
                                                               const float *packed,
-                                                              float *__restrict__ pooled /*[B*N][512]*/,
+                                                              float *__restrict__ pooled,
                                                               int *__restrict__ range_flag
 #ifdef EF_TIMING
                                                               , unsigned long long *tdbg
@@ -409,9 +428,16 @@ __global__ __launch_bounds__(256, 1) void edgeconv_f16_kernel(const float *__res
     L.rs.p = (const char *)packed;
     L.odd = j & 1;
     L.hi = j & 2;
-    L.prow = pooled + ((size_t)b * N + nc) * CTOT + 4 * g + ((j & 1) * 2 + ((j >> 1) & 1));
-    // 2^-S of layers 2..4 (uniform: scalar loads)
-    const float c2 = packed[EC4_OFF_SC], c3 = packed[EC4_OFF_SC + 1], c4 = packed[EC4_OFF_SC + 2];
+    const int cl = 4 * g + ((j & 1) * 2 + ((j >> 1) & 1));       // this lane's channel inside a 16-channel M-tile
+    L.prow = pooled + ((size_t)b * N + nc) * CTOT + cl;
+    L.bn = (size_t)gridDim.y * N;
+    L.ph = (_Float16 *)pooled + ((size_t)(cl >> 3) * L.bn + (size_t)b * N + nc) * 8 + (cl & 7);
+    if (PLANES && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        *(float *)((_Float16 *)pooled + 2 * 512 * L.bn) = packed[EC4_OFF_SC + 12];        // the image's 2^-T_out
+    // power-of-two scales of the four layers' accumulators (uniform: scalar loads), see edgeconv_layout.h
+    const int po = PLANES ? 8 : 4;
+    const EfScale s1 = {packed[EC4_OFF_SC + 0], packed[EC4_OFF_SC + po + 0]}, s2 = {packed[EC4_OFF_SC + 1], packed[EC4_OFF_SC + po + 1]},
+                  s3 = {packed[EC4_OFF_SC + 2], packed[EC4_OFF_SC + po + 2]}, s4 = {1.0f, packed[EC4_OFF_SC + po + 3]};
     float ovf = 0.f;
     // layer 2's first fragments and bias: requested before the gather so that their latency hides behind it
     EfRing R;
@@ -452,7 +478,7 @@ __global__ __launch_bounds__(256, 1) void edgeconv_f16_kernel(const float *__res
                     for (int t = 0; t < MT; t++)
                         accB[mm][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[t][s], accB[mm][t], 0, 0, 0);
             }
-            if (mp + 1 < EC_C1 / 32) ef_finish_all<MT, false, false>(accB, p1[mp], 32 * mp, L, 1.0f, ovf);
+            if (mp + 1 < EC_C1 / 32) ef_finish_all<MT, false, false, PLANES>(accB, p1[mp], 32 * mp, L, s1, ovf);
         }
     }
     int mp_last;
@@ -466,27 +492,28 @@ __global__ __launch_bounds__(256, 1) void edgeconv_f16_kernel(const float *__res
     const int rot = EF_ROT ? (int)(((blockIdx.x + gridDim.x * blockIdx.y) >> 3) % (EC_C4 / 32)) : 0;   // >>3: ids = XCD mod 8
     // ---- layer 2: 64 -> 64   (its first pair hides the finish of layer 1's last pair, and so on down)
     f16x8 p2[EC_C2 / 32][2][MT];
-    ef_layer<MT, EC_C1 / 32, EC_C2 / 32, false, true, false>(
+    ef_layer<MT, EC_C1 / 32, EC_C2 / 32, false, true, false, PLANES>(
         p1, p2, w2, bs2, EfNext{w3, bs3, 0, 2 * (EC_C2 / 32)}, R, EC_C1, accA, accB,
-        32 * (EC_C1 / 32 - 1), &mp_last, L, 0, 1.0f, c2, ovf);
+        32 * (EC_C1 / 32 - 1), &mp_last, L, 0, s1, s2, ovf);
     EF_T(3);
     // ---- layer 3: 64 -> 128
     f16x8 p3[EC_C3 / 32][2][MT];
-    ef_layer<MT, EC_C2 / 32, EC_C3 / 32, false, true, true>(
+    ef_layer<MT, EC_C2 / 32, EC_C3 / 32, false, true, true, PLANES>(
         p2, p3, w3, bs3, EfNext{w4, bs4, rot, 2 * (EC_C3 / 32)}, R, EC_C1 + EC_C2, accA, accB,
-        EC_C1 + 32 * (EC_C2 / 32 - 1), &mp_last, L, 0, c2, c3, ovf);
+        EC_C1 + 32 * (EC_C2 / 32 - 1), &mp_last, L, 0, s2, s3, ovf);
     EF_T(4);
     // ---- layer 4: 128 -> 256, only max-pooled
     f16x8 dummy[1][2][MT];
-    ef_layer<MT, EC_C3 / 32, EC_C4 / 32, true, false, true>(
+    ef_layer<MT, EC_C3 / 32, EC_C4 / 32, true, false, true, PLANES>(
         p3, dummy, w4, bs4, EfNext{w4, bs4, 0, 2 * (EC_C3 / 32)}, R, EC_C1 + EC_C2 + EC_C3, accA, accB,
-        EC_C1 + EC_C2 + 32 * (EC_C3 / 32 - 1), &mp_last, L, rot, c3, c4, ovf);
+        EC_C1 + EC_C2 + 32 * (EC_C3 / 32 - 1), &mp_last, L, rot, s3, s4, ovf);
     asm volatile("s_nop 15\n\ts_nop 15");                       // the last asm MFMAs must have written accB (no compiler padding)
-    ef_finish_all<MT, true, true>(accB, dummy[0], EC_C1 + EC_C2 + EC_C3 + 32 * mp_last, L, c4, ovf);
+    ef_finish_all<MT, true, true, PLANES>(accB, dummy[0], EC_C1 + EC_C2 + EC_C3 + 32 * mp_last, L, s4, ovf);
     EF_T(5);
-    // fp16 range guard: ovf = the largest layer-1..3 activation this lane pooled (post-ReLU, so the pooled maxima
-    // are the maxima).  Never taken for BatchNorm'd networks; the host re-runs on the bf16x3 kernel if it is.
-    if (ovf > 60000.f && range_flag) *(volatile int *)range_flag = 1;     // may live in mapped host memory: plain store
+    // fp16 range guard: ovf = the largest value (in plane units) this lane handed to fp16 planes -- layers 1-3, and the
+    // pooled planes when PLANES; activations are post-ReLU, so the pooled maxima are the maxima.  Not taken while the
+    // activations stay within 16x of the magnitude the packer was told; the host re-runs on the bf16x3 kernel if it is.
+    if (!(ovf <= 60000.f) && range_flag) *(volatile int *)range_flag = 1; // may live in mapped host memory: plain store
 #ifdef EF_TIMING
     if (threadIdx.x == 0)
         for (int i = 0; i < 6; i++) tdbg[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 6 + i] = tk[i];
@@ -495,14 +522,20 @@ __global__ __launch_bounds__(256, 1) void edgeconv_f16_kernel(const float *__res
 
 #ifndef EF_TIMING
 extern "C" int l3d_edgeconv_forward_f16(const float *xyz, const int64_t *idx, int B, int N, int k,
-                                        const float *packed, float *pooled, int *range_flag, l3d_stream_t stream)
+                                        const float *packed, void *out, int out_mode, int *range_flag, l3d_stream_t stream)
 {
-    L3D_REQUIRE(xyz && idx && packed && pooled && B > 0 && N > 0 && k > 0);
-    if (k > 20 || B > 65535 || (((size_t)packed) & 15)) return L3D_ERR_UNSUPPORTED;
+    L3D_REQUIRE(xyz && idx && packed && out && B > 0 && N > 0 && k > 0 && (out_mode == 0 || out_mode == 1));
+    if (k > 20 || B > 65535 || (((size_t)packed) & 15) || (((size_t)out) & 15)) return L3D_ERR_UNSUPPORTED;
     dim3 grid(l3d_divup(N, 16), B), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (k <= 16) hipLaunchKernelGGL(edgeconv_f16_kernel<4>, grid, block, 0, st, xyz, idx, N, k, packed, pooled, range_flag);
-    else              hipLaunchKernelGGL(edgeconv_f16_kernel<5>, grid, block, 0, st, xyz, idx, N, k, packed, pooled, range_flag);
+    float *o = (float *)out;
+    if (out_mode == 0) {
+        if (k <= 16) hipLaunchKernelGGL((edgeconv_f16_kernel<4, false>), grid, block, 0, st, xyz, idx, N, k, packed, o, range_flag);
+        else              hipLaunchKernelGGL((edgeconv_f16_kernel<5, false>), grid, block, 0, st, xyz, idx, N, k, packed, o, range_flag);
+    } else {
+        if (k <= 16) hipLaunchKernelGGL((edgeconv_f16_kernel<4, true>), grid, block, 0, st, xyz, idx, N, k, packed, o, range_flag);
+        else              hipLaunchKernelGGL((edgeconv_f16_kernel<5, true>), grid, block, 0, st, xyz, idx, N, k, packed, o, range_flag);
+    }
     return l3d_check_launch();
 }
 #endif

@@ -33,8 +33,12 @@
 
 // fourth copy, layers 2-4, for the f16x2 kernel (edgeconv_f16.hip): W = w' 2^S (S per layer so that max|W| is in
 // [4,8)) as three fp16 planes H = f16(W), Hs = f16(H 2^-12), M = f16(W - H), same fragment order as the third copy
-// ([step][plane 3: H, Hs, M][lane 64][8 f16]); then the biases of layers 2-4 pre-multiplied by 2^S, then 2^-S of
-// layers 2, 3, 4 (+ one pad float).
+// ([step][plane 3: H, Hs, M][lane 64][8 f16]); then the biases of layers 2-4 in accumulator units, then 16 scale
+// constants.  Activation planes are stored times 2^T (T_l per layer from the expected activation magnitude, so that it
+// sits near 2^12 in fp16's 2^-14 .. 2^16; T_out = min_l T_l for the pooled planes handed to conv5); layer l >= 2
+// accumulates A_l = 2^(S_l + T_(l-1)) times the true value (A_1 = 1).  EC4_OFF_SC + :
+//   0..2  cs_l = 2^T_l / A_l, l = 1..3 (accumulator -> this layer's planes)      4..7  cp_l = 1 / A_l (-> fp32 pooled)
+//   8..11 co_l = 2^T_out / A_l (-> pooled planes for conv5)                      12    2^-T_out
 #define EC4_OFF_W2 EC3_END
 #define EC4_OFF_W3 (EC4_OFF_W2 + (EC_C2 / 16) * (EC_C1 / 32) * 3 * 64 * 4)
 #define EC4_OFF_W4 (EC4_OFF_W3 + (EC_C3 / 16) * (EC_C2 / 32) * 3 * 64 * 4)
@@ -42,4 +46,4 @@
 #define EC4_OFF_B3 (EC4_OFF_B2 + EC_C2)
 #define EC4_OFF_B4 (EC4_OFF_B3 + EC_C3)
 #define EC4_OFF_SC (EC4_OFF_B4 + EC_C4)
-#define EC_PACKED_FLOATS (EC4_OFF_SC + 4)
+#define EC_PACKED_FLOATS (EC4_OFF_SC + 16)

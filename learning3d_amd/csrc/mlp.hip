@@ -81,9 +81,9 @@ static void pack_layer(const float *w /*[cout][cin]*/, const float *scale, int c
                 }
 }
 
-extern "C" int l3d_edgeconv_pack(const float *const w[4], const float *const scale[4],
-                                 const float *const shift[4], int c1, int c2, int c3, int c4,
-                                 float *packed)
+extern "C" int l3d_edgeconv_pack_mag(const float *const w[4], const float *const scale[4],
+                                     const float *const shift[4], const float *act_mag, int c1, int c2, int c3, int c4,
+                                     float *packed)
 {
     L3D_REQUIRE(w && packed && w[0] && w[1] && w[2] && w[3]);
     if (c1 != EC_C1 || c2 != EC_C2 || c3 != EC_C3 || c4 != EC_C4) return L3D_ERR_UNSUPPORTED;
@@ -153,6 +153,7 @@ extern "C" int l3d_edgeconv_pack(const float *const w[4], const float *const sca
     //   M = f16(W - H) in the fragment order of the third copy; biases times 2^S; 2^-S per layer.
     const int o4[4] = {0, EC4_OFF_W2, EC4_OFF_W3, EC4_OFF_W4};
     const int ob4[4] = {0, EC4_OFF_B2, EC4_OFF_B3, EC4_OFF_B4};
+    int Sl[4] = {0, 0, 0, 0};
     for (int l = 1; l < 4; l++) {
         const float *wl = w[l];
         const float *sc = scale ? scale[l] : nullptr;
@@ -169,7 +170,8 @@ extern "C" int l3d_edgeconv_pack(const float *const w[4], const float *const sca
             frexpf(wmax, &e);                                 // wmax = f 2^e, f in [0.5, 1)
             S = 3 - e;
         }
-        const float up = ldexpf(1.0f, S), down = ldexpf(1.0f, -S);
+        Sl[l] = S;
+        const float up = ldexpf(1.0f, S);
         uint16_t *dst = (uint16_t *)(packed + o4[l]);
         const int St = cin[l] / 32;
         for (int m = 0; m < cs[l] / 16; m++)
@@ -191,11 +193,34 @@ extern "C" int l3d_edgeconv_pack(const float *const w[4], const float *const sca
                             dst[(((((size_t)(m >> 1) * St + sidx) * 2 + (m & 1)) * 3 + p) * 64 + lane) * 8 + slot] = bits;
                         }
                     }
-        for (int c = 0; c < cs[l]; c++) packed[ob4[l] + c] = ((shift && shift[l]) ? shift[l][c] : 0.f) * up;
-        packed[EC4_OFF_SC + (l - 1)] = down;
     }
-    packed[EC4_OFF_SC + 3] = 0.f;
+    // plane exponents from the expected activation magnitudes (act_mag[l] 2^T_l in [2^11, 2^12); default magnitude 1)
+    int Tl[4], Tout = 1 << 20;
+    for (int l = 0; l < 4; l++) {
+        const float mag = (act_mag && act_mag[l] > 0.f && act_mag[l] < INFINITY) ? act_mag[l] : 1.0f;
+        int e;
+        frexpf(mag, &e);
+        Tl[l] = 12 - e;
+        Tout = Tl[l] < Tout ? Tl[l] : Tout;
+    }
+    for (int i = 0; i < 16; i++) packed[EC4_OFF_SC + i] = 0.f;
+    for (int l = 0; l < 4; l++) {
+        const int A = l == 0 ? 0 : Sl[l] + Tl[l - 1];           // log2 of the accumulator's scale
+        if (l < 3) packed[EC4_OFF_SC + l] = ldexpf(1.0f, Tl[l] - A);
+        packed[EC4_OFF_SC + 4 + l] = ldexpf(1.0f, -A);
+        packed[EC4_OFF_SC + 8 + l] = ldexpf(1.0f, Tout - A);
+        if (l >= 1)
+            for (int c = 0; c < cs[l]; c++) packed[ob4[l] + c] = ldexpf((shift && shift[l]) ? shift[l][c] : 0.f, A);
+    }
+    packed[EC4_OFF_SC + 12] = ldexpf(1.0f, -Tout);
     return L3D_OK;
+}
+
+extern "C" int l3d_edgeconv_pack(const float *const w[4], const float *const scale[4],
+                                 const float *const shift[4], int c1, int c2, int c3, int c4,
+                                 float *packed)
+{
+    return l3d_edgeconv_pack_mag(w, scale, shift, nullptr, c1, c2, c3, c4, packed);
 }
 
 // One layer for one wave: acc[mt][i] += A(act rows) x B(weight fragments of this wave's N-tiles)

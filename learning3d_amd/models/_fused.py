@@ -241,19 +241,22 @@ class EdgeConvParams:
             tensors += [c.weight, b.weight, b.bias, b.running_mean, b.running_var]
         key = (str(device),) + tuple((t.data_ptr(), t._version) for t in tensors)
         if key != self.key:
-            ws, scs, shs = [], [], []
+            ws, scs, shs, mags = [], [], [], []
             for c, b in zip(convs, bns):
                 w, sc, sh = fold_conv_bn(c, b)
                 ws.append(w.float().cpu().contiguous())
                 scs.append(sc.float().cpu().contiguous())
                 shs.append(sh.float().cpu().contiguous())
+                # expected post-ReLU magnitude of the layer (4 sigma): the f16x2 kernel places its fp16 planes by it
+                mags.append(float((4.0 * b.weight.detach().abs() + b.bias.detach().abs()).max()))
             cs = [w.shape[0] for w in ws]
             nfl = lib().l3d_edgeconv_packed_floats(*cs)
             if nfl == 0:
                 raise NotImplementedError(f"EdgeConv channel widths {cs} are not built (64/64/128/256 only)")
             packed = torch.empty(nfl, dtype=torch.float32)
             arr = lambda ts: (C.c_void_p * 4)(*[t.data_ptr() for t in ts])
-            check(lib().l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), *cs, ptr(packed)), "l3d_edgeconv_pack")
+            check(lib().l3d_edgeconv_pack_mag(arr(ws), arr(scs), arr(shs), (C.c_float * 4)(*mags), *cs, ptr(packed)),
+                  "l3d_edgeconv_pack_mag")
             self.packed = packed.to(device)
             self.key = key
         return self.packed
@@ -317,11 +320,20 @@ def check_range(device=None, sync=False):
 EDGECONV_KERNEL = None
 
 
-def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256), kernel=None):
-    """xyz [B,N,3], idx int64 [B,N,k] -> pooled [B,N,sum(widths)] (channel-last)."""
+def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256), kernel=None, planes=False):
+    """xyz [B,N,3], idx int64 [B,N,k] -> pooled [B,N,sum(widths)] (channel-last).  planes=True (f16 kernel only): an
+    fp16 activation image of the pooled values instead (uint8 tensor), the x operand of pointwise_conv_f16."""
     require_gpu(xyz_bn3, idx, packed)
     B, N, _ = xyz_bn3.shape
     k = idx.shape[2]
+    if planes:
+        if not (k <= 20 and tuple(widths) == (64, 64, 128, 256)):
+            raise ValueError("planes output is produced by the f16 EdgeConv kernel only (k <= 20, 64/64/128/256)")
+        out = torch.empty(lib().l3d_f16_act_bytes(B * N, sum(widths)), dtype=torch.uint8, device=xyz_bn3.device)
+        check_range(xyz_bn3.device)
+        check(lib().l3d_edgeconv_forward_f16(ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), ptr(out), 1,
+                                             ptr(range_flag(xyz_bn3.device)), stream_ptr()), "l3d_edgeconv_forward_f16")
+        return out
     pooled = torch.empty((B, N, sum(widths)), dtype=torch.float32, device=xyz_bn3.device)
     if kernel is None:
         kernel = EDGECONV_KERNEL or {"f16x2": "f16", "bf16x3": "split", "fp32": "chained"}[gemm_arith()]
@@ -332,7 +344,7 @@ def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256), kernel=Non
     if kernel == "f16":
         check_range(xyz_bn3.device)                      # a previous launch's verdict, if it has completed
         flag = range_flag(xyz_bn3.device)
-        check(lib().l3d_edgeconv_forward_f16(ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), ptr(pooled), ptr(flag),
+        check(lib().l3d_edgeconv_forward_f16(ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), ptr(pooled), 0, ptr(flag),
                                              stream_ptr()), "l3d_edgeconv_forward_f16")
     elif kernel == "split":
         check(lib().l3d_edgeconv_forward_split(ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), ptr(pooled),

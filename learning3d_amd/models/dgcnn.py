@@ -38,7 +38,8 @@ class DGCNN(torch.nn.Module):
             w, s, b = _fused.fold_conv_bn(self.conv5, self.bn5)
             w = w.float().contiguous()
             w_split = _fused.split_rows(w) if (_fused.SPLIT_BF16 and w.is_cuda) else None
-            self._c5 = (w, s.float().contiguous(), b.float().contiguous(), w_split)
+            w_f16 = _fused.split_weights_f16(w) if (_fused.SPLIT_BF16 and w.is_cuda) else None
+            self._c5 = (w, s.float().contiguous(), b.float().contiguous(), w_split, w_f16)
             self._c5key = key
         return self._c5
 
@@ -55,9 +56,18 @@ class DGCNN(torch.nn.Module):
                 idx = knn(input_data, k=20)                             # dgcnn.py:32 (k=20 default)
             packed = self._packed.get([self.conv1, self.conv2, self.conv3, self.conv4],
                                       [self.bn1, self.bn2, self.bn3, self.bn4], xyz.device)
+            w5, s5, b5, w5_split, w5_f16 = self._conv5_folded()
+            if (_fused.gemm_arith() == "f16x2" and _fused.EDGECONV_KERNEL in (None, "f16") and w5_f16 is not None
+                    and _fused.f16_eligible(512, self.emb_dims, num_points)):
+                # f16x2 route: the EdgeConv kernel hands conv5 its input already split into fp16 planes (no fp32 pooled
+                # tensor, no split pass); both kernels watch the fp16 range (see _fused.check_range)
+                with _fused.stage("edgeconv"):
+                    pooled_img = _fused.edgeconv_forward(xyz, idx, packed, planes=True)         # dgcnn.py:34-46
+                with _fused.stage("conv5"):
+                    return _fused.pointwise_conv_f16(pooled_img, batch_size, num_points, w5_f16, 512, self.emb_dims,
+                                                     s5, b5, relu=True)                         # dgcnn.py:48
             with _fused.stage("edgeconv"):
                 pooled = _fused.edgeconv_forward(xyz, idx, packed)      # dgcnn.py:34-46
-            w5, s5, b5, w5_split = self._conv5_folded()
             with _fused.stage("conv5"):
                 out = _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True,
                                             w_split=w5_split)                                   # dgcnn.py:48

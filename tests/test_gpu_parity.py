@@ -546,6 +546,44 @@ def test_edgeconv_all_kernels_agree_and_ragged():
             assert np.sqrt((e_s ** 2).mean()) <= 1.5 * np.sqrt((e_c ** 2).mean()), (name, B, N, k, gain)
 
 
+def test_edgeconv_f16_planes_output_equals_pooled():
+    """out_mode 1 of the f16 EdgeConv kernel (pooled values handed to conv5 as fp16 planes, scaled by 2^T_out) decodes
+    to the fp32 pooled output of out_mode 0 within the representation error of the split (2^-23 of the value, or
+    2^-49 of the tensor scale), and conv5 on it equals conv5 on the fp32 pooled tensor split by the generic splitter
+    to fp32 rounding."""
+    from learning3d_amd.models import DGCNN, _fused
+    import learning3d_amd.utils as U
+    torch.manual_seed(4)
+    net = DGCNN(emb_dims=256).cuda().eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.uniform_(-0.1, 0.1); m.running_var.uniform_(0.8, 1.2); m.weight.data.uniform_(0.5, 2.0)
+    B, N, k = 2, 512, 20
+    x = dev(rand((B, N, 3), 91))
+    with torch.no_grad():
+        idx = U.knn(x.permute(0, 2, 1), k)
+        packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
+        pooled = _fused.edgeconv_forward(x, idx, packed, kernel="f16")
+        img = _fused.edgeconv_forward(x, idx, packed, planes=True)
+        _fused.check_range(sync=True)
+        raw = img.cpu().numpy()
+        pb = 64 * B * N * 16
+        h = raw[:pb].view(np.float16).reshape(64, B * N, 8).astype(np.float64)
+        m = raw[pb:2 * pb].view(np.float16).reshape(64, B * N, 8).astype(np.float64)
+        xinv = float(raw[2 * pb:2 * pb + 4].view(np.float32)[0])
+        dec = ((h + m / 4096.0) * xinv).transpose(1, 0, 2).reshape(B, N, 512)
+        want = pooled.cpu().numpy().astype(np.float64)
+        assert np.log2(xinv) == np.round(np.log2(xinv))                      # a power of two
+        np.testing.assert_allclose(dec, want, rtol=2.0 ** -22, atol=np.abs(want).max() * 2.0 ** -40)
+        w5, s5, b5, _, w5f = net._conv5_folded()
+        y1 = _fused.pointwise_conv_f16(img, B, N, w5f, 512, 256, s5, b5, relu=True)
+        y2 = _fused.pointwise_conv_f16(_fused.split_rows_f16(pooled), B, N, w5f, 512, 256, s5, b5, relu=True)
+        np.testing.assert_allclose(y1.cpu().numpy(), y2.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        # and the model's own forward takes this route
+        out = net(x)
+        np.testing.assert_allclose(out.cpu().numpy(), y1.cpu().numpy(), rtol=0, atol=0)
+
+
 def test_edgeconv_f16_range_flag():
     """f16x2 range contract: an activation beyond fp16's range raises the flag (and check_range raises); normal inputs
     never do.  The flag lives in pinned host memory the kernel writes directly."""
