@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--arith", choices=["f16x2", "bf16x3"], default=None,
                     help="GEMM arithmetic of the shared-MLP kernels (default f16x2: 3 fp16 MFMA products per fp32 product; "
                          "bf16x3: 6 bf16 products, full fp32 exponent range)")
+    ap.add_argument("--no-graph", action="store_true", help="issue every step's launches eagerly instead of replaying a hipGraph")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="control-flow self test on CPU/gloo (launcher, sharding, collective, max-over-ranks, JSON): "
                          "NO kernels run and the printed line is not a measurement")
@@ -230,22 +231,60 @@ def main():
 
     loss_pipe = parallel.PipelinedChamferLoss()
 
-    def step(sync_loss):
+    from learning3d_amd.losses.chamfer_distance import chamfer_loss_local
+
+    def compute():
+        """the step's kernels: knn -> edgeconv -> conv5, Chamfer NN search, and the loss tail's local part"""
         with torch.no_grad():
-            feat = net(x)                                   # knn -> edgeconv -> conv5
+            feat = net(x)
             with _fused.stage("chamfer"):
                 d1, d2 = cd(a, b)
-            if sync_loss:
-                loss = parallel.allgather_chamfer_loss(chamfer_partials(d1, d2))   # blocking RCCL all_gather if N>1
-            else:
-                loss = loss_pipe.submit_dists(d1, d2)     # N>1: partial sums + async all_gather (previous step's loss);
-                                                          # N=1: the whole loss tail in one launch
+            part = chamfer_loss_local(d1, d2) if world == 1 else chamfer_partials(d1, d2)
+        return feat, part
+
+    # The six launches of a step are captured once into a hipGraph and replayed: at ~0.36 ms of GPU work per step the
+    # Python / ctypes launch path (~13 us per launch) had become part of the step time (0.436 ms eager).  Steps that
+    # carry the live kernel-timing events (<= 8 per run) are issued eagerly.
+    graph = None
+
+    def step(sync_loss, eager=False):
+        if graph is not None and not eager:
+            graph.replay()
+            feat, part = graph_out
+        else:
+            feat, part = compute()
+        if world == 1:
+            return feat, part                              # the whole loss tail ran in one launch (l3d_chamfer_loss_local)
+        if sync_loss:
+            loss = parallel.allgather_chamfer_loss(part)   # blocking RCCL all_gather
+        else:
+            loss = loss_pipe.submit(part)                  # async all_gather; returns the previous step's loss
         return feat, loss
 
     # clock / cache pre-conditioning before the W official warm-up steps: the first ~50 ms after an idle
     # period run at ramping clocks (measured: 0.545 ms/step over steps 10-60, 0.506 ms/step in steady state)
     for _ in range(PRECONDITION_STEPS):
         step(args.sync_loss)
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    compute()
+            torch.cuda.current_stream().wait_stream(side)
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_):
+                graph_out = compute()
+            graph = g_
+            for _ in range(20):
+                step(args.sync_loss)
+            torch.cuda.synchronize()
+            _fused.check_range(sync=True)
+        except Exception as exc:                               # capture unsupported here: eager launches
+            graph = None
+            if rank == 0:
+                print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eager", file=sys.stderr)
     for _ in range(args.warmup):
         step(args.sync_loss)
 
@@ -256,14 +295,15 @@ def main():
 
     def timed(sync_loss, timer=None):
         """K steps between two (barrier + device sync) brackets; returns (this rank's seconds, last loss)."""
-        stride = max(1, (args.steps + 31) // 32)
+        stride = max(1, (args.steps + 7) // 8)
         sync()
         t0 = time.perf_counter()
         loss = None
         for i in range(args.steps):
+            sampled = timer is not None and i % stride == 0
             if timer is not None:
-                timer.enabled = (i % stride == 0)
-            _, loss = step(sync_loss)
+                timer.enabled = sampled
+            _, loss = step(sync_loss, eager=sampled)
         if not sync_loss:
             last = loss_pipe.flush()                      # the last step's loss, still inside the timed region
             loss = last if last is not None else loss
@@ -271,8 +311,8 @@ def main():
         return time.perf_counter() - t0, loss
 
     # Live HIP-event timing of the dominant kernel inside the timed region, on the stream it is
-    # launched on (torch's current stream).  Only <= 32 evenly spaced steps carry events: a few
-    # hundred un-synchronised timing events exhaust the runtime's signal pool and stall the host.
+    # launched on (torch's current stream).  Only <= 8 evenly spaced steps carry events (they are issued eagerly,
+    # the others replay the graph).
     timer = _fused.StageTimer(only=("edgeconv",))
     _fused.TIMER = timer
     elapsed, loss = timed(args.sync_loss, timer)          # THE timed region: `value` comes from this one
@@ -356,6 +396,7 @@ def main():
                                    "weights) + ChamferDistanceLoss, B=32 clouds per GPU, N=1024, inputs resident in HBM",
                        "global_batch": world * B_PER_GPU, "num_points": NPTS, "k": KNN, "emb_dims": EMB,
                        "untimed_precondition_steps": PRECONDITION_STEPS,
+                       "launch": "hipGraph replay of the step's 6 kernels" if graph is not None else "eager launches",
                        "parallelism": f"batch-sharded x{world}, all_gather of loss partials only"
                                       + ("" if args.sync_loss or world == 1 else " (asynchronous, consumed one step later)")},
             # multi-GPU record: ranks that really joined the process group, its backend ("nccl" = RCCL on ROCm),

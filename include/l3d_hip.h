@@ -122,6 +122,14 @@ int l3d_chamfer_combine(const double *partials, int world, float *loss, l3d_stre
  * loss = (partial[0]/partial[2] + partial[1]/partial[3]) / 2 as l3d_chamfer_combine(partial, 1, loss) would. */
 int l3d_chamfer_loss_local(const float *dist1, const float *dist2, int B, int N, int M, double *partial, float *loss,
                            l3d_stream_t stream);
+/* The same over up to 64 workgroups (the one-workgroup form is a chain of dependent load latencies: 12 us at B=32,
+ * N=1024; this one ~4): per-workgroup fp64 partial sums in ws, added in workgroup order by the workgroup that finishes
+ * last (deterministic; agrees with l3d_chamfer_loss_local to fp64 rounding of the sum order).  ws:
+ * l3d_chamfer_loss_local_ws_bytes() bytes of device memory whose first 8 bytes are zero before the first call (the
+ * kernel re-arms them); one ws per stream. */
+size_t l3d_chamfer_loss_local_ws_bytes(void);
+int l3d_chamfer_loss_local_mb(const float *dist1, const float *dist2, int B, int N, int M, void *ws, double *partial,
+                              float *loss, l3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * PointNet++ native ops  == utils/lib/src/pointnet2_api.cpp:10-25 (pybind `pointnet2_cuda`)

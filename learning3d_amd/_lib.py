@@ -30,6 +30,8 @@ SIGNATURES = {
     "l3d_chamfer_partials": [_P, _P, _I, _I, _I, _P, _P],
     "l3d_chamfer_combine": [_P, _I, _P, _P],
     "l3d_chamfer_loss_local": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "l3d_chamfer_loss_local_ws_bytes": [],
+    "l3d_chamfer_loss_local_mb": [_P, _P, _I, _I, _I, _P, _P, _P, _P],
     "l3d_ball_query": [_I, _I, _I, _F, _I, _P, _P, _P, _P],
     "l3d_group_points": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "l3d_group_points_grad": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
@@ -87,7 +89,7 @@ SIGNATURES = {
 }
 _RESTYPE = {"l3d_status_string": C.c_char_p, "l3d_edgeconv_packed_floats": _SZ, "l3d_split_bytes": _SZ,
             "l3d_soft_correspondence_workspace_floats": _SZ, "l3d_knn_feature_workspace_bytes": _SZ,
-            "l3d_scatter_add_det_workspace_bytes": _SZ, "l3d_f16_plane_bytes": _SZ, "l3d_f16_act_bytes": _SZ, "l3d_conv_f16_weight_bytes": _SZ}
+            "l3d_scatter_add_det_workspace_bytes": _SZ, "l3d_chamfer_loss_local_ws_bytes": _SZ, "l3d_f16_plane_bytes": _SZ, "l3d_f16_act_bytes": _SZ, "l3d_conv_f16_weight_bytes": _SZ}
 
 
 class L3DError(RuntimeError):

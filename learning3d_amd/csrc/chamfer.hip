@@ -451,6 +451,78 @@ __global__ __launch_bounds__(1024) void chamfer_loss_local_kernel(const float *_
     }
 }
 
+// The same tail spread over up to 64 workgroups: the one-workgroup kernel above is a chain of 16 dependent-latency
+// loop trips per thread (12 us for 2 x 32 K values); here every thread loads its one or two float4 at once, each
+// workgroup writes its two fp64 partial sums to ws, and the workgroup that draws the last ticket adds them with a
+// fixed shuffle tree (deterministic) and re-arms the ticket for the next call on the stream.
+//   ws: CHAMFER_LL_WS_BYTES bytes, the first 8 of them zero before the first call.
+#define CHAMFER_LL_BLOCKS 64
+#define CHAMFER_LL_WS_BYTES (16 + CHAMFER_LL_BLOCKS * 16)
+__global__ __launch_bounds__(256) void chamfer_loss_local_mb_kernel(const float *__restrict__ d1, size_t n1,
+                                                                    const float *__restrict__ d2, size_t n2,
+                                                                    unsigned *__restrict__ ws, double *__restrict__ partial,
+                                                                    float *__restrict__ loss)
+{
+    __shared__ double part[2][4];
+    __shared__ bool last;
+    double acc1 = 0.0, acc2 = 0.0;
+    const size_t a4 = n1 >> 2, b4 = n2 >> 2, m4 = a4 > b4 ? a4 : b4;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < m4; i += stride) {
+        if (i < a4) {
+            const float4 v = ((const float4 *)d1)[i];
+            acc1 += ((double)sqrtf(v.x) + (double)sqrtf(v.y)) + ((double)sqrtf(v.z) + (double)sqrtf(v.w));
+        }
+        if (i < b4) {
+            const float4 v = ((const float4 *)d2)[i];
+            acc2 += ((double)sqrtf(v.x) + (double)sqrtf(v.y)) + ((double)sqrtf(v.z) + (double)sqrtf(v.w));
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (size_t i = (a4 << 2) + threadIdx.x; i < n1; i += 256) acc1 += (double)sqrtf(d1[i]);
+        for (size_t i = (b4 << 2) + threadIdx.x; i < n2; i += 256) acc2 += (double)sqrtf(d2[i]);
+    }
+    for (int off = 32; off > 0; off >>= 1) { acc1 += __shfl_down(acc1, off, 64); acc2 += __shfl_down(acc2, off, 64); }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = acc1; part[1][threadIdx.x >> 6] = acc2; }
+    __syncthreads();
+    double *slots = (double *)(ws + 4);
+    if (threadIdx.x == 0) {
+        slots[2 * blockIdx.x] = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
+        slots[2 * blockIdx.x + 1] = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
+        __threadfence();
+        last = atomicAdd(ws, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x < 64) {                 // one wave: a slot pair per lane, then a fixed shuffle tree
+        __threadfence();
+        double t1 = 0.0, t2 = 0.0;
+        if (threadIdx.x < gridDim.x) {
+            t1 = __builtin_nontemporal_load(&slots[2 * threadIdx.x]);
+            t2 = __builtin_nontemporal_load(&slots[2 * threadIdx.x + 1]);
+        }
+        for (int off = 32; off > 0; off >>= 1) { t1 += __shfl_down(t1, off, 64); t2 += __shfl_down(t2, off, 64); }
+        if (threadIdx.x == 0) {
+            partial[0] = t1; partial[1] = t2; partial[2] = (double)n1; partial[3] = (double)n2;
+            loss[0] = (float)((t1 / (double)n1 + t2 / (double)n2) / 2.0);
+            ws[0] = 0;                              // re-armed for the next launch on this stream
+        }
+    }
+}
+
+extern "C" size_t l3d_chamfer_loss_local_ws_bytes(void) { return CHAMFER_LL_WS_BYTES; }
+
+extern "C" int l3d_chamfer_loss_local_mb(const float *dist1, const float *dist2, int B, int N, int M, void *ws, double *partial,
+                                         float *loss, l3d_stream_t stream)
+{
+    L3D_REQUIRE(dist1 && dist2 && ws && partial && loss && B > 0 && N > 0 && M > 0);
+    const size_t n1 = (size_t)B * N, n2 = (size_t)B * M, m4 = (n1 > n2 ? n1 : n2) >> 2;
+    long blocks = l3d_divup((long)m4, 256);
+    blocks = blocks < 1 ? 1 : (blocks > CHAMFER_LL_BLOCKS ? CHAMFER_LL_BLOCKS : blocks);
+    hipLaunchKernelGGL(chamfer_loss_local_mb_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dist1, n1, dist2, n2,
+                       (unsigned *)ws, partial, loss);
+    return l3d_check_launch();
+}
+
 extern "C" int l3d_chamfer_loss_local(const float *dist1, const float *dist2, int B, int N, int M, double *partial,
                                       float *loss, l3d_stream_t stream)
 {

@@ -62,14 +62,23 @@ def chamfer_partials(dist1, dist2):
     return part
 
 
+_LL_WS = {}
+
+
 def chamfer_loss_local(dist1, dist2):
-    """One rank, one launch: the same partial sums and the same combine as chamfer_combine(chamfer_partials(...))."""
+    """One rank, one launch: the same partial sums and the same combine as chamfer_combine(chamfer_partials(...)),
+    spread over up to 64 workgroups (l3d_chamfer_loss_local_mb; workspace cached per device and stream)."""
     B, N = dist1.shape
     M = dist2.shape[1]
+    key = (dist1.device.index, torch.cuda.current_stream(dist1.device).cuda_stream)
+    ws = _LL_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(lib().l3d_chamfer_loss_local_ws_bytes(), dtype=torch.uint8, device=dist1.device)
+        _LL_WS[key] = ws
     part = torch.empty(4, dtype=torch.float64, device=dist1.device)
     loss = torch.empty((), dtype=torch.float32, device=dist1.device)
-    check(lib().l3d_chamfer_loss_local(ptr(dist1), ptr(dist2), B, N, M, ptr(part), ptr(loss), stream_ptr()),
-          "l3d_chamfer_loss_local")
+    check(lib().l3d_chamfer_loss_local_mb(ptr(dist1), ptr(dist2), B, N, M, ptr(ws), ptr(part), ptr(loss), stream_ptr()),
+          "l3d_chamfer_loss_local_mb")
     return loss
 
 
