@@ -25,7 +25,8 @@
 // fragment reads per K chunk are 3a + 2c for an a x c wave tile: 14 for 2 x 4 (16 for 4 x 2).  K chunks of 16 (one MFMA
 // k-step), THREE LDS stages of 40 KB (W 24 KB + x 16 KB); per chunk every wave issues 5 DMA pieces for chunk kc+2,
 // waits for its own pieces of chunk kc (s_waitcnt vmcnt -- the loop has no other vector memory traffic), one barrier,
-// 14 ds_read_b128, 24 MFMAs.
+// 14 ds_read_b128, 24 MFMAs.  Measured, not kept: reading chunk kc+1's x fragments (8 of the 14) during chunk kc's MFMAs --
+// the second register set pushes the kernel to 256 VGPRs + spills at two waves per SIMD: 112 us against 97.
 #include "common.h"
 #include "split_bf16.h"          // f32x4 / f32x16 typedefs
 
