@@ -412,6 +412,38 @@ int l3d_emd_forward(const float *xyz1, const float *xyz2, int B, int n, int m, f
 int l3d_emd_backward(const float *xyz1, const float *xyz2, const float *match, int B, int n, int m,
                      float *grad1, float *grad2, l3d_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Device-side data feed of the registration path (feed.hip)
+ *   l3d_uniform_clouds : out [B,N,3] ~ U(lo,hi), generated on the device from (seed, element index): reproducible, no
+ *       host tensor and no copy.
+ *   l3d_euler_transform == DCPTransform / DeepGMRTransform (ops/transform_functions.py:271-345) for a whole batch:
+ *       euler_zyx [B,3] = (anglez, angley, anglex), trans [B,3]; source [B,N,3] = R template + t with
+ *       R = scipy Rotation.from_euler('zyx', ...) evaluated in fp64; igt [B,4,4] = [R^T | t ; 0 0 0 1] -- the 3x3
+ *       block is Rotation.apply(np.eye(3)), i.e. the transpose, exactly as the reference stores it (:306).
+ * ------------------------------------------------------------------------------------------- */
+int l3d_uniform_clouds(unsigned long long seed, int B, int N, float lo, float hi, float *out, l3d_stream_t stream);
+int l3d_euler_transform(const float *tmpl, const float *euler_zyx, const float *trans, int B, int N, float *source,
+                        float *igt, l3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Training-mode BatchNorm around the 1x1-conv GEMMs (train.hip).  z / dy / y / dz are [B,C,P]
+ * fp32 (P = points, or points x neighbours).  Statistics come out as PER-CLOUD fp64 partial sums [B,C,2] (fixed order,
+ * no atomics); the host adds them in global cloud order (after an all_gather when the batch is sharded across ranks),
+ * which makes the batch statistics -- and the two backward reductions -- bit-identical for any number of GPUs.
+ *   l3d_channel_stats     part[b][c] = (sum_p z, sum_p z^2)
+ *   l3d_bn_act_forward    y = act(z scale[c] + shift[c]),  act: 0 none, 1 ReLU
+ *   l3d_bn_backward_stats part[b][c] = (sum_p g, sum_p g zhat),  g = dy [z scale + shift > 0 if act],  zhat = (z - mean[c]) rstd[c]
+ *   l3d_bn_act_backward   dz = gr[c] (g - m1[c] - zhat m2[c])
+ * ------------------------------------------------------------------------------------------- */
+int l3d_channel_stats(const float *z, int B, int C, long P, double *part, l3d_stream_t stream);
+int l3d_bn_act_forward(const float *z, const float *scale, const float *shift, int B, int C, long P, int act, float *y,
+                       l3d_stream_t stream);
+int l3d_bn_backward_stats(const float *dy, const float *z, const float *scale, const float *shift, const float *mean,
+                          const float *rstd, int B, int C, long P, int act, double *part, l3d_stream_t stream);
+int l3d_bn_act_backward(const float *dy, const float *z, const float *scale, const float *shift, const float *mean,
+                        const float *rstd, const float *gr, const float *m1, const float *m2, int B, int C, long P, int act,
+                        float *dz, l3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,129 @@
+// train.hip -- training-mode BatchNorm around the 1x1-conv GEMMs (reference: the torch modules of
+// models/dgcnn.py:34-48 / models/pcn.py in .train(), examples/train_pcn.py:70-91).
+//
+// conv (HIP GEMM) -> [these kernels] -> next layer.  Batch statistics are formed as PER-CLOUD fp64 partial sums
+// (one workgroup per (cloud, channel), fixed summation order, no atomics) which the host adds in global cloud order --
+// after an all_gather when the batch is sharded over ranks -- so the statistics are bit-identical for any number of
+// GPUs, and the backward's two reductions follow the same scheme.
+//   l3d_channel_stats        z [B,C,P]                      -> part [B,C,2] fp64 = (sum z, sum z^2) per (cloud, channel)
+//   l3d_bn_act_forward       y = act(z * scale[c] + shift[c])                              (act: 0 none, 1 ReLU)
+//   l3d_bn_backward_stats    dy, z, scale, shift, mean, rstd  -> part [B,C,2] fp64 = (sum g, sum g zhat),
+//                            g = dy * [z scale + shift > 0] (ReLU mask recomputed, nothing extra saved), zhat = (z - mean) rstd
+//   l3d_bn_act_backward      dz = gr[c] * (g - m1[c] - zhat * m2[c])      (gr = gamma rstd, m1 = sum g / n, m2 = sum g zhat / n)
+#include "common.h"
+
+__device__ __forceinline__ double tr_block_sum(double v, double *sh)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float *__restrict__ z, int C, long P, double *__restrict__ part)
+{
+    __shared__ double sh[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float *row = z + ((size_t)b * C + c) * P;
+    double s = 0.0, q = 0.0;
+    for (long p = threadIdx.x; p < P; p += 256) {
+        const double v = row[p];
+        s += v;
+        q += v * v;
+    }
+    s = tr_block_sum(s, sh);
+    q = tr_block_sum(q, sh);
+    if (threadIdx.x == 0) {
+        part[((size_t)b * C + c) * 2] = s;
+        part[((size_t)b * C + c) * 2 + 1] = q;
+    }
+}
+
+extern "C" int l3d_channel_stats(const float *z, int B, int C, long P, double *part, l3d_stream_t stream)
+{
+    L3D_REQUIRE(z && part && B > 0 && C > 0 && P > 0 && B <= 65535);
+    hipLaunchKernelGGL(channel_stats_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, z, C, P, part);
+    return l3d_check_launch();
+}
+
+__global__ __launch_bounds__(256) void bn_act_forward_kernel(const float *__restrict__ z, const float *__restrict__ scale,
+                                                             const float *__restrict__ shift, int C, long P, int act,
+                                                             float *__restrict__ y)
+{
+    const int c = blockIdx.y, b = blockIdx.z;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const size_t i = ((size_t)b * C + c) * P + p;
+    const float v = z[i] * scale[c] + shift[c];
+    y[i] = act ? fmaxf(v, 0.f) : v;
+}
+
+extern "C" int l3d_bn_act_forward(const float *z, const float *scale, const float *shift, int B, int C, long P, int act,
+                                  float *y, l3d_stream_t stream)
+{
+    L3D_REQUIRE(z && scale && shift && y && B > 0 && C > 0 && P > 0 && B <= 65535 && C <= 65535);
+    hipLaunchKernelGGL(bn_act_forward_kernel, dim3((unsigned)l3d_divup(P, 256), C, B), dim3(256), 0, (hipStream_t)stream, z, scale, shift,
+                       C, P, act, y);
+    return l3d_check_launch();
+}
+
+__global__ __launch_bounds__(256) void bn_backward_stats_kernel(const float *__restrict__ dy, const float *__restrict__ z,
+                                                                const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                                int C, long P, int act, double *__restrict__ part)
+{
+    __shared__ double sh[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const size_t base = ((size_t)b * C + c) * P;
+    const float sc = scale[c], shf = shift[c], mu = mean[c], rs = rstd[c];
+    double s = 0.0, q = 0.0;
+    for (long p = threadIdx.x; p < P; p += 256) {
+        const float zv = z[base + p];
+        const float g = (!act || zv * sc + shf > 0.f) ? dy[base + p] : 0.f;
+        s += (double)g;
+        q += (double)g * (double)((zv - mu) * rs);
+    }
+    s = tr_block_sum(s, sh);
+    q = tr_block_sum(q, sh);
+    if (threadIdx.x == 0) {
+        part[((size_t)b * C + c) * 2] = s;
+        part[((size_t)b * C + c) * 2 + 1] = q;
+    }
+}
+
+extern "C" int l3d_bn_backward_stats(const float *dy, const float *z, const float *scale, const float *shift, const float *mean,
+                                     const float *rstd, int B, int C, long P, int act, double *part, l3d_stream_t stream)
+{
+    L3D_REQUIRE(dy && z && scale && shift && mean && rstd && part && B > 0 && C > 0 && P > 0 && B <= 65535);
+    hipLaunchKernelGGL(bn_backward_stats_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, dy, z, scale, shift, mean, rstd, C, P,
+                       act, part);
+    return l3d_check_launch();
+}
+
+__global__ __launch_bounds__(256) void bn_act_backward_kernel(const float *__restrict__ dy, const float *__restrict__ z,
+                                                              const float *__restrict__ scale, const float *__restrict__ shift,
+                                                              const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                              const float *__restrict__ gr, const float *__restrict__ m1,
+                                                              const float *__restrict__ m2, int C, long P, int act,
+                                                              float *__restrict__ dz)
+{
+    const int c = blockIdx.y, b = blockIdx.z;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    const size_t i = ((size_t)b * C + c) * P + p;
+    const float zv = z[i];
+    const float g = (!act || zv * scale[c] + shift[c] > 0.f) ? dy[i] : 0.f;
+    dz[i] = gr[c] * (g - m1[c] - (zv - mean[c]) * rstd[c] * m2[c]);
+}
+
+extern "C" int l3d_bn_act_backward(const float *dy, const float *z, const float *scale, const float *shift, const float *mean,
+                                   const float *rstd, const float *gr, const float *m1, const float *m2, int B, int C, long P,
+                                   int act, float *dz, l3d_stream_t stream)
+{
+    L3D_REQUIRE(dy && z && scale && shift && mean && rstd && gr && m1 && m2 && dz && B > 0 && C > 0 && P > 0 && B <= 65535 && C <= 65535);
+    hipLaunchKernelGGL(bn_act_backward_kernel, dim3((unsigned)l3d_divup(P, 256), C, B), dim3(256), 0, (hipStream_t)stream, dy, z, scale,
+                       shift, mean, rstd, gr, m1, m2, C, P, act, dz);
+    return l3d_check_launch();
+}

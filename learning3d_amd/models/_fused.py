@@ -101,6 +101,10 @@ def can_fuse(module, *tensors):
     return True
 
 
+# Training (module.train() with BatchNorm, or autograd through the conv stack): True = conv / dgrad / wgrad on the HIP
+# GEMMs with rank-count-independent batch statistics (_train.py); False = torch convs + torch BatchNorm.
+TRAIN_HIP = True
+
 # fp32 products as six bf16 MFMA products (conv_split.hip): fp32-equivalent results at 6/16 of the
 # fp32-MFMA cost.  False routes every 1x1 conv through the fp32-MFMA kernel of mlp.hip.
 SPLIT_BF16 = True

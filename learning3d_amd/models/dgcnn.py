@@ -74,6 +74,17 @@ class DGCNN(torch.nn.Module):
             return out
 
         output = get_graph_feature(input_data)
+        if (_fused.TRAIN_HIP and self.training and output.is_cuda and self.conv1.bias is None):
+            # training: conv / dgrad / wgrad on the HIP GEMMs, BatchNorm statistics from per-cloud fp64 partial sums
+            # shared across ranks (_train.py); max over k through torch (its backward is an index scatter)
+            from ._train import conv_bn_act
+            output = output.contiguous()
+            outs = []
+            for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3), (self.conv4, self.bn4)):
+                output = conv_bn_act(output, conv, bn)
+                outs.append(output.max(dim=-1, keepdim=True)[0])
+            output = torch.cat(outs, dim=1)
+            return conv_bn_act(output, self.conv5, self.bn5).view(batch_size, -1, num_points)
         output = F.relu(self.bn1(self.conv1(output)))
         output1 = output.max(dim=-1, keepdim=True)[0]
         output = F.relu(self.bn2(self.conv2(output)))

@@ -549,3 +549,27 @@ def dcp_forward_torch(template, source, w, n_heads=4, k=20, dtype="float32"):
     R = torch.stack(Rs, dim=0)
     t = (torch.matmul(-R, src.mean(dim=2, keepdim=True)) + corr.mean(dim=2, keepdim=True)).view(B, 3)
     return {"est_R": R.numpy(), "est_t": t.numpy(), "r": (tf - sf).numpy(), "H": H.numpy()}
+
+
+# ----------------------------------------------------------------- 8(f) rank 4: DCPTransform
+def dcp_transform(template, anglex, angley, anglez, translation):
+    """ops/transform_functions.py:304-310 restated without scipy: Rotation.from_euler('zyx', [az, ay, ax]) is the
+    extrinsic z, y, x sequence, i.e. R = Rx(ax) Ry(ay) Rz(az); source = template R^T + t; igt = [R^T | t ; 0 0 0 1]
+    (the reference stores Rotation.apply(np.eye(3)), which is R^T).  fp64 like scipy, rounded to fp32 at the end."""
+    t = np.asarray(template, np.float64)
+    B = t.shape[0]
+    src = np.empty_like(t)
+    igt = np.zeros((B, 4, 4))
+    for b in range(B):
+        cx, sx = np.cos(anglex[b]), np.sin(anglex[b])
+        cy, sy = np.cos(angley[b]), np.sin(angley[b])
+        cz, sz = np.cos(anglez[b]), np.sin(anglez[b])
+        Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+        Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+        R = Rx @ Ry @ Rz
+        src[b] = t[b] @ R.T + np.asarray(translation[b])[None]
+        igt[b, :3, :3] = R.T
+        igt[b, :3, 3] = translation[b]
+        igt[b, 3, 3] = 1.0
+    return src.astype(np.float32), igt.astype(np.float32)

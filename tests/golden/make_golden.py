@@ -241,6 +241,21 @@ def main():
         save("pointconv_util", xyz=xyz, fps=fps.to(torch.int32), knn_idx_sorted=kidx_sorted.astype(np.int32),
              density=dens, feats=feats, sa_xyz=sa_xyz, sa_points=sa_pts,
              **{"w." + k: v for k, v in sa.state_dict().items()})
+        # ---- 8(f) rank 4: DCPTransform (ops/transform_functions.py:271-315), angles / translation fixed by hand so that the
+        #      fixture does not depend on numpy's global RNG; apply_transformation is the reference's own scipy path ----------
+        from learning3d.ops.transform_functions import DCPTransform
+        tf = DCPTransform(angle_range=45, translation_range=1)
+        ang = rand((4, 3), 28, 0, np.pi / 4).numpy().astype(np.float64)           # columns: anglex, angley, anglez
+        trn = rand((4, 3), 29, -1, 1).numpy().astype(np.float64)
+        tmpl = rand((4, 200, 3), 30, -0.5, 0.5)
+        srcs, igts = [], []
+        for i in range(4):
+            tf.anglex, tf.angley, tf.anglez = ang[i]
+            tf.translation = trn[i]
+            srcs.append(torch.from_numpy(tf.apply_transformation(tmpl[i].numpy())).float())
+            igts.append(tf.igt)
+        save("dcp_transform", template=tmpl, anglex=ang[:, 0], angley=ang[:, 1], anglez=ang[:, 2], translation=trn,
+             source=torch.stack(srcs), igt=torch.stack(igts))
     shutil.rmtree(tmp, ignore_errors=True)
     print("done")
 

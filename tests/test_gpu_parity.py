@@ -1256,3 +1256,115 @@ def test_config3_dcp_full_size_vs_oracle_port():
     et = np.abs(out["est_t"].cpu().numpy() - want["est_t"])[ok].max()
     print(f"config 3 full size: max |dR| {eR:.2e}, max |dt| {et:.2e} over {ok.sum()} well-conditioned clouds")
     assert eR <= 1e-5 and et <= 1e-5, (eR, et)
+
+
+def test_device_feed_dcp_transform_golden(golden):
+    """the batched on-device DCPTransform (l3d_euler_transform) against the reference's own
+    (scipy, one cloud at a time) for fixed angles; the drawing wrapper's ranges; the seeded on-device cloud generator."""
+    from learning3d_amd.ops.transform_functions import DCPTransform, euler_transform
+    from learning3d_amd.data_utils import RegistrationFeed, uniform_clouds
+    g = golden("dcp_transform")
+    euler = np.stack([g["anglez"], g["angley"], g["anglex"]], axis=1).astype(np.float32)
+    src, igt = euler_transform(dev(g["template"]), dev(euler), dev(g["translation"].astype(np.float32)))
+    # the fixture's angles are fp64; the device entry point takes fp32 angles: 1e-6 covers their rounding
+    np.testing.assert_allclose(src.cpu().numpy(), g["source"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(igt.cpu().numpy(), g["igt"], rtol=0, atol=2e-6)
+    # against the oracle at the SAME fp32 angles: one rounding apart at most
+    osrc, oigt = oracle.dcp_transform(g["template"], euler[:, 2].astype(np.float64), euler[:, 1].astype(np.float64),
+                                      euler[:, 0].astype(np.float64), g["translation"].astype(np.float32).astype(np.float64))
+    np.testing.assert_allclose(src.cpu().numpy(), osrc, rtol=0, atol=1.2e-7)
+    np.testing.assert_allclose(igt.cpu().numpy(), oigt, rtol=0, atol=6e-8)
+    tf = DCPTransform(angle_range=45, translation_range=1, generator=torch.Generator(device="cuda").manual_seed(3))
+    t = dev(rand((8, 64, 3), 1, -0.5, 0.5))
+    s = tf(t)
+    R = tf.igt[:, :3, :3].transpose(1, 2)
+    np.testing.assert_allclose((torch.matmul(t, R.transpose(1, 2)) + tf.igt[:, :3, 3].unsqueeze(1)).cpu().numpy(), s.cpu().numpy(), atol=1e-6)
+    np.testing.assert_allclose(torch.linalg.det(R.double()).cpu().numpy(), 1.0, atol=1e-6)
+    assert float(tf.anglex.max()) <= np.pi / 4 and float(tf.anglex.min()) >= 0 and float(tf.translation.abs().max()) <= 1
+    a, b = uniform_clouds(4, 1000, -0.5, 0.5, seed=7), uniform_clouds(4, 1000, -0.5, 0.5, seed=7)
+    assert torch.equal(a, b) and float(a.min()) >= -0.5 and float(a.max()) < 0.5 and abs(float(a.mean())) < 0.02
+    assert not torch.equal(a, uniform_clouds(4, 1000, -0.5, 0.5, seed=8))
+    feed = RegistrationFeed(16, 256, seed=5, length=2)
+    batches = list(feed)
+    assert len(batches) == 2 and batches[0][0].shape == (16, 256, 3) and batches[0][2].shape == (16, 4, 4)
+    assert not torch.equal(batches[0][0], batches[1][0])
+
+
+# ------------------------------------------------------------------------------- training path (8(f) rank 3)
+def test_train_conv_bn_relu_matches_torch():
+    """_train.conv_bn_act (HIP GEMMs for conv / dgrad / wgrad, HIP BatchNorm statistics and normalisation) against
+    torch's Conv2d -> BatchNorm2d (batch statistics) -> ReLU: outputs, the gradients of x, W, gamma, beta, and the
+    running-statistics update.  Also the per-cloud fp64 partial sums against numpy."""
+    from learning3d_amd.models import _train
+    torch.manual_seed(11)
+    for (B, Cin, Cout, N, K) in [(4, 6, 64, 128, 20), (3, 64, 128, 96, 20), (2, 512, 256, 256, 1)]:
+        conv = torch.nn.Conv2d(Cin, Cout, 1, bias=False).cuda()
+        bn = torch.nn.BatchNorm2d(Cout).cuda().train()
+        bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.uniform_(-0.3, 0.3)
+        conv_r, bn_r = torch.nn.Conv2d(Cin, Cout, 1, bias=False).cuda(), torch.nn.BatchNorm2d(Cout).cuda().train()
+        conv_r.load_state_dict(conv.state_dict()); bn_r.load_state_dict(bn.state_dict())
+        x = torch.randn(B, Cin, N, K, device="cuda") * 0.7 + 0.1
+        go = torch.randn(B, Cout, N, K, device="cuda")
+        xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+        ya = _train.conv_bn_act(xa, conv, bn, relu=True, sync=False)
+        yb = torch.relu(bn_r(conv_r(xb)))
+        np.testing.assert_allclose(ya.detach().cpu().numpy(), yb.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+        ya.backward(go); yb.backward(go)
+        for name, a, b in (("x", xa.grad, xb.grad), ("W", conv.weight.grad, conv_r.weight.grad),
+                           ("gamma", bn.weight.grad, bn_r.weight.grad), ("beta", bn.bias.grad, bn_r.bias.grad)):
+            scale = float(b.abs().max())
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-5 * max(1.0, scale), err_msg=name)
+        np.testing.assert_allclose(bn.running_mean.cpu().numpy(), bn_r.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(bn.running_var.cpu().numpy(), bn_r.running_var.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        assert int(bn.num_batches_tracked) == 1
+    z = torch.randn(3, 5, 777, device="cuda")
+    part = _train.channel_stats(z).cpu().numpy()
+    z64 = z.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(part[..., 0], z64.sum(-1), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(part[..., 1], (z64 ** 2).sum(-1), rtol=1e-12)
+
+
+def test_dgcnn_training_step_hip_path_matches_torch_path():
+    """DGCNN in .train(): one forward + backward through the HIP training path (_fused.TRAIN_HIP) and through torch's
+    fp32 convs / BatchNorm, both on top of the HIP kNN + graph-feature kernels, judged against the same step in fp64
+    (torch double on the same graph): loss, every parameter gradient, running statistics.  BatchNorm's backward
+    cancels (g - mean g - zhat mean(g zhat)), so fp32 implementations differ from each other at ~1e-3 of the gradient
+    scale after five layers; the bar is the fp64 truth: the HIP path may be at most 3x as far from it as torch's fp32."""
+    from learning3d_amd.models import DGCNN, _fused
+    import torch.nn.functional as F
+    torch.manual_seed(12)
+    x = dev(rand((4, 256, 3), 60))
+    res = {}
+    for mode in ("hip", "torch32", "torch64"):
+        torch.manual_seed(13)
+        net = DGCNN(emb_dims=256).cuda().train()
+        if mode == "torch64":
+            from learning3d_amd.utils import get_graph_feature
+            with torch.no_grad():
+                feat = get_graph_feature(x.permute(0, 2, 1)).contiguous().double()
+            net = net.double()
+            h = feat
+            outs = []
+            for conv, bn in ((net.conv1, net.bn1), (net.conv2, net.bn2), (net.conv3, net.bn3), (net.conv4, net.bn4)):
+                h = F.relu(bn(conv(h)))
+                outs.append(h.max(dim=-1, keepdim=True)[0])
+            out = F.relu(net.bn5(net.conv5(torch.cat(outs, dim=1)))).view(4, -1, 256)
+        else:
+            _fused.TRAIN_HIP = mode == "hip"
+            try:
+                out = net(x)
+            finally:
+                _fused.TRAIN_HIP = True
+        loss = (out ** 2).mean()
+        loss.backward()
+        res[mode] = (float(loss.detach()), {k: v.grad.detach().double().cpu().numpy() for k, v in net.named_parameters()},
+                     {k: v.detach().double().cpu().numpy() for k, v in net.named_buffers() if "running" in k})
+    truth = res["torch64"]
+    assert abs(res["hip"][0] - truth[0]) <= 1e-5 * max(1.0, abs(truth[0]))
+    for k in truth[1]:
+        scale = np.abs(truth[1][k]).max()
+        e_hip = np.abs(res["hip"][1][k] - truth[1][k]).max()
+        e_t32 = np.abs(res["torch32"][1][k] - truth[1][k]).max()
+        assert e_hip <= 3.0 * e_t32 + 1e-6 * scale, (k, e_hip, e_t32, scale)
+    for k in truth[2]:
+        np.testing.assert_allclose(res["hip"][2][k], truth[2][k], rtol=1e-5, atol=1e-6, err_msg=k)

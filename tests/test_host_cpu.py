@@ -212,3 +212,53 @@ def test_bench_self_launches_two_ranks_gloo():
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and len(j["per_rank_s"]) == 2
     assert abs(j["loss_sync"] - j["loss_expected"]) < 1e-6 and abs(j["loss_pipelined"] - j["loss_expected"]) < 1e-6
+
+
+def _bn_stats_rank(rank, world, port, q):
+    import os
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from learning3d_amd import parallel
+    from learning3d_amd.models import _train
+    rng = np.random.default_rng(5)
+    z = rng.standard_normal((8, 16, 300)).astype(np.float32)               # the WHOLE batch, same on every rank
+    lo, hi = parallel.shard_bounds(z.shape[0], rank, world)
+    zs = z[lo:hi].astype(np.float64)
+    # per-cloud fp64 partial sums of this rank's shard: the stand-in for l3d_channel_stats (tested on the GPU against numpy)
+    part = torch.from_numpy(np.stack([zs.sum(-1), (zs ** 2).sum(-1)], axis=-1))
+    pg = _train.gather_cloud_partials(part)
+    mean, var, n, tot = _train.stats_from_partials(pg, z.shape[2])
+    q.put((rank, pg.numpy().tobytes(), tot.numpy().tobytes(), mean.numpy().tobytes(), var.numpy().tobytes(), n))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_batchnorm_statistics_bit_identical():
+    """train-mode BatchNorm statistics over a batch sharded across 2 ranks (gloo) equal the
+    single-process statistics BIT FOR BIT: per-cloud fp64 partial sums, all_gather, addition in global cloud order."""
+    import socket
+    import numpy as np
+    import torch
+    import torch.multiprocessing as mp
+    from learning3d_amd.models import _train
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bn_stats_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(5)
+    z = rng.standard_normal((8, 16, 300)).astype(np.float32).astype(np.float64)
+    part = torch.from_numpy(np.stack([z.sum(-1), (z ** 2).sum(-1)], axis=-1))
+    mean, var, n, tot = _train.stats_from_partials(part, 300)
+    for rank, pg, t, m, v, nn_ in got:
+        assert pg == part.numpy().tobytes() and t == tot.numpy().tobytes()
+        assert m == mean.numpy().tobytes() and v == var.numpy().tobytes() and nn_ == n

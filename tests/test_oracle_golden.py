@@ -178,3 +178,11 @@ def test_dcp_oracle_port_is_the_reference(golden):
         np.testing.assert_allclose(o[k], g[k], rtol=0, atol=1e-6)
     o64 = oracle.dcp_forward_torch(g["template"], g["source"], w, dtype="float64")
     assert np.abs(o64["est_R"] - g["est_R"]).max() < 1e-5 and np.abs(o64["est_t"] - g["est_t"]).max() < 1e-5
+
+
+def test_dcp_transform_oracle(golden):
+    """8(f) rank 4: the Euler -> (R, t) -> source restatement against the reference's DCPTransform (scipy path)."""
+    g = golden("dcp_transform")
+    src, igt = oracle.dcp_transform(g["template"], g["anglex"], g["angley"], g["anglez"], g["translation"])
+    np.testing.assert_allclose(src, g["source"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(igt, g["igt"], rtol=0, atol=1e-7)
