@@ -3,9 +3,9 @@
 // THREE fp16 MFMA products (half of bf16x3's six) at fp32-level accuracy.  models/dgcnn.py:32-46.
 //
 // Arithmetic (the error-corrected fp16 split of Ootomo & Yokota, IJHPCA 2022, adapted to the MFMA):
-//   activation x (fp32):  h = f16(x),  m' = f16((x - h) * 2^12)            -> x = h + m' 2^-12 up to 2^-24 |x|
+//   activation x (fp32):  h = f16(x),  m' = f16((x - h) * 2^12)            -> x = h + m' 2^-12 up to 2^-22 |x| (worst case of two 11-bit roundings)
 //   weight     w (fp32):  W = w 2^S (S per layer, static, so that max|W| is in [4,8)),
-//                         H = f16(W),  M = f16(W - H),  Hs = f16(H 2^-12)  -> W = H + M up to 2^-24 |W|
+//                         H = f16(W),  M = f16(W - H),  Hs = f16(H 2^-12)  -> W = H + M up to 2^-22 |W|
 //   one accumulator:      acc = b 2^S + sum_k ( M h  +  Hs m'  +  H h )     = 2^S (b + w.x) up to the dropped
 //                         M m' 2^-12 term (2^-24 relative), every fp16 x fp16 product exact in the fp32 accumulator;
 //   epilogue:             y = max(acc, 0) 2^-S  (a power of two: exact).

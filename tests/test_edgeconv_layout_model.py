@@ -74,7 +74,8 @@ def test_edgeconv_fragment_layout_and_row_mapping():
     scs = [rng.uniform(0.5, 1.5, c).astype(np.float32) for c in (C1, C2, C3, C4)]
     shs = [rng.uniform(-0.2, 0.2, c).astype(np.float32) for c in (C1, C2, C3, C4)]
     n = lib.l3d_edgeconv_packed_floats(C1, C2, C3, C4)
-    assert n == 2 * (8 * C1 + C1 * C2 + C2 * C3 + C3 * C4) + C1 + C2 + C3 + C4 + SPLIT_FLOATS   # v1 + chained + biases + bf16x3
+    # v1 + chained + biases + bf16x3 planes + f16x2 planes (same size) + their scaled biases + 16 scale constants
+    assert n == 2 * (8 * C1 + C1 * C2 + C2 * C3 + C3 * C4) + C1 + C2 + C3 + C4 + 2 * SPLIT_FLOATS + (C2 + C3 + C4) + 16
     packed = np.zeros(n, np.float32)
     arr = lambda xs: (C.c_void_p * 4)(*[x.ctypes.data for x in xs])
     assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), C1, C2, C3, C4, packed.ctypes.data) == 0
@@ -129,7 +130,7 @@ def test_edgeconv_chained_register_layout():
     shs = [rng.uniform(-0.2, 0.2, c).astype(np.float32) for c in (C1, C2, C3, C4)]
     n = lib.l3d_edgeconv_packed_floats(C1, C2, C3, C4)
     v1 = 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4 + C1 + C2 + C3 + C4
-    assert n == v1 + 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4 + SPLIT_FLOATS
+    assert n == v1 + 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4 + 2 * SPLIT_FLOATS + (C2 + C3 + C4) + 16
     packed = np.zeros(n, np.float32)
     arr = lambda xs: (C.c_void_p * 4)(*[x.ctypes.data for x in xs])
     assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), C1, C2, C3, C4, packed.ctypes.data) == 0
@@ -277,7 +278,7 @@ def test_edgeconv_split_bf16x3_layout():
                     tot = f[m, s_, 0, :, slot].astype(np.float64) + f[m, s_, 1, :, slot] + f[m, s_, 2, :, slot]
                     np.testing.assert_array_equal(tot.astype(np.float32), folded[oc, ic])
         off += cnt
-    assert off == n
+    assert off == o3 + SPLIT_FLOATS                    # the f16x2 copy follows (test_edgeconv_f16x2_pack)
 
     # ---- lane-level forward for one wave (4 points x 20 neighbours)
     N, k = 16, 20
@@ -370,3 +371,62 @@ def test_edgeconv_split_bf16x3_layout():
             outs.append(hh.max(axis=0))
         want.append(np.concatenate(outs))
     np.testing.assert_allclose(got, np.stack(want), rtol=2e-6, atol=2e-6)
+
+
+def test_edgeconv_f16x2_pack():
+    """The fourth packed copy (edgeconv_f16.hip): per layer W = w' 2^S with max|W| in [4,8); planes H = f16(W),
+    Hs = f16(H 2^-12), M = f16(W - H) in the fragment order of the bf16x3 copy, H + M = W to 2^-22 |W| worst case
+    (two 11-bit roundings; + fp16's subnormal floor); biases in accumulator units; the 16 power-of-two scale constants tie the layers together
+    (cs_l = 2^T_l / A_l, cp_l = 1 / A_l, co_l = 2^T_out / A_l, A_l = 2^(S_l + T_(l-1)), A_1 = 1) with T_l taken from the
+    expected activation magnitudes handed to l3d_edgeconv_pack_mag."""
+    lib = _lib.lib()
+    rng = np.random.default_rng(3)
+    ws = [rng.standard_normal((C1, 6)).astype(np.float32), rng.standard_normal((C2, C1)).astype(np.float32) * 0.2,
+          rng.standard_normal((C3, C2)).astype(np.float32) * 0.02, rng.standard_normal((C4, C3)).astype(np.float32) * 3.0]
+    scs = [rng.uniform(0.5, 1.5, c).astype(np.float32) for c in (C1, C2, C3, C4)]
+    shs = [rng.uniform(-0.2, 0.2, c).astype(np.float32) for c in (C1, C2, C3, C4)]
+    mags = np.array([1.0, 5.0, 0.03, 700.0], np.float32)
+    n = lib.l3d_edgeconv_packed_floats(C1, C2, C3, C4)
+    packed = np.zeros(n, np.float32)
+    arr = lambda xs: (C.c_void_p * 4)(*[x.ctypes.data for x in xs])
+    assert lib.l3d_edgeconv_pack_mag(arr(ws), arr(scs), arr(shs), mags.ctypes.data, C1, C2, C3, C4, packed.ctypes.data) == 0
+    v1 = 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4 + C1 + C2 + C3 + C4
+    o4 = v1 + 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4 + SPLIT_FLOATS
+    o_b4 = o4 + SPLIT_FLOATS
+    o_sc = o_b4 + C2 + C3 + C4
+    assert o_sc + 16 == n
+    sc = packed[o_sc:o_sc + 16].astype(np.float64)
+    T = [12 - (int(np.floor(np.log2(m))) + 1) for m in mags]           # mag 2^T in [2^11, 2^12)
+    assert all(2 ** 11 <= m * 2.0 ** t < 2 ** 12 for m, t in zip(mags, T))
+    Tout = min(T)
+    lanes = np.arange(64)
+    j, g = lanes & 15, lanes >> 4
+    off, boff = o4, o_b4
+    A = [0.0]
+    for li, (cin, cout) in enumerate([(C1, C2), (C2, C3), (C3, C4)], start=1):
+        S_, M_ = cin // 32, cout // 16
+        cnt = M_ * S_ * 3 * 64 * 4
+        raw = packed[off:off + cnt].view(np.float16).reshape(M_ // 2, S_, 2, 3, 64, 8).transpose(0, 2, 1, 3, 4, 5).reshape(M_, S_, 3, 64, 8)
+        folded = (ws[li] * scs[li][:, None]).astype(np.float32)
+        Sexp = 3 - (int(np.floor(np.log2(np.abs(folded).max()))) + 1)
+        assert 4 <= np.abs(folded).max() * 2.0 ** Sexp < 8
+        Wsc = folded.astype(np.float64) * 2.0 ** Sexp
+        for m in range(0, M_, max(1, M_ // 4)):
+            for s_ in range(S_):
+                for slot in range(8):
+                    oc = 16 * m + j
+                    ic = 32 * s_ + 16 * (slot >> 2) + 4 * g + (slot & 3)
+                    H, Hs, Mm = (raw[m, s_, p, :, slot].astype(np.float64) for p in range(3))
+                    np.testing.assert_array_equal(H, Wsc[oc, ic].astype(np.float16).astype(np.float64))
+                    np.testing.assert_array_equal(Hs, (H * 2.0 ** -12).astype(np.float16).astype(np.float64))
+                    assert np.all(np.abs(H + Mm - Wsc[oc, ic]) <= 2.0 ** -22 * np.abs(Wsc[oc, ic]) + 2.0 ** -25)
+        a_l = Sexp + T[li - 1]                                           # log2 of layer li+1's accumulator scale
+        A.append(float(a_l))
+        np.testing.assert_array_equal(packed[boff:boff + cout].astype(np.float64), shs[li].astype(np.float64) * 2.0 ** a_l)
+        off += cnt
+        boff += cout
+    for l in range(4):
+        if l < 3:
+            assert sc[l] == 2.0 ** (T[l] - A[l])
+        assert sc[4 + l] == 2.0 ** (-A[l]) and sc[8 + l] == 2.0 ** (Tout - A[l])
+    assert sc[12] == 2.0 ** (-Tout)
