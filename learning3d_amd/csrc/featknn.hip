@@ -32,18 +32,20 @@ __device__ unsigned long long fk_trip_counter;
 #define FK_SCROFF (FK_NXOFF + 2 * 128 * 4)           // [4 waves][17][64] floats (row 16 = -inf)
 #define FK_LDS (FK_SCROFF + 4 * 17 * 64 * 4)
 
-__global__ __launch_bounds__(256) void featknn_split_kernel(const float *__restrict__ x, int C, int N, int Np,
+// C: the tensor's channels; Cp: C rounded up to a multiple of 32 (the GEMM's K chunk) -- the pad channels are zeros,
+// which change neither the dot products nor |x|^2
+__global__ __launch_bounds__(256) void featknn_split_kernel(const float *__restrict__ x, int C, int Cp, int N, int Np,
                                                             uint4 *__restrict__ xs, float *__restrict__ nxx)
 {
     const int n = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
     if (n >= Np) return;
     const float *xb = x + (size_t)b * C * N;
-    uint4 *xsb = xs + (size_t)b * (C / 16) * 6 * Np;
+    uint4 *xsb = xs + (size_t)b * (Cp / 16) * 6 * Np;
     float s = 0.f;
-    for (int c8 = 0; c8 < C / 8; c8++) {               // kc16 = c8 >> 1, kg = c8 & 1
+    for (int c8 = 0; c8 < Cp / 8; c8++) {              // kc16 = c8 >> 1, kg = c8 & 1
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = n < N ? xb[(size_t)(c8 * 8 + e) * N + n] : 0.f;
+        for (int e = 0; e < 8; e++) v[e] = (n < N && c8 * 8 + e < C) ? xb[(size_t)(c8 * 8 + e) * N + n] : 0.f;
 #pragma unroll
         for (int e = 0; e < 8; e++) s = s + v[e] * v[e];          // x ** 2 then sum: no fused multiply-add
         uint4 h, m, l;
@@ -75,7 +77,7 @@ __device__ __forceinline__ void fk_insert_lex(TopK<K> &t, float key, int j)
 }
 
 template <int K>
-__global__ __launch_bounds__(256, 2) void featknn_kernel(const uint4 *__restrict__ xs, const float *__restrict__ nxx,
+__global__ __launch_bounds__(256, K <= 20 ? 2 : 1) void featknn_kernel(const uint4 *__restrict__ xs, const float *__restrict__ nxx,
                                                          int C, int N, int Np, int k, int64_t *__restrict__ idx_out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void featknn_kernel(const uint4 *__restrict
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
-    static_assert(K == 20, "topk20_insert (common.h) is written for K = 20");
+    static_assert(K == 20 || K == 32 || K == 64, "instantiated list lengths");
 #ifdef FK_COUNT
     int trips = 0;
 #endif
@@ -232,7 +234,8 @@ __global__ __launch_bounds__(256, 2) void featknn_kernel(const uint4 *__restrict
                         const unsigned bn = min((unsigned)(__ffs((int)mask) - 1), 16u);
                         mask &= mask - 1;
                         const float cn = scr[bn * 64 + lane];
-                        topk20_insert(top, cv, rbase + (int)((bp & 3) + 8 * (bp >> 2)));
+                        if constexpr (K == 20) topk20_insert(top, cv, rbase + (int)((bp & 3) + 8 * (bp >> 2)));   // asm network (common.h)
+                        else top.insert(cv, rbase + (int)((bp & 3) + 8 * (bp >> 2)));
                         bp = bn;
                         cv = cn;
                     } while (__builtin_amdgcn_ballot_w64(bp < 16u) != 0);
@@ -281,8 +284,8 @@ __global__ __launch_bounds__(256, 2) void featknn_kernel(const uint4 *__restrict
 extern "C" size_t l3d_knn_feature_workspace_bytes(int B, int C, int N)
 {
     if (B <= 0 || C <= 0 || N <= 0) return 0;
-    const size_t Np = (size_t)l3d_divup(N, 128) * 128;
-    return (size_t)B * C * Np * 6 + (size_t)B * Np * 4;
+    const size_t Np = (size_t)l3d_divup(N, 128) * 128, Cp = (size_t)l3d_divup(C, 32) * 32;
+    return (size_t)B * Cp * Np * 6 + (size_t)B * Np * 4;
 }
 
 extern "C" int l3d_knn_feature(const float *x, int B, int C, int N, int k, void *workspace, int64_t *idx,
@@ -290,13 +293,16 @@ extern "C" int l3d_knn_feature(const float *x, int B, int C, int N, int k, void 
 {
     L3D_REQUIRE(x && workspace && idx && B > 0 && C > 0 && N > 0 && k > 0);
     if (k > N) return L3D_ERR_INVALID_ARG;
-    if (C % 32 != 0 || k > 20 || B > 65535 || (((size_t)workspace) & 15)) return L3D_ERR_UNSUPPORTED;
-    const int Np = l3d_divup(N, 128) * 128;
+    if (k > 64 || B > 65535 || (((size_t)workspace) & 15)) return L3D_ERR_UNSUPPORTED;
+    const int Np = l3d_divup(N, 128) * 128, Cp = l3d_divup(C, 32) * 32;      // any C: padded with zero channels
     uint4 *xs = (uint4 *)workspace;
-    float *nxx = (float *)((unsigned char *)workspace + (size_t)B * C * Np * 6);
+    float *nxx = (float *)((unsigned char *)workspace + (size_t)B * Cp * Np * 6);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(featknn_split_kernel, dim3(l3d_divup(Np, 256), B), dim3(256), 0, st, x, C, N, Np, xs, nxx);
-    hipLaunchKernelGGL(featknn_kernel<20>, dim3(Np / 128, B), dim3(256), FK_LDS, st, (const uint4 *)xs,
-                       (const float *)nxx, C, N, Np, k, idx);
+    hipLaunchKernelGGL(featknn_split_kernel, dim3(l3d_divup(Np, 256), B), dim3(256), 0, st, x, C, Cp, N, Np, xs, nxx);
+    dim3 grid(Np / 128, B), block(256);
+    // k <= 20: the asm insertion network; 20 < k <= 64: the generic one (list lengths 32 / 64)
+    if (k <= 20) hipLaunchKernelGGL(featknn_kernel<20>, grid, block, FK_LDS, st, (const uint4 *)xs, (const float *)nxx, Cp, N, Np, k, idx);
+    else if (k <= 32) hipLaunchKernelGGL(featknn_kernel<32>, grid, block, FK_LDS, st, (const uint4 *)xs, (const float *)nxx, Cp, N, Np, k, idx);
+    else hipLaunchKernelGGL(featknn_kernel<64>, grid, block, FK_LDS, st, (const uint4 *)xs, (const float *)nxx, Cp, N, Np, k, idx);
     return l3d_check_launch();
 }

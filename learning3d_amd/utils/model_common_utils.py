@@ -35,12 +35,12 @@ def knn(x, k, add_one_to_k=False):
         # feature-space graphs (PRNet's DGCNN, models/prnet.py:76-97; C = 64..256): the distance is a real
         # GEMM -> matrix cores (bf16x3) with the top-k as its epilogue, no [B,N,N] tensor
         xf = f32c(x)
-        if Cc % 32 == 0 and k <= 20:
+        if k <= 64:                                              # any C (zero-padded to a multiple of 32 in the split pass)
             ws = torch.empty(lib().l3d_knn_feature_workspace_bytes(B, Cc, N), dtype=torch.uint8, device=x.device)
             idx = torch.empty((B, N, k), dtype=torch.int64, device=x.device)
             check(lib().l3d_knn_feature(ptr(xf), B, Cc, N, k, ptr(ws), ptr(idx), stream_ptr()), "l3d_knn_feature")
             return idx
-        # other widths / k > 20: the reference's own op sequence (model_common_utils.py:4-8) on the device
+        # k > 64 in feature space: no caller in the reference asks for it; the op sequence itself (:4-8) on the device
         inner = -2 * torch.matmul(xf.transpose(2, 1), xf)
         xx = torch.sum(xf ** 2, dim=1, keepdim=True)
         pairwise_distance = -xx - inner - xx.transpose(2, 1)

@@ -628,7 +628,8 @@ def test_knn_feature_space_matches_exact_topk():
     from learning3d_amd.utils import knn, get_graph_feature
     from learning3d_amd import _lib
     for (B, C, N, k, seed) in [(2, 64, 300, 16, 61), (2, 32, 128, 20, 62), (2, 128, 1000, 20, 63), (1, 256, 513, 7, 64),
-                               (1, 96, 77, 1, 65), (1, 64, 200, 24, 66), (1, 48, 150, 8, 67)]:   # last two: torch-op route
+                               (1, 96, 77, 1, 65), (1, 64, 200, 24, 66), (1, 48, 150, 8, 67),   # k > 20; C % 32 != 0 (zero-padded)
+                               (2, 9, 300, 21, 70), (1, 130, 257, 64, 71), (1, 5, 40, 33, 72)]:
         rng = np.random.default_rng(seed)
         x = rng.standard_normal((B, C, N)).astype(np.float32)
         idx = knn(dev(x), k).cpu().numpy()
@@ -664,8 +665,10 @@ def test_knn_feature_space_matches_exact_topk():
     ws = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
     out = torch.empty((1, 64, 8), dtype=torch.int64, device="cuda")
     xx = torch.zeros((1, 48, 64), device="cuda")
-    assert _lib.lib().l3d_knn_feature(_lib.ptr(xx), 1, 48, 64, 8, _lib.ptr(ws), _lib.ptr(out), _lib.stream_ptr()) == -2
-    assert _lib.lib().l3d_knn_feature(_lib.ptr(xx), 1, 32, 64, 65, _lib.ptr(ws), _lib.ptr(out), _lib.stream_ptr()) == -1
+    assert _lib.lib().l3d_knn_feature(_lib.ptr(xx), 1, 48, 64, 65, _lib.ptr(ws), _lib.ptr(out), _lib.stream_ptr()) == -1   # k > N
+    xx = torch.zeros((1, 32, 128), device="cuda")
+    out = torch.empty((1, 128, 80), dtype=torch.int64, device="cuda")
+    assert _lib.lib().l3d_knn_feature(_lib.ptr(xx), 1, 32, 128, 80, _lib.ptr(ws), _lib.ptr(out), _lib.stream_ptr()) == -2  # k > 64
 
 
 def test_pointwise_conv_ragged_shapes():
