@@ -412,6 +412,12 @@ int l3d_emd_forward(const float *xyz1, const float *xyz2, int B, int n, int m, f
 int l3d_emd_backward(const float *xyz1, const float *xyz2, const float *match, int B, int n, int m,
                      float *grad1, float *grad2, l3d_stream_t stream);
 
+/* CurveNet LPFA grouping == utils/curvenet_util.py:260-291 in one pass: geo [B,9,N,k] = (centre, neighbour, neighbour -
+ * centre) coordinates and, when x != NULL, diff [B,C,N,k] = x[:, :, idx] - x[:, :, n].  xyz [B,N,3], x [B,C,N],
+ * idx [B,N,k] int64 (the first k of l3d_knn_graph's k + 1, :264). */
+int l3d_lpfa_group(const float *xyz, const float *x, const int64_t *idx, int B, int N, int C, int k, float *geo, float *diff,
+                   l3d_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Device-side data feed of the registration path (feed.hip)
  *   l3d_uniform_clouds : out [B,N,3] ~ U(lo,hi), generated on the device from (seed, element index): reproducible, no

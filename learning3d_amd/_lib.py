@@ -23,6 +23,7 @@ SIGNATURES = {
     "l3d_knn_graph": [_P, _I, _I, _I, _P, _P],
     "l3d_knn_feature_workspace_bytes": [_I, _I, _I],
     "l3d_knn_feature": [_P, _I, _I, _I, _I, _P, _P, _P],
+    "l3d_lpfa_group": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "l3d_graph_feature": [_P, _P, _I, _I, _I, _I, _P, _P],
     "l3d_chamfer_forward": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     "l3d_chamfer_forward_variant": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P],

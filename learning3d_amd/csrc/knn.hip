@@ -566,3 +566,45 @@ extern "C" int l3d_graph_feature(const float *x, const int64_t *idx, int B, int 
                        (hipStream_t)stream, x, idx, N, C, k, total, out);
     return l3d_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------
+// CurveNet LPFA grouping (utils/curvenet_util.py:260-291), one pass:
+//   geo  [B,9,N,k]  = (centre xyz, neighbour xyz, neighbour - centre)            (:273-275)
+//   diff [B,C,N,k]  = x[:, :, idx] - x[:, :, n]          (only when x != NULL)   (:280-285)
+// xyz [B,N,3]; x [B,C,N] channel-first as the reference holds it; idx [B,N,k] int64 (from l3d_knn_graph with k+1,
+// first k kept, :264).  HBM-bound gathers; one thread per (b, n, j), channel loop with coalesced writes over j.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lpfa_group_kernel(const float *__restrict__ xyz, const float *__restrict__ x,
+                                                         const int64_t *__restrict__ idx, int N, int C, int k, size_t total,
+                                                         float *__restrict__ geo, float *__restrict__ diff)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;            // (b, n, j)
+    if (e >= total) return;
+    const size_t bn = e / k, b = bn / N, n = bn % N;
+    const int jj = (int)(e % k);
+    const int64_t j = idx[e];
+    const float *pc = xyz + bn * 3, *pn = xyz + ((size_t)b * N + j) * 3;
+    const size_t plane = (size_t)N * k, o = n * k + jj;
+    float *g = geo + b * 9 * plane + o;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        g[(size_t)c * plane] = pc[c];
+        g[(size_t)(3 + c) * plane] = pn[c];
+        g[(size_t)(6 + c) * plane] = pn[c] - pc[c];
+    }
+    if (x) {
+        const float *xb = x + b * (size_t)C * N;
+        float *d = diff + b * (size_t)C * plane + o;
+        for (int c = 0; c < C; c++) d[(size_t)c * plane] = xb[(size_t)c * N + j] - xb[(size_t)c * N + n];
+    }
+}
+
+extern "C" int l3d_lpfa_group(const float *xyz, const float *x, const int64_t *idx, int B, int N, int C, int k, float *geo,
+                              float *diff, l3d_stream_t stream)
+{
+    L3D_REQUIRE(xyz && idx && geo && B > 0 && N > 0 && k > 0 && (!x || (diff && C > 0)));
+    const size_t total = (size_t)B * N * k;
+    hipLaunchKernelGGL(lpfa_group_kernel, dim3((unsigned)l3d_divup((long)total, 256)), dim3(256), 0, (hipStream_t)stream, xyz, x, idx, N,
+                       x ? C : 0, k, total, geo, diff);
+    return l3d_check_launch();
+}

@@ -256,6 +256,21 @@ def main():
             igts.append(tf.igt)
         save("dcp_transform", template=tmpl, anglex=ang[:, 0], angley=ang[:, 1], anglez=ang[:, 2], translation=trn,
              source=torch.stack(srcs), igt=torch.stack(igts))
+        # ---- CurveNet LPFA (utils/curvenet_util.py:229-291): kNN on xyz with add_one_to_k, grouping, both variants ------
+        from learning3d.utils.curvenet_util import LPFA
+        torch.manual_seed(9)
+        xyz = rand((2, 3, 200), 31)
+        feats = rand((2, 16, 200), 32, -1, 1)
+        outs = {}
+        for name, initial in (("init", True), ("deep", False)):
+            m = LPFA(9 if initial else 16, 24, k=12, mlp_num=1 if initial else 2, initial=initial).eval()
+            m.device = torch.device("cpu")
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.running_mean.uniform_(-0.2, 0.2); mod.running_var.uniform_(0.5, 1.5)
+            outs["out_" + name] = m(xyz if initial else feats, xyz)            # models/curvenet.py:62 calls lpfa(xyz, xyz)
+            outs.update({f"w_{name}." + k: v for k, v in m.state_dict().items()})
+        save("lpfa", xyz=xyz, feats=feats, **outs)
     shutil.rmtree(tmp, ignore_errors=True)
     print("done")
 

@@ -1371,3 +1371,25 @@ def test_dgcnn_training_step_hip_path_matches_torch_path():
         assert e_hip <= 3.0 * e_t32 + 1e-6 * scale, (k, e_hip, e_t32, scale)
     for k in truth[2]:
         np.testing.assert_allclose(res["hip"][2][k], truth[2][k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def test_curvenet_lpfa_golden(golden):
+    """CurveNet's LPFA (utils/curvenet_util.py:229-291): kNN on xyz with add_one_to_k + the one-pass grouping kernel, both
+    variants (initial: geometry only; deep: feature differences + xyz2feature), against the reference module on the CPU,
+    and the autograd route against the fused one."""
+    from learning3d_amd.utils.curvenet_util import LPFA
+    g = golden("lpfa")
+    xyz, feats = dev(g["xyz"]), dev(g["feats"])
+    for name, initial in (("init", True), ("deep", False)):
+        m = LPFA(9 if initial else 16, 24, k=12, mlp_num=1 if initial else 2, initial=initial)
+        m.load_state_dict({k[len(f"w_{name}."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(f"w_{name}.")})
+        m = m.cuda().eval()
+        with torch.no_grad():
+            out = m(xyz if initial else feats, xyz)
+        np.testing.assert_allclose(out.cpu().numpy(), g["out_" + name], rtol=1e-4, atol=1e-5)
+        x_in = (xyz if initial else feats).clone().requires_grad_()
+        out2 = m(x_in, xyz)
+        np.testing.assert_allclose(out2.detach().cpu().numpy(), g["out_" + name], rtol=1e-4, atol=1e-5)
+        if not initial:
+            out2.sum().backward()
+            assert torch.isfinite(x_in.grad).all() and float(x_in.grad.abs().max()) > 0
