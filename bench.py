@@ -45,16 +45,38 @@ EDGECONV_FLOP_PER_CLOUD = NPTS * KNN * 2 * (6 * 64 + 64 * 64 + 64 * 128 + 128 * 
 CONV5_FLOP_PER_CLOUD = NPTS * 2 * 512 * EMB
 
 
+def pmc_record(tag):
+    """What the committed rocprofv3 PMC passes measured for one kernel (profiles/round2_traffic.json, produced on the
+    GPU box by tools/pmc.sh + tools/traffic_json.py; bench.py cannot run rocprofv3 on itself, so this is the measured
+    figure of the same kernel at the same shapes).  {} if not collected."""
+    for name in ("round2_traffic.json", "round1_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                rec = json.load(f).get(tag)
+            if rec:
+                return rec
+        except (OSError, ValueError):
+            pass
+    return {}
+
+
 def pmc_traffic(tag):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/round1_traffic.json,
-    produced by tools/pmc.sh on the GPU box: FETCH_SIZE doubled per the guide's gfx950 correction for
-    wide coalesced reads, + WRITE_SIZE, both KB -> bytes).  bench.py cannot run rocprofv3 on itself,
-    so this is the measured figure of the same kernel at the same shapes; None if not collected."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "round1_traffic.json")) as f:
-            return json.load(f).get(tag, {}).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        return None
+    """HBM bytes per launch: FETCH_SIZE doubled per the guide's gfx950 correction for wide coalesced reads, + WRITE_SIZE,
+    both KB -> bytes.  None if not collected."""
+    return pmc_record(tag).get("hbm_bytes_per_launch")
+
+
+def knn_executed(knn_ms):
+    """Executed VALU work of the kNN kernel from the PMC pass (SQ_INSTS_VALU = wave-instructions per launch; x64 lanes):
+    lane-operations per candidate pair and the fraction of the fp32 VALU issue peak they occupy -- the honest
+    utilisation figure beside `valu_frac`, which prices only the ~7 algorithmic lane-ops per pair."""
+    insts = pmc_record("knn").get("SQ_INSTS_VALU")
+    if not insts:
+        return {}
+    laneops = insts * 64.0
+    return {"executed_valu_insts_per_launch": insts,
+            "executed_laneops_per_pair": laneops / (B_PER_GPU * NPTS * NPTS),
+            "executed_valu_frac": laneops / (knn_ms * 1e-3) / VALU_PEAK_LANEOPS}
 
 
 def edgeconv_roofline(ec_tf, ec_ms, arith):
@@ -188,9 +210,9 @@ def main():
                     help="N>1: make the blocking exchange the headline (default: pipelined; both are always reported)")
     ap.add_argument("--fp32-mfma", action="store_true",
                     help="run the shared-MLP GEMMs on the fp32 MFMA (157 TF peak) instead of the matrix-core split kernels")
-    ap.add_argument("--arith", choices=["f16x2", "bf16x3"], default=None,
+    ap.add_argument("--arith", choices=["f16x2", "bf16x3", "fp32"], default=None,
                     help="GEMM arithmetic of the shared-MLP kernels (default f16x2: 3 fp16 MFMA products per fp32 product; "
-                         "bf16x3: 6 bf16 products, full fp32 exponent range)")
+                         "bf16x3: 6 bf16 products, full fp32 exponent range; fp32 = --fp32-mfma)")
     ap.add_argument("--no-graph", action="store_true", help="issue every step's launches eagerly instead of replaying a hipGraph")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="control-flow self test on CPU/gloo (launcher, sharding, collective, max-over-ranks, JSON): "
@@ -205,9 +227,9 @@ def main():
     if args.selftest_cpu:
         return selftest_cpu(args, parallel, dist)
     from learning3d_amd.models import DGCNN, _fused
-    if args.fp32_mfma:
+    if args.fp32_mfma or args.arith == "fp32":
         _fused.SPLIT_BF16 = False
-    if args.arith:
+    elif args.arith:
         _fused.GEMM_ARITH = args.arith
     from learning3d_amd.losses.chamfer_distance import ChamferDistance, chamfer_partials
 
@@ -419,7 +441,8 @@ def main():
                              "note": "VALU-bound by construction (33.5 M pair evaluations per 5.6 MB), see DESIGN.md",
                              "pair_evals_per_s": B_PER_GPU * NPTS * NPTS / (stage_ms["knn"] * 1e-3),
                              "valu_frac": B_PER_GPU * NPTS * NPTS * KNN_LANEOPS_PER_PAIR /
-                             (stage_ms["knn"] * 1e-3) / VALU_PEAK_LANEOPS},
+                             (stage_ms["knn"] * 1e-3) / VALU_PEAK_LANEOPS,
+                             **knn_executed(stage_ms["knn"])},
             "kernels": {"knn_ms": stage_ms["knn"], "edgeconv_ms": stage_ms["edgeconv"], "conv5_ms": stage_ms["conv5"],
                         "chamfer_ms": stage_ms["chamfer"], "conv5_tflops": c5_tf, "chamfer_alg_gbs": ch_gbs,
                         "chamfer_valu_frac": 2 * B_PER_GPU * NPTS * NPTS * CHAMFER_LANEOPS_PER_PAIR /

@@ -137,10 +137,23 @@ def ptr(t):
 
 
 def require_gpu(*tensors):
+    """Device tensors only, all on ONE device, which must be the current device: the C ABI launches on the current
+    device's current stream (stream_ptr), so a tensor living elsewhere would be read through a foreign pointer.  Raises
+    instead (callers switch with `with torch.cuda.device(t.device):`)."""
+    dev = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise L3DError("learning3d_amd operates on MI355X device tensors only "
                            "(got a CPU tensor; there is no CPU fallback)")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise L3DError(f"tensors on different devices in one call ({dev} and {t.device})")
+    if dev is not None and dev.index != torch.cuda.current_device():
+        raise L3DError(f"tensors live on {dev} but the current device is cuda:{torch.cuda.current_device()}; "
+                       f"wrap the call in `with torch.cuda.device({dev.index}):`")
 
 
 def f32c(t):

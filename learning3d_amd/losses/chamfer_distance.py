@@ -54,6 +54,8 @@ class ChamferDistance(torch.nn.Module):
 def chamfer_partials(dist1, dist2):
     """Device fp64 tensor [4] = (sum sqrt(dist1), sum sqrt(dist2), #dist1, #dist2): the per-shard
     partial sums the multi-GPU path all-gathers (forward-only helper; no autograd, no host sync)."""
+    require_gpu(dist1, dist2)
+    dist1, dist2 = f32c(dist1), f32c(dist2)                  # the kernels read dense fp32 with 16-byte loads
     B, N = dist1.shape
     M = dist2.shape[1]
     part = torch.empty(4, dtype=torch.float64, device=dist1.device)
@@ -68,6 +70,8 @@ _LL_WS = {}
 def chamfer_loss_local(dist1, dist2):
     """One rank, one launch: the same partial sums and the same combine as chamfer_combine(chamfer_partials(...)),
     spread over up to 64 workgroups (l3d_chamfer_loss_local_mb; workspace cached per device and stream)."""
+    require_gpu(dist1, dist2)
+    dist1, dist2 = f32c(dist1), f32c(dist2)
     B, N = dist1.shape
     M = dist2.shape[1]
     key = (dist1.device.index, torch.cuda.current_stream(dist1.device).cuda_stream)
@@ -84,6 +88,9 @@ def chamfer_loss_local(dist1, dist2):
 
 def chamfer_combine(partials):
     """partials: fp64 [world,4] (or [4]) device tensor -> fp32 scalar loss tensor (on device)."""
+    require_gpu(partials)
+    if partials.dtype != torch.float64:
+        raise TypeError("chamfer_combine expects the fp64 partial sums of chamfer_partials")
     partials = partials.contiguous().view(-1, 4)
     loss = torch.empty((), dtype=torch.float32, device=partials.device)
     check(lib().l3d_chamfer_combine(ptr(partials), partials.shape[0], ptr(loss), stream_ptr()),

@@ -54,6 +54,13 @@ def knn(x, k, add_one_to_k=False):
 def square_distance(src, dst):
     """reference: utils/model_common_utils.py:19-38.  [B,N,3],[B,M,3] -> [B,N,M] fp32."""
     require_gpu(src, dst)
+    if torch.is_grad_enabled() and (src.requires_grad or dst.requires_grad):
+        # differentiable like the reference's matmul form (:34-37): its own op sequence through torch
+        B, N, _ = src.shape
+        M = dst.shape[1]
+        dist = -2 * torch.matmul(src, dst.permute(0, 2, 1))
+        dist = dist + torch.sum(src ** 2, -1).view(B, N, 1)
+        return dist + torch.sum(dst ** 2, -1).view(B, 1, M)
     B, N, Cc = src.shape
     M = dst.shape[1]
     if dst.shape[2] != Cc:
@@ -71,6 +78,12 @@ def index_points(points, idx):
     """reference: utils/model_common_utils.py:40-56.  points [B,N,C], idx [B,S] or [B,S,K] (int64)
     -> [B,S,C] / [B,S,K,C]."""
     require_gpu(points, idx)
+    if torch.is_grad_enabled() and points.requires_grad:
+        # the reference's advanced indexing is differentiable w.r.t. points (:50-55); keep that through torch
+        B = points.shape[0]
+        view_shape = [B] + [1] * (idx.dim() - 1)
+        batch_indices = torch.arange(B, dtype=torch.long, device=points.device).view(view_shape).expand_as(idx)
+        return points[batch_indices, idx.long(), :]
     B, N, Cc = points.shape
     p = f32c(points)
     ix = idx.to(torch.int64).contiguous().view(B, -1)
@@ -106,6 +119,12 @@ def knn_point(k, pos1, pos2):
     M = pos2.shape[1]
     if Cc != 3:
         raise NotImplementedError("knn_point: C=3 only")
+    if torch.is_grad_enabled() and (pos1.requires_grad or pos2.requires_grad):
+        # distances differentiable like the reference's (:94-100): indices from the kernel, values re-formed by torch
+        with torch.no_grad():
+            _, idx = knn_point(k, pos1, pos2)
+        nb = torch.gather(pos1.unsqueeze(1).expand(B, M, N, 3), 2, idx.unsqueeze(-1).expand(B, M, k, 3))
+        return torch.sqrt(torch.sum((nb - pos2.unsqueeze(2)) ** 2, -1)), idx
     p1, p2 = f32c(pos1), f32c(pos2)
     val = torch.empty((B, M, k), dtype=torch.float32, device=pos1.device)
     idx = torch.empty((B, M, k), dtype=torch.int64, device=pos1.device)

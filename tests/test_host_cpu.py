@@ -262,3 +262,35 @@ def test_two_rank_gloo_batchnorm_statistics_bit_identical():
     for rank, pg, t, m, v, nn_ in got:
         assert pg == part.numpy().tobytes() and t == tot.numpy().tobytes()
         assert m == mean.numpy().tobytes() and v == var.numpy().tobytes() and nn_ == n
+
+
+def test_integration_md_shims_match_the_library():
+    """INTEGRATION.md is the binding a maintainer would add: its python shims must compile, call only exported entry
+    points with the number of arguments the C ABI declares, and the prose must not name a symbol that does not exist."""
+    import ast
+    import re
+    from learning3d_amd import _lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    named = set(re.findall(r"\bl3d_[a-z0-9_]+\b", text))
+    known = set(_lib.SIGNATURES)
+    # prose may abbreviate families ("l3d_*_grad", "_workspace_bytes"); full names must exist
+    unknown = {n for n in named if n not in known and n not in ("l3d_hip", "l3d_status")
+               and not any(k.startswith(n) for k in known)}
+    assert not unknown, f"INTEGRATION.md names entry points the library does not export: {sorted(unknown)}"
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    shims = [b for b in blocks if "_l3d." in b]
+    assert len(shims) >= 4
+    src = "\n".join(shims)
+    tree = ast.parse(src)                                   # the shims are valid python
+    calls = 0
+    for node in ast.walk(tree):
+        if (isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute)
+                and isinstance(node.func.value, ast.Name) and node.func.value.id == "_l3d"):
+            name = node.func.attr
+            assert name in known, name
+            if any(isinstance(a, ast.Starred) for a in node.args):
+                continue
+            assert len(node.args) == len(_lib.SIGNATURES[name]), \
+                f"{name}: shim passes {len(node.args)} arguments, the C ABI takes {len(_lib.SIGNATURES[name])}"
+            calls += 1
+    assert calls >= 14

@@ -1,4 +1,4 @@
-"""Run one kernel a few times (for rocprofv3 --pmc passes).  usage: run_one.py knn|chamfer|edgeconv|edgeconv_split|conv5|conv5_split"""
+"""Run one kernel a few times (for rocprofv3 --pmc passes).  usage: run_one.py knn|chamfer|edgeconv|edgeconv_split|edgeconv_f16|conv5|conv5_split|conv5_f16"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,13 +13,16 @@ with torch.no_grad():
     idx = U.knn(x.permute(0, 2, 1), 20)
     packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
     pooled = _fused.edgeconv_forward(x, idx, packed)
-    w5, s5, b5, w5s = net._conv5_folded()
+    w5, s5, b5, w5s, w5f = net._conv5_folded()
+    img = _fused.edgeconv_forward(x, idx, packed, kernel="f16", planes=True)
     torch.cuda.synchronize()
     for _ in range(5):
         if what == "knn": U.knn(x.permute(0, 2, 1), 20)
         elif what == "chamfer": ChamferDistance()(a, b)
         elif what == "edgeconv": _fused.edgeconv_forward(x, idx, packed, kernel="chained")            # fp32 MFMA
         elif what == "edgeconv_split": _fused.edgeconv_forward(x, idx, packed, kernel="split")        # bf16x3
+        elif what == "edgeconv_f16": _fused.edgeconv_forward(x, idx, packed, kernel="f16", planes=True)   # f16x2, plane image out
+        elif what == "conv5_f16": _fused.pointwise_conv_f16(img, 32, 1024, w5f, 512, 1024, s5, b5, relu=True)
         elif what == "conv5": _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True, split=False)
         elif what == "conv5_split": _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True, w_split=w5s)
     torch.cuda.synchronize()

@@ -1,16 +1,27 @@
-"""profiles/round1_pmc_<tag>.txt -> profiles/round1_traffic.json (HBM bytes per launch)."""
+"""profiles/round<R>_pmc_<tag>.txt -> profiles/round<R>_traffic.json: HBM bytes per launch and, where collected, the
+executed VALU / MFMA instruction counts per launch.  usage: traffic_json.py [round]   (default 2; a tag without a
+round-R file falls back to the newest earlier round whose kernel is unchanged)"""
 import json, os, re, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 out = {}
-for tag in ("edgeconv", "edgeconv_split", "conv5", "conv5_split", "knn", "chamfer"):
-    path = os.path.join(root, "profiles", f"round1_pmc_{tag}.txt")
-    if not os.path.exists(path):
+for tag in ("edgeconv", "edgeconv_split", "edgeconv_f16", "conv5", "conv5_split", "conv5_f16", "knn", "chamfer"):
+    path = None
+    for r in range(rnd, 0, -1):
+        cand = os.path.join(root, "profiles", f"round{r}_pmc_{tag}.txt")
+        if os.path.exists(cand):
+            path = cand
+            break
+    if path is None:
         continue
     vals = dict(re.findall(r"^(\w+)\s+n=\s*\d+\s+mean=\s*([\d.]+)", open(path).read(), flags=re.M))
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         f, w = float(vals["FETCH_SIZE"]) * 1024, float(vals["WRITE_SIZE"]) * 1024
-        out[tag] = {"fetch_size_bytes_raw": f, "write_size_bytes": w,
+        out[tag] = {"source": os.path.basename(path), "fetch_size_bytes_raw": f, "write_size_bytes": w,
                     "hbm_bytes_per_launch": 2 * f + w,
                     "note": "FETCH_SIZE x2 (gfx950 rocprofv3 under-reports wide coalesced reads by 2x, MI355X_MICROARCH.md HBM section) + WRITE_SIZE"}
-json.dump(out, open(os.path.join(root, "profiles", "round1_traffic.json"), "w"), indent=1)
+        for k in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_LDS", "GRBM_GUI_ACTIVE"):
+            if k in vals:
+                out[tag][k] = float(vals[k])
+json.dump(out, open(os.path.join(root, "profiles", f"round{rnd}_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
