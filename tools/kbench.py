@@ -66,7 +66,14 @@ def main():
         t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, kernel="split"))
         res["edgeconv_bf16x3_c2"] = (t, B * N * k * 2 * 45440 / t / 1e6, "TFLOP/s(fp32-equiv)")
         pooled = _fused.edgeconv_forward(x, idx, packed)
-        w5, s5, b5, w5s = net._conv5_folded()
+        w5, s5, b5, w5s, w5f = net._conv5_folded()
+        t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, kernel="f16"))
+        res["edgeconv_f16x2_c2"] = (t, B * N * k * 2 * 45440 / t / 1e6, "TFLOP/s(fp32-equiv)")
+        t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, kernel="f16", planes=True))
+        res["edgeconv_f16x2_planes_c2"] = (t, B * N * k * 2 * 45440 / t / 1e6, "TFLOP/s(fp32-equiv)")
+        img = _fused.edgeconv_forward(x, idx, packed, kernel="f16", planes=True)
+        t = timeit(lambda: _fused.pointwise_conv_f16(img, B, N, w5f, 512, 1024, s5, b5, relu=True))
+        res["conv5_f16x2_c2"] = (t, B * N * 2 * 512 * 1024 / t / 1e6, "TFLOP/s(fp32-equiv)")
         t = timeit(lambda: _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True, split=False))
         res["conv5_f32mfma_c2"] = (t, B * N * 2 * 512 * 1024 / t / 1e6, "TFLOP/s")
         t = timeit(lambda: _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True, w_split=w5s))
