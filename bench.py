@@ -70,7 +70,7 @@ def knn_executed(knn_ms):
     """Executed VALU work of the kNN kernel from the PMC pass (SQ_INSTS_VALU = wave-instructions per launch; x64 lanes):
     lane-operations per candidate pair and the fraction of the fp32 VALU issue peak they occupy -- the honest
     utilisation figure beside `valu_frac`, which prices only the ~7 algorithmic lane-ops per pair."""
-    insts = pmc_record("knn").get("SQ_INSTS_VALU")
+    insts = (pmc_record("knn_mfma") or pmc_record("knn")).get("SQ_INSTS_VALU")
     if not insts:
         return {}
     laneops = insts * 64.0
@@ -433,12 +433,12 @@ def main():
             # dominant kernel by time: the fused 4-layer EdgeConv stack
             "roofline": edgeconv_roofline(ec_tf, stage_ms["edgeconv"], arith),
             # the metric's second half: kNN (and Chamfer) HBM rate on ALGORITHMIC bytes
-            "roofline_knn": {"kernel": "topk2_kernel<20,EXPANDED,4>", "bound": "hbm", "achieved": knn_gbs,
+            "roofline_knn": {"kernel": "knn_mfma_kernel<8> (+ topk2_kernel<20,EXPANDED,4> fix-up launch, idle here)", "bound": "hbm", "achieved": knn_gbs,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": knn_gbs / HBM_PEAK_GBS,
-                             "traffic": pmc_traffic("knn"),
+                             "traffic": pmc_traffic("knn_mfma") or pmc_traffic("knn"),
                              "avg_launch_ms": stage_ms["knn"],
                              "algorithmic_bytes_per_launch": B_PER_GPU * KNN_BYTES_PER_CLOUD,
-                             "note": "VALU-bound by construction (33.5 M pair evaluations per 5.6 MB), see DESIGN.md",
+                             "note": "VALU-bound by construction (33.5 M pair evaluations per 5.6 MB; ranking values come from the fp32 matrix cores, selection is VALU work), see DESIGN.md",
                              "pair_evals_per_s": B_PER_GPU * NPTS * NPTS / (stage_ms["knn"] * 1e-3),
                              "valu_frac": B_PER_GPU * NPTS * NPTS * KNN_LANEOPS_PER_PAIR /
                              (stage_ms["knn"] * 1e-3) / VALU_PEAK_LANEOPS,

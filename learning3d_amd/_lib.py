@@ -21,6 +21,7 @@ SIGNATURES = {
     "l3d_status_string": [_I],
     "l3d_last_hip_error": [],
     "l3d_knn_graph": [_P, _I, _I, _I, _P, _P],
+    "l3d_knn_graph_variant": [_P, _I, _I, _I, _P, _I, _P],
     "l3d_knn_feature_workspace_bytes": [_I, _I, _I],
     "l3d_knn_feature": [_P, _I, _I, _I, _I, _P, _P, _P],
     "l3d_lpfa_group": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P],

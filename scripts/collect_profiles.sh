@@ -8,6 +8,7 @@ cp_if "$(find gpurun_out/prof_r2_bf16x3 -name '*kernel_stats.csv' | head -1)" pr
 cp_if gpurun_out/r2_bench.json profiles/round2_bench.json
 cp_if gpurun_out/r2_bench_driver.json profiles/round2_bench_driver_args.json
 cp_if gpurun_out/pmc_edgeconv_f16.txt profiles/round2_pmc_edgeconv_f16.txt
+cp_if gpurun_out/pmc_knn_mfma.txt profiles/round2_pmc_knn_mfma.txt
 cp_if gpurun_out/pmc_conv5_f16.txt profiles/round2_pmc_conv5_f16.txt
 cp_if gpurun_out/r2_kbench.txt profiles/round2_kbench.txt
 python tools/traffic_json.py 2 > /dev/null && echo "  profiles/round2_traffic.json"

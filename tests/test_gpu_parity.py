@@ -1393,3 +1393,63 @@ def test_curvenet_lpfa_golden(golden):
         if not initial:
             out2.sum().backward()
             assert torch.isfinite(x_in.grad).all() and float(x_in.grad.abs().max()) > 0
+
+
+# ------------------------------------------------ kNN on the matrix cores (knn_mfma.hip) vs the insertion kernel
+def _knn_variant(x_bn3, k, variant):
+    from learning3d_amd._lib import check, lib, ptr, stream_ptr
+    x = x_bn3.contiguous()
+    B, N, _ = x.shape
+    idx = torch.full((B, N, k), -7, dtype=torch.int64, device=x.device)
+    check(lib().l3d_knn_graph_variant(ptr(x), B, N, k, ptr(idx), variant, stream_ptr()), "l3d_knn_graph_variant")
+    return idx
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,k", [(4, 1024, 20), (2, 1000, 24), (3, 256, 1), (2, 2048, 20), (2, 1500, 7), (1, 257, 16)])
+def test_knn_mfma_equals_insertion_kernel(B, N, k):
+    """The matrix-core kernel (variant 2) must return the insertion kernel's (variant 1) indices exactly: same ranking
+    bits (the MFMA k-slot chain IS the reference's fma chain), same tie rule.  Uniform, spatially sorted and clustered
+    clouds; the first case is also pinned to the oracle."""
+    g = torch.Generator().manual_seed(N + k)
+    uni = torch.rand((B, N, 3), generator=g)
+    srt = torch.stack([c[torch.argsort(c[:, 0])] for c in torch.rand((B, N, 3), generator=g)])
+    clu = torch.randn((B, N, 3), generator=g) * 0.05 + torch.randn((B, 1, 3), generator=g)
+    for name, pts in (("uniform", uni), ("sorted", srt), ("clustered", clu)):
+        a = _knn_variant(dev(pts), k, 2).cpu().numpy()
+        b = _knn_variant(dev(pts), k, 1).cpu().numpy()
+        assert (a >= 0).all() and (a < N).all(), name
+        assert np.array_equal(a, b), f"{name}: {np.argwhere(a != b)[:5]}"
+    if (B, N, k) == (4, 1024, 20):
+        oracle.assert_knn_equal_modulo_ties(_knn_variant(dev(uni), k, 2).cpu().numpy(), oracle.knn(uni.numpy(), k), uni.numpy())
+
+
+@pytest.mark.gpu
+def test_knn_mfma_ties_duplicates_and_overflow_fixup():
+    """Exact ties resolve to the lower index like the insertion kernel; a cloud with hundreds of copies of one point
+    overflows the 64-key candidate lists of the queries near it -- those blocks are redone by the fix-up launch."""
+    g = torch.Generator().manual_seed(5)
+    N, k = 1024, 20
+    pairs = torch.rand((2, N, 3), generator=g)
+    pairs[:, N // 2:] = pairs[:, :N // 2]                                   # every point twice: ties everywhere
+    heavy = torch.rand((2, N, 3), generator=g)
+    heavy[0, 100:420] = heavy[0, 7]                                          # 321 copies of one point
+    heavy[1, 600:700] = heavy[1, 3]
+    heavy[1, 900:1000] = heavy[1, 3]
+    same = torch.zeros((1, N, 3)) + 0.25                                     # all points identical
+    for name, pts in (("pairs", pairs), ("heavy", heavy), ("same", same)):
+        a = _knn_variant(dev(pts), k, 2).cpu().numpy()
+        b = _knn_variant(dev(pts), k, 1).cpu().numpy()
+        assert np.array_equal(a, b), f"{name}: {np.argwhere(a != b)[:5]}"
+    assert np.array_equal(a[0, 0], np.arange(k))                             # all-equal cloud: first k indices
+
+
+@pytest.mark.gpu
+def test_knn_variant_argument_checks():
+    from learning3d_amd._lib import L3DError
+    x = dev(rand((1, 200, 3), 1))
+    with pytest.raises(L3DError):
+        _knn_variant(x, 7, 2)                                                # N < 256: the matrix-core kernel is not built for it
+    with pytest.raises(L3DError):
+        _knn_variant(dev(rand((1, 512, 3), 1)), 32, 2)                       # k > 24
+    assert np.array_equal(_knn_variant(x, 7, 0).cpu().numpy(), _knn_variant(x, 7, 1).cpu().numpy())
