@@ -25,8 +25,13 @@
 // fragment reads per K chunk are 3a + 2c for an a x c wave tile: 14 for 2 x 4 (16 for 4 x 2).  K chunks of 16 (one MFMA
 // k-step), THREE LDS stages of 40 KB (W 24 KB + x 16 KB); per chunk every wave issues 5 DMA pieces for chunk kc+2,
 // waits for its own pieces of chunk kc (s_waitcnt vmcnt -- the loop has no other vector memory traffic), one barrier,
-// 14 ds_read_b128, 24 MFMAs.  Measured, not kept: reading chunk kc+1's x fragments (8 of the 14) during chunk kc's MFMAs --
-// the second register set pushes the kernel to 256 VGPRs + spills at two waves per SIMD: 112 us against 97.
+// 14 ds_read_b128, 24 MFMAs.  Measured, not kept (LABLOG R2.3 has the numbers): reading chunk kc+1's x fragments during
+// chunk kc's MFMAs (spills: 112 us against 97); a four-wave 128 x 256 workgroup with two LDS stages, two per CU (101 us); the
+// same with the W fragments straight from L2 into registers, 8 LDS reads instead of 14 (110 us); all 14 reads ahead of the
+// first MFMA (105 us); the first product's fragments read across the chunk barrier (105 us).  What the variants have in
+// common: the epilogue's 134 MB of stores are hidden (97 us without them), the loop without any DMA or barrier still
+// takes 82 us, and a bare loop of 14 ds_read_b128 + 24 MFMAs sustains 1.85 PFLOP/s on this chip (tools/probe_mfma_lds.hip),
+// which would be 56 us.
 #include "common.h"
 #include "split_bf16.h"          // f32x4 / f32x16 typedefs
 
@@ -140,7 +145,24 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave & 3, wn = wave >> 2;
-    const int n0 = blockIdx.x * CF_TN, co0 = blockIdx.y * CF_TM, b = blockIdx.z;
+    // Tile order (1-D grid).  Workgroup L runs on XCD L % 8, each with its own L2: the Cout tiles of one point tile are
+    // consecutive slots of ONE XCD, so the point tile's activation planes come from HBM once instead of once per XCD
+    // that happens to host one of its Cout tiles.  It does not change the kernel's time (the reads were hidden), it
+    // halves its HBM read traffic.
+    int pt, ct;
+    {
+        const int nct = Cout / CF_TM, npt = Bn * (N / CF_TN), L = blockIdx.x;
+        if (npt % 8 == 0) {
+            const int xcd = L & 7, slot = L >> 3;
+            ct = slot % nct;
+            pt = (slot / nct) * 8 + xcd;
+        } else {
+            ct = L % nct;
+            pt = L / nct;
+        }
+    }
+    const int ntn = N / CF_TN;
+    const int n0 = (pt % ntn) * CF_TN, co0 = ct * CF_TM, b = pt / ntn;
     const int nk = Cin / 16;
     const size_t BN = (size_t)Bn * N;
 
@@ -258,7 +280,7 @@ extern "C" int l3d_conv_f16_split_weights(const float *w, int Cout, int Cin, voi
     unsigned char *d = (unsigned char *)dst;
     float *inv = (float *)(d + 3 * pb);
     unsigned *amax = (unsigned *)(d + 3 * pb + 4);
-    hipMemsetAsync(amax, 0, 4, st);
+    if (hipMemsetAsync(amax, 0, 4, st) != hipSuccess) return L3D_ERR_LAUNCH;
     const size_t n = (size_t)Cout * Cin;
     const long nblk = l3d_divup((long)n, 256);
     hipLaunchKernelGGL(cf_absmax_kernel, dim3((unsigned)(nblk > 256 ? 256 : nblk)), dim3(256), 0, st, w, n, amax);
@@ -285,7 +307,7 @@ extern "C" int l3d_split_f16_rows(const float *x, long rows, int C, int channel_
     unsigned char *d = (unsigned char *)dst;
     float *inv = (float *)(d + 2 * pb);
     unsigned *amax = (unsigned *)(d + 2 * pb + 4);
-    hipMemsetAsync(amax, 0, 4, st);
+    if (hipMemsetAsync(amax, 0, 4, st) != hipSuccess) return L3D_ERR_LAUNCH;
     const size_t n = (size_t)rows * C;
     const long nblk = l3d_divup((long)n, 1024);
     hipLaunchKernelGGL(cf_absmax_kernel, dim3((unsigned)(nblk > 256 ? 256 : nblk)), dim3(256), 0, st, x, n, amax);
@@ -309,7 +331,7 @@ extern "C" int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes
         return L3D_ERR_UNSUPPORTED;
     const size_t xpb = l3d_f16_plane_bytes((long)B * N, Cin), wpb = l3d_f16_plane_bytes(Cout, Cin);
     const unsigned char *xp = (const unsigned char *)x_planes, *wp = (const unsigned char *)w_planes;
-    dim3 grid(N / CF_TN, Cout / CF_TM, B), block(512);
+    dim3 grid((unsigned)((size_t)(N / CF_TN) * (Cout / CF_TM) * B)), block(512);
     hipLaunchKernelGGL(conv_f16_kernel, grid, block, CF_LDS, (hipStream_t)stream, (const uint4 *)xp, (const uint4 *)(xp + xpb),
                        (const uint4 *)wp, (const uint4 *)(wp + wpb), (const uint4 *)(wp + 2 * wpb), (const float *)(wp + 3 * wpb),
                        (const float *)(xp + 2 * xpb), scale, shift, shift_bstride, B, Cin, Cout, N, relu, y);
