@@ -509,15 +509,15 @@ int l3d_launch_knn_mfma(const float *xyz, int B, int N, int k, int64_t *idx, hip
 extern "C" int l3d_knn_graph_variant(const float *xyz, int B, int N, int k, int64_t *idx, int variant,
                                      l3d_stream_t stream)
 {
-    L3D_REQUIRE(xyz && idx && B > 0 && N > 0 && k > 0 && k <= N && k <= L3D_KNN_MAX_K && variant >= 0 && variant <= 2);
+    L3D_REQUIRE(xyz && idx && B > 0 && N > 0 && k > 0 && k <= N && k <= L3D_KNN_MAX_K && variant >= 0 && variant <= 3);
     hipStream_t st = (hipStream_t)stream;
     const bool mfma = l3d_knn_mfma_supported(N, k);
-    if (variant == 2 && !mfma) return L3D_ERR_UNSUPPORTED;
+    if (variant >= 2 && !mfma) return L3D_ERR_UNSUPPORTED;
     if (variant != 1 && mfma) {
         // ranking values on the matrix cores + selection by rank counting; query blocks whose candidate list
         // overflowed (heavily duplicated points) are redone by the insertion kernel in fix-up mode
         const int rc = l3d_launch_knn_mfma(xyz, B, N, k, idx, st);
-        if (rc != L3D_OK) return rc;
+        if (rc != L3D_OK || variant == 3) return rc;          // 3: diagnostics, overflowed blocks stay marked
         return launch_topk<METRIC_EXPANDED>(xyz, xyz, B, N, N, k, OUT_KNN_GRAPH, idx, nullptr, st, 1);
     }
     return launch_topk<METRIC_EXPANDED>(xyz, xyz, B, N, N, k, OUT_KNN_GRAPH, idx, nullptr, st);

@@ -186,80 +186,115 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
 #pragma unroll
     for (int l = 1; l < 8; l++) thr0_ = fminf(thr0_, thr0s[i * 9 + l]);
 #ifdef KM_TIMING
-    const float thr0 = (k & 0x100) ? INFINITY : thr0_;       // probe: k + 256 = nothing reaches the threshold
+    float thr0 = (k & 0x100) ? INFINITY : thr0_;             // probe: k + 256 = nothing reaches the threshold
     k &= 0xff;
 #else
-    const float thr0 = thr0_;
+    float thr0 = thr0_;
 #endif
     KMT(3)
 
     // ------------------------------------------------------------------ pass 1: collect the candidates >= thr0
+    // Two attempts.  A list overflows (> 64 candidates reach thr0) for about one query in 30 000 of a random cloud --
+    // the tail of the group-maxima bound -- and for every query that sits on a heavily duplicated point.  The first kind
+    // is settled here: the k-th best of the 64 keys that WERE collected is a tighter lower bound that real candidates
+    // reach, so the block collects again with it.  Only if that overflows too (exact ties: more than 64 candidates AT the
+    // k-th best value) does the block go to the fix-up kernel, whose single 64-query workgroup costs a whole 35 us.
     float *mydump = dump + wave * 2048;
     u64 *mylist = qlist + i * KM_STRIDE;
-    bool over = false;
-#pragma unroll
-    for (j = 0; j < T; j += 2) {
-        const bool two = j + 1 < T;
-        f32x16 aA, aB;
-        if constexpr (CT > 0) {
-            aA = kept[j];
-            aB = kept[j + 1];
-        } else {
-            aA = km_tile(cxy, czw, at0 + j * 32, b1, b2, b3, a3);
-            aB = km_tile(cxy, czw, at0 + (two ? j * 32 + 32 : j * 32), b1, b2, b3, a3);
-        }
-        unsigned sgn = 0;                                      // sign bits of (value - thr0): set = below the threshold
-#pragma unroll
-        for (int r = 0; r < 16; r++) sgn = __builtin_amdgcn_alignbit(sgn, __float_as_uint(aA[r] - thr0), 31);
-#pragma unroll
-        for (int r = 0; r < 16; r++) sgn = __builtin_amdgcn_alignbit(sgn, __float_as_uint(aB[r] - thr0), 31);
-        unsigned m = ~sgn;                                     // bit 31 - e: accumulator register e & 15 of tile e >> 4 (A, B)
-        if (!two) m &= 0xFFFF0000u;
-        if (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
-#pragma unroll
-            for (int qd = 0; qd < 4; qd++) {
-                *(float4 *)(mydump + (qd * 64 + lane) * 4) = make_float4(aA[4 * qd], aA[4 * qd + 1], aA[4 * qd + 2], aA[4 * qd + 3]);
-                *(float4 *)(mydump + 1024 + (qd * 64 + lane) * 4) = make_float4(aB[4 * qd], aB[4 * qd + 1], aB[4 * qd + 2], aB[4 * qd + 3]);
+    for (int attempt = 0;; attempt++) {
+        bool over = false;
+    #pragma unroll
+        for (j = 0; j < T; j += 2) {
+            const bool two = j + 1 < T;
+            f32x16 aA, aB;
+            if constexpr (CT > 0) {
+                aA = kept[j];
+                aB = kept[j + 1];
+            } else {
+                aA = km_tile(cxy, czw, at0 + j * 32, b1, b2, b3, a3);
+                aB = km_tile(cxy, czw, at0 + (two ? j * 32 + 32 : j * 32), b1, b2, b3, a3);
             }
-            // Four hits per trip, straight-line: an exec-mask region costs a scalar round trip (LABLOG 4.3b), so a lane
-            // without a hit goes through the same motions with an increment of 0 and a write to the spare slot of its
-            // row.  The dump reads and slot atomics of a trip are in flight together.
-            const int cbase = 128 * j + lane8;
-#pragma unroll 1
-            do {
-                int e[4], slot[4];
-                bool has[4];
-                float vv[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    has[u] = m != 0;
-                    e[u] = has[u] ? __builtin_clz(m) : 31;
-                    m &= ~(0x80000000u >> e[u]);
-                    vv[u] = mydump[((e[u] >> 2) << 8) + lane * 4 + (e[u] & 3)];
-                    slot[u] = atomicAdd(&qcnt[i], has[u] ? 1 : 0);
+            unsigned sgn = 0;                                      // sign bits of (value - thr0): set = below the threshold
+    #pragma unroll
+            for (int r = 0; r < 16; r++) sgn = __builtin_amdgcn_alignbit(sgn, __float_as_uint(aA[r] - thr0), 31);
+    #pragma unroll
+            for (int r = 0; r < 16; r++) sgn = __builtin_amdgcn_alignbit(sgn, __float_as_uint(aB[r] - thr0), 31);
+            unsigned m = ~sgn;                                     // bit 31 - e: accumulator register e & 15 of tile e >> 4 (A, B)
+            if (!two) m &= 0xFFFF0000u;
+            if (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
+    #pragma unroll
+                for (int qd = 0; qd < 4; qd++) {
+                    *(float4 *)(mydump + (qd * 64 + lane) * 4) = make_float4(aA[4 * qd], aA[4 * qd + 1], aA[4 * qd + 2], aA[4 * qd + 3]);
+                    *(float4 *)(mydump + 1024 + (qd * 64 + lane) * 4) = make_float4(aB[4 * qd], aB[4 * qd + 1], aB[4 * qd + 2], aB[4 * qd + 3]);
                 }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const unsigned bits = __float_as_uint(vv[u] + 0.0f);                         // -0 -> +0
-                    const unsigned sk = bits ^ ((unsigned)((int)bits >> 31) | 0x80000000u);       // unsigned order == float order
-                    const u64 key = ((u64)sk << 32) | (unsigned)(~(cbase + 8 * e[u]));            // candidate 128 (j + tile) + 8 r + lane8
-                    const bool fits = slot[u] < KM_MCAP;
-                    over |= has[u] && !fits;
-                    mylist[has[u] && fits ? slot[u] : KM_MCAP] = key;                             // row slot 64: scratch
-                }
-            } while (__builtin_amdgcn_ballot_w64(m != 0) != 0);
+                // Four hits per trip, straight-line: an exec-mask region costs a scalar round trip (LABLOG 4.3b), so a lane
+                // without a hit goes through the same motions with an increment of 0 and a write to the spare slot of its
+                // row.  The dump reads and slot atomics of a trip are in flight together.
+                const int cbase = 128 * j + lane8;
+    #pragma unroll 1
+                do {
+                    int e[4], slot[4];
+                    bool has[4];
+                    float vv[4];
+    #pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        has[u] = m != 0;
+                        e[u] = has[u] ? __builtin_clz(m) : 31;
+                        m &= ~(0x80000000u >> e[u]);
+                        vv[u] = mydump[((e[u] >> 2) << 8) + lane * 4 + (e[u] & 3)];
+                        slot[u] = atomicAdd(&qcnt[i], has[u] ? 1 : 0);
+                    }
+    #pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const unsigned bits = __float_as_uint(vv[u] + 0.0f);                         // -0 -> +0
+                        const unsigned sk = bits ^ ((unsigned)((int)bits >> 31) | 0x80000000u);       // unsigned order == float order
+                        const u64 key = ((u64)sk << 32) | (unsigned)(~(cbase + 8 * e[u]));            // candidate 128 (j + tile) + 8 r + lane8
+                        const bool fits = slot[u] < KM_MCAP;
+                        over |= has[u] && !fits;
+                        mylist[has[u] && fits ? slot[u] : KM_MCAP] = key;                             // row slot 64: scratch
+                    }
+                } while (__builtin_amdgcn_ballot_w64(m != 0) != 0);
+            }
         }
+        if (over) *ovf = 1;
+        KMT(4)
+        __syncthreads();
+        KMT(5)
+        if (*ovf == 0) break;
+        if (attempt == 1) {                                    // still too many: exact ties at the k-th best value
+            if (tid == 0) idx_out[((size_t)b * N + q0) * k] = -1;
+            return;
+        }
+        {
+            u64 own[8];
+            int rank[8];
+#pragma unroll
+            for (int o = 0; o < 8; o++) {
+                own[o] = mylist[lane8 + 8 * o];
+                rank[o] = 0;
+            }
+            for (int f = 0; f < KM_MCAP; f++) {
+                const u64 kf = mylist[f];
+#pragma unroll
+                for (int o = 0; o < 8; o++) rank[o] += kf > own[o] ? 1 : 0;
+            }
+#pragma unroll
+            for (int o = 0; o < 8; o++)
+                if (own[o] != 0ull && rank[o] == k - 1) {      // exactly one key per query: keys are distinct
+                    const unsigned sk = (unsigned)(own[o] >> 32);
+                    thr0s[i * 9] = __uint_as_float((sk & 0x80000000u) ? sk ^ 0x80000000u : ~sk);
+                }
+        }
+        __syncthreads();
+        thr0 = thr0s[i * 9];
+        __syncthreads();                                       // everybody has read the lists and the new thresholds
+        for (int e = tid; e < 32 * KM_STRIDE; e += 256) qlist[e] = 0ull;
+        if (tid < 32) qcnt[tid] = 0;
+        if (tid == 0) *ovf = 0;
+        __syncthreads();
     }
-    if (over) *ovf = 1;
-    KMT(4)
-    __syncthreads();
-    KMT(5)
 
     // ------------------------------------------------------------------ rank: count the keys above each key
-    if (*ovf) {                                                // list overflow: hand the block to the fix-up kernel
-        if (tid == 0) idx_out[((size_t)b * N + q0) * k] = -1;
-        return;
-    }
     int Mi = qcnt[i];
 #pragma unroll
     for (int d = 16; d > 0; d >>= 1) Mi = max(Mi, __shfl_xor(Mi, d, 64));
