@@ -25,13 +25,15 @@
 // fragment reads per K chunk are 3a + 2c for an a x c wave tile: 14 for 2 x 4 (16 for 4 x 2).  K chunks of 16 (one MFMA
 // k-step), THREE LDS stages of 40 KB (W 24 KB + x 16 KB); per chunk every wave issues 5 DMA pieces for chunk kc+2,
 // waits for its own pieces of chunk kc (s_waitcnt vmcnt -- the loop has no other vector memory traffic), one barrier,
-// 14 ds_read_b128, 24 MFMAs.  Measured, not kept (LABLOG R2.3 has the numbers): reading chunk kc+1's x fragments during
-// chunk kc's MFMAs (spills: 112 us against 97); a four-wave 128 x 256 workgroup with two LDS stages, two per CU (101 us); the
-// same with the W fragments straight from L2 into registers, 8 LDS reads instead of 14 (110 us); all 14 reads ahead of the
-// first MFMA (105 us); the first product's fragments read across the chunk barrier (105 us).  What the variants have in
-// common: the epilogue's 134 MB of stores are hidden (97 us without them), the loop without any DMA or barrier still
-// takes 82 us, and a bare loop of 14 ds_read_b128 + 24 MFMAs sustains 1.85 PFLOP/s on this chip (tools/probe_mfma_lds.hip),
-// which would be 56 us.
+// 14 ds_read_b128, 24 MFMAs with the five DMA instructions spread between them.  tools/probe_conv_f16.hip (s_memtime
+// inside the loop): 2.3 k cycles per chunk and wave against 1.54 k of matrix-pipe time for the SIMD's two waves; the
+// DMA data is never waited for (latency hidden), but ISSUING five 1 KB DMA instructions in one block behind the barrier cost
+// every wave ~600 cycles (the CU's vector-memory path takes them at 16 cycles apiece and all eight waves queue at once):
+// spread out, 99 -> 96 us.  The two epilogues (one per tile round; 134 MB) are exposed, ~17 us each.
+// Measured, not kept (LABLOG R2.3): next-chunk x fragments read during this chunk's MFMAs (spills: 112 us); four-wave
+// 128 x 256 workgroups, two per CU, which do hide the epilogue (99 us); those with W fragments straight from L2 (110 us);
+// all 14 reads ahead of the first MFMA (105 us); first-product fragments read across the barrier (105 us); LDS bank
+// padding of the regions (worth 25 % in the bare read + MFMA loop, nothing here); non-temporal epilogue stores (-1 us).
 #include "common.h"
 #include "split_bf16.h"          // f32x4 / f32x16 typedefs
 
@@ -187,12 +189,13 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
             dst[i] = CF_WBYTES + reg * 4096 + quarter * 1024;
         }
     }
+    auto issue_one = [&](int stage, int i) {
+        __builtin_amdgcn_global_load_lds((cf_gbl_ptr_t)src[i], (cf_lds_ptr_t)(lds + stage * CF_STAGE + dst[i]), 16, 0, 0);
+        src[i] += stride[i];
+    };
     auto issue = [&](int stage) {
 #pragma unroll
-        for (int i = 0; i < 5; i++) {
-            __builtin_amdgcn_global_load_lds((cf_gbl_ptr_t)src[i], (cf_lds_ptr_t)(lds + stage * CF_STAGE + dst[i]), 16, 0, 0);
-            src[i] += stride[i];
-        }
+        for (int i = 0; i < 5; i++) issue_one(stage, i);
     };
 
     f32x16 acc[2][4];
@@ -210,13 +213,23 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
     issue(0);
     if (nk > 1) issue(1);
     int stage = 0;
+#ifdef CF_TIMING      // tools/probe_conv_f16.hip: where a wave's chunk time goes (s_memtime sums, written over y)
+    long long tq[5] = {0, 0, 0, 0, 0}, tp = __builtin_amdgcn_s_memtime();
+#define CFT(n) { const long long now_ = __builtin_amdgcn_s_memtime(); tq[n] += now_ - tp; tp = now_; }
+#else
+#define CFT(n)
+#endif
     for (int kc = 0; kc < nk; kc++) {
+        CFT(4)
         // this wave's pieces of chunk kc have landed (chunk kc+1's five may still be in flight) ...
         if (kc + 1 < nk) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CFT(0)
         __builtin_amdgcn_s_barrier();            // ... and so have everybody else's; stage (kc+2)%3 was last read in chunk kc-1
+        CFT(1)
         const int nst = stage == 0 ? 2 : stage - 1;                                   // (kc + 2) % 3
-        if (kc + 2 < nk) issue(nst);
+        const bool more = kc + 2 < nk;
+        CFT(2)
         const unsigned char *base = lds + stage * CF_STAGE;
         f16x8 A[2][3], Bf[4][2];
 #pragma unroll
@@ -228,17 +241,36 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
 #pragma unroll
             for (int a = 0; a < 2; a++) A[a][p] = *(const f16x8 *)(base + a_off + a * 512 + p * 8192);
         // three products, smallest first: M h, Hs m', H h
+        // The five DMA instructions of chunk kc+2 are spread over the chunk's 24 MFMAs, one behind every fifth: the CU's
+        // vector-memory path takes 16 cycles per 1 KB instruction and all eight waves share it -- issued as one block behind
+        // the barrier (40 instructions at once) they cost each wave ~600 cycles of issue stall (tools/probe_conv_f16.hip)
+        // during which it feeds the matrix pipe nothing.
 #pragma unroll
-        for (int prod = 0; prod < 3; prod++) {
+        for (int n = 0; n < 24; n++) {
+            const int prod = n >> 3, a = (n >> 2) & 1, c = n & 3;
             const int pa = prod == 0 ? 2 : (prod == 1 ? 1 : 0), pb = prod == 1 ? 1 : 0;
-#pragma unroll
-            for (int a = 0; a < 2; a++)
-#pragma unroll
-                for (int c = 0; c < 4; c++)
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][pa], Bf[c][pb], acc[a][c], 0, 0, 0);
+            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][pa], Bf[c][pb], acc[a][c], 0, 0, 0);
+            if (n % 5 == 3) {                    // behind MFMA 3, 8, 13, 18, 23
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) issue_one(nst, n / 5);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         stage = stage == 2 ? 0 : stage + 1;
+        CFT(3)
     }
+#ifdef CF_TIMING
+    if (lane == 0) {
+        long long *o = (long long *)y + ((size_t)blockIdx.x * 8 + wave) * 8;
+        for (int n = 0; n < 5; n++) o[n] = tq[n];
+    }
+    {
+        float keep = 0.f;                        // keep the MFMAs alive
+        for (int a = 0; a < 2; a++) for (int c = 0; c < 4; c++) for (int r = 0; r < 16; r++) keep += acc[a][c][r];
+        if (keep == 12345.678f) y[0] = keep;
+    }
+    return;
+#endif
 
     // ---- epilogue: D[co = 32a + (r&3) + 8(r>>2) + 4(lane>>5)][n = 32c + (lane&31)]
     const float inv = *winv * *xinv;             // 2^-S 2^-T: exact
