@@ -270,6 +270,13 @@ int l3d_attention_forward(const float *q, const float *k, const float *v, int B,
 int l3d_attention_forward_strided(const float *q, const float *k, const float *v, int B, int H, int D, int N,
                                   int M, long q_bstride, long k_bstride, long v_bstride, float scale, float *ctx,
                                   l3d_stream_t stream);
+/* The same with both GEMMs as f16x2 on the fp16 matrix cores (three fp16 MFMA products per fp32 product instead of bf16x3's
+ * six, fp32-level accuracy; attention_f16.hip).  fp16's range is handled inside: one extra pass reads max|q|, max|k|, max|v|
+ * into `workspace` (>= 16 bytes of device memory, contents irrelevant) and the operands are scaled by powers of two from
+ * them.  Same shapes and strides as l3d_attention_forward_strided. */
+int l3d_attention_forward_f16(const float *q, const float *k, const float *v, int B, int H, int D, int N, int M,
+                              long q_bstride, long k_bstride, long v_bstride, float scale, void *workspace, float *ctx,
+                              l3d_stream_t stream);
 
 /* LayerNorm of DCP's pointer network == utils/transformer.py:109-119 (unbiased std, eps added to std):
  *   y[r][:] = a * (x[r][:] - mean_r) / (std_r + eps) + b,   x, y [rows][C] fp32, C % 4 == 0, C <= 2048. */

@@ -1,0 +1,324 @@
+// attention_f16.hip -- attention.hip's flash-style kernel with both GEMMs as "f16x2" on the fp16 matrix cores: three fp16
+// MFMA products per fp32 product instead of bf16x3's six, fp32-level accuracy (utils/transformer.py:17-25,
+// MultiHeadedAttention :120-147).  Layouts, tiling and the online softmax are attention.hip's; what changes is the
+// operand arithmetic (see edgeconv_f16.hip / conv_f16.hip for the derivation and the error measurements):
+//   "weight-like" operands -- K in S^T = K^T Q and V in O^T = V P^T (the MFMA A operands):
+//        W = w 2^S with max|W| in [4,8):   H = f16(W),  Hs = f16(H 2^-12),  M = f16(W - H)          three planes
+//   "activation-like" operands -- Q and the probabilities P (the B operands):
+//        X = x 2^T:                        h = f16(X),  m' = f16((X - h) 2^12)                       two planes
+//   acc += M h + Hs m' + H h  =  2^(S+T) w x   up to 2^-22 relative per operand.
+// fp16 has 30 binades, so the scales must be right: S and T come from the tensors' own maxima (one extra read pass,
+// at_absmax3_kernel; q, k, v are bounded by it, so no range flag is needed), probabilities are <= 1 and take T = 12.
+// The scales leave the softmax exactly as it was: 2^-(S_k + T_q) is folded into the log2-domain scale, 2^-(S_v + 12) into
+// the final normalisation.
+// Per 16-channel QK^T chunk a wave now reads 12 + 2 fragments and issues 12 MFMAs (bf16x3: 12 + 3 and 24); per PV k-step
+// 3 ND reads and 3 ND MFMAs (3 ND and 6 ND); the in-lane split of the probabilities drops from three planes to two.
+#include "common.h"
+#include "split_bf16.h"          // f32x4 / f32x16 typedefs
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define AF_TQ 128
+#define AF_TK 128
+#define AF_REG (128 * 16)                 // one (plane, kg) region: 128 rows x 8 fp16
+#define AF_BUF (10 * AF_REG)              // K (or V) 6 regions + Q 4 regions
+#define AF_LDS (2 * AF_BUF)
+#define AF_NEG (-1.0e30f)
+
+// two fp32 -> packed fp16 (H, Hs, M) of w c, c = 2^S
+__device__ __forceinline__ void af_split_w(float a0, float a1, float c, uint32_t &H, uint32_t &Hs, uint32_t &M)
+{
+    float r0, r1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(H) : "v"(a0), "v"(c));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(H) : "v"(a1), "v"(c));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a0), "v"(c), "v"(H));                     // w c - H: exact
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(a1), "v"(c), "v"(H));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, 0" : "=v"(M) : "v"(r0));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, 0" : "+v"(M) : "v"(r1));
+    asm("v_pk_mul_f16 %0, %1, %2" : "=v"(Hs) : "v"(H), "s"(0x0C000C00u));                                            // H 2^-12 (packed fp16 2^-12)
+}
+// two fp32 -> packed fp16 (h, m') of x c, c = 2^T
+__device__ __forceinline__ void af_split_x(float a0, float a1, float c, uint32_t &h, uint32_t &m)
+{
+    float r0, r1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a0), "v"(c));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(a1), "v"(c));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a0), "v"(c), "v"(h));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(a1), "v"(c), "v"(h));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(m) : "v"(r0), "s"(4096.0f));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(m) : "v"(r1), "s"(4096.0f));
+}
+
+// max|x| of q, k, v (blockIdx.y picks the tensor) as float bits, into out[0..2] (zeroed by the caller)
+__global__ __launch_bounds__(256) void at_absmax3_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                         const float *__restrict__ v, long q_bs, long k_bs, long v_bs,
+                                                         long q_span, long kv_span, int B, unsigned *__restrict__ out)
+{
+    const int which = blockIdx.y;
+    const float *p = which == 0 ? q : which == 1 ? k : v;
+    const long bs = which == 0 ? q_bs : which == 1 ? k_bs : v_bs, span = which == 0 ? q_span : kv_span;
+    float m = 0.f;
+    const bool vec = (span & 3) == 0 && (bs & 3) == 0 && (((size_t)p) & 15) == 0;
+    for (int b = 0; b < B; b++) {
+        const float *pb = p + (size_t)b * bs;
+        if (vec) {
+            for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < span / 4; i += (long)gridDim.x * 256) {
+                const f32x4 x = *(const f32x4 *)(pb + 4 * i);
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(x[0]), fabsf(x[1]))), fmaxf(fabsf(x[2]), fabsf(x[3])));
+            }
+        } else {
+            for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < span; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(pb[i]));
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out + which, __float_as_uint(m));
+}
+
+// 2^S with max 2^S in [2^(hi-1), 2^hi)
+__device__ __forceinline__ int af_exponent(float mx, int hi)
+{
+    int e = 0;
+    if (mx > 0.f && mx < 3.0e38f) (void)frexpf(mx, &e);                 // mx = f 2^e, f in [0.5, 1)
+    return hi - e;
+}
+
+template <int ND /* D / 32 */>
+__global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                               const float *__restrict__ v, int H, int N, int M,
+                                                               float scale, float *__restrict__ ctx, long q_bs, long k_bs,
+                                                               long v_bs, const unsigned *__restrict__ amax)
+{
+    constexpr int D = ND * 32;
+    constexpr int NCH = D / 16;                        // QK^T chunks of 16 channels
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int i0 = blockIdx.x * AF_TQ, h = blockIdx.y, b = blockIdx.z;
+    const float *qb = q + (size_t)b * q_bs + (size_t)h * D * N;
+    const float *kb = k + (size_t)b * k_bs + (size_t)h * D * M;
+    const float *vb = v + (size_t)b * v_bs + (size_t)h * D * M;
+
+    // operand scales from the tensors' maxima: q 2^Tq peaks in [2^11, 2^12), k 2^Sk and v 2^Sv in [4, 8)
+    const int Tq = af_exponent(__uint_as_float(amax[0]), 12), Sk = af_exponent(__uint_as_float(amax[1]), 3),
+              Sv = af_exponent(__uint_as_float(amax[2]), 3);
+    const float cq = ldexpf(1.f, Tq), ck = ldexpf(1.f, Sk), cv = ldexpf(1.f, Sv);
+
+    const int srow = t & 127, skg = t >> 7;
+    const int qn = min(i0 + srow, N - 1);
+    const int st_lds = skg * AF_REG + srow * 16;      // + p * 2 * AF_REG (+ 6 * AF_REG for Q)
+
+    const float sl2 = ldexpf(scale * 1.44269504088896340736f, -(Sk + Tq));
+    float m_run = AF_NEG, l_run = 0.f;                 // this lane's query column: i0 + wave*32 + (lane&31)
+    f32x16 o[ND];
+#pragma unroll
+    for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[dt][r] = 0.f;
+
+    const int frag_kg = (lane >> 5) * AF_REG;
+    const int a_off = frag_kg + (lane & 31) * 16;                              // + tile*512 + p*2*AF_REG
+    const int b_off = 6 * AF_REG + frag_kg + (wave * 32 + (lane & 31)) * 16;   // + p*2*AF_REG
+
+    for (int j0 = 0; j0 < M; j0 += AF_TK) {
+        const int kn = min(j0 + srow, M - 1);
+        // ------------------------------------------------------------ S^T = K^T Q over D channels
+        f32x16 s[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) s[a][r] = 0.f;
+        float kv[8], qv[8];
+#define AF_LOAD_QK(KC)                                                                               \
+        do {                                                                                         \
+            _Pragma("unroll") for (int e = 0; e < 8; e++) {                                          \
+                kv[e] = kb[(size_t)((KC) * 16 + skg * 8 + e) * M + kn];                              \
+                qv[e] = qb[(size_t)((KC) * 16 + skg * 8 + e) * N + qn];                              \
+            }                                                                                        \
+        } while (0)
+#define AF_STORE_QK(BUF)                                                                             \
+        do {                                                                                         \
+            unsigned char *base_ = lds + (BUF) * AF_BUF;                                             \
+            uint4 H_, Hs_, M_, h_, m_;                                                               \
+            af_split_w(kv[0], kv[1], ck, H_.x, Hs_.x, M_.x);                                         \
+            af_split_w(kv[2], kv[3], ck, H_.y, Hs_.y, M_.y);                                         \
+            af_split_w(kv[4], kv[5], ck, H_.z, Hs_.z, M_.z);                                         \
+            af_split_w(kv[6], kv[7], ck, H_.w, Hs_.w, M_.w);                                         \
+            *(uint4 *)(base_ + st_lds) = H_;                                                         \
+            *(uint4 *)(base_ + st_lds + 2 * AF_REG) = Hs_;                                           \
+            *(uint4 *)(base_ + st_lds + 4 * AF_REG) = M_;                                            \
+            af_split_x(qv[0], qv[1], cq, h_.x, m_.x);                                                \
+            af_split_x(qv[2], qv[3], cq, h_.y, m_.y);                                                \
+            af_split_x(qv[4], qv[5], cq, h_.z, m_.z);                                                \
+            af_split_x(qv[6], qv[7], cq, h_.w, m_.w);                                                \
+            *(uint4 *)(base_ + 6 * AF_REG + st_lds) = h_;                                            \
+            *(uint4 *)(base_ + 6 * AF_REG + st_lds + 2 * AF_REG) = m_;                               \
+        } while (0)
+
+        __syncthreads();                               // the previous tile's PV reads of both buffers are done
+        AF_LOAD_QK(0);
+        AF_STORE_QK(0);
+        __syncthreads();
+#pragma unroll 1
+        for (int kc = 0; kc < NCH; kc++) {
+            const int buf = kc & 1;
+            const bool more = kc + 1 < NCH;
+            if (more) AF_LOAD_QK(kc + 1);
+            const unsigned char *base = lds + buf * AF_BUF;
+            f16x8 Bf[2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) Bf[p] = *(const f16x8 *)(base + b_off + p * 2 * AF_REG);
+#pragma unroll
+            for (int prod = 0; prod < 3; prod++) {     // M h, Hs m', H h: smallest first
+                const int pa = prod == 0 ? 2 : (prod == 1 ? 1 : 0), pb = prod == 1 ? 1 : 0;
+                f16x8 A[4];
+#pragma unroll
+                for (int a = 0; a < 4; a++) A[a] = *(const f16x8 *)(base + a_off + a * 512 + pa * 2 * AF_REG);
+#pragma unroll
+                for (int a = 0; a < 4; a++) s[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a], Bf[pb], s[a], 0, 0, 0);
+            }
+            if (more) AF_STORE_QK(buf ^ 1);
+            __syncthreads();
+        }
+#undef AF_LOAD_QK
+#undef AF_STORE_QK
+
+        // ------------------------------------------------------------ online softmax (log2 units)
+        // this lane's keys: j0 + 32a + (r&3) + 8(r>>2) + 4(lane>>5)
+        float smax = AF_NEG;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int j = j0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                s[a][r] = j < M ? s[a][r] * sl2 : AF_NEG;
+                smax = fmaxf(smax, s[a][r]);
+            }
+        smax = fmaxf(smax, __shfl_xor(smax, 32, 64));   // the partner lane holds the column's other 64 keys
+        const float m_new = fmaxf(m_run, smax);
+        const float alpha = exp2f(m_run - m_new);
+        float lsum = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float p = s[a][r] > 0.5f * AF_NEG ? exp2f(s[a][r] - m_new) : 0.f;
+                s[a][r] = p;
+                lsum += p;
+            }
+        m_run = m_new;
+        l_run = l_run * alpha + lsum;
+#pragma unroll
+        for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[dt][r] *= alpha;
+
+        // ------------------------------------------------------------ O^T += V P^T over the 128 keys
+        // k-step ks = 2a + u: keys j0 + 16 ks + {4 kg + e, 8 + 4 kg + e}; V row d = srow (only rows < D staged)
+        f32x4 va, vb2;
+#define AF_LOAD_V(KS)                                                                                \
+        do {                                                                                         \
+            if (srow < D) {                                                                          \
+                const float *vp_ = vb + (size_t)srow * M;                                            \
+                const int ja_ = j0 + 16 * (KS) + 4 * skg, jb_ = ja_ + 8;                             \
+                if (ja_ + 3 < M && jb_ + 3 < M && (M & 3) == 0) {                                    \
+                    va = *(const f32x4 *)(vp_ + ja_);                                                \
+                    vb2 = *(const f32x4 *)(vp_ + jb_);                                               \
+                } else {                                                                             \
+                    _Pragma("unroll") for (int e = 0; e < 4; e++) {                                  \
+                        va[e] = ja_ + e < M ? vp_[ja_ + e] : 0.f;                                    \
+                        vb2[e] = jb_ + e < M ? vp_[jb_ + e] : 0.f;                                   \
+                    }                                                                                \
+                }                                                                                    \
+            }                                                                                        \
+        } while (0)
+#define AF_STORE_V(BUF)                                                                              \
+        do {                                                                                         \
+            if (srow < D) {                                                                          \
+                unsigned char *base_ = lds + (BUF) * AF_BUF;                                         \
+                uint4 H_, Hs_, M_;                                                                   \
+                af_split_w(va[0], va[1], cv, H_.x, Hs_.x, M_.x);                                     \
+                af_split_w(va[2], va[3], cv, H_.y, Hs_.y, M_.y);                                     \
+                af_split_w(vb2[0], vb2[1], cv, H_.z, Hs_.z, M_.z);                                   \
+                af_split_w(vb2[2], vb2[3], cv, H_.w, Hs_.w, M_.w);                                   \
+                *(uint4 *)(base_ + st_lds) = H_;                                                     \
+                *(uint4 *)(base_ + st_lds + 2 * AF_REG) = Hs_;                                       \
+                *(uint4 *)(base_ + st_lds + 4 * AF_REG) = M_;                                        \
+            }                                                                                        \
+        } while (0)
+
+        AF_LOAD_V(0);
+        AF_STORE_V(0);                                 // buffer 0: its last QK^T read was before the loop's final barrier
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {
+            const int buf = ks & 1;
+            if (ks + 1 < 8) AF_LOAD_V(ks + 1);
+            // probabilities of this k-step (registers 8u..8u+7 of key tile a) x 2^12 -> two fp16 planes
+            u32x4 ph, pm;
+            {
+                const int a = ks >> 1, u = ks & 1;
+                uint32_t h0, h1, h2, h3, m0, m1, m2, m3;
+                af_split_x(s[a][8 * u + 0], s[a][8 * u + 1], 4096.0f, h0, m0);
+                af_split_x(s[a][8 * u + 2], s[a][8 * u + 3], 4096.0f, h1, m1);
+                af_split_x(s[a][8 * u + 4], s[a][8 * u + 5], 4096.0f, h2, m2);
+                af_split_x(s[a][8 * u + 6], s[a][8 * u + 7], 4096.0f, h3, m3);
+                ph = (u32x4){h0, h1, h2, h3};
+                pm = (u32x4){m0, m1, m2, m3};
+            }
+            // the planes were written by VALU instructions inside inline asm, which the compiler's hazard recogniser cannot
+            // see: keep the first MFMA that reads them at least 4 wait states away (VALU write -> MFMA source read)
+            asm volatile("s_nop 4" : "+v"(ph), "+v"(pm));
+            const f16x8 P[2] = {__builtin_bit_cast(f16x8, ph), __builtin_bit_cast(f16x8, pm)};
+            const unsigned char *base = lds + buf * AF_BUF;
+#pragma unroll
+            for (int prod = 0; prod < 3; prod++) {
+                const int pa = prod == 0 ? 2 : (prod == 1 ? 1 : 0), pb = prod == 1 ? 1 : 0;
+                f16x8 A[ND];
+#pragma unroll
+                for (int dt = 0; dt < ND; dt++) A[dt] = *(const f16x8 *)(base + a_off + dt * 512 + pa * 2 * AF_REG);
+#pragma unroll
+                for (int dt = 0; dt < ND; dt++) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[dt], P[pb], o[dt], 0, 0, 0);
+            }
+            if (ks + 1 < 8) AF_STORE_V(buf ^ 1);
+            __syncthreads();
+        }
+#undef AF_LOAD_V
+#undef AF_STORE_V
+    }
+
+    // ---- normalise (and undo 2^(Sv + 12)) and store: O^T[d = 32 dt + (r&3) + 8(r>>2) + 4(lane>>5)][i = i0 + 32 wave + (lane&31)]
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = ldexpf(1.f / l_tot, -(Sv + 12));
+    const int i = i0 + wave * 32 + (lane & 31);
+    if (i < N) {
+        float *cb = ctx + ((size_t)b * H + h) * D * N + i;
+#pragma unroll
+        for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int d = 32 * dt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                cb[(size_t)d * N] = o[dt][r] * inv;
+            }
+    }
+}
+
+// workspace: 16 bytes of device memory (the three maxima); everything else as l3d_attention_forward_strided
+extern "C" int l3d_attention_forward_f16(const float *q, const float *k, const float *v, int B, int H, int D, int N, int M,
+                                         long q_bstride, long k_bstride, long v_bstride, float scale, void *workspace,
+                                         float *ctx, l3d_stream_t stream)
+{
+    L3D_REQUIRE(q && k && v && ctx && workspace && B > 0 && H > 0 && D > 0 && N > 0 && M > 0);
+    if ((D != 32 && D != 64 && D != 128) || B > 65535 || H > 65535 || (((size_t)v) & 15) || (v_bstride & 3))
+        return L3D_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned *amax = (unsigned *)workspace;
+    if (hipMemsetAsync(amax, 0, 16, st) != hipSuccess) return L3D_ERR_LAUNCH;
+    hipLaunchKernelGGL(at_absmax3_kernel, dim3(128, 3), dim3(256), 0, st, q, k, v, q_bstride, k_bstride, v_bstride,
+                       (long)H * D * N, (long)H * D * M, B, amax);
+    dim3 grid(l3d_divup(N, AF_TQ), H, B), block(256);
+    if (D == 32)      hipLaunchKernelGGL(attention_f16_kernel<1>, grid, block, AF_LDS, st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax);
+    else if (D == 64) hipLaunchKernelGGL(attention_f16_kernel<2>, grid, block, AF_LDS, st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax);
+    else              hipLaunchKernelGGL(attention_f16_kernel<4>, grid, block, AF_LDS, st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax);
+    return l3d_check_launch();
+}

@@ -16,6 +16,18 @@ import torch.nn.functional as F
 
 FLASH_ATTENTION = True      # l3d_attention_forward for d_k in {32, 64, 128}; False: torch matmul + softmax + matmul
 
+_ATT_WS = {}
+
+
+def _attention_workspace(device):
+    """16 bytes per device for l3d_attention_forward_f16's operand maxima (written and read on the launch stream)."""
+    key = str(device)
+    ws = _ATT_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(4, dtype=torch.int32, device=device)
+        _ATT_WS[key] = ws
+    return ws
+
 
 def _fast_linear_ok(lin, x, n_points):
     """bf16x3 conv kernel applicable: inference, GPU, Cout % 256 == 0, points % 128 == 0, Cin % 16 == 0"""
@@ -149,10 +161,17 @@ class MultiHeadedAttention(nn.Module):
             self.attn = None                                   # the [B,h,N,M] map is never formed
             if FLASH_ATTENTION and self.d_k in (32, 64, 128):
                 from .._lib import check, lib, ptr, stream_ptr
+                from ..models import _fused
                 ctx = torch.empty((nb, C_, n_q), dtype=torch.float32, device=q.device)
-                check(lib().l3d_attention_forward_strided(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
+                if _fused.gemm_arith() == "f16x2":             # both GEMMs as f16x2; operand scales from the tensors' maxima
+                    check(lib().l3d_attention_forward_f16(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
                                                           q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),
-                                                          ptr(ctx), stream_ptr()), "l3d_attention_forward_strided")
+                                                          ptr(_attention_workspace(q.device)), ptr(ctx), stream_ptr()),
+                          "l3d_attention_forward_f16")
+                else:
+                    check(lib().l3d_attention_forward_strided(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
+                                                              q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),
+                                                              ptr(ctx), stream_ptr()), "l3d_attention_forward_strided")
             else:
                 qh, kh, vh = [z.reshape(nb, self.h, self.d_k, z.size(2)) for z in (q, k, v)]
                 p = F.softmax(torch.matmul(qh.transpose(-2, -1), kh) / math.sqrt(self.d_k), dim=-1)   # [B,h,N,M]

@@ -933,6 +933,32 @@ def test_flash_attention_vs_fp64():
         check(lib().l3d_attention_forward(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, float(1 / np.sqrt(D)), ptr(out),
                                           stream_ptr()), "l3d_attention_forward")
         np.testing.assert_allclose(out.cpu().numpy().reshape(B, H, D, N), want, rtol=1e-5, atol=2e-6)
+        # the f16x2 kernel: same bar, and its error against fp64 within 2x (max) / 1.5x (rms) of the bf16x3 kernel's own
+        ws = torch.zeros(4, dtype=torch.int32, device=qd.device)
+        out16 = torch.empty_like(qd)
+        check(lib().l3d_attention_forward_f16(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, H * D * N, H * D * M, H * D * M,
+                                              float(1 / np.sqrt(D)), ptr(ws), ptr(out16), stream_ptr()), "l3d_attention_forward_f16")
+        got16 = out16.cpu().numpy().reshape(B, H, D, N)
+        np.testing.assert_allclose(got16, want, rtol=1e-5, atol=2e-6)
+        e3, e16 = out.cpu().numpy().reshape(B, H, D, N) - want, got16 - want
+        assert np.abs(e16).max() <= 2.0 * np.abs(e3).max() + 1e-9 and np.sqrt((e16 ** 2).mean()) <= 1.5 * np.sqrt((e3 ** 2).mean()) + 1e-10
+    # operands far from unit scale: the per-tensor power-of-two scaling must keep fp32-level accuracy (and not overflow fp16)
+    for sq, sk, sv in ((1e-4, 3e2, 1e3), (5e3, 1e-3, 1e-5)):
+        B, H, D, N, M = 1, 2, 64, 256, 384
+        q = (rng.standard_normal((B, H, D, N)) * sq).astype(np.float32)
+        k = (rng.standard_normal((B, H, D, M)) * sk).astype(np.float32)
+        v = (rng.standard_normal((B, H, D, M)) * sv).astype(np.float32)
+        sc = 1.0 / (np.sqrt(D) * sq * sk)
+        s = np.einsum("bhdn,bhdm->bhnm", q.astype(np.float64), k.astype(np.float64)) * sc
+        s = np.exp(s - s.max(axis=-1, keepdims=True))
+        s /= s.sum(axis=-1, keepdims=True)
+        want = np.einsum("bhdm,bhnm->bhdn", v.astype(np.float64), s)
+        qd, kd, vd = dev(q.reshape(B, H * D, N)), dev(k.reshape(B, H * D, M)), dev(v.reshape(B, H * D, M))
+        ws = torch.zeros(4, dtype=torch.int32, device=qd.device)
+        out16 = torch.empty_like(qd)
+        check(lib().l3d_attention_forward_f16(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, H * D * N, H * D * M, H * D * M,
+                                              float(sc), ptr(ws), ptr(out16), stream_ptr()), "l3d_attention_forward_f16")
+        np.testing.assert_allclose(out16.cpu().numpy().reshape(B, H, D, N), want, rtol=2e-5, atol=2e-6 * sv)
 
 
 def test_add_transposed_residual():
