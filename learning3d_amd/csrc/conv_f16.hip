@@ -134,6 +134,73 @@ __global__ __launch_bounds__(256) void cf_split_x_kernel(const float *__restrict
     if (!(big <= 60000.f) && range_flag) *(volatile int *)range_flag = 1;         // inf / NaN inputs land here too
 }
 
+// Channel-last activations x [R][C] through an LDS transpose: a workgroup takes 64 rows x 32 octets (256 channels); it READS
+// with consecutive threads on consecutive octets of one row (1 KB coalesced per 32 threads) and WRITES with consecutive
+// threads on consecutive rows of one octet (the planes' own order: 1 KB per 64 threads).  The one-cell-per-thread kernel
+// above reads 32 bytes per thread at a stride of a whole row: 150 us for conv5's 67 MB input; this one moves it at HBM speed.
+#define CFS_ROWS 64
+#define CFS_OCT 32
+#define CFS_STRIDE (CFS_ROWS + 1)            // cells per octet line in LDS (+1: bank spread)
+__global__ __launch_bounds__(256) void cf_split_x_cl_kernel(const float *__restrict__ src, long R, int C, const unsigned *__restrict__ amax,
+                                                            uint4 *__restrict__ ph, uint4 *__restrict__ pm, float *__restrict__ inv,
+                                                            int *__restrict__ range_flag)
+{
+    __shared__ uint4 lh[CFS_OCT * CFS_STRIDE], lm[CFS_OCT * CFS_STRIDE];
+    const int T = cf_act_exp(__uint_as_float(*amax));
+    const float up = ldexpf(1.0f, T);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *inv = ldexpf(1.0f, -T);
+    const int t = threadIdx.x;
+    const long row0 = (long)blockIdx.x * CFS_ROWS;
+    const int o0 = blockIdx.y * CFS_OCT;
+    float big = 0.f;
+    {
+        const int oc = t & 31, o = o0 + oc;
+#pragma unroll
+        for (int pass = 0; pass < CFS_ROWS / 8; pass++) {
+            const int r = pass * 8 + (t >> 5);
+            const long row = row0 + r;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = 0.f;
+            if (row < R && o * 8 < C) {
+                const float *p = src + (size_t)row * C + o * 8;
+                if (o * 8 + 8 <= C && (C & 3) == 0) {
+                    const f32x4 a = *(const f32x4 *)p, b = *(const f32x4 *)(p + 4);
+                    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) if (o * 8 + e < C) v[e] = p[e];
+                }
+            }
+            _Float16 h[8], m[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float x = v[e] * up;
+                big = fmaxf(big, fabsf(x));
+                h[e] = (_Float16)x;
+                m[e] = (_Float16)((x - (float)h[e]) * 4096.0f);
+            }
+            lh[oc * CFS_STRIDE + r] = *(const uint4 *)h;
+            lm[oc * CFS_STRIDE + r] = *(const uint4 *)m;
+        }
+    }
+    __syncthreads();
+    {
+        const int r = t & 63;
+        const long row = row0 + r;
+        const int noct = (C + 7) / 8;
+#pragma unroll
+        for (int pass = 0; pass < CFS_OCT / 4; pass++) {
+            const int oc = pass * 4 + (t >> 6), o = o0 + oc;
+            if (row < R && o < noct) {
+                ph[(size_t)o * R + row] = lh[oc * CFS_STRIDE + r];
+                pm[(size_t)o * R + row] = lm[oc * CFS_STRIDE + r];
+            }
+        }
+    }
+    if (!(big <= 60000.f) && range_flag) *(volatile int *)range_flag = 1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // The GEMM.  Requires Cout % 256 == 0, N % 256 == 0, Cin % 16 == 0 (dispatcher checks).
 // ---------------------------------------------------------------------------------------------
@@ -348,8 +415,8 @@ extern "C" int l3d_split_f16_rows(const float *x, long rows, int C, int channel_
         hipLaunchKernelGGL(cf_split_x_kernel<true>, dim3((unsigned)l3d_divup(cells, 256)), dim3(256), 0, st, x, rows, C,
                            Npts, (const unsigned *)amax, (uint4 *)d, (uint4 *)(d + pb), inv, range_flag);
     else
-        hipLaunchKernelGGL(cf_split_x_kernel<false>, dim3((unsigned)l3d_divup(cells, 256)), dim3(256), 0, st, x, rows, C,
-                           1, (const unsigned *)amax, (uint4 *)d, (uint4 *)(d + pb), inv, range_flag);
+        hipLaunchKernelGGL(cf_split_x_cl_kernel, dim3((unsigned)l3d_divup(rows, CFS_ROWS), (unsigned)l3d_divup((C + 7) / 8, CFS_OCT)), dim3(256), 0,
+                           st, x, rows, C, (const unsigned *)amax, (uint4 *)d, (uint4 *)(d + pb), inv, range_flag);
     return l3d_check_launch();
 }
 

@@ -204,7 +204,12 @@ def pointwise_conv(x, w, scale=None, shift=None, relu=False, channel_last=False,
     """y[b,co,n] = act(scale[co] * sum_ci w[co,ci] x[b,ci,n] + shift[(b,)co]);  x [B,Cin,N] (or
     [B,N,Cin] when channel_last) -> [B,Cout,N].   == Conv1d(k=1) (+BN eval) (+ReLU).
     shift may be [Cout] or per-cloud [B,Cout].  w_split: cached split_rows(w) (else split per call,
-    a ~3 us kernel); split=False forces the fp32-MFMA kernel."""
+    a ~3 us kernel); split=False forces the fp32-MFMA kernel.
+    Kernel by shape: bf16x3 (conv_split.hip) when Cout % 256 == 0, N % 128 == 0, Cin % 16 == 0; else the fp32 MFMA (mlp.hip).
+    The f16x2 kernel (conv_f16.hip) is NOT routed to from here: it wants its input as fp16 planes, and splitting an fp32
+    tensor first (two passes over x: maximum, then split; ~90 us for 67 MB) costs more than the kernel saves for every
+    shape but conv5's -- measured on DCP's transformer: 8.15 -> 9.64 ms.  Producers that can emit planes themselves (the
+    EdgeConv kernel) call pointwise_conv_f16 directly."""
     require_gpu(x)
     x = f32c(x)
     w = f32c(w)
