@@ -280,7 +280,9 @@ def main():
         if sync_loss:
             loss = parallel.allgather_chamfer_loss(part)   # blocking RCCL all_gather
         else:
-            loss = loss_pipe.submit(part)                  # async all_gather; returns the previous step's loss
+            # async all_gather; returns the previous step's loss.  Under graph replay `part` is the graph's static output
+            # buffer, which the next replay rewrites while this gather may still be in flight: hand the collective a copy
+            loss = loss_pipe.submit(part.clone() if graph is not None and not eager else part)
         return feat, loss
 
     # clock / cache pre-conditioning before the W official warm-up steps: the first ~50 ms after an idle
