@@ -430,7 +430,7 @@ def main():
                                    "weights) + ChamferDistanceLoss, B=32 clouds per GPU, N=1024, inputs resident in HBM",
                        "global_batch": world * B_PER_GPU, "num_points": NPTS, "k": KNN, "emb_dims": EMB,
                        "untimed_precondition_steps": PRECONDITION_STEPS,
-                       "launch": "hipGraph replay of the step's 6 kernels" if graph is not None else "eager launches",
+                       "launch": "hipGraph replay of the step's 5 kernels" if graph is not None else "eager launches",
                        "parallelism": f"batch-sharded x{world}, all_gather of loss partials only"
                                       + ("" if args.sync_loss or world == 1 else " (asynchronous, consumed one step later)")},
             # multi-GPU record: ranks that really joined the process group, its backend ("nccl" = RCCL on ROCm),
@@ -445,7 +445,7 @@ def main():
             # dominant kernel by time: the fused 4-layer EdgeConv stack
             "roofline": edgeconv_roofline(ec_tf, stage_ms["edgeconv"], arith),
             # the metric's second half: kNN (and Chamfer) HBM rate on ALGORITHMIC bytes
-            "roofline_knn": {"kernel": "knn_mfma_kernel<8> (+ topk2_kernel<20,EXPANDED,4> fix-up launch, idle here)", "bound": "hbm", "achieved": knn_gbs,
+            "roofline_knn": {"kernel": "knn_mfma_kernel<8>", "bound": "hbm", "achieved": knn_gbs,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": knn_gbs / HBM_PEAK_GBS,
                              "traffic": pmc_traffic("knn_mfma") or pmc_traffic("knn"),
                              "avg_launch_ms": stage_ms["knn"],

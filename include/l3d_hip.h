@@ -55,9 +55,7 @@ int l3d_last_hip_error(void);
 int l3d_knn_graph(const float *xyz, int B, int N, int k, int64_t *idx, l3d_stream_t stream);
 /* The same with the kernel named explicitly: variant 0 = by shape (what l3d_knn_graph does), 1 = the two-pass insertion
  * kernel (any N, k <= 200), 2 = ranking values on the fp32 matrix cores + selection by rank counting (k <= 24,
- * 256 <= N <= 2048; L3D_ERR_UNSUPPORTED otherwise), 3 = variant 2 WITHOUT its fix-up launch (diagnostics: a 32-query block whose
- * candidate lists overflowed is left marked, idx[first query of the block][0] == -1).  Identical results (lowest index first
- * under exact ties). */
+ * 256 <= N <= 2048; L3D_ERR_UNSUPPORTED otherwise).  Identical results (lowest index first under exact ties). */
 int l3d_knn_graph_variant(const float *xyz, int B, int N, int k, int64_t *idx, int variant, l3d_stream_t stream);
 
 /* Deterministic backward of the gather-type ops (replaces the fp32-atomicAdd scatters of

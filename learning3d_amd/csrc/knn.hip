@@ -167,17 +167,8 @@ __global__ __launch_bounds__(64) void topk_scan_kernel(
 template <int K, int METRIC, int W>
 __global__ __launch_bounds__(64 * W) void topk2_kernel(
     const float *__restrict__ qxyz, const float *__restrict__ cxyz, int Nq, int Nc, int k,
-    int out_mode, void *__restrict__ idx_out, float *__restrict__ val_out, int fixup)
+    int out_mode, void *__restrict__ idx_out, float *__restrict__ val_out)
 {
-    if (fixup) {
-        // fix-up mode behind knn_mfma.hip's kernel (OUT_KNN_GRAPH): redo this 64-query block only if one of its two
-        // 32-query halves marked itself as overflowed (idx[first query][0] == -1); uniform over the workgroup
-        const int64_t *o = (const int64_t *)idx_out;
-        const int qa = blockIdx.x * 64, qb = qa + 32;
-        const size_t row0 = (size_t)blockIdx.y * Nq;
-        const bool need = o[(row0 + qa) * k] == -1 || (qb < Nq && o[(row0 + qb) * k] == -1);
-        if (!need) return;
-    }
     // per-wave LDS: a candidate tile and one scratch area that is the pass-1 key queue
     // ([QCAP][64]), the value-merge mailbox ([K][64]), then the pass-2 collection (akey | aidx | bidx,
     // [K+1][64] each).  20 KiB per wave at K=20 -> two 4-wave workgroups per CU.
@@ -474,13 +465,13 @@ __global__ __launch_bounds__(64 * W) void topk2_kernel(
 
 template <int METRIC>
 static int launch_topk(const float *q, const float *c, int B, int Nq, int Nc, int k, int out_mode,
-                       void *idx, float *val, hipStream_t st, int fixup = 0)
+                       void *idx, float *val, hipStream_t st)
 {
     dim3 grid(l3d_divup(Nq, 64), B), block(64);
 #define L3D_TOPK2_CASE(KK, WW)                                                                   \
     if (k <= KK) {                                                                               \
         hipLaunchKernelGGL((topk2_kernel<KK, METRIC, WW>), grid, dim3(64 * WW), 0, st, q, c, Nq, \
-                           Nc, k, out_mode, idx, val, fixup);                                    \
+                           Nc, k, out_mode, idx, val);                                           \
         return l3d_check_launch();                                                               \
     }
     L3D_TOPK2_CASE(4, 4)
@@ -509,17 +500,12 @@ int l3d_launch_knn_mfma(const float *xyz, int B, int N, int k, int64_t *idx, hip
 extern "C" int l3d_knn_graph_variant(const float *xyz, int B, int N, int k, int64_t *idx, int variant,
                                      l3d_stream_t stream)
 {
-    L3D_REQUIRE(xyz && idx && B > 0 && N > 0 && k > 0 && k <= N && k <= L3D_KNN_MAX_K && variant >= 0 && variant <= 3);
+    L3D_REQUIRE(xyz && idx && B > 0 && N > 0 && k > 0 && k <= N && k <= L3D_KNN_MAX_K && variant >= 0 && variant <= 2);
     hipStream_t st = (hipStream_t)stream;
     const bool mfma = l3d_knn_mfma_supported(N, k);
-    if (variant >= 2 && !mfma) return L3D_ERR_UNSUPPORTED;
-    if (variant != 1 && mfma) {
-        // ranking values on the matrix cores + selection by rank counting; query blocks whose candidate list
-        // overflowed (heavily duplicated points) are redone by the insertion kernel in fix-up mode
-        const int rc = l3d_launch_knn_mfma(xyz, B, N, k, idx, st);
-        if (rc != L3D_OK || variant == 3) return rc;          // 3: diagnostics, overflowed blocks stay marked
-        return launch_topk<METRIC_EXPANDED>(xyz, xyz, B, N, N, k, OUT_KNN_GRAPH, idx, nullptr, st, 1);
-    }
+    if (variant == 2 && !mfma) return L3D_ERR_UNSUPPORTED;
+    if (variant != 1 && mfma)          // ranking values on the matrix cores + selection by rank counting (knn_mfma.hip)
+        return l3d_launch_knn_mfma(xyz, B, N, k, idx, st);
     return launch_topk<METRIC_EXPANDED>(xyz, xyz, B, N, N, k, OUT_KNN_GRAPH, idx, nullptr, st);
 }
 

@@ -1,7 +1,6 @@
 // knn_mfma.hip -- k nearest neighbours of a cloud in itself (utils/model_common_utils.py:3-9, `knn`), ranking values
 // on the fp32 matrix cores, selection by thresholding + rank counting.  k <= 24, 256 <= N <= 2048 (the DGCNN / DCP
-// shapes: N = 1024, k = 20); everything else stays on knn.hip's two-pass insertion kernel, which is also the fix-up
-// path for query blocks whose candidate list overflows here (clouds with hundreds of duplicated points).
+// shapes: N = 1024, k = 20); everything else stays on knn.hip's two-pass insertion kernel.
 //
 // The reference ranks pd[i][j] = (-xx_j + 2 <x_i, x_j>) - xx_i in fp32 with the dot product as the fma chain
 // fma(z,z', fma(y,y', x*x')) (MKL sgemm, K = 3).  v_mfma_f32_32x32x2_f32 accumulates its two k-slots as exactly
@@ -28,8 +27,12 @@
 //           ties) and appended to the query's list in LDS through an LDS atomic counter.
 //   rank    each of the query's 8 lanes takes every 8th key of the list and counts the keys above it; a key of rank
 //           r < k writes its index to idx[q][r].  No sorting network, no per-lane sorted lists.
-// Lists hold 64 keys.  A query block that would exceed that marks itself (idx[first query][0] = -1) and is redone by
-// knn.hip's kernel in fix-up mode (launched right behind this one; its workgroups exit at once when nothing is marked).
+// Lists hold 64 keys.  When a list overflows -- the tail of the bound (one query in 30 000 of a random cloud), or a point
+// duplicated dozens of times -- the block ranks what it did collect, takes the k-th best of those keys as the query's new
+// threshold (real candidates reach it, so it is a valid, tighter bound) and collects again.  If the bound cannot rise
+// (>= 45 of the 64 collected keys sit AT it: exact ties) the query switches to collecting strictly above it; what is then
+// missing from its k are the lowest-index candidates AT the bound, which a last phase picks one per round.  Every step
+// either raises a threshold past at least one value level or ends, so the loop terminates; there is no second kernel.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -48,6 +51,13 @@ __device__ __forceinline__ f32x16 km_tile(const float *__restrict__ cxy, const f
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(czw[at], b2, acc, 0, 0, 0);     // k = (cz * 2qz, -xx_j * 1)
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, acc, 0, 0, 0);          // k = (1 * -xx_i, 0 * 0)
     return acc;
+}
+
+// the next float above x: value > x  <=>  value >= km_nextup(x)
+__device__ __forceinline__ float km_nextup(float x)
+{
+    const unsigned b = __float_as_uint(x + 0.0f);
+    return __uint_as_float((int)b >= 0 ? b + 1u : b - 1u);
 }
 
 #ifdef KM_TIMING       // tools/probe_knn_mfma.hip: s_memtime stamps per wave instead of results
@@ -193,15 +203,13 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
 #endif
     KMT(3)
 
-    // ------------------------------------------------------------------ pass 1: collect the candidates >= thr0
-    // Two attempts.  A list overflows (> 64 candidates reach thr0) for about one query in 30 000 of a random cloud --
-    // the tail of the group-maxima bound -- and for every query that sits on a heavily duplicated point.  The first kind
-    // is settled here: the k-th best of the 64 keys that WERE collected is a tighter lower bound that real candidates
-    // reach, so the block collects again with it.  Only if that overflows too (exact ties: more than 64 candidates AT the
-    // k-th best value) does the block go to the fix-up kernel, whose single 64-query workgroup costs a whole 35 us.
+    // ------------------------------------------------------------------ pass 1: collect the candidates >= thr (or > thr)
     float *mydump = dump + wave * 2048;
     u64 *mylist = qlist + i * KM_STRIDE;
+    float thr = thr0;                  // this query's bound: a value that >= k of its candidates reach
+    bool strict = false;               // collect the candidates strictly above thr (its ties are filled in at the end)
     for (int attempt = 0;; attempt++) {
+        const float thrc = strict ? km_nextup(thr) : thr;
         bool over = false;
     #pragma unroll
         for (j = 0; j < T; j += 2) {
@@ -214,11 +222,11 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
                 aA = km_tile(cxy, czw, at0 + j * 32, b1, b2, b3, a3);
                 aB = km_tile(cxy, czw, at0 + (two ? j * 32 + 32 : j * 32), b1, b2, b3, a3);
             }
-            unsigned sgn = 0;                                      // sign bits of (value - thr0): set = below the threshold
+            unsigned sgn = 0;                                      // sign bits of (value - thrc): set = below the threshold
     #pragma unroll
-            for (int r = 0; r < 16; r++) sgn = __builtin_amdgcn_alignbit(sgn, __float_as_uint(aA[r] - thr0), 31);
+            for (int r = 0; r < 16; r++) sgn = __builtin_amdgcn_alignbit(sgn, __float_as_uint(aA[r] - thrc), 31);
     #pragma unroll
-            for (int r = 0; r < 16; r++) sgn = __builtin_amdgcn_alignbit(sgn, __float_as_uint(aB[r] - thr0), 31);
+            for (int r = 0; r < 16; r++) sgn = __builtin_amdgcn_alignbit(sgn, __float_as_uint(aB[r] - thrc), 31);
             unsigned m = ~sgn;                                     // bit 31 - e: accumulator register e & 15 of tile e >> 4 (A, B)
             if (!two) m &= 0xFFFF0000u;
             if (__builtin_amdgcn_ballot_w64(m != 0) != 0) {
@@ -261,10 +269,14 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
         __syncthreads();
         KMT(5)
         if (*ovf == 0) break;
-        if (attempt == 1) {                                    // still too many: exact ties at the k-th best value
+        if (attempt == 64) {                                   // tripwire: every pass raises a threshold or ends (see the header)
             if (tid == 0) idx_out[((size_t)b * N + q0) * k] = -1;
             return;
         }
+        // Some list of the block overflowed.  For EVERY query: the k-th best of the keys it did collect (any subset of its
+        // candidates >= thr) is a bound that >= k candidates reach and that is >= thr.
+        if (lane8 == 0) thr0s[i * 9 + 8] = thr;                // default: fewer than k keys collected (strict mode)
+        __syncthreads();
         {
             u64 own[8];
             int rank[8];
@@ -280,14 +292,22 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
             }
 #pragma unroll
             for (int o = 0; o < 8; o++)
-                if (own[o] != 0ull && rank[o] == k - 1) {      // exactly one key per query: keys are distinct
+                if (own[o] != 0ull && rank[o] == k - 1) {      // at most one key per query: keys are distinct
                     const unsigned sk = (unsigned)(own[o] >> 32);
-                    thr0s[i * 9] = __uint_as_float((sk & 0x80000000u) ? sk ^ 0x80000000u : ~sk);
+                    thr0s[i * 9 + 8] = __uint_as_float((sk & 0x80000000u) ? sk ^ 0x80000000u : ~sk);
                 }
         }
         __syncthreads();
-        thr0 = thr0s[i * 9];
-        __syncthreads();                                       // everybody has read the lists and the new thresholds
+        {
+            const float thr_new = thr0s[i * 9 + 8];
+            if (thr_new > thr) {                               // a tighter bound: collect >= it
+                thr = thr_new;
+                strict = false;
+            } else {
+                strict = true;                                 // the bound cannot rise (ties at it): collect what lies above
+            }
+        }
+        __syncthreads();                                       // everybody has read the lists and the new bounds
         for (int e = tid; e < 32 * KM_STRIDE; e += 256) qlist[e] = 0ull;
         if (tid < 32) qcnt[tid] = 0;
         if (tid == 0) *ovf = 0;
@@ -335,11 +355,55 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
         rank[0] + rank[1] + rank[2] + rank[3] + rank[4] + rank[5] + rank[6] + rank[7];
     return;
 #endif
+    int64_t *dst = idx_out + ((size_t)b * N + (valid ? q : 0)) * k;
     if (valid) {
-        int64_t *dst = idx_out + ((size_t)b * N + q) * k;
 #pragma unroll
         for (int o = 0; o < 8; o++)
             if (own[o] != 0ull && rank[o] < k) dst[rank[o]] = (int64_t)(unsigned)(~(unsigned)own[o]);
+    }
+
+    // ------------------------------------------------------------------ ties at the bound (strict mode, fewer than k above it)
+    // ranks Mq .. k-1 go to the lowest-index candidates whose value EQUALS thr, one per round: every lane offers its lowest
+    // such slot beyond the one it gave last, the query's 8 lanes take the minimum.  Only blocks with heavily duplicated
+    // points ever get here.
+    const int Mq = qcnt[i];
+    const int need = (strict && Mq < k) ? k - Mq : 0;
+    __syncthreads();                                           // all ranking reads of qcnt / lists are done
+    if (tid == 0) *ovf = 0;
+    __syncthreads();
+    if (need > 0) atomicMax(ovf, need);
+    __syncthreads();
+    const int rounds = *ovf;
+    int last = -1;
+    int *props = (int *)thr0s;
+    for (int round = 0; round < rounds; round++) {
+        int prop = 0x7fffffff;
+        for (int t = T - 1; t >= 0; t--) {                     // descending: the lowest slot is the one that sticks
+            f32x16 av;
+            if constexpr (CT > 0) {
+                av = kept[0];
+#pragma unroll
+                for (int u = 1; u < CT; u++) av = t == u ? kept[u] : av;
+            } else {
+                av = km_tile(cxy, czw, at0 + t * 32, b1, b2, b3, a3);
+            }
+#pragma unroll
+            for (int r = 15; r >= 0; r--) {
+                const int sl = 16 * t + r;
+                prop = (av[r] == thr && sl > last) ? sl : prop;
+            }
+        }
+        const int c = prop != 0x7fffffff ? 8 * prop + lane8 : 0x7fffffff;
+        props[i * 9 + lane8] = c;
+        __syncthreads();
+        int cmin = props[i * 9];
+#pragma unroll
+        for (int l = 1; l < 8; l++) cmin = min(cmin, props[i * 9 + l]);
+        if (c == cmin && c != 0x7fffffff) {
+            last = prop;
+            if (round < need && valid) dst[Mq + round] = c;
+        }
+        __syncthreads();
     }
 }
 
@@ -351,7 +415,6 @@ size_t l3d_knn_mfma_lds_bytes(int N)
 
 bool l3d_knn_mfma_supported(int N, int k) { return k <= 24 && N >= 256 && N <= 2048; }
 
-// launches the kernel; the caller follows it with knn.hip's kernel in fix-up mode
 int l3d_launch_knn_mfma(const float *xyz, int B, int N, int k, int64_t *idx, hipStream_t st)
 {
     const int T = l3d_divup(N, 128);
