@@ -412,6 +412,10 @@ int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes, const flo
 int l3d_fold_mlp(const float *g, int CG, const float *w5g, const float *s5, const void *w6_split,
                  const float *b6, const float *w7, const float *b7, const float *centre, int B, int N,
                  float *out, l3d_stream_t stream);
+/* The same with the conv6 GEMM as f16x2 on the fp16 matrix cores (fold_mlp_f16.hip): w6_planes is W6's [512][512] weight
+ * image from l3d_conv_f16_split_weights; the activation scale is chosen per workgroup from a bound it computes itself. */
+int l3d_fold_mlp_f16(const float *g, int CG, const float *w5g, const float *s5, const void *w6_planes, const float *b6,
+                     const float *w7, const float *b7, const float *centre, int B, int N, float *out, l3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Approximate EMD  == losses/cuda/emd_torch/pkg/include/emd.h:47-50 (pybind `_emd_ext._emd`)

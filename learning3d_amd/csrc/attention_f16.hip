@@ -15,6 +15,7 @@
 // 3 ND reads and 3 ND MFMAs (3 ND and 6 ND); the in-lane split of the probabilities drops from three planes to two.
 #include "common.h"
 #include "split_bf16.h"          // f32x4 / f32x16 typedefs
+#include "split_f16.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -25,30 +26,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define AF_BUF (10 * AF_REG)              // K (or V) 6 regions + Q 4 regions
 #define AF_LDS (2 * AF_BUF)
 #define AF_NEG (-1.0e30f)
-
-// two fp32 -> packed fp16 (H, Hs, M) of w c, c = 2^S
-__device__ __forceinline__ void af_split_w(float a0, float a1, float c, uint32_t &H, uint32_t &Hs, uint32_t &M)
-{
-    float r0, r1;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(H) : "v"(a0), "v"(c));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(H) : "v"(a1), "v"(c));
-    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a0), "v"(c), "v"(H));                     // w c - H: exact
-    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(a1), "v"(c), "v"(H));
-    asm("v_fma_mixlo_f16 %0, %1, 1.0, 0" : "=v"(M) : "v"(r0));
-    asm("v_fma_mixhi_f16 %0, %1, 1.0, 0" : "+v"(M) : "v"(r1));
-    asm("v_pk_mul_f16 %0, %1, %2" : "=v"(Hs) : "v"(H), "s"(0x0C000C00u));                                            // H 2^-12 (packed fp16 2^-12)
-}
-// two fp32 -> packed fp16 (h, m') of x c, c = 2^T
-__device__ __forceinline__ void af_split_x(float a0, float a1, float c, uint32_t &h, uint32_t &m)
-{
-    float r0, r1;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a0), "v"(c));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(a1), "v"(c));
-    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a0), "v"(c), "v"(h));
-    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(a1), "v"(c), "v"(h));
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(m) : "v"(r0), "s"(4096.0f));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(m) : "v"(r1), "s"(4096.0f));
-}
 
 // max|x| of q, k, v (blockIdx.y picks the tensor) as float bits, into out[0..2] (zeroed by the caller)
 __global__ __launch_bounds__(256) void at_absmax3_kernel(const float *__restrict__ q, const float *__restrict__ k,

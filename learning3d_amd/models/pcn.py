@@ -95,15 +95,18 @@ class PCN(torch.nn.Module):
             # conv5 -> conv6 -> conv7 (+ centre) as one kernel: the two [B,512,fine] activations never exist
             from .._lib import check, f32c, lib, ptr, stream_ptr
             w6 = self.conv6.weight.detach().reshape(512, 512)
-            key = (w6.data_ptr(), self.conv6.weight._version, str(w6.device))
+            f16 = _fused.gemm_arith() == "f16x2"                     # conv6 as f16x2 (3 fp16 products) or bf16x3 (6 bf16)
+            key = (w6.data_ptr(), self.conv6.weight._version, str(w6.device), f16)
             if getattr(self, "_w6_split", (None,))[0] != key:
-                self._w6_split = (key, _fused.split_rows(w6.float().contiguous()))
+                w6c = w6.float().contiguous()
+                self._w6_split = (key, _fused.split_weights_f16(w6c) if f16 else _fused.split_rows(w6c))
             g_, ce = f32c(x5), f32c(center)
             B, Nf, _ = g_.shape
             out = torch.empty((B, Nf, 3), dtype=torch.float32, device=g_.device)
-            check(lib().l3d_fold_mlp(ptr(g_), 5, ptr(f32c(w5[:, :5])), ptr(f32c(shift)), ptr(self._w6_split[1]),
-                                     ptr(f32c(self.conv6.bias.detach())), ptr(f32c(self.conv7.weight.detach().reshape(3, 512))),
-                                     ptr(f32c(self.conv7.bias.detach())), ptr(ce), B, Nf, ptr(out), stream_ptr()), "l3d_fold_mlp")
+            fn, name = (lib().l3d_fold_mlp_f16, "l3d_fold_mlp_f16") if f16 else (lib().l3d_fold_mlp, "l3d_fold_mlp")
+            check(fn(ptr(g_), 5, ptr(f32c(w5[:, :5])), ptr(f32c(shift)), ptr(self._w6_split[1]),
+                     ptr(f32c(self.conv6.bias.detach())), ptr(f32c(self.conv7.weight.detach().reshape(3, 512))),
+                     ptr(f32c(self.conv7.bias.detach())), ptr(ce), B, Nf, ptr(out), stream_ptr()), name)
             return out
         h = pc(x5, w5[:, :5], None, shift, relu=True, channel_last=True)
         w, _, b = _fused.fold_conv_bn(self.conv6)

@@ -811,6 +811,40 @@ def test_pcn_fused_matches_reference_order_path():
         np.testing.assert_allclose(fused[k].cpu().numpy(), ref[k].detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
+def test_fold_mlp_both_arithmetics_vs_fp64():
+    """PCN's folding decoder as one kernel (fold_mlp.hip bf16x3, fold_mlp_f16.hip f16x2) against an fp64 evaluation of
+    models/pcn.py:84-101, ragged N, activations from tiny to large: the f16x2 kernel picks its plane scale per workgroup from
+    a bound it computes itself, so no magnitude may overflow fp16 or lose fp32-level accuracy."""
+    from learning3d_amd._lib import check, lib, ptr, stream_ptr
+    from learning3d_amd.models import _fused
+    rng = np.random.default_rng(77)
+    B, N = 2, 600
+    for gscale, sscale in ((1.0, 1.0), (1e-3, 1e-3), (30.0, 100.0)):
+        g = (rng.standard_normal((B, N, 5)) * gscale).astype(np.float32)
+        w5g = (rng.standard_normal((512, 5)) * 0.5).astype(np.float32)
+        s5 = (rng.standard_normal((B, 512)) * sscale).astype(np.float32)
+        w6 = (rng.standard_normal((512, 512)) / 512 ** 0.5).astype(np.float32)
+        b6 = (rng.standard_normal(512) * 0.1 * sscale).astype(np.float32)
+        w7 = (rng.standard_normal((3, 512)) / 512 ** 0.5).astype(np.float32)
+        b7 = rng.standard_normal(3).astype(np.float32)
+        ce = rng.standard_normal((B, N, 3)).astype(np.float32)
+        h5 = np.maximum(s5[:, None, :].astype(np.float64) + g.astype(np.float64) @ w5g.astype(np.float64).T, 0)
+        h6 = np.maximum(h5 @ w6.astype(np.float64).T + b6, 0)
+        want = h6 @ w7.astype(np.float64).T + b7 + ce
+        dv = {k: dev(v) for k, v in dict(g=g, w5g=w5g, s5=s5, w6=w6, b6=b6, w7=w7, b7=b7, ce=ce).items()}
+        outs = {}
+        for name, fn, wimg in (("bf16x3", lib().l3d_fold_mlp, _fused.split_rows(dv["w6"])),
+                               ("f16x2", lib().l3d_fold_mlp_f16, _fused.split_weights_f16(dv["w6"]))):
+            out = torch.empty((B, N, 3), dtype=torch.float32, device="cuda")
+            check(fn(ptr(dv["g"]), 5, ptr(dv["w5g"]), ptr(dv["s5"]), ptr(wimg), ptr(dv["b6"]), ptr(dv["w7"]), ptr(dv["b7"]),
+                     ptr(dv["ce"]), B, N, ptr(out), stream_ptr()), name)
+            outs[name] = out.cpu().numpy() - want
+        scale = np.abs(want).max()
+        e3, e16 = outs["bf16x3"], outs["f16x2"]
+        assert np.abs(e16).max() <= 2e-6 * scale + 2.0 * np.abs(e3).max(), (gscale, np.abs(e16).max(), np.abs(e3).max())
+        assert np.sqrt((e16 ** 2).mean()) <= 1.5 * np.sqrt((e3 ** 2).mean()) + 1e-7 * scale
+
+
 def test_soft_correspondence_flash_vs_fp64():
     """Fused score-GEMM + softmax + weighted target sum (softcorr.hip) against an fp64 evaluation of
     utils/svd.py:22-27, ragged N / M included; and the SVDHead built on it against the oracle."""
