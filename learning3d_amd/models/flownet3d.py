@@ -238,4 +238,7 @@ class FlowNet3D(nn.Module):
         l1_fnew1 = self.su3(l1_pc1, l2_pc1, l1_feature1, l2_fnew1)
         l0_fnew1 = self.fp(pc1, l1_pc1, feature1, l1_fnew1)
         x = _mlp_stack(l0_fnew1, [self.conv1], [self.bn1], self)
+        if _fused.can_fuse(self, x):                  # the 128 -> 3 head on the narrow-head kernel (mlp.hip), not a torch conv
+            w, sc, sh = _fused.fold_conv_bn(self.conv2)
+            return _fused.pointwise_conv(x, w, sc, sh, relu=False)
         return self.conv2(x)
