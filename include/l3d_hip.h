@@ -445,6 +445,13 @@ int l3d_lpfa_group(const float *xyz, const float *x, const int64_t *idx, int B, 
 int l3d_uniform_clouds(unsigned long long seed, int B, int N, float lo, float hi, float *out, l3d_stream_t stream);
 int l3d_euler_transform(const float *tmpl, const float *euler_zyx, const float *trans, int B, int N, float *source,
                         float *igt, l3d_stream_t stream);
+/* PNLKTransform / RPMNetTransform (ops/transform_functions.py:109-192) for a batch: twist [B,6] = (w, v) per cloud;
+ * igt [B,4,4] = se3.exp(x) (template -> source), gt [B,4,4] = se3.exp(-x), source = R template + p. */
+int l3d_twist_transform(const float *tmpl, const float *twist, int B, int N, float *source, float *igt, float *gt,
+                        l3d_stream_t stream);
+/* PCRNetTransform.__call__ (ops/transform_functions.py:194-269) for a batch: pose7 [B,7] = (quaternion w x y z, translation);
+ * the quaternion is normalised as create_pose_7d does; source = qrot(q, template) + t. */
+int l3d_quat_transform(const float *tmpl, const float *pose7, int B, int N, float *source, l3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training-mode BatchNorm around the 1x1-conv GEMMs (train.hip).  z / dy / y / dz are [B,C,P]

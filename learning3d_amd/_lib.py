@@ -94,6 +94,8 @@ SIGNATURES = {
     "l3d_bn_act_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P],
     "l3d_uniform_clouds": [C.c_ulonglong, _I, _I, _F, _F, _P, _P],
     "l3d_euler_transform": [_P, _P, _P, _I, _I, _P, _P, _P],
+    "l3d_twist_transform": [_P, _P, _I, _I, _P, _P, _P, _P],
+    "l3d_quat_transform": [_P, _P, _I, _I, _P, _P],
     "l3d_emd_forward": [_P, _P, _I, _I, _I, _P, _P, _P, _P],
     "l3d_emd_backward": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
 }

@@ -61,3 +61,121 @@ class DCPTransform:
 
 class DeepGMRTransform(DCPTransform):
     """reference: ops/transform_functions.py:317-345 -- the same draw and the same application as DCPTransform."""
+
+
+def twist_transform(template, twist):
+    """template [B,N,3] (device), twist [B,6] = (w, v) -> (source [B,N,3], igt [B,4,4] = se3.exp(twist), gt [B,4,4] =
+    se3.exp(-twist)): ops/transform_functions.py:133-141 for a whole batch in one launch (l3d_twist_transform)."""
+    require_gpu(template, twist)
+    t, x = f32c(template), f32c(twist)
+    B, N, _ = t.shape
+    source = torch.empty_like(t)
+    igt = torch.empty((B, 4, 4), dtype=torch.float32, device=t.device)
+    gt = torch.empty((B, 4, 4), dtype=torch.float32, device=t.device)
+    check(lib().l3d_twist_transform(ptr(t), ptr(x), B, N, ptr(source), ptr(igt), ptr(gt), stream_ptr()), "l3d_twist_transform")
+    return source, igt, gt
+
+
+def quat_transform(template, pose7):
+    """template [B,N,3], pose7 [B,7] = (quaternion w x y z -- normalised here as create_pose_7d does --, translation)
+    -> source = qrot(q, template) + t: PCRNetTransform.__call__ (ops/transform_functions.py:265-269) for a batch."""
+    require_gpu(template, pose7)
+    t, p = f32c(template), f32c(pose7)
+    B, N, _ = t.shape
+    source = torch.empty_like(t)
+    check(lib().l3d_quat_transform(ptr(t), ptr(p), B, N, ptr(source), stream_ptr()), "l3d_quat_transform")
+    return source
+
+
+class PNLKTransform:
+    """reference: ops/transform_functions.py:109-145.  Same constructor; `__call__(tensor)` takes a device batch [B,N,3]
+    (or one cloud [N,3]); `.gt` / `.igt` hold [B,4,4] (or [4,4]) afterwards.  The twist is drawn on the device: a unit
+    6-vector times `mag` (times U(0,1) with mag_randomly), generate_transform :119-127."""
+
+    def __init__(self, mag=1, mag_randomly=False, generator=None):
+        self.mag = mag
+        self.randomly = mag_randomly
+        self.gt = None
+        self.igt = None
+        self.index = 0
+        self.generator = generator
+
+    def generate_transform(self, batch=1, device="cuda"):
+        amp = self.mag
+        if self.randomly:
+            amp = torch.rand((batch, 1), device=device, generator=self.generator) * self.mag
+        x = torch.randn((batch, 6), device=device, generator=self.generator)
+        return x / x.norm(p=2, dim=1, keepdim=True) * amp
+
+    def apply_transform(self, p0, x):
+        single = p0.dim() == 2
+        p = p0.unsqueeze(0) if single else p0
+        p1, igt, gt = twist_transform(p[..., :3].contiguous(), x.reshape(-1, 6))
+        if p.shape[-1] == 6:                       # RPMNetTransform: the normals turn with the rotation only (:170-174)
+            xr = x.reshape(-1, 6).clone()
+            xr[:, 3:] = 0
+            n1, _, _ = twist_transform(p[..., 3:6].contiguous(), xr)
+            p1 = torch.cat([p1, n1], dim=-1)
+        self.gt, self.igt = (gt[0], igt[0]) if single else (gt, igt)
+        return p1[0] if single else p1
+
+    def transform(self, tensor):
+        batch = 1 if tensor.dim() == 2 else tensor.shape[0]
+        return self.apply_transform(tensor, self.generate_transform(batch, tensor.device))
+
+    def __call__(self, tensor):
+        return self.transform(tensor)
+
+
+class RPMNetTransform(PNLKTransform):
+    """reference: ops/transform_functions.py:148-192 -- PNLKTransform that also rotates the normals of [.., 6] clouds."""
+
+
+def _qmul(q, r):
+    """Hamilton product of [B,4] quaternions (ops/transform_functions.py:37-55)."""
+    w0, x0, y0, z0 = q.unbind(1)
+    w1, x1, y1, z1 = r.unbind(1)
+    return torch.stack([w0 * w1 - x0 * x1 - y0 * y1 - z0 * z1, w0 * x1 + x0 * w1 + y0 * z1 - z0 * y1,
+                        w0 * y1 - x0 * z1 + y0 * w1 + z0 * x1, w0 * z1 + x0 * y1 - y0 * x1 + z0 * w1], dim=1)
+
+
+def euler_to_quaternion_xyz(e):
+    """[B,3] Euler angles -> [B,4] quaternions, order "xyz", with the reference's sign convention (:62-107)."""
+    z0 = torch.zeros_like(e[:, 0])
+    rx = torch.stack([torch.cos(e[:, 0] / 2), torch.sin(e[:, 0] / 2), z0, z0], dim=1)
+    ry = torch.stack([torch.cos(e[:, 1] / 2), z0, torch.sin(e[:, 1] / 2), z0], dim=1)
+    rz = torch.stack([torch.cos(e[:, 2] / 2), z0, z0, torch.sin(e[:, 2] / 2)], dim=1)
+    return -_qmul(_qmul(rx, ry), rz)
+
+
+class PCRNetTransform:
+    """reference: ops/transform_functions.py:194-269.  The reference pre-draws `data_size` poses on the host and its dataset
+    picks one by index; here `__call__(template [B,N,3] or [N,3])` draws one pose per cloud on the device (Euler angles
+    ~ U(-angle_range, angle_range)^3 degrees -> quaternion "xyz", translation ~ U(-translation_range, translation_range)^3,
+    create_random_transform :205-214) and applies it (l3d_quat_transform); `.igt` holds the [B,7] poses."""
+
+    def __init__(self, data_size=None, angle_range=45, translation_range=1, generator=None):
+        self.angle_range = angle_range
+        self.translation_range = translation_range
+        self.dtype = torch.float32
+        self.index = 0
+        self.generator = generator
+
+    @staticmethod
+    def deg_to_rad(deg):
+        return math.pi / 180 * deg
+
+    def create_random_transform(self, batch, device):
+        mr = self.deg_to_rad(self.angle_range)
+        r = torch.rand((batch, 6), device=device, generator=self.generator) * 2 - 1
+        return torch.cat([euler_to_quaternion_xyz(r[:, :3] * mr), r[:, 3:] * self.translation_range], dim=1)
+
+    def __call__(self, template):
+        single = template.dim() == 2
+        t = template.unsqueeze(0) if single else template
+        self.igt = self.create_random_transform(t.shape[0], t.device)
+        source = quat_transform(t, self.igt)
+        if single:
+            self.igt = self.igt[0:1]
+            return source[0]
+        return source

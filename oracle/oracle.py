@@ -573,3 +573,43 @@ def dcp_transform(template, anglex, angley, anglez, translation):
         igt[b, :3, 3] = translation[b]
         igt[b, 3, 3] = 1.0
     return src.astype(np.float32), igt.astype(np.float32)
+
+
+def twist_transform(template, twist):
+    """ops/transform_functions.py:133-141 + ops/se3.py:51-74 + ops/sinc.py (PNLKTransform.apply_transform) in fp64:
+    template [B,N,3], twist [B,6] -> (source, igt = se3.exp(x), gt = se3.exp(-x)), rounded to fp32 once."""
+    t = np.asarray(template, np.float64)
+    x = np.asarray(twist, np.float64)
+
+    def exp(xx):
+        out = np.zeros((xx.shape[0], 4, 4))
+        for b, (w, v) in enumerate(zip(xx[:, :3], xx[:, 3:])):
+            th2 = float(w @ w)
+            th = np.sqrt(th2)
+            if th < 0.01:
+                s1 = 1 - th2 / 6 * (1 - th2 / 20 * (1 - th2 / 42))
+                s2 = 0.5 * (1 - th2 / 12 * (1 - th2 / 30 * (1 - th2 / 56)))
+                s3 = 1 / 6 * (1 - th2 / 20 * (1 - th2 / 42 * (1 - th2 / 72)))
+            else:
+                s1, s2, s3 = np.sin(th) / th, (1 - np.cos(th)) / th2, (th - np.sin(th)) / th ** 3
+            W = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+            S = W @ W
+            out[b, :3, :3] = np.eye(3) + s1 * W + s2 * S
+            out[b, :3, 3] = (np.eye(3) + s2 * W + s3 * S) @ v
+            out[b, 3, 3] = 1
+        return out
+    g, gt = exp(x), exp(-x)
+    src = np.einsum("bij,bnj->bni", g[:, :3, :3], t) + g[:, None, :3, 3]
+    return src.astype(np.float32), g.astype(np.float32), gt.astype(np.float32)
+
+
+def quat_transform(template, pose7):
+    """PCRNetTransform.__call__ (ops/transform_functions.py:218-269, ops/quaternion.py:35-53) in fp32 torch ops."""
+    import torch
+    t = torch.from_numpy(np.asarray(template, np.float32))
+    p = torch.from_numpy(np.asarray(pose7, np.float32))
+    q = torch.nn.functional.normalize(p[:, :4], dim=1)[:, None, :].expand(-1, t.shape[1], -1)
+    qv = q[..., 1:]
+    uv = torch.cross(qv, t, dim=2)
+    uuv = torch.cross(qv, uv, dim=2)
+    return (t + 2 * (q[..., :1] * uv + uuv) + p[:, None, 4:]).numpy()

@@ -256,6 +256,28 @@ def main():
             igts.append(tf.igt)
         save("dcp_transform", template=tmpl, anglex=ang[:, 0], angley=ang[:, 1], anglez=ang[:, 2], translation=trn,
              source=torch.stack(srcs), igt=torch.stack(igts))
+        # ---- 8(f) rank 4, the other pose generators: PNLKTransform / RPMNetTransform (twist -> se3.exp, :109-192) and
+        #      PCRNetTransform (quaternion + translation, :194-269), transforms fixed by hand (the classes draw with torch /
+        #      numpy global RNGs) and applied by the reference's own apply_transform / __call__ ------------------------------
+        from learning3d.ops.transform_functions import PNLKTransform, RPMNetTransform, PCRNetTransform
+        twist = torch.cat([rand((5, 6), 33, -1, 1), torch.tensor([[1e-3, -2e-3, 5e-4, 0.3, -0.2, 0.1]])])   # last: Taylor branch of the sinc helpers
+        tmpl = rand((6, 150, 3), 34, -0.5, 0.5)
+        nrm = torch.nn.functional.normalize(rand((6, 150, 3), 35, -1, 1), dim=2)
+        src, igt, gt, src6 = [], [], [], []
+        for i in range(6):
+            t1 = PNLKTransform(mag=1)
+            src.append(t1.apply_transform(tmpl[i], twist[i:i + 1])); igt.append(t1.igt); gt.append(t1.gt)
+            t2 = RPMNetTransform(mag=1)
+            src6.append(t2.apply_transform(torch.cat([tmpl[i], nrm[i]], dim=1), twist[i:i + 1]))
+        pose = torch.cat([rand((6, 4), 36, -1, 1), rand((6, 3), 37, -1, 1)], dim=1)                     # un-normalised quaternion + t
+        psrc = []
+        for i in range(6):
+            t3 = PCRNetTransform(1, angle_range=45, translation_range=1)
+            t3.transformations = [pose[i:i + 1]]
+            t3.index = 0
+            psrc.append(t3(tmpl[i]))
+        save("pose_transforms", template=tmpl, normals=nrm, twist=twist, source=torch.stack(src), igt=torch.stack(igt),
+             gt=torch.stack(gt), source6=torch.stack(src6), pose7=pose, pcr_source=torch.stack(psrc))
         # ---- CurveNet LPFA (utils/curvenet_util.py:229-291): kNN on xyz with add_one_to_k, grouping, both variants ------
         from learning3d.utils.curvenet_util import LPFA
         torch.manual_seed(9)

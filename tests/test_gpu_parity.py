@@ -1563,3 +1563,34 @@ def test_knn_variant_argument_checks():
     with pytest.raises(L3DError):
         _knn_variant(dev(rand((1, 512, 3), 1)), 32, 2)                       # k > 24
     assert np.array_equal(_knn_variant(x, 7, 0).cpu().numpy(), _knn_variant(x, 7, 1).cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_device_pose_transforms_golden(golden):
+    """l3d_twist_transform / l3d_quat_transform and their class mirrors against the reference's PNLKTransform /
+    RPMNetTransform / PCRNetTransform outputs (golden generated by running the reference)."""
+    from learning3d_amd.ops import transform_functions as T
+    g = golden("pose_transforms")
+    src, igt, gt = T.twist_transform(dev(g["template"]), dev(g["twist"]))
+    np.testing.assert_allclose(src.cpu().numpy(), g["source"], atol=2e-6)
+    np.testing.assert_allclose(igt.cpu().numpy(), g["igt"], atol=1e-6)
+    np.testing.assert_allclose(gt.cpu().numpy(), g["gt"], atol=1e-6)
+    tf = T.RPMNetTransform(mag=1)
+    p6 = tf.apply_transform(dev(np.concatenate([g["template"], g["normals"]], axis=2)), dev(g["twist"]))
+    np.testing.assert_allclose(p6.cpu().numpy(), g["source6"], atol=2e-6)
+    np.testing.assert_allclose(tf.igt.cpu().numpy(), g["igt"], atol=1e-6)
+    np.testing.assert_allclose(T.quat_transform(dev(g["template"]), dev(g["pose7"])).cpu().numpy(), g["pcr_source"], atol=1e-6)
+    # the drawing side: unit twists of the requested magnitude, proper rotations, gt = igt^-1
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    t1 = T.PNLKTransform(mag=0.8, generator=gen)
+    x = t1.generate_transform(16, "cuda")
+    np.testing.assert_allclose(x.norm(dim=1).cpu().numpy(), 0.8, rtol=1e-5)
+    out = t1(dev(g["template"]))
+    assert out.shape == g["template"].shape
+    eye = torch.matmul(t1.gt, t1.igt).cpu().numpy()
+    np.testing.assert_allclose(eye, np.broadcast_to(np.eye(4), eye.shape), atol=1e-5)
+    t3 = T.PCRNetTransform(angle_range=45, translation_range=1, generator=gen)
+    s3 = t3(dev(g["template"]))
+    assert t3.igt.shape == (g["template"].shape[0], 7) and torch.isfinite(s3).all()
+    np.testing.assert_allclose(t3.igt[:, :4].norm(dim=1).cpu().numpy(), 1.0, rtol=1e-5)
+    np.testing.assert_allclose(s3.cpu().numpy(), oracle.quat_transform(g["template"], t3.igt.cpu().numpy()), atol=1e-6)

@@ -186,3 +186,14 @@ def test_dcp_transform_oracle(golden):
     src, igt = oracle.dcp_transform(g["template"], g["anglex"], g["angley"], g["anglez"], g["translation"])
     np.testing.assert_allclose(src, g["source"], rtol=0, atol=1e-7)
     np.testing.assert_allclose(igt, g["igt"], rtol=0, atol=1e-7)
+
+
+def test_pose_transforms_golden(golden):
+    """PNLKTransform / RPMNetTransform (twist -> se3.exp) and PCRNetTransform (quaternion + translation) restatements against
+    the reference's own apply_transform / __call__ (tests/golden/make_golden.py `pose_transforms`)."""
+    g = golden("pose_transforms")
+    src, igt, gt = oracle.twist_transform(g["template"], g["twist"])
+    np.testing.assert_allclose(src, g["source"], atol=2e-6)
+    np.testing.assert_allclose(igt, g["igt"], atol=1e-6)
+    np.testing.assert_allclose(gt, g["gt"], atol=1e-6)
+    np.testing.assert_allclose(oracle.quat_transform(g["template"], g["pose7"]), g["pcr_source"], atol=1e-6)
