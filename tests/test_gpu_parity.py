@@ -1594,3 +1594,31 @@ def test_device_pose_transforms_golden(golden):
     assert t3.igt.shape == (g["template"].shape[0], 7) and torch.isfinite(s3).all()
     np.testing.assert_allclose(t3.igt[:, :4].norm(dim=1).cpu().numpy(), 1.0, rtol=1e-5)
     np.testing.assert_allclose(s3.cpu().numpy(), oracle.quat_transform(g["template"], t3.igt.cpu().numpy()), atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_resident_registration_feed():
+    """A dataset resident in HBM served as registration batches: every cloud once per epoch, same batches for the same
+    (seed, epoch), template rows are dataset rows, and (source, igt) are consistent for each device transform."""
+    from learning3d_amd.data_utils.device_feed import ResidentRegistrationFeed
+    from learning3d_amd.ops import transform_functions as T
+    g = torch.Generator().manual_seed(0)
+    data = torch.rand((70, 300, 3), generator=g).cuda() - 0.5
+    labels = torch.arange(70).cuda()
+    feed = ResidentRegistrationFeed(data, labels, batch_size=16, num_points=128, seed=5)
+    batches = list(feed)
+    assert len(batches) == len(feed) == 4
+    seen = torch.cat([b[3] for b in batches])
+    assert seen.unique().numel() == 64                                      # a permutation: no cloud twice
+    for tmpl, src, igt, lab in batches:
+        assert torch.equal(tmpl, data[lab, :128])
+        R, t = igt[:, :3, :3].transpose(1, 2), igt[:, :3, 3]                # DCP's igt holds R^T | t
+        np.testing.assert_allclose(src.cpu().numpy(), (torch.matmul(tmpl, R.transpose(1, 2)) + t[:, None]).cpu().numpy(), atol=1e-5)
+    again = list(ResidentRegistrationFeed(data, labels, batch_size=16, num_points=128, seed=5))
+    assert all(torch.equal(a[1], b[1]) for a, b in zip(batches, again))
+    # a twist transform instead, with the point shuffle
+    feed2 = ResidentRegistrationFeed(data, None, batch_size=10, num_points=64, transform=T.PNLKTransform(mag=0.5), randomize_points=True, seed=1)
+    tmpl, src, igt, lab = next(iter(feed2))
+    assert lab is None and tmpl.shape == (10, 64, 3)
+    want = torch.matmul(tmpl, igt[:, :3, :3].transpose(1, 2)) + igt[:, None, :3, 3]
+    np.testing.assert_allclose(src.cpu().numpy(), want.cpu().numpy(), atol=1e-5)
