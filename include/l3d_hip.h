@@ -280,6 +280,11 @@ int l3d_attention_forward_f16(const float *q, const float *k, const float *v, in
  *   y[r][:] = a * (x[r][:] - mean_r) / (std_r + eps) + b,   x, y [rows][C] fp32, C % 4 == 0, C <= 2048. */
 int l3d_layernorm_ref(const float *x, const float *a, const float *b, float eps, long rows, int C, float *y,
                       l3d_stream_t stream);
+/* The same, and additionally the output as the fp16 activation image l3d_pointwise_conv_f16 consumes (img:
+ * l3d_f16_act_bytes(rows, C) bytes): the Linear layers behind a LayerNorm then run as f16x2 with no split pass.  The
+ * plane scale comes from the layer's parameters (|y_c| <= |a_c| sqrt(C-1) + |b_c|).  C % 8 == 0, C <= 512. */
+int l3d_layernorm_planes(const float *x, const float *a, const float *b, float eps, long rows, int C, float *y, void *img,
+                         l3d_stream_t stream);
 /* Residual connection x + sublayer(norm(x)) of utils/transformer.py:82-88 when the sublayer output is channel-first:
  * out[b][n][c] = x[b][n][c] + y[b][c][n];  x, out fp32 [B,N,C], y fp32 [B,C,N] (tiled transpose through LDS). */
 int l3d_add_transposed(const float *x, const float *y, int B, int N, int C, float *out, l3d_stream_t stream);

@@ -40,7 +40,15 @@ __global__ __launch_bounds__(256) void at_absmax3_kernel(const float *__restrict
     for (int b = 0; b < B; b++) {
         const float *pb = p + (size_t)b * bs;
         if (vec) {
-            for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < span / 4; i += (long)gridDim.x * 256) {
+            const long n4 = span / 4, step = (long)gridDim.x * 256;
+            long i = (long)blockIdx.x * 256 + threadIdx.x;
+            for (; i + 3 * step < n4; i += 4 * step) {                       // four loads in flight per thread
+                const f32x4 x0 = *(const f32x4 *)(pb + 4 * i), x1 = *(const f32x4 *)(pb + 4 * (i + step)),
+                            x2 = *(const f32x4 *)(pb + 4 * (i + 2 * step)), x3 = *(const f32x4 *)(pb + 4 * (i + 3 * step));
+#pragma unroll
+                for (int e = 0; e < 4; e++) m = fmaxf(fmaxf(m, fmaxf(fabsf(x0[e]), fabsf(x1[e]))), fmaxf(fabsf(x2[e]), fabsf(x3[e])));
+            }
+            for (; i < n4; i += step) {
                 const f32x4 x = *(const f32x4 *)(pb + 4 * i);
                 m = fmaxf(fmaxf(m, fmaxf(fabsf(x[0]), fabsf(x[1]))), fmaxf(fabsf(x[2]), fabsf(x[3])));
             }
@@ -50,7 +58,10 @@ __global__ __launch_bounds__(256) void at_absmax3_kernel(const float *__restrict
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(out + which, __float_as_uint(m));
+    __shared__ float wmax[4];                        // ONE atomic per workgroup: thousands of atomics on three words serialise
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out + which, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
 }
 
 // 2^S with max 2^S in [2^(hi-1), 2^hi)
@@ -291,7 +302,7 @@ extern "C" int l3d_attention_forward_f16(const float *q, const float *k, const f
     hipStream_t st = (hipStream_t)stream;
     unsigned *amax = (unsigned *)workspace;
     if (hipMemsetAsync(amax, 0, 16, st) != hipSuccess) return L3D_ERR_LAUNCH;
-    hipLaunchKernelGGL(at_absmax3_kernel, dim3(128, 3), dim3(256), 0, st, q, k, v, q_bstride, k_bstride, v_bstride,
+    hipLaunchKernelGGL(at_absmax3_kernel, dim3(512, 3), dim3(256), 0, st, q, k, v, q_bstride, k_bstride, v_bstride,
                        (long)H * D * N, (long)H * D * M, B, amax);
     dim3 grid(l3d_divup(N, AF_TQ), H, B), block(256);
     if (D == 32)      hipLaunchKernelGGL(attention_f16_kernel<1>, grid, block, AF_LDS, st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax);

@@ -338,3 +338,128 @@ extern "C" int l3d_add_transposed(const float *x, const float *y, int B, int N, 
                        (hipStream_t)stream, x, y, N, C, out);
     return l3d_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm that ALSO emits its output as the fp16 activation image conv_f16.hip consumes (h | m' planes of y 2^T in the
+// tiled layout [C/8][rows][8], then 2^-T): every Linear of the pointer network that follows a LayerNorm (q|k|v, q, k|v,
+// the feed-forward's first layer) then runs on the f16x2 kernel with no split pass over its input.  The plane scale
+// needs no pass over y either: |y_c| <= |a_c| sqrt(C-1) + |b_c| because sum_c z_c^2 <= C-1 for z = (x-mean)/(std+eps)
+// with the unbiased std, so T comes from the layer's own parameters and cannot be exceeded.
+// A workgroup normalises 16 rows (a wave per row, 4 rows per wave), parks the 16-byte plane cells in LDS as [octet][row]
+// and writes them out as 256-byte runs (16 rows of one octet); y itself is written as before.  (32 rows per workgroup --
+// 512-byte runs, 67 KB of LDS, two workgroups per CU -- was slower: 55 us against the plain kernel's 23.)
+// ---------------------------------------------------------------------------------------------
+#define LNP_ROWS 16
+#define LNP_RS 17                      // row stride of the LDS cell array (bank spread)
+template <int VPL /* float4 per lane */>
+__global__ __launch_bounds__(256) void layernorm_planes_kernel(const float *__restrict__ x, const float *__restrict__ a,
+                                                               const float *__restrict__ bb, float eps, long rows, int C,
+                                                               float *__restrict__ y, uint4 *__restrict__ ph, uint4 *__restrict__ pm,
+                                                               float *__restrict__ inv_out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lnp_lds[];
+    const int NO = C >> 3;                                            // octets
+    uint4 *cell = (uint4 *)lnp_lds;                                   // [2][NO][LNP_RS]
+    float *scr = (float *)(cell + 2 * NO * LNP_RS);                   // [4]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int c4 = C >> 2;
+    // ---- plane scale from the layer's parameters
+    float hm = 0.f;
+    const float rt = sqrtf((float)(C - 1));
+    for (int c = t; c < C; c += 256) hm = fmaxf(hm, fmaf(fabsf(a[c]), rt, fabsf(bb[c])));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) hm = fmaxf(hm, __shfl_xor(hm, d, 64));
+    if (lane == 0) scr[wave] = hm;
+    __syncthreads();
+    hm = fmaxf(fmaxf(scr[0], scr[1]), fmaxf(scr[2], scr[3])) * 1.000001f;
+    int e = 0;
+    if (hm > 0.f && hm < 3.0e38f) (void)frexpf(hm, &e);               // hm = f 2^e, f in [0.5, 1)
+    const float up = ldexpf(1.f, 12 - e);
+    if (blockIdx.x == 0 && t == 0) *inv_out = ldexpf(1.f, e - 12);
+
+    const long row0 = (long)blockIdx.x * LNP_ROWS;
+    for (int rr = 0; rr < LNP_ROWS / 4; rr++) {
+        const int rslot = rr * 4 + wave;
+        const long row = row0 + rslot;
+        if (row >= rows) continue;                                    // wave-uniform
+        const float4 *xr = (const float4 *)(x + row * C);
+        float4 v[VPL];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+            const int q = lane + 64 * i;
+            v[i] = q < c4 ? xr[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        const float mean = s / (float)C;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+            if (lane + 64 * i < c4) {
+                const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+                ss += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        const float inv = 1.f / (sqrtf(ss / (float)(C - 1)) + eps);
+        float4 *yr = (float4 *)(y + row * C);
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+            const int q = lane + 64 * i;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < c4) {
+                const float4 ga = ((const float4 *)a)[q], be = ((const float4 *)bb)[q];
+                o.x = ga.x * (v[i].x - mean) * inv + be.x;
+                o.y = ga.y * (v[i].y - mean) * inv + be.y;
+                o.z = ga.z * (v[i].z - mean) * inv + be.z;
+                o.w = ga.w * (v[i].w - mean) * inv + be.w;
+                yr[q] = o;
+            }
+            // the odd lane's four values join the even lane's: one octet = channels 8 o .. 8 o + 7
+            const float n0 = __shfl_down(o.x, 1, 64), n1 = __shfl_down(o.y, 1, 64), n2 = __shfl_down(o.z, 1, 64), n3 = __shfl_down(o.w, 1, 64);
+            if (!(lane & 1) && q < c4) {
+                const float xv[8] = {o.x, o.y, o.z, o.w, n0, n1, n2, n3};
+                _Float16 h[8], m[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const float X = xv[k] * up;
+                    h[k] = (_Float16)X;
+                    m[k] = (_Float16)((X - (float)h[k]) * 4096.0f);
+                }
+                const int oc = q >> 1;
+                cell[oc * LNP_RS + rslot] = *(const uint4 *)h;
+                cell[(NO + oc) * LNP_RS + rslot] = *(const uint4 *)m;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- contiguous runs: LNP_ROWS consecutive rows of one (plane, octet)
+    for (int c = t; c < 2 * NO * LNP_ROWS; c += 256) {
+        const int r = c & (LNP_ROWS - 1), po = c / LNP_ROWS;          // po = plane * NO + octet
+        const long row = row0 + r;
+        if (row < rows) {
+            const int oc = po >= NO ? po - NO : po;
+            (po >= NO ? pm : ph)[(size_t)oc * rows + row] = cell[po * LNP_RS + r];
+        }
+    }
+}
+
+// y as l3d_layernorm_ref, plus img = the activation image of y (l3d_f16_act_bytes(rows, C) bytes) for l3d_pointwise_conv_f16
+extern "C" int l3d_layernorm_planes(const float *x, const float *a, const float *b, float eps, long rows, int C, float *y,
+                                    void *img, l3d_stream_t stream)
+{
+    L3D_REQUIRE(x && a && b && y && img && rows > 0 && C > 1);
+    if (C % 8 || C > 512 || ((((size_t)x) | ((size_t)y) | ((size_t)a) | ((size_t)b) | ((size_t)img)) & 15)) return L3D_ERR_UNSUPPORTED;
+    const size_t pb = (size_t)(C / 8) * (size_t)rows * 16;
+    unsigned char *d = (unsigned char *)img;
+    const size_t lds = (size_t)2 * (C / 8) * LNP_RS * 16 + 64;
+    dim3 grid((unsigned)((rows + LNP_ROWS - 1) / LNP_ROWS)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const int vpl = (C / 4 + 63) / 64;
+    if (vpl <= 1) hipLaunchKernelGGL(layernorm_planes_kernel<1>, grid, block, lds, st, x, a, b, eps, rows, C, y, (uint4 *)d, (uint4 *)(d + pb), (float *)(d + 2 * pb));
+    else          hipLaunchKernelGGL(layernorm_planes_kernel<2>, grid, block, lds, st, x, a, b, eps, rows, C, y, (uint4 *)d, (uint4 *)(d + pb), (float *)(d + 2 * pb));
+    return l3d_check_launch();
+}

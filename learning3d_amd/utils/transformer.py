@@ -40,6 +40,20 @@ def _linear_cf(lin, x, channel_last, relu=False, out_scale=None):
     """Linear over points as a 1x1 conv: x [B,N,Cin] (channel_last) or [B,Cin,N] -> [B,Cout,N];
     out_scale multiplies the whole result (weights and bias) in the kernel's epilogue."""
     from ..models import _fused
+    img = getattr(x, "_l3d_planes", None) if channel_last else None
+    if img is not None and _fused.gemm_arith() == "f16x2" and _fused.f16_eligible(lin.in_features, lin.out_features, x.size(1)):
+        # x is a LayerNorm output that came with its fp16 plane image: f16x2 kernel, no pass over x
+        key = (lin.weight.data_ptr(), lin.weight._version, str(lin.weight.device))
+        c16 = getattr(lin, "_l3d_split_f16", None)
+        if c16 is None or c16[0] != key:
+            c16 = (key, _fused.split_weights_f16(lin.weight.detach().float().contiguous()))
+            lin._l3d_split_f16 = c16
+        bias = lin.bias.detach() if lin.bias is not None else None
+        scale = None
+        if out_scale is not None:
+            scale = torch.full((lin.out_features,), float(out_scale), dtype=torch.float32, device=x.device)
+            bias = bias * float(out_scale) if bias is not None else None
+        return _fused.pointwise_conv_f16(img, x.size(0), x.size(1), c16[1], lin.in_features, lin.out_features, scale, bias, relu=relu)
     key = (lin.weight.data_ptr(), lin.weight._version, str(lin.weight.device))
     cache = getattr(lin, "_l3d_split", None)
     if cache is None or cache[0] != key:
@@ -81,10 +95,20 @@ class LayerNorm(nn.Module):
         if (x.is_cuda and x.dtype == torch.float32 and C % 4 == 0 and 1 < C <= 2048
                 and not (torch.is_grad_enabled() and (x.requires_grad or self.a_2.requires_grad))):
             from .._lib import check, lib, ptr, stream_ptr
+            from ..models import _fused
             xc = x.contiguous()
             y = torch.empty_like(xc)
+            rows = xc.numel() // C
+            if (_fused.gemm_arith() == "f16x2" and x.dim() == 3 and C % 16 == 0 and C <= 512 and x.size(1) % 256 == 0):
+                # also emit y as the fp16 plane image of the f16x2 conv kernel: the Linear layers that read this output
+                # (_linear_cf) then need no split pass; the image rides on the tensor object
+                img = torch.empty(lib().l3d_f16_act_bytes(rows, C), dtype=torch.uint8, device=xc.device)
+                check(lib().l3d_layernorm_planes(ptr(xc), ptr(self.a_2.detach().contiguous()), ptr(self.b_2.detach().contiguous()),
+                                                 float(self.eps), rows, C, ptr(y), ptr(img), stream_ptr()), "l3d_layernorm_planes")
+                y._l3d_planes = img
+                return y
             check(lib().l3d_layernorm_ref(ptr(xc), ptr(self.a_2.detach().contiguous()), ptr(self.b_2.detach().contiguous()),
-                                          float(self.eps), xc.numel() // C, C, ptr(y), stream_ptr()), "l3d_layernorm_ref")
+                                          float(self.eps), rows, C, ptr(y), stream_ptr()), "l3d_layernorm_ref")
             return y
         mean = x.mean(-1, keepdim=True)
         std = x.std(-1, keepdim=True)

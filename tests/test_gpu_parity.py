@@ -1622,3 +1622,31 @@ def test_resident_registration_feed():
     assert lab is None and tmpl.shape == (10, 64, 3)
     want = torch.matmul(tmpl, igt[:, :3, :3].transpose(1, 2)) + igt[:, None, :3, 3]
     np.testing.assert_allclose(src.cpu().numpy(), want.cpu().numpy(), atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_layernorm_planes_matches_layernorm_and_feeds_conv_f16():
+    """l3d_layernorm_planes: y equals l3d_layernorm_ref bit for bit, and its fp16 plane image drives l3d_pointwise_conv_f16
+    to the same result as the f16x2 conv on a split of y (the image is y 2^T with T from the layer's parameters)."""
+    from learning3d_amd._lib import check, lib, ptr, stream_ptr
+    from learning3d_amd.models import _fused
+    rng = np.random.default_rng(17)
+    for (B, N, C, amp) in [(2, 256, 512, 1.0), (1, 512, 128, 40.0), (3, 256, 64, 1e-3)]:
+        x = dev((rng.standard_normal((B, N, C)) * amp + amp).astype(np.float32))
+        a = dev((rng.standard_normal(C) * 0.5 + 1).astype(np.float32))
+        b = dev((rng.standard_normal(C) * 0.2).astype(np.float32))
+        y0 = torch.empty_like(x)
+        check(lib().l3d_layernorm_ref(ptr(x), ptr(a), ptr(b), 1e-6, B * N, C, ptr(y0), stream_ptr()), "ln")
+        y1 = torch.empty_like(x)
+        img = torch.empty(lib().l3d_f16_act_bytes(B * N, C), dtype=torch.uint8, device="cuda")
+        check(lib().l3d_layernorm_planes(ptr(x), ptr(a), ptr(b), 1e-6, B * N, C, ptr(y1), ptr(img), stream_ptr()), "lnp")
+        assert torch.equal(y0, y1)
+        w = dev((rng.standard_normal((256, C)) / C ** 0.5).astype(np.float32))
+        wimg = _fused.split_weights_f16(w)
+        got = _fused.pointwise_conv_f16(img, B, N, wimg, C, 256).cpu().numpy()
+        want = np.einsum("oc,bnc->bon", w.cpu().numpy().astype(np.float64), y0.cpu().numpy().astype(np.float64))
+        ref = _fused.pointwise_conv_f16(_fused.split_rows_f16(y0), B, N, wimg, C, 256).cpu().numpy()
+        scale = np.abs(want).max()
+        assert np.abs(got - want).max() <= 2.0 * np.abs(ref - want).max() + 1e-6 * scale
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-6 * scale)
+    _fused.check_range(sync=True)
