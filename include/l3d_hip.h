@@ -271,10 +271,12 @@ int l3d_attention_forward_strided(const float *q, const float *k, const float *v
 /* The same with both GEMMs as f16x2 on the fp16 matrix cores (three fp16 MFMA products per fp32 product instead of bf16x3's
  * six, fp32-level accuracy; attention_f16.hip).  fp16's range is handled inside: one extra pass reads max|q|, max|k|, max|v|
  * into `workspace` (>= 16 bytes of device memory, contents irrelevant) and the operands are scaled by powers of two from
- * them.  Same shapes and strides as l3d_attention_forward_strided. */
+ * them.  Same shapes and strides as l3d_attention_forward_strided.  Output: ctx (fp32, may be NULL) and / or ctx_img, the
+ * context as the fp16 activation image of l3d_pointwise_conv_f16 (l3d_f16_act_bytes(B N, H D) bytes; may be NULL): the
+ * output projection then needs no split pass (|ctx| <= max|v| fixes the plane scale). */
 int l3d_attention_forward_f16(const float *q, const float *k, const float *v, int B, int H, int D, int N, int M,
                               long q_bstride, long k_bstride, long v_bstride, float scale, void *workspace, float *ctx,
-                              l3d_stream_t stream);
+                              void *ctx_img, l3d_stream_t stream);
 
 /* LayerNorm of DCP's pointer network == utils/transformer.py:109-119 (unbiased std, eps added to std):
  *   y[r][:] = a * (x[r][:] - mean_r) / (std_r + eps) + b,   x, y [rows][C] fp32, C % 4 == 0, C <= 2048. */
@@ -408,6 +410,12 @@ int l3d_split_f16_rows(const float *x, long rows, int C, int channel_first, int 
 int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
                            int shift_bstride, int B, int Cin, int Cout, int N, int relu, float *y,
                            l3d_stream_t stream);
+/* The same layer with its OUTPUT written as an activation image (l3d_f16_act_bytes(B N, Cout) bytes) for the next f16x2
+ * layer instead of fp32 [B,Cout,N]: chains of Linear / 1x1-conv layers stay on the fp16 matrix cores with no split pass in
+ * between.  obs: two device floats {max|shift|, max|scale|} (max|scale| = 1 without a scale); with the weight image's
+ * row-sum maximum and the input image's scale the kernel bounds its outputs and fixes the plane scale itself. */
+int l3d_pointwise_conv_f16_planes(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
+                                  const float *obs, int B, int Cin, int Cout, int N, int relu, void *out_img, l3d_stream_t stream);
 
 /* PCN's folding decoder == models/pcn.py:84-101 (conv5 -> ReLU -> conv6 -> ReLU -> conv7, + centre) in one
  * kernel (fold_mlp.hip): g [B,N,5] = (grid u, v, centre x, y, z) per fine point, w5g [512,5] = conv5's

@@ -64,7 +64,7 @@ SIGNATURES = {
     "l3d_soft_correspondence": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
     "l3d_attention_forward": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P],
     "l3d_attention_forward_strided": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _P],
-    "l3d_attention_forward_f16": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _P, _P],
+    "l3d_attention_forward_f16": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _P, _P, _P],
     "l3d_layernorm_ref": [_P, _P, _P, _F, _L, _I, _P, _P],
     "l3d_layernorm_planes": [_P, _P, _P, _F, _L, _I, _P, _P, _P],
     "l3d_add_transposed": [_P, _P, _I, _I, _I, _P, _P],
@@ -87,6 +87,7 @@ SIGNATURES = {
     "l3d_conv_f16_split_weights": [_P, _I, _I, _P, _P],
     "l3d_split_f16_rows": [_P, _L, _I, _I, _I, _P, _P, _P],
     "l3d_pointwise_conv_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "l3d_pointwise_conv_f16_planes": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "l3d_fold_mlp": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P],
     "l3d_fold_mlp_f16": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P],
     "l3d_channel_stats": [_P, _I, _I, _L, _P, _P],

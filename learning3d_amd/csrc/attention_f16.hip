@@ -76,7 +76,8 @@ template <int ND /* D / 32 */>
 __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                                const float *__restrict__ v, int H, int N, int M,
                                                                float scale, float *__restrict__ ctx, long q_bs, long k_bs,
-                                                               long v_bs, const unsigned *__restrict__ amax)
+                                                               long v_bs, const unsigned *__restrict__ amax,
+                                                               uint2 *__restrict__ cph, uint2 *__restrict__ cpm, float *__restrict__ cinv)
 {
     constexpr int D = ND * 32;
     constexpr int NCH = D / 16;                        // QK^T chunks of 16 channels
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = ldexpf(1.f / l_tot, -(Sv + 12));
     const int i = i0 + wave * 32 + (lane & 31);
-    if (i < N) {
+    if (i < N && ctx) {
         float *cb = ctx + ((size_t)b * H + h) * D * N + i;
 #pragma unroll
         for (int dt = 0; dt < ND; dt++)
@@ -289,14 +290,43 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
                 cb[(size_t)d * N] = o[dt][r] * inv;
             }
     }
+    // The context as the fp16 plane image conv_f16.hip consumes ([H D / 8][B N][8], h | m' of ctx 2^T): a context vector is
+    // a convex combination of value vectors, so |ctx| <= max|v| and T = S_v + 9 puts max|v| 2^T in [2^11, 2^12) -- the
+    // output projection then runs as f16x2 with no split pass.  A lane holds 4 consecutive channels of an octet (its
+    // partner lane ^ 32 the other 4): each writes its 8-byte half of the 16-byte cell.
+    if (cph) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && t == 0) *cinv = ldexpf(1.f, -(Sv + 9));
+        if (i < N) {
+            const float invp = ldexpf(1.f / l_tot, -3);                    // o 2^-(Sv+12) / l  *  2^(Sv+9)
+            const size_t rows = (size_t)gridDim.z * N, row = (size_t)b * N + i;
+            const int half = lane >> 5;
+#pragma unroll
+            for (int dt = 0; dt < ND; dt++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const int oc = (h * D + 32 * dt + 8 * gq) >> 3;
+                    uint32_t h0, h1, m0, m1;
+                    af_split_x(o[dt][4 * gq], o[dt][4 * gq + 1], invp, h0, m0);
+                    af_split_x(o[dt][4 * gq + 2], o[dt][4 * gq + 3], invp, h1, m1);
+                    cph[((size_t)oc * rows + row) * 2 + half] = make_uint2(h0, h1);
+                    cpm[((size_t)oc * rows + row) * 2 + half] = make_uint2(m0, m1);
+                }
+        }
+    }
 }
 
-// workspace: 16 bytes of device memory (the three maxima); everything else as l3d_attention_forward_strided
+// workspace: 16 bytes of device memory (the three maxima); ctx [B, H D, N] fp32 and / or ctx_img = the context as an fp16
+// activation image (l3d_f16_act_bytes(B N, H D) bytes) for l3d_pointwise_conv_f16; everything else as
+// l3d_attention_forward_strided
 extern "C" int l3d_attention_forward_f16(const float *q, const float *k, const float *v, int B, int H, int D, int N, int M,
                                          long q_bstride, long k_bstride, long v_bstride, float scale, void *workspace,
-                                         float *ctx, l3d_stream_t stream)
+                                         float *ctx, void *ctx_img, l3d_stream_t stream)
 {
-    L3D_REQUIRE(q && k && v && ctx && workspace && B > 0 && H > 0 && D > 0 && N > 0 && M > 0);
+    L3D_REQUIRE(q && k && v && (ctx || ctx_img) && workspace && B > 0 && H > 0 && D > 0 && N > 0 && M > 0);
+    if (ctx_img && (((size_t)ctx_img) & 15)) return L3D_ERR_UNSUPPORTED;
+    const size_t cpb = (size_t)(H * D / 8) * ((size_t)B * N) * 16;
+    uint2 *cph = (uint2 *)ctx_img, *cpm = ctx_img ? (uint2 *)((unsigned char *)ctx_img + cpb) : nullptr;
+    float *cinv = ctx_img ? (float *)((unsigned char *)ctx_img + 2 * cpb) : nullptr;
     if ((D != 32 && D != 64 && D != 128) || B > 65535 || H > 65535 || (((size_t)v) & 15) || (v_bstride & 3))
         return L3D_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -305,8 +335,8 @@ extern "C" int l3d_attention_forward_f16(const float *q, const float *k, const f
     hipLaunchKernelGGL(at_absmax3_kernel, dim3(512, 3), dim3(256), 0, st, q, k, v, q_bstride, k_bstride, v_bstride,
                        (long)H * D * N, (long)H * D * M, B, amax);
     dim3 grid(l3d_divup(N, AF_TQ), H, B), block(256);
-    if (D == 32)      hipLaunchKernelGGL(attention_f16_kernel<1>, grid, block, AF_LDS, st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax);
-    else if (D == 64) hipLaunchKernelGGL(attention_f16_kernel<2>, grid, block, AF_LDS, st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax);
-    else              hipLaunchKernelGGL(attention_f16_kernel<4>, grid, block, AF_LDS, st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax);
+    if (D == 32)      hipLaunchKernelGGL(attention_f16_kernel<1>, grid, block, AF_LDS, st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax, cph, cpm, cinv);
+    else if (D == 64) hipLaunchKernelGGL(attention_f16_kernel<2>, grid, block, AF_LDS, st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax, cph, cpm, cinv);
+    else              hipLaunchKernelGGL(attention_f16_kernel<4>, grid, block, AF_LDS, st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax, cph, cpm, cinv);
     return l3d_check_launch();
 }

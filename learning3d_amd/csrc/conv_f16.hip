@@ -36,6 +36,7 @@
 // padding of the regions (worth 25 % in the bare read + MFMA loop, nothing here); non-temporal epilogue stores (-1 us).
 #include "common.h"
 #include "split_bf16.h"          // f32x4 / f32x16 typedefs
+#include "split_f16.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
@@ -94,6 +95,23 @@ __global__ __launch_bounds__(256) void cf_split_w_kernel(const float *__restrict
     pH[(size_t)o * R + row] = *(const uint4 *)H;
     pHs[(size_t)o * R + row] = *(const uint4 *)Hs;
     pM[(size_t)o * R + row] = *(const uint4 *)M;
+}
+
+// max over rows of sum_c |w[r][c]| (float bits, atomicMax): with |x| <= X it bounds every output of the layer,
+// |y_r| <= |shift_r| + |scale_r| X sum_c |w_rc| -- what lets conv_f16_kernel write its OUTPUT as fp16 planes with a scale
+// fixed before the first tile is computed.  One wave per row.
+__global__ __launch_bounds__(256) void cf_rowsum_kernel(const float *__restrict__ src, int R, int C, unsigned *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    float s = 0.f;
+    if (row < R)
+        for (int c = lane; c < C; c += 64) s += fabsf(src[(size_t)row * C + c]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    __shared__ float ws[4];
+    if (lane == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(ws[0], ws[1]), fmaxf(ws[2], ws[3]))));
 }
 
 // x [R][C] (row-major, channel-last) or, with CFIRST, x [B][C][Npts] (R = B * Npts) -> h / m' planes
@@ -209,7 +227,8 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
                                                        const uint4 *__restrict__ wM, const float *__restrict__ winv,
                                                        const float *__restrict__ xinv, const float *__restrict__ scale, const float *__restrict__ shift,
                                                        int shift_bstride, int Bn, int Cin, int Cout, int N, int relu,
-                                                       float *__restrict__ y)
+                                                       float *__restrict__ y, uint2 *__restrict__ oph, uint2 *__restrict__ opm,
+                                                       float *__restrict__ oinv, const float *__restrict__ obs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -341,6 +360,48 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
 
     // ---- epilogue: D[co = 32a + (r&3) + 8(r>>2) + 4(lane>>5)][n = 32c + (lane&31)]
     const float inv = *winv * *xinv;             // 2^-S 2^-T: exact
+    if (oph) {
+        // Output as the fp16 plane image of the NEXT f16x2 layer ([Cout/8][B N][8], h | m' of y 2^To) instead of fp32: the
+        // scale is fixed from a bound, |y| <= max|shift| + max|scale| (max_r sum_c |w_rc|) max|x| with max|x| <= 2^12 2^-T
+        // (obs = {max|shift|, max|scale|}, the row-sum maximum sits behind 2^-S in the weight image).  A lane holds 4
+        // consecutive channels of an octet, its partner (lane ^ 32) the other 4: each writes its 8-byte half of the cell.
+        float bound = fmaf(obs[1] * winv[2], 4096.0f * *xinv, obs[0]) * 1.000001f;
+        int e = 0;
+        if (bound > 0.f && bound < 3.0e38f) (void)frexpf(bound, &e);
+        const float up = ldexpf(1.f, 12 - e);
+        if (blockIdx.x == 0 && t == 0) *oinv = ldexpf(1.f, e - 12);
+        const size_t rows = (size_t)Bn * N;
+        const int half = lane >> 5;
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                const int cob = co0 + wm * 64 + a * 32 + 8 * gq + 4 * half;          // this lane's 4 channels: cob .. cob + 3
+                float sc[4], sh[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    sc[u] = (scale ? scale[cob + u] : 1.f) * inv;
+                    sh[u] = shift ? shift[cob + u] : 0.f;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        v[u] = acc[a][c][4 * gq + u] * sc[u] + sh[u];
+                        if (relu) v[u] = l3d_act(v[u], relu);
+                    }
+                    uint32_t h0, h1, m0, m1;
+                    af_split_x(v[0], v[1], up, h0, m0);
+                    af_split_x(v[2], v[3], up, h1, m1);
+                    const size_t row = (size_t)b * N + n0 + wn * 128 + c * 32 + (lane & 31);
+                    const size_t cellh = ((size_t)(cob >> 3) * rows + row) * 2 + half;
+                    oph[cellh] = make_uint2(h0, h1);
+                    opm[cellh] = make_uint2(m0, m1);
+                }
+            }
+        return;
+    }
     float *yb = y + (size_t)b * Cout * N;
 #pragma unroll
     for (int a = 0; a < 2; a++)
@@ -365,7 +426,7 @@ extern "C" size_t l3d_f16_plane_bytes(long rows, int cols)
 }
 
 // weights [Cout][Cin] fp32 -> dst = H | Hs | M planes (3 x l3d_f16_plane_bytes) followed by 16 bytes holding 2^-S (fp32)
-// and the |w| maximum's bits (scratch)
+// then the |w| maximum's bits (scratch) and max_r sum_c |w_rc| (fp32, for layers that write fp16 planes)
 extern "C" size_t l3d_conv_f16_weight_bytes(int Cout, int Cin)
 {
     return 3 * l3d_f16_plane_bytes(Cout, Cin) + 16;
@@ -379,10 +440,11 @@ extern "C" int l3d_conv_f16_split_weights(const float *w, int Cout, int Cin, voi
     unsigned char *d = (unsigned char *)dst;
     float *inv = (float *)(d + 3 * pb);
     unsigned *amax = (unsigned *)(d + 3 * pb + 4);
-    if (hipMemsetAsync(amax, 0, 4, st) != hipSuccess) return L3D_ERR_LAUNCH;
+    if (hipMemsetAsync(amax, 0, 8, st) != hipSuccess) return L3D_ERR_LAUNCH;       // |w| maximum and row-sum maximum
     const size_t n = (size_t)Cout * Cin;
     const long nblk = l3d_divup((long)n, 256);
     hipLaunchKernelGGL(cf_absmax_kernel, dim3((unsigned)(nblk > 256 ? 256 : nblk)), dim3(256), 0, st, w, n, amax);
+    hipLaunchKernelGGL(cf_rowsum_kernel, dim3((unsigned)l3d_divup(Cout, 4)), dim3(256), 0, st, w, Cout, Cin, amax + 1);
     const long cells = (long)Cout * ((Cin + 7) / 8);
     hipLaunchKernelGGL(cf_split_w_kernel, dim3((unsigned)l3d_divup(cells, 256)), dim3(256), 0, st, w, Cout, Cin, (const unsigned *)amax,
                        (uint4 *)d, (uint4 *)(d + pb), (uint4 *)(d + 2 * pb), inv);
@@ -421,18 +483,39 @@ extern "C" int l3d_split_f16_rows(const float *x, long rows, int C, int channel_
 }
 
 // x_act: an activation image (l3d_f16_act_bytes), w_planes: a weight image (l3d_conv_f16_weight_bytes)
+static int cf_launch(const void *x_planes, const void *w_planes, const float *scale, const float *shift, int shift_bstride, int B,
+                     int Cin, int Cout, int N, int relu, float *y, void *out_img, const float *obs, hipStream_t st)
+{
+    if (Cout % CF_TM || N % CF_TN || Cin % 16 || B > 65535 || (((size_t)x_planes) & 15) || (((size_t)w_planes) & 15) ||
+        (((size_t)out_img) & 15))
+        return L3D_ERR_UNSUPPORTED;
+    const size_t xpb = l3d_f16_plane_bytes((long)B * N, Cin), wpb = l3d_f16_plane_bytes(Cout, Cin);
+    const size_t opb = l3d_f16_plane_bytes((long)B * N, Cout);
+    const unsigned char *xp = (const unsigned char *)x_planes, *wp = (const unsigned char *)w_planes;
+    unsigned char *op = (unsigned char *)out_img;
+    dim3 grid((unsigned)((size_t)(N / CF_TN) * (Cout / CF_TM) * B)), block(512);
+    hipLaunchKernelGGL(conv_f16_kernel, grid, block, CF_LDS, st, (const uint4 *)xp, (const uint4 *)(xp + xpb),
+                       (const uint4 *)wp, (const uint4 *)(wp + wpb), (const uint4 *)(wp + 2 * wpb), (const float *)(wp + 3 * wpb),
+                       (const float *)(xp + 2 * xpb), scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, (uint2 *)op,
+                       op ? (uint2 *)(op + opb) : nullptr, op ? (float *)(op + 2 * opb) : nullptr, obs);
+    return l3d_check_launch();
+}
+
 extern "C" int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
                                       int shift_bstride, int B, int Cin, int Cout, int N, int relu, float *y,
                                       l3d_stream_t stream)
 {
     L3D_REQUIRE(x_planes && w_planes && y && B > 0 && Cin > 0 && Cout > 0 && N > 0);
-    if (Cout % CF_TM || N % CF_TN || Cin % 16 || B > 65535 || (((size_t)x_planes) & 15) || (((size_t)w_planes) & 15))
-        return L3D_ERR_UNSUPPORTED;
-    const size_t xpb = l3d_f16_plane_bytes((long)B * N, Cin), wpb = l3d_f16_plane_bytes(Cout, Cin);
-    const unsigned char *xp = (const unsigned char *)x_planes, *wp = (const unsigned char *)w_planes;
-    dim3 grid((unsigned)((size_t)(N / CF_TN) * (Cout / CF_TM) * B)), block(512);
-    hipLaunchKernelGGL(conv_f16_kernel, grid, block, CF_LDS, (hipStream_t)stream, (const uint4 *)xp, (const uint4 *)(xp + xpb),
-                       (const uint4 *)wp, (const uint4 *)(wp + wpb), (const uint4 *)(wp + 2 * wpb), (const float *)(wp + 3 * wpb),
-                       (const float *)(xp + 2 * xpb), scale, shift, shift_bstride, B, Cin, Cout, N, relu, y);
-    return l3d_check_launch();
+    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, nullptr, nullptr, (hipStream_t)stream);
+}
+
+// The same layer with its OUTPUT written as an activation image (l3d_f16_act_bytes(B N, Cout) bytes) for the next f16x2 layer
+// instead of fp32 [B,Cout,N].  obs: two device floats {max|shift|, max|scale|} (max|scale| = 1 without a scale) from which, with
+// the weight image's row-sum maximum and the input image's scale, the kernel bounds its outputs and fixes the plane scale.
+extern "C" int l3d_pointwise_conv_f16_planes(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
+                                             const float *obs, int B, int Cin, int Cout, int N, int relu, void *out_img,
+                                             l3d_stream_t stream)
+{
+    L3D_REQUIRE(x_planes && w_planes && out_img && obs && B > 0 && Cin > 0 && Cout > 0 && N > 0);
+    return cf_launch(x_planes, w_planes, scale, shift, 0, B, Cin, Cout, N, relu, nullptr, out_img, obs, (hipStream_t)stream);
 }

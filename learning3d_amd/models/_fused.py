@@ -154,10 +154,21 @@ def f16_eligible(Cin, Cout, N):
     return Cout % 256 == 0 and N % 256 == 0 and Cin % 16 == 0 and Cin >= 32
 
 
-def pointwise_conv_f16(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=None, relu=False):
-    """l3d_pointwise_conv_f16 on pre-split operands -> y [B,Cout,N] fp32"""
+def pointwise_conv_f16(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=None, relu=False, out_planes=False):
+    """l3d_pointwise_conv_f16 on pre-split operands -> y [B,Cout,N] fp32; out_planes=True: the output as an fp16 activation
+    image (uint8 tensor) for the next f16x2 layer instead (l3d_pointwise_conv_f16_planes; shift must be [Cout] or None)."""
     scale = f32c(scale) if scale is not None else None
     shift = f32c(shift) if shift is not None else None
+    if out_planes:
+        if shift is not None and shift.dim() != 1:
+            raise ValueError("plane output takes a per-channel shift only")
+        dev = x_planes.device
+        obs = torch.stack([shift.abs().max() if shift is not None else torch.zeros((), device=dev),
+                           scale.abs().max() if scale is not None else torch.ones((), device=dev)]).float()
+        img = torch.empty(lib().l3d_f16_act_bytes(B * N, Cout), dtype=torch.uint8, device=dev)
+        check(lib().l3d_pointwise_conv_f16_planes(ptr(x_planes), ptr(w_planes), ptr(scale), ptr(shift), ptr(obs), B, Cin, Cout, N,
+                                                  int(relu), ptr(img), stream_ptr()), "l3d_pointwise_conv_f16_planes")
+        return img
     bstride = Cout if (shift is not None and shift.dim() == 2) else 0
     y = torch.empty((B, Cout, N), dtype=torch.float32, device=x_planes.device)
     check(lib().l3d_pointwise_conv_f16(ptr(x_planes), ptr(w_planes), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N, int(relu),

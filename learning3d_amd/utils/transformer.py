@@ -36,12 +36,18 @@ def _fast_linear_ok(lin, x, n_points):
             and _fused.split_eligible(lin.in_features, lin.out_features, n_points))
 
 
-def _linear_cf(lin, x, channel_last, relu=False, out_scale=None):
+def _linear_cf(lin, x, channel_last, relu=False, out_scale=None, planes=None, out_planes=False):
     """Linear over points as a 1x1 conv: x [B,N,Cin] (channel_last) or [B,Cin,N] -> [B,Cout,N];
-    out_scale multiplies the whole result (weights and bias) in the kernel's epilogue."""
+    out_scale multiplies the whole result (weights and bias) in the kernel's epilogue.
+    planes = (image, B, N): the input exists only as an fp16 plane image (x is None); out_planes: return (image, B, N) of the
+    output instead of the fp32 tensor (f16x2 path only; None if that path does not apply)."""
     from ..models import _fused
-    img = getattr(x, "_l3d_planes", None) if channel_last else None
-    if img is not None and _fused.gemm_arith() == "f16x2" and _fused.f16_eligible(lin.in_features, lin.out_features, x.size(1)):
+    if planes is not None:
+        img, nb_, np_ = planes
+    else:
+        img = getattr(x, "_l3d_planes", None) if channel_last else None
+        nb_, np_ = (x.size(0), x.size(1)) if img is not None else (0, 0)
+    if img is not None and _fused.gemm_arith() == "f16x2" and _fused.f16_eligible(lin.in_features, lin.out_features, np_):
         # x is a LayerNorm output that came with its fp16 plane image: f16x2 kernel, no pass over x
         key = (lin.weight.data_ptr(), lin.weight._version, str(lin.weight.device))
         c16 = getattr(lin, "_l3d_split_f16", None)
@@ -51,9 +57,14 @@ def _linear_cf(lin, x, channel_last, relu=False, out_scale=None):
         bias = lin.bias.detach() if lin.bias is not None else None
         scale = None
         if out_scale is not None:
-            scale = torch.full((lin.out_features,), float(out_scale), dtype=torch.float32, device=x.device)
+            scale = torch.full((lin.out_features,), float(out_scale), dtype=torch.float32, device=img.device)
             bias = bias * float(out_scale) if bias is not None else None
-        return _fused.pointwise_conv_f16(img, x.size(0), x.size(1), c16[1], lin.in_features, lin.out_features, scale, bias, relu=relu)
+        if out_planes:
+            return (_fused.pointwise_conv_f16(img, nb_, np_, c16[1], lin.in_features, lin.out_features, scale, bias, relu=relu,
+                                              out_planes=True), nb_, np_)
+        return _fused.pointwise_conv_f16(img, nb_, np_, c16[1], lin.in_features, lin.out_features, scale, bias, relu=relu)
+    if out_planes:
+        return None
     key = (lin.weight.data_ptr(), lin.weight._version, str(lin.weight.device))
     cache = getattr(lin, "_l3d_split", None)
     if cache is None or cache[0] != key:
@@ -186,11 +197,22 @@ class MultiHeadedAttention(nn.Module):
             if FLASH_ATTENTION and self.d_k in (32, 64, 128):
                 from .._lib import check, lib, ptr, stream_ptr
                 from ..models import _fused
-                ctx = torch.empty((nb, C_, n_q), dtype=torch.float32, device=q.device)
-                if _fused.gemm_arith() == "f16x2":             # both GEMMs as f16x2; operand scales from the tensors' maxima
+                out_lin = self.linears[-1]
+                if (_fused.gemm_arith() == "f16x2" and C_ % 16 == 0
+                        and _fused.f16_eligible(out_lin.in_features, out_lin.out_features, n_q)):
+                    # both GEMMs as f16x2 (operand scales from the tensors' maxima); the context leaves the kernel as the
+                    # fp16 plane image of the f16x2 conv kernel, so the output projection needs no split pass either
+                    img = torch.empty(lib().l3d_f16_act_bytes(nb * n_q, C_), dtype=torch.uint8, device=q.device)
                     check(lib().l3d_attention_forward_f16(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
                                                           q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),
-                                                          ptr(_attention_workspace(q.device)), ptr(ctx), stream_ptr()),
+                                                          ptr(_attention_workspace(q.device)), None, ptr(img), stream_ptr()),
+                          "l3d_attention_forward_f16")
+                    return _linear_cf(out_lin, None, True, planes=(img, nb, n_q)).transpose(1, 2)     # [B,N,C] view
+                ctx = torch.empty((nb, C_, n_q), dtype=torch.float32, device=q.device)
+                if _fused.gemm_arith() == "f16x2":
+                    check(lib().l3d_attention_forward_f16(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
+                                                          q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),
+                                                          ptr(_attention_workspace(q.device)), ptr(ctx), None, stream_ptr()),
                           "l3d_attention_forward_f16")
                 else:
                     check(lib().l3d_attention_forward_strided(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
@@ -218,6 +240,11 @@ class PositionwiseFeedForward(nn.Module):
 
     def forward(self, x):
         if x.dim() == 3 and _fast_linear_ok(self.w_1, x, x.size(1)) and _fast_linear_ok(self.w_2, x, x.size(1)):
+            from ..models import _fused
+            if _fused.gemm_arith() == "f16x2" and _fused.f16_eligible(self.w_2.in_features, self.w_2.out_features, x.size(1)):
+                hp = _linear_cf(self.w_1, x, True, relu=True, out_planes=True)      # hidden layer as fp16 planes, never fp32
+                if hp is not None:
+                    return _linear_cf(self.w_2, None, True, planes=hp).transpose(1, 2)
             h = _linear_cf(self.w_1, x, True, relu=True)                  # [B,d_ff,N]
             return _linear_cf(self.w_2, h, False).transpose(1, 2)         # [B,N,d_model] view
         return self.w_2(F.relu(self.w_1(x)))

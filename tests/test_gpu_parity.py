@@ -971,7 +971,7 @@ def test_flash_attention_vs_fp64():
         ws = torch.zeros(4, dtype=torch.int32, device=qd.device)
         out16 = torch.empty_like(qd)
         check(lib().l3d_attention_forward_f16(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, H * D * N, H * D * M, H * D * M,
-                                              float(1 / np.sqrt(D)), ptr(ws), ptr(out16), stream_ptr()), "l3d_attention_forward_f16")
+                                              float(1 / np.sqrt(D)), ptr(ws), ptr(out16), None, stream_ptr()), "l3d_attention_forward_f16")
         got16 = out16.cpu().numpy().reshape(B, H, D, N)
         np.testing.assert_allclose(got16, want, rtol=1e-5, atol=2e-6)
         e3, e16 = out.cpu().numpy().reshape(B, H, D, N) - want, got16 - want
@@ -991,7 +991,7 @@ def test_flash_attention_vs_fp64():
         ws = torch.zeros(4, dtype=torch.int32, device=qd.device)
         out16 = torch.empty_like(qd)
         check(lib().l3d_attention_forward_f16(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, H * D * N, H * D * M, H * D * M,
-                                              float(sc), ptr(ws), ptr(out16), stream_ptr()), "l3d_attention_forward_f16")
+                                              float(sc), ptr(ws), ptr(out16), None, stream_ptr()), "l3d_attention_forward_f16")
         np.testing.assert_allclose(out16.cpu().numpy().reshape(B, H, D, N), want, rtol=2e-5, atol=2e-6 * sv)
 
 
@@ -1649,4 +1649,53 @@ def test_layernorm_planes_matches_layernorm_and_feeds_conv_f16():
         scale = np.abs(want).max()
         assert np.abs(got - want).max() <= 2.0 * np.abs(ref - want).max() + 1e-6 * scale
         np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-6 * scale)
+    _fused.check_range(sync=True)
+
+
+@pytest.mark.gpu
+def test_attention_f16_context_planes_feed_conv_f16():
+    """l3d_attention_forward_f16 can hand its context to the output projection as an fp16 plane image (scale from max|v|):
+    the f16x2 conv on that image must equal the projection of the fp32 context to fp32-level accuracy."""
+    from learning3d_amd._lib import check, lib, ptr, stream_ptr
+    from learning3d_amd.models import _fused
+    rng = np.random.default_rng(23)
+    for (B, H, D, N, M, vs) in [(2, 4, 128, 256, 256, 1.0), (1, 4, 64, 512, 300, 250.0), (2, 8, 32, 256, 256, 1e-3)]:
+        C = H * D
+        q, k = (dev(rng.standard_normal((B, C, n)).astype(np.float32)) for n in (N, M))
+        v = dev((rng.standard_normal((B, C, M)) * vs).astype(np.float32))
+        ws = torch.zeros(4, dtype=torch.int32, device="cuda")
+        ctx = torch.empty((B, C, N), dtype=torch.float32, device="cuda")
+        img = torch.empty(lib().l3d_f16_act_bytes(B * N, C), dtype=torch.uint8, device="cuda")
+        check(lib().l3d_attention_forward_f16(ptr(q), ptr(k), ptr(v), B, H, D, N, M, C * N, C * M, C * M, float(1 / np.sqrt(D)),
+                                              ptr(ws), ptr(ctx), ptr(img), stream_ptr()), "att")
+        w = dev((rng.standard_normal((256, C)) / C ** 0.5).astype(np.float32))
+        got = _fused.pointwise_conv_f16(img, B, N, _fused.split_weights_f16(w), C, 256).cpu().numpy()
+        want = np.einsum("oc,bcn->bon", w.cpu().numpy().astype(np.float64), ctx.cpu().numpy().astype(np.float64))
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=3e-6 * np.abs(want).max())
+    _fused.check_range(sync=True)
+
+
+@pytest.mark.gpu
+def test_conv_f16_plane_output_chains():
+    """Two f16x2 layers chained through an fp16 plane image (l3d_pointwise_conv_f16_planes -> l3d_pointwise_conv_f16): the
+    hidden layer is never written in fp32; its plane scale comes from a bound the kernel derives from the weights' row
+    sums and the input image's scale.  Against fp64, with hidden activations from tiny to large."""
+    from learning3d_amd.models import _fused
+    rng = np.random.default_rng(29)
+    B, N, C0, C1, C2 = 2, 512, 256, 512, 256
+    for xs, w1s, b1s in ((1.0, 1.0, 0.1), (1e-3, 1.0, 1e-4), (20.0, 5.0, 50.0)):
+        x = (rng.standard_normal((B, N, C0)) * xs).astype(np.float32)
+        w1 = (rng.standard_normal((C1, C0)) * w1s / C0 ** 0.5).astype(np.float32)
+        b1 = (rng.standard_normal(C1) * b1s).astype(np.float32)
+        w2 = (rng.standard_normal((C2, C1)) / C1 ** 0.5).astype(np.float32)
+        b2 = rng.standard_normal(C2).astype(np.float32)
+        h = np.maximum(x.astype(np.float64) @ w1.astype(np.float64).T + b1, 0)
+        want = (h @ w2.astype(np.float64).T + b2).transpose(0, 2, 1)
+        ximg = _fused.split_rows_f16(dev(x))
+        himg = _fused.pointwise_conv_f16(ximg, B, N, _fused.split_weights_f16(dev(w1)), C0, C1, None, dev(b1), relu=True, out_planes=True)
+        got = _fused.pointwise_conv_f16(himg, B, N, _fused.split_weights_f16(dev(w2)), C1, C2, None, dev(b2)).cpu().numpy()
+        hf = _fused.pointwise_conv_f16(ximg, B, N, _fused.split_weights_f16(dev(w1)), C0, C1, None, dev(b1), relu=True)       # fp32 hidden
+        ref = _fused.pointwise_conv_f16(_fused.split_rows_f16(hf, channel_first=True), B, N, _fused.split_weights_f16(dev(w2)), C1, C2, None, dev(b2)).cpu().numpy()
+        scale = np.abs(want).max()
+        assert np.abs(got - want).max() <= 2.0 * np.abs(ref - want).max() + 2e-6 * scale, (xs, np.abs(got - want).max(), np.abs(ref - want).max())
     _fused.check_range(sync=True)

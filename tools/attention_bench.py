@@ -13,7 +13,7 @@ for _ in range(30): fn()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 30
 print(f"attention B={B} H={H} D={D} N={N}: {dt*1e6:.1f} us  {4.0*B*H*N*N*D/dt/1e12:.1f} TFLOP/s fp32-equiv")
 ws = torch.zeros(4, dtype=torch.int32, device="cuda")
-fn16 = lambda: check(lib().l3d_attention_forward_f16(ptr(q), ptr(k), ptr(v), B, H, D, N, N, H * D * N, H * D * N, H * D * N, 1.0 / D ** 0.5, ptr(ws), ptr(ctx), stream_ptr()), "att16")
+fn16 = lambda: check(lib().l3d_attention_forward_f16(ptr(q), ptr(k), ptr(v), B, H, D, N, N, H * D * N, H * D * N, H * D * N, 1.0 / D ** 0.5, ptr(ws), ptr(ctx), None, stream_ptr()), "att16")
 for _ in range(10): fn16()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(30): fn16()
