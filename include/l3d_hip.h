@@ -416,6 +416,18 @@ int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes, const flo
  * row-sum maximum and the input image's scale the kernel bounds its outputs and fixes the plane scale itself. */
 int l3d_pointwise_conv_f16_planes(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
                                   const float *obs, int B, int Cin, int Cout, int N, int relu, void *out_img, l3d_stream_t stream);
+/* The layer with either or both of: its output as an activation image (out_img; obs as above, max|shift| taken over every
+ * (b, co) when the shift is per cloud, shift_bstride = Cout), and ypool [B][Cout][N/128] fp32 = the maxima over runs of 128
+ * points -- a global max-pool (models/pooling.py:9-12 after pcn.py:115,124 / pointnet.py:49) is then a reduce over N/128
+ * values per channel and the layer's [B,Cout,N] output is never written. */
+int l3d_pointwise_conv_f16_pool(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
+                                int shift_bstride, const float *obs, int B, int Cin, int Cout, int N, int relu,
+                                void *out_img, float *ypool, l3d_stream_t stream);
+/* First layer of a per-point MLP (Cin <= 8; pcn.py:26-33 conv1 3 -> 128, pointnet.py:42) written straight as an activation
+ * image: x [B][N][Cin] (channel_last) or [B][Cin][N], w [Cout][Cin], shift [Cout] or NULL, xmax = device float >= max|x|
+ * (the plane scale follows from max_r(|shift_r| + xmax sum_c |w_rc|)); raises *range_flag if xmax was not a bound. */
+int l3d_first_layer_f16_planes(const float *x, int channel_last, const float *w, const float *shift, const float *xmax,
+                               int B, int Cin, int Cout, int N, int relu, void *out_img, int *range_flag, l3d_stream_t stream);
 
 /* PCN's folding decoder == models/pcn.py:84-101 (conv5 -> ReLU -> conv6 -> ReLU -> conv7, + centre) in one
  * kernel (fold_mlp.hip): g [B,N,5] = (grid u, v, centre x, y, z) per fine point, w5g [512,5] = conv5's

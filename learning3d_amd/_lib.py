@@ -88,6 +88,8 @@ SIGNATURES = {
     "l3d_split_f16_rows": [_P, _L, _I, _I, _I, _P, _P, _P],
     "l3d_pointwise_conv_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_pointwise_conv_f16_planes": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "l3d_pointwise_conv_f16_pool": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P],
+    "l3d_first_layer_f16_planes": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "l3d_fold_mlp": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P],
     "l3d_fold_mlp_f16": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P],
     "l3d_channel_stats": [_P, _I, _I, _L, _P, _P],

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
                                                        const float *__restrict__ xinv, const float *__restrict__ scale, const float *__restrict__ shift,
                                                        int shift_bstride, int Bn, int Cin, int Cout, int N, int relu,
                                                        float *__restrict__ y, uint2 *__restrict__ oph, uint2 *__restrict__ opm,
-                                                       float *__restrict__ oinv, const float *__restrict__ obs)
+                                                       float *__restrict__ oinv, const float *__restrict__ obs, float *__restrict__ ypool)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -360,28 +360,35 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
 
     // ---- epilogue: D[co = 32a + (r&3) + 8(r>>2) + 4(lane>>5)][n = 32c + (lane&31)]
     const float inv = *winv * *xinv;             // 2^-S 2^-T: exact
-    if (oph) {
-        // Output as the fp16 plane image of the NEXT f16x2 layer ([Cout/8][B N][8], h | m' of y 2^To) instead of fp32: the
+    if (oph || ypool) {
+        // (1) Output as the fp16 plane image of the NEXT f16x2 layer ([Cout/8][B N][8], h | m' of y 2^To) instead of fp32: the
         // scale is fixed from a bound, |y| <= max|shift| + max|scale| (max_r sum_c |w_rc|) max|x| with max|x| <= 2^12 2^-T
         // (obs = {max|shift|, max|scale|}, the row-sum maximum sits behind 2^-S in the weight image).  A lane holds 4
         // consecutive channels of an octet, its partner (lane ^ 32) the other 4: each writes its 8-byte half of the cell.
-        float bound = fmaf(obs[1] * winv[2], 4096.0f * *xinv, obs[0]) * 1.000001f;
-        int e = 0;
-        if (bound > 0.f && bound < 3.0e38f) (void)frexpf(bound, &e);
-        const float up = ldexpf(1.f, 12 - e);
-        if (blockIdx.x == 0 && t == 0) *oinv = ldexpf(1.f, e - 12);
+        // (2) ypool [B][Cout][N/128]: the maximum over the wave tile's 128 points (4 tiles in registers, then the 32 lanes of
+        // a half) -- a global max-pool (pcn.py:115,124, pointnet.py:49 + pooling.py) finishes with a reduce over N/128 values and
+        // the layer's [B,Cout,N] output is never written.  Both may be asked for (pcn.py:115-119 pools conv2's output AND feeds it on).
+        float up = 1.f;
+        if (oph) {
+            float bound = fmaf(obs[1] * winv[2], 4096.0f * *xinv, obs[0]) * 1.000001f;
+            int e = 0;
+            if (bound > 0.f && bound < 3.0e38f) (void)frexpf(bound, &e);
+            up = ldexpf(1.f, 12 - e);
+            if (blockIdx.x == 0 && t == 0) *oinv = ldexpf(1.f, e - 12);
+        }
         const size_t rows = (size_t)Bn * N;
-        const int half = lane >> 5;
+        const int half = lane >> 5, NP = N / 128;
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
                 const int cob = co0 + wm * 64 + a * 32 + 8 * gq + 4 * half;          // this lane's 4 channels: cob .. cob + 3
-                float sc[4], sh[4];
+                float sc[4], sh[4], vmax[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     sc[u] = (scale ? scale[cob + u] : 1.f) * inv;
-                    sh[u] = shift ? shift[cob + u] : 0.f;
+                    sh[u] = shift ? shift[(size_t)b * shift_bstride + cob + u] : 0.f;
+                    vmax[u] = -INFINITY;
                 }
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
@@ -390,14 +397,29 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
                     for (int u = 0; u < 4; u++) {
                         v[u] = acc[a][c][4 * gq + u] * sc[u] + sh[u];
                         if (relu) v[u] = l3d_act(v[u], relu);
+                        vmax[u] = fmaxf(vmax[u], v[u]);
                     }
-                    uint32_t h0, h1, m0, m1;
-                    af_split_x(v[0], v[1], up, h0, m0);
-                    af_split_x(v[2], v[3], up, h1, m1);
-                    const size_t row = (size_t)b * N + n0 + wn * 128 + c * 32 + (lane & 31);
-                    const size_t cellh = ((size_t)(cob >> 3) * rows + row) * 2 + half;
-                    oph[cellh] = make_uint2(h0, h1);
-                    opm[cellh] = make_uint2(m0, m1);
+                    if (oph) {
+                        uint32_t h0, h1, m0, m1;
+                        af_split_x(v[0], v[1], up, h0, m0);
+                        af_split_x(v[2], v[3], up, h1, m1);
+                        const size_t row = (size_t)b * N + n0 + wn * 128 + c * 32 + (lane & 31);
+                        const size_t cellh = ((size_t)(cob >> 3) * rows + row) * 2 + half;
+                        oph[cellh] = make_uint2(h0, h1);
+                        opm[cellh] = make_uint2(m0, m1);
+                    }
+                }
+                if (ypool) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+#pragma unroll
+                        for (int d = 1; d < 32; d <<= 1) vmax[u] = fmaxf(vmax[u], __shfl_xor(vmax[u], d, 64));
+                    }
+                    if ((lane & 31) == 0) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            ypool[((size_t)b * Cout + cob + u) * NP + (n0 + wn * 128) / 128] = vmax[u];
+                    }
                 }
             }
         return;
@@ -484,7 +506,7 @@ extern "C" int l3d_split_f16_rows(const float *x, long rows, int C, int channel_
 
 // x_act: an activation image (l3d_f16_act_bytes), w_planes: a weight image (l3d_conv_f16_weight_bytes)
 static int cf_launch(const void *x_planes, const void *w_planes, const float *scale, const float *shift, int shift_bstride, int B,
-                     int Cin, int Cout, int N, int relu, float *y, void *out_img, const float *obs, hipStream_t st)
+                     int Cin, int Cout, int N, int relu, float *y, void *out_img, const float *obs, float *ypool, hipStream_t st)
 {
     if (Cout % CF_TM || N % CF_TN || Cin % 16 || B > 65535 || (((size_t)x_planes) & 15) || (((size_t)w_planes) & 15) ||
         (((size_t)out_img) & 15))
@@ -497,7 +519,7 @@ static int cf_launch(const void *x_planes, const void *w_planes, const float *sc
     hipLaunchKernelGGL(conv_f16_kernel, grid, block, CF_LDS, st, (const uint4 *)xp, (const uint4 *)(xp + xpb),
                        (const uint4 *)wp, (const uint4 *)(wp + wpb), (const uint4 *)(wp + 2 * wpb), (const float *)(wp + 3 * wpb),
                        (const float *)(xp + 2 * xpb), scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, (uint2 *)op,
-                       op ? (uint2 *)(op + opb) : nullptr, op ? (float *)(op + 2 * opb) : nullptr, obs);
+                       op ? (uint2 *)(op + opb) : nullptr, op ? (float *)(op + 2 * opb) : nullptr, obs, ypool);
     return l3d_check_launch();
 }
 
@@ -506,7 +528,7 @@ extern "C" int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes
                                       l3d_stream_t stream)
 {
     L3D_REQUIRE(x_planes && w_planes && y && B > 0 && Cin > 0 && Cout > 0 && N > 0);
-    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, nullptr, nullptr, (hipStream_t)stream);
+    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
 // The same layer with its OUTPUT written as an activation image (l3d_f16_act_bytes(B N, Cout) bytes) for the next f16x2 layer
@@ -517,5 +539,94 @@ extern "C" int l3d_pointwise_conv_f16_planes(const void *x_planes, const void *w
                                              l3d_stream_t stream)
 {
     L3D_REQUIRE(x_planes && w_planes && out_img && obs && B > 0 && Cin > 0 && Cout > 0 && N > 0);
-    return cf_launch(x_planes, w_planes, scale, shift, 0, B, Cin, Cout, N, relu, nullptr, out_img, obs, (hipStream_t)stream);
+    return cf_launch(x_planes, w_planes, scale, shift, 0, B, Cin, Cout, N, relu, nullptr, out_img, obs, nullptr, (hipStream_t)stream);
+}
+
+// The layer with either or both of: its output as an activation image (out_img, needs obs = {max|shift| over every (b, co), max|scale|}),
+// and the per-128-point maxima ypool [B][Cout][N/128] fp32 (a global max-pool is then a reduce over N/128 values per channel; the
+// [B,Cout,N] output is never written).  shift may be per cloud (shift_bstride = Cout).  pcn.py:110-124: conv2 -> (pool, conv3 with
+// the pooled half of W3 as a per-cloud shift) -> conv4 -> pool.
+extern "C" int l3d_pointwise_conv_f16_pool(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
+                                           int shift_bstride, const float *obs, int B, int Cin, int Cout, int N, int relu,
+                                           void *out_img, float *ypool, l3d_stream_t stream)
+{
+    L3D_REQUIRE(x_planes && w_planes && (out_img || ypool) && (!out_img || obs) && B > 0 && Cin > 0 && Cout > 0 && N > 0);
+    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, nullptr, out_img, obs, ypool, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// First layer of a per-point MLP (Cin <= 8: xyz, or xyz + a few features) written straight as an activation image:
+// pcn.py:26-33 / pointnet.py:42 conv1 (3 -> 64/128).  24 FMAs per 8 outputs on the VALU; one thread per (row, octet) cell, rows
+// fastest so that the plane writes are 1 KB per wave.  The plane scale comes from a bound computed by every workgroup from the
+// weights, max_r(|shift_r| + xmax sum_c |w_rc|), xmax = a device float >= max|x| (the host passes x.abs().max()).
+// ---------------------------------------------------------------------------------------------
+#define CFN_MAXCIN 8
+__global__ __launch_bounds__(256) void cf_first_layer_kernel(const float *__restrict__ x, int channel_last, const float *__restrict__ w,
+                                                             const float *__restrict__ shift, const float *__restrict__ xmax, int Cin,
+                                                             int Cout, int Npts, long R, int relu, uint4 *__restrict__ ph,
+                                                             uint4 *__restrict__ pm, float *__restrict__ oinv, int *__restrict__ range_flag)
+{
+    __shared__ float red[4];
+    const int t = threadIdx.x;
+    const float xm = *xmax;
+    float bnd = 0.f;
+    for (int r = t; r < Cout; r += 256) {
+        float s = 0.f;
+        for (int c = 0; c < Cin; c++) s += fabsf(w[r * Cin + c]);
+        bnd = fmaxf(bnd, fmaf(s, xm, shift ? fabsf(shift[r]) : 0.f));
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) bnd = fmaxf(bnd, __shfl_xor(bnd, d, 64));
+    if ((t & 63) == 0) red[t >> 6] = bnd;
+    __syncthreads();
+    bnd = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * 1.000001f;
+    int e = 0;
+    if (bnd > 0.f && bnd < 3.0e38f) (void)frexpf(bnd, &e);
+    const float up = ldexpf(1.f, 12 - e);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) *oinv = ldexpf(1.f, e - 12);
+    const long row = (long)blockIdx.x * 256 + t;
+    const int o = blockIdx.y;
+    if (row >= R) return;
+    float xv[CFN_MAXCIN];
+#pragma unroll
+    for (int c = 0; c < CFN_MAXCIN; c++)
+        xv[c] = c < Cin ? (channel_last ? x[(size_t)row * Cin + c] : x[((size_t)(row / Npts) * Cin + c) * Npts + row % Npts]) : 0.f;
+    float v[8], big = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int co = o * 8 + u;
+        float s = 0.f;
+        if (co < Cout) {
+#pragma unroll
+            for (int c = 0; c < CFN_MAXCIN; c++)
+                if (c < Cin) s = fmaf(w[co * Cin + c], xv[c], s);
+            s += shift ? shift[co] : 0.f;
+            if (relu) s = l3d_act(s, relu);
+        }
+        v[u] = s;
+        big = fmaxf(big, fabsf(s * up));
+    }
+    uint32_t h[4], m[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) af_split_x(v[2 * u], v[2 * u + 1], up, h[u], m[u]);
+    ph[(size_t)o * R + row] = make_uint4(h[0], h[1], h[2], h[3]);
+    pm[(size_t)o * R + row] = make_uint4(m[0], m[1], m[2], m[3]);
+    if (!(big <= 60000.f) && range_flag) *(volatile int *)range_flag = 1;      // xmax was not a bound (or inf / NaN)
+}
+
+// x [B][N][Cin] (channel_last) or [B][Cin][N]; w [Cout][Cin]; shift [Cout] or NULL; xmax: device float >= max|x|;
+// out_img: l3d_f16_act_bytes(B N, Cout) bytes.  Cin <= 8.
+extern "C" int l3d_first_layer_f16_planes(const float *x, int channel_last, const float *w, const float *shift, const float *xmax,
+                                          int B, int Cin, int Cout, int N, int relu, void *out_img, int *range_flag,
+                                          l3d_stream_t stream)
+{
+    L3D_REQUIRE(x && w && xmax && out_img && B > 0 && Cin > 0 && Cout > 0 && N > 0);
+    if (Cin > CFN_MAXCIN || (((size_t)out_img) & 15)) return L3D_ERR_UNSUPPORTED;
+    const long R = (long)B * N;
+    const size_t pb = l3d_f16_plane_bytes(R, Cout);
+    unsigned char *d = (unsigned char *)out_img;
+    dim3 grid((unsigned)l3d_divup(R, 256), (unsigned)((Cout + 7) / 8));
+    hipLaunchKernelGGL(cf_first_layer_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, channel_last, w, shift, xmax, Cin, Cout, N, R,
+                       relu, (uint4 *)d, (uint4 *)(d + pb), (float *)(d + 2 * pb), range_flag);
+    return l3d_check_launch();
 }

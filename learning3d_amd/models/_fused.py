@@ -176,6 +176,44 @@ def pointwise_conv_f16(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=No
     return y
 
 
+def first_layer_f16_planes(x, w, shift, relu, channel_last):
+    """Conv1d(Cin <= 8 -> Cout, k=1) (+ReLU) written straight as the fp16 activation image of the next f16x2 layer
+    (l3d_first_layer_f16_planes).  x [B,N,Cin] (channel_last) or [B,Cin,N]."""
+    require_gpu(x)
+    x, w = f32c(x), f32c(w)
+    if channel_last:
+        B, N, Cin = x.shape
+    else:
+        B, Cin, N = x.shape
+    Cout = w.shape[0]
+    shift = f32c(shift) if shift is not None else None
+    xmax = x.abs().max().reshape(1)
+    img = torch.empty(lib().l3d_f16_act_bytes(B * N, Cout), dtype=torch.uint8, device=x.device)
+    check(lib().l3d_first_layer_f16_planes(ptr(x), int(channel_last), ptr(w), ptr(shift), ptr(xmax), B, Cin, Cout, N, int(relu),
+                                           ptr(img), ptr(range_flag(x.device)), stream_ptr()), "l3d_first_layer_f16_planes")
+    return img
+
+
+def pointwise_conv_f16_pool(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=None, relu=False, out_planes=False, pool=True):
+    """l3d_pointwise_conv_f16_pool: the layer's output as an activation image (out_planes) and / or its maximum over all N points
+    [B,Cout] (pool; per-128-point maxima from the kernel's epilogue, then a reduce over N/128).  shift [Cout] or per cloud [B,Cout].
+    Returns (img or None, pooled or None)."""
+    scale = f32c(scale) if scale is not None else None
+    shift = f32c(shift) if shift is not None else None
+    dev = x_planes.device
+    bstride = Cout if (shift is not None and shift.dim() == 2) else 0
+    obs = img = part = None
+    if out_planes:
+        obs = torch.stack([shift.abs().max() if shift is not None else torch.zeros((), device=dev),
+                           scale.abs().max() if scale is not None else torch.ones((), device=dev)]).float()
+        img = torch.empty(lib().l3d_f16_act_bytes(B * N, Cout), dtype=torch.uint8, device=dev)
+    if pool:
+        part = torch.empty((B, Cout, N // 128), dtype=torch.float32, device=dev)
+    check(lib().l3d_pointwise_conv_f16_pool(ptr(x_planes), ptr(w_planes), ptr(scale), ptr(shift), bstride, ptr(obs), B, Cin, Cout, N,
+                                            int(relu), ptr(img), ptr(part), stream_ptr()), "l3d_pointwise_conv_f16_pool")
+    return img, (part.max(dim=2)[0] if pool else None)
+
+
 def pointwise_conv_maxpool(x, w, scale, shift, relu, pool, w_split=None):
     """pointwise_conv followed by max over every `pool` consecutive points, in one launch:
     x [B,Cin,S*pool] -> [B,Cout,S].  pool in (8, 16, 32, 64); returns None if the kernel does not take the shape."""

@@ -1,7 +1,7 @@
 """Drop-in for learning3d/models/pcn.py on MI355X (reference: models/pcn.py:8-153).
 
-Inference path: every Conv1d(k=1) is an fp32-MFMA GEMM launch.  Two algebraic fusions remove the
-reference's largest temporaries:
+Inference path: every Conv1d(k=1) is a matrix-core GEMM launch (f16x2 on the fp16 MFMAs by default, chained through fp16
+planes; bf16x3 / fp32 MFMA under L3D_GEMM_ARITH).  Two algebraic fusions remove the reference's largest temporaries:
   * encoder (:117-119) concatenates the per-cloud global feature to every point before conv3; here
     W3 is split and the global half becomes a per-cloud shift:  W3 [h ; g] = W3a h + (W3b g);
   * fine decoder (:84-101) materialises a [B, 16384, 1029] feature (4.3 GB at B=64) of which 1024
@@ -69,7 +69,35 @@ class PCN(torch.nn.Module):
         return out.permute(0, 2, 1) + center
 
     # -- fused inference path ----------------------------------------------------------------------
+    def _w_f16(self, name, w):
+        """f16x2 weight image of a conv's (slice of a) weight, rebuilt when the parameter changes"""
+        cache = self.__dict__.setdefault("_w_f16_cache", {})
+        key = (w.data_ptr(), getattr(self, name).weight._version, str(w.device), tuple(w.shape))
+        if cache.get(name, (None,))[0] != key:
+            cache[name] = (key, _fused.split_weights_f16(w.float().contiguous()))
+        return cache[name][1]
+
+    def _encode_f16(self, x, channel_last):
+        """The encoder (pcn.py:110-124) as a chain on the fp16 matrix cores (f16x2 arithmetic, conv_f16.hip): conv1 writes fp16
+        planes, conv2 reads them and writes planes AND its per-cloud maximum, conv3 takes the pooled half of W3 as a per-cloud
+        shift, conv4's epilogue pools -- no fp32 [B,C,N] activation is written or read anywhere."""
+        B = x.shape[0]
+        N = x.shape[1] if channel_last else x.shape[2]
+        img = _fused.first_layer_f16_planes(x, self.conv1.weight.detach().reshape(128, 3), self.conv1.bias.detach(), True, channel_last)
+        w2 = self._w_f16("conv2", self.conv2.weight.detach().reshape(256, 128))
+        img, g = _fused.pointwise_conv_f16_pool(img, B, N, w2, 128, 256, None, self.conv2.bias.detach(), relu=False, out_planes=True)
+        w3 = self.conv3.weight.detach().reshape(512, 512)
+        shift = torch.addmm(self.conv3.bias.detach(), g, w3[:, 256:].t())  # per-cloud [B,512]
+        img, _ = _fused.pointwise_conv_f16_pool(img, B, N, self._w_f16("conv3", w3[:, :256]), 256, 512, None, shift, relu=True,
+                                                out_planes=True, pool=False)
+        w4 = self._w_f16("conv4", self.conv4.weight.detach().reshape(self.emb_dims, 512))
+        return _fused.pointwise_conv_f16_pool(img, B, N, w4, 512, self.emb_dims, None, self.conv4.bias.detach(), relu=False)[1]
+
     def _encode_fused(self, x, channel_last):
+        N = x.shape[1] if channel_last else x.shape[2]
+        if (_fused.gemm_arith() == "f16x2" and _fused.SPLIT_BF16 and N % 256 == 0 and self.emb_dims % 256 == 0
+                and self.pooling.pool_type == 'max'):
+            return self._encode_f16(x, channel_last)
         pc = _fused.pointwise_conv
         w, _, b = _fused.fold_conv_bn(self.conv1)
         h = pc(x, w, None, b, relu=True, channel_last=channel_last)

@@ -1699,3 +1699,73 @@ def test_conv_f16_plane_output_chains():
         scale = np.abs(want).max()
         assert np.abs(got - want).max() <= 2.0 * np.abs(ref - want).max() + 2e-6 * scale, (xs, np.abs(got - want).max(), np.abs(ref - want).max())
     _fused.check_range(sync=True)
+
+
+def test_conv_f16_pool_epilogue_and_first_layer():
+    """conv_f16.hip's pooled epilogue and the first-layer plane writer, the pieces of PCN's f16x2 encoder chain (pcn.py:110-124):
+    (1) l3d_first_layer_f16_planes (3 -> 128, ReLU) feeding a 128 -> 256 layer, against fp64, both input layouts;
+    (2) ypool == the maximum of the same layer's fp32 output, alone and together with a plane image; (3) a per-cloud shift in
+    plane mode (conv3 with the pooled half of W3 folded into the shift).  Activations from tiny to large."""
+    from learning3d_amd.models import _fused
+    rng = np.random.default_rng(31)
+    B, N = 3, 512
+    for xs, bs in ((1.0, 0.1), (1e-3, 1e-4), (40.0, 30.0)):
+        x = (rng.uniform(-1, 1, (B, N, 3)) * xs).astype(np.float32)
+        w1 = rng.standard_normal((128, 3)).astype(np.float32)
+        b1 = (rng.standard_normal(128) * bs).astype(np.float32)
+        w2 = (rng.standard_normal((256, 128)) / 128 ** 0.5).astype(np.float32)
+        b2 = (rng.standard_normal(256) * bs).astype(np.float32)
+        w3 = (rng.standard_normal((256, 256)) / 16).astype(np.float32)
+        s3 = (rng.standard_normal((B, 256)) * bs * 3).astype(np.float32)           # per-cloud shift
+        h1 = np.maximum(x.astype(np.float64) @ w1.astype(np.float64).T + b1, 0)
+        h2 = h1 @ w2.astype(np.float64).T + b2                                     # [B,N,256]
+        h3 = np.maximum(h2 @ w3.astype(np.float64).T + s3[:, None, :], 0)
+        w2i, w3i = _fused.split_weights_f16(dev(w2)), _fused.split_weights_f16(dev(w3))
+        for cl in (True, False):
+            xin = dev(x) if cl else dev(np.ascontiguousarray(x.transpose(0, 2, 1)))
+            img1 = _fused.first_layer_f16_planes(xin, dev(w1), dev(b1), True, cl)
+            y2 = _fused.pointwise_conv_f16(img1, B, N, w2i, 128, 256, None, dev(b2))                       # fp32 [B,256,N]
+            tol = 1e-5 * np.abs(h2).max()
+            assert np.abs(y2.cpu().numpy() - h2.transpose(0, 2, 1)).max() <= tol, (xs, cl)
+        img2, g = _fused.pointwise_conv_f16_pool(img1, B, N, w2i, 128, 256, None, dev(b2), relu=False, out_planes=True)
+        assert torch.equal(g, y2.max(dim=2)[0])
+        _, g_only = _fused.pointwise_conv_f16_pool(img1, B, N, w2i, 128, 256, None, dev(b2), relu=False)
+        assert torch.equal(g_only, g)
+        y3 = _fused.pointwise_conv_f16(img2, B, N, w3i, 256, 256, None, dev(s3), relu=True)                # per-cloud shift, fp32 out
+        assert np.abs(y3.cpu().numpy() - h3.transpose(0, 2, 1)).max() <= 1e-5 * np.abs(h3).max() + 1e-5 * np.abs(h2).max()
+        img3, g3 = _fused.pointwise_conv_f16_pool(img2, B, N, w3i, 256, 256, None, dev(s3), relu=True, out_planes=True)
+        assert torch.equal(g3, y3.max(dim=2)[0])
+        ident = np.eye(256, dtype=np.float32)
+        back = _fused.pointwise_conv_f16(img3, B, N, _fused.split_weights_f16(dev(ident)), 256, 256).cpu().numpy()   # read the image back
+        assert np.abs(back - y3.cpu().numpy()).max() <= 1e-6 * np.abs(h3).max()
+    _fused.check_range(sync=True)
+
+
+def test_pcn_encoder_f16_chain_matches_reference_order_path():
+    """PCN with N % 256 == 0 takes the f16x2 encoder chain (models/pcn.py::_encode_f16); against the reference-order torch
+    route (autograd path) and an fp64 evaluation of pcn.py:110-124, both input layouts."""
+    from learning3d_amd.models import PCN, _fused
+    assert _fused.gemm_arith() == "f16x2"
+    for shape in ("bnc", "bcn"):
+        torch.manual_seed(5)
+        net = PCN(emb_dims=1024, input_shape=shape, num_coarse=64, grid_size=2, detailed_output=True).cuda().eval()
+        x = dev(rand((3, 512, 3), 6, -0.5, 0.5))
+        if shape == "bcn":
+            x = x.permute(0, 2, 1).contiguous()
+        with torch.no_grad():
+            fused = net(x)
+            gf = net.global_feature_v.clone()
+        assert "conv4" in net.__dict__.get("_w_f16_cache", {}), "the f16x2 chain did not run"
+        ref = net(x.clone().requires_grad_())
+        gr = net.global_feature_v.detach()
+        xd = (x if shape == "bcn" else x.permute(0, 2, 1)).double().cpu()
+        p = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}
+        conv = lambda n, t: torch.einsum("oc,bcn->bon", p[n + ".weight"][:, :, 0], t) + p[n + ".bias"][None, :, None]
+        h = conv("conv2", torch.relu(conv("conv1", xd)))
+        h = torch.cat([h, h.max(dim=2, keepdim=True)[0].expand(-1, -1, h.shape[2])], dim=1)
+        want = conv("conv4", torch.relu(conv("conv3", h))).max(dim=2)[0].numpy()
+        e_f16, e_ref = np.abs(gf.cpu().numpy() - want).max(), np.abs(gr.cpu().numpy() - want).max()
+        assert e_f16 <= 2 * e_ref + 2e-6 * np.abs(want).max(), (e_f16, e_ref)
+        for k in ("coarse_output", "fine_output"):
+            np.testing.assert_allclose(fused[k].cpu().numpy(), ref[k].detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    _fused.check_range(sync=True)
