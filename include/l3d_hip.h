@@ -277,6 +277,11 @@ int l3d_attention_forward_strided(const float *q, const float *k, const float *v
 int l3d_attention_forward_f16(const float *q, const float *k, const float *v, int B, int H, int D, int N, int M,
                               long q_bstride, long k_bstride, long v_bstride, float scale, void *workspace, float *ctx,
                               void *ctx_img, l3d_stream_t stream);
+/* The same with the three operand maxima already in `maxima` (uint32 float bits of upper bounds of max|q|, |k|, |v|, e.g. from
+ * l3d_pointwise_conv_f16_absmax): the pass over q, k, v is not run. */
+int l3d_attention_forward_f16_maxima(const float *q, const float *k, const float *v, int B, int H, int D, int N, int M,
+                                     long q_bstride, long k_bstride, long v_bstride, float scale, const void *maxima,
+                                     float *ctx, void *ctx_img, l3d_stream_t stream);
 
 /* LayerNorm of DCP's pointer network == utils/transformer.py:109-119 (unbiased std, eps added to std):
  *   y[r][:] = a * (x[r][:] - mean_r) / (std_r + eps) + b,   x, y [rows][C] fp32, C % 4 == 0, C <= 2048. */
@@ -416,6 +421,12 @@ int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes, const flo
  * row-sum maximum and the input image's scale the kernel bounds its outputs and fixes the plane scale itself. */
 int l3d_pointwise_conv_f16_planes(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
                                   const float *obs, int B, int Cin, int Cout, int N, int relu, void *out_img, l3d_stream_t stream);
+/* l3d_pointwise_conv_f16 that also reports max|y| per group of amax_cdiv output channels (amax_cdiv % 256 == 0) into
+ * amax_out[Cout / amax_cdiv] (uint32 float bits, atomic maximum: the caller zeroes them first): the operand maxima
+ * l3d_attention_forward_f16_maxima wants, from the projection's own epilogue (utils/transformer.py:183-189). */
+int l3d_pointwise_conv_f16_absmax(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
+                                  int shift_bstride, int B, int Cin, int Cout, int N, int relu, float *y,
+                                  void *amax_out, int amax_cdiv, l3d_stream_t stream);
 /* The layer with either or both of: its output as an activation image (out_img; obs as above, max|shift| taken over every
  * (b, co) when the shift is per cloud, shift_bstride = Cout), and ypool [B][Cout][N/128] fp32 = the maxima over runs of 128
  * points -- a global max-pool (models/pooling.py:9-12 after pcn.py:115,124 / pointnet.py:49) is then a reduce over N/128

@@ -65,6 +65,7 @@ SIGNATURES = {
     "l3d_attention_forward": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P],
     "l3d_attention_forward_strided": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _P],
     "l3d_attention_forward_f16": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _P, _P, _P],
+    "l3d_attention_forward_f16_maxima": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _P, _P, _P],
     "l3d_layernorm_ref": [_P, _P, _P, _F, _L, _I, _P, _P],
     "l3d_layernorm_planes": [_P, _P, _P, _F, _L, _I, _P, _P, _P],
     "l3d_add_transposed": [_P, _P, _I, _I, _I, _P, _P],
@@ -88,6 +89,7 @@ SIGNATURES = {
     "l3d_split_f16_rows": [_P, _L, _I, _I, _I, _P, _P, _P],
     "l3d_pointwise_conv_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_pointwise_conv_f16_planes": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "l3d_pointwise_conv_f16_absmax": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "l3d_pointwise_conv_f16_pool": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "l3d_first_layer_f16_planes": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "l3d_fold_mlp": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P],

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
 // workspace: 16 bytes of device memory (the three maxima); ctx [B, H D, N] fp32 and / or ctx_img = the context as an fp16
 // activation image (l3d_f16_act_bytes(B N, H D) bytes) for l3d_pointwise_conv_f16; everything else as
 // l3d_attention_forward_strided
-extern "C" int l3d_attention_forward_f16(const float *q, const float *k, const float *v, int B, int H, int D, int N, int M,
+static int af_launch(int maxima_ready, const float *q, const float *k, const float *v, int B, int H, int D, int N, int M,
                                          long q_bstride, long k_bstride, long v_bstride, float scale, void *workspace,
                                          float *ctx, void *ctx_img, l3d_stream_t stream)
 {
@@ -331,12 +331,31 @@ extern "C" int l3d_attention_forward_f16(const float *q, const float *k, const f
         return L3D_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     unsigned *amax = (unsigned *)workspace;
-    if (hipMemsetAsync(amax, 0, 16, st) != hipSuccess) return L3D_ERR_LAUNCH;
-    hipLaunchKernelGGL(at_absmax3_kernel, dim3(512, 3), dim3(256), 0, st, q, k, v, q_bstride, k_bstride, v_bstride,
-                       (long)H * D * N, (long)H * D * M, B, amax);
+    if (!maxima_ready) {
+        if (hipMemsetAsync(amax, 0, 16, st) != hipSuccess) return L3D_ERR_LAUNCH;
+        hipLaunchKernelGGL(at_absmax3_kernel, dim3(512, 3), dim3(256), 0, st, q, k, v, q_bstride, k_bstride, v_bstride,
+                           (long)H * D * N, (long)H * D * M, B, amax);
+    }
     dim3 grid(l3d_divup(N, AF_TQ), H, B), block(256);
     if (D == 32)      hipLaunchKernelGGL(attention_f16_kernel<1>, grid, block, AF_LDS, st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax, cph, cpm, cinv);
     else if (D == 64) hipLaunchKernelGGL(attention_f16_kernel<2>, grid, block, AF_LDS, st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax, cph, cpm, cinv);
     else              hipLaunchKernelGGL(attention_f16_kernel<4>, grid, block, AF_LDS, st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax, cph, cpm, cinv);
     return l3d_check_launch();
+}
+
+extern "C" int l3d_attention_forward_f16(const float *q, const float *k, const float *v, int B, int H, int D, int N, int M,
+                                         long q_bstride, long k_bstride, long v_bstride, float scale, void *workspace,
+                                         float *ctx, void *ctx_img, l3d_stream_t stream)
+{
+    return af_launch(0, q, k, v, B, H, D, N, M, q_bstride, k_bstride, v_bstride, scale, workspace, ctx, ctx_img, stream);
+}
+
+// The same with the operand maxima already in place: maxima = three uint32 holding the float bits of (upper bounds of) max|q|,
+// max|k|, max|v| -- written by the projections' own epilogues (l3d_pointwise_conv_f16_absmax), so the pass over q, k, v
+// (at_absmax3_kernel, 200 MB at DCP's shapes) is not run.
+extern "C" int l3d_attention_forward_f16_maxima(const float *q, const float *k, const float *v, int B, int H, int D, int N, int M,
+                                                long q_bstride, long k_bstride, long v_bstride, float scale, const void *maxima,
+                                                float *ctx, void *ctx_img, l3d_stream_t stream)
+{
+    return af_launch(1, q, k, v, B, H, D, N, M, q_bstride, k_bstride, v_bstride, scale, (void *)maxima, ctx, ctx_img, stream);
 }

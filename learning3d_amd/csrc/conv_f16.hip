@@ -228,7 +228,8 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
                                                        const float *__restrict__ xinv, const float *__restrict__ scale, const float *__restrict__ shift,
                                                        int shift_bstride, int Bn, int Cin, int Cout, int N, int relu,
                                                        float *__restrict__ y, uint2 *__restrict__ oph, uint2 *__restrict__ opm,
-                                                       float *__restrict__ oinv, const float *__restrict__ obs, float *__restrict__ ypool)
+                                                       float *__restrict__ oinv, const float *__restrict__ obs, float *__restrict__ ypool,
+                                                       unsigned *__restrict__ amax_out, int amax_cdiv)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
         return;
     }
     float *yb = y + (size_t)b * Cout * N;
+    float big = 0.f;
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -436,9 +438,27 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
             for (int c = 0; c < 4; c++) {
                 float v = acc[a][c][r] * sc + sh;
                 if (relu) v = l3d_act(v, relu);
+                big = fmaxf(big, fabsf(v));
                 yb[(size_t)co * N + n0 + wn * 128 + c * 32 + (lane & 31)] = v;
             }
         }
+    if (amax_out) {
+        // max|y| per group of amax_cdiv output channels (amax_cdiv % 256 == 0: a workgroup's 256 channels lie in one group), as
+        // float bits: the consumer's operand scale (attention_f16.hip takes max|q|, |k|, |v| of a fused q|k|v projection from
+        // here instead of a pass over the three tensors).  One atomic per workgroup, skipped when it would not raise the value.
+        float *red = (float *)lds;                 // the stages are dead: every wave is past its last fragment read ...
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) big = fmaxf(big, __shfl_xor(big, d, 64));
+        __syncthreads();                           // ... after this barrier
+        if (lane == 0) red[wave] = big;
+        __syncthreads();
+        if (t == 0) {
+            float m = red[0];
+            for (int w = 1; w < 8; w++) m = fmaxf(m, red[w]);
+            unsigned *dst = amax_out + co0 / amax_cdiv;
+            if (!(m <= __uint_as_float(__atomic_load_n(dst, __ATOMIC_RELAXED)))) atomicMax(dst, __float_as_uint(m));   // NaN goes through too
+        }
+    }
 }
 
 // bytes of ONE fp16 plane of a [rows][cols] matrix in the tiled layout
@@ -506,7 +526,8 @@ extern "C" int l3d_split_f16_rows(const float *x, long rows, int C, int channel_
 
 // x_act: an activation image (l3d_f16_act_bytes), w_planes: a weight image (l3d_conv_f16_weight_bytes)
 static int cf_launch(const void *x_planes, const void *w_planes, const float *scale, const float *shift, int shift_bstride, int B,
-                     int Cin, int Cout, int N, int relu, float *y, void *out_img, const float *obs, float *ypool, hipStream_t st)
+                     int Cin, int Cout, int N, int relu, float *y, void *out_img, const float *obs, float *ypool, unsigned *amax_out,
+                     int amax_cdiv, hipStream_t st)
 {
     if (Cout % CF_TM || N % CF_TN || Cin % 16 || B > 65535 || (((size_t)x_planes) & 15) || (((size_t)w_planes) & 15) ||
         (((size_t)out_img) & 15))
@@ -519,7 +540,7 @@ static int cf_launch(const void *x_planes, const void *w_planes, const float *sc
     hipLaunchKernelGGL(conv_f16_kernel, grid, block, CF_LDS, st, (const uint4 *)xp, (const uint4 *)(xp + xpb),
                        (const uint4 *)wp, (const uint4 *)(wp + wpb), (const uint4 *)(wp + 2 * wpb), (const float *)(wp + 3 * wpb),
                        (const float *)(xp + 2 * xpb), scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, (uint2 *)op,
-                       op ? (uint2 *)(op + opb) : nullptr, op ? (float *)(op + 2 * opb) : nullptr, obs, ypool);
+                       op ? (uint2 *)(op + opb) : nullptr, op ? (float *)(op + 2 * opb) : nullptr, obs, ypool, amax_out, amax_cdiv);
     return l3d_check_launch();
 }
 
@@ -528,7 +549,7 @@ extern "C" int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes
                                       l3d_stream_t stream)
 {
     L3D_REQUIRE(x_planes && w_planes && y && B > 0 && Cin > 0 && Cout > 0 && N > 0);
-    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, nullptr, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
 }
 
 // The same layer with its OUTPUT written as an activation image (l3d_f16_act_bytes(B N, Cout) bytes) for the next f16x2 layer
@@ -539,7 +560,20 @@ extern "C" int l3d_pointwise_conv_f16_planes(const void *x_planes, const void *w
                                              l3d_stream_t stream)
 {
     L3D_REQUIRE(x_planes && w_planes && out_img && obs && B > 0 && Cin > 0 && Cout > 0 && N > 0);
-    return cf_launch(x_planes, w_planes, scale, shift, 0, B, Cin, Cout, N, relu, nullptr, out_img, obs, nullptr, (hipStream_t)stream);
+    return cf_launch(x_planes, w_planes, scale, shift, 0, B, Cin, Cout, N, relu, nullptr, out_img, obs, nullptr, nullptr, 0, (hipStream_t)stream);
+}
+
+// l3d_pointwise_conv_f16 that also reports max|y| per group of amax_cdiv output channels into amax_out[Cout / amax_cdiv] (float
+// bits, atomicMax: the caller zeroes them; amax_cdiv % 256 == 0).  transformer.py:183-189: the fused q|k|v projection hands the
+// attention kernel its operand maxima.
+extern "C" int l3d_pointwise_conv_f16_absmax(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
+                                             int shift_bstride, int B, int Cin, int Cout, int N, int relu, float *y,
+                                             void *amax_out, int amax_cdiv, l3d_stream_t stream)
+{
+    L3D_REQUIRE(x_planes && w_planes && y && amax_out && B > 0 && Cin > 0 && Cout > 0 && N > 0 && amax_cdiv > 0);
+    if (amax_cdiv % CF_TM) return L3D_ERR_UNSUPPORTED;
+    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, nullptr, nullptr, nullptr,
+                     (unsigned *)amax_out, amax_cdiv, (hipStream_t)stream);
 }
 
 // The layer with either or both of: its output as an activation image (out_img, needs obs = {max|shift| over every (b, co), max|scale|}),
@@ -551,7 +585,7 @@ extern "C" int l3d_pointwise_conv_f16_pool(const void *x_planes, const void *w_p
                                            void *out_img, float *ypool, l3d_stream_t stream)
 {
     L3D_REQUIRE(x_planes && w_planes && (out_img || ypool) && (!out_img || obs) && B > 0 && Cin > 0 && Cout > 0 && N > 0);
-    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, nullptr, out_img, obs, ypool, (hipStream_t)stream);
+    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, nullptr, out_img, obs, ypool, nullptr, 0, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------

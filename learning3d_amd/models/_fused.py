@@ -154,9 +154,11 @@ def f16_eligible(Cin, Cout, N):
     return Cout % 256 == 0 and N % 256 == 0 and Cin % 16 == 0 and Cin >= 32
 
 
-def pointwise_conv_f16(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=None, relu=False, out_planes=False):
+def pointwise_conv_f16(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=None, relu=False, out_planes=False, amax=None):
     """l3d_pointwise_conv_f16 on pre-split operands -> y [B,Cout,N] fp32; out_planes=True: the output as an fp16 activation
-    image (uint8 tensor) for the next f16x2 layer instead (l3d_pointwise_conv_f16_planes; shift must be [Cout] or None)."""
+    image (uint8 tensor) for the next f16x2 layer instead (l3d_pointwise_conv_f16_planes; shift must be [Cout] or None).
+    amax = (int32 tensor, channels per group): also max|y| per channel group as float bits, atomically maximised into the
+    (pre-zeroed) tensor (l3d_pointwise_conv_f16_absmax)."""
     scale = f32c(scale) if scale is not None else None
     shift = f32c(shift) if shift is not None else None
     if out_planes:
@@ -171,6 +173,11 @@ def pointwise_conv_f16(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=No
         return img
     bstride = Cout if (shift is not None and shift.dim() == 2) else 0
     y = torch.empty((B, Cout, N), dtype=torch.float32, device=x_planes.device)
+    if amax is not None:
+        check(lib().l3d_pointwise_conv_f16_absmax(ptr(x_planes), ptr(w_planes), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N,
+                                                  int(relu), ptr(y), ptr(amax[0]), int(amax[1]), stream_ptr()),
+              "l3d_pointwise_conv_f16_absmax")
+        return y
     check(lib().l3d_pointwise_conv_f16(ptr(x_planes), ptr(w_planes), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N, int(relu),
                                        ptr(y), stream_ptr()), "l3d_pointwise_conv_f16")
     return y

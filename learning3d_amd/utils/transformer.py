@@ -15,6 +15,7 @@ import torch.nn.functional as F
 
 
 FLASH_ATTENTION = True      # l3d_attention_forward for d_k in {32, 64, 128}; False: torch matmul + softmax + matmul
+PROJECTION_MAXIMA = True    # the f16x2 q|k|v projections report max|q|, |k|, |v| from their epilogues (False: a pass over q, k, v)
 
 _ATT_WS = {}
 
@@ -36,11 +37,13 @@ def _fast_linear_ok(lin, x, n_points):
             and _fused.split_eligible(lin.in_features, lin.out_features, n_points))
 
 
-def _linear_cf(lin, x, channel_last, relu=False, out_scale=None, planes=None, out_planes=False):
+def _linear_cf(lin, x, channel_last, relu=False, out_scale=None, planes=None, out_planes=False, amax=None):
     """Linear over points as a 1x1 conv: x [B,N,Cin] (channel_last) or [B,Cin,N] -> [B,Cout,N];
     out_scale multiplies the whole result (weights and bias) in the kernel's epilogue.
     planes = (image, B, N): the input exists only as an fp16 plane image (x is None); out_planes: return (image, B, N) of the
-    output instead of the fp32 tensor (f16x2 path only; None if that path does not apply)."""
+    output instead of the fp32 tensor (f16x2 path only; None if that path does not apply).
+    amax = (int32 tensor, channels per group): the f16x2 kernel also maximises max|y| per channel group into the tensor and
+    the result carries `_l3d_amax = True`; ignored (no attribute) on the other routes."""
     from ..models import _fused
     if planes is not None:
         img, nb_, np_ = planes
@@ -62,6 +65,10 @@ def _linear_cf(lin, x, channel_last, relu=False, out_scale=None, planes=None, ou
         if out_planes:
             return (_fused.pointwise_conv_f16(img, nb_, np_, c16[1], lin.in_features, lin.out_features, scale, bias, relu=relu,
                                               out_planes=True), nb_, np_)
+        if amax is not None and amax[1] % 256 == 0 and PROJECTION_MAXIMA:
+            y = _fused.pointwise_conv_f16(img, nb_, np_, c16[1], lin.in_features, lin.out_features, scale, bias, relu=relu, amax=amax)
+            y._l3d_amax = True
+            return y
         return _fused.pointwise_conv_f16(img, nb_, np_, c16[1], lin.in_features, lin.out_features, scale, bias, relu=relu)
     if out_planes:
         return None
@@ -184,15 +191,22 @@ class MultiHeadedAttention(nn.Module):
             n_q, n_k = query.size(1), key.size(1)
             # projections that share an input run as ONE conv with concatenated weights (q|k|v for
             # self-attention, k|v for cross-attention); q, k, v are then channel slices of its [B, 3C, N] output
+            # the f16x2 projections leave max|q|, |k|, |v| in the attention workspace from their own epilogues
+            ws = _attention_workspace(query.device)
+            ws.zero_()
             if query is key and key is value:
-                qkv = _linear_cf(self._fused_linear(0, 3), query, True)
+                qkv = _linear_cf(self._fused_linear(0, 3), query, True, amax=(ws, C_))
                 q, k, v = qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:]
+                have_max = getattr(qkv, "_l3d_amax", False)
             elif key is value:
-                q = _linear_cf(self.linears[0], query, True)
-                kv = _linear_cf(self._fused_linear(1, 3), key, True)
+                q = _linear_cf(self.linears[0], query, True, amax=(ws, C_))
+                kv = _linear_cf(self._fused_linear(1, 3), key, True, amax=(ws[1:], C_))
                 k, v = kv[:, :C_], kv[:, C_:]
+                have_max = getattr(q, "_l3d_amax", False) and getattr(kv, "_l3d_amax", False)
             else:
-                q, k, v = [_linear_cf(lin, x, True) for lin, x in zip(self.linears, (query, key, value))]   # [B,C,N]
+                q, k, v = [_linear_cf(lin, x, True, amax=(ws[i:], C_))
+                           for i, (lin, x) in enumerate(zip(self.linears, (query, key, value)))]   # [B,C,N]
+                have_max = all(getattr(z, "_l3d_amax", False) for z in (q, k, v))
             self.attn = None                                   # the [B,h,N,M] map is never formed
             if FLASH_ATTENTION and self.d_k in (32, 64, 128):
                 from .._lib import check, lib, ptr, stream_ptr
@@ -203,17 +217,17 @@ class MultiHeadedAttention(nn.Module):
                     # both GEMMs as f16x2 (operand scales from the tensors' maxima); the context leaves the kernel as the
                     # fp16 plane image of the f16x2 conv kernel, so the output projection needs no split pass either
                     img = torch.empty(lib().l3d_f16_act_bytes(nb * n_q, C_), dtype=torch.uint8, device=q.device)
-                    check(lib().l3d_attention_forward_f16(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
-                                                          q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),
-                                                          ptr(_attention_workspace(q.device)), None, ptr(img), stream_ptr()),
-                          "l3d_attention_forward_f16")
+                    att = lib().l3d_attention_forward_f16_maxima if have_max else lib().l3d_attention_forward_f16
+                    check(att(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
+                              q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),
+                              ptr(ws), None, ptr(img), stream_ptr()), "l3d_attention_forward_f16")
                     return _linear_cf(out_lin, None, True, planes=(img, nb, n_q)).transpose(1, 2)     # [B,N,C] view
                 ctx = torch.empty((nb, C_, n_q), dtype=torch.float32, device=q.device)
                 if _fused.gemm_arith() == "f16x2":
-                    check(lib().l3d_attention_forward_f16(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
-                                                          q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),
-                                                          ptr(_attention_workspace(q.device)), ptr(ctx), None, stream_ptr()),
-                          "l3d_attention_forward_f16")
+                    att = lib().l3d_attention_forward_f16_maxima if have_max else lib().l3d_attention_forward_f16
+                    check(att(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
+                              q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),
+                              ptr(ws), ptr(ctx), None, stream_ptr()), "l3d_attention_forward_f16")
                 else:
                     check(lib().l3d_attention_forward_strided(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
                                                               q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),

@@ -1769,3 +1769,32 @@ def test_pcn_encoder_f16_chain_matches_reference_order_path():
         for k in ("coarse_output", "fine_output"):
             np.testing.assert_allclose(fused[k].cpu().numpy(), ref[k].detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
     _fused.check_range(sync=True)
+
+
+def test_conv_f16_absmax_feeds_attention_maxima():
+    """The fused q|k|v projection reports max|q|, |k|, |v| from its own epilogue (l3d_pointwise_conv_f16_absmax) and
+    l3d_attention_forward_f16_maxima takes them instead of a pass over the three tensors: the maxima equal torch's, and the
+    attention output is bit-identical to the entry point that measures them itself (utils/transformer.py:183-189)."""
+    from learning3d_amd._lib import check, lib, ptr, stream_ptr
+    from learning3d_amd.models import _fused
+    rng = np.random.default_rng(41)
+    B, N, C, H = 2, 512, 512, 4
+    x = rng.standard_normal((B, N, C)).astype(np.float32)
+    w = (rng.standard_normal((3 * C, C)) / C ** 0.5 * np.repeat([1.0, 3.0, 0.2], C)[:, None]).astype(np.float32)
+    b = rng.standard_normal(3 * C).astype(np.float32) * 0.1
+    ws = torch.zeros(4, dtype=torch.int32, device="cuda")
+    qkv = _fused.pointwise_conv_f16(_fused.split_rows_f16(dev(x)), B, N, _fused.split_weights_f16(dev(w)), C, 3 * C, None, dev(b), amax=(ws, C))
+    plain = _fused.pointwise_conv_f16(_fused.split_rows_f16(dev(x)), B, N, _fused.split_weights_f16(dev(w)), C, 3 * C, None, dev(b))
+    assert torch.equal(qkv, plain)
+    got = ws[:3].view(torch.float32).cpu().numpy()
+    want = np.array([float(qkv[:, i * C:(i + 1) * C].abs().max()) for i in range(3)], dtype=np.float32)
+    assert np.array_equal(got, want), (got, want)
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    outs = []
+    for fn, wsp in ((lib().l3d_attention_forward_f16_maxima, ws), (lib().l3d_attention_forward_f16, torch.zeros(4, dtype=torch.int32, device="cuda"))):
+        ctx = torch.empty((B, C, N), dtype=torch.float32, device="cuda")
+        check(fn(ptr(q), ptr(k), ptr(v), B, H, C // H, N, N, q.stride(0), k.stride(0), v.stride(0), 1.0 / (C // H) ** 0.5,
+                 ptr(wsp), ptr(ctx), None, stream_ptr()), "attention")
+        outs.append(ctx)
+    assert torch.equal(outs[0], outs[1])
+    _fused.check_range(sync=True)
