@@ -72,6 +72,26 @@ __device__ __forceinline__ int af_exponent(float mx, int hi)
     return hi - e;
 }
 
+// Ablation builds of tools/probe_attention_f16.hip (timing only; results are garbage): at DCP's shape the kernel takes 352 us;
+// without its global loads 269; without the operand splits 310; without exp2 354; without all three 213 -- against 82 us of
+// matrix-pipe time.  What remains is the loop's structure: 16 barriers per key tile with 12 MFMAs behind each, two waves per SIMD.
+#ifdef AF_NOSPLIT
+#define af_split_w(a0, a1, c, H, Hs, M) do { H = __float_as_uint(a0); Hs = __float_as_uint(a1); M = H ^ Hs; } while (0)
+#define af_split_x(a0, a1, c, h, m) do { h = __float_as_uint(a0); m = __float_as_uint(a1); } while (0)
+#endif
+#ifdef AF_NOEXP
+#define AF_EXP2(x) (x)
+#else
+#define AF_EXP2(x) exp2f(x)
+#endif
+#ifdef AF_NOLOAD
+#define AF_GLOAD(x) (0.25f + 0.001f * (float)(lane + e))
+#define AF_GLOAD4(p) ((f32x4){0.25f, 0.5f, 0.125f, 0.375f} + 0.001f * (float)lane)
+#else
+#define AF_GLOAD(x) (x)
+#define AF_GLOAD4(p) (*(const f32x4 *)(p))
+#endif
+
 template <int ND /* D / 32 */>
 __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                                const float *__restrict__ v, int H, int N, int M,
@@ -121,8 +141,8 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
 #define AF_LOAD_QK(KC)                                                                               \
         do {                                                                                         \
             _Pragma("unroll") for (int e = 0; e < 8; e++) {                                          \
-                kv[e] = kb[(size_t)((KC) * 16 + skg * 8 + e) * M + kn];                              \
-                qv[e] = qb[(size_t)((KC) * 16 + skg * 8 + e) * N + qn];                              \
+                kv[e] = AF_GLOAD(kb[(size_t)((KC) * 16 + skg * 8 + e) * M + kn]);                    \
+                qv[e] = AF_GLOAD(qb[(size_t)((KC) * 16 + skg * 8 + e) * N + qn]);                    \
             }                                                                                        \
         } while (0)
 #define AF_STORE_QK(BUF)                                                                             \
@@ -185,13 +205,13 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
             }
         smax = fmaxf(smax, __shfl_xor(smax, 32, 64));   // the partner lane holds the column's other 64 keys
         const float m_new = fmaxf(m_run, smax);
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = AF_EXP2(m_run - m_new);
         float lsum = 0.f;
 #pragma unroll
         for (int a = 0; a < 4; a++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const float p = s[a][r] > 0.5f * AF_NEG ? exp2f(s[a][r] - m_new) : 0.f;
+                const float p = s[a][r] > 0.5f * AF_NEG ? AF_EXP2(s[a][r] - m_new) : 0.f;
                 s[a][r] = p;
                 lsum += p;
             }
@@ -211,8 +231,8 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
                 const float *vp_ = vb + (size_t)srow * M;                                            \
                 const int ja_ = j0 + 16 * (KS) + 4 * skg, jb_ = ja_ + 8;                             \
                 if (ja_ + 3 < M && jb_ + 3 < M && (M & 3) == 0) {                                    \
-                    va = *(const f32x4 *)(vp_ + ja_);                                                \
-                    vb2 = *(const f32x4 *)(vp_ + jb_);                                               \
+                    va = AF_GLOAD4(vp_ + ja_);                                                       \
+                    vb2 = AF_GLOAD4(vp_ + jb_);                                                      \
                 } else {                                                                             \
                     _Pragma("unroll") for (int e = 0; e < 4; e++) {                                  \
                         va[e] = ja_ + e < M ? vp_[ja_ + e] : 0.f;                                    \
