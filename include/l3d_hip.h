@@ -233,6 +233,14 @@ int l3d_group_concat(const float *xyz, const float *new_xyz, const float *featur
 int l3d_group_concat2(const float *xyz, const float *new_xyz, const float *features, const float *centre,
                       const int32_t *idx, int B, int N, int S, int K, int C, int C1, int order, float *out,
                       l3d_stream_t stream);
+/* The FIRST LAYER of those grouped MLPs without the grouped tensor (models/flownet3d.py:125-180, :182-242, :73-123): conv1
+ * is linear in [xyz[idx] - centre | feat[idx] | centre_feat], so with the per-point products U = (s W_feat) feat [B,N,C1],
+ * V = (s W_centre) centre_feat + t [B,S,C1] (or NULL, then `shift` [C1] carries t) and wx = s W_xyz [C1][3] (BN scale s and
+ * shift t folded in),  out[b][s K + k][:] = act(U[b][idx] + V[b][s] + wx (xyz[idx] - new_xyz[s])),  out [B, S K, C1]
+ * channel-last (the next layer's kernels take it as channel_last input).  C1 % 4 == 0, C1 <= 1024. */
+int l3d_group_first_layer(const float *U, const float *V, const float *shift, const float *wx, const float *xyz,
+                          const float *new_xyz, const int32_t *idx, int B, int N, int S, int K, int C1, int relu,
+                          float *out, l3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Batched 3x3 SVD head  == utils/svd.py:29-58 (T6, without the B host syncs)

@@ -39,6 +39,7 @@ SIGNATURES = {
     "l3d_group_points_grad": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "l3d_group_concat": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_group_concat2": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "l3d_group_first_layer": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_scatter_add_det_workspace_bytes": [_I, _I, _I],
     "l3d_scatter_add_det": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "l3d_edge_gather_max": [_P, _P, _I, _I, _I, _I, _I, _P, _L, _P],

@@ -14,6 +14,7 @@
 //
 // (K13/K14 knn / three_nn live in knn.hip.)
 #include "common.h"
+#include "split_bf16.h"          // f32x4
 
 #define BQ_TILE 2048
 
@@ -868,6 +869,67 @@ extern "C" int l3d_group_concat2(const float *xyz, const float *new_xyz, const f
     if (B > 65535) return L3D_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(group_concat2_kernel, dim3(l3d_divup((long)S * K, 256), B), dim3(256), 0, (hipStream_t)stream, xyz,
                        new_xyz, features, centre, idx, N, S, K, C, C1, order, out);
+    return l3d_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// First layer of a grouped shared MLP WITHOUT the grouped tensor (models/flownet3d.py:125-180 FlowEmbedding, :182-242
+// PointNetSetUpConv, :73-123 PointNetSetAbstraction).  The 1x1 conv acts on [xyz[idx] - centre | feat[idx] | centre_feat],
+// so -- like the PRNet layer below -- it splits into per-POINT products computed before the grouping,
+//     U = (s W_feat) feat  over the source points,   V = (s W_centre) centre_feat + t  over the centres,   Wx = s W_xyz,
+// and the layer's output for neighbour k of centre i is  act(U[idx_ik] + V_i + Wx (xyz[idx_ik] - centre_i)):
+// K times fewer conv flops and no [B, 3+C+C1, S, K] tensor (2.2 GB for FlowNet3D's su3 at B = 32, read once more by conv1).
+// Channel-last on both sides: a gathered row of U and an output row are C1 contiguous floats (16 bytes per lane); the
+// output [B, S K, C1] is what the next layer's kernels take as channel_last input.  A thread owns 4 channels and walks rows.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void group_first_layer_kernel(const float *__restrict__ U /*[B,N,C1]*/,
+                                                                const float *__restrict__ V /*[B,S,C1] or null*/,
+                                                                const float *__restrict__ shift /*[C1] or null*/,
+                                                                const float *__restrict__ wx /*[C1][3]*/,
+                                                                const float *__restrict__ xyz /*[B,N,3]*/,
+                                                                const float *__restrict__ new_xyz /*[B,S,3]*/,
+                                                                const int32_t *__restrict__ idx /*[B,S,K]*/, int N, int S, int K,
+                                                                int C1, int act, float *__restrict__ out /*[B,S*K,C1]*/)
+{
+    const int lpr = C1 >> 2, rpb = 256 / lpr;                    // lanes per row, rows per pass of the workgroup
+    const int lc = threadIdx.x % lpr, rsub = threadIdx.x / lpr;
+    if (rsub >= rpb) return;
+    const int b = blockIdx.y;
+    f32x4 w0, w1, w2, sh;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const float *w = wx + (size_t)(4 * lc + u) * 3;
+        w0[u] = w[0]; w1[u] = w[1]; w2[u] = w[2];
+        sh[u] = shift ? shift[4 * lc + u] : 0.f;
+    }
+    const long SK = (long)S * K;
+    const int32_t *ib = idx + (size_t)b * SK;
+    for (long e = (long)blockIdx.x * rpb + rsub; e < SK; e += (long)gridDim.x * rpb) {
+        const int s_ = (int)(e / K), j = ib[e];
+        const float *p = xyz + ((size_t)b * N + j) * 3, *q = new_xyz + ((size_t)b * S + s_) * 3;
+        const float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+        f32x4 r = *(const f32x4 *)(U + ((size_t)b * N + j) * C1 + 4 * lc) + sh;
+        if (V) r += *(const f32x4 *)(V + ((size_t)b * S + s_) * C1 + 4 * lc);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float v = fmaf(w2[u], dz, fmaf(w1[u], dy, fmaf(w0[u], dx, r[u])));
+            r[u] = act ? l3d_act(v, act) : v;
+        }
+        *(f32x4 *)(out + ((size_t)b * SK + e) * C1 + 4 * lc) = r;
+    }
+}
+
+extern "C" int l3d_group_first_layer(const float *U, const float *V, const float *shift, const float *wx, const float *xyz,
+                                     const float *new_xyz, const int32_t *idx, int B, int N, int S, int K, int C1, int relu,
+                                     float *out, l3d_stream_t stream)
+{
+    L3D_REQUIRE(U && wx && xyz && new_xyz && idx && out && B > 0 && N > 0 && S > 0 && K > 0 && C1 > 0);
+    if (B > 65535 || (C1 & 3) || C1 > 1024 || (((size_t)U | (size_t)V | (size_t)out) & 15)) return L3D_ERR_UNSUPPORTED;
+    const int rpb = 256 / (C1 >> 2);
+    long nblk = l3d_divup((long)S * K, rpb);
+    if (nblk > 2048) nblk = 2048;
+    hipLaunchKernelGGL(group_first_layer_kernel, dim3((unsigned)nblk, B), dim3(256), 0, (hipStream_t)stream, U, V, shift, wx, xyz,
+                       new_xyz, idx, N, S, K, C1, relu, out);
     return l3d_check_launch();
 }
 

@@ -221,12 +221,16 @@ def pointwise_conv_f16_pool(x_planes, B, N, w_planes, Cin, Cout, scale=None, shi
     return img, (part.max(dim=2)[0] if pool else None)
 
 
-def pointwise_conv_maxpool(x, w, scale, shift, relu, pool, w_split=None):
+def pointwise_conv_maxpool(x, w, scale, shift, relu, pool, w_split=None, channel_last=False):
     """pointwise_conv followed by max over every `pool` consecutive points, in one launch:
-    x [B,Cin,S*pool] -> [B,Cout,S].  pool in (8, 16, 32, 64); returns None if the kernel does not take the shape."""
+    x [B,Cin,S*pool] (or [B,S*pool,Cin] with channel_last) -> [B,Cout,S].  pool in (8, 16, 32, 64); returns None if the
+    kernel does not take the shape."""
     require_gpu(x)
     x, w = f32c(x), f32c(w)
-    B, Cin, N = x.shape
+    if channel_last:
+        B, N, Cin = x.shape
+    else:
+        B, Cin, N = x.shape
     Cout = w.shape[0]
     if pool not in (8, 16, 32, 64) or N % pool or Cout <= 8:
         return None
@@ -237,11 +241,11 @@ def pointwise_conv_maxpool(x, w, scale, shift, relu, pool, w_split=None):
     if split_eligible(Cin, Cout, N) and N % 256 == 0:
         if w_split is None:
             w_split = split_rows(w)
-        check(lib().l3d_pointwise_conv_split_maxpool(ptr(x), 0, ptr(w_split), ptr(scale), ptr(shift), bstride, B, Cin, Cout,
+        check(lib().l3d_pointwise_conv_split_maxpool(ptr(x), int(channel_last), ptr(w_split), ptr(scale), ptr(shift), bstride, B, Cin, Cout,
                                                      N, int(relu), pool, ptr(y), stream_ptr()),
               "l3d_pointwise_conv_split_maxpool")
         return y
-    check(lib().l3d_pointwise_conv_maxpool(ptr(x), 0, ptr(w), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N, int(relu),
+    check(lib().l3d_pointwise_conv_maxpool(ptr(x), int(channel_last), ptr(w), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N, int(relu),
                                            pool, ptr(y), stream_ptr()), "l3d_pointwise_conv_maxpool")
     return y
 

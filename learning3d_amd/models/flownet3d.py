@@ -13,28 +13,79 @@ from ..utils.model_common_utils import query_ball_point
 from . import _fused
 
 
-def _mlp_stack(x, convs, bns, module, pool=False):
+FACTOR_FIRST_LAYER = True    # grouped first layers as per-point products + a gather (l3d_group_first_layer); False: grouped tensor + conv
+
+
+def _mlp_stack(x, convs, bns, module, pool=False, cl_shape=None):
     """x [B,C,S,K] (or [B,C,N]) through [conv1x1 + BN + ReLU]*; fused MFMA path at inference.
     pool=True (x 4-D): also take the max over K, i.e. return [B,C',S] -- at inference the last layer's
-    kernel does it in its epilogue (no [B,C',S,K] activation, no reduction launch)."""
+    kernel does it in its epilogue (no [B,C',S,K] activation, no reduction launch).
+    cl_shape = (S, K): x is [B, S*K, C] channel-last (the factored first layer's output, inference only)."""
     if len(convs) == 0:
+        if cl_shape is not None:
+            x = x.view(x.shape[0], cl_shape[0], cl_shape[1], x.shape[2]).permute(0, 3, 1, 2)
         return torch.max(x, -1)[0] if pool else x
-    if _fused.can_fuse(module, x):
-        shp = x.shape
-        h = x.reshape(shp[0], shp[1], -1)
+    if cl_shape is not None or _fused.can_fuse(module, x):
+        if cl_shape is not None:
+            shp = (x.shape[0], x.shape[2], cl_shape[0], cl_shape[1])
+            h = x
+        else:
+            shp = x.shape
+            h = x.reshape(shp[0], shp[1], -1)
         last = len(convs) - 1
         for i, (conv, bn) in enumerate(zip(convs, bns)):
             w, sc, sh = _fused.fold_conv_bn(conv, bn)
-            if pool and i == last and x.dim() == 4:
-                y = _fused.pointwise_conv_maxpool(h, w, sc, sh, True, shp[3])
+            cl = cl_shape is not None and i == 0
+            if pool and i == last and len(shp) == 4:
+                y = _fused.pointwise_conv_maxpool(h, w, sc, sh, True, shp[3], channel_last=cl)
                 if y is not None:
                     return y
-            h = _fused.pointwise_conv(h, w, sc, sh, relu=True)
+            h = _fused.pointwise_conv(h, w, sc, sh, relu=True, channel_last=cl)
         h = h.view(shp[0], h.shape[1], *shp[2:])
         return torch.max(h, -1)[0] if pool else h
     for conv, bn in zip(convs, bns):
         x = F.relu(bn(conv(x)))
     return torch.max(x, -1)[0] if pool else x
+
+
+def _factored_first_layer(src_xyz_t, centre_xyz_t, src_feat, centre_feat, idx, order, conv, bn, module):
+    """conv1 + BN + ReLU of a grouped MLP (reference models/flownet3d.py:163-172, :226-232) without forming its input: the
+    conv is linear in [xyz[idx] - centre | feat[idx] | centre_feat] (order 0; order 1: [feat[idx] | xyz[idx] - centre]), so
+    U = (s W_feat) feat over the SOURCE points and V = (s W_centre) centre_feat + t over the centres are 1x1 convs on
+    ungrouped tensors (K times fewer rows) and the layer is a gather: act(U[idx] + V + (s W_xyz)(xyz[idx] - centre)).
+    -> [B, S*K, C1] channel-last, or None when the route does not apply (the caller then groups and convolves)."""
+    if (not FACTOR_FIRST_LAYER or not _fused.can_fuse(module, src_xyz_t, centre_xyz_t, src_feat) or not src_feat.is_cuda
+            or idx.dtype != torch.int32 or (centre_feat is not None and not _fused.can_fuse(module, centre_feat))):
+        return None
+    from .._lib import check, lib, ptr, stream_ptr
+    w, sc, sh = _fused.fold_conv_bn(conv, bn)
+    C1, C = w.shape[0], src_feat.shape[1]
+    Cc = centre_feat.shape[1] if centre_feat is not None else 0
+    if C1 % 4 or C1 > 1024 or w.shape[1] != 3 + C + Cc:
+        return None
+    key = (w.data_ptr(), w._version, sc.data_ptr() if sc is not None else 0, order, C, Cc)
+    hit = conv.__dict__.get("_l3d_factored")
+    if hit is None or hit[0] != key:
+        if order == 0:
+            wx, wf, wc = w[:, :3], w[:, 3:3 + C], w[:, 3 + C:]
+        else:
+            wf, wx, wc = w[:, :C], w[:, C:C + 3], w[:, C + 3:]
+        wx = (wx * sc[:, None] if sc is not None else wx).contiguous()
+        hit = (key, (wf.contiguous(), wc.contiguous() if Cc else None, wx))
+        conv.__dict__["_l3d_factored"] = hit
+    wf, wc, wx = hit[1]
+    B, N, _ = src_xyz_t.shape
+    S, K = idx.shape[1], idx.shape[2]
+    # the per-point products are ordinary 1x1 convs (K times fewer rows than the grouped layer); channel-last for the gather
+    U = _fused.pointwise_conv(src_feat.float().contiguous(), wf, sc, None).transpose(1, 2).contiguous()           # [B,N,C1]
+    V = None
+    if Cc:
+        V = _fused.pointwise_conv(centre_feat.float().contiguous(), wc, sc, sh).transpose(1, 2).contiguous()     # [B,S,C1]
+    out = torch.empty((B, S * K, C1), dtype=torch.float32, device=U.device)
+    check(lib().l3d_group_first_layer(ptr(U), ptr(V), ptr(sh) if (V is None and sh is not None) else None, ptr(wx),
+                                      ptr(src_xyz_t.contiguous()), ptr(centre_xyz_t.contiguous()), ptr(idx.contiguous()),
+                                      B, N, S, K, C1, 1, ptr(out), stream_ptr()), "l3d_group_first_layer")
+    return out
 
 
 def _grouped_input(src_xyz_t, centre_xyz_t, src_feat, centre_feat, idx, order, module):
@@ -109,6 +160,9 @@ class FlowEmbedding(nn.Module):
             _, idx_knn = pointutils.knn(self.nsample, pos1_t, pos2_t)
             cnt = cnt.view(B, -1, 1).repeat(1, 1, self.nsample)
             idx = idx_knn[cnt > (self.nsample - 1)]
+        first = _factored_first_layer(pos2_t, pos1_t, feature2, feature1, idx, 0, self.mlp_convs[0], self.mlp_bns[0], self)
+        if first is not None:
+            return pos1, _mlp_stack(first, self.mlp_convs[1:], self.mlp_bns[1:], self, pool=True, cl_shape=tuple(idx.shape[1:]))
         fused = _grouped_input(pos2_t, pos1_t, feature2, feature1, idx, 0, self)
         if fused is not None:
             return pos1, _mlp_stack(fused, self.mlp_convs, self.mlp_bns, self, pool=True)
@@ -147,13 +201,20 @@ class PointNetSetUpConv(nn.Module):
             _, idx = pointutils.knn(self.nsample, pos1_t, pos2_t)
         else:
             idx = query_ball_point(self.radius, self.nsample, pos2_t, pos1_t)
-        feat_new = _grouped_input(pos2_t, pos1_t, feature2, None, idx, 1, self)
-        if feat_new is None:
+        first = None
+        if len(self.mlp1_convs):
+            first = _factored_first_layer(pos2_t, pos1_t, feature2, None, idx, 1, self.mlp1_convs[0][0], self.mlp1_convs[0][1], self)
+        feat_new = _grouped_input(pos2_t, pos1_t, feature2, None, idx, 1, self) if first is None else None
+        if first is None and feat_new is None:
             pos2_grouped = pointutils.grouping_operation(pos2.contiguous(), idx)
             pos_diff = pos2_grouped - pos1.view(B, -1, N, 1)
             feat2_grouped = pointutils.grouping_operation(feature2.contiguous(), idx)
             feat_new = torch.cat([feat2_grouped, pos_diff], dim=1)
-        feat_new = _mlp_stack(feat_new, [s[0] for s in self.mlp1_convs], [s[1] for s in self.mlp1_convs], self, pool=True)
+        if first is not None:
+            feat_new = _mlp_stack(first, [s[0] for s in self.mlp1_convs[1:]], [s[1] for s in self.mlp1_convs[1:]], self, pool=True,
+                                  cl_shape=tuple(idx.shape[1:]))
+        else:
+            feat_new = _mlp_stack(feat_new, [s[0] for s in self.mlp1_convs], [s[1] for s in self.mlp1_convs], self, pool=True)
         if feature1 is not None:
             feat_new = torch.cat([feat_new, feature1], dim=1)
         return _mlp_stack(feat_new, [s[0] for s in self.mlp2_convs], [s[1] for s in self.mlp2_convs], self)

@@ -1798,3 +1798,41 @@ def test_conv_f16_absmax_feeds_attention_maxima():
         outs.append(ctx)
     assert torch.equal(outs[0], outs[1])
     _fused.check_range(sync=True)
+
+
+def test_flownet3d_factored_first_layer_matches_grouped_route():
+    """FlowEmbedding / PointNetSetUpConv (reference models/flownet3d.py:125-180, :182-242): the first grouped layer as
+    per-point products + l3d_group_first_layer against (a) the grouped-tensor route of this package and (b) the reference-order
+    torch ops (autograd route), random BN statistics, kNN and ball-query grouping."""
+    import learning3d_amd.models.flownet3d as F3
+    rng = np.random.default_rng(53)
+    B, N1, N2, C = 2, 256, 128, 64
+    pos1 = dev(rng.uniform(-1, 1, (B, 3, N1)).astype(np.float32))
+    pos2 = dev(rng.uniform(-1, 1, (B, 3, N2)).astype(np.float32))
+    f1 = dev(rng.standard_normal((B, C, N1)).astype(np.float32))
+    f2 = dev(rng.standard_normal((B, C, N2)).astype(np.float32))
+    torch.manual_seed(9)
+    mods = [F3.FlowEmbedding(radius=10.0, nsample=16, in_channel=C, mlp=[128, 128, 128], pooling='max', corr_func='concat'),
+            F3.PointNetSetUpConv(nsample=8, radius=2.4, f1_channel=C, f2_channel=C, mlp=[128, 64, 256], mlp2=[128]),
+            F3.PointNetSetUpConv(nsample=8, radius=0.9, f1_channel=C, f2_channel=C, mlp=[64], mlp2=[], knn=False)]
+    for m in mods:
+        m.cuda().eval()
+        for sub in m.modules():
+            if isinstance(sub, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                sub.running_mean.uniform_(-0.2, 0.2); sub.running_var.uniform_(0.5, 1.5)
+                sub.weight.data.uniform_(0.5, 1.5); sub.bias.data.uniform_(-0.3, 0.3)
+        outs = {}
+        for flag in (True, False):
+            F3.FACTOR_FIRST_LAYER = flag
+            try:
+                with torch.no_grad():
+                    r = m(pos1, pos2, f1, f2)
+            finally:
+                F3.FACTOR_FIRST_LAYER = True
+            outs[flag] = (r[1] if isinstance(r, tuple) else r)
+        ref = m(pos1, pos2, f1.clone().requires_grad_(), f2)                      # torch conv / BN ops in the reference's order
+        ref = (ref[1] if isinstance(ref, tuple) else ref).detach()
+        scale = float(ref.abs().max())
+        for flag in (True, False):
+            assert outs[flag].shape == ref.shape
+            assert float((outs[flag] - ref).abs().max()) <= 2e-5 * scale + 1e-6, (type(m).__name__, flag)
