@@ -35,6 +35,14 @@ def _mlp_stack(x, convs, bns, module, pool=False, cl_shape=None):
         last = len(convs) - 1
         for i, (conv, bn) in enumerate(zip(convs, bns)):
             w, sc, sh = _fused.fold_conv_bn(conv, bn)
+            if i == 0 and cl_shape is None and h.shape[1] > w.shape[1]:
+                # the producer padded the input with zero channels to a multiple of 16 (PointNetFeaturePropogation: 259 -> 272,
+                # which moves the layer from the fp32-MFMA kernel to the matrix-core split kernels): zero weight columns to match
+                hit = conv.__dict__.get("_l3d_wpad")
+                if hit is None or hit[0] != (w.data_ptr(), w._version, h.shape[1]):
+                    hit = ((w.data_ptr(), w._version, h.shape[1]), F.pad(w, (0, h.shape[1] - w.shape[1])).contiguous())
+                    conv.__dict__["_l3d_wpad"] = hit
+                w = hit[1]
             cl = cl_shape is not None and i == 0
             if pool and i == last and len(shp) == 4:
                 y = _fused.pointwise_conv_maxpool(h, w, sc, sh, True, shp[3], channel_last=cl)
@@ -247,6 +255,10 @@ class PointNetFeaturePropogation(nn.Module):
             from .._lib import check, lib, ptr, stream_ptr
             f2 = feature2.float().contiguous()
             f1 = feature1.float().contiguous() if feature1 is not None else None
+            cin = f2.shape[1] + (f1.shape[1] if f1 is not None else 0)
+            if (f1 is not None and cin % 16 and len(self.mlp_convs) and _fused.split_eligible(cin + (-cin) % 16, self.mlp_convs[0].out_channels, N)):
+                # conv1's 259 input channels keep it off the bf16x3 / f16x2 kernels (Cin % 16): carry zero channels along
+                f1 = torch.cat([f1, f1.new_zeros((B, (-cin) % 16, N))], dim=1)
             c, c1, m = f2.shape[1], (f1.shape[1] if f1 is not None else 0), f2.shape[2]
             feat_new = torch.empty((B, c + c1, N), dtype=torch.float32, device=f2.device)
             check(lib().l3d_three_interpolate_concat(B, c, m, N, ptr(f2), ptr(idx.contiguous()), ptr(weight.contiguous()),
