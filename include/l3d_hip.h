@@ -297,7 +297,8 @@ int l3d_layernorm_ref(const float *x, const float *a, const float *b, float eps,
                       l3d_stream_t stream);
 /* The same, and additionally the output as the fp16 activation image l3d_pointwise_conv_f16 consumes (img:
  * l3d_f16_act_bytes(rows, C) bytes): the Linear layers behind a LayerNorm then run as f16x2 with no split pass.  The
- * plane scale comes from the layer's parameters (|y_c| <= |a_c| sqrt(C-1) + |b_c|).  C % 8 == 0, C <= 512. */
+ * plane scale comes from the layer's parameters (|y_c| <= |a_c| sqrt(C-1) + |b_c|).  C % 8 == 0, C <= 512.  y may be NULL
+ * (image only). */
 int l3d_layernorm_planes(const float *x, const float *a, const float *b, float eps, long rows, int C, float *y, void *img,
                          l3d_stream_t stream);
 /* Residual connection x + sublayer(norm(x)) of utils/transformer.py:82-88 when the sublayer output is channel-first:

@@ -346,7 +346,7 @@ extern "C" int l3d_add_transposed(const float *x, const float *y, int B, int N, 
 // needs no pass over y either: |y_c| <= |a_c| sqrt(C-1) + |b_c| because sum_c z_c^2 <= C-1 for z = (x-mean)/(std+eps)
 // with the unbiased std, so T comes from the layer's own parameters and cannot be exceeded.
 // A workgroup normalises 16 rows (a wave per row, 4 rows per wave), parks the 16-byte plane cells in LDS as [octet][row]
-// and writes them out as 256-byte runs (16 rows of one octet); y itself is written as before.  (32 rows per workgroup --
+// and writes them out as 256-byte runs (16 rows of one octet); y itself is written as before (when asked for).  (32 rows per workgroup --
 // 512-byte runs, 67 KB of LDS, two workgroups per CU -- was slower: 55 us against the plain kernel's 23.)
 // ---------------------------------------------------------------------------------------------
 #define LNP_ROWS 16
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(const float *__re
                 o.y = ga.y * (v[i].y - mean) * inv + be.y;
                 o.z = ga.z * (v[i].z - mean) * inv + be.z;
                 o.w = ga.w * (v[i].w - mean) * inv + be.w;
-                yr[q] = o;
+                if (y) yr[q] = o;
             }
             // the odd lane's four values join the even lane's: one octet = channels 8 o .. 8 o + 7
             const float n0 = __shfl_down(o.x, 1, 64), n1 = __shfl_down(o.y, 1, 64), n2 = __shfl_down(o.z, 1, 64), n3 = __shfl_down(o.w, 1, 64);
@@ -447,11 +447,12 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(const float *__re
     }
 }
 
-// y as l3d_layernorm_ref, plus img = the activation image of y (l3d_f16_act_bytes(rows, C) bytes) for l3d_pointwise_conv_f16
+// y as l3d_layernorm_ref (or NULL: planes only -- every consumer of the pointer network's sublayer norms reads the image, and the
+// fp32 copy is a third of this kernel's traffic), plus img = the activation image of y (l3d_f16_act_bytes(rows, C) bytes)
 extern "C" int l3d_layernorm_planes(const float *x, const float *a, const float *b, float eps, long rows, int C, float *y,
                                     void *img, l3d_stream_t stream)
 {
-    L3D_REQUIRE(x && a && b && y && img && rows > 0 && C > 1);
+    L3D_REQUIRE(x && a && b && img && rows > 0 && C > 1);
     if (C % 8 || C > 512 || ((((size_t)x) | ((size_t)y) | ((size_t)a) | ((size_t)b) | ((size_t)img)) & 15)) return L3D_ERR_UNSUPPORTED;
     const size_t pb = (size_t)(C / 8) * (size_t)rows * 16;
     unsigned char *d = (unsigned char *)img;

@@ -15,6 +15,7 @@ import torch.nn.functional as F
 
 
 FLASH_ATTENTION = True      # l3d_attention_forward for d_k in {32, 64, 128}; False: torch matmul + softmax + matmul
+DEFER_LN_VALUES = True      # sublayer norms write only their fp16 plane image; fp32 values on demand (_ln_values)
 PROJECTION_MAXIMA = True    # the f16x2 q|k|v projections report max|q|, |k|, |v| from their epilogues (False: a pass over q, k, v)
 
 _ATT_WS = {}
@@ -28,6 +29,27 @@ def _attention_workspace(device):
         ws = torch.zeros(4, dtype=torch.int32, device=device)
         _ATT_WS[key] = ws
     return ws
+
+
+def _ln_values(t):
+    """A LayerNorm output whose fp32 values were deferred (LayerNorm.forward(values=False): only the fp16 plane image was
+    written): compute them now, into the tensor's own storage.  Everything in this module that READS such a tensor calls this
+    first; the fast routes never do (they consume the image)."""
+    pend = getattr(t, "_l3d_pending", None) if t is not None else None
+    if pend is not None:
+        from .._lib import check, lib, ptr, stream_ptr
+        xc, ln = pend
+        C = xc.size(-1)
+        check(lib().l3d_layernorm_ref(ptr(xc), ptr(ln.a_2.detach().contiguous()), ptr(ln.b_2.detach().contiguous()),
+                                      float(ln.eps), xc.numel() // C, C, ptr(t), stream_ptr()), "l3d_layernorm_ref")
+        t._l3d_pending = None
+    return t
+
+
+def _planes_ok(fn):
+    """Marks a sublayer callable whose every read of its input goes through _ln_values / the plane image."""
+    fn._l3d_planes_ok = True
+    return fn
 
 
 def _fast_linear_ok(lin, x, n_points):
@@ -72,6 +94,7 @@ def _linear_cf(lin, x, channel_last, relu=False, out_scale=None, planes=None, ou
         return _fused.pointwise_conv_f16(img, nb_, np_, c16[1], lin.in_features, lin.out_features, scale, bias, relu=relu)
     if out_planes:
         return None
+    x = _ln_values(x)
     key = (lin.weight.data_ptr(), lin.weight._version, str(lin.weight.device))
     cache = getattr(lin, "_l3d_split", None)
     if cache is None or cache[0] != key:
@@ -108,7 +131,9 @@ class LayerNorm(nn.Module):
         self.b_2 = nn.Parameter(torch.zeros(features))
         self.eps = eps
 
-    def forward(self, x):
+    def forward(self, x, values=True):
+        """values=False (internal; SublayerConnection passes it for sublayers marked _planes_ok): when the output is also
+        produced as an fp16 plane image, the fp32 values are not written until somebody asks (_ln_values)."""
         C = x.size(-1)
         if (x.is_cuda and x.dtype == torch.float32 and C % 4 == 0 and 1 < C <= 2048
                 and not (torch.is_grad_enabled() and (x.requires_grad or self.a_2.requires_grad))):
@@ -122,8 +147,11 @@ class LayerNorm(nn.Module):
                 # (_linear_cf) then need no split pass; the image rides on the tensor object
                 img = torch.empty(lib().l3d_f16_act_bytes(rows, C), dtype=torch.uint8, device=xc.device)
                 check(lib().l3d_layernorm_planes(ptr(xc), ptr(self.a_2.detach().contiguous()), ptr(self.b_2.detach().contiguous()),
-                                                 float(self.eps), rows, C, ptr(y), ptr(img), stream_ptr()), "l3d_layernorm_planes")
+                                                 float(self.eps), rows, C, ptr(y) if values else None, ptr(img), stream_ptr()),
+                      "l3d_layernorm_planes")
                 y._l3d_planes = img
+                if not values:
+                    y._l3d_pending = (xc, self)
                 return y
             check(lib().l3d_layernorm_ref(ptr(xc), ptr(self.a_2.detach().contiguous()), ptr(self.b_2.detach().contiguous()),
                                           float(self.eps), rows, C, ptr(y), stream_ptr()), "l3d_layernorm_ref")
@@ -139,7 +167,7 @@ class SublayerConnection(nn.Module):
         self.norm = LayerNorm(size)
 
     def forward(self, x, sublayer):
-        y = sublayer(self.norm(x))
+        y = sublayer(self.norm(x, values=not (DEFER_LN_VALUES and getattr(sublayer, "_l3d_planes_ok", False))))
         if (x.is_cuda and x.dim() == 3 and y.shape == x.shape and x.dtype == torch.float32 and y.dtype == torch.float32
                 and x.is_contiguous() and not y.is_contiguous() and y.transpose(1, 2).is_contiguous()
                 and not (torch.is_grad_enabled() and (x.requires_grad or y.requires_grad))):
@@ -237,7 +265,7 @@ class MultiHeadedAttention(nn.Module):
                 p = F.softmax(torch.matmul(qh.transpose(-2, -1), kh) / math.sqrt(self.d_k), dim=-1)   # [B,h,N,M]
                 ctx = torch.matmul(vh, p.transpose(-2, -1)).reshape(nb, C_, n_q)
             return _linear_cf(self.linears[-1], ctx, False).transpose(1, 2)                       # [B,N,C] view
-        q, k, v = [lin(x).view(nb, -1, self.h, self.d_k).transpose(1, 2)
+        q, k, v = [lin(_ln_values(x)).view(nb, -1, self.h, self.d_k).transpose(1, 2)
                    for lin, x in zip(self.linears, (query, key, value))]
         x, self.attn = attention(q, k, v, mask=mask, dropout=self.dropout)
         x = x.transpose(1, 2).contiguous().view(nb, -1, self.h * self.d_k)
@@ -245,6 +273,8 @@ class MultiHeadedAttention(nn.Module):
 
 
 class PositionwiseFeedForward(nn.Module):
+    _l3d_planes_ok = True          # reads its input through the plane image or _ln_values only
+
     def __init__(self, d_model, d_ff, dropout=0.1):
         super().__init__()
         self.w_1 = nn.Linear(d_model, d_ff)
@@ -261,7 +291,7 @@ class PositionwiseFeedForward(nn.Module):
                     return _linear_cf(self.w_2, None, True, planes=hp).transpose(1, 2)
             h = _linear_cf(self.w_1, x, True, relu=True)                  # [B,d_ff,N]
             return _linear_cf(self.w_2, h, False).transpose(1, 2)         # [B,N,d_model] view
-        return self.w_2(F.relu(self.w_1(x)))
+        return self.w_2(F.relu(self.w_1(_ln_values(x))))
 
 
 class EncoderLayer(nn.Module):
@@ -273,7 +303,7 @@ class EncoderLayer(nn.Module):
         self.size = size
 
     def forward(self, x, mask):
-        x = self.sublayer[0](x, lambda y: self.self_attn(y, y, y, mask))
+        x = self.sublayer[0](x, _planes_ok(lambda y: self.self_attn(y, y, y, mask)))
         return self.sublayer[1](x, self.feed_forward)
 
 
@@ -287,8 +317,8 @@ class DecoderLayer(nn.Module):
         self.sublayer = clones(SublayerConnection(size, dropout), 3)
 
     def forward(self, x, memory, src_mask, tgt_mask):
-        x = self.sublayer[0](x, lambda y: self.self_attn(y, y, y, tgt_mask))
-        x = self.sublayer[1](x, lambda y: self.src_attn(y, memory, memory, src_mask))
+        x = self.sublayer[0](x, _planes_ok(lambda y: self.self_attn(y, y, y, tgt_mask)))
+        x = self.sublayer[1](x, _planes_ok(lambda y: self.src_attn(y, memory, memory, src_mask)))
         return self.sublayer[2](x, self.feed_forward)
 
 

@@ -1836,3 +1836,34 @@ def test_flownet3d_factored_first_layer_matches_grouped_route():
         for flag in (True, False):
             assert outs[flag].shape == ref.shape
             assert float((outs[flag] - ref).abs().max()) <= 2e-5 * scale + 1e-6, (type(m).__name__, flag)
+
+
+def test_layernorm_deferred_values_materialise_on_demand():
+    """utils/transformer.py: inside SublayerConnection the norm output of a sublayer marked _planes_ok is written as the fp16
+    plane image only (reference :82-88, :109-119); whoever reads its fp32 values gets them through _ln_values.  Unmarked
+    sublayers (user callables) always see real values; a marked sublayer that falls to its slow route (mask given) must too."""
+    from learning3d_amd.utils import transformer as T
+    torch.manual_seed(21)
+    ln = T.LayerNorm(512).cuda()
+    ln.a_2.data.uniform_(0.5, 1.5); ln.b_2.data.uniform_(-0.5, 0.5)
+    x = dev(rand((2, 256, 512), 22, -2, 2))
+    with torch.no_grad():
+        full = ln(x)
+        lazy = ln(x, values=False)
+        assert getattr(lazy, "_l3d_pending", None) is not None and getattr(full, "_l3d_pending", None) is None
+        assert torch.equal(lazy._l3d_planes[:-12], full._l3d_planes[:-12])          # planes + 2^-T (the last 12 bytes are scratch)
+        assert T._ln_values(lazy) is lazy and lazy._l3d_pending is None
+        np.testing.assert_allclose(lazy.cpu().numpy(), full.cpu().numpy(), rtol=1e-6, atol=1e-6)
+        sc = T.SublayerConnection(512).cuda().eval()
+        sc.norm.a_2.data.copy_(ln.a_2.data); sc.norm.b_2.data.copy_(ln.b_2.data)
+        out = sc(x, lambda y: y * 2.0)                                        # unmarked callable
+        np.testing.assert_allclose(out.cpu().numpy(), (x + 2.0 * full).cpu().numpy(), rtol=1e-6, atol=1e-5)
+        mha = T.MultiHeadedAttention(4, 512).cuda().eval()
+        mask = torch.ones((1, 256, 256), device="cuda")
+        got = sc(x, T._planes_ok(lambda y: mha(y, y, y, mask)))               # marked, but the mask forces the slow route
+        want = x + mha(full, full, full, mask)
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        ffn = T.PositionwiseFeedForward(512, 1000).cuda().eval()              # d_ff not a multiple of 256: bf16x3 / torch route
+        got = sc(x, ffn)
+        want = x + ffn(full)
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-4)

@@ -24,6 +24,7 @@ with torch.no_grad():
     sp, tp = net.pointer(se, te)
     print("SVD head               %9.1f us" % timeit(lambda: net.head(se + sp, te + tp, src, tmpl)))
     import learning3d_amd.utils.transformer as T
-    for flag in (False, True, False, True):
-        T.PROJECTION_MAXIMA = flag
-        print("pointer, projection maxima %-5s %9.1f us" % (flag, timeit(lambda: net.pointer(se, te), warm=3, iters=20)))
+    for name in ("PROJECTION_MAXIMA", "DEFER_LN_VALUES"):
+        for flag in (False, True, False, True):
+            setattr(T, name, flag)
+            print("pointer, %s %-5s %9.1f us" % (name, flag, timeit(lambda: net.pointer(se, te), warm=3, iters=20)))
