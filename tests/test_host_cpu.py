@@ -42,6 +42,19 @@ def test_argument_validation_without_gpu():
     assert l.l3d_ball_query(1, 0, 1, 0.5, 4, None, None, None, None) == -1
     assert l.l3d_edgeconv_packed_floats(64, 64, 128, 256) == 46080 + 45568 + 67584 + 67584 + 448 + 16   # + the f16x2 copy, its biases, 16 scales
     assert l.l3d_edgeconv_packed_floats(32, 32, 64, 128) == 0
+    # round-2 entry points: same contract (null / non-positive -> -1; shapes the kernels do not take -> -2, before any launch)
+    import ctypes as C
+    buf = C.create_string_buffer(64)
+    p = C.cast(buf, C.c_void_p)
+    assert l.l3d_group_first_layer(None, None, None, None, None, None, None, 1, 8, 4, 2, 32, 1, None, None) == -1
+    assert l.l3d_group_first_layer(p, None, None, p, p, p, p, 1, 8, 4, 2, 30, 1, p, None) == -2          # C1 % 4
+    assert l.l3d_first_layer_f16_planes(None, 1, None, None, None, 1, 3, 128, 256, 1, None, None, None) == -1
+    assert l.l3d_first_layer_f16_planes(p, 1, p, None, p, 1, 9, 128, 256, 1, p, None, None) == -2         # Cin > 8
+    assert l.l3d_pointwise_conv_f16_pool(p, p, None, None, 0, None, 1, 128, 256, 256, 0, None, None, None) == -1   # no output asked for
+    assert l.l3d_pointwise_conv_f16_pool(p, p, None, None, 0, None, 1, 128, 256, 256, 0, p, None, None) == -1      # image without obs
+    assert l.l3d_pointwise_conv_f16_absmax(p, p, None, None, 0, 1, 128, 256, 256, 0, p, p, 100, None) == -2        # group size % 256
+    assert l.l3d_attention_forward_f16_maxima(None, None, None, 1, 4, 128, 256, 256, 0, 0, 0, 0.1, None, None, None, None) == -1
+    assert l.l3d_layernorm_planes(p, p, p, 1e-6, 4, 520, None, p, None) == -2                                      # C > 512
 
 
 def test_product_path_fails_loudly_on_cpu_tensors():
