@@ -241,6 +241,13 @@ int l3d_group_concat2(const float *xyz, const float *new_xyz, const float *featu
 int l3d_group_first_layer(const float *U, const float *V, const float *shift, const float *wx, const float *xyz,
                           const float *new_xyz, const int32_t *idx, int B, int N, int S, int K, int C1, int relu,
                           float *out, l3d_stream_t stream);
+/* The same layer written as the fp16 activation image of the next f16x2 layer (l3d_f16_act_bytes(B S K, C1) bytes, rows
+ * (b, s, k)) instead of fp32: the rest of the grouped MLP then runs on l3d_pointwise_conv_f16_planes / _pool with no fp32
+ * activation.  bound: device float >= max|output| (fixes the plane scale; *range_flag is raised if it was exceeded).
+ * C1 = 64, 128 or 256. */
+int l3d_group_first_layer_planes(const float *U, const float *V, const float *shift, const float *wx, const float *xyz,
+                                 const float *new_xyz, const int32_t *idx, int B, int N, int S, int K, int C1, int relu,
+                                 const float *bound, void *out_img, int *range_flag, l3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Batched 3x3 SVD head  == utils/svd.py:29-58 (T6, without the B host syncs)
@@ -413,7 +420,8 @@ int l3d_pointwise_conv_split_maxpool(const void *x, int x_mode, const void *w_sp
  *   l3d_conv_f16_split_weights               w [Cout][Cin] fp32 (device) -> that image (device); two small launches
  *   l3d_split_f16_rows                       x [rows][C] fp32, or [B][C][Npts] with channel_first -> activation image
  *   l3d_pointwise_conv_f16                   y[b][co][n] = act(scale[co] sum_k w[co][k] x[b][n][k] + shift[(b,)co]);
- *                                            Cout % 256 == 0, N % 256 == 0, Cin % 16 == 0, else L3D_ERR_UNSUPPORTED
+ *                                            Cin % 16 == 0 and (Cout % 256 == 0, N % 256 == 0) or (Cout % 128 == 0,
+ *                                            N % 512 == 0: the narrow tile), else L3D_ERR_UNSUPPORTED
  * ------------------------------------------------------------------------------------------- */
 size_t l3d_f16_plane_bytes(long rows, int cols);
 size_t l3d_f16_act_bytes(long rows, int cols);
@@ -437,12 +445,13 @@ int l3d_pointwise_conv_f16_absmax(const void *x_planes, const void *w_planes, co
                                   int shift_bstride, int B, int Cin, int Cout, int N, int relu, float *y,
                                   void *amax_out, int amax_cdiv, l3d_stream_t stream);
 /* The layer with either or both of: its output as an activation image (out_img; obs as above, max|shift| taken over every
- * (b, co) when the shift is per cloud, shift_bstride = Cout), and ypool [B][Cout][N/128] fp32 = the maxima over runs of 128
- * points -- a global max-pool (models/pooling.py:9-12 after pcn.py:115,124 / pointnet.py:49) is then a reduce over N/128
- * values per channel and the layer's [B,Cout,N] output is never written. */
+ * (b, co) when the shift is per cloud, shift_bstride = Cout), and ypool [B][Cout][N/pool] fp32 = the maxima over runs of
+ * `pool` (8, 16, 32, 64, 128) consecutive points: pool = 128 for a global max-pool (models/pooling.py:9-12 after
+ * pcn.py:115,124 / pointnet.py:49; a reduce over N/128 values per channel finishes it), pool = K for the max over a group's
+ * K neighbours (models/flownet3d.py:179, :234).  The layer's [B,Cout,N] output is never written. */
 int l3d_pointwise_conv_f16_pool(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
                                 int shift_bstride, const float *obs, int B, int Cin, int Cout, int N, int relu,
-                                void *out_img, float *ypool, l3d_stream_t stream);
+                                void *out_img, float *ypool, int pool, l3d_stream_t stream);
 /* First layer of a per-point MLP (Cin <= 8; pcn.py:26-33 conv1 3 -> 128, pointnet.py:42) written straight as an activation
  * image: x [B][N][Cin] (channel_last) or [B][Cin][N], w [Cout][Cin], shift [Cout] or NULL, xmax = device float >= max|x|
  * (the plane scale follows from max_r(|shift_r| + xmax sum_c |w_rc|)); raises *range_flag if xmax was not a bound. */

@@ -40,6 +40,7 @@ SIGNATURES = {
     "l3d_group_concat": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_group_concat2": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_group_first_layer": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "l3d_group_first_layer_planes": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "l3d_scatter_add_det_workspace_bytes": [_I, _I, _I],
     "l3d_scatter_add_det": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "l3d_edge_gather_max": [_P, _P, _I, _I, _I, _I, _I, _P, _L, _P],
@@ -91,7 +92,7 @@ SIGNATURES = {
     "l3d_pointwise_conv_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_pointwise_conv_f16_planes": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "l3d_pointwise_conv_f16_absmax": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
-    "l3d_pointwise_conv_f16_pool": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P],
+    "l3d_pointwise_conv_f16_pool": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "l3d_first_layer_f16_planes": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "l3d_fold_mlp": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P],
     "l3d_fold_mlp_f16": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P],

@@ -220,8 +220,14 @@ __global__ __launch_bounds__(256) void cf_split_x_cl_kernel(const float *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// The GEMM.  Requires Cout % 256 == 0, N % 256 == 0, Cin % 16 == 0 (dispatcher checks).
+// The GEMM.  Requires Cin % 16 == 0 and (Cout % 256 == 0, N % 256 == 0) or (Cout % 128 == 0, N % 512 == 0) (dispatcher checks).
 // ---------------------------------------------------------------------------------------------
+// NARROW: workgroup tile 128 (co) x 512 (n) for layers with Cout % 256 != 0 (FlowNet3D's 128-channel set-conv layers,
+// models/flownet3d.py:125-242): the same eight 64 x 128 wave tiles arranged 2 x 4 instead of 4 x 2; W regions halve, x regions
+// double (stage 44 KB, 48 DMA instructions per chunk -- four of them duplicates so that every wave issues six).
+// AMAX: the fp32 epilogue also reduces max|y| (its own instantiation: the reduction costs the plain kernel its spill-free
+// register allocation -- 218 VGPRs against 256 + scratch).
+template <bool NARROW, bool AMAX>
 __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__ xh, const uint4 *__restrict__ xm,
                                                        const uint4 *__restrict__ wH, const uint4 *__restrict__ wHs,
                                                        const uint4 *__restrict__ wM, const float *__restrict__ winv,
@@ -229,18 +235,22 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
                                                        int shift_bstride, int Bn, int Cin, int Cout, int N, int relu,
                                                        float *__restrict__ y, uint2 *__restrict__ oph, uint2 *__restrict__ opm,
                                                        float *__restrict__ oinv, const float *__restrict__ obs, float *__restrict__ ypool,
-                                                       unsigned *__restrict__ amax_out, int amax_cdiv)
+                                                       int pool, unsigned *__restrict__ amax_out, int amax_cdiv)
 {
+    constexpr int TM = NARROW ? 128 : CF_TM, TN = NARROW ? 512 : CF_TN;
+    constexpr int WR = TM * 16, XR = TN * 16;                   // bytes of one (plane, octet) region of W / x
+    constexpr int WBYTES = 6 * WR, STAGE = WBYTES + 4 * XR;
+    constexpr int NPIECE = NARROW ? 6 : 5;                      // DMA instructions per wave and chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave & 3, wn = wave >> 2;
+    const int wm = NARROW ? (wave & 1) : (wave & 3), wn = NARROW ? (wave >> 1) : (wave >> 2);
     // Tile order (1-D grid).  Workgroup L runs on XCD L % 8, each with its own L2: the Cout tiles of one point tile are
     // consecutive slots of ONE XCD, so the point tile's activation planes come from HBM once instead of once per XCD
     // that happens to host one of its Cout tiles.  It does not change the kernel's time (the reads were hidden), it
     // halves its HBM read traffic.
     int pt, ct;
     {
-        const int nct = Cout / CF_TM, npt = Bn * (N / CF_TN), L = blockIdx.x;
+        const int nct = Cout / TM, npt = Bn * (N / TN), L = blockIdx.x;
         if (npt % 8 == 0) {
             const int xcd = L & 7, slot = L >> 3;
             ct = slot % nct;
@@ -250,39 +260,42 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
             pt = L / nct;
         }
     }
-    const int ntn = N / CF_TN;
-    const int n0 = (pt % ntn) * CF_TN, co0 = ct * CF_TM, b = pt / ntn;
+    const int ntn = N / TN;
+    const int n0 = (pt % ntn) * TN, co0 = ct * TM, b = pt / ntn;
     const int nk = Cin / 16;
     const size_t BN = (size_t)Bn * N;
 
-    // ---- DMA pieces: 40 per chunk (W: 6 regions x 4 quarters of 64 rows, x: 4 regions x 4), 5 per wave
-    const uint4 *src[5];
-    size_t stride[5];
-    int dst[5];
+    // ---- DMA pieces of 64 rows (1 KB): W 6 regions x TM/64, x 4 regions x TN/64 -- 40 per chunk, 5 per wave (NARROW: 44, 6
+    // per wave; wave 7's last four repeat x pieces 0..3: the same bytes to the same place, so that every wave counts alike)
+    const uint4 *src[NPIECE];
+    size_t stride[NPIECE];
+    int dst[NPIECE];
+    constexpr int WQ = TM / 64, XQ = TN / 64, NWP = 6 * WQ, NXP = 4 * XQ;
 #pragma unroll
-    for (int i = 0; i < 5; i++) {
-        const int q = wave * 5 + i;
-        if (q < 24) {
-            const int reg = q >> 2, p = reg >> 1, kg = reg & 1, quarter = q & 3;
+    for (int i = 0; i < NPIECE; i++) {
+        int q = wave * NPIECE + i;
+        if (q >= NWP + NXP) q -= NXP;
+        if (q < NWP) {
+            const int reg = q / WQ, p = reg >> 1, kg = reg & 1, quarter = q % WQ;
             const uint4 *pl = p == 0 ? wH : (p == 1 ? wHs : wM);
             src[i] = pl + (size_t)kg * Cout + co0 + quarter * 64 + lane;
             stride[i] = 2 * (size_t)Cout;
-            dst[i] = reg * 4096 + quarter * 1024;
+            dst[i] = reg * WR + quarter * 1024;
         } else {
-            const int q2 = q - 24, reg = q2 >> 2, p = reg >> 1, kg = reg & 1, quarter = q2 & 3;
+            const int q2 = q - NWP, reg = q2 / XQ, p = reg >> 1, kg = reg & 1, quarter = q2 % XQ;
             const uint4 *pl = p == 0 ? xh : xm;
             src[i] = pl + (size_t)kg * BN + (size_t)b * N + n0 + quarter * 64 + lane;
             stride[i] = 2 * BN;
-            dst[i] = CF_WBYTES + reg * 4096 + quarter * 1024;
+            dst[i] = WBYTES + reg * XR + quarter * 1024;
         }
     }
     auto issue_one = [&](int stage, int i) {
-        __builtin_amdgcn_global_load_lds((cf_gbl_ptr_t)src[i], (cf_lds_ptr_t)(lds + stage * CF_STAGE + dst[i]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((cf_gbl_ptr_t)src[i], (cf_lds_ptr_t)(lds + stage * STAGE + dst[i]), 16, 0, 0);
         src[i] += stride[i];
     };
     auto issue = [&](int stage) {
 #pragma unroll
-        for (int i = 0; i < 5; i++) issue_one(stage, i);
+        for (int i = 0; i < NPIECE; i++) issue_one(stage, i);
     };
 
     f32x16 acc[2][4];
@@ -294,8 +307,8 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
             for (int r = 0; r < 16; r++) acc[a][c][r] = 0.f;
 
     const int kgl = lane >> 5;
-    const int a_off = kgl * 4096 + (wm * 64 + (lane & 31)) * 16;                     // + a*512 + p*8192
-    const int b_off = CF_WBYTES + kgl * 4096 + (wn * 128 + (lane & 31)) * 16;        // + c*512 + p*8192
+    const int a_off = kgl * WR + (wm * 64 + (lane & 31)) * 16;                       // + a*512 + p*2*WR
+    const int b_off = WBYTES + kgl * XR + (wn * 128 + (lane & 31)) * 16;             // + c*512 + p*2*XR
 
     issue(0);
     if (nk > 1) issue(1);
@@ -309,24 +322,25 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
     for (int kc = 0; kc < nk; kc++) {
         CFT(4)
         // this wave's pieces of chunk kc have landed (chunk kc+1's five may still be in flight) ...
-        if (kc + 1 < nk) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kc + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (NARROW) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         CFT(0)
         __builtin_amdgcn_s_barrier();            // ... and so have everybody else's; stage (kc+2)%3 was last read in chunk kc-1
         CFT(1)
         const int nst = stage == 0 ? 2 : stage - 1;                                   // (kc + 2) % 3
         const bool more = kc + 2 < nk;
         CFT(2)
-        const unsigned char *base = lds + stage * CF_STAGE;
+        const unsigned char *base = lds + stage * STAGE;
         f16x8 A[2][3], Bf[4][2];
 #pragma unroll
         for (int p = 0; p < 2; p++)
 #pragma unroll
-            for (int c = 0; c < 4; c++) Bf[c][p] = *(const f16x8 *)(base + b_off + c * 512 + p * 8192);
+            for (int c = 0; c < 4; c++) Bf[c][p] = *(const f16x8 *)(base + b_off + c * 512 + p * 2 * XR);
 #pragma unroll
         for (int p = 2; p >= 0; p--)
 #pragma unroll
-            for (int a = 0; a < 2; a++) A[a][p] = *(const f16x8 *)(base + a_off + a * 512 + p * 8192);
+            for (int a = 0; a < 2; a++) A[a][p] = *(const f16x8 *)(base + a_off + a * 512 + p * 2 * WR);
         // three products, smallest first: M h, Hs m', H h
         // The five DMA instructions of chunk kc+2 are spread over the chunk's 24 MFMAs, one behind every fifth: the CU's
         // vector-memory path takes 16 cycles per 1 KB instruction and all eight waves share it -- issued as one block behind
@@ -337,9 +351,9 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
             const int prod = n >> 3, a = (n >> 2) & 1, c = n & 3;
             const int pa = prod == 0 ? 2 : (prod == 1 ? 1 : 0), pb = prod == 1 ? 1 : 0;
             acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][pa], Bf[c][pb], acc[a][c], 0, 0, 0);
-            if (n % 5 == 3) {                    // behind MFMA 3, 8, 13, 18, 23
+            if (NARROW ? (n % 4 == 3) : (n % 5 == 3)) {          // behind MFMA 3, 8, 13, 18, 23 (NARROW: 3, 7, .. 23)
                 __builtin_amdgcn_sched_barrier(0);
-                if (more) issue_one(nst, n / 5);
+                if (more) issue_one(nst, NARROW ? n / 4 : n / 5);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -366,9 +380,10 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
         // scale is fixed from a bound, |y| <= max|shift| + max|scale| (max_r sum_c |w_rc|) max|x| with max|x| <= 2^12 2^-T
         // (obs = {max|shift|, max|scale|}, the row-sum maximum sits behind 2^-S in the weight image).  A lane holds 4
         // consecutive channels of an octet, its partner (lane ^ 32) the other 4: each writes its 8-byte half of the cell.
-        // (2) ypool [B][Cout][N/128]: the maximum over the wave tile's 128 points (4 tiles in registers, then the 32 lanes of
-        // a half) -- a global max-pool (pcn.py:115,124, pointnet.py:49 + pooling.py) finishes with a reduce over N/128 values and
-        // the layer's [B,Cout,N] output is never written.  Both may be asked for (pcn.py:115-119 pools conv2's output AND feeds it on).
+        // (2) ypool [B][Cout][N/pool]: maxima over runs of `pool` consecutive points (lanes of a 32-point tile by shuffles, tiles
+        // in registers).  pool = 128: a global max-pool (pcn.py:115,124, pointnet.py:49 + pooling.py) finishes with a reduce over
+        // N/128 values; pool = K: the max over a group's K neighbours (flownet3d.py:179, :234) -- in both cases the layer's
+        // [B,Cout,N] output is never written.  Both outputs may be asked for (pcn.py:115-119 pools conv2's output AND feeds it on).
         float up = 1.f;
         if (oph) {
             float bound = fmaf(obs[1] * winv[2], 4096.0f * *xinv, obs[0]) * 1.000001f;
@@ -378,18 +393,19 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
             if (blockIdx.x == 0 && t == 0) *oinv = ldexpf(1.f, e - 12);
         }
         const size_t rows = (size_t)Bn * N;
-        const int half = lane >> 5, NP = N / 128;
+        const int half = lane >> 5, NP = N / pool;               // pool: 8, 16, 32, 64 or 128 consecutive points per maximum
+        const int span = pool < 32 ? pool : 32;                  // lanes of one 32-point tile that share a maximum
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
                 const int cob = co0 + wm * 64 + a * 32 + 8 * gq + 4 * half;          // this lane's 4 channels: cob .. cob + 3
-                float sc[4], sh[4], vmax[4];
+                float sc[4], sh[4], run[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     sc[u] = (scale ? scale[cob + u] : 1.f) * inv;
                     sh[u] = shift ? shift[(size_t)b * shift_bstride + cob + u] : 0.f;
-                    vmax[u] = -INFINITY;
+                    run[u] = -INFINITY;
                 }
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
@@ -398,7 +414,6 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
                     for (int u = 0; u < 4; u++) {
                         v[u] = acc[a][c][4 * gq + u] * sc[u] + sh[u];
                         if (relu) v[u] = l3d_act(v[u], relu);
-                        vmax[u] = fmaxf(vmax[u], v[u]);
                     }
                     if (oph) {
                         uint32_t h0, h1, m0, m1;
@@ -409,24 +424,29 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
                         oph[cellh] = make_uint2(h0, h1);
                         opm[cellh] = make_uint2(m0, m1);
                     }
-                }
-                if (ypool) {
+                    if (ypool) {
+                        // across `span` lanes of this 32-point tile by shuffles, then (pool 64 / 128) across tiles in `run`
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                        for (int u = 0; u < 4; u++) {
+                            for (int d = 1; d < span; d <<= 1) v[u] = fmaxf(v[u], __shfl_xor(v[u], d, 64));
+                            run[u] = fmaxf(run[u], v[u]);
+                        }
+                        const int tiles = pool <= 32 ? 1 : pool / 32;                 // 32-point tiles per maximum
+                        if (((c + 1) & (tiles - 1)) == 0) {
+                            if (((lane & 31) & (span - 1)) == 0) {
+                                const int n = n0 + wn * 128 + (c + 1 - tiles) * 32 + (lane & 31);
 #pragma unroll
-                        for (int d = 1; d < 32; d <<= 1) vmax[u] = fmaxf(vmax[u], __shfl_xor(vmax[u], d, 64));
-                    }
-                    if ((lane & 31) == 0) {
+                                for (int u = 0; u < 4; u++) ypool[((size_t)b * Cout + cob + u) * NP + n / pool] = run[u];
+                            }
 #pragma unroll
-                        for (int u = 0; u < 4; u++)
-                            ypool[((size_t)b * Cout + cob + u) * NP + (n0 + wn * 128) / 128] = vmax[u];
+                            for (int u = 0; u < 4; u++) run[u] = -INFINITY;
+                        }
                     }
                 }
             }
         return;
     }
     float *yb = y + (size_t)b * Cout * N;
-    float big = 0.f;
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -438,15 +458,22 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
             for (int c = 0; c < 4; c++) {
                 float v = acc[a][c][r] * sc + sh;
                 if (relu) v = l3d_act(v, relu);
-                big = fmaxf(big, fabsf(v));
                 yb[(size_t)co * N + n0 + wn * 128 + c * 32 + (lane & 31)] = v;
+                if constexpr (AMAX) acc[a][c][r] = fabsf(v);     // kept for the maximum below (the accumulator is dead)
             }
         }
-    if (amax_out) {
+    if constexpr (AMAX) {
         // max|y| per group of amax_cdiv output channels (amax_cdiv % 256 == 0: a workgroup's 256 channels lie in one group), as
         // float bits: the consumer's operand scale (attention_f16.hip takes max|q|, |k|, |v| of a fused q|k|v projection from
         // here instead of a pass over the three tensors).  One atomic per workgroup, skipped when it would not raise the value.
         float *red = (float *)lds;                 // the stages are dead: every wave is past its last fragment read ...
+        float big = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) big = fmaxf(big, acc[a][c][r]);
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) big = fmaxf(big, __shfl_xor(big, d, 64));
         __syncthreads();                           // ... after this barrier
@@ -526,21 +553,31 @@ extern "C" int l3d_split_f16_rows(const float *x, long rows, int C, int channel_
 
 // x_act: an activation image (l3d_f16_act_bytes), w_planes: a weight image (l3d_conv_f16_weight_bytes)
 static int cf_launch(const void *x_planes, const void *w_planes, const float *scale, const float *shift, int shift_bstride, int B,
-                     int Cin, int Cout, int N, int relu, float *y, void *out_img, const float *obs, float *ypool, unsigned *amax_out,
-                     int amax_cdiv, hipStream_t st)
+                     int Cin, int Cout, int N, int relu, float *y, void *out_img, const float *obs, float *ypool, int pool,
+                     unsigned *amax_out, int amax_cdiv, hipStream_t st)
 {
-    if (Cout % CF_TM || N % CF_TN || Cin % 16 || B > 65535 || (((size_t)x_planes) & 15) || (((size_t)w_planes) & 15) ||
-        (((size_t)out_img) & 15))
+    // wide tile (256 x 256) when Cout allows it, else the narrow one (128 x 512)
+    const bool narrow = Cout % CF_TM != 0;
+    const int tm = narrow ? 128 : CF_TM, tn = narrow ? 512 : CF_TN;
+    if (Cout % tm || N % tn || Cin % 16 || B > 65535 || (((size_t)x_planes) & 15) || (((size_t)w_planes) & 15) ||
+        (((size_t)out_img) & 15) || (amax_out && amax_cdiv % tm))
         return L3D_ERR_UNSUPPORTED;
+    if (ypool && pool != 8 && pool != 16 && pool != 32 && pool != 64 && pool != 128) return L3D_ERR_UNSUPPORTED;
     const size_t xpb = l3d_f16_plane_bytes((long)B * N, Cin), wpb = l3d_f16_plane_bytes(Cout, Cin);
     const size_t opb = l3d_f16_plane_bytes((long)B * N, Cout);
     const unsigned char *xp = (const unsigned char *)x_planes, *wp = (const unsigned char *)w_planes;
     unsigned char *op = (unsigned char *)out_img;
-    dim3 grid((unsigned)((size_t)(N / CF_TN) * (Cout / CF_TM) * B)), block(512);
-    hipLaunchKernelGGL(conv_f16_kernel, grid, block, CF_LDS, st, (const uint4 *)xp, (const uint4 *)(xp + xpb),
-                       (const uint4 *)wp, (const uint4 *)(wp + wpb), (const uint4 *)(wp + 2 * wpb), (const float *)(wp + 3 * wpb),
-                       (const float *)(xp + 2 * xpb), scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, (uint2 *)op,
-                       op ? (uint2 *)(op + opb) : nullptr, op ? (float *)(op + 2 * opb) : nullptr, obs, ypool, amax_out, amax_cdiv);
+    dim3 grid((unsigned)((size_t)(N / tn) * (Cout / tm) * B)), block(512);
+    if (!ypool) pool = 128;
+#define CF_ARGS (const uint4 *)xp, (const uint4 *)(xp + xpb), (const uint4 *)wp, (const uint4 *)(wp + wpb), (const uint4 *)(wp + 2 * wpb), \
+                (const float *)(wp + 3 * wpb), (const float *)(xp + 2 * xpb), scale, shift, shift_bstride, B, Cin, Cout, N, relu, y,      \
+                (uint2 *)op, op ? (uint2 *)(op + opb) : nullptr, op ? (float *)(op + 2 * opb) : nullptr, obs, ypool, pool, amax_out, amax_cdiv
+    const size_t nlds = 3 * (6 * 128 * 16 + 4 * 512 * 16);
+    if (narrow && amax_out) hipLaunchKernelGGL((conv_f16_kernel<true, true>), grid, block, nlds, st, CF_ARGS);
+    else if (narrow)        hipLaunchKernelGGL((conv_f16_kernel<true, false>), grid, block, nlds, st, CF_ARGS);
+    else if (amax_out)      hipLaunchKernelGGL((conv_f16_kernel<false, true>), grid, block, CF_LDS, st, CF_ARGS);
+    else                    hipLaunchKernelGGL((conv_f16_kernel<false, false>), grid, block, CF_LDS, st, CF_ARGS);
+#undef CF_ARGS
     return l3d_check_launch();
 }
 
@@ -549,7 +586,7 @@ extern "C" int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes
                                       l3d_stream_t stream)
 {
     L3D_REQUIRE(x_planes && w_planes && y && B > 0 && Cin > 0 && Cout > 0 && N > 0);
-    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, nullptr, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
+    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, nullptr, nullptr, nullptr, 0, nullptr, 0, (hipStream_t)stream);
 }
 
 // The same layer with its OUTPUT written as an activation image (l3d_f16_act_bytes(B N, Cout) bytes) for the next f16x2 layer
@@ -560,7 +597,7 @@ extern "C" int l3d_pointwise_conv_f16_planes(const void *x_planes, const void *w
                                              l3d_stream_t stream)
 {
     L3D_REQUIRE(x_planes && w_planes && out_img && obs && B > 0 && Cin > 0 && Cout > 0 && N > 0);
-    return cf_launch(x_planes, w_planes, scale, shift, 0, B, Cin, Cout, N, relu, nullptr, out_img, obs, nullptr, nullptr, 0, (hipStream_t)stream);
+    return cf_launch(x_planes, w_planes, scale, shift, 0, B, Cin, Cout, N, relu, nullptr, out_img, obs, nullptr, 0, nullptr, 0, (hipStream_t)stream);
 }
 
 // l3d_pointwise_conv_f16 that also reports max|y| per group of amax_cdiv output channels into amax_out[Cout / amax_cdiv] (float
@@ -571,21 +608,22 @@ extern "C" int l3d_pointwise_conv_f16_absmax(const void *x_planes, const void *w
                                              void *amax_out, int amax_cdiv, l3d_stream_t stream)
 {
     L3D_REQUIRE(x_planes && w_planes && y && amax_out && B > 0 && Cin > 0 && Cout > 0 && N > 0 && amax_cdiv > 0);
-    if (amax_cdiv % CF_TM) return L3D_ERR_UNSUPPORTED;
-    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, nullptr, nullptr, nullptr,
+    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, nullptr, nullptr, nullptr, 0,
                      (unsigned *)amax_out, amax_cdiv, (hipStream_t)stream);
 }
 
 // The layer with either or both of: its output as an activation image (out_img, needs obs = {max|shift| over every (b, co), max|scale|}),
-// and the per-128-point maxima ypool [B][Cout][N/128] fp32 (a global max-pool is then a reduce over N/128 values per channel; the
-// [B,Cout,N] output is never written).  shift may be per cloud (shift_bstride = Cout).  pcn.py:110-124: conv2 -> (pool, conv3 with
-// the pooled half of W3 as a per-cloud shift) -> conv4 -> pool.
+// and ypool [B][Cout][N/pool] fp32 = the maxima over runs of `pool` (8, 16, 32, 64 or 128) consecutive points: with pool = 128 a global
+// max-pool is a reduce over N/128 values per channel (pcn.py:110-124: conv2 -> (pool, conv3 with the pooled half of W3 as a per-cloud
+// shift) -> conv4 -> pool); with pool = K it is the max over a group's K neighbours (flownet3d.py:179, :234).  The [B,Cout,N] output
+// is never written.  shift may be per cloud (shift_bstride = Cout).
 extern "C" int l3d_pointwise_conv_f16_pool(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
                                            int shift_bstride, const float *obs, int B, int Cin, int Cout, int N, int relu,
-                                           void *out_img, float *ypool, l3d_stream_t stream)
+                                           void *out_img, float *ypool, int pool, l3d_stream_t stream)
 {
     L3D_REQUIRE(x_planes && w_planes && (out_img || ypool) && (!out_img || obs) && B > 0 && Cin > 0 && Cout > 0 && N > 0);
-    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, nullptr, out_img, obs, ypool, nullptr, 0, (hipStream_t)stream);
+    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, nullptr, out_img, obs, ypool, pool, nullptr, 0,
+                     (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -662,5 +700,115 @@ extern "C" int l3d_first_layer_f16_planes(const float *x, int channel_last, cons
     dim3 grid((unsigned)l3d_divup(R, 256), (unsigned)((Cout + 7) / 8));
     hipLaunchKernelGGL(cf_first_layer_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, channel_last, w, shift, xmax, Cin, Cout, N, R,
                        relu, (uint4 *)d, (uint4 *)(d + pb), (float *)(d + 2 * pb), range_flag);
+    return l3d_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// The factored first layer of a grouped MLP (grouping.hip, l3d_group_first_layer: act(U[idx] + V + Wx (xyz[idx] - centre)))
+// written straight as the activation image of the next f16x2 layer -- models/flownet3d.py:125-242's 128-channel stacks then run
+// conv2 / conv3 on the fp16 matrix cores (narrow tile) with no fp32 activation in between.  A workgroup takes 64 rows (s, k) of
+// one cloud and all C1/8 octets: pass 1 reads with consecutive threads on consecutive octets of one gathered row (C1 * 4
+// contiguous bytes), computes, splits and parks the 16-byte cells in LDS; pass 2 writes them with consecutive threads on
+// consecutive rows of one octet (the planes' own order, 1 KB per wave) -- cf_split_x_cl_kernel's pattern.
+// The plane scale comes from *bound >= max|output| (the host adds max|U| + max|V| + max_r sum_d |wx_rd| * max|coordinate difference|).
+// ---------------------------------------------------------------------------------------------
+#define GFP_ROWS 64
+#define GFP_STRIDE (GFP_ROWS + 1)
+template <int NO /* octets = C1 / 8: 8, 16 or 32 */>
+__global__ __launch_bounds__(256) void group_first_layer_planes_kernel(const float *__restrict__ U, const float *__restrict__ V,
+                                                                       const float *__restrict__ shift, const float *__restrict__ wx,
+                                                                       const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                                       const int32_t *__restrict__ idx, int N, int S, int K, int act,
+                                                                       const float *__restrict__ bound, uint4 *__restrict__ ph,
+                                                                       uint4 *__restrict__ pm, float *__restrict__ oinv,
+                                                                       int *__restrict__ range_flag)
+{
+    __shared__ uint4 lh[NO * GFP_STRIDE], lm[NO * GFP_STRIDE];
+    constexpr int C1 = NO * 8, RPP = 256 / NO;                   // rows per pass
+    const int t = threadIdx.x, b = blockIdx.y;
+    const long SK = (long)S * K, e0 = (long)blockIdx.x * GFP_ROWS, rows = (long)gridDim.y * SK;
+    int ex = 0;
+    {
+        const float bd = *bound * 1.000001f;
+        if (bd > 0.f && bd < 3.0e38f) (void)frexpf(bd, &ex);
+    }
+    const float up = ldexpf(1.f, 12 - ex);
+    if (blockIdx.x == 0 && b == 0 && t == 0) *oinv = ldexpf(1.f, ex - 12);
+    const int oc = t % NO, r0 = t / NO;
+    float w0[8], w1[8], w2[8], sh[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const float *w = wx + (size_t)(8 * oc + u) * 3;
+        w0[u] = w[0]; w1[u] = w[1]; w2[u] = w[2];
+        sh[u] = shift ? shift[8 * oc + u] : 0.f;
+    }
+    float big = 0.f;
+#pragma unroll 2
+    for (int pass = 0; pass < GFP_ROWS / RPP; pass++) {
+        const int r = pass * RPP + r0;
+        const long e = e0 + r;
+        uint4 hc = make_uint4(0, 0, 0, 0), mc = hc;
+        if (e < SK) {
+            const int s_ = (int)(e / K), j = idx[(size_t)b * SK + e];
+            const float *p = xyz + ((size_t)b * N + j) * 3, *q = new_xyz + ((size_t)b * S + s_) * 3;
+            const float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+            const f32x4 *up4 = (const f32x4 *)(U + ((size_t)b * N + j) * C1 + 8 * oc);
+            f32x4 ua = up4[0], ub = up4[1];
+            if (V) {
+                const f32x4 *vp4 = (const f32x4 *)(V + ((size_t)b * S + s_) * C1 + 8 * oc);
+                ua += vp4[0]; ub += vp4[1];
+            }
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                float x = (u < 4 ? ua[u] : ub[u - 4]) + sh[u];
+                x = fmaf(w2[u], dz, fmaf(w1[u], dy, fmaf(w0[u], dx, x)));
+                if (act) x = l3d_act(x, act);
+                v[u] = x;
+                big = fmaxf(big, fabsf(x * up));
+            }
+            af_split_x(v[0], v[1], up, hc.x, mc.x);
+            af_split_x(v[2], v[3], up, hc.y, mc.y);
+            af_split_x(v[4], v[5], up, hc.z, mc.z);
+            af_split_x(v[6], v[7], up, hc.w, mc.w);
+        }
+        lh[oc * GFP_STRIDE + r] = hc;
+        lm[oc * GFP_STRIDE + r] = mc;
+    }
+    __syncthreads();
+    {
+        const int r = t & 63;
+        const long e = e0 + r;
+        if (e < SK) {
+            const size_t row = (size_t)b * SK + e;
+#pragma unroll
+            for (int pass = 0; pass < NO / 4; pass++) {
+                const int o = pass * 4 + (t >> 6);
+                ph[(size_t)o * rows + row] = lh[o * GFP_STRIDE + r];
+                pm[(size_t)o * rows + row] = lm[o * GFP_STRIDE + r];
+            }
+        }
+    }
+    if (!(big <= 60000.f) && range_flag) *(volatile int *)range_flag = 1;        // *bound was not a bound (or inf / NaN)
+}
+
+// as l3d_group_first_layer (grouping.hip), output = activation image (l3d_f16_act_bytes(B S K, C1) bytes) instead of fp32 rows;
+// bound: device float >= max|output|.  C1 = 64, 128 or 256.
+extern "C" int l3d_group_first_layer_planes(const float *U, const float *V, const float *shift, const float *wx, const float *xyz,
+                                            const float *new_xyz, const int32_t *idx, int B, int N, int S, int K, int C1, int relu,
+                                            const float *bound, void *out_img, int *range_flag, l3d_stream_t stream)
+{
+    L3D_REQUIRE(U && wx && xyz && new_xyz && idx && bound && out_img && B > 0 && N > 0 && S > 0 && K > 0 && C1 > 0);
+    if (B > 65535 || (C1 != 64 && C1 != 128 && C1 != 256) || (((size_t)U | (size_t)V | (size_t)out_img) & 15)) return L3D_ERR_UNSUPPORTED;
+    const long R = (long)B * S * K;
+    const size_t pb = l3d_f16_plane_bytes(R, C1);
+    unsigned char *d = (unsigned char *)out_img;
+    dim3 grid((unsigned)l3d_divup((long)S * K, GFP_ROWS), B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define GFP_ARGS U, V, shift, wx, xyz, new_xyz, idx, N, S, K, relu, bound, (uint4 *)d, (uint4 *)(d + pb), (float *)(d + 2 * pb), range_flag
+    if (C1 == 64)       hipLaunchKernelGGL(group_first_layer_planes_kernel<8>, grid, block, 0, st, GFP_ARGS);
+    else if (C1 == 128) hipLaunchKernelGGL(group_first_layer_planes_kernel<16>, grid, block, 0, st, GFP_ARGS);
+    else                hipLaunchKernelGGL(group_first_layer_planes_kernel<32>, grid, block, 0, st, GFP_ARGS);
+#undef GFP_ARGS
     return l3d_check_launch();
 }

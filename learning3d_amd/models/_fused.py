@@ -151,7 +151,8 @@ def split_rows_f16(x, channel_first=False):
 
 
 def f16_eligible(Cin, Cout, N):
-    return Cout % 256 == 0 and N % 256 == 0 and Cin % 16 == 0 and Cin >= 32
+    """conv_f16_kernel's tiles: 256 x 256 (Cout % 256 == 0), else 128 x 512 (Cout % 128 == 0)"""
+    return Cin % 16 == 0 and Cin >= 32 and ((Cout % 256 == 0 and N % 256 == 0) or (Cout % 128 == 0 and N % 512 == 0))
 
 
 def pointwise_conv_f16(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=None, relu=False, out_planes=False, amax=None):
@@ -201,10 +202,12 @@ def first_layer_f16_planes(x, w, shift, relu, channel_last):
     return img
 
 
-def pointwise_conv_f16_pool(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=None, relu=False, out_planes=False, pool=True):
+def pointwise_conv_f16_pool(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=None, relu=False, out_planes=False, pool=True,
+                            group=None):
     """l3d_pointwise_conv_f16_pool: the layer's output as an activation image (out_planes) and / or its maximum over all N points
-    [B,Cout] (pool; per-128-point maxima from the kernel's epilogue, then a reduce over N/128).  shift [Cout] or per cloud [B,Cout].
-    Returns (img or None, pooled or None)."""
+    [B,Cout] (pool; per-128-point maxima from the kernel's epilogue, then a reduce over N/128) -- or, with group=K (8, 16, 32, 64),
+    the maximum over every K consecutive points [B,Cout,N/K] (a grouped layer's max over its K neighbours).
+    shift [Cout] or per cloud [B,Cout].  Returns (img or None, pooled or None)."""
     scale = f32c(scale) if scale is not None else None
     shift = f32c(shift) if shift is not None else None
     dev = x_planes.device
@@ -214,10 +217,13 @@ def pointwise_conv_f16_pool(x_planes, B, N, w_planes, Cin, Cout, scale=None, shi
         obs = torch.stack([shift.abs().max() if shift is not None else torch.zeros((), device=dev),
                            scale.abs().max() if scale is not None else torch.ones((), device=dev)]).float()
         img = torch.empty(lib().l3d_f16_act_bytes(B * N, Cout), dtype=torch.uint8, device=dev)
-    if pool:
-        part = torch.empty((B, Cout, N // 128), dtype=torch.float32, device=dev)
+    pk = int(group) if group else 128
+    if pool or group:
+        part = torch.empty((B, Cout, N // pk), dtype=torch.float32, device=dev)
     check(lib().l3d_pointwise_conv_f16_pool(ptr(x_planes), ptr(w_planes), ptr(scale), ptr(shift), bstride, ptr(obs), B, Cin, Cout, N,
-                                            int(relu), ptr(img), ptr(part), stream_ptr()), "l3d_pointwise_conv_f16_pool")
+                                            int(relu), ptr(img), ptr(part), pk, stream_ptr()), "l3d_pointwise_conv_f16_pool")
+    if group:
+        return img, part
     return img, (part.max(dim=2)[0] if pool else None)
 
 

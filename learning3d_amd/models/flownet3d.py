@@ -14,6 +14,11 @@ from . import _fused
 
 
 FACTOR_FIRST_LAYER = True    # grouped first layers as per-point products + a gather (l3d_group_first_layer); False: grouped tensor + conv
+# ... and the layers behind them as an f16x2 chain on fp16 plane images (conv_f16.hip's 128 x 512 tile, max over K in the last
+# layer's epilogue).  Correct and tested, but OFF: at config 5's shapes these 128-channel layers have 8 K-chunks per tile and
+# move 0.5 GB each -- 118 us on the narrow f16x2 tile against 165 us on the fp32 MFMA, which the extra bound / scale
+# reductions (21 tiny launches per forward) more than eat: 5.12 -> 5.28 ms (tools/flownet_bench.py, LABLOG R2.4f).
+F16_GROUPED_STACK = False
 
 
 def _mlp_stack(x, convs, bns, module, pool=False, cl_shape=None):
@@ -56,12 +61,13 @@ def _mlp_stack(x, convs, bns, module, pool=False, cl_shape=None):
     return torch.max(x, -1)[0] if pool else x
 
 
-def _factored_first_layer(src_xyz_t, centre_xyz_t, src_feat, centre_feat, idx, order, conv, bn, module):
+def _factored_first_layer(src_xyz_t, centre_xyz_t, src_feat, centre_feat, idx, order, conv, bn, module, planes=False):
     """conv1 + BN + ReLU of a grouped MLP (reference models/flownet3d.py:163-172, :226-232) without forming its input: the
     conv is linear in [xyz[idx] - centre | feat[idx] | centre_feat] (order 0; order 1: [feat[idx] | xyz[idx] - centre]), so
     U = (s W_feat) feat over the SOURCE points and V = (s W_centre) centre_feat + t over the centres are 1x1 convs on
     ungrouped tensors (K times fewer rows) and the layer is a gather: act(U[idx] + V + (s W_xyz)(xyz[idx] - centre)).
-    -> [B, S*K, C1] channel-last, or None when the route does not apply (the caller then groups and convolves)."""
+    -> [B, S*K, C1] channel-last (planes=True: the same as the fp16 activation image of conv_f16.hip, a uint8 tensor), or None
+    when the route does not apply (the caller then groups and convolves)."""
     if (not FACTOR_FIRST_LAYER or not _fused.can_fuse(module, src_xyz_t, centre_xyz_t, src_feat) or not src_feat.is_cuda
             or idx.dtype != torch.int32 or (centre_feat is not None and not _fused.can_fuse(module, centre_feat))):
         return None
@@ -89,11 +95,50 @@ def _factored_first_layer(src_xyz_t, centre_xyz_t, src_feat, centre_feat, idx, o
     V = None
     if Cc:
         V = _fused.pointwise_conv(centre_feat.float().contiguous(), wc, sc, sh).transpose(1, 2).contiguous()     # [B,S,C1]
+    shp = sh if (V is None and sh is not None) else None
+    sx, cx = src_xyz_t.contiguous(), centre_xyz_t.contiguous()
+    if planes:
+        # |output| <= max|U| + max|V| (or max|shift|) + max_r sum_d |wx_rd| * (max|src coordinate| + max|centre coordinate|)
+        bound = U.abs().max() + (V.abs().max() if V is not None else (shp.abs().max() if shp is not None else 0.0)) \
+            + wx.abs().sum(dim=1).max() * (sx.abs().max() + cx.abs().max())
+        bound = bound.reshape(1).float()
+        img = torch.empty(lib().l3d_f16_act_bytes(B * S * K, C1), dtype=torch.uint8, device=U.device)
+        check(lib().l3d_group_first_layer_planes(ptr(U), ptr(V), ptr(shp), ptr(wx), ptr(sx), ptr(cx), ptr(idx.contiguous()),
+                                                 B, N, S, K, C1, 1, ptr(bound), ptr(img), ptr(_fused.range_flag(U.device)),
+                                                 stream_ptr()), "l3d_group_first_layer_planes")
+        return img
     out = torch.empty((B, S * K, C1), dtype=torch.float32, device=U.device)
-    check(lib().l3d_group_first_layer(ptr(U), ptr(V), ptr(sh) if (V is None and sh is not None) else None, ptr(wx),
-                                      ptr(src_xyz_t.contiguous()), ptr(centre_xyz_t.contiguous()), ptr(idx.contiguous()),
+    check(lib().l3d_group_first_layer(ptr(U), ptr(V), ptr(shp), ptr(wx), ptr(sx), ptr(cx), ptr(idx.contiguous()),
                                       B, N, S, K, C1, 1, ptr(out), stream_ptr()), "l3d_group_first_layer")
     return out
+
+
+def _f16_stack_ok(C1, convs, S, K, pool):
+    """The layers behind a factored first layer can run as an f16x2 chain (conv_f16.hip: plane image in, plane image or
+    grouped maxima out): every layer on one of its two tiles, max over K in the last layer's epilogue."""
+    if not (F16_GROUPED_STACK and _fused.gemm_arith() == "f16x2" and len(convs) and pool and C1 in (64, 128, 256)
+            and K in (8, 16, 32, 64)):
+        return False
+    cin = C1
+    for conv in convs:
+        if not _fused.f16_eligible(cin, conv.out_channels, S * K):
+            return False
+        cin = conv.out_channels
+    return True
+
+
+def _f16_stack(img, B, S, K, convs, bns):
+    """[conv1x1 + BN + ReLU]* on a plane image, max over K from the last layer's epilogue -> [B,C',S]"""
+    N, last = S * K, len(convs) - 1
+    for i, (conv, bn) in enumerate(zip(convs, bns)):
+        w, sc, sh = _fused.fold_conv_bn(conv, bn)
+        hit = conv.__dict__.get("_l3d_w_f16")
+        if hit is None or hit[0] != (w.data_ptr(), w._version):
+            hit = ((w.data_ptr(), w._version), _fused.split_weights_f16(w))
+            conv.__dict__["_l3d_w_f16"] = hit
+        if i == last:
+            return _fused.pointwise_conv_f16_pool(img, B, N, hit[1], w.shape[1], w.shape[0], sc, sh, relu=True, group=K)[1]
+        img = _fused.pointwise_conv_f16(img, B, N, hit[1], w.shape[1], w.shape[0], sc, sh, relu=True, out_planes=True)
 
 
 def _grouped_input(src_xyz_t, centre_xyz_t, src_feat, centre_feat, idx, order, module):
@@ -168,9 +213,13 @@ class FlowEmbedding(nn.Module):
             _, idx_knn = pointutils.knn(self.nsample, pos1_t, pos2_t)
             cnt = cnt.view(B, -1, 1).repeat(1, 1, self.nsample)
             idx = idx_knn[cnt > (self.nsample - 1)]
-        first = _factored_first_layer(pos2_t, pos1_t, feature2, feature1, idx, 0, self.mlp_convs[0], self.mlp_bns[0], self)
+        S_, K_ = idx.shape[1], idx.shape[2]
+        f16 = _f16_stack_ok(self.mlp_convs[0].out_channels, self.mlp_convs[1:], S_, K_, True)
+        first = _factored_first_layer(pos2_t, pos1_t, feature2, feature1, idx, 0, self.mlp_convs[0], self.mlp_bns[0], self, planes=f16)
         if first is not None:
-            return pos1, _mlp_stack(first, self.mlp_convs[1:], self.mlp_bns[1:], self, pool=True, cl_shape=tuple(idx.shape[1:]))
+            if f16:
+                return pos1, _f16_stack(first, B, S_, K_, self.mlp_convs[1:], self.mlp_bns[1:])
+            return pos1, _mlp_stack(first, self.mlp_convs[1:], self.mlp_bns[1:], self, pool=True, cl_shape=(S_, K_))
         fused = _grouped_input(pos2_t, pos1_t, feature2, feature1, idx, 0, self)
         if fused is not None:
             return pos1, _mlp_stack(fused, self.mlp_convs, self.mlp_bns, self, pool=True)
@@ -209,16 +258,20 @@ class PointNetSetUpConv(nn.Module):
             _, idx = pointutils.knn(self.nsample, pos1_t, pos2_t)
         else:
             idx = query_ball_point(self.radius, self.nsample, pos2_t, pos1_t)
-        first = None
+        first, f16 = None, False
         if len(self.mlp1_convs):
-            first = _factored_first_layer(pos2_t, pos1_t, feature2, None, idx, 1, self.mlp1_convs[0][0], self.mlp1_convs[0][1], self)
+            f16 = _f16_stack_ok(self.mlp1_convs[0][0].out_channels, [s[0] for s in self.mlp1_convs[1:]], idx.shape[1], idx.shape[2], True)
+            first = _factored_first_layer(pos2_t, pos1_t, feature2, None, idx, 1, self.mlp1_convs[0][0], self.mlp1_convs[0][1], self,
+                                          planes=f16)
         feat_new = _grouped_input(pos2_t, pos1_t, feature2, None, idx, 1, self) if first is None else None
         if first is None and feat_new is None:
             pos2_grouped = pointutils.grouping_operation(pos2.contiguous(), idx)
             pos_diff = pos2_grouped - pos1.view(B, -1, N, 1)
             feat2_grouped = pointutils.grouping_operation(feature2.contiguous(), idx)
             feat_new = torch.cat([feat2_grouped, pos_diff], dim=1)
-        if first is not None:
+        if first is not None and f16:
+            feat_new = _f16_stack(first, B, idx.shape[1], idx.shape[2], [s[0] for s in self.mlp1_convs[1:]], [s[1] for s in self.mlp1_convs[1:]])
+        elif first is not None:
             feat_new = _mlp_stack(first, [s[0] for s in self.mlp1_convs[1:]], [s[1] for s in self.mlp1_convs[1:]], self, pool=True,
                                   cl_shape=tuple(idx.shape[1:]))
         else:

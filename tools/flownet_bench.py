@@ -13,10 +13,12 @@ pc2 = (pc1 + 0.05 * torch.randn((B, 3, N), generator=g).cuda()).contiguous()
 f1 = torch.rand((B, 3, N), generator=g).cuda(); f2 = torch.rand((B, 3, N), generator=g).cuda()
 with torch.no_grad():
     outs = {}
-    for flag in (False, True, False, True):
-        F3.FACTOR_FIRST_LAYER = flag
+    for flag in ((False, False), (True, False), (True, True), (False, False), (True, False), (True, True)):
+        F3.FACTOR_FIRST_LAYER, F3.F16_GROUPED_STACK = flag
         t = timeit(lambda: net(pc1, pc2, f1, f2), warm=2, iters=5)
         outs[flag] = net(pc1, pc2, f1, f2)
-        print(f"FlowNet3D forward B=32 N=8192, factored first layers {flag!s:5}: {t:8.1f} us")
-    d = (outs[True] - outs[False]).abs().max().item()
-    print(f"max |difference| between the routes: {d:.3e} (max |flow| {outs[False].abs().max().item():.3e})")
+        print(f"FlowNet3D forward B=32 N=8192, factored first layers {flag[0]!s:5} f16x2 stacks {flag[1]!s:5}: {t:8.1f} us")
+    for flag in ((True, False), (True, True)):
+        d = (outs[flag] - outs[(False, False)]).abs().max().item()
+        print(f"max |difference| of {flag} to the grouped-tensor route: {d:.3e} (max |flow| {outs[(False, False)].abs().max().item():.3e})")
+F3.FACTOR_FIRST_LAYER, F3.F16_GROUPED_STACK = True, False
