@@ -49,11 +49,19 @@ def _mlp_stack(x, convs, bns, module, pool=False, cl_shape=None):
                     conv.__dict__["_l3d_wpad"] = hit
                 w = hit[1]
             cl = cl_shape is not None and i == 0
+            n_pts = h.shape[1] if cl else h.shape[2]
+            ws = None
+            if _fused.split_eligible(w.shape[1], w.shape[0], n_pts):     # bf16x3 kernel: its weight planes are cached per layer
+                hit = conv.__dict__.get("_l3d_wsplit")
+                if hit is None or hit[0] != (w.data_ptr(), w._version):
+                    hit = ((w.data_ptr(), w._version), _fused.split_rows(w))
+                    conv.__dict__["_l3d_wsplit"] = hit
+                ws = hit[1]
             if pool and i == last and len(shp) == 4:
-                y = _fused.pointwise_conv_maxpool(h, w, sc, sh, True, shp[3], channel_last=cl)
+                y = _fused.pointwise_conv_maxpool(h, w, sc, sh, True, shp[3], w_split=ws, channel_last=cl)
                 if y is not None:
                     return y
-            h = _fused.pointwise_conv(h, w, sc, sh, relu=True, channel_last=cl)
+            h = _fused.pointwise_conv(h, w, sc, sh, relu=True, channel_last=cl, w_split=ws)
         h = h.view(shp[0], h.shape[1], *shp[2:])
         return torch.max(h, -1)[0] if pool else h
     for conv, bn in zip(convs, bns):
