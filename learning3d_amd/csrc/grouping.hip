@@ -716,6 +716,35 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, in
     }
 }
 
+// The same with the channel rows staged in LDS: a workgroup owns CG channels of one cloud (CG * m floats, <= 64 KB) and walks
+// ALL n points, so the 3 random 4-byte reads per output are LDS reads instead of three trips through the texture path
+// (FlowNet3D's feature propagation, models/flownet3d.py:268: 256 channels x 8192 points from 1024 -- 208 -> 75 us).  idx and
+// weights of a point stay in registers across the CG channels; stores are coalesced over points.  Same operation order.
+__global__ __launch_bounds__(256) void three_interpolate_lds_kernel(int c, int m, int n, int CG,
+                                                                    const float *__restrict__ points,
+                                                                    const int32_t *__restrict__ idx,
+                                                                    const float *__restrict__ weight,
+                                                                    float *__restrict__ out, long out_bstride)
+{
+    extern __shared__ float tirow[];                             // [CG][m]
+    const int b = blockIdx.y, c0 = blockIdx.x * CG;
+    const int cg = min(CG, c - c0);
+    const float *pb = points + ((size_t)b * c + c0) * m;
+    for (int e = threadIdx.x; e < cg * m; e += 256) tirow[e] = pb[e];
+    __syncthreads();
+    float *ob = out + (size_t)b * out_bstride + (size_t)c0 * n;
+    for (int pt = threadIdx.x; pt < n; pt += 256) {
+        const int32_t *ix = idx + ((size_t)b * n + pt) * 3;
+        const float *w = weight + ((size_t)b * n + pt) * 3;
+        const int i0 = ix[0], i1 = ix[1], i2 = ix[2];
+        const float w0 = w[0], w1 = w[1], w2 = w[2];
+        for (int cc = 0; cc < cg; cc++) {
+            const float *p = tirow + cc * m;
+            ob[(size_t)cc * n + pt] = (w0 * p[i0] + w1 * p[i1]) + w2 * p[i2];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void three_interpolate_grad_kernel(
     int c, int n, int m, const float *__restrict__ grad_out, const int32_t *__restrict__ idx,
     const float *__restrict__ weight, float *__restrict__ grad_points)
@@ -737,13 +766,27 @@ __global__ __launch_bounds__(256) void three_interpolate_grad_kernel(
     }
 }
 
+// LDS-staged kernel when a useful number of channel rows fits (CG >= 4 rows of m floats in 64 KB) and there are enough points to
+// amortise the staging; else one thread per point with global gathers
+static void ti_launch(int b, int c, int m, int n, const float *points, const int32_t *idx, const float *weight, float *out,
+                      long out_bstride, hipStream_t st)
+{
+    int cg = 16384 / m;
+    if (cg > 16) cg = 16;
+    if (cg >= 4 && n >= 4 * m && b <= 65535)
+        hipLaunchKernelGGL(three_interpolate_lds_kernel, dim3(l3d_divup(c, cg), b), dim3(256), (size_t)cg * m * 4, st, c, m, n, cg,
+                           points, idx, weight, out, out_bstride);
+    else
+        hipLaunchKernelGGL(three_interpolate_kernel, dim3(l3d_divup(n, 256), l3d_divup(c, GP_CCHUNK), b), dim3(256), 0, st, c, m, n,
+                           points, idx, weight, out, out_bstride);
+}
+
 extern "C" int l3d_three_interpolate(int b, int c, int m, int n, const float *points,
                                      const int32_t *idx, const float *weight, float *out,
                                      l3d_stream_t stream)
 {
     L3D_REQUIRE(points && idx && weight && out && b > 0 && c > 0 && m > 0 && n > 0);
-    hipLaunchKernelGGL(three_interpolate_kernel, dim3(l3d_divup(n, 256), l3d_divup(c, GP_CCHUNK), b),
-                       dim3(256), 0, (hipStream_t)stream, c, m, n, points, idx, weight, out, (long)c * n);
+    ti_launch(b, c, m, n, points, idx, weight, out, (long)c * n, (hipStream_t)stream);
     return l3d_check_launch();
 }
 
@@ -757,8 +800,7 @@ extern "C" int l3d_three_interpolate_concat(int b, int c, int m, int n, const fl
     L3D_REQUIRE(points && idx && weight && out && b > 0 && c > 0 && m > 0 && n > 0 && c1 >= 0 && (c1 == 0 || skip));
     hipStream_t st = (hipStream_t)stream;
     const long bs = (long)(c + c1) * n;
-    hipLaunchKernelGGL(three_interpolate_kernel, dim3(l3d_divup(n, 256), l3d_divup(c, GP_CCHUNK), b), dim3(256), 0, st, c,
-                       m, n, points, idx, weight, out, bs);
+    ti_launch(b, c, m, n, points, idx, weight, out, bs, st);
     if (c1 > 0) {
         hipError_t e = hipMemcpy2DAsync(out + (size_t)c * n, (size_t)bs * 4, skip, (size_t)c1 * n * 4, (size_t)c1 * n * 4, b,
                                         hipMemcpyDeviceToDevice, st);

@@ -1933,3 +1933,26 @@ def test_group_first_layer_planes_equals_fp32_rows():
         if back is not None:                                    # (64 output channels are not a conv_f16 tile: compare 128 / 256)
             assert (back.transpose(1, 2) - rows).abs().max().item() <= 2e-6 * float(bound)
     _fused.check_range(sync=True)
+
+
+def test_three_interpolate_lds_staged_kernel():
+    """three_interpolate at shapes that take the LDS-staged kernel (n >= 4 m, channel rows in LDS; FlowNet3D's feature
+    propagation, models/flownet3d.py:268): against the definition (w0 p[i0] + w1 p[i1]) + w2 p[i2] evaluated in fp32 with the same
+    operation order, ragged channel count, and through the concat entry point with skip channels."""
+    from learning3d_amd._lib import check, lib, ptr, stream_ptr
+    from learning3d_amd.utils import pointnet2_utils as P
+    rng = np.random.default_rng(71)
+    for B, c, m, n, c1 in ((2, 40, 256, 2048, 0), (2, 24, 1024, 4096, 5), (1, 7, 3000, 12288, 3)):
+        pts = dev(rng.standard_normal((B, c, m)).astype(np.float32))
+        idx = dev(rng.integers(0, m, (B, n, 3)).astype(np.int32))
+        w = rng.uniform(0.05, 1, (B, n, 3)).astype(np.float32)
+        w = dev(w / w.sum(-1, keepdims=True))
+        g = [torch.gather(pts, 2, idx[:, :, j].long().unsqueeze(1).expand(-1, c, -1)) for j in range(3)]
+        want = (w[:, :, 0].unsqueeze(1) * g[0] + w[:, :, 1].unsqueeze(1) * g[1]) + w[:, :, 2].unsqueeze(1) * g[2]
+        got = P.three_interpolate(pts, idx, w)
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-6, atol=1e-7)
+        if c1:
+            skip = dev(rng.standard_normal((B, c1, n)).astype(np.float32))
+            out = torch.empty((B, c + c1, n), dtype=torch.float32, device="cuda")
+            check(lib().l3d_three_interpolate_concat(B, c, m, n, ptr(pts), ptr(idx), ptr(w), ptr(skip), c1, ptr(out), stream_ptr()), "concat")
+            assert torch.equal(out[:, :c], got) and torch.equal(out[:, c:], skip)
