@@ -1,5 +1,6 @@
 """reference: models/classifier.py:6-29 -- 3 FC layers on a [B, emb] vector (config 1 plumbing; tiny,
-stays torch/rocBLAS)."""
+stays torch/rocBLAS).  The max-pool in front of them (:23) is taken inside the feature model's last conv kernel when the model
+offers forward_pooled (PointNet, DGCNN at inference)."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -22,7 +23,12 @@ class Classifier(nn.Module):
         self.pooling = Pooling('max')
 
     def forward(self, input_data):
-        output = self.pooling(self.feature_model(input_data))
+        output = None
+        pooled = getattr(self.feature_model, "forward_pooled", None)
+        if pooled is not None and self.pooling.pool_type == 'max':
+            output = pooled(input_data)              # max-pool in the last conv's epilogue: no [B,emb,N] feature map
+        if output is None:
+            output = self.pooling(self.feature_model(input_data))
         output = F.relu(self.bn1(self.linear1(output)))
         output = self.dropout1(output)
         output = F.relu(self.bn2(self.linear2(output)))

@@ -43,7 +43,13 @@ class DGCNN(torch.nn.Module):
             self._c5key = key
         return self._c5
 
-    def forward(self, input_data):
+    def forward_pooled(self, input_data):
+        """max over the points of forward()'s [B,emb,N] output -> [B,emb] (what models/classifier.py:23 computes next), with the
+        maximum taken in conv5's epilogue on the f16x2 route: the feature map is never written.  None if that route does not
+        apply (the caller then pools forward()'s output)."""
+        return self.forward(input_data, _pooled=True)
+
+    def forward(self, input_data, _pooled=False):
         if self.input_shape == "bnc":
             input_data = input_data.permute(0, 2, 1)
         if input_data.shape[1] != 3:
@@ -51,19 +57,25 @@ class DGCNN(torch.nn.Module):
         batch_size, num_dims, num_points = input_data.size()
 
         if _fused.can_fuse(self, input_data):
+            w5, s5, b5, w5_split, w5_f16 = self._conv5_folded()
+            f16_route = (_fused.gemm_arith() == "f16x2" and _fused.EDGECONV_KERNEL in (None, "f16") and w5_f16 is not None
+                         and _fused.f16_eligible(512, self.emb_dims, num_points))
+            if _pooled and not f16_route:
+                return None
             xyz = _as_bn3(input_data)                                   # [B,N,3] (no copy for "bnc")
             with _fused.stage("knn"):
                 idx = knn(input_data, k=20)                             # dgcnn.py:32 (k=20 default)
             packed = self._packed.get([self.conv1, self.conv2, self.conv3, self.conv4],
                                       [self.bn1, self.bn2, self.bn3, self.bn4], xyz.device)
-            w5, s5, b5, w5_split, w5_f16 = self._conv5_folded()
-            if (_fused.gemm_arith() == "f16x2" and _fused.EDGECONV_KERNEL in (None, "f16") and w5_f16 is not None
-                    and _fused.f16_eligible(512, self.emb_dims, num_points)):
+            if f16_route:
                 # f16x2 route: the EdgeConv kernel hands conv5 its input already split into fp16 planes (no fp32 pooled
                 # tensor, no split pass); both kernels watch the fp16 range (see _fused.check_range)
                 with _fused.stage("edgeconv"):
                     pooled_img = _fused.edgeconv_forward(xyz, idx, packed, planes=True)         # dgcnn.py:34-46
                 with _fused.stage("conv5"):
+                    if _pooled:
+                        return _fused.pointwise_conv_f16_pool(pooled_img, batch_size, num_points, w5_f16, 512, self.emb_dims,
+                                                              s5, b5, relu=True)[1]
                     return _fused.pointwise_conv_f16(pooled_img, batch_size, num_points, w5_f16, 512, self.emb_dims,
                                                      s5, b5, relu=True)                         # dgcnn.py:48
             with _fused.stage("edgeconv"):
@@ -73,6 +85,8 @@ class DGCNN(torch.nn.Module):
                                             w_split=w5_split)                                   # dgcnn.py:48
             return out
 
+        if _pooled:
+            return None
         output = get_graph_feature(input_data)
         if (_fused.TRAIN_HIP and self.training and output.is_cuda and self.conv1.bias is None):
             # training: conv / dgrad / wgrad on the HIP GEMMs, BatchNorm statistics from per-cloud fp64 partial sums

@@ -49,6 +49,23 @@ class PointNet(torch.nn.Module):
         bns = [self.bn1, self.bn2, self.bn3, self.bn4, self.bn5] if self.use_bn else [None] * 5
         return list(zip(convs, bns))
 
+    def forward_pooled(self, input_data):
+        """max over the points of forward()'s [B,emb,N] output -> [B,emb] (what models/classifier.py:23 computes next): conv5's
+        kernel takes partial maxima in its epilogue, the feature map is never written.  None when the fused route does not
+        apply (training, autograd, global_feat=False); the caller then pools forward()'s output."""
+        if not self.global_feat or not _fused.can_fuse(self, input_data) or not input_data.is_cuda:
+            return None
+        channel_last = self.input_shape == "bnc"
+        if input_data.shape[2 if channel_last else 1] != 3:
+            raise RuntimeError("shape of x must be of [Batch x 3 x NumInPoints]")
+        x = input_data
+        stack = self._stack()
+        for i, (conv, bn) in enumerate(stack):
+            w, sc, sh = _fused.fold_conv_bn(conv, bn)
+            if i == len(stack) - 1:
+                return _fused.conv_global_max(x, w, sc, sh, True)
+            x = _fused.pointwise_conv(x, w, sc, sh, relu=True, channel_last=(channel_last and i == 0))
+
     def forward(self, input_data):
         if self.input_shape == "bnc":
             num_points = input_data.shape[1]
