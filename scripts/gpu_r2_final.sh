@@ -17,5 +17,5 @@ bash scripts/gpu_prof.sh r2_f16
 bash scripts/gpu_prof.sh r2_bf16x3 "--arith bf16x3"
 bash tools/pmc.sh edgeconv_f16 edgeconv_f16 > /dev/null 2>&1; grep -E "FETCH|WRITE|MFMA|GUI" gpurun_out/pmc_edgeconv_f16.txt
 bash tools/pmc.sh knn "knn_mfma_kernel" > /dev/null 2>&1; cp gpurun_out/pmc_knn.txt gpurun_out/pmc_knn_mfma.txt; grep -E "FETCH|WRITE|INSTS_VALU |GUI" gpurun_out/pmc_knn_mfma.txt
-bash tools/pmc.sh conv5_f16 "^conv_f16_kernel" > /dev/null 2>&1; grep -E "FETCH|WRITE|MFMA|GUI" gpurun_out/pmc_conv5_f16.txt
+bash tools/pmc.sh conv5_f16 "^(void )?conv_f16_kernel" > /dev/null 2>&1; grep -E "FETCH|WRITE|MFMA|GUI" gpurun_out/pmc_conv5_f16.txt
 cd $R && timeout 600 python tools/kbench.py > gpurun_out/r2_kbench.txt 2>&1; tail -5 gpurun_out/r2_kbench.txt
