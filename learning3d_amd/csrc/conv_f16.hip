@@ -227,7 +227,11 @@ __global__ __launch_bounds__(256) void cf_split_x_cl_kernel(const float *__restr
 // double (stage 44 KB, 48 DMA instructions per chunk -- four of them duplicates so that every wave issues six).
 // AMAX: the fp32 epilogue also reduces max|y| (its own instantiation: the reduction costs the plain kernel its spill-free
 // register allocation -- 218 VGPRs against 256 + scratch).
-template <bool NARROW, bool AMAX>
+// GROUP: the pooled epilogue takes runs of 8 ... 64 points (a grouped layer's max over K neighbours) instead of 128; its own
+// instantiation as well -- with the general code in the common kernel the 128-point pool ran at half speed (312 -> 612 us at PCN's
+// conv4) and, one rewrite later, the fp32 epilogue's main loop lost 35 % to a different instruction schedule
+// (tools/bin/cfv probes, LABLOG R2.4h): this kernel's loop is sensitive to what is compiled around it.
+template <bool NARROW, bool AMAX, bool GROUP>
 __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__ xh, const uint4 *__restrict__ xm,
                                                        const uint4 *__restrict__ wH, const uint4 *__restrict__ wHs,
                                                        const uint4 *__restrict__ wM, const float *__restrict__ winv,
@@ -392,20 +396,20 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
             up = ldexpf(1.f, 12 - e);
             if (blockIdx.x == 0 && t == 0) *oinv = ldexpf(1.f, e - 12);
         }
+      if constexpr (!GROUP) {
         const size_t rows = (size_t)Bn * N;
-        const int half = lane >> 5, NP = N / pool;               // pool: 8, 16, 32, 64 or 128 consecutive points per maximum
-        const int span = pool < 32 ? pool : 32;                  // lanes of one 32-point tile that share a maximum
+        const int half = lane >> 5, NP = N / 128;
 #pragma unroll
         for (int a = 0; a < 2; a++)
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
                 const int cob = co0 + wm * 64 + a * 32 + 8 * gq + 4 * half;          // this lane's 4 channels: cob .. cob + 3
-                float sc[4], sh[4], run[4];
+                float sc[4], sh[4], vmax[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     sc[u] = (scale ? scale[cob + u] : 1.f) * inv;
                     sh[u] = shift ? shift[(size_t)b * shift_bstride + cob + u] : 0.f;
-                    run[u] = -INFINITY;
+                    vmax[u] = -INFINITY;
                 }
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
@@ -414,6 +418,7 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
                     for (int u = 0; u < 4; u++) {
                         v[u] = acc[a][c][4 * gq + u] * sc[u] + sh[u];
                         if (relu) v[u] = l3d_act(v[u], relu);
+                        vmax[u] = fmaxf(vmax[u], v[u]);
                     }
                     if (oph) {
                         uint32_t h0, h1, m0, m1;
@@ -424,26 +429,86 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
                         oph[cellh] = make_uint2(h0, h1);
                         opm[cellh] = make_uint2(m0, m1);
                     }
-                    if (ypool) {
-                        // across `span` lanes of this 32-point tile by shuffles, then (pool 64 / 128) across tiles in `run`
+                }
+                if (ypool) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+#pragma unroll
+                        for (int d = 1; d < 32; d <<= 1) vmax[u] = fmaxf(vmax[u], __shfl_xor(vmax[u], d, 64));
+                    }
+                    if ((lane & 31) == 0) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            ypool[((size_t)b * Cout + cob + u) * NP + (n0 + wn * 128) / 128] = vmax[u];
+                    }
+                }
+            }
+      } else {
+        const size_t rows = (size_t)Bn * N;
+        const int half = lane >> 5, NP = N / pool;               // pool: 8, 16, 32, 64 or 128 consecutive points per maximum
+        const int span = pool < 32 ? pool : 32;                  // lanes of one 32-point tile that share a maximum
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                const int cob = co0 + wm * 64 + a * 32 + 8 * gq + 4 * half;          // this lane's 4 channels: cob .. cob + 3
+                float sc[4], sh[4], pv[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    sc[u] = (scale ? scale[cob + u] : 1.f) * inv;
+                    sh[u] = shift ? shift[(size_t)b * shift_bstride + cob + u] : 0.f;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        v[u] = acc[a][c][4 * gq + u] * sc[u] + sh[u];
+                        if (relu) v[u] = l3d_act(v[u], relu);
+                        pv[c][u] = v[u];
+                    }
+                    if (oph) {
+                        uint32_t h0, h1, m0, m1;
+                        af_split_x(v[0], v[1], up, h0, m0);
+                        af_split_x(v[2], v[3], up, h1, m1);
+                        const size_t row = (size_t)b * N + n0 + wn * 128 + c * 32 + (lane & 31);
+                        const size_t cellh = ((size_t)(cob >> 3) * rows + row) * 2 + half;
+                        oph[cellh] = make_uint2(h0, h1);
+                        opm[cellh] = make_uint2(m0, m1);
+                    }
+                }
+                if (ypool) {
+                    // tiles of one run first (registers), then across the `span` lanes of a tile: shuffles with constant distances
+                    // (DPP, not ds_bpermute) and as few of them as the run length allows -- 5 per channel for pool = 128
+                    if (pool >= 64) {
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
-                            for (int d = 1; d < span; d <<= 1) v[u] = fmaxf(v[u], __shfl_xor(v[u], d, 64));
-                            run[u] = fmaxf(run[u], v[u]);
+                            pv[0][u] = fmaxf(pv[0][u], pv[1][u]);
+                            pv[2][u] = fmaxf(pv[2][u], pv[3][u]);
+                            if (pool == 128) pv[0][u] = fmaxf(pv[0][u], pv[2][u]);
                         }
-                        const int tiles = pool <= 32 ? 1 : pool / 32;                 // 32-point tiles per maximum
-                        if (((c + 1) & (tiles - 1)) == 0) {
-                            if (((lane & 31) & (span - 1)) == 0) {
-                                const int n = n0 + wn * 128 + (c + 1 - tiles) * 32 + (lane & 31);
+                    }
+                    const int step = pool == 128 ? 4 : (pool == 64 ? 2 : 1);        // tiles per maximum
 #pragma unroll
-                                for (int u = 0; u < 4; u++) ypool[((size_t)b * Cout + cob + u) * NP + n / pool] = run[u];
-                            }
+                    for (int c = 0; c < 4; c++) {
+                        if (c % step) continue;
 #pragma unroll
-                            for (int u = 0; u < 4; u++) run[u] = -INFINITY;
+                        for (int u = 0; u < 4; u++) {
+                            float m = pv[c][u];
+#pragma unroll
+                            for (int d = 1; d < 32; d <<= 1)
+                                if (d < span) m = fmaxf(m, __shfl_xor(m, d, 64));
+                            pv[c][u] = m;
+                        }
+                        if (((lane & 31) & (span - 1)) == 0) {
+                            const int n = n0 + wn * 128 + c * 32 + (lane & 31);
+#pragma unroll
+                            for (int u = 0; u < 4; u++) ypool[((size_t)b * Cout + cob + u) * NP + n / pool] = pv[c][u];
                         }
                     }
                 }
             }
+      }
         return;
     }
     float *yb = y + (size_t)b * Cout * N;
@@ -573,10 +638,14 @@ static int cf_launch(const void *x_planes, const void *w_planes, const float *sc
                 (const float *)(wp + 3 * wpb), (const float *)(xp + 2 * xpb), scale, shift, shift_bstride, B, Cin, Cout, N, relu, y,      \
                 (uint2 *)op, op ? (uint2 *)(op + opb) : nullptr, op ? (float *)(op + 2 * opb) : nullptr, obs, ypool, pool, amax_out, amax_cdiv
     const size_t nlds = 3 * (6 * 128 * 16 + 4 * 512 * 16);
-    if (narrow && amax_out) hipLaunchKernelGGL((conv_f16_kernel<true, true>), grid, block, nlds, st, CF_ARGS);
-    else if (narrow)        hipLaunchKernelGGL((conv_f16_kernel<true, false>), grid, block, nlds, st, CF_ARGS);
-    else if (amax_out)      hipLaunchKernelGGL((conv_f16_kernel<false, true>), grid, block, CF_LDS, st, CF_ARGS);
-    else                    hipLaunchKernelGGL((conv_f16_kernel<false, false>), grid, block, CF_LDS, st, CF_ARGS);
+    const bool group = ypool && pool != 128;
+    if (group && amax_out) return L3D_ERR_UNSUPPORTED;
+    if (narrow && group)         hipLaunchKernelGGL((conv_f16_kernel<true, false, true>), grid, block, nlds, st, CF_ARGS);
+    else if (narrow && amax_out) hipLaunchKernelGGL((conv_f16_kernel<true, true, false>), grid, block, nlds, st, CF_ARGS);
+    else if (narrow)             hipLaunchKernelGGL((conv_f16_kernel<true, false, false>), grid, block, nlds, st, CF_ARGS);
+    else if (group)              hipLaunchKernelGGL((conv_f16_kernel<false, false, true>), grid, block, CF_LDS, st, CF_ARGS);
+    else if (amax_out)           hipLaunchKernelGGL((conv_f16_kernel<false, true, false>), grid, block, CF_LDS, st, CF_ARGS);
+    else                         hipLaunchKernelGGL((conv_f16_kernel<false, false, false>), grid, block, CF_LDS, st, CF_ARGS);
 #undef CF_ARGS
     return l3d_check_launch();
 }
