@@ -309,3 +309,28 @@ def test_integration_md_shims_match_the_library():
                 f"{name}: shim passes {len(node.args)} arguments, the C ABI takes {len(_lib.SIGNATURES[name])}"
             calls += 1
     assert calls >= 14
+
+
+def test_hot_kernels_compile_without_scratch():
+    """The kernels of the benchmark step (and the f16x2 GEMMs of PCN / DCP) must not spill: a spilled register in conv_f16_kernel
+    was a silent 35 % on its main loop (LABLOG R2.4h).  Read from the code objects inside libl3d_hip.so (tools/kernel_meta.py:
+    AMDGPU metadata notes), so it runs without a GPU."""
+    import importlib.util
+    from learning3d_amd import _lib
+    spec = importlib.util.spec_from_file_location("kernel_meta", os.path.join(ROOT, "tools", "kernel_meta.py"))
+    km = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(km)
+    meta = km.kernel_metadata(_lib.LIB_PATH)
+    assert len(meta) > 100                                   # every translation unit's code object was found
+    hot = {"_Z15conv_f16_kernelILb0ELb0ELb0EE": 224,         # conv5 / Linear layers (wide tile): VGPR budget 218 today
+           "_Z15conv_f16_kernelILb1ELb0ELb0EE": 224,         # narrow tile
+           "_Z19edgeconv_f16_kernelILi5ELb1EE": 512,
+           "_Z15knn_mfma_kernelILi8EE": 256,
+           "_Z25chamfer_fwd_packed_kernel": 128,
+           "_Z19fold_mlp_f16_kernelILi5EE": 256}
+    for prefix, vgpr_max in hot.items():
+        ks = [k for n, k in meta.items() if n.startswith(prefix)]
+        assert len(ks) == 1, prefix
+        k = ks[0]
+        assert k.get(".private_segment_fixed_size", 0) == 0 and k.get(".vgpr_spill_count", 0) == 0, (prefix, k)
+        assert k.get(".vgpr_count", 0) <= vgpr_max, (prefix, k.get(".vgpr_count"))
