@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void cf_split_x_cl_kernel(const float *__restr
 // GROUP: the pooled epilogue takes runs of 8 ... 64 points (a grouped layer's max over K neighbours) instead of 128; its own
 // instantiation as well -- with the general code in the common kernel the 128-point pool ran at half speed (312 -> 612 us at PCN's
 // conv4) and, one rewrite later, the fp32 epilogue's main loop lost 35 % to a different instruction schedule
-// (tools/bin/cfv probes, LABLOG R2.4h): this kernel's loop is sensitive to what is compiled around it.
+// (tools/conv_f16_version_probe.sh, LABLOG R2.4h): this kernel's loop is sensitive to what is compiled around it.
 template <bool NARROW, bool AMAX, bool GROUP>
 __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__ xh, const uint4 *__restrict__ xm,
                                                        const uint4 *__restrict__ wH, const uint4 *__restrict__ wHs,
