@@ -10,7 +10,7 @@ for CTRS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU 
             "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   rm -rf $R/gpurun_out/pmc_tmp
-  timeout 300 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $R/gpurun_out/pmc_tmp -o p -- python $R/tools/run_one.py $TAG > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $R/gpurun_out/pmc_tmp -o p -- python $R/tools/pmc_one.py $TAG > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1
   f=$(find $R/gpurun_out/pmc_tmp -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then python - "$f" "$RE" <<'PY' > $R/gpurun_out/pmc_${TAG}_$i.txt
 import csv, sys, re, collections

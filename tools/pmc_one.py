@@ -1,4 +1,4 @@
-"""Run one kernel a few times (for rocprofv3 --pmc passes).  usage: run_one.py knn|chamfer|edgeconv|edgeconv_split|edgeconv_f16|conv5|conv5_split|conv5_f16"""
+"""Run one kernel a few times (for rocprofv3 --pmc passes).  usage: pmc_one.py knn|chamfer|edgeconv|edgeconv_split|edgeconv_f16|conv5|conv5_split|conv5_f16"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
