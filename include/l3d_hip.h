@@ -513,18 +513,36 @@ int l3d_quat_transform(const float *tmpl, const float *pose7, int B, int N, floa
  * no atomics); the host adds them in global cloud order (after an all_gather when the batch is sharded across ranks),
  * which makes the batch statistics -- and the two backward reductions -- bit-identical for any number of GPUs.
  *   l3d_channel_stats     part[b][c] = (sum_p z, sum_p z^2)
- *   l3d_bn_act_forward    y = act(z scale[c] + shift[c]),  act: 0 none, 1 ReLU
- *   l3d_bn_backward_stats part[b][c] = (sum_p g, sum_p g zhat),  g = dy [z scale + shift > 0 if act],  zhat = (z - mean[c]) rstd[c]
+ *   l3d_bn_act_forward    y = act(z scale[c] + shift[c]),  act: 0 none, 1 ReLU, > 1 the fp32 bits of a LeakyReLU slope
+ *   l3d_bn_backward_stats part[b][c] = (sum_p g, sum_p g zhat),  g = dy act'(z scale + shift),  zhat = (z - mean[c]) rstd[c]
  *   l3d_bn_act_backward   dz = gr[c] (g - m1[c] - zhat m2[c])
  * ------------------------------------------------------------------------------------------- */
 int l3d_channel_stats(const float *z, int B, int C, long P, double *part, l3d_stream_t stream);
 int l3d_bn_act_forward(const float *z, const float *scale, const float *shift, int B, int C, long P, int act, float *y,
                        l3d_stream_t stream);
-int l3d_bn_backward_stats(const float *dy, const float *z, const float *scale, const float *shift, const float *mean,
-                          const float *rstd, int B, int C, long P, int act, double *part, l3d_stream_t stream);
-int l3d_bn_act_backward(const float *dy, const float *z, const float *scale, const float *shift, const float *mean,
-                        const float *rstd, const float *gr, const float *m1, const float *m2, int B, int C, long P, int act,
+int l3d_bn_backward_stats(const float *dy, const float *z, const float *scale, const float *shift, const double *mean,
+                          const double *rstd, int B, int C, long P, int act, double *part, l3d_stream_t stream);
+/* mean, rstd, gr, m1, m2 [C] are fp64 and dz is evaluated in fp64 and rounded once (sum_p dz = 0 by construction: an
+ * fp32-rounded m1 is a systematic error the weight gradient multiplies by the point count).  m1 = m2 = 0: eval-mode
+ * BatchNorm or a plain bias layer (the statistics do not depend on z). */
+int l3d_bn_act_backward(const float *dy, const float *z, const float *scale, const float *shift, const double *mean,
+                        const double *rstd, const double *gr, const double *m1, const double *m2, int B, int C, long P, int act,
                         float *dz, l3d_stream_t stream);
+/* tot[j] = part[0][j] + part[1][j] + ... + part[B-1][j]: per-cloud fp64 partials [B][M] added left to right, i.e. in
+ * global cloud order whatever B's factorisation into ranks was. */
+int l3d_sum_clouds_f64(const double *part, int B, long M, double *tot, l3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight gradient of a 1x1 conv / Linear over points (wgrad.hip; the autograd of nn.Conv1d / Conv2d(k=1) in
+ * models/dgcnn.py:34-48, models/pcn.py:110-153, models/pointnet.py:51-73 under examples/train_pcn.py:70-91):
+ *   dw[co][ci] = sum_b sum_p dz[b][co][p] x[b][ci][p]          dz [B,Cout,P], x [B,Cin,P] fp32
+ * exact-fp32 products on the fp32 MFMA, the B*P reduction split into (cloud, pc-point chunk) pieces whose partial sums
+ * are added in piece order in fp64: deterministic (no atomics) and accurate to one rounding of <= pc-term fp32 sums.
+ * pc <= 0: 2048.  workspace: l3d_wgrad_workspace_bytes(B, Cout, Cin, P, pc) bytes, caller-allocated.
+ * ------------------------------------------------------------------------------------------- */
+size_t l3d_wgrad_workspace_bytes(int B, int Cout, int Cin, long P, int pc);
+int l3d_wgrad(const float *dz, const float *x, int B, int Cout, int Cin, long P, int pc, float *workspace, float *dw,
+              l3d_stream_t stream);
 
 #ifdef __cplusplus
 }

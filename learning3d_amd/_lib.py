@@ -100,6 +100,9 @@ SIGNATURES = {
     "l3d_bn_act_forward": [_P, _P, _P, _I, _I, _L, _I, _P, _P],
     "l3d_bn_backward_stats": [_P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P],
     "l3d_bn_act_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P],
+    "l3d_sum_clouds_f64": [_P, _I, _L, _P, _P],
+    "l3d_wgrad_workspace_bytes": [_I, _I, _I, _L, _I],
+    "l3d_wgrad": [_P, _P, _I, _I, _I, _L, _I, _P, _P, _P],
     "l3d_uniform_clouds": [C.c_ulonglong, _I, _I, _F, _F, _P, _P],
     "l3d_euler_transform": [_P, _P, _P, _I, _I, _P, _P, _P],
     "l3d_twist_transform": [_P, _P, _I, _I, _P, _P, _P, _P],
@@ -109,7 +112,8 @@ SIGNATURES = {
 }
 _RESTYPE = {"l3d_status_string": C.c_char_p, "l3d_edgeconv_packed_floats": _SZ, "l3d_split_bytes": _SZ,
             "l3d_soft_correspondence_workspace_floats": _SZ, "l3d_knn_feature_workspace_bytes": _SZ,
-            "l3d_scatter_add_det_workspace_bytes": _SZ, "l3d_chamfer_loss_local_ws_bytes": _SZ, "l3d_f16_plane_bytes": _SZ, "l3d_f16_act_bytes": _SZ, "l3d_conv_f16_weight_bytes": _SZ}
+            "l3d_scatter_add_det_workspace_bytes": _SZ, "l3d_chamfer_loss_local_ws_bytes": _SZ, "l3d_f16_plane_bytes": _SZ, "l3d_f16_act_bytes": _SZ, "l3d_conv_f16_weight_bytes": _SZ,
+            "l3d_wgrad_workspace_bytes": _SZ}
 
 
 class L3DError(RuntimeError):
@@ -134,7 +138,12 @@ def lib():
     return _lib
 
 
+LAUNCH_LOG = None      # set to a list to record the name of every C-ABI call that passes through check() (tests: which route ran)
+
+
 def check(status, what):
+    if LAUNCH_LOG is not None:
+        LAUNCH_LOG.append(what)
     if status != 0:
         l = lib()
         msg = l.l3d_status_string(status).decode()

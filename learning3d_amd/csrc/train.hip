@@ -8,9 +8,22 @@
 //   l3d_channel_stats        z [B,C,P]                      -> part [B,C,2] fp64 = (sum z, sum z^2) per (cloud, channel)
 //   l3d_bn_act_forward       y = act(z * scale[c] + shift[c])                              (act: 0 none, 1 ReLU)
 //   l3d_bn_backward_stats    dy, z, scale, shift, mean, rstd  -> part [B,C,2] fp64 = (sum g, sum g zhat),
-//                            g = dy * [z scale + shift > 0] (ReLU mask recomputed, nothing extra saved), zhat = (z - mean) rstd
+//                            g = dy * act'(z scale + shift) (mask recomputed, nothing extra saved; act: 0 none, 1 ReLU, else a
+//                            LeakyReLU slope's bits as in common.h), zhat = (z - mean) rstd
 //   l3d_bn_act_backward      dz = gr[c] * (g - m1[c] - zhat * m2[c])      (gr = gamma rstd, m1 = sum g / n, m2 = sum g zhat / n)
+//   l3d_sum_clouds_f64       tot[j] = part[0][j] + part[1][j] + ... in cloud order (one thread per j: a fixed left-to-right order)
+// The per-channel constants of the two backward kernels (mean, rstd, gr, m1, m2) are fp64 and dz is evaluated in fp64 and
+// rounded once: sum_p dz is zero by construction, and the weight gradient sums dz x over 10^5..10^6 points, so an fp32
+// rounding of m1 (a SYSTEMATIC error, the same for every point) would be multiplied by the point count.  These kernels are
+// HBM-bound; the fp64 arithmetic is free.  Eval-mode BatchNorm / plain bias layers use the same kernels with m1 = m2 = 0.
 #include "common.h"
+
+// d act(v) / dv for the library's activation code (common.h l3d_act): 0 none, 1 ReLU, else the bits of a LeakyReLU slope
+__device__ __forceinline__ float tr_act_grad(float v, int act)
+{
+    if (!act || v > 0.f) return 1.f;
+    return act == 1 ? 0.f : __int_as_float(act);
+}
 
 __device__ __forceinline__ double tr_block_sum(double v, double *sh)
 {
@@ -57,7 +70,7 @@ __global__ __launch_bounds__(256) void bn_act_forward_kernel(const float *__rest
     if (p >= P) return;
     const size_t i = ((size_t)b * C + c) * P + p;
     const float v = z[i] * scale[c] + shift[c];
-    y[i] = act ? fmaxf(v, 0.f) : v;
+    y[i] = act ? l3d_act(v, act) : v;
 }
 
 extern "C" int l3d_bn_act_forward(const float *z, const float *scale, const float *shift, int B, int C, long P, int act,
@@ -71,19 +84,20 @@ extern "C" int l3d_bn_act_forward(const float *z, const float *scale, const floa
 
 __global__ __launch_bounds__(256) void bn_backward_stats_kernel(const float *__restrict__ dy, const float *__restrict__ z,
                                                                 const float *__restrict__ scale, const float *__restrict__ shift,
-                                                                const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                                const double *__restrict__ mean, const double *__restrict__ rstd,
                                                                 int C, long P, int act, double *__restrict__ part)
 {
     __shared__ double sh[4];
     const int c = blockIdx.x, b = blockIdx.y;
     const size_t base = ((size_t)b * C + c) * P;
-    const float sc = scale[c], shf = shift[c], mu = mean[c], rs = rstd[c];
+    const float sc = scale[c], shf = shift[c];
+    const double mu = mean[c], rs = rstd[c];
     double s = 0.0, q = 0.0;
     for (long p = threadIdx.x; p < P; p += 256) {
         const float zv = z[base + p];
-        const float g = (!act || zv * sc + shf > 0.f) ? dy[base + p] : 0.f;
+        const float g = dy[base + p] * tr_act_grad(zv * sc + shf, act);
         s += (double)g;
-        q += (double)g * (double)((zv - mu) * rs);
+        q += (double)g * (((double)zv - mu) * rs);
     }
     s = tr_block_sum(s, sh);
     q = tr_block_sum(q, sh);
@@ -93,8 +107,8 @@ __global__ __launch_bounds__(256) void bn_backward_stats_kernel(const float *__r
     }
 }
 
-extern "C" int l3d_bn_backward_stats(const float *dy, const float *z, const float *scale, const float *shift, const float *mean,
-                                     const float *rstd, int B, int C, long P, int act, double *part, l3d_stream_t stream)
+extern "C" int l3d_bn_backward_stats(const float *dy, const float *z, const float *scale, const float *shift, const double *mean,
+                                     const double *rstd, int B, int C, long P, int act, double *part, l3d_stream_t stream)
 {
     L3D_REQUIRE(dy && z && scale && shift && mean && rstd && part && B > 0 && C > 0 && P > 0 && B <= 65535);
     hipLaunchKernelGGL(bn_backward_stats_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, dy, z, scale, shift, mean, rstd, C, P,
@@ -104,9 +118,9 @@ extern "C" int l3d_bn_backward_stats(const float *dy, const float *z, const floa
 
 __global__ __launch_bounds__(256) void bn_act_backward_kernel(const float *__restrict__ dy, const float *__restrict__ z,
                                                               const float *__restrict__ scale, const float *__restrict__ shift,
-                                                              const float *__restrict__ mean, const float *__restrict__ rstd,
-                                                              const float *__restrict__ gr, const float *__restrict__ m1,
-                                                              const float *__restrict__ m2, int C, long P, int act,
+                                                              const double *__restrict__ mean, const double *__restrict__ rstd,
+                                                              const double *__restrict__ gr, const double *__restrict__ m1,
+                                                              const double *__restrict__ m2, int C, long P, int act,
                                                               float *__restrict__ dz)
 {
     const int c = blockIdx.y, b = blockIdx.z;
@@ -114,16 +128,32 @@ __global__ __launch_bounds__(256) void bn_act_backward_kernel(const float *__res
     if (p >= P) return;
     const size_t i = ((size_t)b * C + c) * P + p;
     const float zv = z[i];
-    const float g = (!act || zv * scale[c] + shift[c] > 0.f) ? dy[i] : 0.f;
-    dz[i] = gr[c] * (g - m1[c] - (zv - mean[c]) * rstd[c] * m2[c]);
+    const float g = dy[i] * tr_act_grad(zv * scale[c] + shift[c], act);
+    dz[i] = (float)(gr[c] * ((double)g - m1[c] - ((double)zv - mean[c]) * rstd[c] * m2[c]));
 }
 
-extern "C" int l3d_bn_act_backward(const float *dy, const float *z, const float *scale, const float *shift, const float *mean,
-                                   const float *rstd, const float *gr, const float *m1, const float *m2, int B, int C, long P,
+extern "C" int l3d_bn_act_backward(const float *dy, const float *z, const float *scale, const float *shift, const double *mean,
+                                   const double *rstd, const double *gr, const double *m1, const double *m2, int B, int C, long P,
                                    int act, float *dz, l3d_stream_t stream)
 {
     L3D_REQUIRE(dy && z && scale && shift && mean && rstd && gr && m1 && m2 && dz && B > 0 && C > 0 && P > 0 && B <= 65535 && C <= 65535);
     hipLaunchKernelGGL(bn_act_backward_kernel, dim3((unsigned)l3d_divup(P, 256), C, B), dim3(256), 0, (hipStream_t)stream, dy, z, scale,
                        shift, mean, rstd, gr, m1, m2, C, P, act, dz);
+    return l3d_check_launch();
+}
+
+__global__ __launch_bounds__(256) void sum_clouds_f64_kernel(const double *__restrict__ part, int B, long M, double *__restrict__ tot)
+{
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= M) return;
+    double s = 0.0;
+    for (int b = 0; b < B; b++) s += part[(size_t)b * M + j];
+    tot[j] = s;
+}
+
+extern "C" int l3d_sum_clouds_f64(const double *part, int B, long M, double *tot, l3d_stream_t stream)
+{
+    L3D_REQUIRE(part && tot && B > 0 && M > 0);
+    hipLaunchKernelGGL(sum_clouds_f64_kernel, dim3((unsigned)l3d_divup(M, 256)), dim3(256), 0, (hipStream_t)stream, part, B, M, tot);
     return l3d_check_launch();
 }

@@ -1,9 +1,17 @@
-"""Host-side glue for the fp32-MFMA shared-MLP kernels (mlp.hip): BatchNorm folding, parameter
-packing (cached per parameter version) and the two launches.  Inference / no-grad only: with
-autograd or train-mode BatchNorm (batch statistics) the modules route the 1x1 convs through torch
-(rocBLAS/MIOpen) on top of the HIP kNN / grouping kernels -- the training path is ranked under
-"next" in SURVEY.md 8(f)."""
+"""Host-side glue for the shared-MLP kernels: BatchNorm folding, parameter packing (cached per parameter version), the
+launches, and the two mechanisms that decide WHICH route a model's forward takes:
+
+  * `checkpointed(module, impl, *tensors)`: the fused kernels are the forward a reference user gets.  The reference's own
+    scripts run `model.eval()` with grad mode ON and never call `torch.no_grad()` (examples/test_pointnet.py:31-60,
+    examples/test_dcp.py:43-73), so "needs no gradient" cannot be the gate.  Whenever the module's forward is a pure function
+    of its inputs and parameters (eval-mode BatchNorm / no BatchNorm, no active dropout) the fused launches run inside an
+    autograd.Function; its backward re-evaluates the module through the differentiable per-layer route (_train.py's HIP
+    conv / dgrad / wgrad kernels) and back-propagates through that -- activation checkpointing with a faster forward.
+  * `run_guarded(device, run)`: f16x2 kernels watch fp16's range; the verdict is read at the end of the SAME call (one event
+    wait) and an overflowing call is re-run on bf16x3 (fp32's exponent range) before anything is returned.
+Train-mode BatchNorm (batch statistics) takes the per-layer route directly (_train.py)."""
 import ctypes as C
+import threading
 
 import torch
 
@@ -91,14 +99,128 @@ def fold_conv_bn(conv, bn=None):
     return out
 
 
-def can_fuse(module, *tensors):
-    """Fused MFMA path: inference semantics only (no grad, BatchNorm in eval mode)."""
-    if module.training and any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in module.modules()):
+def _stochastic_or_batch_dependent(module):
+    """train-mode BatchNorm (batch statistics) or an active Dropout: forward is not a pure function of inputs + parameters"""
+    if not module.training:
         return False
-    if torch.is_grad_enabled() and (any(t.requires_grad for t in tensors) or
+    for m in module.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training:
+            return True
+        if isinstance(m, torch.nn.modules.dropout._DropoutNd) and m.training and m.p > 0:
+            return True
+    return False
+
+
+def can_fuse(module, *tensors):
+    """May this call site launch the fused kernels DIRECTLY: BatchNorm in eval mode and nothing to differentiate.  Inside
+    `checkpointed`'s forward grad mode is off, so this is True there; inside its backward recomputation it is False and the
+    call site takes its differentiable route."""
+    if _stochastic_or_batch_dependent(module):
+        return False
+    if torch.is_grad_enabled() and (any(t.requires_grad for t in tensors if t is not None) or
                                     any(p.requires_grad for p in module.parameters())):
         return False
     return True
+
+
+_TLS = threading.local()
+
+
+def recomputing():
+    return getattr(_TLS, "recomputing", False)
+
+
+class per_layer_route:
+    """`with _fused.per_layer_route():` -- modules called inside with autograd live take their differentiable per-layer route
+    directly, exactly as the backward recomputation of `checkpointed` does (tests compare it with the fused forward)."""
+
+    def __enter__(self):
+        self.prev = recomputing()
+        _TLS.recomputing = True
+
+    def __exit__(self, *exc):
+        _TLS.recomputing = self.prev
+        return False
+
+
+def _flatten(out):
+    """model output (tensor | tuple / list | dict of tensors, one level) -> (list of tensors, rebuild function)"""
+    if isinstance(out, torch.Tensor):
+        return [out], lambda ts: ts[0]
+    if isinstance(out, dict):
+        keys = list(out.keys())
+        return [out[k] for k in keys], lambda ts: {k: t for k, t in zip(keys, ts)}
+    if isinstance(out, (tuple, list)):
+        kind = type(out)
+        return list(out), lambda ts: kind(ts)
+    raise TypeError(f"checkpointed: unsupported output type {type(out)}")
+
+
+class _Recompute(torch.autograd.Function):
+    """forward: impl(*tensors) with grad mode off (the fused kernels).  backward: impl again with grad mode on, on detached
+    inputs (the call sites then take their differentiable routes), and autograd through that graph."""
+
+    @staticmethod
+    def forward(ctx, impl, holder, n_in, *args):
+        ins = args[:n_in]
+        outs, rebuild = _flatten(impl(*ins))
+        holder["rebuild"] = rebuild
+        ctx.impl, ctx.n_in = impl, n_in
+        ctx.save_for_backward(*[a for a in ins if isinstance(a, torch.Tensor)])
+        ctx.is_tensor = [isinstance(a, torch.Tensor) for a in ins]
+        ctx.non_tensor = [a for a in ins if not isinstance(a, torch.Tensor)]
+        ctx.params = list(args[n_in:])          # the module's own Parameter objects (alive as long as the module is)
+        # an output that IS an input (identity branches) must be a new tensor object for autograd
+        in_ids = {id(a) for a in ins if isinstance(a, torch.Tensor)}
+        return tuple(o.view_as(o) if id(o) in in_ids else o for o in outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        saved, others = list(ctx.saved_tensors), list(ctx.non_tensor)
+        args = [saved.pop(0) if t else others.pop(0) for t in ctx.is_tensor]
+        params = ctx.params
+        ins = []
+        for i in range(ctx.n_in):
+            a = args[i]
+            if isinstance(a, torch.Tensor):
+                a = a.detach()
+                if ctx.needs_input_grad[3 + i]:
+                    a.requires_grad_(True)
+            ins.append(a)
+        prev = recomputing()
+        _TLS.recomputing = True
+        try:
+            with torch.enable_grad():
+                outs, _ = _flatten(ctx.impl(*ins))
+        finally:
+            _TLS.recomputing = prev
+        wrt = [a for i, a in enumerate(ins) if isinstance(a, torch.Tensor) and ctx.needs_input_grad[3 + i]]
+        wrt += [p for j, p in enumerate(params) if ctx.needs_input_grad[3 + ctx.n_in + j]]
+        pairs = [(o, g) for o, g in zip(outs, grads) if g is not None and o.requires_grad]
+        got = iter(torch.autograd.grad([o for o, _ in pairs], wrt, [g for _, g in pairs], allow_unused=True) if pairs and wrt
+                   else [None] * len(wrt))
+        res = [None, None, None]
+        for i, a in enumerate(ins):
+            res.append(next(got) if isinstance(a, torch.Tensor) and ctx.needs_input_grad[3 + i] else None)
+        for j in range(len(params)):
+            res.append(next(got) if ctx.needs_input_grad[3 + ctx.n_in + j] else None)
+        return tuple(res)
+
+
+def checkpointed(module, impl, *tensors):
+    """Run `impl(*tensors)` (a module's forward body) so that the fused kernels serve the forward whatever the grad mode:
+    nothing to differentiate -> impl directly; batch statistics / dropout -> impl directly (its call sites pick the per-layer
+    route); otherwise inside _Recompute.  Outputs: a tensor, or a tuple / list / dict of tensors."""
+    if not torch.is_grad_enabled() or recomputing() or _stochastic_or_batch_dependent(module):
+        return impl(*tensors)
+    params = [p for p in module.parameters() if p.requires_grad]
+    if not params and not any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
+        return impl(*tensors)
+    if not all(t.is_cuda for t in tensors if isinstance(t, torch.Tensor)):
+        return impl(*tensors)
+    holder = {}
+    outs = _Recompute.apply(impl, holder, len(tensors), *tensors, *params)
+    return holder["rebuild"](list(outs))
 
 
 # Training (module.train() with BatchNorm, or autograd through the conv stack): True = conv / dgrad / wgrad on the HIP
@@ -302,6 +424,12 @@ def pointwise_conv(x, w, scale=None, shift=None, relu=False, channel_last=False,
     return y
 
 
+def linear_rows(x, lin, relu=False):
+    """nn.Linear over rows x [R, Cin] -> [R, Cout] (+ ReLU) on the conv kernels: the rows are the points of one cloud"""
+    w, _, b = fold_conv_bn(lin)
+    return pointwise_conv(f32c(x).unsqueeze(0), w, None, b, relu=relu, channel_last=True)[0].t()
+
+
 class EdgeConvParams:
     """Folded + fragment-packed parameters of a 4-layer EdgeConv stack, cached on the module and
     rebuilt only when a parameter / running statistic changes (tensor._version) or moves device."""
@@ -350,7 +478,26 @@ GEMM_ARITH = "f16x2"
 
 
 def gemm_arith():
-    return GEMM_ARITH if SPLIT_BF16 else "fp32"
+    if not SPLIT_BF16:
+        return "fp32"
+    return getattr(_TLS, "arith", None) or GEMM_ARITH
+
+
+class arith:
+    """`with _fused.arith("bf16x3"):` -- GEMM arithmetic of the calls inside, for this thread"""
+
+    def __init__(self, name):
+        if name not in ("f16x2", "bf16x3", "fp32"):
+            raise ValueError(f"unknown GEMM arithmetic {name!r}")
+        self.name = name
+
+    def __enter__(self):
+        self.prev = getattr(_TLS, "arith", None)
+        _TLS.arith = self.name
+
+    def __exit__(self, *exc):
+        _TLS.arith = self.prev
+        return False
 
 
 class L3DRangeError(RuntimeError):
@@ -371,11 +518,60 @@ def range_flag(device):
     return f
 
 
+# What a model does about the f16x2 range flag at the end of its fused forward:
+#   "retry"  (default) wait for the call's kernels (one event), read the flag, and if it is set re-run THIS call on bf16x3
+#            (fp32's exponent range) -- the caller always receives valid results, like the reference for any input scale;
+#   "raise"  the same wait, L3DRangeError instead of the re-run;
+#   "async"  no wait: the flag is looked at when the NEXT guarded call starts (check_range) -- maximum launch pipelining for
+#            callers that know their activations' range (BatchNorm'd networks on normalised clouds).
+# While a hipGraph is being captured nothing can be waited for: the capture owner calls check_range(sync=True) after replays
+# (bench.py does).
+RANGE_POLICY = "retry"
+RANGE_RETRIES = 0          # number of calls re-run on bf16x3 so far (tests, diagnostics)
+
+
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def range_raised(device, clear=True):
+    """Wait for the work queued on the current stream of `device`, then read (and clear) its range flag."""
+    f = range_flag(device)
+    ev = torch.cuda.Event()
+    ev.record()
+    ev.synchronize()
+    hit = int(f[0]) != 0
+    if hit and clear:
+        f[0] = 0
+    return hit
+
+
+def run_guarded(device, run):
+    """run() launches a model's fused forward under the arithmetic gemm_arith() reports and returns its outputs.  With f16x2
+    the call's range verdict is read before returning (RANGE_POLICY) and an overflowing call is repeated on bf16x3."""
+    global RANGE_RETRIES
+    if gemm_arith() != "f16x2":
+        return run()
+    if _capturing() or RANGE_POLICY == "async":
+        if not _capturing():
+            check_range(device)                      # an earlier call's verdict, if it has completed
+        return run()
+    out = run()
+    if range_raised(device):
+        if RANGE_POLICY == "raise":
+            raise L3DRangeError("an activation left the fp16 range (|x| > 60000) inside a f16x2 matrix-core kernel "
+                                "(_fused.RANGE_POLICY = 'raise')")
+        RANGE_RETRIES += 1
+        with arith("bf16x3"):
+            out = run()
+    return out
+
+
 def check_range(device=None, sync=False):
     """Raise if a f16x2 kernel launched earlier on `device` (default: every device used) reported an out-of-range
-    activation: its outputs were invalid.  sync=True waits for the device first (tests, end of a bench run); the
-    default looks at what has already completed -- the models call it at the start of every fused forward, so an
-    overflow is reported at the next call at the latest."""
+    activation: its outputs were invalid.  sync=True waits for the device first (tests, the end of a graph-replay loop);
+    the default looks at what has already completed.  Models under RANGE_POLICY "retry" / "raise" never leave a raised
+    flag behind; this is the check for "async" callers and for hipGraph replays."""
     keys = list(_RANGE_FLAGS) if device is None else [torch.device(device).index or 0]
     for key in keys:
         f = _RANGE_FLAGS.get(key)
@@ -405,7 +601,6 @@ def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256), kernel=Non
         if not (k <= 20 and tuple(widths) == (64, 64, 128, 256)):
             raise ValueError("planes output is produced by the f16 EdgeConv kernel only (k <= 20, 64/64/128/256)")
         out = torch.empty(lib().l3d_f16_act_bytes(B * N, sum(widths)), dtype=torch.uint8, device=xyz_bn3.device)
-        check_range(xyz_bn3.device)
         args = (ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), ptr(out), 1, ptr(range_flag(xyz_bn3.device)), stream_ptr())
         with stage("edgeconv_kernel"):                   # the launch alone: a timing span here holds no Python between its
             rc = lib().l3d_edgeconv_forward_f16(*args)   # first event and the kernel (bench.py's live roofline timing)
@@ -419,7 +614,6 @@ def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256), kernel=Non
     if kernel != "lds" and (k > 20 or tuple(widths) != (64, 64, 128, 256)):
         kernel = "lds"
     if kernel == "f16":
-        check_range(xyz_bn3.device)                      # a previous launch's verdict, if it has completed
         fn, name = lib().l3d_edgeconv_forward_f16, "l3d_edgeconv_forward_f16"
         args = (ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), ptr(pooled), 0, ptr(range_flag(xyz_bn3.device)), stream_ptr())
     elif kernel == "split":

@@ -1,18 +1,21 @@
-"""Training path of the shared MLP: 1x1 conv + train-mode BatchNorm (+ ReLU) on the HIP kernels, with batch
-statistics that are bit-identical for any sharding of the batch across GPUs.
+"""Differentiable shared-MLP layer on the HIP kernels: 1x1 conv / Linear (+ bias) (+ BatchNorm, batch OR running statistics)
+(+ ReLU), forward and backward, with batch statistics that are bit-identical for any sharding of the batch across GPUs
+(SURVEY.md 8(f) rank 3).  This is the route every model takes whenever autograd is live -- `.train()` with BatchNorm, and
+the backward recomputation of `_fused.checkpointed` (eval mode / no BatchNorm with grad enabled).
 
-reference: models/dgcnn.py:34-48 (Conv2d -> BatchNorm2d -> ReLU) and models/pcn.py in .train(); the only multi-GPU
-hook the reference has is nn.DataParallel (examples/train_flownet.py:243-245), whose BatchNorm statistics are
-PER-REPLICA.  Here:
-  forward   z = W x              HIP GEMM (pointwise_conv: f16x2 / bf16x3 / fp32 MFMA by shape, _fused.py)
-            per-cloud (sum z, sum z^2) fp64            l3d_channel_stats
-            [all_gather of the partials across ranks]  torch.distributed (RCCL on GPUs, gloo in the CPU test)
-            summed in GLOBAL cloud order -> mean, var  same bits whatever the number of ranks
-            y = relu(z scale + shift)                  l3d_bn_act_forward
-  backward  per-cloud (sum g, sum g zhat) fp64         l3d_bn_backward_stats  [+ all_gather], as torch's SyncBatchNorm
-            dz                                          l3d_bn_act_backward
-            dx = W^T dz   (dgrad)                       HIP GEMM (pointwise_conv with the transposed weight)
-            dW = sum_b dz_b x_b^T   (wgrad)             HIP GEMM per cloud (points are the K axis), summed in cloud order
+reference: models/dgcnn.py:34-48 (Conv2d -> BatchNorm2d -> ReLU), models/pointnet.py:22-49, models/pcn.py:26-82, as trained by
+examples/train_pcn.py:70-91; the only multi-GPU hook the reference has is nn.DataParallel
+(examples/train_flownet.py:243-245), whose BatchNorm statistics are PER-REPLICA.  Here:
+  forward   z = W x              HIP GEMM (pointwise_conv: bf16x3 / fp32 MFMA by shape, _fused.py)
+            batch statistics:    per-cloud (sum z, sum z^2) fp64              l3d_channel_stats
+                                 [all_gather of the partials across ranks]    torch.distributed (RCCL on GPUs, gloo in the CPU test)
+                                 added in GLOBAL cloud order -> mean, var     l3d_sum_clouds_f64: same bits whatever the rank count
+            running statistics / no BatchNorm: the layer is the affine map y = scale z + shift
+            y = relu(z scale + shift)                                         l3d_bn_act_forward
+  backward  per-cloud (sum g, sum g zhat) fp64                                l3d_bn_backward_stats  [+ all_gather], as SyncBatchNorm
+            dz = gr (g - m1 - zhat m2), evaluated in fp64                     l3d_bn_act_backward    (m1 = m2 = 0 without batch statistics)
+            dx = W^T dz   (dgrad)                                             HIP GEMM (pointwise_conv with the transposed weight)
+            dW = sum_b sum_p dz x^T   (wgrad)                                 l3d_wgrad: split-K on the fp32 MFMA, pieces added in fp64, no atomics
 The running statistics follow torch.nn.BatchNorm (momentum update with the unbiased variance, num_batches_tracked).
 """
 import torch
@@ -24,20 +27,40 @@ from . import _fused
 
 def gather_cloud_partials(part):
     """part [B_local, C, 2] fp64 (this rank's clouds) -> [B_global, C, 2] in global cloud order (ranks hold contiguous
-    shards of equal size, parallel.shard_bounds).  Single process: returned as is."""
+    shards, parallel.shard_bounds; shard sizes may differ: the last batch of an epoch).  Single process: returned as is."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         world = dist.get_world_size()
-        flat = torch.empty((world * part.shape[0],) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
-        dist.all_gather_into_tensor(flat, part.contiguous())             # concatenation along dim 0 in rank order
-        return flat
+        sizes = torch.zeros(world, dtype=torch.int64, device=part.device)
+        sizes[dist.get_rank()] = part.shape[0]
+        dist.all_reduce(sizes)                                           # every rank's shard size (uneven last batch)
+        sizes = [int(s) for s in sizes.tolist()]
+        if len(set(sizes)) == 1:
+            flat = torch.empty((world * part.shape[0],) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
+            dist.all_gather_into_tensor(flat, part.contiguous())         # concatenation along dim 0 in rank order
+            return flat
+        bufs = [torch.empty((s,) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device) for s in sizes]
+        dist.all_gather(bufs, part.contiguous())
+        return torch.cat(bufs, dim=0)
     return part
 
 
+def sum_clouds(part):
+    """[B, ...] fp64 per-cloud partials -> [...] added in cloud order 0, 1, 2, ... (a fixed left-to-right order, independent
+    of B's factorisation into ranks); one launch (l3d_sum_clouds_f64).  CPU tensors (the gloo tests): the same order in torch."""
+    if not part.is_cuda:
+        tot = torch.zeros_like(part[0])
+        for b in range(part.shape[0]):
+            tot = tot + part[b]
+        return tot
+    part = part.contiguous()
+    tot = torch.empty(part.shape[1:], dtype=torch.float64, device=part.device)
+    check(lib().l3d_sum_clouds_f64(ptr(part), part.shape[0], tot.numel(), ptr(tot), stream_ptr()), "l3d_sum_clouds_f64")
+    return tot
+
+
 def stats_from_partials(part_global, points_per_cloud):
-    """[B,C,2] fp64 per-cloud sums -> (mean [C], biased var [C], n) in fp64, added in cloud order 0, 1, 2, ..."""
-    tot = torch.zeros_like(part_global[0])
-    for b in range(part_global.shape[0]):                    # a fixed left-to-right order, independent of B's factorisation
-        tot = tot + part_global[b]
+    """[B,C,2] fp64 per-cloud sums -> (mean [C], biased var [C], n, totals [C,2]) in fp64"""
+    tot = sum_clouds(part_global)
     n = float(part_global.shape[0]) * float(points_per_cloud)
     mean = tot[:, 0] / n
     var = torch.clamp(tot[:, 1] / n - mean * mean, min=0.0)
@@ -51,70 +74,127 @@ def channel_stats(z):
     return part
 
 
-class _ConvBNActTrain(torch.autograd.Function):
+def wgrad(dz, x, pc=0):
+    """dW [Cout,Cin] = sum_b dz_b [Cout,P] x_b^T [P,Cin]   (dz [B,Cout,P], x [B,Cin,P] fp32 contiguous): l3d_wgrad"""
+    B, Cout, P = dz.shape
+    Cin = x.shape[1]
+    if pc <= 0:
+        # pieces = B * ceil(P / pc): enough workgroups to fill 256 CUs even for a 64 x 6 gradient, a bounded workspace for 1024 x 512
+        tiles = ((Cout + 63) // 64) * ((Cin + 63) // 64)
+        pc = 2048
+        while pc > 256 and tiles * B * ((P + pc - 1) // pc) < 1024:
+            pc //= 2
+        while B * ((P + pc - 1) // pc) > 65535:
+            pc *= 2
+    ws = torch.empty(lib().l3d_wgrad_workspace_bytes(B, Cout, Cin, P, pc) // 4, dtype=torch.float32, device=dz.device)
+    dw = torch.empty((Cout, Cin), dtype=torch.float32, device=dz.device)
+    check(lib().l3d_wgrad(ptr(dz), ptr(x), B, Cout, Cin, P, pc, ptr(ws), ptr(dw), stream_ptr()), "l3d_wgrad")
+    return dw
+
+
+class _ConvAffineAct(torch.autograd.Function):
+    """y = act(BN(W x + bias)) for x [B,Cin,P]; bn None: y = act(W x + bias).  batch_stats: BatchNorm with the batch's own
+    statistics (train mode), else its running statistics (eval mode: an affine map)."""
+
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, bn, relu, sync):
+    def forward(ctx, x, weight, bias, gamma, beta, bn, relu, batch_stats, sync):
         x = f32c(x)                                                      # [B, Cin, P]
         B, Cin, P = x.shape
         w = f32c(weight.reshape(weight.shape[0], -1))
         Cout = w.shape[0]
+        dev = x.device
         z = _fused.pointwise_conv(x, w)                                  # HIP GEMM, no epilogue
-        part = channel_stats(z)
-        pg = gather_cloud_partials(part) if sync else part
-        mean64, var64, n, _ = stats_from_partials(pg, P)
-        with torch.no_grad():                                            # running statistics, as torch.nn.BatchNorm in train mode
-            if bn.track_running_stats and bn.running_mean is not None:
-                bn.num_batches_tracked += 1
-                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                unbiased = var64 * (n / max(n - 1.0, 1.0))
-                bn.running_mean.mul_(1 - m).add_(mean64.to(bn.running_mean.dtype), alpha=m)
-                bn.running_var.mul_(1 - m).add_(unbiased.to(bn.running_var.dtype), alpha=m)
-        rstd64 = torch.rsqrt(var64 + bn.eps)
-        scale = (gamma.detach().double() * rstd64).float().contiguous()
-        shift = (beta.detach().double() - mean64 * gamma.detach().double() * rstd64).float().contiguous()
+        b64 = bias.detach().double() if bias is not None else None
+        n = float(B) * float(P)
+        if bn is not None and batch_stats:
+            part = channel_stats(z)
+            pg = gather_cloud_partials(part) if sync else part
+            mean64, var64, n, _ = stats_from_partials(pg, P)             # of z; the layer's bias shifts the mean only
+            with torch.no_grad():                                        # running statistics, as torch.nn.BatchNorm in train mode
+                if bn.track_running_stats and bn.running_mean is not None:
+                    bn.num_batches_tracked += 1
+                    m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                    unbiased = var64 * (n / max(n - 1.0, 1.0))
+                    mean_in = mean64 + b64 if b64 is not None else mean64
+                    bn.running_mean.mul_(1 - m).add_(mean_in.to(bn.running_mean.dtype), alpha=m)
+                    bn.running_var.mul_(1 - m).add_(unbiased.to(bn.running_var.dtype), alpha=m)
+            rstd64 = torch.rsqrt(var64 + bn.eps)
+        elif bn is not None:
+            mean64 = bn.running_mean.detach().double()                   # of (z + bias): in z-space the mean is rm - bias
+            if b64 is not None:
+                mean64 = mean64 - b64
+            rstd64 = torch.rsqrt(bn.running_var.detach().double() + bn.eps)
+        else:
+            mean64 = -b64 if b64 is not None else torch.zeros(Cout, dtype=torch.float64, device=dev)
+            rstd64 = torch.ones(Cout, dtype=torch.float64, device=dev)
+        g64 = gamma.detach().double() if gamma is not None else torch.ones(Cout, dtype=torch.float64, device=dev)
+        be64 = beta.detach().double() if beta is not None else torch.zeros(Cout, dtype=torch.float64, device=dev)
+        gr64 = (g64 * rstd64).contiguous()
+        scale = gr64.float().contiguous()
+        shift = (be64 - mean64 * gr64).float().contiguous()
         y = torch.empty_like(z)
         check(lib().l3d_bn_act_forward(ptr(z), ptr(scale), ptr(shift), B, Cout, P, int(relu), ptr(y), stream_ptr()), "l3d_bn_act_forward")
-        ctx.save_for_backward(x, w, z, scale, shift, mean64.float().contiguous(), rstd64.float().contiguous(), gamma.detach().float().contiguous())
+        ctx.save_for_backward(x, w, z, scale, shift, mean64.contiguous(), rstd64.contiguous(), gr64)
         ctx.relu, ctx.sync, ctx.n, ctx.wshape = relu, sync, n, weight.shape
+        ctx.batch_stats, ctx.has_bn = bool(bn is not None and batch_stats), bn is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, z, scale, shift, mean, rstd, gamma = ctx.saved_tensors
+        x, w, z, scale, shift, mean64, rstd64, gr64 = ctx.saved_tensors
         dy = f32c(dy)
         B, Cout, P = z.shape
-        Cin = x.shape[1]
         part = torch.empty((B, Cout, 2), dtype=torch.float64, device=z.device)
-        check(lib().l3d_bn_backward_stats(ptr(dy), ptr(z), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), B, Cout, P, int(ctx.relu), ptr(part),
-                                          stream_ptr()), "l3d_bn_backward_stats")
-        local = stats_from_partials(part, P)[3]                          # this rank's (sum g, sum g zhat): the parameter gradients
-        tot = stats_from_partials(gather_cloud_partials(part), P)[3] if ctx.sync else local
-        dbeta, dgamma = local[:, 0].float(), local[:, 1].float()
-        gr = (gamma * rstd).contiguous()
-        m1, m2 = (tot[:, 0] / ctx.n).float().contiguous(), (tot[:, 1] / ctx.n).float().contiguous()
+        check(lib().l3d_bn_backward_stats(ptr(dy), ptr(z), ptr(scale), ptr(shift), ptr(mean64), ptr(rstd64), B, Cout, P, int(ctx.relu),
+                                          ptr(part), stream_ptr()), "l3d_bn_backward_stats")
+        local = sum_clouds(part)                                         # this rank's (sum g, sum g zhat): the parameter gradients
+        zero = torch.zeros(Cout, dtype=torch.float64, device=z.device)
+        if ctx.batch_stats:
+            tot = sum_clouds(gather_cloud_partials(part)) if ctx.sync else local
+            m1, m2 = (tot[:, 0] / ctx.n).contiguous(), (tot[:, 1] / ctx.n).contiguous()
+        else:
+            m1 = m2 = zero
         dz = torch.empty_like(z)
-        check(lib().l3d_bn_act_backward(ptr(dy), ptr(z), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), ptr(gr), ptr(m1), ptr(m2), B, Cout, P,
-                                        int(ctx.relu), ptr(dz), stream_ptr()), "l3d_bn_act_backward")
-        dx = dw = None
+        check(lib().l3d_bn_act_backward(ptr(dy), ptr(z), ptr(scale), ptr(shift), ptr(mean64), ptr(rstd64), ptr(gr64), ptr(m1), ptr(m2),
+                                        B, Cout, P, int(ctx.relu), ptr(dz), stream_ptr()), "l3d_bn_act_backward")
+        dx = dw = dbias = dgamma = dbeta = None
         if ctx.needs_input_grad[0]:
             dx = _fused.pointwise_conv(dz, w.t().contiguous())           # dgrad: [B, Cin, P]
         if ctx.needs_input_grad[1]:
-            # wgrad: dW = sum_b dz_b [Cout, P] x_b^T [P, Cin]; per cloud the points are the GEMM's K axis: x_b is a
-            # "channel-last" [N' = Cin, K' = P] operand and dz_b the [Cout, K'] weight of the same kernel
-            acc = torch.zeros((Cout, Cin), dtype=torch.float32, device=z.device)
-            for b in range(B):
-                acc = acc + _fused.pointwise_conv(x[b:b + 1], dz[b], channel_last=True, split=False)[0]
-            dw = acc.reshape(ctx.wshape)
-        return dx, dw, (dgamma if ctx.needs_input_grad[2] else None), (dbeta if ctx.needs_input_grad[3] else None), None, None, None
+            dw = wgrad(dz, x).reshape(ctx.wshape)
+        if ctx.needs_input_grad[2]:
+            # batch statistics: a bias in front of BatchNorm cancels; else d/dbias = sum_p dz = gr * sum g
+            dbias = torch.zeros(Cout, dtype=torch.float32, device=z.device) if ctx.batch_stats else (gr64 * local[:, 0]).float()
+        if ctx.has_bn and ctx.needs_input_grad[3]:
+            dgamma = local[:, 1].float()
+        if ctx.has_bn and ctx.needs_input_grad[4]:
+            dbeta = local[:, 0].float()
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None
 
 
-def conv_bn_act(x, conv, bn, relu=True, sync=None):
-    """Conv(1x1, no bias or bias folded into BN: a bias before BatchNorm cancels) -> BatchNorm (batch statistics) -> ReLU
-    for x [B, Cin, P] or [B, Cin, N, K]; returns the same rank as x.  sync: share the statistics across ranks
-    (default: whenever torch.distributed is initialised with more than one rank)."""
+def conv_bn_act(x, conv, bn=None, relu=True, sync=None):
+    """1x1 Conv1d / Conv2d or Linear-shaped module `conv` (weight [Cout,Cin,...], optional bias) -> optional BatchNorm `bn`
+    (batch statistics in train mode, running statistics in eval mode) -> optional ReLU, for x [B, Cin, P] or [B, Cin, N, K];
+    returns the same rank as x.  sync: share batch statistics across ranks (default: whenever torch.distributed is initialised
+    with more than one rank)."""
     if sync is None:
         sync = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    batch_stats = bn is not None and (bn.training or not bn.track_running_stats or bn.running_mean is None)
     shp = x.shape
     x3 = x.reshape(shp[0], shp[1], -1)
-    y = _ConvBNActTrain.apply(x3, conv.weight, bn.weight, bn.bias, bn, relu, sync)
+    y = _ConvAffineAct.apply(x3, conv.weight, conv.bias, bn.weight if bn is not None else None,
+                             bn.bias if bn is not None else None, bn, relu, batch_stats, sync and batch_stats)
     return y.reshape(shp[0], y.shape[1], *shp[2:])
+
+
+def linear_act(x, lin, relu=False):
+    """nn.Linear over the last axis of x [..., Cin] (+ ReLU) through the same Function: the rows are the points of one cloud."""
+    shp = x.shape
+    x3 = x.reshape(-1, shp[-1]).t().unsqueeze(0)                          # [1, Cin, rows] (made contiguous by the Function)
+    y = _ConvAffineAct.apply(x3, lin.weight, lin.bias, None, None, None, relu, False, False)
+    return y[0].t().reshape(*shp[:-1], y.shape[1])
+
+
+def hip_layers_ok(x):
+    """the HIP differentiable layers apply: fp32 tensors on the GPU, switched on (_fused.TRAIN_HIP)"""
+    return _fused.TRAIN_HIP and x.is_cuda and x.dtype == torch.float32

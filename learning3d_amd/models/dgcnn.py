@@ -1,9 +1,10 @@
 """Drop-in for learning3d/models/dgcnn.py on MI355X (reference: models/dgcnn.py:6-49).
 
 Same constructor, attribute / parameter names (state_dict compatible) and output layout.
-Inference (eval + no grad): 3 launches -- fused kNN graph, fused 4-layer EdgeConv stack on fp32 MFMA
-(activations never leave the CU), conv5 as an MFMA GEMM writing [B, emb, N].
-Training: HIP kNN + graph-feature gather, convs/BN through torch (batch statistics)."""
+Eval-mode BatchNorm (whatever the grad mode -- the reference's scripts never use no_grad): 3 launches -- fused kNN graph,
+fused 4-layer EdgeConv stack on the matrix cores (activations never leave the CU), conv5 as an MFMA GEMM writing [B, emb, N];
+a backward through it recomputes the layers on the HIP conv / dgrad / wgrad kernels (_fused.checkpointed).
+Train-mode BatchNorm: HIP kNN + graph-feature gather, HIP conv + batch statistics per layer (_train.py)."""
 import torch
 import torch.nn.functional as F
 
@@ -43,62 +44,79 @@ class DGCNN(torch.nn.Module):
             self._c5key = key
         return self._c5
 
+    def _pooled_route(self, num_points):
+        return (_fused.gemm_arith() == "f16x2" and _fused.EDGECONV_KERNEL in (None, "f16") and _fused.SPLIT_BF16
+                and _fused.f16_eligible(512, self.emb_dims, num_points))
+
     def forward_pooled(self, input_data):
         """max over the points of forward()'s [B,emb,N] output -> [B,emb] (what models/classifier.py:23 computes next), with the
         maximum taken in conv5's epilogue on the f16x2 route: the feature map is never written.  None if that route does not
         apply (the caller then pools forward()'s output)."""
-        return self.forward(input_data, _pooled=True)
+        n = input_data.shape[1] if self.input_shape == "bnc" else input_data.shape[2]
+        if (not input_data.is_cuda or _fused._stochastic_or_batch_dependent(self) or not self._pooled_route(n)):
+            return None
+        return _fused.checkpointed(self, self._forward_pooled, input_data)
 
-    def forward(self, input_data, _pooled=False):
+    def forward(self, input_data):
+        return _fused.checkpointed(self, self._forward, input_data)
+
+    def _forward_pooled(self, input_data):
+        return self._forward(input_data, _pooled=True)
+
+    def _fused_forward(self, input_data, _pooled):
+        """kNN -> EdgeConv stack -> conv5 as 3 launches under the arithmetic _fused.gemm_arith() names"""
+        batch_size, _, num_points = input_data.size()
+        w5, s5, b5, w5_split, w5_f16 = self._conv5_folded()
+        f16_route = (_fused.gemm_arith() == "f16x2" and _fused.EDGECONV_KERNEL in (None, "f16") and w5_f16 is not None
+                     and _fused.f16_eligible(512, self.emb_dims, num_points))
+        xyz = _as_bn3(input_data)                                   # [B,N,3] (no copy for "bnc")
+        with _fused.stage("knn"):
+            idx = knn(input_data, k=20)                             # dgcnn.py:32 (k=20 default)
+        packed = self._packed.get([self.conv1, self.conv2, self.conv3, self.conv4],
+                                  [self.bn1, self.bn2, self.bn3, self.bn4], xyz.device)
+        if f16_route:
+            # f16x2 route: the EdgeConv kernel hands conv5 its input already split into fp16 planes (no fp32 pooled
+            # tensor, no split pass); the EdgeConv kernel watches the fp16 range (_fused.run_guarded reads its verdict)
+            with _fused.stage("edgeconv"):
+                pooled_img = _fused.edgeconv_forward(xyz, idx, packed, planes=True)         # dgcnn.py:34-46
+            with _fused.stage("conv5"):
+                if _pooled:
+                    return _fused.pointwise_conv_f16_pool(pooled_img, batch_size, num_points, w5_f16, 512, self.emb_dims,
+                                                          s5, b5, relu=True)[1]
+                return _fused.pointwise_conv_f16(pooled_img, batch_size, num_points, w5_f16, 512, self.emb_dims,
+                                                 s5, b5, relu=True)                         # dgcnn.py:48
+        with _fused.stage("edgeconv"):
+            pooled = _fused.edgeconv_forward(xyz, idx, packed)      # dgcnn.py:34-46
+        with _fused.stage("conv5"):
+            out = _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True,
+                                        w_split=w5_split)                                   # dgcnn.py:48
+        return out.max(dim=2)[0] if _pooled else out
+
+    def _forward(self, input_data, _pooled=False):
         if self.input_shape == "bnc":
             input_data = input_data.permute(0, 2, 1)
         if input_data.shape[1] != 3:
             raise RuntimeError("shape of x must be of [Batch x 3 x NumInPoints]")
         batch_size, num_dims, num_points = input_data.size()
 
-        if _fused.can_fuse(self, input_data):
-            w5, s5, b5, w5_split, w5_f16 = self._conv5_folded()
-            f16_route = (_fused.gemm_arith() == "f16x2" and _fused.EDGECONV_KERNEL in (None, "f16") and w5_f16 is not None
-                         and _fused.f16_eligible(512, self.emb_dims, num_points))
-            if _pooled and not f16_route:
-                return None
-            xyz = _as_bn3(input_data)                                   # [B,N,3] (no copy for "bnc")
-            with _fused.stage("knn"):
-                idx = knn(input_data, k=20)                             # dgcnn.py:32 (k=20 default)
-            packed = self._packed.get([self.conv1, self.conv2, self.conv3, self.conv4],
-                                      [self.bn1, self.bn2, self.bn3, self.bn4], xyz.device)
-            if f16_route:
-                # f16x2 route: the EdgeConv kernel hands conv5 its input already split into fp16 planes (no fp32 pooled
-                # tensor, no split pass); both kernels watch the fp16 range (see _fused.check_range)
-                with _fused.stage("edgeconv"):
-                    pooled_img = _fused.edgeconv_forward(xyz, idx, packed, planes=True)         # dgcnn.py:34-46
-                with _fused.stage("conv5"):
-                    if _pooled:
-                        return _fused.pointwise_conv_f16_pool(pooled_img, batch_size, num_points, w5_f16, 512, self.emb_dims,
-                                                              s5, b5, relu=True)[1]
-                    return _fused.pointwise_conv_f16(pooled_img, batch_size, num_points, w5_f16, 512, self.emb_dims,
-                                                     s5, b5, relu=True)                         # dgcnn.py:48
-            with _fused.stage("edgeconv"):
-                pooled = _fused.edgeconv_forward(xyz, idx, packed)      # dgcnn.py:34-46
-            with _fused.stage("conv5"):
-                out = _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True,
-                                            w_split=w5_split)                                   # dgcnn.py:48
-            return out
+        if _fused.can_fuse(self, input_data) and input_data.is_cuda:
+            return _fused.run_guarded(input_data.device, lambda: self._fused_forward(input_data, _pooled))
 
-        if _pooled:
-            return None
         output = get_graph_feature(input_data)
-        if (_fused.TRAIN_HIP and self.training and output.is_cuda and self.conv1.bias is None):
-            # training: conv / dgrad / wgrad on the HIP GEMMs, BatchNorm statistics from per-cloud fp64 partial sums
-            # shared across ranks (_train.py); max over k through torch (its backward is an index scatter)
-            from ._train import conv_bn_act
+        from ._train import conv_bn_act, hip_layers_ok
+        if hip_layers_ok(output) and self.conv1.bias is None:
+            # autograd is live (train-mode BatchNorm, or the backward recomputation of _fused.checkpointed): conv / dgrad /
+            # wgrad on the HIP GEMMs; BatchNorm with per-cloud fp64 partial sums shared across ranks in train mode, its
+            # running statistics in eval mode (_train.py); max over k through torch (its backward is an index scatter)
             output = output.contiguous()
             outs = []
             for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3), (self.conv4, self.bn4)):
                 output = conv_bn_act(output, conv, bn)
                 outs.append(output.max(dim=-1, keepdim=True)[0])
             output = torch.cat(outs, dim=1)
-            return conv_bn_act(output, self.conv5, self.bn5).view(batch_size, -1, num_points)
+            output = conv_bn_act(output, self.conv5, self.bn5).view(batch_size, -1, num_points)
+            return output.max(dim=2)[0] if _pooled else output
+        # CPU tensors / _fused.TRAIN_HIP = False: the reference's op sequence on torch
         output = F.relu(self.bn1(self.conv1(output)))
         output1 = output.max(dim=-1, keepdim=True)[0]
         output = F.relu(self.bn2(self.conv2(output)))
@@ -109,4 +127,4 @@ class DGCNN(torch.nn.Module):
         output4 = output.max(dim=-1, keepdim=True)[0]
         output = torch.cat((output1, output2, output3, output4), dim=1)
         output = F.relu(self.bn5(self.conv5(output))).view(batch_size, -1, num_points)
-        return output
+        return output.max(dim=2)[0] if _pooled else output

@@ -64,8 +64,11 @@ def _mlp_stack(x, convs, bns, module, pool=False, cl_shape=None):
             h = _fused.pointwise_conv(h, w, sc, sh, relu=True, channel_last=cl, w_split=ws)
         h = h.view(shp[0], h.shape[1], *shp[2:])
         return torch.max(h, -1)[0] if pool else h
+    from ._train import conv_bn_act, hip_layers_ok
     for conv, bn in zip(convs, bns):
-        x = F.relu(bn(conv(x)))
+        # autograd is live (train-mode BatchNorm, or the backward recomputation of _fused.checkpointed): HIP conv / dgrad /
+        # wgrad + BatchNorm kernels per layer (_train.py)
+        x = conv_bn_act(x.contiguous(), conv, bn) if hip_layers_ok(x) else F.relu(bn(conv(x)))
     return torch.max(x, -1)[0] if pool else x
 
 
@@ -349,6 +352,10 @@ class FlowNet3D(nn.Module):
         self.conv2 = nn.Conv1d(128, 3, kernel_size=1, bias=True)
 
     def forward(self, pc1, pc2, feature1, feature2):
+        """reference :305-328.  Eval-mode BatchNorm: the fused route in every grad mode (_fused.checkpointed)."""
+        return _fused.checkpointed(self, self._forward, pc1, pc2, feature1, feature2)
+
+    def _forward(self, pc1, pc2, feature1, feature2):
         if (_fused.can_fuse(self, pc1, pc2, feature1, feature2) and pc1.is_cuda and pc1.shape == pc2.shape
                 and feature1.shape == feature2.shape):
             # sa1 / sa2 are applied to BOTH clouds with the same weights (reference :307-310) and every op in them
@@ -375,4 +382,5 @@ class FlowNet3D(nn.Module):
         if _fused.can_fuse(self, x):                  # the 128 -> 3 head on the narrow-head kernel (mlp.hip), not a torch conv
             w, sc, sh = _fused.fold_conv_bn(self.conv2)
             return _fused.pointwise_conv(x, w, sc, sh, relu=False)
-        return self.conv2(x)
+        from ._train import conv_bn_act, hip_layers_ok
+        return conv_bn_act(x.contiguous(), self.conv2, None, relu=False) if hip_layers_ok(x) else self.conv2(x)

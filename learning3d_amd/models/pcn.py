@@ -7,7 +7,9 @@ planes; bf16x3 / fp32 MFMA under L3D_GEMM_ARITH).  Two algebraic fusions remove 
   * fine decoder (:84-101) materialises a [B, 16384, 1029] feature (4.3 GB at B=64) of which 1024
     channels are the same per-cloud vector; conv5 is applied to the 5 varying channels (grid 2 +
     coarse point 3) and W5[:,5:] global_feature goes into the per-cloud shift.
-The FC decoder (3 Linear layers on [B, emb]) stays torch (rocBLAS)."""
+The FC decoder (3 Linear layers on [B, emb]) runs on the same conv kernels with the clouds as the points of one row block.
+With autograd live, forward is still these kernels (_fused.checkpointed); the backward recomputes layer by layer on the HIP
+conv / dgrad / wgrad kernels (_train.py) in the reference's op order."""
 import torch
 
 from . import _fused
@@ -44,12 +46,27 @@ class PCN(torch.nn.Module):
             self.conv6 = torch.nn.Conv1d(512, 512, 1)
             self.conv7 = torch.nn.Conv1d(512, 3, 1)
 
-    # -- reference-order torch path (training / autograd) ------------------------------------------
+    # -- reference-order differentiable path (autograd live: train_pcn.py's loop, or the backward of _fused.checkpointed) ----
+    def _layer(self, conv, x, relu):
+        """Conv1d(k=1) (+ ReLU) on the HIP conv / dgrad / wgrad kernels (_train.py); torch only off the GPU"""
+        from ._train import conv_bn_act, hip_layers_ok
+        if hip_layers_ok(x):
+            return conv_bn_act(x, conv, None, relu=relu)
+        y = conv(x)
+        return self.relu(y) if relu else y
+
+    def _fc(self, lin, x, relu):
+        from ._train import hip_layers_ok, linear_act
+        if hip_layers_ok(x):
+            return linear_act(x, lin, relu=relu)
+        y = lin(x)
+        return self.relu(y) if relu else y
+
     def _encode_torch(self, x):
-        out = self.conv2(self.relu(self.conv1(x)))
+        out = self._layer(self.conv2, self._layer(self.conv1, x, True), False)
         g = self.pooling(out).unsqueeze(2).repeat(1, 1, self.num_points)
         out = torch.cat([out, g], dim=1)
-        out = self.conv4(self.relu(self.conv3(out)))
+        out = self._layer(self.conv4, self._layer(self.conv3, out, True), False)
         return self.pooling(out)
 
     def _grid_center(self, coarse):
@@ -65,7 +82,7 @@ class PCN(torch.nn.Module):
         grid_feature, center = self._grid_center(coarse)
         global_feature = gfeat.unsqueeze(1).repeat([1, self.num_fine, 1])
         feature = torch.cat([grid_feature, center, global_feature], dim=2).permute(0, 2, 1)
-        out = self.conv7(self.relu(self.conv6(self.relu(self.conv5(feature)))))
+        out = self._layer(self.conv7, self._layer(self.conv6, self._layer(self.conv5, feature, True), True), False)
         return out.permute(0, 2, 1) + center
 
     # -- fused inference path ----------------------------------------------------------------------
@@ -144,6 +161,16 @@ class PCN(torch.nn.Module):
         return h.permute(0, 2, 1) + center
 
     def forward(self, input_data):
+        """reference: models/pcn.py:127-153.  The fused kernels serve the forward in every grad mode (PCN has no BatchNorm or
+        dropout, so also under .train(): examples/train_pcn.py:70-91); a backward recomputes through the per-layer HIP route."""
+        outs = _fused.checkpointed(self, self._forward, input_data)
+        self.global_feature_v, self.coarse_output = outs[0], outs[1]
+        result = {'coarse_output': self.coarse_output}
+        if self.detailed_output:
+            result['fine_output'] = outs[2]
+        return result
+
+    def _forward(self, input_data):
         if self.input_shape == "bnc":
             self.num_points = input_data.shape[1]
             input_data = input_data.permute(0, 2, 1)
@@ -152,18 +179,17 @@ class PCN(torch.nn.Module):
         if input_data.shape[1] != 3:
             raise RuntimeError("shape of x must be of [Batch x 3 x NumInPoints]")
 
-        fused = _fused.can_fuse(self, input_data)
-        if fused:
+        if _fused.can_fuse(self, input_data) and input_data.is_cuda:
             cl = self.input_shape == "bnc"
-            self.global_feature_v = self._encode_fused(input_data.permute(0, 2, 1) if cl else input_data, cl)
-        else:
-            self.global_feature_v = self._encode_torch(input_data)
-        out = self.linear3(self.relu(self.linear2(self.relu(self.linear1(self.global_feature_v)))))
-        self.coarse_output = out.view(self.global_feature_v.shape[0], self.num_coarse, 3)
-        result = {'coarse_output': self.coarse_output}
-        if self.detailed_output:
-            if fused:
-                result['fine_output'] = self._fine_fused(self.coarse_output, self.global_feature_v)
-            else:
-                result['fine_output'] = self._fine_torch(self.coarse_output, self.global_feature_v)
-        return result
+            x = input_data.permute(0, 2, 1) if cl else input_data
+
+            def run():
+                g = self._encode_fused(x, cl)
+                lr = _fused.linear_rows                                       # FC decoder (pcn.py:132-137): rows = clouds
+                c = lr(lr(lr(g, self.linear1, True), self.linear2, True), self.linear3).contiguous().view(g.shape[0], self.num_coarse, 3)
+                return (g, c, self._fine_fused(c, g)) if self.detailed_output else (g, c)
+            return _fused.run_guarded(input_data.device, run)
+        g = self._encode_torch(input_data)
+        c = self._fc(self.linear3, self._fc(self.linear2, self._fc(self.linear1, g, True), True), False)
+        c = c.view(g.shape[0], self.num_coarse, 3)
+        return (g, c, self._fine_torch(c, g)) if self.detailed_output else (g, c)

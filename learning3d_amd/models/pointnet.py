@@ -51,10 +51,18 @@ class PointNet(torch.nn.Module):
 
     def forward_pooled(self, input_data):
         """max over the points of forward()'s [B,emb,N] output -> [B,emb] (what models/classifier.py:23 computes next): conv5's
-        kernel takes partial maxima in its epilogue, the feature map is never written.  None when the fused route does not
-        apply (training, autograd, global_feat=False); the caller then pools forward()'s output."""
-        if not self.global_feat or not _fused.can_fuse(self, input_data) or not input_data.is_cuda:
+        kernel takes partial maxima in its epilogue, the feature map is never written.  None when this route does not
+        apply (batch statistics, global_feat=False); the caller then pools forward()'s output."""
+        if not self.global_feat or not input_data.is_cuda or _fused._stochastic_or_batch_dependent(self):
             return None
+        return _fused.checkpointed(self, self._forward_pooled, input_data)
+
+    def forward(self, input_data):
+        return _fused.checkpointed(self, self._forward, input_data)
+
+    def _forward_pooled(self, input_data):
+        if not _fused.can_fuse(self, input_data):
+            return self._forward(input_data).max(dim=2)[0]
         channel_last = self.input_shape == "bnc"
         if input_data.shape[2 if channel_last else 1] != 3:
             raise RuntimeError("shape of x must be of [Batch x 3 x NumInPoints]")
@@ -66,7 +74,7 @@ class PointNet(torch.nn.Module):
                 return _fused.conv_global_max(x, w, sc, sh, True)
             x = _fused.pointwise_conv(x, w, sc, sh, relu=True, channel_last=(channel_last and i == 0))
 
-    def forward(self, input_data):
+    def _forward(self, input_data):
         if self.input_shape == "bnc":
             num_points = input_data.shape[1]
             input_data = input_data.permute(0, 2, 1)
@@ -76,7 +84,7 @@ class PointNet(torch.nn.Module):
             raise RuntimeError("shape of x must be of [Batch x 3 x NumInPoints]")
 
         output = input_data
-        if _fused.can_fuse(self, input_data):
+        if _fused.can_fuse(self, input_data) and input_data.is_cuda:
             # "bnc" input is consumed channel-last directly (no transpose copy)
             channel_last = self.input_shape == "bnc"
             x = input_data.permute(0, 2, 1) if channel_last else input_data
@@ -92,10 +100,23 @@ class PointNet(torch.nn.Module):
                     point_feature = x
             output = x
         else:
-            for idx, layer in enumerate(self.layers):
-                output = layer(output)
-                if idx == 1 and not self.global_feat:
-                    point_feature = output
+            from ._train import conv_bn_act, hip_layers_ok
+            if hip_layers_ok(input_data):
+                # autograd is live: every layer on the HIP conv / dgrad / wgrad kernels (_train.py), BatchNorm with batch
+                # statistics in train mode and running statistics in eval mode
+                for i, (conv, bn) in enumerate(self._stack()):
+                    if i == 0 and not self.global_feat and self.use_bn:
+                        point_feature = conv_bn_act(output, conv, bn, relu=False)       # layers[1] = bn1 (pointnet.py:66)
+                        output = torch.relu(point_feature)
+                        continue
+                    output = conv_bn_act(output, conv, bn, relu=True)
+                    if i == 0 and not self.global_feat:
+                        point_feature = output                                          # layers[1] = the ReLU
+            else:
+                for idx, layer in enumerate(self.layers):
+                    output = layer(output)
+                    if idx == 1 and not self.global_feat:
+                        point_feature = output
 
         if self.global_feat:
             return output

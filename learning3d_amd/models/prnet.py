@@ -63,6 +63,9 @@ class DGCNN(torch.nn.Module):
         return hit[1:]
 
     def forward(self, x):
+        return _fused.checkpointed(self, self._forward, x)
+
+    def _forward(self, x):
         batch_size, num_dims, num_points = x.size()
         if _fused.can_fuse(self, x) and x.is_cuda:
             B, N = batch_size, num_points
@@ -86,7 +89,16 @@ class DGCNN(torch.nn.Module):
             with _fused.stage("conv5"):
                 return _fused.pointwise_conv(cat, w5, None, t5, relu=ACT_LRELU, w_split=w5_split)
 
-        # reference op sequence (prnet.py:76-97)
+        # reference op sequence (prnet.py:76-97); with autograd live on the GPU each Conv2d + BatchNorm + LeakyReLU is the HIP
+        # conv / dgrad / wgrad + BatchNorm layer of _train.py
+        from ._train import conv_bn_act, hip_layers_ok
+        if hip_layers_ok(x):
+            xs = []
+            for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3), (self.conv4, self.bn4)):
+                x = conv_bn_act(get_graph_feature(x).contiguous(), conv, bn, relu=ACT_LRELU).max(dim=-1, keepdim=True)[0]
+                xs.append(x)
+            x = conv_bn_act(torch.cat(xs, dim=1), self.conv5, self.bn5, relu=ACT_LRELU)
+            return x.view(batch_size, -1, num_points)
         x = get_graph_feature(x)
         x = F.leaky_relu(self.bn1(self.conv1(x)), negative_slope=NEG_SLOPE)
         x1 = x.max(dim=-1, keepdim=True)[0]

@@ -118,6 +118,12 @@ class SVDHead(nn.Module):
         self.input_shape = input_shape
 
     def forward(self, *input):
+        """Flash-style soft correspondences + Kabsch kernel in every grad mode; a backward recomputes the score matrix route
+        below and the analytic Kabsch backward (_fused.checkpointed)."""
+        from ..models import _fused
+        return _fused.checkpointed(self, self._forward, input[0], input[1], input[2], input[3])
+
+    def _forward(self, *input):
         src_embedding, tgt_embedding, src, tgt = input[0], input[1], input[2], input[3]
         batch_size = src.size(0)
         if self.input_shape == "bnc":

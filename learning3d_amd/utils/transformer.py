@@ -380,6 +380,12 @@ class Transformer(nn.Module):
                                     nn.Sequential(), nn.Sequential(), nn.Sequential())
 
     def forward(self, *input):
+        """The fused pointer network serves the forward in every grad mode (dropout is None throughout, reference :163-217);
+        a backward recomputes through the reference's op sequence (_fused.checkpointed)."""
+        from ..models import _fused
+        return _fused.checkpointed(self, self._forward, input[0], input[1])
+
+    def _forward(self, *input):
         src = input[0].transpose(2, 1).contiguous()
         tgt = input[1].transpose(2, 1).contiguous()
         tgt_embedding = self.model(src, tgt, None, None).transpose(2, 1).contiguous()

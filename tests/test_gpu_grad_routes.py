@@ -1,0 +1,361 @@
+"""Which route a reference user gets, and that gradients through it are right.
+
+The reference's scripts run `model.eval()` with grad mode ON and never use torch.no_grad() (examples/test_pointnet.py:31-60,
+examples/test_dcp.py:43-73, examples/test_pcn.py); examples/train_pcn.py:70-91 trains a network without BatchNorm.  These
+tests drive the models exactly like that and assert (1) through the C-ABI launch log that the fused matrix-core kernels
+served the forward, (2) outputs equal the no_grad results and the reference goldens, (3) `.backward()` gradients against an
+fp64 evaluation of the reference's op sequence, (4) an fp16-range overflow is repaired inside the same call.
+Tolerances are written where they are applied."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+
+
+def rand(shape, seed, lo=0.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * (hi - lo) + lo).numpy()
+
+
+class launch_log:
+    def __enter__(self):
+        from learning3d_amd import _lib
+        self.lib = _lib
+        _lib.LAUNCH_LOG = []
+        return _lib.LAUNCH_LOG
+
+    def __exit__(self, *exc):
+        self.lib.LAUNCH_LOG = None
+        return False
+
+
+def _load(net, g):
+    sd = {k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("w.")}
+    net.load_state_dict(sd)
+    return net.cuda().eval()
+
+
+def _rel(a, b):
+    """max |a - b| over the scale max |b| (both numpy, b the fp64 truth)"""
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+# --------------------------------------------------------------------------------------------- (1) + (2): the route
+def test_eval_with_grad_enabled_runs_the_fused_kernels_dgcnn(golden):
+    """examples/test_pointnet.py's call pattern on DGCNN: eval(), grad mode on, no no_grad."""
+    from learning3d_amd.models import DGCNN
+    g = golden("dgcnn_emb64")
+    net = _load(DGCNN(emb_dims=64), g)
+    assert torch.is_grad_enabled() and all(p.requires_grad for p in net.parameters())
+    with launch_log() as log:
+        out = net(dev(g["x"]))
+    assert "l3d_knn_graph" in log and any(n.startswith("l3d_edgeconv_forward") for n in log), log
+    assert not any(n in log for n in ("l3d_bn_act_forward", "l3d_graph_feature")), log      # the per-layer route did not run
+    assert out.requires_grad                                                              # and the result is differentiable
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out"], rtol=1e-4, atol=1e-5)
+    with torch.no_grad():
+        assert torch.equal(net(dev(g["x"])), out.detach())
+    # benchmark shape: the f16x2 EdgeConv kernel and the f16x2 conv5 are what runs
+    torch.manual_seed(1)
+    big = DGCNN(emb_dims=1024).cuda().eval()
+    x = dev(rand((4, 1024, 3), 0))
+    with launch_log() as log:
+        y = big(x)
+    assert log.count("l3d_edgeconv_forward_f16") == 1 and log.count("l3d_pointwise_conv_f16") == 1, log
+    with torch.no_grad():
+        assert torch.equal(big(x), y.detach())
+
+
+def test_eval_with_grad_enabled_runs_the_fused_kernels_other_models(golden):
+    from learning3d_amd.models import DCP, DGCNN, PCN, Classifier, PointNet, FlowNet3D
+    # PointNet classifier (config 1's pattern, examples/test_pointnet.py:98-118)
+    torch.manual_seed(2)
+    clf = Classifier(feature_model=PointNet(emb_dims=1024, use_bn=True)).cuda().eval()
+    x = dev(rand((4, 1024, 3), 3, -1, 1))
+    with launch_log() as log:
+        logits = clf(x)
+    assert any(n.startswith("l3d_pointwise_conv") for n in log) and "l3d_bn_act_forward" not in log, log
+    with torch.no_grad():
+        assert torch.equal(clf(x), logits.detach())
+    # PCN, in train() mode as examples/train_pcn.py:70-91 runs it (no BatchNorm, no dropout: the same pure function)
+    torch.manual_seed(3)
+    pcn = PCN(emb_dims=1024, num_coarse=64, grid_size=2, detailed_output=True).cuda().train()
+    xp = dev(rand((2, 512, 3), 4, -0.5, 0.5))
+    with launch_log() as log:
+        out = pcn(xp)
+    assert "l3d_first_layer_f16_planes" in log and "l3d_pointwise_conv_f16_pool" in log and "l3d_fold_mlp_f16" in log, log
+    assert "l3d_bn_act_forward" not in log
+    assert out["fine_output"].requires_grad and pcn.coarse_output is out["coarse_output"]
+    with torch.no_grad():
+        ref = pcn(xp)
+    for k in out:
+        assert torch.equal(out[k].detach(), ref[k]), k
+    # DCP (examples/test_dcp.py:43-73): fused attention + soft correspondences + Kabsch
+    gd = golden("dcp_emb64")
+    dcp = _load(DCP(DGCNN(emb_dims=64)), gd)
+    with launch_log() as log:
+        o = dcp(dev(gd["template"]), dev(gd["source"]))
+    assert "l3d_soft_correspondence" in log and "l3d_kabsch" in log, log
+    np.testing.assert_allclose(o["est_R"].detach().cpu().numpy(), gd["est_R"], atol=1e-5)
+    np.testing.assert_allclose(o["est_t"].detach().cpu().numpy(), gd["est_t"], atol=1e-5)
+    assert o["est_R"].requires_grad
+    o["est_R"].sum().backward()                                          # the whole chain back-propagates
+    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in dcp.parameters())
+    assert dcp.emb_nn.conv1.weight.grad is not None and float(dcp.emb_nn.conv1.weight.grad.abs().max()) > 0
+    # DCP at emb 512 (d_k = 128: the flash attention kernel and the f16x2 Linear layers)
+    torch.manual_seed(4)
+    dcp512 = DCP(DGCNN(emb_dims=512)).cuda().eval()
+    tmpl = dev(rand((2, 256, 3), 5, -0.5, 0.5))
+    src = (tmpl @ dev(np.array([[0.8, -0.6, 0], [0.6, 0.8, 0], [0, 0, 1]], dtype=np.float32)).t() + 0.1).contiguous()
+    with launch_log() as log:
+        o5 = dcp512(tmpl, src)
+    assert any(n.startswith("l3d_attention_forward") for n in log) and "l3d_layernorm_planes" in log, sorted(set(log))
+    with torch.no_grad():
+        r5 = dcp512(tmpl, src)
+    assert torch.equal(o5["est_R"].detach(), r5["est_R"]) and torch.equal(o5["r"].detach(), r5["r"])
+    # FlowNet3D
+    torch.manual_seed(0)
+    fn = FlowNet3D().cuda().eval()
+    gq = torch.Generator().manual_seed(3)
+    pc1 = torch.clamp(torch.randn((2, 3, 2048), generator=gq), -2, 2).cuda()
+    pc2 = (pc1 + 0.05 * torch.randn((2, 3, 2048), generator=gq).cuda()).contiguous()
+    f1, f2 = torch.rand((2, 3, 2048), generator=gq).cuda(), torch.rand((2, 3, 2048), generator=gq).cuda()
+    with launch_log() as log:
+        sf = fn(pc1, pc2, f1, f2)
+    assert "l3d_group_first_layer" in log and "l3d_bn_act_forward" not in log, log
+    with torch.no_grad():
+        assert torch.equal(fn(pc1, pc2, f1, f2), sf.detach())
+
+
+# --------------------------------------------------------------------------------------------- (3): gradients
+def _dgcnn_fp64(net, x):
+    """fp64 evaluation of models/dgcnn.py:25-49 on the HIP kNN graph, torch ops"""
+    from learning3d_amd.utils import knn
+    B, N, _ = x.shape
+    with torch.no_grad():
+        idx = knn(x.permute(0, 2, 1).contiguous(), 20)                       # [B,N,k]
+    n64 = type(net)(emb_dims=net.emb_dims).cuda().double()
+    n64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    n64.train(net.training)
+    x64 = x.double().requires_grad_()
+    nb = torch.gather(x64.unsqueeze(1).expand(B, N, N, 3), 2, idx.unsqueeze(-1).expand(B, N, 20, 3))
+    ce = x64.unsqueeze(2).expand(B, N, 20, 3)
+    h = torch.cat([nb - ce, ce], dim=3).permute(0, 3, 1, 2)
+    outs = []
+    for conv, bn in ((n64.conv1, n64.bn1), (n64.conv2, n64.bn2), (n64.conv3, n64.bn3), (n64.conv4, n64.bn4)):
+        h = F.relu(bn(conv(h)))
+        outs.append(h.max(dim=-1, keepdim=True)[0])
+    out = F.relu(n64.bn5(n64.conv5(torch.cat(outs, dim=1)))).view(B, -1, N)
+    return n64, x64, out
+
+
+def test_eval_backward_matches_fp64_dgcnn():
+    """eval-mode DGCNN, grad on: forward = fused kernels, backward = recomputation on the HIP conv / dgrad / wgrad kernels.
+    Every parameter gradient and the input gradient against fp64: <= 1e-5 of the gradient's scale (max |truth|)."""
+    from learning3d_amd.models import DGCNN
+    torch.manual_seed(21)
+    net = DGCNN(emb_dims=256).cuda().eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.uniform_(-0.2, 0.2); m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5); m.bias.data.uniform_(-0.2, 0.2)
+    x = dev(rand((4, 256, 3), 61)).requires_grad_()
+    w = dev(np.random.default_rng(5).standard_normal((4, 256, 256)).astype(np.float32))
+    with launch_log() as log:
+        out = net(x)
+        assert any(n.startswith("l3d_edgeconv_forward") for n in log)
+        (out * w).sum().backward()
+        assert "l3d_wgrad" in log and "l3d_bn_act_backward" in log, log       # the backward ran on the HIP layer kernels
+    n64, x64, o64 = _dgcnn_fp64(net, x.detach())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), o64.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    (o64 * w.double()).sum().backward()
+    errs = {}
+    for (k, p), (_, q) in zip(net.named_parameters(), n64.named_parameters()):
+        errs[k] = _rel(p.grad.double().cpu().numpy(), q.grad.cpu().numpy())
+    errs["x"] = _rel(x.grad.double().cpu().numpy(), x64.grad.cpu().numpy())
+    print("eval-backward relative errors:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs.values()) <= 1e-5, errs
+
+
+def test_wgrad_kernel_vs_fp64_and_deterministic():
+    """l3d_wgrad (split-K fp32 MFMA, pieces added in fp64) against an fp64 einsum, ragged shapes included; two runs give the
+    same bits.  Bar: 2e-6 of max |dW| (fp32 products, <= 2048-term fp32 partial sums, one final rounding)."""
+    from learning3d_amd.models import _train
+    rng = np.random.default_rng(9)
+    for (B, Cout, Cin, P) in [(4, 64, 6, 5120), (3, 128, 64, 1000), (2, 256, 128, 20480), (5, 100, 37, 333), (1, 1024, 512, 64),
+                              (2, 3, 512, 4096)]:
+        dz = dev(rng.standard_normal((B, Cout, P)).astype(np.float32))
+        x = dev((rng.standard_normal((B, Cin, P)) + 0.5).astype(np.float32))
+        got = _train.wgrad(dz, x)
+        want = torch.einsum("bop,bip->oi", dz.double(), x.double())
+        assert _rel(got.double().cpu().numpy(), want.cpu().numpy()) <= 2e-6, (B, Cout, Cin, P)
+        assert torch.equal(got, _train.wgrad(dz, x))
+        assert torch.equal(_train.wgrad(dz, x, pc=256), _train.wgrad(dz, x, pc=256))
+
+
+def test_conv_layer_eval_bias_and_leaky_variants_vs_fp64():
+    """_train.conv_bn_act in its three statistic modes (batch, running, none), with and without bias, ReLU / LeakyReLU / no
+    activation, and linear_act: outputs and all gradients against fp64 torch.  Bar 1e-5 of each gradient's scale."""
+    from learning3d_amd.models import _train
+    from learning3d_amd.models.prnet import ACT_LRELU
+    torch.manual_seed(31)
+    cases = [("batch", True, 1), ("batch", False, ACT_LRELU), ("running", True, 1), ("running", False, 0), ("none", True, 1),
+             ("none", True, 0), ("none", False, ACT_LRELU)]
+    for (B, Cin, Cout, P) in [(3, 6, 64, 2560), (2, 128, 256, 512), (2, 259, 64, 300)]:
+        for mode, bias, act in cases:
+            conv = torch.nn.Conv1d(Cin, Cout, 1, bias=bias).cuda()
+            bn = None
+            if mode != "none":
+                bn = torch.nn.BatchNorm1d(Cout).cuda()
+                bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.uniform_(-0.3, 0.3)
+                bn.running_mean.uniform_(-0.3, 0.3); bn.running_var.uniform_(0.5, 2.0)
+                bn.train(mode == "batch")
+            c64 = torch.nn.Conv1d(Cin, Cout, 1, bias=bias).cuda().double()
+            c64.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+            b64 = None
+            if bn is not None:
+                b64 = torch.nn.BatchNorm1d(Cout).cuda().double()
+                b64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+                b64.train(mode == "batch")
+            x = (torch.randn(B, Cin, P, device="cuda") * 0.7 + 0.2)
+            go = torch.randn(B, Cout, P, device="cuda")
+            xa, xb = x.clone().requires_grad_(), x.double().requires_grad_()
+            ya = _train.conv_bn_act(xa, conv, bn, relu=act, sync=False)
+            z = c64(xb)
+            z = b64(z) if b64 is not None else z
+            yb = z if act == 0 else (F.relu(z) if act == 1 else F.leaky_relu(z, 0.2))
+            np.testing.assert_allclose(ya.detach().cpu().numpy(), yb.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+            ya.backward(go); yb.backward(go.double())
+            pairs = [("x", xa.grad, xb.grad), ("W", conv.weight.grad, c64.weight.grad)]
+            if bias:
+                pairs.append(("bias", conv.bias.grad, c64.bias.grad))
+            if bn is not None:
+                pairs += [("gamma", bn.weight.grad, b64.weight.grad), ("beta", bn.bias.grad, b64.bias.grad)]
+            for name, a, b in pairs:
+                if mode == "batch" and name == "bias":
+                    assert float(a.abs().max()) <= 1e-4 * float(go.abs().sum())     # cancels in front of batch statistics
+                    continue
+                assert _rel(a.double().cpu().numpy(), b.cpu().numpy()) <= 1e-5, ((B, Cin, Cout, P), mode, bias, act, name,
+                                                                                 _rel(a.double().cpu().numpy(), b.cpu().numpy()))
+            if mode == "batch":
+                np.testing.assert_allclose(bn.running_mean.cpu().numpy(), b64.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
+                np.testing.assert_allclose(bn.running_var.cpu().numpy(), b64.running_var.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    lin = torch.nn.Linear(1024, 192).cuda()
+    l64 = torch.nn.Linear(1024, 192).cuda().double()
+    l64.load_state_dict({k: v.double() for k, v in lin.state_dict().items()})
+    x = torch.randn(7, 1024, device="cuda")
+    xa, xb = x.clone().requires_grad_(), x.double().requires_grad_()
+    ya, yb = _train.linear_act(xa, lin, relu=True), F.relu(l64(xb))
+    np.testing.assert_allclose(ya.detach().cpu().numpy(), yb.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    go = torch.randn(7, 192, device="cuda")
+    ya.backward(go); yb.backward(go.double())
+    for a, b in ((xa.grad, xb.grad), (lin.weight.grad, l64.weight.grad), (lin.bias.grad, l64.bias.grad)):
+        assert _rel(a.double().cpu().numpy(), b.cpu().numpy()) <= 1e-5
+
+
+def test_pcn_training_step_vs_fp64():
+    """examples/train_pcn.py:70-91's step on the HIP path end to end: PCN.train() forward (fused f16x2 kernels) -> Chamfer loss
+    (HIP) -> backward (recomputation on the HIP conv / dgrad / wgrad kernels + the HIP Chamfer backward), against the same
+    step in fp64 torch (reference op order, models/pcn.py:110-153).  Bar: loss 1e-5 relative, every parameter gradient within
+    1e-5 of its scale."""
+    from learning3d_amd.losses import ChamferDistanceLoss
+    from learning3d_amd.models import PCN
+    torch.manual_seed(41)
+    net = PCN(emb_dims=1024, num_coarse=64, grid_size=2, detailed_output=True).cuda().train()
+    x = dev(rand((3, 512, 3), 42, -0.5, 0.5))
+    gt = dev(rand((3, 1024, 3), 43, -0.5, 0.5))
+    with launch_log() as log:
+        out = net(x)
+        loss = ChamferDistanceLoss()(gt, out["fine_output"]) + ChamferDistanceLoss()(gt, out["coarse_output"])
+        loss.backward()
+    assert "l3d_fold_mlp_f16" in log and "l3d_wgrad" in log and "l3d_chamfer_backward" in log, sorted(set(log))
+    n64 = PCN(emb_dims=1024, num_coarse=64, grid_size=2, detailed_output=True).cuda().double()
+    n64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+    x64 = x.double().permute(0, 2, 1)
+    h = n64.conv2(F.relu(n64.conv1(x64)))
+    h = torch.cat([h, h.max(dim=2, keepdim=True)[0].expand(-1, -1, h.shape[2])], dim=1)
+    gfeat = n64.conv4(F.relu(n64.conv3(h))).max(dim=2)[0]
+    coarse = n64.linear3(F.relu(n64.linear2(F.relu(n64.linear1(gfeat))))).view(3, 64, 3)
+    n64.num_points = 512
+    fine = n64._fine_torch(coarse, gfeat)
+
+    def cd64(a, b):
+        d = torch.cdist(a, b) ** 2
+        return 0.5 * (d.min(dim=2)[0].sqrt().mean() + d.min(dim=1)[0].sqrt().mean())
+    loss64 = cd64(gt.double(), fine) + cd64(gt.double(), coarse)
+    loss64.backward()
+    assert abs(float(loss) - float(loss64)) <= 1e-5 * abs(float(loss64))
+    errs = {k: _rel(p.grad.double().cpu().numpy(), q.grad.cpu().numpy())
+            for (k, p), (_, q) in zip(net.named_parameters(), n64.named_parameters())}
+    print("PCN training-step relative gradient errors:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs.values()) <= 1e-5, errs
+
+
+def test_pointnet_eval_and_train_backward_vs_fp64():
+    """PointNet (models/pointnet.py:51-73), with and without BatchNorm, eval and train: gradients through the HIP layers against
+    fp64.  Bar 1e-5 of each gradient's scale."""
+    from learning3d_amd.models import PointNet
+    for use_bn, training in ((False, False), (True, False), (True, True)):
+        torch.manual_seed(51)
+        net = PointNet(emb_dims=256, use_bn=use_bn).cuda()
+        if use_bn:
+            for m in net.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.running_mean.uniform_(-0.2, 0.2); m.running_var.uniform_(0.5, 1.5)
+        net.train(training)
+        n64 = PointNet(emb_dims=256, use_bn=use_bn).double().cuda()
+        n64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in net.state_dict().items()})
+        n64.train(training)
+        x = dev(rand((4, 512, 3), 52, -1, 1))
+        w = dev(np.random.default_rng(6).standard_normal((4, 256, 512)).astype(np.float32))
+        out = net(x)
+        (out * w).sum().backward()
+        h = x.double().permute(0, 2, 1)
+        for layer in n64.layers:
+            h = layer(h)
+        (h * w.double()).sum().backward()
+        np.testing.assert_allclose(out.detach().cpu().numpy(), h.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+        errs = {k: _rel(p.grad.double().cpu().numpy(), q.grad.cpu().numpy())
+                for (k, p), (_, q) in zip(net.named_parameters(), n64.named_parameters())}
+        assert max(errs.values()) <= 1e-5, (use_bn, training, errs)
+
+
+# --------------------------------------------------------------------------------------------- (4): fp16 range
+def test_f16_overflow_is_repaired_inside_the_same_call():
+    """Unnormalised clouds (coordinates ~1e4) under eval BatchNorm overflow the f16x2 EdgeConv kernel's static exponents.  The
+    first call already returns the right features (re-run on bf16x3 inside the call), like the reference for any input
+    scale; "raise" turns the same event into L3DRangeError; "async" leaves it to check_range."""
+    from learning3d_amd.models import DGCNN, _fused
+    torch.manual_seed(71)
+    net = DGCNN(emb_dims=256).cuda().eval()
+    x = dev(rand((2, 256, 3), 72)) * 3.0e4
+    assert _fused.gemm_arith() == "f16x2" and _fused.RANGE_POLICY == "retry"
+    before = _fused.RANGE_RETRIES
+    with torch.no_grad():
+        out = net(x)
+        torch.cuda.synchronize()
+        assert _fused.RANGE_RETRIES == before + 1, "the overflow was not detected in the call that caused it"
+        with _fused.arith("bf16x3"):
+            want = net(x)
+        assert torch.equal(out, want)
+        _, _, o64 = _dgcnn_fp64(net, x)
+        np.testing.assert_allclose(out.cpu().numpy(), o64.detach().cpu().numpy(), rtol=1e-4, atol=1e-5 * float(o64.abs().max()))
+        _fused.check_range(sync=True)                                   # nothing left behind
+        small = net(dev(rand((2, 256, 3), 73)))                         # in-range input: no retry
+        assert _fused.RANGE_RETRIES == before + 1 and torch.isfinite(small).all()
+        _fused.RANGE_POLICY = "raise"
+        try:
+            with pytest.raises(_fused.L3DRangeError):
+                net(x)
+        finally:
+            _fused.RANGE_POLICY = "retry"
+        _fused.check_range(sync=True)
+    # grad mode on: the same repair inside the checkpointed forward
+    out2 = net(x)
+    assert torch.equal(out2.detach(), out) and _fused.RANGE_RETRIES == before + 2

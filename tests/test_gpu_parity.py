@@ -397,10 +397,14 @@ def test_dgcnn_golden(golden):
         out = net(dev(g["x"]))
     assert out.shape == (2, 64, 128)
     np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-4, atol=1e-5)
-    # the autograd / train-capable route (HIP graph feature + torch convs) agrees too
+    # the differentiable per-layer route (HIP graph feature + HIP conv / BatchNorm layers; what a backward recomputes) agrees too
+    from learning3d_amd.models import _fused
     x = dev(g["x"]).requires_grad_()
-    out2 = net(x)
+    with _fused.per_layer_route():
+        out2 = net(x)
     np.testing.assert_allclose(out2.detach().cpu().numpy(), g["out"], rtol=1e-4, atol=1e-5)
+    # and with grad mode on (the reference's own call pattern) the forward is the fused one, bit for bit
+    assert torch.equal(net(dev(g["x"])).detach(), out)
 
 
 def test_graph_feature_backward_matches_torch_indexing():
@@ -436,8 +440,10 @@ def test_prnet_dgcnn_dynamic_graphs_golden(golden):
         out = net(dev(g["x"]))
     assert out.shape == (2, 64, 128)
     np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-4, atol=2e-5)
+    from learning3d_amd.models import _fused
     x = dev(g["x"]).requires_grad_()
-    out2 = net(x)
+    with _fused.per_layer_route():
+        out2 = net(x)
     np.testing.assert_allclose(out2.detach().cpu().numpy(), g["out"], rtol=1e-4, atol=2e-5)
     out2.sum().backward()
     assert x.grad is not None and torch.isfinite(x.grad).all()
@@ -450,7 +456,8 @@ def test_prnet_dgcnn_dynamic_graphs_golden(golden):
     xb = dev(rand((2, 3, 1024), 31))
     with torch.no_grad():
         fused = big(xb)
-    ref = big(xb.clone().requires_grad_()).detach()
+    with _fused.per_layer_route():
+        ref = big(xb.clone().requires_grad_()).detach()
     # a neighbour swapped at a rounding-level tie changes a max over k only where that neighbour won it
     bad = (fused - ref).abs() > 1e-4 + 1e-4 * ref.abs()
     assert bad.float().mean().item() < 1e-3, bad.float().mean().item()
@@ -806,7 +813,9 @@ def test_pcn_fused_matches_reference_order_path():
     x = dev(rand((2, 300, 3), 4, -0.5, 0.5))
     with torch.no_grad():
         fused = net(x)
-    ref = net(x.clone().requires_grad_())            # autograd route = the reference's op order in torch
+    from learning3d_amd.models import _fused
+    with _fused.per_layer_route():
+        ref = net(x.clone().requires_grad_())        # per-layer differentiable route = the reference's op order
     for k in ("coarse_output", "fine_output"):
         np.testing.assert_allclose(fused[k].cpu().numpy(), ref[k].detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
 
@@ -1090,8 +1099,10 @@ def test_flownet3d_forward_runs():
     with torch.no_grad():
         sf = net(pc1, pc2, f1, f2)
     assert sf.shape == (2, 3, 2048) and torch.isfinite(sf).all()
-    # fused (inference) and torch-conv (autograd) routes agree
-    sf2 = net(pc1, pc2, f1.clone().requires_grad_(), f2)
+    # fused and per-layer differentiable routes agree
+    from learning3d_amd.models import _fused
+    with _fused.per_layer_route():
+        sf2 = net(pc1, pc2, f1.clone().requires_grad_(), f2)
     np.testing.assert_allclose(sf.cpu().numpy(), sf2.detach().cpu().numpy(), rtol=2e-3, atol=2e-4)
 
 
@@ -1172,7 +1183,9 @@ def test_pcn_reference_golden(golden):
     x = dev(g["x"])
     with torch.no_grad():
         fused = net(x)
-    ref_route = net(x.clone().requires_grad_())
+    from learning3d_amd.models import _fused
+    with _fused.per_layer_route():
+        ref_route = net(x.clone().requires_grad_())
     for k in ("coarse_output", "fine_output"):
         np.testing.assert_allclose(fused[k].cpu().numpy(), g[k], rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(ref_route[k].detach().cpu().numpy(), g[k], rtol=1e-4, atol=1e-5)
@@ -1391,9 +1404,11 @@ def test_dgcnn_training_step_hip_path_matches_torch_path():
     """DGCNN in .train(): one forward + backward through the HIP training path (_fused.TRAIN_HIP) and through torch's
     fp32 convs / BatchNorm, both on top of the HIP kNN + graph-feature kernels, judged against the same step in fp64
     (torch double on the same graph): loss, every parameter gradient, running statistics.  BatchNorm's backward
-    cancels (g - mean g - zhat mean(g zhat)), so fp32 implementations differ from each other at ~1e-3 of the gradient
-    scale after five layers; the bar is the fp64 truth: the HIP path may be at most 3x as far from it as torch's fp32, or
-    3e-3 of the gradient's scale where torch happens to be more accurate than that."""
+    cancels (g - mean g - zhat mean(g zhat)) and the weight gradient then sums dz x over all points: an fp32-rounded mean is a
+    systematic error multiplied by the point count (round 2's HIP path sat at 7.2e-4 of the gradient scale for conv1.weight,
+    torch's own fp32 anywhere from 1.8e-6 to 1.0e-3 depending on the solver MIOpen picks).  The backward kernels now carry the
+    per-channel constants in fp64 and the weight gradient adds its split-K pieces in fp64: the bar is the tier's 1e-5 of each
+    gradient's scale, against the fp64 truth, whatever torch's fp32 does on the box."""
     from learning3d_amd.models import DGCNN, _fused
     import torch.nn.functional as F
     torch.manual_seed(12)
@@ -1429,10 +1444,8 @@ def test_dgcnn_training_step_hip_path_matches_torch_path():
         scale = np.abs(truth[1][k]).max()
         e_hip = np.abs(res["hip"][1][k] - truth[1][k]).max()
         e_t32 = np.abs(res["torch32"][1][k] - truth[1][k]).max()
-        # torch's own fp32 error is not a stable yardstick: MIOpen picks its backward solver per box / per run (measured for
-        # conv1.weight: 1.8e-6 of the gradient scale on one box, 1.0e-3 on another, the HIP path 7.2e-4 on both, bit-identical
-        # run to run), so the bar is 3x torch's error OR 3e-3 of the gradient scale, whichever is larger
-        assert e_hip <= max(3.0 * e_t32, 3e-3 * scale), (k, e_hip, e_t32, scale)
+        print(f"{k:14s} hip {e_hip / scale:.2e}  torch32 {e_t32 / scale:.2e}  (of the gradient scale)")
+        assert e_hip <= 1e-5 * scale, (k, e_hip, e_t32, scale)
     for k in truth[2]:
         np.testing.assert_allclose(res["hip"][2][k], truth[2][k], rtol=1e-5, atol=1e-6, err_msg=k)
 
@@ -1760,7 +1773,8 @@ def test_pcn_encoder_f16_chain_matches_reference_order_path():
             fused = net(x)
             gf = net.global_feature_v.clone()
         assert "conv4" in net.__dict__.get("_w_f16_cache", {}), "the f16x2 chain did not run"
-        ref = net(x.clone().requires_grad_())
+        with _fused.per_layer_route():
+            ref = net(x.clone().requires_grad_())
         gr = net.global_feature_v.detach()
         xd = (x if shape == "bcn" else x.permute(0, 2, 1)).double().cpu()
         p = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}
@@ -1978,4 +1992,9 @@ def test_classifier_pools_inside_the_feature_models_last_conv():
             logits = model(x)
             ref = model.linear3(torch.relu(model.bn2(model.linear2(torch.relu(model.bn1(model.linear1(want)))))))
             assert torch.equal(logits, ref)
-        assert fm.forward_pooled(x.clone().requires_grad_()) is None          # autograd route: the Classifier pools itself
+        # grad mode on (the reference's scripts never use no_grad): the same fused route, and it is differentiable
+        xg = x.clone().requires_grad_()
+        pooled_g = fm.forward_pooled(xg)
+        assert pooled_g is not None and torch.equal(pooled_g.detach(), pooled)
+        pooled_g.sum().backward()
+        assert torch.isfinite(xg.grad).all() and float(xg.grad.abs().max()) > 0
