@@ -49,7 +49,7 @@ def pmc_record(tag):
     """What the committed rocprofv3 PMC passes measured for one kernel (profiles/round2_traffic.json, produced on the
     GPU box by tools/pmc.sh + tools/traffic_json.py; bench.py cannot run rocprofv3 on itself, so this is the measured
     figure of the same kernel at the same shapes).  {} if not collected."""
-    for name in ("round2_traffic.json", "round1_traffic.json"):
+    for name in ("round3_traffic.json", "round2_traffic.json", "round1_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f).get(tag)
@@ -199,12 +199,165 @@ def selftest_cpu(args, parallel, dist):
         dist.barrier()
         dist.destroy_process_group()
 
+# ----------------------------------------------------------------------------------------------------------------------
+# --workload c5: BASELINE configs[4] -- FlowNet3D's first set-conv layer (models/flownet3d.py:93-123, :293), the one config
+# north_star shards: B = 256 at 8 GPUs = 32 clouds per GPU, N = 8192, npoint 1024, radius 0.5, nsample 16, mlp 32/32/64.
+C5_N, C5_S, C5_K, C5_R, C5_MLP = 8192, 1024, 16, 0.5, (32, 32, 64)
+# SURVEY.md 8(d), grouping c5 per GPU: idx 2 097 152 + gathered reads 12 582 912 + out [32,6,1024,16] 12 582 912 B
+C5_GROUP_BYTES_PER_CLOUD = C5_S * C5_K * 4 + 2 * 6 * C5_S * C5_K * 4                    # 851 968 B  (x 32 = 27 262 976)
+C5_MLP_FLOP_PER_CLOUD = C5_S * C5_K * 2 * (6 * 32 + 32 * 32 + 32 * 64)
+
+
+def c5_cpu_baseline(sample_clouds=4, repeats=1):
+    """oracle.set_abstraction_forward_torch (C restatements of the reference's FPS / ball query / grouping kernels + torch-CPU
+    conv / BatchNorm ops, the composition pinned by tests/golden/flownet3d_sa1_c5.npz) on this box's host cores."""
+    import oracle
+    from learning3d_amd.models import PointNetSetAbstraction
+    torch.manual_seed(1)
+    sa = PointNetSetAbstraction(npoint=C5_S, radius=C5_R, nsample=C5_K, in_channel=3, mlp=list(C5_MLP), group_all=False).eval()
+    w = {k: v.numpy() for k, v in sa.state_dict().items()}
+    g = torch.Generator().manual_seed(0)
+    xyz = torch.clamp(torch.randn((sample_clouds, 3, C5_N), generator=g), -2, 2).numpy()
+    feat = torch.rand((sample_clouds, 3, C5_N), generator=g).numpy()
+    nthr = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(nthr)
+    best = float("inf")
+    for _ in range(1 + repeats):
+        t0 = time.perf_counter()
+        oracle.set_abstraction_forward_torch(xyz, feat, w, "", C5_S, C5_R, C5_K)
+        best = min(best, time.perf_counter() - t0)
+    return {"value": sample_clouds / best, "unit": "clouds/s", "cores": nthr, "kind": "port", "host_cpus": os.cpu_count(),
+            "cpu_model": cpu_model(),
+            "sample": f"{sample_clouds} clouds x N={C5_N} (sa1: scalar C FPS / ball query / grouping restatements, one core each, + "
+                      f"torch-CPU conv stack on {nthr} threads), min of {1 + repeats} runs"}
+
+
+def main_c5(args, rank, world, local, dev, dist, parallel):
+    from learning3d_amd.models import PointNetSetAbstraction, _fused
+    g = torch.Generator().manual_seed(2000 + rank)
+    xyz = torch.clamp(torch.randn((B_PER_GPU, 3, C5_N), generator=g), -2, 2).to(dev)      # SURVEY 8(d) c5: N(0,1) clipped to [-2,2]
+    feat = torch.rand((B_PER_GPU, 3, C5_N), generator=g).to(dev)
+    torch.manual_seed(1)
+    sa = PointNetSetAbstraction(npoint=C5_S, radius=C5_R, nsample=C5_K, in_channel=3, mlp=list(C5_MLP), group_all=False).to(dev).eval()
+
+    def compute():
+        with torch.no_grad():
+            new_xyz, new_feat = sa(xyz, feat)
+            # the shard's digest (sum, sum of squares, count, centroid checksum): where a training loop's per-shard loss partials go
+            f64 = new_feat.double()
+            part = torch.stack([f64.sum(), (f64 * f64).sum(), f64.new_full((), float(f64.numel())), new_xyz.double().sum()])
+        return new_feat, part
+
+    graph, graph_out = None, None
+
+    def step(eager=False):
+        if graph is not None and not eager:
+            graph.replay()
+            nf, part = graph_out
+        else:
+            nf, part = compute()
+        if world > 1:
+            flat = torch.empty(world * 4, dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(flat, part.clone() if graph is not None and not eager else part)   # 32 B per rank over RCCL
+            return nf, flat.view(world, 4).sum(0)
+        return nf, part
+
+    for _ in range(20):
+        step()
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    compute()
+            torch.cuda.current_stream().wait_stream(side)
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_):
+                graph_out = compute()
+            graph = g_
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+        except Exception as exc:
+            graph = None
+            if rank == 0:
+                print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eager", file=sys.stderr)
+    for _ in range(args.warmup):
+        step()
+
+    def sync():
+        if world > 1:
+            dist.barrier(device_ids=[local])
+        torch.cuda.synchronize()
+
+    timer = _fused.StageTimer(only=("group_kernel", "fps", "ball_query", "mlp"))
+    _fused.TIMER = timer
+    nsamp = max(1, min(8, args.steps // 10))
+    stride = max(1, -(-args.steps // nsamp))
+    sync()
+    t0 = time.perf_counter()
+    digest = None
+    for i in range(args.steps):
+        sampled = i % stride == 0
+        timer.enabled = sampled
+        _, digest = step(eager=sampled)
+    sync()
+    elapsed = time.perf_counter() - t0
+    _fused.TIMER = None
+    stage_ms = timer.mean_ms()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    per_rank = [t.clone() for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank, t)
+    per_rank = torch.stack(per_rank).cpu()
+    elapsed = float(per_rank[:, 0].max())
+    if rank == 0:
+        grp_ms = stage_ms["group_kernel"]
+        grp_gbs = B_PER_GPU * C5_GROUP_BYTES_PER_CLOUD / (grp_ms * 1e-3) / 1e9
+        out = {
+            "metric": "clouds/sec DGCNN-fwd+Chamfer B=32 N=1024; kNN HBM GB/s vs peak at 1/2/4/8 GPU",
+            "value": world * B_PER_GPU * args.steps / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 (index work int32; shared MLP on the fp32 MFMA)", "data": "synthetic",
+            "config": {"workload": "configs[4] (NOT the headline config; --workload c5): FlowNet3D sa1 set-conv forward -- furthest "
+                                   "point sampling 8192 -> 1024, ball query r=0.5 K=16, grouping, shared MLP 6->32->32->64 + max "
+                                   "over K, eval, random-init weights; 32 clouds per GPU, inputs resident in HBM",
+                       "global_batch": world * B_PER_GPU, "num_points": C5_N, "npoint": C5_S, "nsample": C5_K, "radius": C5_R,
+                       "launch": "hipGraph replay" if graph is not None else "eager launches",
+                       "parallelism": f"batch-sharded x{world}, no data-path collective; one 32-byte all_gather of the shard digest per step"},
+            "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "dist_backend": dist.get_backend() if world > 1 else None,
+            "per_rank_ms_per_step": [float(v) / args.steps * 1e3 for v in per_rank[:, 0]],
+            # the one HBM-bound op of the path (SURVEY.md 8(d)): the grouping gather
+            "roofline": {"kernel": "group_concat_kernel", "bound": "hbm", "achieved": grp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": grp_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("group_c5"), "avg_launch_ms": grp_ms,
+                         "algorithmic_bytes_per_launch": B_PER_GPU * C5_GROUP_BYTES_PER_CLOUD,
+                         "note": "13 us of a ~1.2 ms step: the step is bound by furthest point sampling's 1024 dependent rounds "
+                                 "(latency, one workgroup per cloud), see kernels.fps_ms"},
+            "kernels": {"fps_ms": stage_ms.get("fps"), "ball_query_ms": stage_ms.get("ball_query"), "group_ms": grp_ms,
+                        "mlp_ms": stage_ms.get("mlp"),
+                        "mlp_tflops": B_PER_GPU * C5_MLP_FLOP_PER_CLOUD / (stage_ms["mlp"] * 1e-3) / 1e12 if stage_ms.get("mlp") else None,
+                        "fps_pair_evals_per_s": B_PER_GPU * C5_S * C5_N / (stage_ms["fps"] * 1e-3) if stage_ms.get("fps") else None},
+            "digest": [float(v) for v in digest],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = c5_cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local])
+        dist.destroy_process_group()
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--workload", choices=["c2", "c5"], default="c2",
+                    help="c2 (default, the headline): DGCNN forward + Chamfer, 32 clouds x 1024 points per GPU; "
+                         "c5: BASELINE configs[4]'s sharded layer, FlowNet3D sa1 set-conv (FPS + ball query + grouping + "
+                         "3-layer shared MLP), 32 clouds x 8192 points per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-loss", action="store_true",
                     help="N>1: make the blocking exchange the headline (default: pipelined; both are always reported)")
@@ -241,6 +394,17 @@ def main():
     local = local % torch.cuda.device_count()     # a launcher that narrows visibility leaves one device at index 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        # a multi-GPU run is an RCCL run or it is not a measurement: fail before timing anything
+        if dist.get_backend() != "nccl" or dist.get_world_size() != args.gpus:
+            raise SystemExit(f"[bench] expected {args.gpus} RCCL ranks (backend 'nccl'), got backend {dist.get_backend()!r} with "
+                             f"{dist.get_world_size()} ranks")
+        probe = torch.full((1,), float(rank + 1), dtype=torch.float64, device=dev)
+        dist.all_reduce(probe)                                     # one collective over RCCL before anything is timed
+        if abs(float(probe) - world * (world + 1) / 2) > 0:
+            raise SystemExit(f"[bench] RCCL all_reduce probe returned {float(probe)}, expected {world * (world + 1) / 2}")
+    if args.workload == "c5":
+        return main_c5(args, rank, world, local, dev, dist, parallel)
 
     # synthetic, seeded, already resident (weak scaling: 32 clouds per GPU; rank-specific seed)
     g = torch.Generator().manual_seed(1000 + rank)
@@ -313,7 +477,7 @@ def main():
     # for a few hundred milliseconds although every kernel keeps its own duration (two of nine default runs on the last day
     # of round 2).  The K timed steps should measure the steady state, not that transient: a few eager steps give the sum
     # of the kernels' own durations (HIP events around each stage), then probes of 20 replayed steps run until one comes
-    # within 12 % of that sum (at most 12 probes, 0.25 s apart).
+    # within 12 % of that sum (at most 4 probes, 0.25 s apart).
     settle_probes = 0
     if world == 1:
         probe_timer = _fused.StageTimer(only=("knn", "edgeconv_kernel", "conv5", "chamfer"))
@@ -323,7 +487,7 @@ def main():
         torch.cuda.synchronize()
         _fused.TIMER = None
         kernel_sum_ms = sum(probe_timer.mean_ms().values())
-        while settle_probes < 12:
+        while settle_probes < 4:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(20):

@@ -190,12 +190,14 @@ class PointNetSetAbstraction(nn.Module):
     def forward(self, xyz, points):
         xyz_t = xyz.permute(0, 2, 1).contiguous()
         if not self.group_all:
-            fps_idx = pointutils.furthest_point_sample(xyz_t, self.npoint)
+            with _fused.stage("fps"):
+                fps_idx = pointutils.furthest_point_sample(xyz_t, self.npoint)
             new_xyz = pointutils.gather_operation(xyz.contiguous(), fps_idx)          # [B,3,S]
         else:
             new_xyz = xyz
         new_points = self.queryandgroup(xyz_t, new_xyz.transpose(2, 1).contiguous(), points)   # [B,3+D,S,K]
-        return new_xyz, _mlp_stack(new_points, self.mlp_convs, self.mlp_bns, self, pool=True)
+        with _fused.stage("mlp"):
+            return new_xyz, _mlp_stack(new_points, self.mlp_convs, self.mlp_bns, self, pool=True)
 
 
 class FlowEmbedding(nn.Module):

@@ -6,8 +6,13 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import struct
+
 from .._lib import check, f32c, lib, ptr, require_gpu, stream_ptr
 from .model_common_utils import farthest_point_sample, index_points, knn, query_ball_point, square_distance  # noqa: F401
+
+
+_ACT_LRELU = struct.unpack("<i", struct.pack("<f", 0.2))[0]      # activation code of the conv kernels: the LeakyReLU slope's fp32 bits
 
 
 def lpfa_group(xyz, x, idx):
@@ -41,9 +46,18 @@ class LPFA(nn.Module):
             in_channel = out_channel
         self.mlp = nn.Sequential(*mlp)
 
+    def _conv_bn(self, seq, h, act):
+        """Conv2d + BatchNorm2d (+ LeakyReLU 0.2) of one nn.Sequential: with autograd live on the GPU the HIP conv / dgrad /
+        wgrad + BatchNorm layer (models/_train.py), else the torch modules."""
+        from ..models._train import conv_bn_act, hip_layers_ok
+        if torch.is_grad_enabled() and hip_layers_ok(h) and (h.requires_grad or seq[0].weight.requires_grad):
+            return conv_bn_act(h.contiguous(), seq[0], seq[1], relu=(_ACT_LRELU if act else 0))
+        return seq(h)
+
     def forward(self, x, xyz, idx=None):
         x = self.group_feature(x, xyz, idx)
-        x = self.mlp(x)
+        for seq in self.mlp:
+            x = self._conv_bn(seq, x, True)
         return x.max(dim=-1, keepdim=False)[0] if self.initial else x.mean(dim=-1, keepdim=False)
 
     def group_feature(self, x, xyz, idx):
@@ -61,7 +75,7 @@ class LPFA(nn.Module):
                 return geo
             xt = x.transpose(2, 1)
             feat = torch.gather(xt.unsqueeze(1).expand(B, N, N, C), 2, idx.unsqueeze(-1).expand(B, N, self.k, C)) - xt.unsqueeze(2)
-            return F.leaky_relu(feat.permute(0, 3, 1, 2) + self.xyz2feature(geo), 0.2)
+            return F.leaky_relu(feat.permute(0, 3, 1, 2) + self._conv_bn(self.xyz2feature, geo, False), 0.2)
         geo, diff = lpfa_group(xyz, None if self.initial else x, idx)
         if self.initial:
             return geo

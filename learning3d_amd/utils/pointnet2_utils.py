@@ -236,7 +236,9 @@ class QueryAndGroup(nn.Module):
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
 
     def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None):
-        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        from ..models._fused import stage
+        with stage("ball_query"):
+            idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
         needs_grad = torch.is_grad_enabled() and (xyz.requires_grad or (features is not None and features.requires_grad))
         if not needs_grad and (self.use_xyz or features is not None):
             # one pass: gather + centring + concat (no grouped temporaries, no torch.cat copy)
@@ -247,8 +249,10 @@ class QueryAndGroup(nn.Module):
             x_, q_ = f32c(xyz), f32c(new_xyz)
             f_ = f32c(features) if features is not None else None
             out = torch.empty((B, (3 if self.use_xyz else 0) + Cf, S, self.nsample), dtype=torch.float32, device=xyz.device)
-            check(lib().l3d_group_concat(ptr(x_), ptr(q_), ptr(f_), ptr(idx), B, N, S, self.nsample, Cf, int(self.use_xyz),
-                                         ptr(out), stream_ptr()), "l3d_group_concat")
+            with stage("group_kernel"):                  # the launch alone (bench.py --workload c5: the live HBM-roofline timing)
+                rc = lib().l3d_group_concat(ptr(x_), ptr(q_), ptr(f_), ptr(idx), B, N, S, self.nsample, Cf, int(self.use_xyz),
+                                            ptr(out), stream_ptr())
+            check(rc, "l3d_group_concat")
             return out
         xyz_trans = xyz.transpose(1, 2).contiguous()
         grouped_xyz = grouping_operation(xyz_trans, idx)                  # (B, 3, npoint, nsample)

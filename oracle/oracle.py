@@ -439,6 +439,104 @@ def pcn_forward_torch(x_bn3, w, num_coarse, grid_size):
     return coarse.numpy(), (out.permute(0, 2, 1) + point_feature).numpy()
 
 
+# ----------------------------------------------------------------- a12 as a model: FlowNet3D (config 5)
+def _cbr(h, w, pre, eps=1e-5):
+    """Conv(1x1, optional bias) -> BatchNorm (eval) -> ReLU with the state_dict keys pre.{weight | bias | running_*};
+    `pre` = (conv key prefix, bn key prefix).  h [B,C,N] or [B,C,S,K]."""
+    import torch.nn.functional as F
+    ck, bk = pre
+    wt = _t(w[ck + ".weight"])
+    b = _t(w[ck + ".bias"]) if ck + ".bias" in w else None
+    h = F.conv2d(h, wt, b) if h.dim() == 4 else F.conv1d(h, wt, b)
+    h = F.batch_norm(h, _t(w[bk + ".running_mean"]), _t(w[bk + ".running_var"]), _t(w[bk + ".weight"]), _t(w[bk + ".bias"]),
+                     False, 0.0, eps)
+    return F.relu(h)
+
+
+def set_abstraction_forward_torch(xyz_b3n, feat_bcn, w, prefix, npoint, radius, nsample, n_layers=3):
+    """PointNetSetAbstraction.forward, models/flownet3d.py:93-123: furthest_point_sample (K12) -> gather_operation (K10)
+    -> QueryAndGroup = ball_query (K7) + grouping_operation (K8) - centre, concat [xyz | features]
+    (utils/lib/pointnet2_utils.py:259-292) -> [Conv2d + BN + ReLU] * n -> max over the nsample axis.
+    `w`: state_dict with keys prefix.mlp_convs.i.weight / prefix.mlp_bns.i.*; prefix may be "" for a bare layer."""
+    import torch
+    xyz = np.ascontiguousarray(np.asarray(xyz_b3n, np.float32))
+    feat = np.ascontiguousarray(np.asarray(feat_bcn, np.float32))
+    xyz_t = np.ascontiguousarray(xyz.transpose(0, 2, 1))
+    fps = furthest_point_sampling(xyz_t, npoint)
+    new_xyz = gather_points(xyz, fps)                                               # [B,3,S]
+    idx = ball_query(radius, nsample, xyz_t, np.ascontiguousarray(new_xyz.transpose(0, 2, 1)))
+    g_xyz = group_points(xyz, idx) - new_xyz[:, :, :, None]
+    h = torch.from_numpy(np.concatenate([g_xyz, group_points(feat, idx)], axis=1))
+    pre = prefix + "." if prefix else ""
+    with torch.no_grad():
+        for i in range(n_layers):
+            h = _cbr(h, w, (f"{pre}mlp_convs.{i}", f"{pre}mlp_bns.{i}"))
+        return new_xyz, h.max(-1)[0].numpy()
+
+
+def flownet3d_forward_torch(pc1, pc2, feature1, feature2, w, return_intermediates=False):
+    """FlowNet3D.forward, models/flownet3d.py:305-328 (layer hyper-parameters :293-303), eval mode, composed from the K7-K16
+    restatements of oracle.c and torch-CPU conv / BatchNorm functionals: PointNetSetAbstraction :93-123 (above),
+    FlowEmbedding :142-180 (knn branch), PointNetSetUpConv :208-242 (knn branch), PointNetFeaturePropogation :256-286.
+    `w`: the reference FlowNet3D's state_dict (numpy values)."""
+    import torch
+    pc1, pc2 = np.asarray(pc1, np.float32), np.asarray(pc2, np.float32)
+    f1, f2 = np.asarray(feature1, np.float32), np.asarray(feature2, np.float32)
+    tr = lambda a: np.ascontiguousarray(a.transpose(0, 2, 1))
+    sa = lambda x, f, name, S, r, K: set_abstraction_forward_torch(x, f, w, name, S, r, K)
+
+    def flow_embedding(pos1, pos2, feat1, feat2, nsample=64):                      # :142-180, self.knn = True
+        _, idx = knn_pair(nsample, tr(pos1), tr(pos2))
+        pos_diff = group_points(pos2, idx) - pos1[:, :, :, None]
+        feat_diff = np.concatenate([group_points(feat2, idx), np.repeat(feat1[:, :, :, None], nsample, axis=3)], axis=1)
+        h = torch.from_numpy(np.concatenate([pos_diff, feat_diff], axis=1))
+        for i in range(3):
+            h = _cbr(h, w, (f"fe_layer.mlp_convs.{i}", f"fe_layer.mlp_bns.{i}"))
+        return h.max(-1)[0].numpy()
+
+    def set_upconv(name, pos1, pos2, feat1, feat2, n1, n2, nsample=8):              # :208-242
+        _, idx = knn_pair(nsample, tr(pos1), tr(pos2))
+        pos_diff = group_points(pos2, idx) - pos1[:, :, :, None]
+        h = torch.from_numpy(np.concatenate([group_points(feat2, idx), pos_diff], axis=1))
+        for i in range(n1):
+            h = _cbr(h, w, (f"{name}.mlp1_convs.{i}.0", f"{name}.mlp1_convs.{i}.1"))
+        h = h.max(-1)[0]
+        if feat1 is not None:
+            h = torch.cat([h, torch.from_numpy(feat1)], dim=1)
+        for i in range(n2):
+            h = _cbr(h, w, (f"{name}.mlp2_convs.{i}.0", f"{name}.mlp2_convs.{i}.1"))
+        return h.numpy()
+
+    def feature_propagation(pos1, pos2, feat1, feat2):                              # :256-286
+        dists, idx = three_nn(tr(pos1), tr(pos2))
+        dists = np.where(dists < 1e-10, np.float32(1e-10), dists).astype(np.float32)
+        weight = (np.float32(1.0) / dists).astype(np.float32)
+        weight = (weight / weight.sum(-1, keepdims=True)).astype(np.float32)
+        g = torch.from_numpy(group_points(feat2, idx)) * torch.from_numpy(weight)[:, None]     # [B,C,N,3]
+        h = torch.cat([torch.sum(g, dim=-1), torch.from_numpy(feat1)], dim=1)
+        for i in range(2):
+            h = _cbr(h, w, (f"fp.mlp_convs.{i}", f"fp.mlp_bns.{i}"))
+        return h
+
+    with torch.no_grad():
+        l1_pc1, l1_f1 = sa(pc1, f1, "sa1", 1024, 0.5, 16)
+        l2_pc1, l2_f1 = sa(l1_pc1, l1_f1, "sa2", 256, 1.0, 16)
+        l1_pc2, l1_f2 = sa(pc2, f2, "sa1", 1024, 0.5, 16)
+        l2_pc2, l2_f2 = sa(l1_pc2, l1_f2, "sa2", 256, 1.0, 16)
+        l2_f1_new = flow_embedding(l2_pc1, l2_pc2, l2_f1, l2_f2)
+        l3_pc1, l3_f1 = sa(l2_pc1, l2_f1_new, "sa3", 64, 2.0, 8)
+        l4_pc1, l4_f1 = sa(l3_pc1, l3_f1, "sa4", 16, 4.0, 8)
+        l3_fnew1 = set_upconv("su1", l3_pc1, l4_pc1, l3_f1, l4_f1, 0, 2)
+        l2_fnew1 = set_upconv("su2", l2_pc1, l3_pc1, np.concatenate([l2_f1, l2_f1_new], axis=1), l3_fnew1, 3, 1)
+        l1_fnew1 = set_upconv("su3", l1_pc1, l2_pc1, l1_f1, l2_fnew1, 3, 1)
+        l0 = feature_propagation(pc1, l1_pc1, f1, l1_fnew1)
+        x = _cbr(l0, w, ("conv1", "bn1"))
+        sf = torch.nn.functional.conv1d(x, _t(w["conv2.weight"]), _t(w["conv2.bias"])).numpy()
+    if return_intermediates:
+        return sf, dict(l1_pc1=l1_pc1, l1_feature1=l1_f1, l2_feature1=l2_f1, l2_feature1_new=l2_f1_new)
+    return sf
+
+
 def pointnet_classifier_forward_torch(x_bn3, w, eps=1e-5):
     """models/pointnet.py:45-73 (use_bn=True) -> Pooling('max') -> models/classifier.py:22-29, eval mode (dropout is
     the identity), restated with torch CPU functionals.  `w` has the checkpoint's keys (feature_model.*, linear*, bn*)."""

@@ -34,6 +34,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
+sys.path.insert(0, HERE)
 
 
 def import_reference():
@@ -42,6 +43,11 @@ def import_reference():
                     ignore=shutil.ignore_patterns("pretrained", "images", "build", "dist", "*.egg-info"))
     sys.dont_write_bytecode = True
     sys.modules.setdefault("h5py", types.ModuleType("h5py"))
+    # the reference's utils/lib/pointnet2_utils.py imports the compiled `pointnet2_cuda` module, which does not build
+    # against torch 2.x: a CPU stand-in made of the oracle's K7-K16 restatements (bit-pinned against the reference's own
+    # kernels on the GPU) takes its place, so that FlowNet3D imports and runs (ref_pointnet2_cpu.py)
+    import ref_pointnet2_cpu
+    sys.modules.setdefault("pointnet2_cuda", ref_pointnet2_cpu.make_module())
     sys.path.insert(0, tmp)
     import learning3d.utils as U          # noqa
     import learning3d.models as Mo        # noqa
@@ -64,7 +70,6 @@ def rand(shape, seed, lo=0.0, hi=1.0):
     return torch.rand(shape, generator=g) * (hi - lo) + lo
 
 
-sys.path.insert(0, HERE)
 from seeded import seeded_params  # noqa: E402  (shared with the tests)
 
 
@@ -212,6 +217,13 @@ def main():
         out = pcn(x)
         save("pcn_seeded", x=x, coarse_output=out["coarse_output"], fine_output=out["fine_output"],
              keys=np.array(sorted(pcn.state_dict().keys())), seed=700)
+        # ---- config 4's PCN (num_coarse 1024, grid 4 -> 16384 fine points) on 2 partial clouds of 2048 points --------------
+        pcn4 = Mo.PCN(emb_dims=1024, num_coarse=1024, grid_size=4, detailed_output=True).eval()
+        seeded_params(pcn4, 710)
+        x4 = rand((2, 2048, 3), 27, -0.5, 0.5)
+        out4 = pcn4(x4)
+        save("pcn_seeded_c4", seed_x=27, coarse_output=out4["coarse_output"], fine_output=out4["fine_output"],
+             keys=np.array(sorted(pcn4.state_dict().keys())), seed=710)
         # ---- config 1: PointNet classifier with the reference's own trained checkpoint
         #      (pretrained/exp_classifier/models/best_model.t7, examples/test_pointnet.py:98-118, B=8 N=1024) ----------
         ckpt = torch.load(os.path.join(REF, "pretrained", "exp_classifier", "models", "best_model.t7"), map_location="cpu")
@@ -293,6 +305,39 @@ def main():
             outs["out_" + name] = m(xyz if initial else feats, xyz)            # models/curvenet.py:62 calls lpfa(xyz, xyz)
             outs.update({f"w_{name}." + k: v for k, v in m.state_dict().items()})
         save("lpfa", xyz=xyz, feats=feats, **outs)
+        # ---- FlowNet3D as a model (models/flownet3d.py:73-328): the reference's own module + its own pointnet2_utils.py
+        #      wrappers, running on the CPU stand-in for pointnet2_cuda; seeded weights by state_dict key --------------
+        import learning3d.utils as U2
+        assert hasattr(U2, "pointnet2_utils"), "the reference's pointnet2_utils did not import"
+        from learning3d.models.flownet3d import FlowNet3D, PointNetSetAbstraction
+        cuda_types = (torch.cuda.IntTensor, torch.cuda.FloatTensor)
+        torch.cuda.IntTensor, torch.cuda.FloatTensor = torch.IntTensor, torch.FloatTensor   # pointnet2_utils.py:25-28 allocates with these
+        try:
+            fn = FlowNet3D().eval()
+            seeded_params(fn, 900)
+            g = torch.Generator().manual_seed(90)
+            pc1 = torch.clamp(torch.randn((2, 3, 2048), generator=g), -2, 2)
+            pc2 = (pc1 + 0.05 * torch.randn((2, 3, 2048), generator=g)).contiguous()
+            f1, f2 = torch.rand((2, 3, 2048), generator=g), torch.rand((2, 3, 2048), generator=g)
+            l1_pc1, l1_f1 = fn.sa1(pc1, f1)
+            l2_pc1, l2_f1 = fn.sa2(l1_pc1, l1_f1)
+            l1_pc2, l1_f2 = fn.sa1(pc2, f2)
+            l2_pc2, l2_f2 = fn.sa2(l1_pc2, l1_f2)
+            _, l2_f1_new = fn.fe_layer(l2_pc1, l2_pc2, l2_f1, l2_f2)
+            sf = fn(pc1, pc2, f1, f2)
+            save("flownet3d_seeded", pc1=pc1, pc2=pc2, f1=f1, f2=f2, sf=sf, l1_pc1=l1_pc1, l1_feature1=l1_f1,
+                 l2_feature1=l2_f1, l2_feature1_new=l2_f1_new, keys=np.array(sorted(fn.state_dict().keys())), seed=900)
+            # config 5's layer at its own shape on 4 clouds (sa1: npoint 1024 of N 8192, r 0.5, K 16, mlp 32/32/64)
+            sa = PointNetSetAbstraction(npoint=1024, radius=0.5, nsample=16, in_channel=3, mlp=[32, 32, 64], group_all=False).eval()
+            seeded_params(sa, 910)
+            g = torch.Generator().manual_seed(0)
+            xyz = torch.clamp(torch.randn((4, 3, 8192), generator=g), -2, 2)
+            feat = torch.rand((4, 3, 8192), generator=torch.Generator().manual_seed(1))
+            new_xyz, new_feat = sa(xyz, feat)
+            save("flownet3d_sa1_c5", seed_xyz=0, seed_feat=1, new_xyz=new_xyz, new_feat=new_feat.to(torch.float32), seed=910,
+                 keys=np.array(sorted(sa.state_dict().keys())))
+        finally:
+            torch.cuda.IntTensor, torch.cuda.FloatTensor = cuda_types
     shutil.rmtree(tmp, ignore_errors=True)
     print("done")
 

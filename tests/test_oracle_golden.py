@@ -197,3 +197,45 @@ def test_pose_transforms_golden(golden):
     np.testing.assert_allclose(igt, g["igt"], atol=1e-6)
     np.testing.assert_allclose(gt, g["gt"], atol=1e-6)
     np.testing.assert_allclose(oracle.quat_transform(g["template"], g["pose7"]), g["pcr_source"], atol=1e-6)
+
+
+def _seeded_state(module, seed):
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from seeded import seeded_params
+    return {k: v.numpy() for k, v in seeded_params(module.eval(), seed).state_dict().items()}
+
+
+def test_flownet3d_oracle_port_is_the_reference(golden):
+    """config 5's model: oracle.flownet3d_forward_torch (K7-K16 restatements + torch-CPU conv / BatchNorm functionals) against
+    the golden made by the reference's OWN models/flownet3d.py + utils/lib/pointnet2_utils.py (make_golden.py drives them on a
+    CPU stand-in for pointnet2_cuda built from those same restatements, which are bit-pinned against the reference's kernels
+    on the GPU): the composition -- layer order, channel orders of the concatenations, which cloud is grouped around which,
+    the 1e-10 clamp and normalisation of the 3-NN weights, BatchNorm placement -- is what this pins.  Sampled / grouped
+    coordinates and the first three feature levels bit-exact, flow within 1e-6."""
+    from learning3d_amd.models import FlowNet3D
+    g = golden("flownet3d_seeded")
+    net = FlowNet3D()
+    assert sorted(net.state_dict().keys()) == [str(k) for k in g["keys"]]            # state_dict-compatible with the reference
+    w = _seeded_state(net, int(g["seed"]))
+    sf, inter = oracle.flownet3d_forward_torch(g["pc1"], g["pc2"], g["f1"], g["f2"], w, return_intermediates=True)
+    assert np.array_equal(inter["l1_pc1"], g["l1_pc1"])
+    for k in ("l1_feature1", "l2_feature1", "l2_feature1_new"):
+        np.testing.assert_allclose(inter[k], g[k], rtol=0, atol=1e-6, err_msg=k)
+    np.testing.assert_allclose(sf, g["sf"], rtol=0, atol=1e-6)
+
+
+def test_flownet3d_sa1_config5_shape_oracle(golden):
+    """BASELINE config 5's layer at its own shape (N = 8192 -> 1024 centroids, r = 0.5, K = 16, mlp 32/32/64) on 4 clouds of
+    SURVEY 8(d)'s c5 distribution: oracle composition against the reference's PointNetSetAbstraction.forward."""
+    import torch
+    from learning3d_amd.models import PointNetSetAbstraction
+    g = golden("flownet3d_sa1_c5")
+    sa = PointNetSetAbstraction(npoint=1024, radius=0.5, nsample=16, in_channel=3, mlp=[32, 32, 64], group_all=False)
+    assert sorted(sa.state_dict().keys()) == [str(k) for k in g["keys"]]
+    w = _seeded_state(sa, int(g["seed"]))
+    xyz = torch.clamp(torch.randn((4, 3, 8192), generator=torch.Generator().manual_seed(int(g["seed_xyz"]))), -2, 2).numpy()
+    feat = torch.rand((4, 3, 8192), generator=torch.Generator().manual_seed(int(g["seed_feat"]))).numpy()
+    new_xyz, new_feat = oracle.set_abstraction_forward_torch(xyz, feat, w, "", 1024, 0.5, 16)
+    assert np.array_equal(new_xyz, g["new_xyz"])
+    np.testing.assert_allclose(new_feat, g["new_feat"], rtol=0, atol=1e-6)
