@@ -507,6 +507,16 @@ int l3d_twist_transform(const float *tmpl, const float *twist, int B, int N, flo
  * the quaternion is normalised as create_pose_7d does; source = qrot(q, template) + t. */
 int l3d_quat_transform(const float *tmpl, const float *pose7, int B, int N, float *source, l3d_stream_t stream);
 
+/* SceneflowDataset.__getitem__ (data_utils/dataloaders.py:400-432) for a batch, from a dataset resident in HBM: points1 /
+ * color1 / flow [F,n1,3], valid_mask1 [F,n1] (bytes), points2 / color2 [F,n2,3]; scene_idx [B] int64; sample1 / sample2
+ * [B,S] int32 row indices (np.random.choice(n, npoints, replace=False) of the train partition) or both NULL (test partition:
+ * the first S rows).  Outputs [B,S,3] (mask [B,S] bytes): pos1 and pos2 minus np.mean(pos1, 0) of the sampled rows, the mean
+ * replayed in numpy's order (sequential fp32 adds, fp64 divide) -- bit-identical to the reference.  S <= 8192. */
+int l3d_sceneflow_batch(const float *points1, const float *points2, const float *color1, const float *color2, const float *flow,
+                        const unsigned char *mask1, const long long *scene_idx, const int *sample1, const int *sample2, int B, int n1,
+                        int n2, int S, float *o_pos1, float *o_pos2, float *o_color1, float *o_color2, float *o_flow,
+                        unsigned char *o_mask, l3d_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Training-mode BatchNorm around the 1x1-conv GEMMs (train.hip).  z / dy / y / dz are [B,C,P]
  * fp32 (P = points, or points x neighbours).  Statistics come out as PER-CLOUD fp64 partial sums [B,C,2] (fixed order,

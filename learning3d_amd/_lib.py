@@ -107,6 +107,7 @@ SIGNATURES = {
     "l3d_euler_transform": [_P, _P, _P, _I, _I, _P, _P, _P],
     "l3d_twist_transform": [_P, _P, _I, _I, _P, _P, _P, _P],
     "l3d_quat_transform": [_P, _P, _I, _I, _P, _P],
+    "l3d_sceneflow_batch": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "l3d_emd_forward": [_P, _P, _I, _I, _I, _P, _P, _P, _P],
     "l3d_emd_backward": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
 }

@@ -173,3 +173,76 @@ extern "C" int l3d_quat_transform(const float *tmpl, const float *pose7, int B, 
     hipLaunchKernelGGL(quat_transform_kernel, dim3(l3d_divup(N, 256), B), dim3(256), 0, (hipStream_t)stream, tmpl, pose7, N, source);
     return l3d_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// l3d_sceneflow_batch -- SceneflowDataset.__getitem__ (data_utils/dataloaders.py:400-432) for a whole batch, from a dataset
+// that lives in HBM (the processed FlyingThings3D set, `data_processed_maxcut_35_20k_2k_8192`, is ~10 GB: it fits once).
+//   per sample b: scene s = scene_idx[b]; rows sample1[b][:] of points1 / color1 / flow / valid_mask1 and rows
+//   sample2[b][:] of points2 / color2 (train: np.random.choice without replacement; test: the first npoints rows =
+//   sample pointers NULL); centre = np.mean(pos1, 0) of the SAMPLED rows; pos1 -= centre; pos2 -= centre.
+// np.mean over axis 0 of a float32 [S,3] array adds the rows one after the other in fp32 and divides in fp64
+// (tests/test_oracle_golden.py pins that): one lane per coordinate replays exactly that chain over the rows staged in LDS,
+// so the centred clouds are bit-identical to the reference's.
+// One workgroup per sample; S <= 8192 (96 KB of LDS for the staged pos1 rows).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sceneflow_batch_kernel(
+    const float *__restrict__ points1, const float *__restrict__ points2, const float *__restrict__ color1,
+    const float *__restrict__ color2, const float *__restrict__ flow, const unsigned char *__restrict__ mask1,
+    const long long *__restrict__ scene_idx, const int *__restrict__ sample1, const int *__restrict__ sample2, int n1, int n2, int S,
+    float *__restrict__ o_pos1, float *__restrict__ o_pos2, float *__restrict__ o_color1, float *__restrict__ o_color2,
+    float *__restrict__ o_flow, unsigned char *__restrict__ o_mask)
+{
+    extern __shared__ float sf_pos1[];          // [S][3]
+    __shared__ float sf_centre[3];
+    const int b = blockIdx.x;
+    const size_t s = (size_t)scene_idx[b];
+    const float *p1 = points1 + s * n1 * 3, *p2 = points2 + s * n2 * 3;
+    const float *c1 = color1 + s * n1 * 3, *c2 = color2 + s * n2 * 3, *fl = flow + s * n1 * 3;
+    const unsigned char *mk = mask1 + s * n1;
+    const size_t ob = (size_t)b * S;
+    for (int i = threadIdx.x; i < S; i += 256) {
+        const int r1 = sample1 ? sample1[ob + i] : i;
+        const int r2 = sample2 ? sample2[ob + i] : i;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            sf_pos1[i * 3 + c] = p1[(size_t)r1 * 3 + c];
+            o_color1[(ob + i) * 3 + c] = c1[(size_t)r1 * 3 + c];
+            o_flow[(ob + i) * 3 + c] = fl[(size_t)r1 * 3 + c];
+            o_color2[(ob + i) * 3 + c] = c2[(size_t)r2 * 3 + c];
+        }
+        o_mask[ob + i] = mk[r1];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float acc = 0.f;                         // numpy's axis-0 reduction: row after row, fp32
+        for (int i = 0; i < S; i++) acc = acc + sf_pos1[i * 3 + threadIdx.x];
+        sf_centre[threadIdx.x] = (float)((double)acc / (double)S);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < S; i += 256) {
+        const int r2 = sample2 ? sample2[ob + i] : i;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            o_pos1[(ob + i) * 3 + c] = sf_pos1[i * 3 + c] - sf_centre[c];
+            o_pos2[(ob + i) * 3 + c] = p2[(size_t)r2 * 3 + c] - sf_centre[c];
+        }
+    }
+}
+
+extern "C" int l3d_sceneflow_batch(const float *points1, const float *points2, const float *color1, const float *color2,
+                                   const float *flow, const unsigned char *mask1, const long long *scene_idx, const int *sample1,
+                                   const int *sample2, int B, int n1, int n2, int S, float *o_pos1, float *o_pos2, float *o_color1,
+                                   float *o_color2, float *o_flow, unsigned char *o_mask, l3d_stream_t stream)
+{
+    L3D_REQUIRE(points1 && points2 && color1 && color2 && flow && mask1 && scene_idx && o_pos1 && o_pos2 && o_color1 && o_color2 &&
+                o_flow && o_mask && B > 0 && n1 > 0 && n2 > 0 && S > 0 && S <= 8192 && S <= n1 && S <= n2);
+    L3D_REQUIRE((sample1 == nullptr) == (sample2 == nullptr));
+    const size_t lds = (size_t)S * 3 * sizeof(float);
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)sceneflow_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { g_l3d_last_hip_error = (int)e; return L3D_ERR_LAUNCH; }
+    }
+    hipLaunchKernelGGL(sceneflow_batch_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, points1, points2, color1, color2, flow,
+                       mask1, scene_idx, sample1, sample2, n1, n2, S, o_pos1, o_pos2, o_color1, o_color2, o_flow, o_mask);
+    return l3d_check_launch();
+}

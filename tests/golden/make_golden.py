@@ -42,7 +42,24 @@ def import_reference():
     shutil.copytree(REF, os.path.join(tmp, "learning3d"),
                     ignore=shutil.ignore_patterns("pretrained", "images", "build", "dist", "*.egg-info"))
     sys.dont_write_bytecode = True
-    sys.modules.setdefault("h5py", types.ModuleType("h5py"))
+    # h5py is not in the image.  The reference imports it at module scope (unused in utils/transformer.py:4; used by
+    # data_utils/dataloaders.py:39-44, whose ModelNet40Data() default arguments run at import, :230, :251).  A stand-in whose
+    # File() serves the datasets of an .npz written under the .h5 name lets the reference's OWN dataset classes import and run
+    # on the synthetic files make_dataset_files() puts where they look (<package>/data/...).
+    h5 = types.ModuleType("h5py")
+
+    class _File:
+        def __init__(self, name, mode="r"):
+            self._z = np.load(name)
+
+        def __getitem__(self, k):
+            return self._z[k]
+
+        def close(self):
+            self._z.close()
+    h5.File = _File
+    sys.modules["h5py"] = h5
+    make_dataset_files(os.path.join(tmp, "learning3d", "data"))
     # the reference's utils/lib/pointnet2_utils.py imports the compiled `pointnet2_cuda` module, which does not build
     # against torch 2.x: a CPU stand-in made of the oracle's K7-K16 restatements (bit-pinned against the reference's own
     # kernels on the GPU) takes its place, so that FlowNet3D imports and runs (ref_pointnet2_cpu.py)
@@ -53,6 +70,34 @@ def import_reference():
     import learning3d.models as Mo        # noqa
     import learning3d.losses.chamfer_distance as CD  # noqa
     return tmp, U, Mo, CD
+
+
+def make_dataset_files(data_dir):
+    """Synthetic stand-ins for the two on-disk datasets, in the reference's layouts: ModelNet40 `ply_data_{train,test}*.h5`
+    (here: npz bytes under that name, datasets `data` [n,2048,3], `normal`, `label` [n,1] uint8) + shape_names.txt, and
+    FlyingThings3D `TRAIN*/TEST*.npz` (points1/2, color1/2, flow [n,3], valid_mask1 [n] bool)."""
+    rng = np.random.default_rng(2024)
+    mn = os.path.join(data_dir, "modelnet40_ply_hdf5_2048")
+    os.makedirs(mn, exist_ok=True)
+    for part, counts in (("train", (5, 4)), ("test", (3,))):
+        for i, n in enumerate(counts):
+            arrs = dict(data=rng.uniform(-1, 1, (n, 2048, 3)).astype(np.float32), normal=rng.standard_normal((n, 2048, 3)).astype(np.float32),
+                        label=rng.integers(0, 40, (n, 1)).astype(np.uint8))
+            with open(os.path.join(mn, f"ply_data_{part}{i}.h5"), "wb") as f:
+                np.savez(f, **arrs)
+    with open(os.path.join(mn, "shape_names.txt"), "w") as f:
+        f.write("\n".join(f"class{i}" for i in range(40)) + "\n")
+    sf = os.path.join(data_dir, "data_processed_maxcut_35_20k_2k_8192")
+    os.makedirs(sf, exist_ok=True)
+    for name in ("TRAIN_A_0000_left_0006-0", "TRAIN_A_0001_left_0007-0", "TRAIN_B_0002_right_0008-0", "TEST_A_0000_left_0006-0",
+                 "TEST_A_0001_left_0007-0"):
+        n = 700
+        p1 = (rng.standard_normal((n, 3)) * 5 + np.array([3.0, -2.0, 20.0])).astype(np.float32)
+        fl = (rng.standard_normal((n, 3)) * 0.3).astype(np.float32)
+        np.savez(os.path.join(sf, name + ".npz"), points1=p1, points2=(p1 + fl + rng.standard_normal((n, 3)) * 0.01).astype(np.float32),
+                 color1=rng.uniform(0, 1, (n, 3)).astype(np.float32), color2=rng.uniform(0, 1, (n, 3)).astype(np.float32), flow=fl,
+                 valid_mask1=rng.uniform(0, 1, n) > 0.1)
+    return mn, sf
 
 
 def load_cd_ref():
@@ -338,6 +383,41 @@ def main():
                  keys=np.array(sorted(sa.state_dict().keys())))
         finally:
             torch.cuda.IntTensor, torch.cuda.FloatTensor = cuda_types
+    # ---- f4, the on-disk half: the reference's own dataset classes (data_utils/dataloaders.py:184-247, :364-435) on the synthetic
+    #      files; the fixture carries the files' arrays so that the tests can rebuild them on the GPU box ------------------------
+    import learning3d.data_utils.dataloaders as DL
+    data_dir = os.path.join(tmp, "learning3d", "data")
+    mn, sf = os.path.join(data_dir, "modelnet40_ply_hdf5_2048"), os.path.join(data_dir, "data_processed_maxcut_35_20k_2k_8192")
+    out = {}
+    for fn in sorted(glob.glob(os.path.join(mn, "ply_data_*.h5"))):
+        z = np.load(fn)
+        for k in ("data", "normal", "label"):
+            out[f"mn.{os.path.basename(fn)[:-3]}.{k}"] = z[k][:, :256] if k != "label" else z[k]     # the tests use num_points <= 256
+    for part, train in (("train", True), ("test", False)):
+        ds = DL.ModelNet40Data(train=train, num_points=128, download=False, randomize_data=False)
+        # the reference concatenates in glob order (file-system dependent): record it
+        out[f"mn.{part}.order"] = np.array([os.path.basename(f)[:-3] for f in glob.glob(os.path.join(mn, f"ply_data_{part}*.h5"))])
+        pts, lab = zip(*[ds[i] for i in range(len(ds))])
+        out[f"mn.{part}.points"], out[f"mn.{part}.labels"] = torch.stack(pts).numpy(), torch.stack(lab).numpy()
+    ds = DL.ModelNet40Data(train=True, num_points=128, download=False, randomize_data=True, use_normals=True)
+    np.random.seed(77)
+    out["mn.rand.points"] = torch.stack([ds[i][0] for i in (0, 3, 8)]).numpy()
+    cls = DL.ClassificationData(DL.ModelNet40Data(train=False, num_points=64, download=False))
+    out["mn.cls.points"], out["mn.cls.label"] = cls[1][0].numpy(), cls[1][1].numpy()
+    out["mn.cls.shape"] = np.array(str(cls.get_shape(int(cls[1][1]))))
+    for fn in sorted(glob.glob(os.path.join(sf, "*.npz"))):
+        z = np.load(fn)
+        for k in z.files:
+            out[f"sf.{os.path.basename(fn)[:-4]}.{k}"] = z[k]
+    for part in ("train", "test"):
+        ds = DL.SceneflowDataset(npoints=256, root=sf, partition=part)
+        out[f"sf.{part}.order"] = np.array([os.path.basename(f)[:-4] for f in ds.datapath])
+        np.random.seed(91)
+        for i in range(len(ds)):
+            item = ds[i]
+            for name, v in zip(("pos1", "pos2", "color1", "color2", "flow", "mask1"), item):
+                out[f"sf.{part}.{i}.{name}"] = np.array(v)
+    save("datasets", **out)
     shutil.rmtree(tmp, ignore_errors=True)
     print("done")
 
