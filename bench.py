@@ -91,7 +91,7 @@ def edgeconv_roofline(ec_tf, ec_ms, arith):
     prods = SPLIT_PRODUCTS[arith]
     peak = MFMA_BF16_PEAK_TF / prods
     l1 = B_PER_GPU * NPTS * KNN * 2 * 6 * 64                       # layer 1 stays on the fp32 MFMA
-    name = "edgeconv_f16_kernel<5,true>" if arith == "f16x2" else "edgeconv_split_kernel<5>"
+    name = "edgeconv_f16b_kernel<5,true>" if arith == "f16x2" else "edgeconv_split_kernel<5>"
     return {"kernel": name, "bound": "mfma", "achieved": ec_tf, "peak": peak,
             "unit": "TFLOP/s", "frac": ec_tf / peak, "traffic": pmc_traffic("edgeconv_f16" if arith == "f16x2" else "edgeconv_split"),
             "avg_launch_ms": ec_ms, "algorithmic_flop_per_launch": alg,

@@ -355,6 +355,12 @@ int l3d_edgeconv_forward_split(const float *xyz, const int64_t *idx, int B, int 
  * plane value exceeds 60000 -- the outputs are then invalid and the caller re-runs l3d_edgeconv_forward_split.  k <= 20. */
 int l3d_edgeconv_forward_f16(const float *xyz, const int64_t *idx, int B, int N, int k, const float *packed, void *out,
                              int out_mode, int *range_flag, l3d_stream_t stream);
+/* The two-plane variant (edgeconv_f16b.hip): same arguments and outputs; two fp16 weight planes per fragment step and an
+ * unscaled activation residual (fifth packed copy, csrc/edgeconv_layout.h).  Usable only when the packer could place every
+ * layer's weights (packed[l3d_edgeconv_packed_v2_flag_index()] == 1 in the HOST copy of the packed block). */
+int l3d_edgeconv_forward_f16b(const float *xyz, const int64_t *idx, int B, int N, int k, const float *packed, void *out,
+                             int out_mode, int *range_flag, l3d_stream_t stream);
+int l3d_edgeconv_packed_v2_flag_index(void);
 /* l3d_edgeconv_pack with act_mag[4]: the magnitude (a few standard deviations) expected of each layer's post-ReLU
  * activations; NULL or non-positive entries mean 1.  Only the f16x2 kernel uses it. */
 int l3d_edgeconv_pack_mag(const float *const w[4], const float *const scale[4], const float *const shift[4],

@@ -77,6 +77,8 @@ SIGNATURES = {
     "l3d_edgeconv_forward_chained": [_P, _P, _I, _I, _I, _P, _P, _P],
     "l3d_edgeconv_forward_split": [_P, _P, _I, _I, _I, _P, _P, _P],
     "l3d_edgeconv_forward_f16": [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P],
+    "l3d_edgeconv_forward_f16b": [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P],
+    "l3d_edgeconv_packed_v2_flag_index": [],
     "l3d_edgeconv_pack_mag": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "l3d_pointwise_conv": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_pointwise_conv_maxpool": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],

@@ -34,7 +34,9 @@ def build(force=False, verbose=False):
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        if force or _stale(obj, [src] + hdrs):
+        with open(src) as f:                           # variants that #include another kernel source (edgeconv_f16b.hip)
+            inc = [os.path.join(CSRC, line.split('"')[1]) for line in f if line.startswith("#include \"") and line.split('"')[1].endswith(".hip")]
+        if force or _stale(obj, [src] + inc + hdrs):
             cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))

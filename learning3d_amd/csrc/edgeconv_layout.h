@@ -46,4 +46,26 @@
 #define EC4_OFF_B3 (EC4_OFF_B2 + EC_C2)
 #define EC4_OFF_B4 (EC4_OFF_B3 + EC_C3)
 #define EC4_OFF_SC (EC4_OFF_B4 + EC_C4)
-#define EC_PACKED_FLOATS (EC4_OFF_SC + 16)
+#define EC4_END (EC4_OFF_SC + 16)
+
+// fifth copy, for the two-plane f16x2 kernel (edgeconv_f16b.hip = edgeconv_f16.hip with EF_V2): the activation residual is
+// carried UNSCALED (m = f16(x - h)), so the Hs plane is gone -- two fp16 weight planes H = f16(W), M = f16(W - H) per
+// fragment step ([step][plane 2: H, M][lane 64][8 f16], same step order) and the products are M h + H m + H h.  Weights are
+// scaled as in the fourth copy (W = w' 2^S_l, max|W| in [4,8)).  The accumulators of layers 1-3 ARE the next layer's planes
+// (no multiply in the split: h = cvt_pk_f16(a), m = cvt_pk_f16(a - h)): layer 1's fp32 weights and bias are stored times
+// 2^T_1 (EC5_OFF_W1 / _B1, layout of the second copy) and T_l = S_l + T_(l-1) for l = 2, 3; T_1 is chosen so that the
+// highest-placed layer has its expected magnitude in [2^11, 2^12).  A layer placed below 2^4 clears EC5_OFF_SC + 13 and
+// the host uses the three-plane kernel.  Layer 4: A_4 = 2^(S_4 + T_3).
+// EC5_OFF_SC + :  4..7 cp_l = 1 / A_l (-> fp32 pooled)   8..11 co_l = 2^T_out / A_l (-> pooled planes)   12  2^-T_out
+//                 13  1.0 if the block is usable
+#define EC5_NPL 2
+#define EC5_OFF_W2 EC4_END
+#define EC5_OFF_W3 (EC5_OFF_W2 + (EC_C2 / 16) * (EC_C1 / 32) * EC5_NPL * 64 * 4)
+#define EC5_OFF_W4 (EC5_OFF_W3 + (EC_C3 / 16) * (EC_C2 / 32) * EC5_NPL * 64 * 4)
+#define EC5_OFF_B2 (EC5_OFF_W4 + (EC_C4 / 16) * (EC_C3 / 32) * EC5_NPL * 64 * 4)
+#define EC5_OFF_B3 (EC5_OFF_B2 + EC_C2)
+#define EC5_OFF_B4 (EC5_OFF_B3 + EC_C3)
+#define EC5_OFF_W1 (EC5_OFF_B4 + EC_C4)
+#define EC5_OFF_B1 (EC5_OFF_W1 + 8 * EC_C1)
+#define EC5_OFF_SC (EC5_OFF_B1 + EC_C1)
+#define EC_PACKED_FLOATS (EC5_OFF_SC + 16)

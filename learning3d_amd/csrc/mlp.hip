@@ -213,8 +213,92 @@ extern "C" int l3d_edgeconv_pack_mag(const float *const w[4], const float *const
             for (int c = 0; c < cs[l]; c++) packed[ob4[l] + c] = ldexpf((shift && shift[l]) ? shift[l][c] : 0.f, A);
     }
     packed[EC4_OFF_SC + 12] = ldexpf(1.0f, -Tout);
+
+    // fifth copy (edgeconv_layout.h): two weight planes, accumulators of layers 1-3 ARE the planes of the next layer.
+    // Weights keep the fourth copy's scaling (max|W| in [4,8): an unscaled fp16 residual M = f16(W - H) is a normal number
+    // for |W| >= 2^-3, and costs 2^-25 absolute below that -- against typical weights of order one).  The plane exponents
+    // then follow from the weights, T_l = S_l + T_(l-1), and only T_1 is free: it is set so that the layer whose expected
+    // magnitude lands highest sits in [2^11, 2^12) (fp16 tops out at 2^16).  The other layers sit lower; an activation's
+    // unscaled residual costs 2^-25 absolute in plane units, harmless while a layer's expected magnitude is placed at
+    // >= 2^4 -- otherwise the block is marked unusable and the host runs the three-plane kernel.
+    {
+        const int o5[4] = {0, EC5_OFF_W2, EC5_OFF_W3, EC5_OFF_W4};
+        const int ob5[4] = {EC5_OFF_B1, EC5_OFF_B2, EC5_OFF_B3, EC5_OFF_B4};
+        int el[4], A5[4], T5[4];
+        for (int l = 0; l < 4; l++) {
+            const float mag = (act_mag && act_mag[l] > 0.f && act_mag[l] < INFINITY) ? act_mag[l] : 1.0f;
+            frexpf(mag, &el[l]);                                     // mag in [2^(e-1), 2^e)
+        }
+        // T5[l] = T1 + cum[l], cum = S_2 + .. + S_(l+1) (layers are 1-based in the comments, l is 0-based here).  With
+        // max|W| in [4,8) every layer lifts the planes by S_l ~ 5 binades (default-initialised convs: max|w| ~ 1/8), more
+        // than the 8 binades between "expected magnitude at 2^12" and "at 2^4" allow over two layers: layers 2 and 3 then
+        // give up to two binades of weight scale each (max|W| in [1,2) at worst: M's 2^-25 floor against typical |W| ~ 0.3).
+        int S5[4] = {0, Sl[1], Sl[2], Sl[3]};
+        int T1 = 0;
+        bool ok = true;
+        for (int pass = 0; pass < 5; pass++) {
+            const int cum[3] = {0, S5[1], S5[1] + S5[2]};
+            T1 = 1 << 20;
+            for (int l = 0; l < 3; l++) T1 = (12 - el[l] - cum[l]) < T1 ? (12 - el[l] - cum[l]) : T1;
+            int lo = 1 << 20;
+            for (int l = 0; l < 3; l++) {
+                T5[l] = T1 + cum[l];
+                lo = (el[l] + T5[l]) < lo ? (el[l] + T5[l]) : lo;
+            }
+            ok = lo >= 4;                                            // every layer's expected magnitude placed at >= 2^3
+            if (ok || pass == 4) break;
+            if (S5[2] > Sl[2] - 2) S5[2]--;                          // lower the later layer's weight scale first
+            else if (S5[1] > Sl[1] - 2) S5[1]--;
+            else break;
+        }
+        T5[3] = 0;
+        A5[0] = T5[0];
+        for (int l = 1; l < 4; l++) A5[l] = S5[l] + T5[l - 1];       // == T5[l] for l = 1, 2
+        int Tout5 = T5[0];
+        for (int l = 1; l < 3; l++) Tout5 = T5[l] < Tout5 ? T5[l] : Tout5;
+        Tout5 = Tout < Tout5 ? Tout : Tout5;                         // the pooled planes for conv5: no higher than any layer's
+        // layer 1 (fp32 MFMA): the second copy's layout, times 2^T_1 (exact)
+        for (int i = 0; i < 8 * EC_C1; i++) packed[EC5_OFF_W1 + i] = ldexpf(packed[EC2_OFF_W1 + i], T5[0]);
+        for (int c = 0; c < EC_C1; c++) packed[EC5_OFF_B1 + c] = ldexpf((shift && shift[0]) ? shift[0][c] : 0.f, T5[0]);
+        for (int l = 1; l < 4; l++) {
+            const float *wl = w[l];
+            const float *sc = scale ? scale[l] : nullptr;
+            const float up = ldexpf(1.0f, S5[l]);
+            uint16_t *dst = (uint16_t *)(packed + o5[l]);
+            const int St = cin[l] / 32;
+            for (int m = 0; m < cs[l] / 16; m++)
+                for (int sidx = 0; sidx < St; sidx++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int slot = 0; slot < 8; slot++) {
+                            const int oc = 16 * m + (lane & 15);
+                            const int ic = 32 * sidx + 16 * (slot >> 2) + 4 * (lane >> 4) + (slot & 3);
+                            float v = wl[(size_t)oc * cin[l] + ic];
+                            if (sc) v *= sc[oc];
+                            v *= up;                               // exact (power of two)
+                            const _Float16 H = (_Float16)v;
+                            const _Float16 M = (_Float16)(v - (float)H);
+                            const _Float16 pl[2] = {H, M};
+                            for (int p = 0; p < 2; p++) {
+                                uint16_t bits;
+                                memcpy(&bits, &pl[p], 2);
+                                dst[(((((size_t)(m >> 1) * St + sidx) * 2 + (m & 1)) * 2 + p) * 64 + lane) * 8 + slot] = bits;
+                            }
+                        }
+            for (int c = 0; c < cs[l]; c++) packed[ob5[l] + c] = ldexpf((shift && shift[l]) ? shift[l][c] : 0.f, A5[l]);
+        }
+        for (int i = 0; i < 16; i++) packed[EC5_OFF_SC + i] = 0.f;
+        for (int l = 0; l < 4; l++) {
+            if (l < 3) packed[EC5_OFF_SC + l] = 1.0f;
+            packed[EC5_OFF_SC + 4 + l] = ldexpf(1.0f, -A5[l]);
+            packed[EC5_OFF_SC + 8 + l] = ldexpf(1.0f, Tout5 - A5[l]);
+        }
+        packed[EC5_OFF_SC + 12] = ldexpf(1.0f, -Tout5);
+        packed[EC5_OFF_SC + 13] = ok ? 1.0f : 0.f;
+    }
     return L3D_OK;
 }
+
+extern "C" int l3d_edgeconv_packed_v2_flag_index(void) { return EC5_OFF_SC + 13; }
 
 extern "C" int l3d_edgeconv_pack(const float *const w[4], const float *const scale[4],
                                  const float *const shift[4], int c1, int c2, int c3, int c4,

@@ -437,6 +437,7 @@ class EdgeConvParams:
     def __init__(self):
         self.key = None
         self.packed = None
+        self.v2_ok = False
 
     def get(self, convs, bns, device):
         tensors = []
@@ -460,6 +461,8 @@ class EdgeConvParams:
             arr = lambda ts: (C.c_void_p * 4)(*[t.data_ptr() for t in ts])
             check(lib().l3d_edgeconv_pack_mag(arr(ws), arr(scs), arr(shs), (C.c_float * 4)(*mags), *cs, ptr(packed)),
                   "l3d_edgeconv_pack_mag")
+            # the two-plane f16x2 kernel's block is usable when every layer's weights fit its scaling window
+            self.v2_ok = bool(packed[lib().l3d_edgeconv_packed_v2_flag_index()] == 1.0)
             self.packed = packed.to(device)
             self.key = key
         return self.packed
@@ -591,9 +594,16 @@ def check_range(device=None, sync=False):
 EDGECONV_KERNEL = None
 
 
-def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256), kernel=None, planes=False):
+# f16x2 EdgeConv kernel: True = the two-plane kernel (edgeconv_f16b.hip: H, M weight planes, unscaled residual, conversion-only
+# split) whenever the packed block allows it; False = the three-plane kernel (edgeconv_f16.hip)
+EDGECONV_F16_TWO_PLANE = True
+
+
+def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256), kernel=None, planes=False, v2=False):
     """xyz [B,N,3], idx int64 [B,N,k] -> pooled [B,N,sum(widths)] (channel-last).  planes=True (f16 kernel only): an
-    fp16 activation image of the pooled values instead (uint8 tensor), the x operand of pointwise_conv_f16."""
+    fp16 activation image of the pooled values instead (uint8 tensor), the x operand of pointwise_conv_f16.
+    v2: the packed block's two-plane copy is usable (EdgeConvParams.v2_ok) -> the f16 kernel is the two-plane one."""
+    v2 = bool(v2) and EDGECONV_F16_TWO_PLANE
     require_gpu(xyz_bn3, idx, packed)
     B, N, _ = xyz_bn3.shape
     k = idx.shape[2]
@@ -602,9 +612,10 @@ def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256), kernel=Non
             raise ValueError("planes output is produced by the f16 EdgeConv kernel only (k <= 20, 64/64/128/256)")
         out = torch.empty(lib().l3d_f16_act_bytes(B * N, sum(widths)), dtype=torch.uint8, device=xyz_bn3.device)
         args = (ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), ptr(out), 1, ptr(range_flag(xyz_bn3.device)), stream_ptr())
+        fn16 = lib().l3d_edgeconv_forward_f16b if v2 else lib().l3d_edgeconv_forward_f16
         with stage("edgeconv_kernel"):                   # the launch alone: a timing span here holds no Python between its
-            rc = lib().l3d_edgeconv_forward_f16(*args)   # first event and the kernel (bench.py's live roofline timing)
-        check(rc, "l3d_edgeconv_forward_f16")
+            rc = fn16(*args)                             # first event and the kernel (bench.py's live roofline timing)
+        check(rc, "l3d_edgeconv_forward_f16b" if v2 else "l3d_edgeconv_forward_f16")
         return out
     pooled = torch.empty((B, N, sum(widths)), dtype=torch.float32, device=xyz_bn3.device)
     if kernel is None:
@@ -614,7 +625,7 @@ def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256), kernel=Non
     if kernel != "lds" and (k > 20 or tuple(widths) != (64, 64, 128, 256)):
         kernel = "lds"
     if kernel == "f16":
-        fn, name = lib().l3d_edgeconv_forward_f16, "l3d_edgeconv_forward_f16"
+        fn, name = (lib().l3d_edgeconv_forward_f16b, "l3d_edgeconv_forward_f16b") if v2 else (lib().l3d_edgeconv_forward_f16, "l3d_edgeconv_forward_f16")
         args = (ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), ptr(pooled), 0, ptr(range_flag(xyz_bn3.device)), stream_ptr())
     elif kernel == "split":
         fn, name = lib().l3d_edgeconv_forward_split, "l3d_edgeconv_forward_split"

@@ -78,7 +78,7 @@ class DGCNN(torch.nn.Module):
             # f16x2 route: the EdgeConv kernel hands conv5 its input already split into fp16 planes (no fp32 pooled
             # tensor, no split pass); the EdgeConv kernel watches the fp16 range (_fused.run_guarded reads its verdict)
             with _fused.stage("edgeconv"):
-                pooled_img = _fused.edgeconv_forward(xyz, idx, packed, planes=True)         # dgcnn.py:34-46
+                pooled_img = _fused.edgeconv_forward(xyz, idx, packed, planes=True, v2=self._packed.v2_ok)   # dgcnn.py:34-46
             with _fused.stage("conv5"):
                 if _pooled:
                     return _fused.pointwise_conv_f16_pool(pooled_img, batch_size, num_points, w5_f16, 512, self.emb_dims,
@@ -86,7 +86,7 @@ class DGCNN(torch.nn.Module):
                 return _fused.pointwise_conv_f16(pooled_img, batch_size, num_points, w5_f16, 512, self.emb_dims,
                                                  s5, b5, relu=True)                         # dgcnn.py:48
         with _fused.stage("edgeconv"):
-            pooled = _fused.edgeconv_forward(xyz, idx, packed)      # dgcnn.py:34-46
+            pooled = _fused.edgeconv_forward(xyz, idx, packed, v2=self._packed.v2_ok)      # dgcnn.py:34-46
         with _fused.stage("conv5"):
             out = _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True,
                                         w_split=w5_split)                                   # dgcnn.py:48

@@ -14,6 +14,8 @@ from learning3d_amd import _lib
 C1, C2, C3, C4 = 64, 64, 128, 256
 # third weight copy (layers 2-4) for the bf16x3 kernel: [m][s][plane 3][lane 64][8 bf16] = 4 floats per fragment
 SPLIT_FLOATS = ((C2 // 16) * (C1 // 32) + (C3 // 16) * (C2 // 32) + (C4 // 16) * (C3 // 32)) * 3 * 64 * 4
+# fifth copy (two-plane f16x2 kernel): two-plane fragments + scaled biases of layers 2-4 + layer 1's scaled weights / bias + 16 constants
+V2_FLOATS = SPLIT_FLOATS // 3 * 2 + (C2 + C3 + C4) + 8 * C1 + C1 + 16
 MT = 5
 
 
@@ -75,7 +77,7 @@ def test_edgeconv_fragment_layout_and_row_mapping():
     shs = [rng.uniform(-0.2, 0.2, c).astype(np.float32) for c in (C1, C2, C3, C4)]
     n = lib.l3d_edgeconv_packed_floats(C1, C2, C3, C4)
     # v1 + chained + biases + bf16x3 planes + f16x2 planes (same size) + their scaled biases + 16 scale constants
-    assert n == 2 * (8 * C1 + C1 * C2 + C2 * C3 + C3 * C4) + C1 + C2 + C3 + C4 + 2 * SPLIT_FLOATS + (C2 + C3 + C4) + 16
+    assert n == 2 * (8 * C1 + C1 * C2 + C2 * C3 + C3 * C4) + C1 + C2 + C3 + C4 + 2 * SPLIT_FLOATS + (C2 + C3 + C4) + 16 + V2_FLOATS
     packed = np.zeros(n, np.float32)
     arr = lambda xs: (C.c_void_p * 4)(*[x.ctypes.data for x in xs])
     assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), C1, C2, C3, C4, packed.ctypes.data) == 0
@@ -130,7 +132,7 @@ def test_edgeconv_chained_register_layout():
     shs = [rng.uniform(-0.2, 0.2, c).astype(np.float32) for c in (C1, C2, C3, C4)]
     n = lib.l3d_edgeconv_packed_floats(C1, C2, C3, C4)
     v1 = 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4 + C1 + C2 + C3 + C4
-    assert n == v1 + 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4 + 2 * SPLIT_FLOATS + (C2 + C3 + C4) + 16
+    assert n == v1 + 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4 + 2 * SPLIT_FLOATS + (C2 + C3 + C4) + 16 + V2_FLOATS
     packed = np.zeros(n, np.float32)
     arr = lambda xs: (C.c_void_p * 4)(*[x.ctypes.data for x in xs])
     assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), C1, C2, C3, C4, packed.ctypes.data) == 0
@@ -394,7 +396,7 @@ def test_edgeconv_f16x2_pack():
     o4 = v1 + 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4 + SPLIT_FLOATS
     o_b4 = o4 + SPLIT_FLOATS
     o_sc = o_b4 + C2 + C3 + C4
-    assert o_sc + 16 == n
+    assert o_sc + 16 + V2_FLOATS == n
     sc = packed[o_sc:o_sc + 16].astype(np.float64)
     T = [12 - (int(np.floor(np.log2(m))) + 1) for m in mags]           # mag 2^T in [2^11, 2^12)
     assert all(2 ** 11 <= m * 2.0 ** t < 2 ** 12 for m, t in zip(mags, T))
@@ -430,3 +432,104 @@ def test_edgeconv_f16x2_pack():
             assert sc[l] == 2.0 ** (T[l] - A[l])
         assert sc[4 + l] == 2.0 ** (-A[l]) and sc[8 + l] == 2.0 ** (Tout - A[l])
     assert sc[12] == 2.0 ** (-Tout)
+
+
+def test_edgeconv_f16x2_two_plane_pack():
+    """The fifth packed copy (edgeconv_f16b.hip): two fp16 weight planes H = f16(W), M = f16(W - H) per fragment step with the
+    fourth copy's weight scaling (max|W| in [4,8)); the accumulators of layers 1-3 are the next layer's planes -- layer 1's fp32
+    weights / bias times 2^T_1, T_l = S_l + T_(l-1), T_1 such that the highest-placed layer's expected magnitude sits in
+    [2^11, 2^12) -- biases in accumulator units, the pooled-output constants, and the usability flag (a layer whose expected
+    magnitude would be placed below 2^4 clears it)."""
+    lib = _lib.lib()
+    rng = np.random.default_rng(5)
+    ws = [rng.standard_normal((C1, 6)).astype(np.float32), rng.standard_normal((C2, C1)).astype(np.float32) * 0.2,
+          rng.standard_normal((C3, C2)).astype(np.float32) * 0.05, rng.standard_normal((C4, C3)).astype(np.float32) * 3.0]
+    scs = [rng.uniform(0.5, 1.5, c).astype(np.float32) for c in (C1, C2, C3, C4)]
+    shs = [rng.uniform(-0.2, 0.2, c).astype(np.float32) for c in (C1, C2, C3, C4)]
+    arr = lambda xs: (C.c_void_p * 4)(*[x.ctypes.data for x in xs])
+    n = lib.l3d_edgeconv_packed_floats(C1, C2, C3, C4)
+    flag = lib.l3d_edgeconv_packed_v2_flag_index()
+    o5 = n - V2_FLOATS
+    assert flag == n - 16 + 13
+
+    def pack(mags):
+        packed = np.zeros(n, np.float32)
+        m = np.asarray(mags, np.float32)
+        assert lib.l3d_edgeconv_pack_mag(arr(ws), arr(scs), arr(shs), m.ctypes.data, C1, C2, C3, C4, packed.ctypes.data) == 0
+        return packed
+    mags = [3.0, 5.0, 0.7, 40.0]
+    packed = pack(mags)
+    assert packed[flag] == 1.0
+    e = [int(np.floor(np.log2(m))) + 1 for m in mags]                     # mag in [2^(e-1), 2^e)
+    folded = [(w * sc[:, None]).astype(np.float32) for w, sc in zip(ws, scs)]
+    S0 = [0] + [3 - (int(np.floor(np.log2(np.abs(f).max()))) + 1) for f in folded[1:]]
+    assert all(4 <= np.abs(f).max() * 2.0 ** s_ < 8 for f, s_ in zip(folded[1:], S0[1:]))
+
+    def place(S0, e):
+        """the packer's policy: T_1 puts the highest layer at 2^12; layers 2, 3 give up to two binades of weight scale each
+        until every layer's expected magnitude sits at >= 2^4"""
+        S = list(S0)
+        for _ in range(5):
+            cum = [0, S[1], S[1] + S[2]]
+            T1 = min(12 - e[l] - cum[l] for l in range(3))
+            T = [T1 + cum[l] for l in range(3)]
+            ok = min(e[l] + T[l] for l in range(3)) >= 4
+            if ok:
+                break
+            if S[2] > S0[2] - 2:
+                S[2] -= 1
+            elif S[1] > S0[1] - 2:
+                S[1] -= 1
+            else:
+                break
+        return S, T, ok
+    S, T, ok = place(S0, e)
+    assert ok and max(e[l] + T[l] for l in range(3)) == 12 and min(e[l] + T[l] for l in range(3)) >= 4
+    assert all(1 <= np.abs(f).max() * 2.0 ** s_ < 8 for f, s_ in zip(folded[1:], S[1:]))
+    A = [T[0], S[1] + T[0], S[2] + T[1], S[3] + T[2]]
+    assert A[1] == T[1] and A[2] == T[2]                                   # accumulator units = the next layer's plane units
+    lanes = np.arange(64)
+    j, g = lanes & 15, lanes >> 4
+    off = o5
+    frag_floats = [(C2 // 16) * (C1 // 32) * 2 * 64 * 4, (C3 // 16) * (C2 // 32) * 2 * 64 * 4, (C4 // 16) * (C3 // 32) * 2 * 64 * 4]
+    o_b = o5 + sum(frag_floats)
+    o_w1 = o_b + C2 + C3 + C4
+    o_b1 = o_w1 + 8 * C1
+    o_sc = o_b1 + C1
+    assert o_sc + 16 == n
+    boff = o_b
+    for li, (cin, cout) in enumerate([(C1, C2), (C2, C3), (C3, C4)], start=1):
+        S_, M_ = cin // 32, cout // 16
+        raw = packed[off:off + frag_floats[li - 1]].view(np.float16).reshape(M_ // 2, S_, 2, 2, 64, 8).transpose(0, 2, 1, 3, 4, 5).reshape(M_, S_, 2, 64, 8)
+        Wsc = folded[li].astype(np.float64) * 2.0 ** S[li]
+        for m in range(0, M_, max(1, M_ // 4)):
+            for s_ in range(S_):
+                for slot in range(8):
+                    oc = 16 * m + j
+                    ic = 32 * s_ + 16 * (slot >> 2) + 4 * g + (slot & 3)
+                    H, Mm = (raw[m, s_, p, :, slot].astype(np.float64) for p in range(2))
+                    np.testing.assert_array_equal(H, Wsc[oc, ic].astype(np.float16).astype(np.float64))
+                    assert np.all(np.abs(H + Mm - Wsc[oc, ic]) <= 2.0 ** -22 * np.abs(Wsc[oc, ic]) + 2.0 ** -25)
+        np.testing.assert_array_equal(packed[boff:boff + cout].astype(np.float64), shs[li].astype(np.float64) * 2.0 ** A[li])
+        off += frag_floats[li - 1]
+        boff += cout
+    # layer 1: the second copy's fragments and the bias, times 2^T_1
+    v1 = 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4 + C1 + C2 + C3 + C4
+    np.testing.assert_array_equal(packed[o_w1:o_w1 + 8 * C1], packed[v1:v1 + 8 * C1] * np.float32(2.0 ** T[0]))
+    np.testing.assert_array_equal(packed[o_b1:o_b1 + C1], shs[0] * np.float32(2.0 ** T[0]))
+    sc = packed[o_sc:o_sc + 16].astype(np.float64)
+    Tout = min(min(T), min(12 - x for x in e))
+    for l in range(4):
+        assert sc[4 + l] == 2.0 ** (-A[l]) and sc[8 + l] == 2.0 ** (Tout - A[l])
+    assert sc[12] == 2.0 ** (-Tout) and sc[0] == sc[1] == sc[2] == 1.0
+    # expected magnitudes so far apart that one layer would sit below 2^4: the flag drops (the host runs the three-plane kernel)
+    for bad in ([3.0, 3.0e6, 0.7, 40.0], [3.0, 5.0, 1.0e5, 40.0], [4e-3, 4.0, 4.0, 4.0]):
+        assert pack(bad)[flag] == 0.0 and not place(S0, [int(np.floor(np.log2(m))) + 1 for m in bad])[2]
+    # default-initialised DGCNN (max|w| ~ 1/8 in every layer, magnitudes 4): usable after lowering the weight scales
+    ws_d = [rng.uniform(-0.4, 0.4, (C1, 6)).astype(np.float32), rng.uniform(-0.125, 0.125, (C2, C1)).astype(np.float32),
+            rng.uniform(-0.125, 0.125, (C3, C2)).astype(np.float32), rng.uniform(-0.088, 0.088, (C4, C3)).astype(np.float32)]
+    ones = [np.ones(c, np.float32) for c in (C1, C2, C3, C4)]
+    packed = np.zeros(n, np.float32)
+    m4 = np.full(4, 4.0, np.float32)
+    assert lib.l3d_edgeconv_pack_mag(arr(ws_d), arr(ones), arr(shs), m4.ctypes.data, C1, C2, C3, C4, packed.ctypes.data) == 0
+    assert packed[flag] == 1.0

@@ -534,6 +534,11 @@ def test_edgeconv_all_kernels_agree_and_ragged():
             c = _fused.edgeconv_forward(x, idx, packed, kernel="chained")
             sp = _fused.edgeconv_forward(x, idx, packed, kernel="split")
             f16 = _fused.edgeconv_forward(x, idx, packed, kernel="f16")
+            # the two-plane kernel (edgeconv_f16b.hip) where its block is usable: BatchNorm magnitudes that say what the
+            # activations are (gain 1); with bn1 scaled by 1e-3 / 30 the later layers' magnitudes no longer follow from their own
+            # BatchNorm parameters, the packer marks the block unusable and the host runs the three-plane kernel
+            assert net._packed.v2_ok == (gain == 1.0), (gain, net._packed.v2_ok)
+            f16b = _fused.edgeconv_forward(x, idx, packed, kernel="f16", v2=net._packed.v2_ok)
             _fused.check_range(x.device, sync=True)
             # fp64 torch evaluation of dgcnn.py:32-46 on the same graph
             nb = torch.gather(x.unsqueeze(1).expand(B, N, N, 3), 2, idx.unsqueeze(-1).expand(B, N, k, 3))
@@ -549,8 +554,9 @@ def test_edgeconv_all_kernels_agree_and_ragged():
         np.testing.assert_allclose(c.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(sp.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(f16.cpu().numpy(), want, rtol=1e-4, atol=1e-5 * max(1.0, gain))
+        np.testing.assert_allclose(f16b.cpu().numpy(), want, rtol=1e-4, atol=1e-5 * max(1.0, gain))
         e_c = np.abs(c.cpu().numpy() - want64)
-        for name, got in (("bf16x3", sp), ("f16x2", f16)):
+        for name, got in (("bf16x3", sp), ("f16x2", f16), ("f16x2-two-plane", f16b)):
             e_s = np.abs(got.cpu().numpy() - want64)
             print(f"edgeconv {name} B={B} N={N} k={k} gain={gain}: max err {e_s.max():.3e} ({e_s.max() / e_c.max():.2f}x fp32-MFMA), "
                   f"rms {np.sqrt((e_s ** 2).mean()):.3e} ({np.sqrt((e_s ** 2).mean()) / np.sqrt((e_c ** 2).mean()):.2f}x)")
@@ -575,23 +581,25 @@ def test_edgeconv_f16_planes_output_equals_pooled():
     with torch.no_grad():
         idx = U.knn(x.permute(0, 2, 1), k)
         packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
-        pooled = _fused.edgeconv_forward(x, idx, packed, kernel="f16")
-        img = _fused.edgeconv_forward(x, idx, packed, planes=True)
-        _fused.check_range(sync=True)
-        raw = img.cpu().numpy()
-        pb = 64 * B * N * 16
-        h = raw[:pb].view(np.float16).reshape(64, B * N, 8).astype(np.float64)
-        m = raw[pb:2 * pb].view(np.float16).reshape(64, B * N, 8).astype(np.float64)
-        xinv = float(raw[2 * pb:2 * pb + 4].view(np.float32)[0])
-        dec = ((h + m / 4096.0) * xinv).transpose(1, 0, 2).reshape(B, N, 512)
-        want = pooled.cpu().numpy().astype(np.float64)
-        assert np.log2(xinv) == np.round(np.log2(xinv))                      # a power of two
-        np.testing.assert_allclose(dec, want, rtol=2.0 ** -22, atol=np.abs(want).max() * 2.0 ** -40)
-        w5, s5, b5, _, w5f = net._conv5_folded()
-        y1 = _fused.pointwise_conv_f16(img, B, N, w5f, 512, 256, s5, b5, relu=True)
-        y2 = _fused.pointwise_conv_f16(_fused.split_rows_f16(pooled), B, N, w5f, 512, 256, s5, b5, relu=True)
-        np.testing.assert_allclose(y1.cpu().numpy(), y2.cpu().numpy(), rtol=1e-5, atol=1e-6)
-        # and the model's own forward takes this route
+        for v2 in (False, True):                        # three-plane kernel, two-plane kernel (edgeconv_f16b.hip)
+            pooled = _fused.edgeconv_forward(x, idx, packed, kernel="f16", v2=v2)
+            img = _fused.edgeconv_forward(x, idx, packed, planes=True, v2=v2)
+            _fused.check_range(sync=True)
+            raw = img.cpu().numpy()
+            pb = 64 * B * N * 16
+            h = raw[:pb].view(np.float16).reshape(64, B * N, 8).astype(np.float64)
+            m = raw[pb:2 * pb].view(np.float16).reshape(64, B * N, 8).astype(np.float64)
+            xinv = float(raw[2 * pb:2 * pb + 4].view(np.float32)[0])
+            dec = ((h + m / 4096.0) * xinv).transpose(1, 0, 2).reshape(B, N, 512)
+            want = pooled.cpu().numpy().astype(np.float64)
+            assert np.log2(xinv) == np.round(np.log2(xinv))                      # a power of two
+            np.testing.assert_allclose(dec, want, rtol=2.0 ** -22, atol=np.abs(want).max() * 2.0 ** -40)
+            w5, s5, b5, _, w5f = net._conv5_folded()
+            y1 = _fused.pointwise_conv_f16(img, B, N, w5f, 512, 256, s5, b5, relu=True)
+            y2 = _fused.pointwise_conv_f16(_fused.split_rows_f16(pooled), B, N, w5f, 512, 256, s5, b5, relu=True)
+            np.testing.assert_allclose(y1.cpu().numpy(), y2.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        # and the model's own forward takes this route (the two-plane kernel by default)
+        assert net._packed.v2_ok and _fused.EDGECONV_F16_TWO_PLANE
         out = net(x)
         np.testing.assert_allclose(out.cpu().numpy(), y1.cpu().numpy(), rtol=0, atol=0)
 

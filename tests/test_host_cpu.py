@@ -40,7 +40,8 @@ def test_argument_validation_without_gpu():
     assert l.l3d_knn_graph(None, 1, 8, 4, None, None) == -1
     assert l.l3d_chamfer_forward(None, None, 1, 1, 1, None, None, None, None, None) == -1
     assert l.l3d_ball_query(1, 0, 1, 0.5, 4, None, None, None, None) == -1
-    assert l.l3d_edgeconv_packed_floats(64, 64, 128, 256) == 46080 + 45568 + 67584 + 67584 + 448 + 16   # + the f16x2 copy, its biases, 16 scales
+    # + the f16x2 copy, its biases, 16 scales; + the two-plane copy (2/3 of the planes), its biases, layer 1 scaled, 16 constants
+    assert l.l3d_edgeconv_packed_floats(64, 64, 128, 256) == 46080 + 45568 + 67584 + 67584 + 448 + 16 + (45056 + 448 + 512 + 64 + 16)
     assert l.l3d_edgeconv_packed_floats(32, 32, 64, 128) == 0
     # round-2 entry points: same contract (null / non-positive -> -1; shapes the kernels do not take -> -2, before any launch)
     import ctypes as C
@@ -325,6 +326,8 @@ def test_hot_kernels_compile_without_scratch():
     hot = {"_Z15conv_f16_kernelILb0ELb0ELb0EE": 224,         # conv5 / Linear layers (wide tile): VGPR budget 218 today
            "_Z15conv_f16_kernelILb1ELb0ELb0EE": 224,         # narrow tile
            "_Z19edgeconv_f16_kernelILi5ELb1EE": 512,
+           "_Z20edgeconv_f16b_kernelILi5ELb1EE": 512,       # the two-plane, persistent kernel of the benchmark step
+           "_Z20edgeconv_f16b_kernelILi5ELb0EE": 512,
            "_Z15knn_mfma_kernelILi8EE": 256,
            "_Z25chamfer_fwd_packed_kernel": 128,
            "_Z19fold_mlp_f16_kernelILi5EE": 256}

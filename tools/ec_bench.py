@@ -22,12 +22,16 @@ def main():
         packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
         ref = _fused.edgeconv_forward(x, idx, packed, kernel="chained")
         flop = B * N * k * 2 * (6 * 64 + 64 * 64 + 64 * 128 + 128 * 256)
-        for kern in sys.argv[1:] or ("f16", "split", "chained"):
-            out = _fused.edgeconv_forward(x, idx, packed, kernel=kern)
-            err = (out - ref).abs().max().item()
+        for kern in sys.argv[1:] or ("f16b", "f16b-planes", "f16", "f16-planes", "split", "chained"):
+            name, planes = (kern[:-7], True) if kern.endswith("-planes") else (kern, False)
+            kw = dict(kernel="f16", v2=True) if name == "f16b" else dict(kernel=name)
+            if planes:
+                kw = dict(planes=True, v2=kw.get("v2", False))
+            out = _fused.edgeconv_forward(x, idx, packed, **kw)
+            err = float("nan") if planes else (out - ref).abs().max().item()
             for _ in range(3):
-                t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, kernel=kern), warm=20, iters=100)
-            print(f"edgeconv {kern:8s} {t:8.1f} us  {flop / t / 1e6:7.1f} TFLOP/s fp32-equiv   max|diff vs chained| {err:.2e}")
+                t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, **kw), warm=20, iters=100)
+            print(f"edgeconv {kern:12s} {t:8.1f} us  {flop / t / 1e6:7.1f} TFLOP/s fp32-equiv   max|diff vs chained| {err:.2e}")
         _fused.check_range(x.device, sync=True)
 
 
