@@ -26,51 +26,10 @@
 // 16m + 4g + r of M-tile m; the B operand of k-step s is the pair of previous-layer accumulators (2s, 2s+1) of the
 // same lane after ReLU and the split: no LDS, no barriers, no cross-lane traffic.  The A operand is pre-split and
 // pre-permuted on the host (l3d_edgeconv_pack, fourth block) and streamed as 1 KB fragments.
-//
-// EF_V2 (edgeconv_f16b.hip includes this file with it set; entry point l3d_edgeconv_forward_f16b): the TWO-PLANE variant.
-//   * the residual is carried unscaled, m = f16(x - h): with the planes placed so that typical activations sit near 2^11
-//     (the packer's T_l), a subnormal residual costs 2^-25 ABSOLUTE in plane units -- below fp32's own rounding of any
-//     activation that matters to the sum -- so the Hs = H 2^-12 weight plane is not needed: products M h + H m + H h,
-//     two weight fragments per step instead of three (a third fewer global_load issues beside the MFMA stream);
-//   * accumulators of layers 1-3 come out in plane units (edgeconv_layout.h, fifth copy), so the split needs no scale
-//     and no v_fma_mix: v_cvt_pk_f16_f32 (gfx950) rounds the pair to h, two v_cvt_f32_f16 + two v_sub_f32 form the exact
-//     residuals, a second v_cvt_pk_f16_f32 rounds them to m -- six full-rate VALU instructions where the three-plane
-//     kernel issues six v_fma_mix* (measured ~2.4x the issue cost of a plain VALU beside the MFMA stream, LABLOG R2.2).
 #include <type_traits>
 #include "common.h"
 #include "edgeconv_layout.h"
 #include "split_bf16.h"      // f32x2 / f32x4 typedefs
-
-#ifndef EF_V2
-#define EF_V2 0
-#endif
-#if EF_V2
-#define EF_NPL 2
-#define EFO_W2 EC5_OFF_W2
-#define EFO_W3 EC5_OFF_W3
-#define EFO_W4 EC5_OFF_W4
-#define EFO_B2 EC5_OFF_B2
-#define EFO_B3 EC5_OFF_B3
-#define EFO_B4 EC5_OFF_B4
-#define EFO_SC EC5_OFF_SC
-#define EFO_W1 EC5_OFF_W1
-#define EFO_B1 EC5_OFF_B1
-#define EF_KERNEL edgeconv_f16b_kernel
-#define EF_ENTRY l3d_edgeconv_forward_f16b
-#else
-#define EF_NPL 3
-#define EFO_W2 EC4_OFF_W2
-#define EFO_W3 EC4_OFF_W3
-#define EFO_W4 EC4_OFF_W4
-#define EFO_B2 EC4_OFF_B2
-#define EFO_B3 EC4_OFF_B3
-#define EFO_B4 EC4_OFF_B4
-#define EFO_SC EC4_OFF_SC
-#define EFO_W1 EC2_OFF_W1
-#define EFO_B1 EC_OFF_B1
-#define EF_KERNEL edgeconv_f16_kernel
-#define EF_ENTRY l3d_edgeconv_forward_f16
-#endif
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -147,19 +106,6 @@ __device__ __forceinline__ float ef_dpp_max_x2(float give, float keep)
 __device__ __forceinline__ void ef_split_pair(float a0, float a1, float c, uint32_t &h, uint32_t &m)
 {
     float r0, r1;
-#if EF_V2
-    // accumulators are already in plane units (c == 1): round the pair, subtract the rounded halves back (exact), round the
-    // residuals.  s_nop: VALU write -> SDWA read of the same VGPR, not seen by the hazard recogniser inside asm.
-    float f0, f1;
-    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a0), "v"(a1));
-    asm volatile("v_cvt_f32_f16_e32 %0, %1" : "=v"(f0) : "v"(h));
-    asm volatile("s_nop 0\n\tv_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f1) : "v"(h));
-    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r0) : "v"(a0), "v"(f0));
-    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r1) : "v"(a1), "v"(f1));
-    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(m) : "v"(r0), "v"(r1));
-    (void)c;
-    return;
-#endif
     asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a0), "v"(c));
     asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(a1), "v"(c));
     asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a0), "v"(c), "v"(h));
@@ -299,7 +245,7 @@ __device__ __forceinline__ void ef_finish_all(f32x4 (&h)[2][MT], f16x8 (&pl)[2][
 #define EF_PD 4
 #endif
 struct EfRing {
-    u32x4 a[EF_PD][EF_NPL];  // fragments (H, Hs, M planes; EF_V2: H, M) of the next EF_PD steps
+    u32x4 a[EF_PD][3];       // fragments (H, Hs, M planes) of the next EF_PD steps
     f32x4 bv[2];             // bias (pre-scaled) of the current pair's two M-tiles
 };
 struct EfNext {              // where the pair executed after this one finds its fragments / bias
@@ -324,7 +270,7 @@ __device__ __forceinline__ void ef_ring_fill(EfRing &R, ef_rsrc_t rs, int woff, 
 #pragma unroll
     for (int d = 0; d < EF_PD; d++)
 #pragma unroll
-        for (int p = 0; p < EF_NPL; p++) R.a[d][p] = ef_ldfrag(rs, woff, (mp * steps + d) * EF_NPL + p, (unsigned)lane * 16u);
+        for (int p = 0; p < 3; p++) R.a[d][p] = ef_ldfrag(rs, woff, (mp * steps + d) * 3 + p, (unsigned)lane * 16u);
     R.bv[0] = *(const f32x4 *)(bias4g + 32 * mp);
     R.bv[1] = *(const f32x4 *)(bias4g + 32 * mp + 16);
 }
@@ -350,13 +296,13 @@ __device__ __forceinline__ void ef_pair(int mp, const EfNext &nx, const f16x8 (&
     ef_static_for<0, 2 * S>([&](auto rc) {
         // execution step r = 2 s + mm; fragment EF_PD steps ahead: inside this pair, or the first steps of the next
         constexpr int r = decltype(rc)::value, s = r >> 1, mm = r & 1;
-        u32x4 an[EF_NPL];
+        u32x4 an[3];
         if constexpr (r + EF_PD < 2 * S) {
 #pragma unroll
-            for (int p = 0; p < EF_NPL; p++) an[p] = ef_ldfrag(L.rs, woff, (mp * 2 * S + r + EF_PD) * EF_NPL + p, L.laneoff);
+            for (int p = 0; p < 3; p++) an[p] = ef_ldfrag(L.rs, woff, (mp * 2 * S + r + EF_PD) * 3 + p, L.laneoff);
         } else {
 #pragma unroll
-            for (int p = 0; p < EF_NPL; p++) an[p] = ef_ldfrag(L.rs, nx.woff, (nx.mp * nx.steps + (r + EF_PD - 2 * S)) * EF_NPL + p, L.laneoff);
+            for (int p = 0; p < 3; p++) an[p] = ef_ldfrag(L.rs, nx.woff, (nx.mp * nx.steps + (r + EF_PD - 2 * S)) * 3 + p, L.laneoff);
         }
         EF_PIN();
         if constexpr (s == S - 1 && mm == 0 && NSL < 2 * S * 3 * MT)
@@ -364,11 +310,7 @@ __device__ __forceinline__ void ef_pair(int mp, const EfNext &nx, const f16x8 (&
         // three products, smallest first (M h, Hs m', H h); MT independent accumulators between dependent MFMAs
         ef_static_for<0, 3>([&](auto pc) {
             constexpr int prod = decltype(pc)::value;
-#if EF_V2
-            constexpr int pa = prod == 0 ? 1 : 0;                                     // W plane: M  H  H   (packed H, M)
-#else
             constexpr int pa = prod == 0 ? 2 : (prod == 1 ? 1 : 0);                   // W plane: M  Hs H   (packed H, Hs, M)
-#endif
             constexpr int pb = prod == 1 ? 1 : 0;                                     // x plane: h  m' h
             ef_static_for<0, MT>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
@@ -398,7 +340,7 @@ __device__ __forceinline__ void ef_pair(int mp, const EfNext &nx, const f16x8 (&
             EF_PIN();
         }
 #pragma unroll
-        for (int p = 0; p < EF_NPL; p++) {
+        for (int p = 0; p < 3; p++) {
 #pragma unroll
             for (int d = 0; d + 1 < EF_PD; d++) R.a[d][p] = R.a[d + 1][p];
             R.a[EF_PD - 1][p] = an[p];
@@ -415,14 +357,11 @@ __device__ __forceinline__ void ef_pair(int mp, const EfNext &nx, const f16x8 (&
 // array is indexed by the pair): this workgroup starts at pair `rot`.
 // IN_RAW: accB on entry was produced by asm MFMAs (layers >= 2) rather than builtins (layer 1).
 // c_in / c_own: 2^-S of the previous layer (whose last pair is finished here) and of this layer; bias is pre-scaled.
-struct EfNoHook { __device__ __forceinline__ void operator()(int) const {} };
-
-template <int MT, int S, int NPAIR, bool LAST, bool UNROLL, bool IN_RAW, bool PLANES, class HOOK = EfNoHook>
+template <int MT, int S, int NPAIR, bool LAST, bool UNROLL, bool IN_RAW, bool PLANES>
 __device__ __forceinline__ void ef_layer(const f16x8 (&pin)[S][2][MT], f16x8 (&pout)[LAST ? 1 : NPAIR][2][MT],
                                          int woff, const float *bias4g, const EfNext &after, EfRing &R, int ch_own,
                                          f32x4 (&accA)[2][MT], f32x4 (&accB)[2][MT], int ch_in,
-                                         int *mp_out, const EfLane &L, int rot, const EfScale &c_in, const EfScale &c_own, float &ovf,
-                                         HOOK &&hook = EfNoHook())
+                                         int *mp_out, const EfLane &L, int rot, const EfScale &c_in, const EfScale &c_own, float &ovf)
 {
     static_assert(NPAIR % 2 == 0 && S >= 2, "pairs are processed two at a time; deferred finish needs S >= 2");
     constexpr int NS = 2 * S * 3 * MT, NSD = (S - 1) * 6 * MT;      // MFMA slots of a pair; of its k-steps 0 .. S-2
@@ -446,7 +385,6 @@ __device__ __forceinline__ void ef_layer(const f16x8 (&pin)[S][2][MT], f16x8 (&p
         int mpB = q1;                                                   // pair whose results sit in accB
 #pragma unroll 1
         for (int i = 2; i < NPAIR; i += 2) {
-            hook(i);                                                        // persistent kernel: the next tile's gather loads
             const int m0 = (i + rot) % NPAIR, m1 = (i + 1 + rot) % NPAIR, m2 = (i + 2 + rot) % NPAIR;
             ef_pair<MT, S, LAST, true, PLANES, NS>(m0, in_layer(m1), pin, last, woff, R, accA, accB, pout[0], ch_own + 32 * mpB, L, c_own, ovf);
             ef_pair<MT, S, LAST, true, PLANES, NS>(m1, i + 2 < NPAIR ? in_layer(m2) : after, pin, last, woff, R, accB, accA, pout[0],
@@ -459,62 +397,9 @@ __device__ __forceinline__ void ef_layer(const f16x8 (&pin)[S][2][MT], f16x8 (&p
 
 // PLANES = false: pooled [B*N][512] fp32 (channel-last).  PLANES = true: `pooled` is an fp16 activation image for
 // conv_f16.hip -- h | m' planes [512/8][B*N][8] of the pooled values times 2^T_out, then 2^-T_out (written here too).
-//
-// EF_PERSIST (default): one workgroup per CU walks the tiles (16 points each) with stride gridDim.x, and the gather of the
-// NEXT tile -- neighbour indices, then the coordinates they point to: two dependent trips to memory, ~4.9 k of a tile's
-// ~40 k cycles when they stood at the head of every workgroup with nothing to hide behind (tools/probe_ef.hip) -- is issued
-// from inside layer 4 of the current one (indices at its second pair, coordinates at its fourth) and consumed a tile later.
-// The weight ring is handed across tiles like across layers: layer 4's last pair prefetches layer 2's first fragments.
-// (the three-plane kernel, now the fallback, keeps one workgroup per tile: with its 36-register ring the prefetched gather spills)
-#ifndef EF_PERSIST
-#if defined(EF_TIMING) || !EF_V2
-#define EF_PERSIST 0
-#else
-#define EF_PERSIST 1
-#endif
-#endif
-
-template <int MT>
-struct EfGather {                      // what a lane needs of a tile before its first MFMA
-    long long nb[MT];                  // neighbour indices of its MT rows
-    float c[3];                        // its point's coordinates
-    float b1[MT][2];                   // layer 1's B operands (after the second trip)
-    int b, nc;
-};
-
-template <int MT>
-__device__ __forceinline__ void ef_gather_idx(EfGather<MT> &G, int tile, int tiles_per_cloud, int N, int k, const float *__restrict__ xyz,
-                                              const int64_t *__restrict__ idx, int wave, int j)
-{
-    const int b = tile / tiles_per_cloud, xb = tile - b * tiles_per_cloud;
-    const int n = (xb * 4 + wave) * 4 + (j >> 2);
-    const int nc = min(n, N - 1);                                   // lanes past N recompute point N-1
-    G.b = b;
-    G.nc = nc;
-    const float *pc = xyz + ((size_t)b * N + nc) * 3;
-    G.c[0] = pc[0]; G.c[1] = pc[1]; G.c[2] = pc[2];
-#pragma unroll
-    for (int t = 0; t < MT; t++) {
-        const int jj = 4 * t + (j & 3);
-        G.nb[t] = idx[((size_t)b * N + nc) * k + (jj < k ? jj : 0)];   // pad k up to 4*MT with a duplicate
-    }
-}
-
-template <int MT>
-__device__ __forceinline__ void ef_gather_xyz(EfGather<MT> &G, int N, const float *__restrict__ xyz, int g)
-{
-#pragma unroll
-    for (int t = 0; t < MT; t++) {
-        const float *pn = xyz + ((size_t)G.b * N + G.nb[t]) * 3;
-        const float nx = pn[0], ny = pn[1], nz = pn[2];
-        G.b1[t][0] = g == 0 ? nx : (g == 1 ? ny : (g == 2 ? nz : G.c[0]));
-        G.b1[t][1] = g == 0 ? G.c[1] : (g == 1 ? G.c[2] : 0.f);
-    }
-}
-
 template <int MT, bool PLANES>
-__global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xyz,
-                                                              const int64_t *__restrict__ idx, int B, int N, int k,
+__global__ __launch_bounds__(256, 1) void edgeconv_f16_kernel(const float *__restrict__ xyz,
+                                                              const int64_t *__restrict__ idx, int N, int k,
                                                               const float *packed,
                                                               float *__restrict__ pooled,
                                                               int *__restrict__ range_flag
@@ -533,7 +418,9 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
     constexpr int CTOT = EC_C1 + EC_C2 + EC_C3 + EC_C4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
-    const int tiles_per_cloud = (N + 15) / 16, ntiles = B * tiles_per_cloud;
+    const int b = blockIdx.y;
+    const int n = (blockIdx.x * 4 + wave) * 4 + (j >> 2);          // this lane's point
+    const int nc = min(n, N - 1);
     // pooled stores: after the transposing quad reduce lane q = j & 3 holds channel register {0,2,1,3}[q] of its point;
     // lanes past N recompute point N-1 and store the same bits to the same place
     EfLane L;
@@ -542,62 +429,46 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
     L.odd = j & 1;
     L.hi = j & 2;
     const int cl = 4 * g + ((j & 1) * 2 + ((j >> 1) & 1));       // this lane's channel inside a 16-channel M-tile
-    L.bn = (size_t)B * N;
-    if (PLANES && blockIdx.x == 0 && threadIdx.x == 0)
-        *(float *)((_Float16 *)pooled + 2 * 512 * L.bn) = packed[EFO_SC + 12];        // the image's 2^-T_out
+    L.prow = pooled + ((size_t)b * N + nc) * CTOT + cl;
+    L.bn = (size_t)gridDim.y * N;
+    L.ph = (_Float16 *)pooled + ((size_t)(cl >> 3) * L.bn + (size_t)b * N + nc) * 8 + (cl & 7);
+    if (PLANES && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        *(float *)((_Float16 *)pooled + 2 * 512 * L.bn) = packed[EC4_OFF_SC + 12];        // the image's 2^-T_out
     // power-of-two scales of the four layers' accumulators (uniform: scalar loads), see edgeconv_layout.h
     const int po = PLANES ? 8 : 4;
-    const EfScale s1 = {packed[EFO_SC + 0], packed[EFO_SC + po + 0]}, s2 = {packed[EFO_SC + 1], packed[EFO_SC + po + 1]},
-                  s3 = {packed[EFO_SC + 2], packed[EFO_SC + po + 2]}, s4 = {1.0f, packed[EFO_SC + po + 3]};
+    const EfScale s1 = {packed[EC4_OFF_SC + 0], packed[EC4_OFF_SC + po + 0]}, s2 = {packed[EC4_OFF_SC + 1], packed[EC4_OFF_SC + po + 1]},
+                  s3 = {packed[EC4_OFF_SC + 2], packed[EC4_OFF_SC + po + 2]}, s4 = {1.0f, packed[EC4_OFF_SC + po + 3]};
     float ovf = 0.f;
-    constexpr int w2 = EFO_W2 * 4, w3 = EFO_W3 * 4, w4 = EFO_W4 * 4;      // byte offsets inside the descriptor
-    const float *bs2 = packed + EFO_B2 + 4 * g, *bs3 = packed + EFO_B3 + 4 * g, *bs4 = packed + EFO_B4 + 4 * g;
-#ifndef EF_ROT
-#define EF_ROT 1
-#endif
-
-    int tile = blockIdx.x;
-    if (tile >= ntiles) return;
-    // the first tile's gather stands in the open; its index loads go out before the weight ring's so that the dependent
-    // coordinate loads do not queue behind 8 KB of fragments
-    EfGather<MT> G;
-    ef_gather_idx<MT>(G, tile, tiles_per_cloud, N, k, xyz, idx, wave, j);
-    EF_PIN();
-    // layer 2's first fragments and bias: requested before the gather's second trip so that their latency hides behind it
+    // layer 2's first fragments and bias: requested before the gather so that their latency hides behind it
     EfRing R;
-    ef_ring_fill(R, L.rs, EFO_W2 * 4, packed + EFO_B2 + 4 * g, 0, 2 * (EC_C1 / 32), lane);
+    ef_ring_fill(R, L.rs, EC4_OFF_W2 * 4, packed + EC4_OFF_B2 + 4 * g, 0, 2 * (EC_C1 / 32), lane);
     EF_PIN();
-    ef_gather_xyz<MT>(G, N, xyz, g);
-
-#if EF_PERSIST
-    for (; tile < ntiles; tile += gridDim.x) {
-#else
-    {
-#endif
-    const int b = G.b;
-    L.prow = pooled + ((size_t)b * N + G.nc) * CTOT + cl;
-    L.ph = (_Float16 *)pooled + ((size_t)(cl >> 3) * L.bn + (size_t)b * N + G.nc) * 8 + (cl & 7);
-    float b1[MT][2];
-#pragma unroll
-    for (int t = 0; t < MT; t++) { b1[t][0] = G.b1[t][0]; b1[t][1] = G.b1[t][1]; }
-#if EF_PERSIST
-    const int tile_next = tile + (int)gridDim.x;
-    const bool has_next = tile_next < ntiles;                    // uniform
-#endif
 
     // ---- layer 1 on the fp32 MFMA (as edgeconv2.hip): graph feature rows as B operands, k-step s,
     //      lane group g -> channel 4s + g of (neighbour xyz, centre xyz, 0, 0)          dgcnn.py:32
+    const float *pc = xyz + ((size_t)b * N + nc) * 3;
+    const float cx = pc[0], cy = pc[1], cz = pc[2];
+    float b1[MT][2];
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+        const int jj = 4 * t + (j & 3);
+        const int64_t nb = idx[((size_t)b * N + nc) * k + (jj < k ? jj : 0)];   // pad k up to 4*MT with a duplicate
+        const float *pn = xyz + ((size_t)b * N + nb) * 3;
+        const float nx = pn[0], ny = pn[1], nz = pn[2];
+        b1[t][0] = g == 0 ? nx : (g == 1 ? ny : (g == 2 ? nz : cx));
+        b1[t][1] = g == 0 ? cy : (g == 1 ? cz : 0.f);
+    }
     EF_T(1);
     f16x8 p1[EC_C1 / 32][2][MT];
     f32x4 accA[2][MT], accB[2][MT];                    // accB: the pair whose finish is pending
     {
-        const f32x2 *w1 = (const f32x2 *)(packed + EFO_W1);
+        const f32x2 *w1 = (const f32x2 *)(packed + EC2_OFF_W1);
 #pragma unroll
         for (int mp = 0; mp < EC_C1 / 32; mp++) {
 #pragma unroll
             for (int mm = 0; mm < 2; mm++) {
                 const int m = 2 * mp + mm;
-                const f32x4 bv = *(const f32x4 *)(packed + EFO_B1 + 16 * m + 4 * g);
+                const f32x4 bv = *(const f32x4 *)(packed + EC_OFF_B1 + 16 * m + 4 * g);
                 const f32x2 a = w1[m * 64 + lane];
 #pragma unroll
                 for (int t = 0; t < MT; t++) accB[mm][t] = bv;
@@ -613,7 +484,12 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
     int mp_last;
 
     EF_T(2);
-    const int rot = EF_ROT ? (int)(((unsigned)tile >> 3) % (EC_C4 / 32)) : 0;   // >>3: ids = XCD mod 8
+    constexpr int w2 = EC4_OFF_W2 * 4, w3 = EC4_OFF_W3 * 4, w4 = EC4_OFF_W4 * 4;      // byte offsets inside the descriptor
+    const float *bs2 = packed + EC4_OFF_B2 + 4 * g, *bs3 = packed + EC4_OFF_B3 + 4 * g, *bs4 = packed + EC4_OFF_B4 + 4 * g;
+#ifndef EF_ROT
+#define EF_ROT 1
+#endif
+    const int rot = EF_ROT ? (int)(((blockIdx.x + gridDim.x * blockIdx.y) >> 3) % (EC_C4 / 32)) : 0;   // >>3: ids = XCD mod 8
     // ---- layer 2: 64 -> 64   (its first pair hides the finish of layer 1's last pair, and so on down)
     f16x8 p2[EC_C2 / 32][2][MT];
     ef_layer<MT, EC_C1 / 32, EC_C2 / 32, false, true, false, PLANES>(
@@ -626,72 +502,39 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
         p2, p3, w3, bs3, EfNext{w4, bs4, rot, 2 * (EC_C3 / 32)}, R, EC_C1 + EC_C2, accA, accB,
         EC_C1 + 32 * (EC_C2 / 32 - 1), &mp_last, L, 0, s2, s3, ovf);
     EF_T(4);
-    // ---- layer 4: 128 -> 256, only max-pooled; its last pair prefetches layer 2's first fragments for the next tile
+    // ---- layer 4: 128 -> 256, only max-pooled
     f16x8 dummy[1][2][MT];
-#if EF_PERSIST
-    auto hook = [&](int i) {
-        if (has_next) {
-            if (i == 2) { ef_gather_idx<MT>(G, tile_next, tiles_per_cloud, N, k, xyz, idx, wave, j); EF_PIN(); }
-            if (i == 6) { ef_gather_xyz<MT>(G, N, xyz, g); EF_PIN(); }
-        }
-    };
-    ef_layer<MT, EC_C3 / 32, EC_C4 / 32, true, false, true, PLANES>(
-        p3, dummy, w4, bs4, EfNext{w2, bs2, 0, 2 * (EC_C1 / 32)}, R, EC_C1 + EC_C2 + EC_C3, accA, accB,
-        EC_C1 + EC_C2 + 32 * (EC_C3 / 32 - 1), &mp_last, L, rot, s3, s4, ovf, hook);
-#else
     ef_layer<MT, EC_C3 / 32, EC_C4 / 32, true, false, true, PLANES>(
         p3, dummy, w4, bs4, EfNext{w4, bs4, 0, 2 * (EC_C3 / 32)}, R, EC_C1 + EC_C2 + EC_C3, accA, accB,
         EC_C1 + EC_C2 + 32 * (EC_C3 / 32 - 1), &mp_last, L, rot, s3, s4, ovf);
-#endif
     asm volatile("s_nop 15\n\ts_nop 15");                       // the last asm MFMAs must have written accB (no compiler padding)
     ef_finish_all<MT, true, true, PLANES>(accB, dummy[0], EC_C1 + EC_C2 + EC_C3 + 32 * mp_last, L, s4, ovf);
     EF_T(5);
-    }
     // fp16 range guard: ovf = the largest value (in plane units) this lane handed to fp16 planes -- layers 1-3, and the
     // pooled planes when PLANES; activations are post-ReLU, so the pooled maxima are the maxima.  Not taken while the
     // activations stay within 16x of the magnitude the packer was told; the host re-runs on the bf16x3 kernel if it is.
     if (!(ovf <= 60000.f) && range_flag) *(volatile int *)range_flag = 1; // may live in mapped host memory: plain store
 #ifdef EF_TIMING
     if (threadIdx.x == 0)
-        for (int i = 0; i < 6; i++) tdbg[(size_t)blockIdx.x * 6 + i] = tk[i];
+        for (int i = 0; i < 6; i++) tdbg[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 6 + i] = tk[i];
 #endif
 }
 
 #ifndef EF_TIMING
-// workgroups to launch: one per CU (persistent), or one per tile
-static int ef_grid(int ntiles)
-{
-#if EF_PERSIST
-    static thread_local int cus[16] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    if (cus[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus[dev] = n;
-    }
-    return ntiles < cus[dev] ? ntiles : cus[dev];
-#else
-    return ntiles;
-#endif
-}
-
-extern "C" int EF_ENTRY(const float *xyz, const int64_t *idx, int B, int N, int k,
+extern "C" int l3d_edgeconv_forward_f16(const float *xyz, const int64_t *idx, int B, int N, int k,
                                         const float *packed, void *out, int out_mode, int *range_flag, l3d_stream_t stream)
 {
     L3D_REQUIRE(xyz && idx && packed && out && B > 0 && N > 0 && k > 0 && (out_mode == 0 || out_mode == 1));
     if (k > 20 || B > 65535 || (((size_t)packed) & 15) || (((size_t)out) & 15)) return L3D_ERR_UNSUPPORTED;
-    const long ntiles = (long)B * l3d_divup(N, 16);
-    if (ntiles > 0x7fffffffL / 2) return L3D_ERR_UNSUPPORTED;
-    dim3 grid(ef_grid((int)ntiles)), block(256);
+    dim3 grid(l3d_divup(N, 16), B), block(256);
     hipStream_t st = (hipStream_t)stream;
     float *o = (float *)out;
     if (out_mode == 0) {
-        if (k <= 16) hipLaunchKernelGGL((EF_KERNEL<4, false>), grid, block, 0, st, xyz, idx, B, N, k, packed, o, range_flag);
-        else              hipLaunchKernelGGL((EF_KERNEL<5, false>), grid, block, 0, st, xyz, idx, B, N, k, packed, o, range_flag);
+        if (k <= 16) hipLaunchKernelGGL((edgeconv_f16_kernel<4, false>), grid, block, 0, st, xyz, idx, N, k, packed, o, range_flag);
+        else              hipLaunchKernelGGL((edgeconv_f16_kernel<5, false>), grid, block, 0, st, xyz, idx, N, k, packed, o, range_flag);
     } else {
-        if (k <= 16) hipLaunchKernelGGL((EF_KERNEL<4, true>), grid, block, 0, st, xyz, idx, B, N, k, packed, o, range_flag);
-        else              hipLaunchKernelGGL((EF_KERNEL<5, true>), grid, block, 0, st, xyz, idx, B, N, k, packed, o, range_flag);
+        if (k <= 16) hipLaunchKernelGGL((edgeconv_f16_kernel<4, true>), grid, block, 0, st, xyz, idx, N, k, packed, o, range_flag);
+        else              hipLaunchKernelGGL((edgeconv_f16_kernel<5, true>), grid, block, 0, st, xyz, idx, N, k, packed, o, range_flag);
     }
     return l3d_check_launch();
 }

@@ -1,4 +1,727 @@
-// edgeconv_f16b.hip -- the two-plane f16x2 EdgeConv kernel: edgeconv_f16.hip compiled with EF_V2 (see its header),
-// entry point l3d_edgeconv_forward_f16b, parameters from the fifth packed copy (edgeconv_layout.h).
+// edgeconv_f16b.hip -- the TWO-PLANE, PERSISTENT f16x2 EdgeConv kernel (the default of the benchmark step); derived from
+// edgeconv_f16.hip (the three-plane kernel of round 2, kept unchanged as the fallback for parameter blocks whose plane
+// exponents cannot be chained, see edgeconv_layout.h "fifth copy").  Entry point l3d_edgeconv_forward_f16b.  What follows is
+// that file's description; the differences are listed under "EF_V2" below.
+//
+// the register-chained EdgeConv stack of edgeconv_split.hip with layers 2-4 as "f16x2":
+// every fp32 operand is carried as an fp16 HIGH part and a 2^12-SCALED fp16 residual, and one fp32 product costs
+// THREE fp16 MFMA products (half of bf16x3's six) at fp32-level accuracy.  models/dgcnn.py:32-46.
+//
+// Arithmetic (the error-corrected fp16 split of Ootomo & Yokota, IJHPCA 2022, adapted to the MFMA):
+//   activation x (fp32):  h = f16(x),  m' = f16((x - h) * 2^12)            -> x = h + m' 2^-12 up to 2^-22 |x| (worst case of two 11-bit roundings)
+//   weight     w (fp32):  W = w 2^S (S per layer, static, so that max|W| is in [4,8)),
+//                         H = f16(W),  M = f16(W - H),  Hs = f16(H 2^-12)  -> W = H + M up to 2^-22 |W|
+//   one accumulator:      acc = b 2^S + sum_k ( M h  +  Hs m'  +  H h )     = 2^S (b + w.x) up to the dropped
+//                         M m' 2^-12 term (2^-24 relative), every fp16 x fp16 product exact in the fp32 accumulator;
+//   epilogue:             y = max(acc, 0) 2^-S  (a power of two: exact).
+// Scaling the residual keeps it a NORMAL fp16 number whenever x is one (an unscaled residual of x < 0.25 is
+// subnormal and loses the bits it exists to carry); scaling the weights does the same for M.  CPU emulation
+// (K = 64..512, activations scaled 1e-3 .. 1e2): max error 0.5-1.1x, rms 0.7-1.2x of the fp32-MFMA kernel's own error
+// against fp64 (bf16x3: 0.7-1.1x / 0.7-0.9x); tests/test_gpu_parity.py holds this kernel to the same <= 2x / 1.5x bar.
+// Range: fp16 tops out at 65504.  Activations are post-ReLU, so the max-pooled outputs the kernel writes anyway ARE
+// the largest activations: each wave tracks their maximum and raises *range_flag if a layer-1..3 output exceeds
+// 60000 (results are then invalid; the host falls back to edgeconv_split.hip, whose bf16 planes have fp32's range).
+//
+// The split is 4 VALU instructions per value pair instead of bf16x3's 10: v_fma_mixlo/hi_f16 convert WITH the
+// power-of-two scale, v_fma_mix_f32 forms the residual straight from the packed fp16 halves.
+//
+// Chaining with v_mfma_f32_16x16x32_f16 is that of edgeconv_split.hip: every layer transposed,
+// D[ch][row] = sum_k W'[ch][k] act[row][k], weights = A operand, activations = B operand, one wave
+// owns MT row tiles of 16 rows (4 points x 4*MT neighbours); lane (j = row, g) register r holds channel
+// 16m + 4g + r of M-tile m; the B operand of k-step s is the pair of previous-layer accumulators (2s, 2s+1) of the
+// same lane after ReLU and the split: no LDS, no barriers, no cross-lane traffic.  The A operand is pre-split and
+// pre-permuted on the host (l3d_edgeconv_pack, fourth block) and streamed as 1 KB fragments.
+//
+// EF_V2 (always set in this file): the TWO-PLANE variant.
+//   * the residual is carried unscaled, m = f16(x - h): with the planes placed so that typical activations sit near 2^11
+//     (the packer's T_l), a subnormal residual costs 2^-25 ABSOLUTE in plane units -- below fp32's own rounding of any
+//     activation that matters to the sum -- so the Hs = H 2^-12 weight plane is not needed: products M h + H m + H h,
+//     two weight fragments per step instead of three (a third fewer global_load issues beside the MFMA stream);
+//   * accumulators of layers 1-3 come out in plane units (edgeconv_layout.h, fifth copy), so the split needs no scale
+//     and no v_fma_mix: v_cvt_pk_f16_f32 (gfx950) rounds the pair to h, two v_cvt_f32_f16 + two v_sub_f32 form the exact
+//     residuals, a second v_cvt_pk_f16_f32 rounds them to m -- six full-rate VALU instructions where the three-plane
+//     kernel issues six v_fma_mix* (measured ~2.4x the issue cost of a plain VALU beside the MFMA stream, LABLOG R2.2).
+#include <type_traits>
+#include "common.h"
+#include "edgeconv_layout.h"
+#include "split_bf16.h"      // f32x2 / f32x4 typedefs
+
 #define EF_V2 1
-#include "edgeconv_f16.hip"
+// EF_W4_LDS (two-plane persistent kernel): layer 4's weight fragments (128 KB as two planes) are copied to LDS once per
+// workgroup and read from there by every tile -- a ds_read_b128 beside the MFMA stream costs about half of a
+// global_load_dwordx4 (LABLOG R2.2: +19 vs +43 cycles per 5 MFMAs) and layer 4 issues 128 of them per tile.
+#ifndef EF_W4_LDS
+#if !defined(EF_TIMING)
+#define EF_W4_LDS 1
+#else
+#define EF_W4_LDS 0
+#endif
+#endif
+#define EF_W4_BYTES ((EC_C4 / 16) * (EC_C3 / 32) * 2 * 1024)
+#define EF_NPL 2
+#define EFO_W2 EC5_OFF_W2
+#define EFO_W3 EC5_OFF_W3
+#define EFO_W4 EC5_OFF_W4
+#define EFO_B2 EC5_OFF_B2
+#define EFO_B3 EC5_OFF_B3
+#define EFO_B4 EC5_OFF_B4
+#define EFO_SC EC5_OFF_SC
+#define EFO_W1 EC5_OFF_W1
+#define EFO_B1 EC5_OFF_B1
+#define EF_KERNEL edgeconv_f16b_kernel
+#define EF_ENTRY l3d_edgeconv_forward_f16b
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct EfBase { const char *p; };     // the packed parameter block
+typedef __attribute__((address_space(3))) const char *ef_lds_t;
+typedef EfBase ef_rsrc_t;
+
+// ---------------------------------------------------------------------------------------------
+// Register homes.  With __launch_bounds__(256, 1) hipcc selects the AGPR form of every MFMA builtin: accumulators
+// live in AGPRs and each value the finish work touches costs a v_accvgpr_read first -- measured at ~15 cycles apiece
+// beside the MFMA stream (4.7 k of layer 4's 22 k cycles went on moving accumulators, tools/probe_ef.hip).  The dense
+// layers therefore issue their MFMAs as volatile inline asm with the homes fixed by constraints:
+//     accumulators  VGPRs ("+v")  -- the finish VALU reads and writes them in place, no copies;
+//     B operands    AGPRs ("a")   -- the split activation planes are only ever MFMA operands (<= 240 registers);
+//     A operands    VGPRs ("v")   -- weight fragments arrive by global_load.
+// Volatile asm statements keep their program order, so the interleave of finish work and MFMAs below is the issue
+// order; the compiler still places the fragment loads, address arithmetic and s_waitcnt (asm operands are uses).
+// What it no longer does is pad MFMA hazards: every read of an accumulator by VALU code is >= 5 MFMAs after the
+// MFMA that wrote it (see the unit order), and the two places where that does not hold by construction carry s_nop.
+// ---------------------------------------------------------------------------------------------
+#ifndef EF_AHOME
+#define EF_AHOME 1          // weight fragments (MFMA A operand): 0 = VGPRs, 1 = AGPRs (global_load writes them directly)
+#endif
+#if EF_AHOME
+#define EF_ACON "a"
+#else
+#define EF_ACON "v"
+#endif
+__device__ __forceinline__ void ef_mfma_init(f32x4 &d, const u32x4 &a, const f16x8 &b, const f32x4 &c)
+{
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=&v"(d) : EF_ACON(a), "a"(b), "v"(c));
+}
+__device__ __forceinline__ void ef_mfma_acc(f32x4 &d, const u32x4 &a, const f16x8 &b)
+{
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : EF_ACON(a), "a"(b));
+}
+// a freshly split 16-byte fragment -> an AGPR tuple, once, at its creation
+__device__ __forceinline__ f16x8 ef_home_agpr(u32x4 v)
+{
+    f16x8 r = __builtin_bit_cast(f16x8, v);
+    asm("" : "+a"(r));
+    return r;
+}
+
+// VALU written out (volatile: issue position = program position)
+__device__ __forceinline__ float ef_vmax(float a, float b)
+{
+    float r;
+    asm volatile("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float ef_vmax3(float a, float b, float c)
+{
+    float r;
+    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// d[lane] = max(give[lane ^ 1], keep[lane]) / (lane ^ 2).  The s_nop covers the VALU-write -> DPP-read hazard (2 wait
+// states) that the compiler's hazard recogniser does not see inside inline asm.
+__device__ __forceinline__ float ef_dpp_max_x1(float give, float keep)
+{
+    float r;
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(give), "v"(keep));
+    return r;
+}
+__device__ __forceinline__ float ef_dpp_max_x2(float give, float keep)
+{
+    float r;
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(give), "v"(keep));
+    return r;
+}
+
+// relu'd accumulators (scaled domain: a = 2^S y) of one value pair -> packed fp16 (h, m') words of y = a c:
+//   h = f16(a c) (c = 2^-S: the product is exact, one rounding), r = a c - h (exact), m' = f16(r 2^12)
+__device__ __forceinline__ void ef_split_pair(float a0, float a1, float c, uint32_t &h, uint32_t &m)
+{
+    float r0, r1;
+    // accumulators are already in plane units (c == 1): round the pair, subtract the rounded halves back (exact), round the
+    // residuals.  s_nop: VALU write -> SDWA read of the same VGPR, not seen by the hazard recogniser inside asm.
+    float f0, f1;
+    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a0), "v"(a1));
+    asm volatile("v_cvt_f32_f16_e32 %0, %1" : "=v"(f0) : "v"(h));
+    asm volatile("s_nop 0\n\tv_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f1) : "v"(h));
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r0) : "v"(a0), "v"(f0));
+    asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r1) : "v"(a1), "v"(f1));
+    asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(m) : "v"(r0), "v"(r1));
+    (void)c;
+    return;
+    asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a0), "v"(c));
+    asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(a1), "v"(c));
+    asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a0), "v"(c), "v"(h));
+    asm volatile("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(a1), "v"(c), "v"(h));
+    asm volatile("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(m) : "v"(r0), "s"(4096.0f));
+    asm volatile("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(m) : "v"(r1), "s"(4096.0f));
+}
+
+// Lane-constant context of the pooled stores.  q = lane & 3 (neighbour slot inside the quad); after the transposing
+// quad reduce lane q holds channel register {0,2,1,3}[q] of its point, and stores it to pooled[point][ch0 + 4g + that].
+struct EfLane {
+    bool odd, hi;            // q & 1, q & 2
+    unsigned laneoff;        // lane * 16: byte offset of the lane's 16 bytes inside a 1 KB fragment
+    ef_rsrc_t rs;            // the packed parameter block
+    ef_lds_t w4lds;          // EF_W4_LDS: layer 4's fragment block in LDS
+    float *prow;             // out_mode 0: pooled + (b N + point) CTOT + 4 g + {0,2,1,3}[q]
+    _Float16 *ph;            // out_mode 1: the h plane's cell of (this lane's channel within a 16-channel M-tile, its point)
+    size_t bn;               // B N: channel ch0 + 16 k lies (ch0 + 16 k) * bn halfs further, the m' plane 512 * bn beyond that
+};
+
+// Power-of-two scales of one layer's accumulators (edgeconv_layout.h): to its split planes, to the pooled output
+struct EfScale {
+    float split, pool;
+};
+
+// Scratch values that live from one micro-unit to the next
+struct EfTmp {
+    f32x4 mx[2];             // max over the row tiles, per M-tile
+    u32x4 qh, qm;            // the 16-byte h / m' fragments being assembled for one row tile
+    f32x2 xs[2];             // quad reduce, after its first step
+};
+
+// ---------------------------------------------------------------------------------------------
+// The finish work of a completed M-tile pair (ReLU, two-plane split, max-pool) as MICRO-UNITS of 2-8 VALU instructions,
+// issued one by one between the MFMAs of the next pair (with one wave per SIMD nothing else hides VALU work):
+//   not LAST:  per row tile t: [relu h0[t]] [relu h1[t]] [split pair 0] [1] [2] [3 + the two fragments -> AGPRs]
+//              then 8 x [pool one register of one M-tile], 2 x ([quad reduce, step 1] [step 2 + store])  = 6 MT + 12
+//   LAST:      the 8 pool and 4 quad units on the raw accumulators, ReLU on the one pooled value per lane      = 12
+// ORDER is the MFMA -> VALU hazard cover: the first units touch M-tile 0 only (finished a whole step earlier);
+// h1[MT-1], written by the pair's very last MFMA, is first read by unit 6 (MT-1) + 1 resp. pool unit 4.
+// The quad reduce is a transposing butterfly: 4 registers x 4 lanes -> ONE value per lane in 3 DPP max (+6 selects),
+// and every lane stores its dword -- no `if (writer)` exec-mask branch.
+// RAW = false (layer 1's accumulators come from MFMA builtins, straight after them): the first reader of every
+// accumulator is a compiler-visible instruction, so the compiler pads the hazard.
+// ---------------------------------------------------------------------------------------------
+template <int MT, bool LAST> struct EfN { static constexpr int UNITS = LAST ? 12 : 6 * MT + 12; };
+
+template <int MT, bool LAST, bool RAW, bool PLANES, int U>
+__device__ __forceinline__ void ef_micro(f32x4 (&h)[2][MT], f16x8 (&pl)[2][MT], EfTmp &T, int ch0, const EfLane &L, const EfScale &sc, float &ovf)
+{
+    const float c = sc.split;
+    constexpr int NT = LAST ? 0 : 6 * MT;                    // units before the pool units
+    if constexpr (U < NT) {
+        constexpr int t = U / 6, k = U % 6;
+        if constexpr (k < 2) {                               // relu of M-tile k, row tile t
+#pragma unroll
+            for (int r = 0; r < 4; r++) h[k][t][r] = RAW ? ef_vmax(h[k][t][r], 0.f) : fmaxf(h[k][t][r], 0.f);
+        } else {                                             // split value pair k-2 of the (M-tile pair, row tile t) fragment
+            constexpr int i = k - 2;
+            uint32_t a, b;
+            ef_split_pair(h[i >> 1][t][2 * (i & 1)], h[i >> 1][t][2 * (i & 1) + 1], c, a, b);
+            T.qh[i] = a;
+            T.qm[i] = b;
+            if constexpr (i == 3) {                          // whole 16-byte fragments, homed in AGPRs: the type the MFMA reads
+                pl[0][t] = ef_home_agpr(T.qh);
+                pl[1][t] = ef_home_agpr(T.qm);
+            }
+        }
+    } else if constexpr (U < NT + 8) {                       // max over the row tiles (= 4 MT neighbours), one register
+        constexpr int k = (U - NT) / 4, r = (U - NT) % 4;
+        static_assert(MT >= 3 && MT <= 5, "row tiles per wave");
+        if constexpr (RAW) {
+            float m = ef_vmax3(h[k][0][r], h[k][1][r], h[k][2][r]);
+            if constexpr (MT == 4) m = ef_vmax(m, h[k][3][r]);
+            if constexpr (MT == 5) m = ef_vmax3(m, h[k][3][r], h[k][4][r]);
+            T.mx[k][r] = m;
+        } else {
+            float m = h[k][0][r];
+#pragma unroll
+            for (int t = 1; t < MT; t++) m = fmaxf(m, h[k][t][r]);
+            T.mx[k][r] = m;
+        }
+    } else {                                                 // transposing quad reduce, ReLU (LAST), scale, store
+        constexpr int k = (U - NT - 8) / 2, part = (U - NT - 8) % 2;
+        if constexpr (part == 0) {
+            const float k0 = L.odd ? T.mx[k][2] : T.mx[k][0], g0 = L.odd ? T.mx[k][0] : T.mx[k][2];
+            const float k1 = L.odd ? T.mx[k][3] : T.mx[k][1], g1 = L.odd ? T.mx[k][1] : T.mx[k][3];
+            T.xs[k][0] = ef_dpp_max_x1(g0, k0);
+            T.xs[k][1] = ef_dpp_max_x1(g1, k1);
+        } else {
+            const float kk = L.hi ? T.xs[k][1] : T.xs[k][0], gg = L.hi ? T.xs[k][0] : T.xs[k][1];
+            float v = ef_dpp_max_x2(gg, kk);
+            if constexpr (LAST) v = ef_vmax(v, 0.f);         // non-LAST values were ReLU'd before pooling
+            if constexpr (!LAST) ovf = ef_vmax(ovf, v * sc.split);   // in plane units: what the next layer's fp16 planes hold
+            v *= sc.pool;
+            if constexpr (PLANES) {                          // pooled output as fp16 planes (times 2^T_out) for conv_f16.hip
+                ovf = ef_vmax(ovf, v);
+                const _Float16 hh = (_Float16)v;
+                const _Float16 mm = (_Float16)((v - (float)hh) * 4096.0f);
+                _Float16 *d = L.ph + (size_t)(ch0 + 16 * k) * L.bn;
+                d[0] = hh;
+                d[(size_t)512 * L.bn] = mm;
+            } else {
+                L.prow[ch0 + 16 * k] = v;
+            }
+        }
+    }
+}
+
+// Compile-time loops: every register-array index in this file must be a constant, and `#pragma unroll`
+// is only a request (bodies this large exceed the unroller's pragma threshold, the loop stays rolled,
+// the index becomes dynamic and the accumulators / planes land in scratch memory).
+template <int I0, int I1, class F>
+__device__ __forceinline__ void ef_static_for(F &&f)
+{
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        ef_static_for<I0 + 1, I1>(f);
+    }
+}
+
+template <int MT, bool LAST, bool RAW, bool PLANES>
+__device__ __forceinline__ void ef_finish_all(f32x4 (&h)[2][MT], f16x8 (&pl)[2][MT], int ch0, const EfLane &L, const EfScale &sc, float &ovf)
+{
+    EfTmp T;
+    ef_static_for<0, EfN<MT, LAST>::UNITS>([&](auto u) { ef_micro<MT, LAST, RAW, PLANES, decltype(u)::value>(h, pl, T, ch0, L, sc, ovf); });
+}
+
+// EF_PIN: the compiler's IR passes sink a load towards its first use (two steps later) regardless of
+// sched_barrier, which collapses the prefetch distance; a memory clobber right after the issue pins it
+// (the fragment pointer is deliberately NOT __restrict__, or the clobber would not order the load).
+#define EF_PIN() asm volatile("" ::: "memory")
+
+// Weight fragments are prefetched EF_PD execution steps ahead into a ring of registers that is handed from pair to
+// pair and from layer to layer.  A step is only 3 x MT MFMAs (~250 cycles): two steps ahead (what the bf16x3 kernel,
+// with 6 x MT MFMAs per step, gets away with) is less than an L2 hit under load and stalled every step.
+#ifndef EF_PD
+#define EF_PD 4
+#endif
+struct EfRing {
+    u32x4 a[EF_PD][EF_NPL];  // fragments (H, Hs, M planes; EF_V2: H, M) of the next EF_PD steps
+    f32x4 bv[2];             // bias (pre-scaled) of the current pair's two M-tiles
+};
+struct EfNext {              // where the pair executed after this one finds its fragments / bias
+    int woff;                // byte offset of the layer's fragment block inside the packed parameters
+    const float *bias;       // layer's scaled bias + 4 g
+    int mp;                  // pair index inside that layer
+    int steps;               // 2 S of that layer
+};
+
+// fragment `frag` (1 KB each) of the layer block at byte offset `byte_off` of the packed parameters.
+// Measured alternatives for the addressing (tools/probe_ef.hip, layer 4): plain pointers as here 19.9 k cycles (the
+// compiler spends ~50 VALU per 240 MFMAs on 64-bit address arithmetic); a buffer descriptor with scalar offsets
+// (no VALU at all) 20.9 k -- the cost beside the MFMAs is the issue of the load itself (one global_load_dwordx4 per
+// 5 MFMAs costs the stream ~40 cycles, tools/probe_mfma_filler.hip), not its address.
+__device__ __forceinline__ u32x4 ef_ldfrag(ef_rsrc_t rs, int byte_off, int frag, unsigned laneoff)
+{
+    return *(const u32x4 *)(rs.p + (size_t)byte_off + (size_t)frag * 1024 + laneoff);
+}
+
+__device__ __forceinline__ u32x4 ef_ldfrag_lds(ef_lds_t base, int frag, unsigned laneoff)
+{
+    return *(__attribute__((address_space(3))) const u32x4 *)(base + frag * 1024 + laneoff);
+}
+
+__device__ __forceinline__ void ef_ring_fill(EfRing &R, ef_rsrc_t rs, int woff, const float *bias4g, int mp, int steps, int lane)
+{
+#pragma unroll
+    for (int d = 0; d < EF_PD; d++)
+#pragma unroll
+        for (int p = 0; p < EF_NPL; p++) R.a[d][p] = ef_ldfrag(rs, woff, (mp * steps + d) * EF_NPL + p, (unsigned)lane * 16u);
+    R.bv[0] = *(const f32x4 *)(bias4g + 32 * mp);
+    R.bv[1] = *(const f32x4 *)(bias4g + 32 * mp + 16);
+}
+
+// One output M-tile pair of a dense layer: 2 x S steps (k-step outer, M-tile inner -- the order the
+// fragments are packed in) of {prefetch fragment step+EF_PD, 3 products x MT MFMAs}, with one micro-unit of the finish
+// of a PREVIOUS pair (hp) after each of the first NSL MFMAs.  That previous pair is the preceding pair of this layer
+// (NSL = every MFMA slot) or, for a layer's first pair, the LAST pair of the previous layer, whose planes are this
+// layer's k-step S-1: its units then ride on the MFMAs of k-steps 0 .. S-2 only and are complete (plus an s_nop for
+// the accvgpr-write -> MFMA-read hazard) before the first MFMA that reads them.
+// mp = this pair; nx = the pair executed after it, in this layer or the first of the next (fragment and bias
+// prefetches cross both boundaries); pairs may be executed in any order.  R.bv: this pair's bias (the MFMA C operand of
+// each M-tile's first product); replaced by the next pair's on return.  c_prev: 2^-S of hp's layer.
+template <int MT, int S, bool PREV_LAST, bool PREV_RAW, bool PLANES, int NSL, bool OWN_LDS = false, bool NX_LDS = false>
+__device__ __forceinline__ void ef_pair(int mp, const EfNext &nx, const f16x8 (&pin)[S][2][MT], const f16x8 (&pin_last)[2][MT],
+                                        int woff, EfRing &R,
+                                        f32x4 (&acc)[2][MT], f32x4 (&hp)[2][MT], f16x8 (&po_prev)[2][MT],
+                                        int ch_prev, const EfLane &L, const EfScale &c_prev, float &ovf)
+{
+    static_assert(2 * S >= EF_PD, "a pair is at least EF_PD steps long");
+    constexpr int NU = EfN<MT, PREV_LAST>::UNITS;                    // micro-units to hide
+    EfTmp T;
+    ef_static_for<0, 2 * S>([&](auto rc) {
+        // execution step r = 2 s + mm; fragment EF_PD steps ahead: inside this pair, or the first steps of the next
+        constexpr int r = decltype(rc)::value, s = r >> 1, mm = r & 1;
+        u32x4 an[EF_NPL];
+        if constexpr (r + EF_PD < 2 * S) {
+#pragma unroll
+            for (int p = 0; p < EF_NPL; p++)
+                an[p] = OWN_LDS ? ef_ldfrag_lds(L.w4lds, (mp * 2 * S + r + EF_PD) * EF_NPL + p, L.laneoff)
+                                : ef_ldfrag(L.rs, woff, (mp * 2 * S + r + EF_PD) * EF_NPL + p, L.laneoff);
+        } else {
+#pragma unroll
+            for (int p = 0; p < EF_NPL; p++)
+                an[p] = NX_LDS ? ef_ldfrag_lds(L.w4lds, (nx.mp * nx.steps + (r + EF_PD - 2 * S)) * EF_NPL + p, L.laneoff)
+                               : ef_ldfrag(L.rs, nx.woff, (nx.mp * nx.steps + (r + EF_PD - 2 * S)) * EF_NPL + p, L.laneoff);
+        }
+        EF_PIN();
+        if constexpr (s == S - 1 && mm == 0 && NSL < 2 * S * 3 * MT)
+            asm volatile("s_nop 7");                                  // pin_last was written by v_accvgpr_write just now
+        // three products, smallest first (M h, Hs m', H h); MT independent accumulators between dependent MFMAs
+        ef_static_for<0, 3>([&](auto pc) {
+            constexpr int prod = decltype(pc)::value;
+            constexpr int pa = prod == 0 ? 1 : 0;                                     // W plane: M  H  H   (packed H, M)
+            constexpr int pb = prod == 1 ? 1 : 0;                                     // x plane: h  m' h
+            ef_static_for<0, MT>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                const f16x8 &bop = s == S - 1 ? pin_last[pb][t] : pin[s][pb][t];
+                if constexpr (s == 0 && prod == 0) ef_mfma_init(acc[mm][t], R.a[0][pa], bop, R.bv[mm]);
+                else ef_mfma_acc(acc[mm][t], R.a[0][pa], bop);
+                constexpr int slot = (r * 3 + prod) * MT + t;
+#ifdef EF_NOFINISH                                                     // timing experiment: accumulators kept alive, no finish work
+                if constexpr (slot == 0) {
+#pragma unroll
+                    for (int kk = 0; kk < 2; kk++)
+#pragma unroll
+                        for (int tt = 0; tt < MT; tt++) asm volatile("" ::"v"(hp[kk][tt]));
+                }
+                if constexpr (false)
+#else
+                if constexpr (slot < NSL)
+#endif
+                    ef_static_for<slot * NU / NSL, (slot + 1) * NU / NSL>([&](auto u) {
+                        ef_micro<MT, PREV_LAST, PREV_RAW, PLANES, decltype(u)::value>(hp, po_prev, T, ch_prev, L, c_prev, ovf);
+                    });
+            });
+        });
+        if constexpr (r == 1) {                                       // both M-tiles have consumed their bias: fetch the next pair's
+            R.bv[0] = *(const f32x4 *)(nx.bias + 32 * nx.mp);
+            R.bv[1] = *(const f32x4 *)(nx.bias + 32 * nx.mp + 16);
+            EF_PIN();
+        }
+#pragma unroll
+        for (int p = 0; p < EF_NPL; p++) {
+#pragma unroll
+            for (int d = 0; d + 1 < EF_PD; d++) R.a[d][p] = R.a[d + 1][p];
+            R.a[EF_PD - 1][p] = an[p];
+        }
+    });
+}
+
+// One dense layer: S input k-steps (32 channels each, planes in pin), NPAIR output M-tile pairs,
+// software-pipelined over pairs (accumulators double-buffered: pair i's MFMAs hide pair i-1's finish).
+// On entry accB holds the previous layer's last, unfinished pair (its planes are pin[S-1], its pooled
+// output goes to channel ch_in) and R the fragments / bias of this layer's first pair; on return accB holds THIS
+// layer's last unfinished pair (pair index *mp_out) and R what `after` (the next layer's first pair) needs.
+// wl: [step = (pair*S + s)*2 + mm][plane][lane] fragments.  rot (only for the rolled LAST layer, where no register
+// array is indexed by the pair): this workgroup starts at pair `rot`.
+// IN_RAW: accB on entry was produced by asm MFMAs (layers >= 2) rather than builtins (layer 1).
+// c_in / c_own: 2^-S of the previous layer (whose last pair is finished here) and of this layer; bias is pre-scaled.
+struct EfNoHook { __device__ __forceinline__ void operator()(int) const {} };
+
+template <int MT, int S, int NPAIR, bool LAST, bool UNROLL, bool IN_RAW, bool PLANES, class HOOK = EfNoHook, bool OWN_LDS = false, bool AFTER_LDS = false>
+__device__ __forceinline__ void ef_layer(const f16x8 (&pin)[S][2][MT], f16x8 (&pout)[LAST ? 1 : NPAIR][2][MT],
+                                         int woff, const float *bias4g, const EfNext &after, EfRing &R, int ch_own,
+                                         f32x4 (&accA)[2][MT], f32x4 (&accB)[2][MT], int ch_in,
+                                         int *mp_out, const EfLane &L, int rot, const EfScale &c_in, const EfScale &c_own, float &ovf,
+                                         HOOK &&hook = EfNoHook())
+{
+    static_assert(NPAIR % 2 == 0 && S >= 2, "pairs are processed two at a time; deferred finish needs S >= 2");
+    constexpr int NS = 2 * S * 3 * MT, NSD = (S - 1) * 6 * MT;      // MFMA slots of a pair; of its k-steps 0 .. S-2
+    f16x8 last[2][MT];              // planes of k-step S-1: produced here by the deferred finish (pin[S-1] is never written)
+    auto in_layer = [&](int mp) { return EfNext{woff, bias4g, mp, 2 * S}; };
+    if constexpr (UNROLL) {
+        // written out (NPAIR is 2 or 4): a `#pragma unroll` loop over this much code is not always
+        // unrolled, and a rolled loop indexes pout dynamically, which sends the planes to scratch
+        static_assert(NPAIR == 2 || NPAIR == 4, "unrolled layers have 2 or 4 output pairs");
+        static_assert(!OWN_LDS, "only the rolled (last) layer keeps its weights in LDS");
+        ef_pair<MT, S, false, IN_RAW, PLANES, NSD>(0, in_layer(1), pin, last, woff, R, accA, accB, last, ch_in, L, c_in, ovf);
+        if constexpr (NPAIR > 2)
+            ef_pair<MT, S, LAST, true, PLANES, NS>(1, in_layer(2), pin, last, woff, R, accB, accA, pout[0], ch_own, L, c_own, ovf);
+        else
+            ef_pair<MT, S, LAST, true, PLANES, NS, false, AFTER_LDS>(1, after, pin, last, woff, R, accB, accA, pout[0], ch_own, L, c_own, ovf);
+        if constexpr (NPAIR == 4) {
+            ef_pair<MT, S, LAST, true, PLANES, NS>(2, in_layer(3), pin, last, woff, R, accA, accB, pout[1], ch_own + 32, L, c_own, ovf);
+            ef_pair<MT, S, LAST, true, PLANES, NS, false, AFTER_LDS>(3, after, pin, last, woff, R, accB, accA, pout[2], ch_own + 64, L, c_own, ovf);
+        }
+        *mp_out = NPAIR - 1;
+    } else {
+        const int q0 = rot % NPAIR, q1 = (1 + rot) % NPAIR, q2 = (2 + rot) % NPAIR;
+        ef_pair<MT, S, false, IN_RAW, PLANES, NSD, OWN_LDS, OWN_LDS>(q0, in_layer(q1), pin, last, woff, R, accA, accB, last, ch_in, L, c_in, ovf);
+        ef_pair<MT, S, LAST, true, PLANES, NS, OWN_LDS, OWN_LDS>(q1, in_layer(q2), pin, last, woff, R, accB, accA, pout[0], ch_own + 32 * q0, L, c_own, ovf);
+        int mpB = q1;                                                   // pair whose results sit in accB
+#pragma unroll 1
+        for (int i = 2; i < NPAIR; i += 2) {
+            hook(i);                                                        // persistent kernel: the next tile's gather loads
+            const int m0 = (i + rot) % NPAIR, m1 = (i + 1 + rot) % NPAIR, m2 = (i + 2 + rot) % NPAIR;
+            ef_pair<MT, S, LAST, true, PLANES, NS, OWN_LDS, OWN_LDS>(m0, in_layer(m1), pin, last, woff, R, accA, accB, pout[0], ch_own + 32 * mpB, L, c_own, ovf);
+            if (i + 2 < NPAIR)
+                ef_pair<MT, S, LAST, true, PLANES, NS, OWN_LDS, OWN_LDS>(m1, in_layer(m2), pin, last, woff, R, accB, accA, pout[0],
+                                                                         ch_own + 32 * m0, L, c_own, ovf);
+            else
+                ef_pair<MT, S, LAST, true, PLANES, NS, OWN_LDS, AFTER_LDS>(m1, after, pin, last, woff, R, accB, accA, pout[0],
+                                                                           ch_own + 32 * m0, L, c_own, ovf);
+            mpB = m1;
+        }
+        *mp_out = mpB;
+    }
+}
+
+// PLANES = false: pooled [B*N][512] fp32 (channel-last).  PLANES = true: `pooled` is an fp16 activation image for
+// conv_f16.hip -- h | m' planes [512/8][B*N][8] of the pooled values times 2^T_out, then 2^-T_out (written here too).
+//
+// EF_PERSIST (default): one workgroup per CU walks the tiles (16 points each) with stride gridDim.x, and the gather of the
+// NEXT tile -- neighbour indices, then the coordinates they point to: two dependent trips to memory, ~4.9 k of a tile's
+// ~40 k cycles when they stood at the head of every workgroup with nothing to hide behind (tools/probe_ef.hip) -- is issued
+// from inside layer 4 of the current one (indices at its second pair, coordinates at its fourth) and consumed a tile later.
+// The weight ring is handed across tiles like across layers: layer 4's last pair prefetches layer 2's first fragments.
+// (the three-plane kernel, edgeconv_f16.hip, keeps one workgroup per tile: with its 36-register ring the prefetched gather spills)
+#ifndef EF_PERSIST
+#if defined(EF_TIMING)
+#define EF_PERSIST 0
+#else
+#define EF_PERSIST 1
+#endif
+#endif
+
+template <int MT>
+struct EfGather {                      // what a lane needs of a tile before its first MFMA
+    long long nb[MT];                  // neighbour indices of its MT rows
+    float c[3];                        // its point's coordinates
+    float b1[MT][2];                   // layer 1's B operands (after the second trip)
+    int b, nc;
+};
+
+template <int MT>
+__device__ __forceinline__ void ef_gather_idx(EfGather<MT> &G, int tile, int tiles_per_cloud, int N, int k, const float *__restrict__ xyz,
+                                              const int64_t *__restrict__ idx, int wave, int j)
+{
+    const int b = tile / tiles_per_cloud, xb = tile - b * tiles_per_cloud;
+    const int n = (xb * 4 + wave) * 4 + (j >> 2);
+    const int nc = min(n, N - 1);                                   // lanes past N recompute point N-1
+    G.b = b;
+    G.nc = nc;
+    const float *pc = xyz + ((size_t)b * N + nc) * 3;
+    G.c[0] = pc[0]; G.c[1] = pc[1]; G.c[2] = pc[2];
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+        const int jj = 4 * t + (j & 3);
+        G.nb[t] = idx[((size_t)b * N + nc) * k + (jj < k ? jj : 0)];   // pad k up to 4*MT with a duplicate
+    }
+}
+
+template <int MT>
+__device__ __forceinline__ void ef_gather_xyz(EfGather<MT> &G, int N, const float *__restrict__ xyz, int g)
+{
+#pragma unroll
+    for (int t = 0; t < MT; t++) {
+        const float *pn = xyz + ((size_t)G.b * N + G.nb[t]) * 3;
+        const float nx = pn[0], ny = pn[1], nz = pn[2];
+        G.b1[t][0] = g == 0 ? nx : (g == 1 ? ny : (g == 2 ? nz : G.c[0]));
+        G.b1[t][1] = g == 0 ? G.c[1] : (g == 1 ? G.c[2] : 0.f);
+    }
+}
+
+template <int MT, bool PLANES>
+__global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xyz,
+                                                              const int64_t *__restrict__ idx, int B, int N, int k,
+                                                              const float *packed,
+                                                              float *__restrict__ pooled,
+                                                              int *__restrict__ range_flag
+#ifdef EF_TIMING
+                                                              , unsigned long long *tdbg
+#endif
+)
+{
+#ifdef EF_TIMING
+    unsigned long long tk[6];
+#define EF_T(i) tk[i] = __builtin_amdgcn_s_memtime()
+#else
+#define EF_T(i)
+#endif
+    EF_T(0);
+    constexpr int CTOT = EC_C1 + EC_C2 + EC_C3 + EC_C4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int tiles_per_cloud = (N + 15) / 16, ntiles = B * tiles_per_cloud;
+    // pooled stores: after the transposing quad reduce lane q = j & 3 holds channel register {0,2,1,3}[q] of its point;
+    // lanes past N recompute point N-1 and store the same bits to the same place
+    EfLane L;
+    L.laneoff = (unsigned)lane * 16u;
+    L.rs.p = (const char *)packed;
+    L.odd = j & 1;
+    L.hi = j & 2;
+    const int cl = 4 * g + ((j & 1) * 2 + ((j >> 1) & 1));       // this lane's channel inside a 16-channel M-tile
+    L.bn = (size_t)B * N;
+#if EF_W4_LDS
+    extern __shared__ __attribute__((aligned(16))) unsigned char ef_w4[];
+    L.w4lds = (ef_lds_t)ef_w4;
+    {   // layer 4's fragments -> LDS, once per workgroup; the barrier stands in front of the first tile's layer 4
+        const uint4 *src = (const uint4 *)(packed + EFO_W4);
+        uint4 *dst = (uint4 *)ef_w4;
+#pragma unroll 4
+        for (int i = threadIdx.x; i < EF_W4_BYTES / 16; i += 256) dst[i] = src[i];
+    }
+    bool w4_ready = false;
+#else
+    L.w4lds = nullptr;
+#endif
+    if (PLANES && blockIdx.x == 0 && threadIdx.x == 0)
+        *(float *)((_Float16 *)pooled + 2 * 512 * L.bn) = packed[EFO_SC + 12];        // the image's 2^-T_out
+    // power-of-two scales of the four layers' accumulators (uniform: scalar loads), see edgeconv_layout.h
+    const int po = PLANES ? 8 : 4;
+    const EfScale s1 = {packed[EFO_SC + 0], packed[EFO_SC + po + 0]}, s2 = {packed[EFO_SC + 1], packed[EFO_SC + po + 1]},
+                  s3 = {packed[EFO_SC + 2], packed[EFO_SC + po + 2]}, s4 = {1.0f, packed[EFO_SC + po + 3]};
+    float ovf = 0.f;
+    constexpr int w2 = EFO_W2 * 4, w3 = EFO_W3 * 4, w4 = EFO_W4 * 4;      // byte offsets inside the descriptor
+    const float *bs2 = packed + EFO_B2 + 4 * g, *bs3 = packed + EFO_B3 + 4 * g, *bs4 = packed + EFO_B4 + 4 * g;
+#ifndef EF_ROT
+#define EF_ROT 1
+#endif
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    // the first tile's gather stands in the open; its index loads go out before the weight ring's so that the dependent
+    // coordinate loads do not queue behind 8 KB of fragments
+    EfGather<MT> G;
+    ef_gather_idx<MT>(G, tile, tiles_per_cloud, N, k, xyz, idx, wave, j);
+    EF_PIN();
+    // layer 2's first fragments and bias: requested before the gather's second trip so that their latency hides behind it
+    EfRing R;
+    ef_ring_fill(R, L.rs, EFO_W2 * 4, packed + EFO_B2 + 4 * g, 0, 2 * (EC_C1 / 32), lane);
+    EF_PIN();
+    ef_gather_xyz<MT>(G, N, xyz, g);
+
+#if EF_PERSIST
+    for (; tile < ntiles; tile += gridDim.x) {
+#else
+    {
+#endif
+    const int b = G.b;
+    L.prow = pooled + ((size_t)b * N + G.nc) * CTOT + cl;
+    L.ph = (_Float16 *)pooled + ((size_t)(cl >> 3) * L.bn + (size_t)b * N + G.nc) * 8 + (cl & 7);
+    float b1[MT][2];
+#pragma unroll
+    for (int t = 0; t < MT; t++) { b1[t][0] = G.b1[t][0]; b1[t][1] = G.b1[t][1]; }
+#if EF_PERSIST
+    const int tile_next = tile + (int)gridDim.x;
+    const bool has_next = tile_next < ntiles;                    // uniform
+#endif
+
+    // ---- layer 1 on the fp32 MFMA (as edgeconv2.hip): graph feature rows as B operands, k-step s,
+    //      lane group g -> channel 4s + g of (neighbour xyz, centre xyz, 0, 0)          dgcnn.py:32
+    EF_T(1);
+    f16x8 p1[EC_C1 / 32][2][MT];
+    f32x4 accA[2][MT], accB[2][MT];                    // accB: the pair whose finish is pending
+    {
+        const f32x2 *w1 = (const f32x2 *)(packed + EFO_W1);
+#pragma unroll
+        for (int mp = 0; mp < EC_C1 / 32; mp++) {
+#pragma unroll
+            for (int mm = 0; mm < 2; mm++) {
+                const int m = 2 * mp + mm;
+                const f32x4 bv = *(const f32x4 *)(packed + EFO_B1 + 16 * m + 4 * g);
+                const f32x2 a = w1[m * 64 + lane];
+#pragma unroll
+                for (int t = 0; t < MT; t++) accB[mm][t] = bv;
+#pragma unroll
+                for (int s = 0; s < 2; s++)
+#pragma unroll
+                    for (int t = 0; t < MT; t++)
+                        accB[mm][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[t][s], accB[mm][t], 0, 0, 0);
+            }
+            if (mp + 1 < EC_C1 / 32) ef_finish_all<MT, false, false, PLANES>(accB, p1[mp], 32 * mp, L, s1, ovf);
+        }
+    }
+    int mp_last;
+
+    EF_T(2);
+    const int rot = EF_ROT ? (int)(((unsigned)tile >> 3) % (EC_C4 / 32)) : 0;   // >>3: ids = XCD mod 8
+    // ---- layer 2: 64 -> 64   (its first pair hides the finish of layer 1's last pair, and so on down)
+    f16x8 p2[EC_C2 / 32][2][MT];
+    ef_layer<MT, EC_C1 / 32, EC_C2 / 32, false, true, false, PLANES>(
+        p1, p2, w2, bs2, EfNext{w3, bs3, 0, 2 * (EC_C2 / 32)}, R, EC_C1, accA, accB,
+        32 * (EC_C1 / 32 - 1), &mp_last, L, 0, s1, s2, ovf);
+    EF_T(3);
+    // ---- layer 3: 64 -> 128
+    f16x8 p3[EC_C3 / 32][2][MT];
+#if EF_W4_LDS
+    if (!w4_ready) { __syncthreads(); w4_ready = true; }        // layer 3's last pair prefetches layer 4's first fragments from LDS
+#endif
+    ef_layer<MT, EC_C2 / 32, EC_C3 / 32, false, true, true, PLANES, EfNoHook, false, EF_W4_LDS != 0>(
+        p2, p3, w3, bs3, EfNext{w4, bs4, rot, 2 * (EC_C3 / 32)}, R, EC_C1 + EC_C2, accA, accB,
+        EC_C1 + 32 * (EC_C2 / 32 - 1), &mp_last, L, 0, s2, s3, ovf);
+    EF_T(4);
+    // ---- layer 4: 128 -> 256, only max-pooled; its last pair prefetches layer 2's first fragments for the next tile
+    f16x8 dummy[1][2][MT];
+#if EF_PERSIST
+    auto hook = [&](int i) {
+        if (has_next) {
+            if (i == 2) { ef_gather_idx<MT>(G, tile_next, tiles_per_cloud, N, k, xyz, idx, wave, j); EF_PIN(); }
+            if (i == 6) { ef_gather_xyz<MT>(G, N, xyz, g); EF_PIN(); }
+        }
+    };
+    ef_layer<MT, EC_C3 / 32, EC_C4 / 32, true, false, true, PLANES, decltype(hook) &, EF_W4_LDS != 0, false>(
+        p3, dummy, w4, bs4, EfNext{w2, bs2, 0, 2 * (EC_C1 / 32)}, R, EC_C1 + EC_C2 + EC_C3, accA, accB,
+        EC_C1 + EC_C2 + 32 * (EC_C3 / 32 - 1), &mp_last, L, rot, s3, s4, ovf, hook);
+#else
+    ef_layer<MT, EC_C3 / 32, EC_C4 / 32, true, false, true, PLANES>(
+        p3, dummy, w4, bs4, EfNext{w4, bs4, 0, 2 * (EC_C3 / 32)}, R, EC_C1 + EC_C2 + EC_C3, accA, accB,
+        EC_C1 + EC_C2 + 32 * (EC_C3 / 32 - 1), &mp_last, L, rot, s3, s4, ovf);
+#endif
+    asm volatile("s_nop 15\n\ts_nop 15");                       // the last asm MFMAs must have written accB (no compiler padding)
+    ef_finish_all<MT, true, true, PLANES>(accB, dummy[0], EC_C1 + EC_C2 + EC_C3 + 32 * mp_last, L, s4, ovf);
+    EF_T(5);
+    }
+    // fp16 range guard: ovf = the largest value (in plane units) this lane handed to fp16 planes -- layers 1-3, and the
+    // pooled planes when PLANES; activations are post-ReLU, so the pooled maxima are the maxima.  Not taken while the
+    // activations stay within 16x of the magnitude the packer was told; the host re-runs on the bf16x3 kernel if it is.
+    if (!(ovf <= 60000.f) && range_flag) *(volatile int *)range_flag = 1; // may live in mapped host memory: plain store
+#ifdef EF_TIMING
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 6; i++) tdbg[(size_t)blockIdx.x * 6 + i] = tk[i];
+#endif
+}
+
+#ifndef EF_TIMING
+// workgroups to launch: one per CU (persistent), or one per tile
+static int ef_grid(int ntiles)
+{
+#if EF_PERSIST
+    static thread_local int cus[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return ntiles < cus[dev] ? ntiles : cus[dev];
+#else
+    return ntiles;
+#endif
+}
+
+extern "C" int EF_ENTRY(const float *xyz, const int64_t *idx, int B, int N, int k,
+                                        const float *packed, void *out, int out_mode, int *range_flag, l3d_stream_t stream)
+{
+    L3D_REQUIRE(xyz && idx && packed && out && B > 0 && N > 0 && k > 0 && (out_mode == 0 || out_mode == 1));
+    if (k > 20 || B > 65535 || (((size_t)packed) & 15) || (((size_t)out) & 15)) return L3D_ERR_UNSUPPORTED;
+    const long ntiles = (long)B * l3d_divup(N, 16);
+    if (ntiles > 0x7fffffffL / 2) return L3D_ERR_UNSUPPORTED;
+    dim3 grid(ef_grid((int)ntiles)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    float *o = (float *)out;
+    const size_t lds = EF_W4_LDS ? EF_W4_BYTES : 0;
+    if (out_mode == 0) {
+        if (k <= 16) hipLaunchKernelGGL((EF_KERNEL<4, false>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag);
+        else              hipLaunchKernelGGL((EF_KERNEL<5, false>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag);
+    } else {
+        if (k <= 16) hipLaunchKernelGGL((EF_KERNEL<4, true>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag);
+        else              hipLaunchKernelGGL((EF_KERNEL<5, true>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag);
+    }
+    return l3d_check_launch();
+}
+#endif

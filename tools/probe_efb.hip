@@ -1,7 +1,7 @@
-// Per-layer cycle breakdown (s_memtime) of (edgeconv_f16_kernel<5, false>) at the BASELINE shape; weights are
+// Per-layer cycle breakdown (s_memtime) of (edgeconv_f16b_kernel<5, false>) at the BASELINE shape; weights are
 // zeros (timing does not depend on values), neighbours pseudo-random.  Not a product path.
 #define EF_TIMING
-#include "../learning3d_amd/csrc/edgeconv_f16.hip"
+#include "../learning3d_amd/csrc/edgeconv_f16b.hip"
 #include <cstdio>
 #include <vector>
 #include <algorithm>
@@ -20,12 +20,12 @@ int main()
     std::vector<int64_t> hi((size_t)B * N * K);
     for (size_t i = 0; i < hi.size(); i++) hi[i] = (i * 40503u) % N;
     hipMemcpy(idx, hi.data(), 8 * hi.size(), hipMemcpyHostToDevice);
-    dim3 grid(N / 16, B), block(256);
+    dim3 grid((N / 16) * B), block(256);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((edgeconv_f16_kernel<5, false>), grid, block, 0, 0, xyz, idx, N, K, packed, pooled, (int*)nullptr, tdbg);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((edgeconv_f16b_kernel<5, false>), grid, block, 0, 0, xyz, idx, B, N, K, packed, pooled, (int*)nullptr, tdbg);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int i = 0; i < 10; i++) hipLaunchKernelGGL((edgeconv_f16_kernel<5, false>), grid, block, 0, 0, xyz, idx, N, K, packed, pooled, (int*)nullptr, tdbg);
+    for (int i = 0; i < 10; i++) hipLaunchKernelGGL((edgeconv_f16b_kernel<5, false>), grid, block, 0, 0, xyz, idx, B, N, K, packed, pooled, (int*)nullptr, tdbg);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("kernel: %.1f us\n", ms / 10 * 1e3);
