@@ -93,7 +93,7 @@ def edgeconv_roofline(ec_tf, ec_ms, arith):
     l1 = B_PER_GPU * NPTS * KNN * 2 * 6 * 64                       # layer 1 stays on the fp32 MFMA
     name = "edgeconv_f16b_kernel<5,true>" if arith == "f16x2" else "edgeconv_split_kernel<5>"
     return {"kernel": name, "bound": "mfma", "achieved": ec_tf, "peak": peak,
-            "unit": "TFLOP/s", "frac": ec_tf / peak, "traffic": pmc_traffic("edgeconv_f16" if arith == "f16x2" else "edgeconv_split"),
+            "unit": "TFLOP/s", "frac": ec_tf / peak, "traffic": pmc_traffic("edgeconv_f16b" if arith == "f16x2" else "edgeconv_split") or pmc_traffic("edgeconv_f16"),
             "avg_launch_ms": ec_ms, "algorithmic_flop_per_launch": alg,
             "peak_note": f"fp32-equivalent ceiling = dense fp16/bf16 MFMA peak 2500 TFLOP/s / {prods} products per fp32 product "
                          "(the fp32 MFMA peak is 157.3 TFLOP/s)",
@@ -508,9 +508,9 @@ def main():
 
     def timed(sync_loss, timer=None):
         """K steps between two (barrier + device sync) brackets; returns (this rank's seconds, last loss)."""
-        # steps that carry the live kernel-timing events are issued eagerly (~0.16 ms of extra host time each): at most 8
-        # per run and at most one in ten, so a 20-step run has 2
-        nsamp = max(1, min(8, args.steps // 10))
+        # steps that carry the live kernel-timing events are issued eagerly (~0.2 ms of extra host time each): at most 8
+        # per run and at most one in twenty, so a 20-step run has 1
+        nsamp = max(1, min(8, args.steps // 20))
         stride = max(1, -(-args.steps // nsamp))
         sync()
         t0 = time.perf_counter()
@@ -574,13 +574,14 @@ def main():
         arith_ = _fused.gemm_arith()
         w5_, s5_, b5_, w5s_, w5f_ = net._conv5_folded()
         if arith_ == "f16x2":
-            img_ = _fused.edgeconv_forward(x, idx_, packed_, planes=True)
+            img_ = _fused.edgeconv_forward(x, idx_, packed_, planes=True, v2=net._packed.v2_ok)
             stage_ms["conv5"] = per_launch_ms(lambda: _fused.pointwise_conv_f16(img_, B_PER_GPU, NPTS, w5f_, 512, EMB, s5_, b5_, relu=True))
         else:
             pooled_ = _fused.edgeconv_forward(x, idx_, packed_)
             stage_ms["conv5"] = per_launch_ms(lambda: _fused.pointwise_conv(pooled_, w5_, s5_, b5_, relu=True, channel_last=True,
                                                                               w_split=w5s_))
-        stage_ms.setdefault("edgeconv", per_launch_ms(lambda: _fused.edgeconv_forward(x, idx_, packed_, planes=(arith_ == "f16x2"))))
+        if "edgeconv" not in stage_ms:
+            stage_ms["edgeconv"] = per_launch_ms(lambda: _fused.edgeconv_forward(x, idx_, packed_, planes=(arith_ == "f16x2"), v2=net._packed.v2_ok))
         _fused.check_range(sync=True)                 # no activation left the fp16 range during the run
 
     # max over ranks (the contract), and every rank's own time for the record

@@ -1,4 +1,5 @@
-"""Run one kernel a few times (for rocprofv3 --pmc passes).  usage: pmc_one.py knn|chamfer|edgeconv|edgeconv_split|edgeconv_f16|conv5|conv5_split|conv5_f16"""
+"""Run one kernel a few times (for rocprofv3 --pmc passes).
+usage: pmc_one.py knn|chamfer|edgeconv|edgeconv_split|edgeconv_f16|edgeconv_f16b|conv5|conv5_split|conv5_f16|group_c5"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,12 +17,24 @@ with torch.no_grad():
     w5, s5, b5, w5s, w5f = net._conv5_folded()
     img = _fused.edgeconv_forward(x, idx, packed, kernel="f16", planes=True)
     torch.cuda.synchronize()
+    if what == "group_c5":                       # config 5's grouping gather (bench.py --workload c5: the HBM-bound op)
+        from learning3d_amd.utils import pointnet2_utils as P
+        gq = torch.Generator().manual_seed(0)
+        xyz5 = torch.clamp(torch.randn((32, 8192, 3), generator=gq), -2, 2).cuda()
+        feat5 = torch.rand((32, 3, 8192), generator=gq).cuda()
+        new5 = xyz5[:, :1024].contiguous()
+        qg = P.QueryAndGroup(0.5, 16)
+        for _ in range(5):
+            qg(xyz5, new5, feat5)
+        torch.cuda.synchronize()
+        sys.exit(0)
     for _ in range(5):
         if what == "knn": U.knn(x.permute(0, 2, 1), 20)
         elif what == "chamfer": ChamferDistance()(a, b)
         elif what == "edgeconv": _fused.edgeconv_forward(x, idx, packed, kernel="chained")            # fp32 MFMA
         elif what == "edgeconv_split": _fused.edgeconv_forward(x, idx, packed, kernel="split")        # bf16x3
-        elif what == "edgeconv_f16": _fused.edgeconv_forward(x, idx, packed, kernel="f16", planes=True)   # f16x2, plane image out
+        elif what == "edgeconv_f16": _fused.edgeconv_forward(x, idx, packed, planes=True)                 # f16x2 three-plane kernel, plane image out
+        elif what == "edgeconv_f16b": _fused.edgeconv_forward(x, idx, packed, planes=True, v2=True)      # f16x2 two-plane persistent kernel (the step's)
         elif what == "conv5_f16": _fused.pointwise_conv_f16(img, 32, 1024, w5f, 512, 1024, s5, b5, relu=True)
         elif what == "conv5": _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True, split=False)
         elif what == "conv5_split": _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True, w_split=w5s)

@@ -5,7 +5,7 @@ import json, os, re, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 out = {}
-for tag in ("edgeconv", "edgeconv_split", "edgeconv_f16", "conv5", "conv5_split", "conv5_f16", "knn", "knn_mfma", "chamfer"):
+for tag in ("edgeconv", "edgeconv_split", "edgeconv_f16", "edgeconv_f16b", "conv5", "conv5_split", "conv5_f16", "knn", "knn_mfma", "chamfer", "group_c5"):
     path = None
     for r in range(rnd, 0, -1):
         cand = os.path.join(root, "profiles", f"round{r}_pmc_{tag}.txt")
@@ -20,7 +20,8 @@ for tag in ("edgeconv", "edgeconv_split", "edgeconv_f16", "conv5", "conv5_split"
         out[tag] = {"source": os.path.basename(path), "fetch_size_bytes_raw": f, "write_size_bytes": w,
                     "hbm_bytes_per_launch": 2 * f + w,
                     "note": "FETCH_SIZE x2 (gfx950 rocprofv3 under-reports wide coalesced reads by 2x, MI355X_MICROARCH.md HBM section) + WRITE_SIZE"}
-        for k in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_LDS", "GRBM_GUI_ACTIVE"):
+        for k in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_LDS", "GRBM_GUI_ACTIVE", "SQ_LDS_BANK_CONFLICT",
+                  "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_LDS", "SQ_INSTS_VMEM_RD"):
             if k in vals:
                 out[tag][k] = float(vals[k])
 json.dump(out, open(os.path.join(root, "profiles", f"round{rnd}_traffic.json"), "w"), indent=1)
