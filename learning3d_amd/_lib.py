@@ -181,6 +181,26 @@ def require_gpu(*tensors):
                        f"wrap the call in `with torch.cuda.device({dev.index}):`")
 
 
+class on_device_of:
+    """`with on_device_of(t, ...):` -- make the first device tensor's GPU the current device for the calls inside (the C ABI
+    launches on the current device's current stream).  A no-op when it already is, or when no tensor is a device tensor."""
+
+    def __init__(self, *tensors):
+        self.dev = next((t.device for t in tensors if isinstance(t, torch.Tensor) and t.is_cuda), None)
+        self.ctx = None
+
+    def __enter__(self):
+        if self.dev is not None and self.dev.index != torch.cuda.current_device():
+            self.ctx = torch.cuda.device(self.dev)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 def f32c(t):
     """contiguous fp32 view/copy of a device tensor"""
     if t.dtype != torch.float32:

@@ -518,6 +518,9 @@ extern "C" int l3d_chamfer_loss_local_mb(const float *dist1, const float *dist2,
     const size_t n1 = (size_t)B * N, n2 = (size_t)B * M, m4 = (n1 > n2 ? n1 : n2) >> 2;
     long blocks = l3d_divup((long)m4, 256);
     blocks = blocks < 1 ? 1 : (blocks > CHAMFER_LL_BLOCKS ? CHAMFER_LL_BLOCKS : blocks);
+    // the 4-byte ticket is zeroed on the launch stream before every launch (a memset node under graph capture): a launch that
+    // aborted before its last block re-armed the ticket must not leave later calls on this workspace without a "last" block
+    if (hipMemsetAsync(ws, 0, 4, (hipStream_t)stream) != hipSuccess) { (void)l3d_check_launch(); return L3D_ERR_LAUNCH; }
     hipLaunchKernelGGL(chamfer_loss_local_mb_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dist1, n1, dist2, n2,
                        (unsigned *)ws, partial, loss);
     return l3d_check_launch();

@@ -101,12 +101,14 @@ def chamfer_combine(partials):
 def chamfer_distance(template: torch.Tensor, source: torch.Tensor):
     """reference: losses/chamfer_distance.py:34-43 -- (mean sqrt d1 + mean sqrt d2) / 2, one scalar
     over the whole batch."""
-    cost_p0_p1, cost_p1_p0 = ChamferDistance()(template, source)
-    if torch.is_grad_enabled() and (template.requires_grad or source.requires_grad):
-        cost_p0_p1 = torch.mean(torch.sqrt(cost_p0_p1))
-        cost_p1_p0 = torch.mean(torch.sqrt(cost_p1_p0))
-        return (cost_p0_p1 + cost_p1_p0) / 2.0
-    return chamfer_loss_local(cost_p0_p1, cost_p1_p0)          # == chamfer_combine(chamfer_partials(...)), one launch
+    from .._lib import on_device_of
+    with on_device_of(template, source):               # tensors on a GPU other than the current one: switch for the call
+        cost_p0_p1, cost_p1_p0 = ChamferDistance()(template, source)
+        if torch.is_grad_enabled() and (template.requires_grad or source.requires_grad):
+            cost_p0_p1 = torch.mean(torch.sqrt(cost_p0_p1))
+            cost_p1_p0 = torch.mean(torch.sqrt(cost_p1_p0))
+            return (cost_p0_p1 + cost_p1_p0) / 2.0
+        return chamfer_loss_local(cost_p0_p1, cost_p1_p0)      # == chamfer_combine(chamfer_partials(...)), one launch
 
 
 def chamfer(a, b):

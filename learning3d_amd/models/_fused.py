@@ -187,10 +187,11 @@ class _Recompute(torch.autograd.Function):
                 if ctx.needs_input_grad[3 + i]:
                     a.requires_grad_(True)
             ins.append(a)
+        from .._lib import on_device_of
         prev = recomputing()
         _TLS.recomputing = True
         try:
-            with torch.enable_grad():
+            with torch.enable_grad(), on_device_of(*ins):
                 outs, _ = _flatten(ctx.impl(*ins))
         finally:
             _TLS.recomputing = prev
@@ -211,15 +212,18 @@ def checkpointed(module, impl, *tensors):
     """Run `impl(*tensors)` (a module's forward body) so that the fused kernels serve the forward whatever the grad mode:
     nothing to differentiate -> impl directly; batch statistics / dropout -> impl directly (its call sites pick the per-layer
     route); otherwise inside _Recompute.  Outputs: a tensor, or a tuple / list / dict of tensors."""
+    from .._lib import on_device_of
     if not torch.is_grad_enabled() or recomputing() or _stochastic_or_batch_dependent(module):
-        return impl(*tensors)
+        with on_device_of(*tensors):                 # tensors on a GPU that is not the current one: switch for the call
+            return impl(*tensors)
     params = [p for p in module.parameters() if p.requires_grad]
     if not params and not any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
         return impl(*tensors)
     if not all(t.is_cuda for t in tensors if isinstance(t, torch.Tensor)):
         return impl(*tensors)
     holder = {}
-    outs = _Recompute.apply(impl, holder, len(tensors), *tensors, *params)
+    with on_device_of(*tensors):
+        outs = _Recompute.apply(impl, holder, len(tensors), *tensors, *params)
     return holder["rebuild"](list(outs))
 
 

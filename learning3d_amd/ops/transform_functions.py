@@ -25,6 +25,14 @@ def euler_transform(template, euler_zyx, translation):
     return source, igt
 
 
+def _on_gpu(t):
+    """The reference's Dataset.__getitem__ hands these transforms CPU tensors [N,3] (data_utils/dataloaders.py:290-296): they are
+    moved to the current GPU, transformed there, and the results handed back on the CPU; device tensors stay where they are."""
+    if t.is_cuda:
+        return t, False
+    return t.cuda(), True
+
+
 class DCPTransform:
     """reference: ops/transform_functions.py:271-315.  Same constructor; `__call__(template)` takes a device batch
     [B,N,3] (or one cloud [N,3]) and returns the transformed source; `.igt` holds the batch's [B,4,4] ground truth
@@ -49,13 +57,17 @@ class DCPTransform:
         return source
 
     def __call__(self, template):
+        template, back = _on_gpu(template)
         single = template.dim() == 2
         t = template.unsqueeze(0) if single else template
         self.generate_transform(t.shape[0], t.device)
         source = self.apply_transformation(t)
         if single:
             self.igt = self.igt[0]
-            return source[0]
+            source = source[0]
+        if back:
+            self.igt = self.igt.cpu()
+            return source.cpu()
         return source
 
 
@@ -124,7 +136,12 @@ class PNLKTransform:
         return self.apply_transform(tensor, self.generate_transform(batch, tensor.device))
 
     def __call__(self, tensor):
-        return self.transform(tensor)
+        tensor, back = _on_gpu(tensor)
+        out = self.transform(tensor)
+        if back:
+            self.gt, self.igt = self.gt.cpu(), self.igt.cpu()
+            return out.cpu()
+        return out
 
 
 class RPMNetTransform(PNLKTransform):
@@ -160,6 +177,8 @@ class PCRNetTransform:
         self.dtype = torch.float32
         self.index = 0
         self.generator = generator
+        self.data_size = data_size
+        self.transformations = None          # [data_size, 7], drawn on first use (the reference pre-draws them on the host, :200-203)
 
     @staticmethod
     def deg_to_rad(deg):
@@ -171,11 +190,21 @@ class PCRNetTransform:
         return torch.cat([euler_to_quaternion_xyz(r[:, :3] * mr), r[:, 3:] * self.translation_range], dim=1)
 
     def __call__(self, template):
+        template, back = _on_gpu(template)
         single = template.dim() == 2
         t = template.unsqueeze(0) if single else template
-        self.igt = self.create_random_transform(t.shape[0], t.device)
+        if single and self.data_size:
+            # the reference's dataset semantics (:216-218, dataloaders.py:291): a fixed pose per sample index
+            if self.transformations is None:
+                self.transformations = self.create_random_transform(int(self.data_size), t.device)
+            self.igt = self.transformations[self.index % int(self.data_size)].unsqueeze(0)
+        else:
+            self.igt = self.create_random_transform(t.shape[0], t.device)
         source = quat_transform(t, self.igt)
         if single:
             self.igt = self.igt[0:1]
-            return source[0]
+            source = source[0]
+        if back:
+            self.igt = self.igt.cpu()
+            return source.cpu()
         return source

@@ -167,7 +167,16 @@ class SublayerConnection(nn.Module):
         self.norm = LayerNorm(size)
 
     def forward(self, x, sublayer):
-        y = sublayer(self.norm(x, values=not (DEFER_LN_VALUES and getattr(sublayer, "_l3d_planes_ok", False))))
+        # the fp32 values of the norm's output may be deferred only for sublayers that are known to read their input through
+        # the plane image / _ln_values: the marked lambdas of this module, or a PositionwiseFeedForward whose forward is the
+        # one defined here (not a subclass override) and that carries no hooks
+        ok = getattr(sublayer, "_l3d_planes_ok", False)
+        if ok and isinstance(sublayer, nn.Module):
+            ok = (type(sublayer).forward is PositionwiseFeedForward.forward and not sublayer._forward_hooks
+                  and not sublayer._forward_pre_hooks)
+        if self.norm._forward_hooks or self.norm._forward_pre_hooks:
+            ok = False
+        y = sublayer(self.norm(x, values=not (DEFER_LN_VALUES and ok)))
         if (x.is_cuda and x.dim() == 3 and y.shape == x.shape and x.dtype == torch.float32 and y.dtype == torch.float32
                 and x.is_contiguous() and not y.is_contiguous() and y.transpose(1, 2).is_contiguous()
                 and not (torch.is_grad_enabled() and (x.requires_grad or y.requires_grad))):
