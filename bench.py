@@ -385,6 +385,10 @@ def main():
     elif args.arith:
         _fused.GEMM_ARITH = args.arith
     from learning3d_amd.losses.chamfer_distance import ChamferDistance, chamfer_partials
+    # the f16x2 range verdict: the default policy waits for the forward and reads the flag before returning (a host sync per
+    # call); the bench's steps are graph replays (where nothing can be waited for) plus a few eager ones, so it takes the
+    # asynchronous policy and checks the flag itself after the replays and at the end of the run (check_range(sync=True))
+    _fused.RANGE_POLICY = "async"
 
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:

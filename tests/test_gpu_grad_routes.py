@@ -448,3 +448,35 @@ def test_f16_overflow_is_repaired_inside_the_same_call():
     # grad mode on: the same repair inside the checkpointed forward
     out2 = net(x)
     assert torch.equal(out2.detach(), out) and _fused.RANGE_RETRIES == before + 2
+
+
+def test_transforms_take_the_reference_datasets_cpu_inputs_and_hooks_see_layernorm_values():
+    """ The reference's RegistrationData hands its transforms CPU tensors [N,3] (data_utils/dataloaders.py:290-296):
+    accepted, computed on the device, returned on the CPU; PCRNetTransform keeps a fixed pose per sample index.  A forward hook
+    on a sublayer's LayerNorm (or a subclassed feed-forward) must see real values, not the deferred-output buffer."""
+    from learning3d_amd.ops.transform_functions import DCPTransform, PCRNetTransform, PNLKTransform
+    from learning3d_amd.utils.transformer import Transformer
+    t = torch.rand((64, 3)) - 0.5
+    for tf in (DCPTransform(45, 1), PNLKTransform(0.8, True), PCRNetTransform(10, 45, 1)):
+        src = tf(t)
+        assert not src.is_cuda and src.shape == (64, 3) and not tf.igt.is_cuda and torch.isfinite(src).all()
+    pcr = PCRNetTransform(5, 45, 1)
+    pcr.index = 3
+    a = pcr(t)
+    pcr.index = 1
+    pcr(t)
+    pcr.index = 3
+    assert torch.equal(pcr(t), a)                                       # the same pose for the same index
+    torch.manual_seed(5)
+    net = Transformer(512, 1, 0.0, 1024, 4).cuda().eval()
+    x = torch.randn(2, 512, 256, device="cuda")
+    with torch.no_grad():
+        want = net(x, x)
+        seen = []
+        h = net.model.encoder.layers[0].sublayer[1].norm.register_forward_hook(lambda m, i, o: seen.append(o.clone()))
+        got = net(x, x)
+        h.remove()
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    ln = net.model.encoder.layers[0].sublayer[1].norm
+    assert len(seen) == 2 and all(torch.isfinite(o).all() for o in seen)
+    assert all(abs(float(o.mean())) < 0.1 and 0.5 < float(o.std()) < 2.0 for o in seen)     # normalised values, not scratch memory
