@@ -578,14 +578,17 @@ def main():
         arith_ = _fused.gemm_arith()
         w5_, s5_, b5_, w5s_, w5f_ = net._conv5_folded()
         if arith_ == "f16x2":
-            img_ = _fused.edgeconv_forward(x, idx_, packed_, planes=True, v2=net._packed.v2_ok)
-            stage_ms["conv5"] = per_launch_ms(lambda: _fused.pointwise_conv_f16(img_, B_PER_GPU, NPTS, w5f_, 512, EMB, s5_, b5_, relu=True))
+            v2_ = net._packed.v2_ok and _fused.EDGECONV_F16_TWO_PLANE
+            img_ = _fused.edgeconv_forward(x, idx_, packed_, planes=True, v2=v2_, unscaled=v2_)
+            stage_ms["conv5"] = per_launch_ms(lambda: _fused.pointwise_conv_f16(img_, B_PER_GPU, NPTS, w5f_, 512, EMB, s5_, b5_, relu=True,
+                                                                                  unscaled=v2_))
         else:
             pooled_ = _fused.edgeconv_forward(x, idx_, packed_)
             stage_ms["conv5"] = per_launch_ms(lambda: _fused.pointwise_conv(pooled_, w5_, s5_, b5_, relu=True, channel_last=True,
                                                                               w_split=w5s_))
         if "edgeconv" not in stage_ms:
-            stage_ms["edgeconv"] = per_launch_ms(lambda: _fused.edgeconv_forward(x, idx_, packed_, planes=(arith_ == "f16x2"), v2=net._packed.v2_ok))
+            stage_ms["edgeconv"] = per_launch_ms(lambda: _fused.edgeconv_forward(x, idx_, packed_, planes=(arith_ == "f16x2"), v2=net._packed.v2_ok,
+                                                                                   unscaled=(arith_ == "f16x2" and net._packed.v2_ok)))
         _fused.check_range(sync=True)                 # no activation left the fp16 range during the run
 
     # max over ranks (the contract), and every rank's own time for the record

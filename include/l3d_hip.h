@@ -357,7 +357,9 @@ int l3d_edgeconv_forward_f16(const float *xyz, const int64_t *idx, int B, int N,
                              int out_mode, int *range_flag, l3d_stream_t stream);
 /* The two-plane variant (edgeconv_f16b.hip): same arguments and outputs; two fp16 weight planes per fragment step and an
  * unscaled activation residual (fifth packed copy, csrc/edgeconv_layout.h).  Usable only when the packer could place every
- * layer's weights (packed[l3d_edgeconv_packed_v2_flag_index()] == 1 in the HOST copy of the packed block). */
+ * layer's weights (packed[l3d_edgeconv_packed_v2_flag_index()] == 1 in the HOST copy of the packed block).
+ * out_mode 2: the pooled values as an fp16 activation image like out_mode 1, but with the residual plane unscaled, the
+ * x operand of l3d_pointwise_conv_f16_2p. */
 int l3d_edgeconv_forward_f16b(const float *xyz, const int64_t *idx, int B, int N, int k, const float *packed, void *out,
                              int out_mode, int *range_flag, l3d_stream_t stream);
 int l3d_edgeconv_packed_v2_flag_index(void);
@@ -436,6 +438,12 @@ int l3d_conv_f16_split_weights(const float *w, int Cout, int Cin, void *dst, l3d
 int l3d_split_f16_rows(const float *x, long rows, int C, int channel_first, int Npts, void *dst, int *range_flag,
                        l3d_stream_t stream);
 int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
+                           int shift_bstride, int B, int Cin, int Cout, int N, int relu, float *y,
+                           l3d_stream_t stream);
+/* l3d_pointwise_conv_f16 for an activation image whose residual plane is UNSCALED (m = f16(X - h); written by
+ * l3d_edgeconv_forward_f16b with out_mode 2): the Hs plane of the weight image is not read (two weight planes, 12 instead of 14
+ * LDS fragment reads and 4 instead of 5 DMA pieces per chunk and wave).  Cout % 256 == 0, N % 256 == 0. */
+int l3d_pointwise_conv_f16_2p(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
                            int shift_bstride, int B, int Cin, int Cout, int N, int relu, float *y,
                            l3d_stream_t stream);
 /* The same layer with its OUTPUT written as an activation image (l3d_f16_act_bytes(B N, Cout) bytes) for the next f16x2

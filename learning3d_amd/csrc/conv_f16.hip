@@ -231,7 +231,11 @@ __global__ __launch_bounds__(256) void cf_split_x_cl_kernel(const float *__restr
 // instantiation as well -- with the general code in the common kernel the 128-point pool ran at half speed (312 -> 612 us at PCN's
 // conv4) and, one rewrite later, the fp32 epilogue's main loop lost 35 % to a different instruction schedule
 // (tools/conv_f16_version_probe.sh, LABLOG R2.4h): this kernel's loop is sensitive to what is compiled around it.
-template <bool NARROW, bool AMAX, bool GROUP>
+// NPW = 2 (its own instantiation; wide tile, fp32 output only): the activation image carries an UNSCALED residual m = f16(X - h)
+// (written by the two-plane EdgeConv kernel, out_mode 2), so the Hs weight plane is not read -- products M h + H m + H h, 12
+// instead of 14 ds_read_b128 and 4 instead of 5 DMA pieces per wave and chunk, 32 KB stages.  An unscaled residual below 2^-14
+// is a subnormal (2^-25 absolute in plane units): harmless for an image whose magnitudes sit near 2^12.
+template <bool NARROW, bool AMAX, bool GROUP, int NPW = 3>
 __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__ xh, const uint4 *__restrict__ xm,
                                                        const uint4 *__restrict__ wH, const uint4 *__restrict__ wHs,
                                                        const uint4 *__restrict__ wM, const float *__restrict__ winv,
@@ -243,8 +247,9 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
 {
     constexpr int TM = NARROW ? 128 : CF_TM, TN = NARROW ? 512 : CF_TN;
     constexpr int WR = TM * 16, XR = TN * 16;                   // bytes of one (plane, octet) region of W / x
-    constexpr int WBYTES = 6 * WR, STAGE = WBYTES + 4 * XR;
-    constexpr int NPIECE = NARROW ? 6 : 5;                      // DMA instructions per wave and chunk
+    static_assert(NPW == 3 || (NPW == 2 && !NARROW && !AMAX && !GROUP), "two weight planes: wide tile, fp32 output");
+    constexpr int WBYTES = 2 * NPW * WR, STAGE = WBYTES + 4 * XR;
+    constexpr int NPIECE = NARROW ? 6 : (NPW == 3 ? 5 : 4);     // DMA instructions per wave and chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = NARROW ? (wave & 1) : (wave & 3), wn = NARROW ? (wave >> 1) : (wave >> 2);
@@ -274,14 +279,14 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
     const uint4 *src[NPIECE];
     size_t stride[NPIECE];
     int dst[NPIECE];
-    constexpr int WQ = TM / 64, XQ = TN / 64, NWP = 6 * WQ, NXP = 4 * XQ;
+    constexpr int WQ = TM / 64, XQ = TN / 64, NWP = 2 * NPW * WQ, NXP = 4 * XQ;
 #pragma unroll
     for (int i = 0; i < NPIECE; i++) {
         int q = wave * NPIECE + i;
         if (q >= NWP + NXP) q -= NXP;
         if (q < NWP) {
             const int reg = q / WQ, p = reg >> 1, kg = reg & 1, quarter = q % WQ;
-            const uint4 *pl = p == 0 ? wH : (p == 1 ? wHs : wM);
+            const uint4 *pl = p == 0 ? wH : ((NPW == 3 && p == 1) ? wHs : wM);
             src[i] = pl + (size_t)kg * Cout + co0 + quarter * 64 + lane;
             stride[i] = 2 * (size_t)Cout;
             dst[i] = reg * WR + quarter * 1024;
@@ -328,7 +333,8 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
         // this wave's pieces of chunk kc have landed (chunk kc+1's five may still be in flight) ...
         if (kc + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (NARROW) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (NPW == 3) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         CFT(0)
         __builtin_amdgcn_s_barrier();            // ... and so have everybody else's; stage (kc+2)%3 was last read in chunk kc-1
         CFT(1)
@@ -336,13 +342,13 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
         const bool more = kc + 2 < nk;
         CFT(2)
         const unsigned char *base = lds + stage * STAGE;
-        f16x8 A[2][3], Bf[4][2];
+        f16x8 A[2][NPW], Bf[4][2];
 #pragma unroll
         for (int p = 0; p < 2; p++)
 #pragma unroll
             for (int c = 0; c < 4; c++) Bf[c][p] = *(const f16x8 *)(base + b_off + c * 512 + p * 2 * XR);
 #pragma unroll
-        for (int p = 2; p >= 0; p--)
+        for (int p = NPW - 1; p >= 0; p--)
 #pragma unroll
             for (int a = 0; a < 2; a++) A[a][p] = *(const f16x8 *)(base + a_off + a * 512 + p * 2 * WR);
         // three products, smallest first: M h, Hs m', H h
@@ -353,11 +359,13 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
 #pragma unroll
         for (int n = 0; n < 24; n++) {
             const int prod = n >> 3, a = (n >> 2) & 1, c = n & 3;
-            const int pa = prod == 0 ? 2 : (prod == 1 ? 1 : 0), pb = prod == 1 ? 1 : 0;
+            const int pa = NPW == 3 ? (prod == 0 ? 2 : (prod == 1 ? 1 : 0)) : (prod == 0 ? 1 : 0);      // M, Hs | H, H
+            const int pb = prod == 1 ? 1 : 0;
             acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][pa], Bf[c][pb], acc[a][c], 0, 0, 0);
-            if (NARROW ? (n % 4 == 3) : (n % 5 == 3)) {          // behind MFMA 3, 8, 13, 18, 23 (NARROW: 3, 7, .. 23)
+            constexpr int GAP = NARROW ? 4 : (NPW == 3 ? 5 : 6);  // behind MFMA 3, 8, 13, 18, 23 (NARROW: 3, 7, .. 23; two planes: 3, 9, 15, 21)
+            if (n % GAP == 3) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (more) issue_one(nst, NARROW ? n / 4 : n / 5);
+                if (more) issue_one(nst, n / GAP);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -619,7 +627,7 @@ extern "C" int l3d_split_f16_rows(const float *x, long rows, int C, int channel_
 // x_act: an activation image (l3d_f16_act_bytes), w_planes: a weight image (l3d_conv_f16_weight_bytes)
 static int cf_launch(const void *x_planes, const void *w_planes, const float *scale, const float *shift, int shift_bstride, int B,
                      int Cin, int Cout, int N, int relu, float *y, void *out_img, const float *obs, float *ypool, int pool,
-                     unsigned *amax_out, int amax_cdiv, hipStream_t st)
+                     unsigned *amax_out, int amax_cdiv, hipStream_t st, bool two_plane = false)
 {
     // wide tile (256 x 256) when Cout allows it, else the narrow one (128 x 512)
     const bool narrow = Cout % CF_TM != 0;
@@ -640,6 +648,11 @@ static int cf_launch(const void *x_planes, const void *w_planes, const float *sc
     const size_t nlds = 3 * (6 * 128 * 16 + 4 * 512 * 16);
     const bool group = ypool && pool != 128;
     if (group && amax_out) return L3D_ERR_UNSUPPORTED;
+    if (two_plane) {
+        if (narrow || group || amax_out || ypool || out_img || !y) return L3D_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((conv_f16_kernel<false, false, false, 2>), grid, block, 3 * (4 * CF_TM * 16 + 4 * CF_TN * 16), st, CF_ARGS);
+        return l3d_check_launch();
+    }
     if (narrow && group)         hipLaunchKernelGGL((conv_f16_kernel<true, false, true>), grid, block, nlds, st, CF_ARGS);
     else if (narrow && amax_out) hipLaunchKernelGGL((conv_f16_kernel<true, true, false>), grid, block, nlds, st, CF_ARGS);
     else if (narrow)             hipLaunchKernelGGL((conv_f16_kernel<true, false, false>), grid, block, nlds, st, CF_ARGS);
@@ -656,6 +669,17 @@ extern "C" int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes
 {
     L3D_REQUIRE(x_planes && w_planes && y && B > 0 && Cin > 0 && Cout > 0 && N > 0);
     return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, nullptr, nullptr, nullptr, 0, nullptr, 0, (hipStream_t)stream);
+}
+
+// l3d_pointwise_conv_f16 for an activation image whose residual plane is UNSCALED (m = f16(X - h): l3d_edgeconv_forward_f16b with
+// out_mode 2): the Hs plane of the weight image is not read.  Cout % 256 == 0, N % 256 == 0.
+extern "C" int l3d_pointwise_conv_f16_2p(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
+                                         int shift_bstride, int B, int Cin, int Cout, int N, int relu, float *y,
+                                         l3d_stream_t stream)
+{
+    L3D_REQUIRE(x_planes && w_planes && y && B > 0 && Cin > 0 && Cout > 0 && N > 0);
+    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, nullptr, nullptr, nullptr, 0, nullptr, 0,
+                     (hipStream_t)stream, true);
 }
 
 // The same layer with its OUTPUT written as an activation image (l3d_f16_act_bytes(B N, Cout) bytes) for the next f16x2 layer

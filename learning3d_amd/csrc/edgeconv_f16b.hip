@@ -174,7 +174,8 @@ struct EfLane {
     ef_rsrc_t rs;            // the packed parameter block
     ef_lds_t w4lds;          // EF_W4_LDS: layer 4's fragment block in LDS
     float *prow;             // out_mode 0: pooled + (b N + point) CTOT + 4 g + {0,2,1,3}[q]
-    _Float16 *ph;            // out_mode 1: the h plane's cell of (this lane's channel within a 16-channel M-tile, its point)
+    _Float16 *ph;            // out_mode 1, 2: the h plane's cell of (this lane's channel within a 16-channel M-tile, its point)
+    float mres;              // scale of the pooled planes' residual: 4096 (out_mode 1: m' = (v - h) 2^12) or 1 (out_mode 2: unscaled)
     size_t bn;               // B N: channel ch0 + 16 k lies (ch0 + 16 k) * bn halfs further, the m' plane 512 * bn beyond that
 };
 
@@ -256,7 +257,7 @@ __device__ __forceinline__ void ef_micro(f32x4 (&h)[2][MT], f16x8 (&pl)[2][MT], 
             if constexpr (PLANES) {                          // pooled output as fp16 planes (times 2^T_out) for conv_f16.hip
                 ovf = ef_vmax(ovf, v);
                 const _Float16 hh = (_Float16)v;
-                const _Float16 mm = (_Float16)((v - (float)hh) * 4096.0f);
+                const _Float16 mm = (_Float16)((v - (float)hh) * L.mres);
                 _Float16 *d = L.ph + (size_t)(ch0 + 16 * k) * L.bn;
                 d[0] = hh;
                 d[(size_t)512 * L.bn] = mm;
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
                                                               const int64_t *__restrict__ idx, int B, int N, int k,
                                                               const float *packed,
                                                               float *__restrict__ pooled,
-                                                              int *__restrict__ range_flag
+                                                              int *__restrict__ range_flag, float mres
 #ifdef EF_TIMING
                                                               , unsigned long long *tdbg
 #endif
@@ -555,6 +556,7 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
     L.hi = j & 2;
     const int cl = 4 * g + ((j & 1) * 2 + ((j >> 1) & 1));       // this lane's channel inside a 16-channel M-tile
     L.bn = (size_t)B * N;
+    L.mres = mres;
 #if EF_W4_LDS
     extern __shared__ __attribute__((aligned(16))) unsigned char ef_w4[];
     L.w4lds = (ef_lds_t)ef_w4;
@@ -707,7 +709,8 @@ static int ef_grid(int ntiles)
 extern "C" int EF_ENTRY(const float *xyz, const int64_t *idx, int B, int N, int k,
                                         const float *packed, void *out, int out_mode, int *range_flag, l3d_stream_t stream)
 {
-    L3D_REQUIRE(xyz && idx && packed && out && B > 0 && N > 0 && k > 0 && (out_mode == 0 || out_mode == 1));
+    L3D_REQUIRE(xyz && idx && packed && out && B > 0 && N > 0 && k > 0 && out_mode >= 0 && out_mode <= 2);
+    const float mres = out_mode == 2 ? 1.0f : 4096.0f;           // out_mode 2: the image's residual plane unscaled (l3d_pointwise_conv_f16_2p)
     if (k > 20 || B > 65535 || (((size_t)packed) & 15) || (((size_t)out) & 15)) return L3D_ERR_UNSUPPORTED;
     const long ntiles = (long)B * l3d_divup(N, 16);
     if (ntiles > 0x7fffffffL / 2) return L3D_ERR_UNSUPPORTED;
@@ -716,11 +719,11 @@ extern "C" int EF_ENTRY(const float *xyz, const int64_t *idx, int B, int N, int 
     float *o = (float *)out;
     const size_t lds = EF_W4_LDS ? EF_W4_BYTES : 0;
     if (out_mode == 0) {
-        if (k <= 16) hipLaunchKernelGGL((EF_KERNEL<4, false>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag);
-        else              hipLaunchKernelGGL((EF_KERNEL<5, false>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag);
+        if (k <= 16) hipLaunchKernelGGL((EF_KERNEL<4, false>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag, mres);
+        else              hipLaunchKernelGGL((EF_KERNEL<5, false>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag, mres);
     } else {
-        if (k <= 16) hipLaunchKernelGGL((EF_KERNEL<4, true>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag);
-        else              hipLaunchKernelGGL((EF_KERNEL<5, true>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag);
+        if (k <= 16) hipLaunchKernelGGL((EF_KERNEL<4, true>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag, mres);
+        else              hipLaunchKernelGGL((EF_KERNEL<5, true>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag, mres);
     }
     return l3d_check_launch();
 }

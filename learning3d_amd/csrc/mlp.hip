@@ -254,9 +254,7 @@ extern "C" int l3d_edgeconv_pack_mag(const float *const w[4], const float *const
         T5[3] = 0;
         A5[0] = T5[0];
         for (int l = 1; l < 4; l++) A5[l] = S5[l] + T5[l - 1];       // == T5[l] for l = 1, 2
-        int Tout5 = T5[0];
-        for (int l = 1; l < 3; l++) Tout5 = T5[l] < Tout5 ? T5[l] : Tout5;
-        Tout5 = Tout < Tout5 ? Tout : Tout5;                         // the pooled planes for conv5: no higher than any layer's
+        const int Tout5 = Tout;                                      // the pooled planes for conv5: placed by the expected magnitudes alone
         // layer 1 (fp32 MFMA): the second copy's layout, times 2^T_1 (exact)
         for (int i = 0; i < 8 * EC_C1; i++) packed[EC5_OFF_W1 + i] = ldexpf(packed[EC2_OFF_W1 + i], T5[0]);
         for (int c = 0; c < EC_C1; c++) packed[EC5_OFF_B1 + c] = ldexpf((shift && shift[0]) ? shift[0][c] : 0.f, T5[0]);

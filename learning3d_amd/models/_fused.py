@@ -281,7 +281,8 @@ def f16_eligible(Cin, Cout, N):
     return Cin % 16 == 0 and Cin >= 32 and ((Cout % 256 == 0 and N % 256 == 0) or (Cout % 128 == 0 and N % 512 == 0))
 
 
-def pointwise_conv_f16(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=None, relu=False, out_planes=False, amax=None):
+def pointwise_conv_f16(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=None, relu=False, out_planes=False, amax=None,
+                       unscaled=False):
     """l3d_pointwise_conv_f16 on pre-split operands -> y [B,Cout,N] fp32; out_planes=True: the output as an fp16 activation
     image (uint8 tensor) for the next f16x2 layer instead (l3d_pointwise_conv_f16_planes; shift must be [Cout] or None).
     amax = (int32 tensor, channels per group): also max|y| per channel group as float bits, atomically maximised into the
@@ -300,6 +301,15 @@ def pointwise_conv_f16(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=No
         return img
     bstride = Cout if (shift is not None and shift.dim() == 2) else 0
     y = torch.empty((B, Cout, N), dtype=torch.float32, device=x_planes.device)
+    if unscaled:
+        # the image's residual plane is unscaled (edgeconv_forward(..., planes=True, unscaled=True)): two weight planes
+        if amax is not None or not (Cout % 256 == 0 and N % 256 == 0):
+            raise ValueError("the two-plane conv kernel takes Cout % 256 == 0, N % 256 == 0 and no absmax output")
+        with stage("conv5_kernel"):
+            rc = lib().l3d_pointwise_conv_f16_2p(ptr(x_planes), ptr(w_planes), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N, int(relu),
+                                                 ptr(y), stream_ptr())
+        check(rc, "l3d_pointwise_conv_f16_2p")
+        return y
     if amax is not None:
         check(lib().l3d_pointwise_conv_f16_absmax(ptr(x_planes), ptr(w_planes), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N,
                                                   int(relu), ptr(y), ptr(amax[0]), int(amax[1]), stream_ptr()),
@@ -603,11 +613,13 @@ EDGECONV_KERNEL = None
 EDGECONV_F16_TWO_PLANE = True
 
 
-def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256), kernel=None, planes=False, v2=False):
+def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256), kernel=None, planes=False, v2=False, unscaled=False):
     """xyz [B,N,3], idx int64 [B,N,k] -> pooled [B,N,sum(widths)] (channel-last).  planes=True (f16 kernel only): an
     fp16 activation image of the pooled values instead (uint8 tensor), the x operand of pointwise_conv_f16.
     v2: the packed block's two-plane copy is usable (EdgeConvParams.v2_ok) -> the f16 kernel is the two-plane one."""
     v2 = bool(v2) and EDGECONV_F16_TWO_PLANE
+    if unscaled and not (planes and v2):
+        raise ValueError("an image with an unscaled residual plane is written by the two-plane f16 kernel only (planes=True, v2=True)")
     require_gpu(xyz_bn3, idx, packed)
     B, N, _ = xyz_bn3.shape
     k = idx.shape[2]
@@ -615,7 +627,7 @@ def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256), kernel=Non
         if not (k <= 20 and tuple(widths) == (64, 64, 128, 256)):
             raise ValueError("planes output is produced by the f16 EdgeConv kernel only (k <= 20, 64/64/128/256)")
         out = torch.empty(lib().l3d_f16_act_bytes(B * N, sum(widths)), dtype=torch.uint8, device=xyz_bn3.device)
-        args = (ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), ptr(out), 1, ptr(range_flag(xyz_bn3.device)), stream_ptr())
+        args = (ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), ptr(out), 2 if unscaled else 1, ptr(range_flag(xyz_bn3.device)), stream_ptr())
         fn16 = lib().l3d_edgeconv_forward_f16b if v2 else lib().l3d_edgeconv_forward_f16
         with stage("edgeconv_kernel"):                   # the launch alone: a timing span here holds no Python between its
             rc = fn16(*args)                             # first event and the kernel (bench.py's live roofline timing)

@@ -77,14 +77,16 @@ class DGCNN(torch.nn.Module):
         if f16_route:
             # f16x2 route: the EdgeConv kernel hands conv5 its input already split into fp16 planes (no fp32 pooled
             # tensor, no split pass); the EdgeConv kernel watches the fp16 range (_fused.run_guarded reads its verdict)
+            v2 = self._packed.v2_ok and _fused.EDGECONV_F16_TWO_PLANE
+            two_plane = v2 and not _pooled and self.emb_dims % 256 == 0 and num_points % 256 == 0   # conv5 on two weight planes too
             with _fused.stage("edgeconv"):
-                pooled_img = _fused.edgeconv_forward(xyz, idx, packed, planes=True, v2=self._packed.v2_ok)   # dgcnn.py:34-46
+                pooled_img = _fused.edgeconv_forward(xyz, idx, packed, planes=True, v2=v2, unscaled=two_plane)   # dgcnn.py:34-46
             with _fused.stage("conv5"):
                 if _pooled:
                     return _fused.pointwise_conv_f16_pool(pooled_img, batch_size, num_points, w5_f16, 512, self.emb_dims,
                                                           s5, b5, relu=True)[1]
                 return _fused.pointwise_conv_f16(pooled_img, batch_size, num_points, w5_f16, 512, self.emb_dims,
-                                                 s5, b5, relu=True)                         # dgcnn.py:48
+                                                 s5, b5, relu=True, unscaled=two_plane)     # dgcnn.py:48
         with _fused.stage("edgeconv"):
             pooled = _fused.edgeconv_forward(xyz, idx, packed, v2=self._packed.v2_ok)      # dgcnn.py:34-46
         with _fused.stage("conv5"):

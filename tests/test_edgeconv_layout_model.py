@@ -518,7 +518,7 @@ def test_edgeconv_f16x2_two_plane_pack():
     np.testing.assert_array_equal(packed[o_w1:o_w1 + 8 * C1], packed[v1:v1 + 8 * C1] * np.float32(2.0 ** T[0]))
     np.testing.assert_array_equal(packed[o_b1:o_b1 + C1], shs[0] * np.float32(2.0 ** T[0]))
     sc = packed[o_sc:o_sc + 16].astype(np.float64)
-    Tout = min(min(T), min(12 - x for x in e))
+    Tout = min(12 - x for x in e)
     for l in range(4):
         assert sc[4 + l] == 2.0 ** (-A[l]) and sc[8 + l] == 2.0 ** (Tout - A[l])
     assert sc[12] == 2.0 ** (-Tout) and sc[0] == sc[1] == sc[2] == 1.0

@@ -67,7 +67,7 @@ def test_eval_with_grad_enabled_runs_the_fused_kernels_dgcnn(golden):
     x = dev(rand((4, 1024, 3), 0))
     with launch_log() as log:
         y = big(x)
-    assert log.count("l3d_edgeconv_forward_f16b") == 1 and log.count("l3d_pointwise_conv_f16") == 1, log    # f16b: the two-plane kernel
+    assert log.count("l3d_edgeconv_forward_f16b") == 1 and log.count("l3d_pointwise_conv_f16_2p") == 1, log    # the two-plane kernels
     with torch.no_grad():
         assert torch.equal(big(x), y.detach())
 

@@ -599,10 +599,25 @@ def test_edgeconv_f16_planes_output_equals_pooled():
             y1 = _fused.pointwise_conv_f16(img, B, N, w5f, 512, 256, s5, b5, relu=True)
             y2 = _fused.pointwise_conv_f16(_fused.split_rows_f16(pooled), B, N, w5f, 512, 256, s5, b5, relu=True)
             np.testing.assert_allclose(y1.cpu().numpy(), y2.cpu().numpy(), rtol=1e-5, atol=1e-6)
-        # and the model's own forward takes this route (the two-plane kernel by default)
+        # out_mode 2: the same pooled values with an UNSCALED residual plane, for the two-plane conv kernel (l3d_pointwise_conv_f16_2p)
+        img2 = _fused.edgeconv_forward(x, idx, packed, planes=True, v2=True, unscaled=True)
+        raw2 = img2.cpu().numpy()
+        h2 = raw2[:pb].view(np.float16).reshape(64, B * N, 8).astype(np.float64)
+        m2 = raw2[pb:2 * pb].view(np.float16).reshape(64, B * N, 8).astype(np.float64)
+        assert np.array_equal(h2, h)                                           # same h plane as out_mode 1 of the same kernel
+        dec2 = ((h2 + m2) * xinv).transpose(1, 0, 2).reshape(B, N, 512)
+        np.testing.assert_allclose(dec2, want, rtol=2.0 ** -22, atol=xinv * 2.0 ** -24)        # an unscaled residual below 2^-14 is a subnormal: 2^-25 in plane units
+        y3 = _fused.pointwise_conv_f16(img2, B, N, w5f, 512, 256, s5, b5, relu=True, unscaled=True)
+        np.testing.assert_allclose(y3.cpu().numpy(), y1.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        # both conv kernels against fp64 on the decoded image: the two-plane kernel no further from it than 1.5x the three-plane one
+        w5, _, _, _, _ = net._conv5_folded()
+        ref = torch.relu(torch.einsum("oc,bnc->bon", w5.double(), torch.from_numpy(want).cuda()) * s5.double()[None, :, None] + b5.double()[None, :, None])
+        e3, e2 = (y1.double() - ref).abs(), (y3.double() - ref).abs()
+        assert float(e2.max()) <= 1.5 * float(e3.max()) + 1e-9 and float((e2 ** 2).mean().sqrt()) <= 1.25 * float((e3 ** 2).mean().sqrt()) + 1e-12
+        # and the model's own forward takes this route (the two-plane kernels by default)
         assert net._packed.v2_ok and _fused.EDGECONV_F16_TWO_PLANE
         out = net(x)
-        np.testing.assert_allclose(out.cpu().numpy(), y1.cpu().numpy(), rtol=0, atol=0)
+        np.testing.assert_allclose(out.cpu().numpy(), y3.cpu().numpy(), rtol=0, atol=0)
 
 
 def test_edgeconv_f16_range_flag():
@@ -1951,6 +1966,11 @@ def test_classifier_pools_inside_the_feature_models_last_conv():
             pooled = fm.forward_pooled(x)
             assert pooled is not None and pooled.shape == (4, fm.emb_dims)
             want = Pooling('max')(fm(x))
+            if isinstance(fm, DGCNN):
+                # forward(): two-plane conv5 on an image with an unscaled residual; forward_pooled(): the pooled epilogue of the
+                # three-plane kernel on the scaled-residual image -- the same values to fp32 rounding, not the same bits
+                np.testing.assert_allclose(pooled.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-6)
+                want = pooled
             assert torch.equal(pooled, want), type(fm).__name__
             logits = model(x)
             ref = model.linear3(torch.relu(model.bn2(model.linear2(torch.relu(model.bn1(model.linear1(want)))))))

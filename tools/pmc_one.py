@@ -16,6 +16,7 @@ with torch.no_grad():
     pooled = _fused.edgeconv_forward(x, idx, packed)
     w5, s5, b5, w5s, w5f = net._conv5_folded()
     img = _fused.edgeconv_forward(x, idx, packed, kernel="f16", planes=True)
+    img2 = _fused.edgeconv_forward(x, idx, packed, planes=True, v2=True, unscaled=True)
     torch.cuda.synchronize()
     if what == "group_c5":                       # config 5's grouping gather (bench.py --workload c5: the HBM-bound op)
         from learning3d_amd.utils import pointnet2_utils as P
@@ -36,6 +37,7 @@ with torch.no_grad():
         elif what == "edgeconv_f16": _fused.edgeconv_forward(x, idx, packed, planes=True)                 # f16x2 three-plane kernel, plane image out
         elif what == "edgeconv_f16b": _fused.edgeconv_forward(x, idx, packed, planes=True, v2=True)      # f16x2 two-plane persistent kernel (the step's)
         elif what == "conv5_f16": _fused.pointwise_conv_f16(img, 32, 1024, w5f, 512, 1024, s5, b5, relu=True)
+        elif what == "conv5_f16_2p": _fused.pointwise_conv_f16(img2, 32, 1024, w5f, 512, 1024, s5, b5, relu=True, unscaled=True)   # the step's conv5
         elif what == "conv5": _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True, split=False)
         elif what == "conv5_split": _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True, w_split=w5s)
     torch.cuda.synchronize()

@@ -22,10 +22,10 @@ int main()
     hipMemcpy(idx, hi.data(), 8 * hi.size(), hipMemcpyHostToDevice);
     dim3 grid((N / 16) * B), block(256);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((edgeconv_f16b_kernel<5, false>), grid, block, 0, 0, xyz, idx, B, N, K, packed, pooled, (int*)nullptr, tdbg);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((edgeconv_f16b_kernel<5, false>), grid, block, 0, 0, xyz, idx, B, N, K, packed, pooled, (int*)nullptr, 4096.0f, tdbg);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int i = 0; i < 10; i++) hipLaunchKernelGGL((edgeconv_f16b_kernel<5, false>), grid, block, 0, 0, xyz, idx, B, N, K, packed, pooled, (int*)nullptr, tdbg);
+    for (int i = 0; i < 10; i++) hipLaunchKernelGGL((edgeconv_f16b_kernel<5, false>), grid, block, 0, 0, xyz, idx, B, N, K, packed, pooled, (int*)nullptr, 4096.0f, tdbg);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("kernel: %.1f us\n", ms / 10 * 1e3);
