@@ -545,8 +545,10 @@ __device__ __forceinline__ int wave_min_i(int v)
 
 // LDS_XYZ: the cloud is also kept in LDS (12 B/point, n <= 12288) so the coordinates of the point
 // picked in the previous round come from a wave-uniform LDS read instead of a dependent global load.
+// Launch bound: PPT >= 8 is only ever launched with 512 threads (launch_fps: n >= 4096), and under a 1024-thread bound (128 VGPRs)
+// the 32-points-per-thread instantiation spilled 118-186 VGPRs (profiles/round2_kernel_resources.txt).
 template <int PPT, bool OUT64, bool LDS_XYZ>
-__global__ __launch_bounds__(1024) void fps_kernel(int n, int m, const float *__restrict__ xyz,
+__global__ __launch_bounds__(PPT >= 8 ? 512 : 1024) void fps_kernel(int n, int m, const float *__restrict__ xyz,
                                                    const int64_t *__restrict__ start,
                                                    float *__restrict__ temp,
                                                    void *__restrict__ out)

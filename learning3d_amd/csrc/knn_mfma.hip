@@ -40,6 +40,7 @@ typedef unsigned long long u64;
 
 #define KM_MCAP 64                         // keys per query list
 #define KM_STRIDE 65                       // u64 row stride of the lists (bank spread)
+#define KM_WPAD 16                         // floats between the waves' candidate blocks (see the kernel)
 #define KM_T3S 25                          // float row stride of the 24 per-query bound values
 #define KM_PAD (-3.0e38f)                  // -xx of a padding candidate: its ranking value stays finite and below any real one
 
@@ -73,7 +74,10 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
 {
     const int T = CT > 0 ? CT : T_;
     extern __shared__ __attribute__((aligned(16))) unsigned char km_smem[];
-    const int P = 4 * T * 32;                                  // candidate slots (>= N), [wave][tile][row]
+    // candidate slots (>= N), [wave][tile][row]; every wave's block is followed by KM_WPAD floats: the staging scatter sends the
+    // four lanes that differ only in (c & 7) >> 1 to the same offset of four DIFFERENT blocks, and with a block of T x 32
+    // floats (a multiple of the 64 banks) they all hit one bank -- the 24.5 % LDS conflict rate of round 2's PMC pass
+    const int NS = 4 * T * 32, WS = T * 32 + KM_WPAD, P = 4 * WS;
     float *cx = (float *)km_smem;                              // cx | cy | cz | cw, P floats each
     float *cz = cx + 2 * P;
     float *dump = cx + 4 * P;                                  // [4 waves][2 tiles][4 quads][64 lanes][4]
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
     KMT(7)
 
     // ---- stage the cloud in slot order (coalesced reads issued four deep, scattered LDS writes), padding included
-    for (int c0 = tid; c0 < P; c0 += 1024) {
+    for (int c0 = tid; c0 < NS; c0 += 1024) {
         float x[4], y[4], z[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -105,10 +109,10 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int c = c0 + 256 * u;
-            if (c < P) {
+            if (c < NS) {
                 const float w = c < N ? -((x[u] * x[u] + y[u] * y[u]) + z[u] * z[u]) : KM_PAD;
                 const int l8 = c & 7, s = c >> 3, j = s >> 4, r = s & 15;
-                const int p = ((l8 >> 1) * T + j) * 32 + ((r >> 2) << 3) + ((l8 & 1) << 2) + (r & 3);
+                const int p = (l8 >> 1) * WS + j * 32 + ((r >> 2) << 3) + ((l8 & 1) << 2) + (r & 3);
                 cx[p] = x[u];
                 cx[P + p] = y[u];
                 cz[p] = z[u];
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
     const float a3 = h ? 0.0f : 1.0f;
     const float *cxy = cx + h * P;                             // lane (i, h) supplies k-slot h of row i
     const float *czw = cz + h * P;
-    const int at0 = wave * T * 32 + i;
+    const int at0 = wave * WS + i;
     KMT(0)
     __syncthreads();
     KMT(1)
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
 size_t l3d_knn_mfma_lds_bytes(int N)
 {
     const int T = l3d_divup(N, 128);
-    return (size_t)4 * (4 * T * 32) * 4 + 4 * 2048 * 4 + 32 * KM_STRIDE * 8 + 32 * KM_T3S * 4 + 32 * 9 * 4 + 32 * 4 + 16;
+    return (size_t)4 * (4 * (T * 32 + KM_WPAD)) * 4 + 4 * 2048 * 4 + 32 * KM_STRIDE * 8 + 32 * KM_T3S * 4 + 32 * 9 * 4 + 32 * 4 + 16;
 }
 
 bool l3d_knn_mfma_supported(int N, int k) { return k <= 24 && N >= 256 && N <= 2048; }
