@@ -298,6 +298,13 @@ int l3d_attention_forward_f16_maxima(const float *q, const float *k, const float
                                      long q_bstride, long k_bstride, long v_bstride, float scale, const void *maxima,
                                      float *ctx, void *ctx_img, l3d_stream_t stream);
 
+/* The same computation on the restructured kernel (attention_f16b.hip: 256 queries per workgroup, Q fragments in registers, the
+ * probabilities handed from the score accumulators to the second product without leaving registers, one barrier per 32-key
+ * tile, unscaled fp16 residuals).  maxima_ready != 0: workspace already holds the three maxima. */
+int l3d_attention_forward_f16b(const float *q, const float *k, const float *v, int B, int H, int D, int N, int M,
+                               long q_bstride, long k_bstride, long v_bstride, float scale, void *workspace, int maxima_ready,
+                               float *ctx, void *ctx_img, l3d_stream_t stream);
+
 /* LayerNorm of DCP's pointer network == utils/transformer.py:109-119 (unbiased std, eps added to std):
  *   y[r][:] = a * (x[r][:] - mean_r) / (std_r + eps) + b,   x, y [rows][C] fp32, C % 4 == 0, C <= 2048. */
 int l3d_layernorm_ref(const float *x, const float *a, const float *b, float eps, long rows, int C, float *y,

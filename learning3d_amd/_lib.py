@@ -68,6 +68,7 @@ SIGNATURES = {
     "l3d_attention_forward_strided": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _P],
     "l3d_attention_forward_f16": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _P, _P, _P],
     "l3d_attention_forward_f16_maxima": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _P, _P, _P],
+    "l3d_attention_forward_f16b": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _I, _P, _P, _P],
     "l3d_layernorm_ref": [_P, _P, _P, _F, _L, _I, _P, _P],
     "l3d_layernorm_planes": [_P, _P, _P, _F, _L, _I, _P, _P, _P],
     "l3d_add_transposed": [_P, _P, _I, _I, _I, _P, _P],

@@ -335,6 +335,15 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const float *__re
     }
 }
 
+// host-side handle on at_absmax3_kernel for attention_f16b.hip (zeroes the three words, then the reduction)
+int l3d_attention_absmax3(const float *q, const float *k, const float *v, long q_bs, long k_bs, long v_bs, long q_span, long kv_span,
+                          int B, unsigned *amax, hipStream_t st)
+{
+    if (hipMemsetAsync(amax, 0, 16, st) != hipSuccess) return L3D_ERR_LAUNCH;
+    hipLaunchKernelGGL(at_absmax3_kernel, dim3(512, 3), dim3(256), 0, st, q, k, v, q_bs, k_bs, v_bs, q_span, kv_span, B, amax);
+    return l3d_check_launch();
+}
+
 // workspace: 16 bytes of device memory (the three maxima); ctx [B, H D, N] fp32 and / or ctx_img = the context as an fp16
 // activation image (l3d_f16_act_bytes(B N, H D) bytes) for l3d_pointwise_conv_f16; everything else as
 // l3d_attention_forward_strided

@@ -17,6 +17,7 @@ import torch.nn.functional as F
 FLASH_ATTENTION = True      # l3d_attention_forward for d_k in {32, 64, 128}; False: torch matmul + softmax + matmul
 DEFER_LN_VALUES = True      # sublayer norms write only their fp16 plane image; fp32 values on demand (_ln_values)
 PROJECTION_MAXIMA = True    # the f16x2 q|k|v projections report max|q|, |k|, |v| from their epilogues (False: a pass over q, k, v)
+ATTENTION_F16B = True       # f16x2 attention on the restructured kernel (attention_f16b.hip); False: attention_f16.hip
 
 _ATT_WS = {}
 
@@ -254,13 +255,24 @@ class MultiHeadedAttention(nn.Module):
                     # both GEMMs as f16x2 (operand scales from the tensors' maxima); the context leaves the kernel as the
                     # fp16 plane image of the f16x2 conv kernel, so the output projection needs no split pass either
                     img = torch.empty(lib().l3d_f16_act_bytes(nb * n_q, C_), dtype=torch.uint8, device=q.device)
-                    att = lib().l3d_attention_forward_f16_maxima if have_max else lib().l3d_attention_forward_f16
-                    check(att(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
-                              q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),
-                              ptr(ws), None, ptr(img), stream_ptr()), "l3d_attention_forward_f16")
+                    if ATTENTION_F16B:
+                        check(lib().l3d_attention_forward_f16b(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
+                                                               q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),
+                                                               ptr(ws), int(bool(have_max)), None, ptr(img), stream_ptr()),
+                              "l3d_attention_forward_f16b")
+                    else:
+                        att = lib().l3d_attention_forward_f16_maxima if have_max else lib().l3d_attention_forward_f16
+                        check(att(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
+                                  q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),
+                                  ptr(ws), None, ptr(img), stream_ptr()), "l3d_attention_forward_f16")
                     return _linear_cf(out_lin, None, True, planes=(img, nb, n_q)).transpose(1, 2)     # [B,N,C] view
                 ctx = torch.empty((nb, C_, n_q), dtype=torch.float32, device=q.device)
-                if _fused.gemm_arith() == "f16x2":
+                if _fused.gemm_arith() == "f16x2" and ATTENTION_F16B:
+                    check(lib().l3d_attention_forward_f16b(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
+                                                           q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),
+                                                           ptr(ws), int(bool(have_max)), ptr(ctx), None, stream_ptr()),
+                          "l3d_attention_forward_f16b")
+                elif _fused.gemm_arith() == "f16x2":
                     att = lib().l3d_attention_forward_f16_maxima if have_max else lib().l3d_attention_forward_f16
                     check(att(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
                               q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),

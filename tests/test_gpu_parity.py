@@ -1009,6 +1009,24 @@ def test_flash_attention_vs_fp64():
         np.testing.assert_allclose(got16, want, rtol=1e-5, atol=2e-6)
         e3, e16 = out.cpu().numpy().reshape(B, H, D, N) - want, got16 - want
         assert np.abs(e16).max() <= 2.0 * np.abs(e3).max() + 1e-9 and np.sqrt((e16 ** 2).mean()) <= 1.5 * np.sqrt((e3 ** 2).mean()) + 1e-10
+        # the restructured kernel (attention_f16b.hip): same bars; fp32 context and the plane image of it
+        ws.zero_()
+        outb = torch.empty_like(qd)
+        imgb = torch.empty(lib().l3d_f16_act_bytes(B * N, H * D), dtype=torch.uint8, device=qd.device)
+        check(lib().l3d_attention_forward_f16b(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, H * D * N, H * D * M, H * D * M,
+                                               float(1 / np.sqrt(D)), ptr(ws), 0, ptr(outb), ptr(imgb), stream_ptr()), "l3d_attention_forward_f16b")
+        gotb = outb.cpu().numpy().reshape(B, H, D, N)
+        np.testing.assert_allclose(gotb, want, rtol=1e-5, atol=2e-6)
+        eb = gotb - want
+        assert np.abs(eb).max() <= 2.0 * np.abs(e3).max() + 1e-9 and np.sqrt((eb ** 2).mean()) <= 1.5 * np.sqrt((e3 ** 2).mean()) + 1e-10, \
+            (B, H, D, N, M, np.abs(eb).max(), np.abs(e3).max())
+        raw = imgb.cpu().numpy()
+        pb = (H * D // 8) * B * N * 16
+        ph = raw[:pb].view(np.float16).reshape(H * D // 8, B * N, 8).astype(np.float64)
+        pm = raw[pb:2 * pb].view(np.float16).reshape(H * D // 8, B * N, 8).astype(np.float64)
+        xinv = float(raw[2 * pb:2 * pb + 4].view(np.float32)[0])
+        dec = ((ph + pm / 4096.0) * xinv).transpose(1, 0, 2).reshape(B, N, H * D).transpose(0, 2, 1).reshape(B, H, D, N)
+        np.testing.assert_allclose(dec, gotb.astype(np.float64), rtol=2.0 ** -21, atol=np.abs(gotb).max() * 2.0 ** -30)
     # operands far from unit scale: the per-tensor power-of-two scaling must keep fp32-level accuracy (and not overflow fp16)
     for sq, sk, sv in ((1e-4, 3e2, 1e3), (5e3, 1e-3, 1e-5)):
         B, H, D, N, M = 1, 2, 64, 256, 384
@@ -1026,6 +1044,10 @@ def test_flash_attention_vs_fp64():
         check(lib().l3d_attention_forward_f16(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, H * D * N, H * D * M, H * D * M,
                                               float(sc), ptr(ws), ptr(out16), None, stream_ptr()), "l3d_attention_forward_f16")
         np.testing.assert_allclose(out16.cpu().numpy().reshape(B, H, D, N), want, rtol=2e-5, atol=2e-6 * sv)
+        outb = torch.empty_like(qd)
+        check(lib().l3d_attention_forward_f16b(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, H * D * N, H * D * M, H * D * M,
+                                               float(sc), ptr(ws), 0, ptr(outb), None, stream_ptr()), "l3d_attention_forward_f16b")
+        np.testing.assert_allclose(outb.cpu().numpy().reshape(B, H, D, N), want, rtol=2e-5, atol=2e-6 * sv)
 
 
 def test_add_transposed_residual():
