@@ -190,18 +190,33 @@ __global__ __launch_bounds__(512) void attention_f16b_kernel(const float *__rest
 
     // ---- the three phases of a key tile
     // S^T = K Q^T (rows = keys, permuted; column = this lane's query): 3 KS MFMAs
+    // Consecutive MFMAs never share an accumulator: a dependent 32x32x16 MFMA waits for its predecessor's result (the bare loop with
+    // one S accumulator and O[dt] updated three times in a row ran at 0.6 of the matrix-pipe rate, tools/probe_attention_f16b.hip):
+    // S is accumulated in two halves (even / odd k-steps), the PV products walk the d-tiles innermost.
     auto score = [&](f32x16 &S, int stage) {
         const unsigned char *base = ab_lds + stage * STAGE;
+        f32x16 S1;
 #pragma unroll
-        for (int r = 0; r < 16; r++) S[r] = 0.f;
+        for (int r = 0; r < 16; r++) { S[r] = 0.f; S1[r] = 0.f; }
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) {
+        for (int ks = 0; ks < KS; ks += 2) {
+#ifdef AB_NOLDSREAD
+            const f16x8 Kh = Qm[ks], Km = Qh[ks], Kh1 = Qm[ks + 1], Km1 = Qh[ks + 1];
+#else
             const f16x8 Kh = *(const f16x8 *)(base + ka_off + ks * 1024);
             const f16x8 Km = *(const f16x8 *)(base + KPL + ka_off + ks * 1024);
+            const f16x8 Kh1 = *(const f16x8 *)(base + ka_off + (ks + 1) * 1024);
+            const f16x8 Km1 = *(const f16x8 *)(base + KPL + ka_off + (ks + 1) * 1024);
+#endif
             S = __builtin_amdgcn_mfma_f32_32x32x16_f16(Km, Qh[ks], S, 0, 0, 0);
+            S1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Km1, Qh[ks + 1], S1, 0, 0, 0);
             S = __builtin_amdgcn_mfma_f32_32x32x16_f16(Kh, Qm[ks], S, 0, 0, 0);
+            S1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Kh1, Qm[ks + 1], S1, 0, 0, 0);
             S = __builtin_amdgcn_mfma_f32_32x32x16_f16(Kh, Qh[ks], S, 0, 0, 0);
+            S1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Kh1, Qh[ks + 1], S1, 0, 0, 0);
         }
+#pragma unroll
+        for (int r = 0; r < 16; r++) S[r] += S1[r];
     };
     // online softmax in the log2 domain on the raw accumulators (sc2 > 0: the maximum commutes with the scale); accumulator
     // register r = 4 a + b of half g is key 16 (a >> 1) + 8 g + 4 (a & 1) + b.  Leaves the probabilities times 2^12 as the PV
@@ -263,15 +278,24 @@ __global__ __launch_bounds__(512) void attention_f16b_kernel(const float *__rest
     auto pv = [&](int stage, const f16x8 (&Ph)[2], const f16x8 (&Pm)[2]) {
         const unsigned char *base = ab_lds + stage * STAGE;
 #pragma unroll
-        for (int dt = 0; dt < ND; dt++)
+        for (int s2 = 0; s2 < 2; s2++) {
+            f16x8 Vh[ND], Vm[ND];
 #pragma unroll
-            for (int s2 = 0; s2 < 2; s2++) {
-                const f16x8 Vh = *(const f16x8 *)(base + va_off + s2 * (2 * D * 16) + dt * 512);
-                const f16x8 Vm = *(const f16x8 *)(base + VPL + va_off + s2 * (2 * D * 16) + dt * 512);
-                O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Vm, Ph[s2], O[dt], 0, 0, 0);
-                O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Vh, Pm[s2], O[dt], 0, 0, 0);
-                O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Vh, Ph[s2], O[dt], 0, 0, 0);
+            for (int dt = 0; dt < ND; dt++) {
+#ifdef AB_NOLDSREAD
+                Vh[dt] = Qh[dt]; Vm[dt] = Qm[dt];
+#else
+                Vh[dt] = *(const f16x8 *)(base + va_off + s2 * (2 * D * 16) + dt * 512);
+                Vm[dt] = *(const f16x8 *)(base + VPL + va_off + s2 * (2 * D * 16) + dt * 512);
+#endif
             }
+#pragma unroll
+            for (int dt = 0; dt < ND; dt++) O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Vm[dt], Ph[s2], O[dt], 0, 0, 0);
+#pragma unroll
+            for (int dt = 0; dt < ND; dt++) O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Vh[dt], Pm[s2], O[dt], 0, 0, 0);
+#pragma unroll
+            for (int dt = 0; dt < ND; dt++) O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Vh[dt], Ph[s2], O[dt], 0, 0, 0);
+        }
     };
 
     // ---- main loop.  A SIMD hosts wave w and wave w + 4.  Left to themselves both would run the same phase at the same time
@@ -303,7 +327,9 @@ __global__ __launch_bounds__(512) void attention_f16b_kernel(const float *__rest
             if (more) store_tile(st_next);
             score(S, st_cur);
         }
+#ifndef AB_NOBARRIER
         __syncthreads();                                          // tile kt+1 is in place; tile kt-1's stage is free
+#endif
         const int tmp = st_prev;
         st_prev = st_cur;
         st_cur = st_next;
