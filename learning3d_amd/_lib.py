@@ -144,12 +144,15 @@ def lib():
 
 
 LAUNCH_LOG = None      # set to a list to record the name of every C-ABI call that passes through check() (tests: which route ran)
+FAILED_CALLS = 0       # number of C-ABI calls that returned a non-zero status (holders of cross-call device state re-arm on a change)
 
 
 def check(status, what):
     if LAUNCH_LOG is not None:
         LAUNCH_LOG.append(what)
     if status != 0:
+        global FAILED_CALLS
+        FAILED_CALLS += 1
         l = lib()
         msg = l.l3d_status_string(status).decode()
         raise L3DError(f"{what}: {msg} (status {status}, hipError {l.l3d_last_hip_error()})")

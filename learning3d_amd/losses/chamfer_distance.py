@@ -75,10 +75,14 @@ def chamfer_loss_local(dist1, dist2):
     B, N = dist1.shape
     M = dist2.shape[1]
     key = (dist1.device.index, torch.cuda.current_stream(dist1.device).cuda_stream)
-    ws = _LL_WS.get(key)
-    if ws is None:
-        ws = torch.zeros(lib().l3d_chamfer_loss_local_ws_bytes(), dtype=torch.uint8, device=dist1.device)
-        _LL_WS[key] = ws
+    from .. import _lib
+    hit = _LL_WS.get(key)
+    if hit is None or hit[1] != _lib.FAILED_CALLS:
+        # the kernel's last block re-arms the workspace's ticket; after ANY failed C-ABI call (a launch that may have aborted
+        # before doing so) the workspace is zeroed again instead of trusting it
+        ws = hit[0].zero_() if hit is not None else torch.zeros(lib().l3d_chamfer_loss_local_ws_bytes(), dtype=torch.uint8, device=dist1.device)
+        _LL_WS[key] = (ws, _lib.FAILED_CALLS)
+    ws = _LL_WS[key][0]
     part = torch.empty(4, dtype=torch.float64, device=dist1.device)
     loss = torch.empty((), dtype=torch.float32, device=dist1.device)
     check(lib().l3d_chamfer_loss_local_mb(ptr(dist1), ptr(dist2), B, N, M, ptr(ws), ptr(part), ptr(loss), stream_ptr()),

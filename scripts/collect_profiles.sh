@@ -9,7 +9,7 @@ cp_if gpurun_out/r3_bench.json profiles/round3_bench.json
 cp_if gpurun_out/r3_bench_driver.json profiles/round3_bench_driver_args.json
 cp_if gpurun_out/r3_bench_c5.json profiles/round3_bench_c5.json
 cp_if gpurun_out/pmc_edgeconv_f16b.txt profiles/round3_pmc_edgeconv_f16b.txt
-cp_if gpurun_out/pmc_conv5_f16.txt profiles/round3_pmc_conv5_f16.txt
+cp_if gpurun_out/pmc_conv5_f16_2p.txt profiles/round3_pmc_conv5_f16_2p.txt
 cp_if gpurun_out/pmc_knn_mfma.txt profiles/round3_pmc_knn_mfma.txt
 cp_if gpurun_out/pmc_group_c5.txt profiles/round3_pmc_group_c5.txt
 cp_if gpurun_out/r3_kbench.txt profiles/round3_kbench.txt

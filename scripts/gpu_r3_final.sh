@@ -10,7 +10,7 @@ timeout 300 python bench.py --workload c5 --steps 50 --warmup 10 > gpurun_out/r3
 ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r3 -o b -- python $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline > $R/gpurun_out/prof_r3.log 2>&1 )
 ( cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r3_c5 -o c5 -- python $R/bench.py --workload c5 --steps 50 --warmup 10 --no-cpu-baseline --no-graph > $R/gpurun_out/prof_r3_c5.log 2>&1 )
 bash tools/pmc.sh edgeconv_f16b edgeconv_f16b > /dev/null 2>&1
-bash tools/pmc.sh conv5_f16 "^(void )?conv_f16_kernel" > /dev/null 2>&1
+bash tools/pmc.sh conv5_f16_2p "^(void )?conv_f16_kernel" > /dev/null 2>&1
 bash tools/pmc.sh knn_mfma knn_mfma_kernel > /dev/null 2>&1
 bash tools/pmc.sh group_c5 group_concat_kernel > /dev/null 2>&1
 timeout 900 python tools/kbench.py > gpurun_out/r3_kbench.txt 2>&1
