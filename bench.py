@@ -33,6 +33,7 @@ B_PER_GPU, NPTS, KNN, EMB = 32, 1024, 20, 1024
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
 MFMA_F32_PEAK_TF = 157.3         # MI355X_MICROARCH.md: dense fp32 MFMA peak
 MFMA_BF16_PEAK_TF = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA peak (2.17 PF sustained in tools/probe_mfma_bf16.hip)
+FORK_DEFAULT = "none"             # see --fork
 PRECONDITION_STEPS = 150         # untimed, before the --warmup steps (~80 ms of GPU work)
 SPLIT_PRODUCTS = {"f16x2": 3, "bf16x3": 6}    # low-precision MFMA products per fp32 product
 VALU_PEAK_LANEOPS = 256 * 4 * 16 * 2.4e9     # 39.3 T lane-ops/s: 256 CUs x 4 SIMD16 x 2.4 GHz (an fma counts once)
@@ -367,6 +368,11 @@ def main():
                     help="GEMM arithmetic of the shared-MLP kernels (default f16x2: 3 fp16 MFMA products per fp32 product; "
                          "bf16x3: 6 bf16 products, full fp32 exponent range; fp32 = --fp32-mfma)")
     ap.add_argument("--no-graph", action="store_true", help="issue every step's launches eagerly instead of replaying a hipGraph")
+    ap.add_argument("--fork", choices=["none", "start", "edgeconv", "conv5"], default=FORK_DEFAULT,
+                    help="c2: where the step's Chamfer branch (NN search + loss tail; independent of the DGCNN chain) leaves the "
+                         "main stream: 'none' = one stream, the five kernels back to back; 'start' / 'edgeconv' / 'conv5' = on a "
+                         "second stream from the start of the step / from the moment that stage's kernel is issued, joined at "
+                         "the end of the step (two branches of the replayed hipGraph)")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="control-flow self test on CPU/gloo (launcher, sharding, collective, max-over-ranks, JSON): "
                          "NO kernels run and the printed line is not a measurement")
@@ -423,14 +429,42 @@ def main():
 
     from learning3d_amd.losses.chamfer_distance import chamfer_loss_local
 
-    def compute():
-        """the step's kernels: knn -> edgeconv -> conv5, Chamfer NN search, and the loss tail's local part"""
+    branch = torch.cuda.Stream() if args.fork != "none" else None
+
+    def chamfer_branch():
+        with _fused.stage("chamfer"):
+            d1, d2 = cd(a, b)
+        return chamfer_loss_local(d1, d2) if world == 1 else chamfer_partials(d1, d2)
+
+    def compute(fork=True):
+        """the step's kernels: knn -> edgeconv -> conv5, Chamfer NN search, and the loss tail's local part.  The Chamfer pair
+        does not depend on the DGCNN chain: with --fork it is issued on a second stream from the named point of the chain and
+        joined at the end of the step (chamfer_fwd_packed_kernel's 71 VGPRs / 36 KB LDS fit beside conv5's two 204-register
+        waves per SIMD and 120 KB, so its VALU work runs in the matrix kernel's shadow)."""
         with torch.no_grad():
-            feat = net(x)
-            with _fused.stage("chamfer"):
-                d1, d2 = cd(a, b)
-            part = chamfer_loss_local(d1, d2) if world == 1 else chamfer_partials(d1, d2)
-        return feat, part
+            if branch is None or not fork:
+                feat = net(x)
+                return feat, chamfer_branch()
+            main = torch.cuda.current_stream()
+            out = []
+
+            def leave(name):
+                if name == args.fork and not out:
+                    branch.wait_stream(main)
+                    with torch.cuda.stream(branch):
+                        out.append(chamfer_branch())
+
+            if args.fork == "start":
+                leave("start")
+            prev, _fused.ON_STAGE = _fused.ON_STAGE, leave
+            try:
+                feat = net(x)
+            finally:
+                _fused.ON_STAGE = prev
+            if not out:
+                raise SystemExit(f"[bench] --fork {args.fork}: the DGCNN forward never entered that stage")
+            main.wait_stream(branch)
+        return feat, out[0]
 
     # The six launches of a step are captured once into a hipGraph and replayed: at ~0.36 ms of GPU work per step the
     # Python / ctypes launch path (~13 us per launch) had become part of the step time (0.436 ms eager).  Steps that
@@ -442,7 +476,7 @@ def main():
             graph.replay()
             feat, part = graph_out
         else:
-            feat, part = compute()
+            feat, part = compute(fork=not eager)           # event-carrying steps stay on one stream: clean per-kernel durations
         if world == 1:
             return feat, part                              # the whole loss tail ran in one launch (l3d_chamfer_loss_local)
         if sync_loss:
@@ -628,6 +662,8 @@ def main():
                        "global_batch": world * B_PER_GPU, "num_points": NPTS, "k": KNN, "emb_dims": EMB,
                        "untimed_precondition_steps": PRECONDITION_STEPS, "untimed_settle_probes_of_20_steps": settle_probes,
                        "launch": "hipGraph replay of the step's 5 kernels" if graph is not None else "eager launches",
+                       "chamfer_branch": ("one stream" if branch is None else
+                                          f"second stream, leaves the chain at '{args.fork}', joined at the end of the step"),
                        "parallelism": f"batch-sharded x{world}, all_gather of loss partials only"
                                       + ("" if args.sync_loss or world == 1 else " (asynchronous, consumed one step later)")},
             # multi-GPU record: ranks that really joined the process group, its backend ("nccl" = RCCL on ROCm),

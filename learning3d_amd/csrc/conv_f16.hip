@@ -235,6 +235,12 @@ __global__ __launch_bounds__(256) void cf_split_x_cl_kernel(const float *__restr
 // (written by the two-plane EdgeConv kernel, out_mode 2), so the Hs weight plane is not read -- products M h + H m + H h, 12
 // instead of 14 ds_read_b128 and 4 instead of 5 DMA pieces per wave and chunk, 32 KB stages.  An unscaled residual below 2^-14
 // is a subnormal (2^-25 absolute in plane units): harmless for an image whose magnitudes sit near 2^12.
+#ifdef CF_TIMELINE    // tools/probe_conv_timeline.hip: s_memrealtime (100 MHz) marks of every workgroup, through a device global
+__device__ long long *g_cf_timeline;
+#define CFM(i) { if (threadIdx.x == 0) g_cf_timeline[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define CFM(i)
+#endif
 template <bool NARROW, bool AMAX, bool GROUP, int NPW = 3>
 __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__ xh, const uint4 *__restrict__ xm,
                                                        const uint4 *__restrict__ wH, const uint4 *__restrict__ wHs,
@@ -253,6 +259,10 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = NARROW ? (wave & 1) : (wave & 3), wn = NARROW ? (wave >> 1) : (wave >> 2);
+    CFM(0)
+#ifdef CF_TIMELINE
+    if (t == 0) { unsigned id; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id)); g_cf_timeline[(size_t)blockIdx.x * 8 + 7] = id; }
+#endif
     // Tile order (1-D grid).  Workgroup L runs on XCD L % 8, each with its own L2: the Cout tiles of one point tile are
     // consecutive slots of ONE XCD, so the point tile's activation planes come from HBM once instead of once per XCD
     // that happens to host one of its Cout tiles.  It does not change the kernel's time (the reads were hidden), it
@@ -337,6 +347,9 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
         else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         CFT(0)
         __builtin_amdgcn_s_barrier();            // ... and so have everybody else's; stage (kc+2)%3 was last read in chunk kc-1
+#ifdef CF_TIMELINE
+        if (kc == 0) CFM(1)
+#endif
         CFT(1)
         const int nst = stage == 0 ? 2 : stage - 1;                                   // (kc + 2) % 3
         const bool more = kc + 2 < nk;
@@ -385,6 +398,7 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
     return;
 #endif
 
+    CFM(2)
     // ---- epilogue: D[co = 32a + (r&3) + 8(r>>2) + 4(lane>>5)][n = 32c + (lane&31)]
     const float inv = *winv * *xinv;             // 2^-S 2^-T: exact
     if (oph || ypool) {
@@ -535,6 +549,13 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
                 if constexpr (AMAX) acc[a][c][r] = fabsf(v);     // kept for the maximum below (the accumulator is dead)
             }
         }
+#ifdef CF_TIMELINE
+    CFM(3)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CFM(4)
+    __syncthreads();
+    CFM(5)
+#endif
     if constexpr (AMAX) {
         // max|y| per group of amax_cdiv output channels (amax_cdiv % 256 == 0: a workgroup's 256 channels lie in one group), as
         // float bits: the consumer's operand scale (attention_f16.hip takes max|q|, |k|, |v| of a fused q|k|v projection from

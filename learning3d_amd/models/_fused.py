@@ -60,9 +60,13 @@ class StageTimer:
 
 
 TIMER = None
+ON_STAGE = None       # optional callable(name), called as a stage is entered and before its launches are issued: lets a caller
+                      # fork independent work onto another stream at that point of the chain (bench.py --fork)
 
 
 def stage(name):
+    if ON_STAGE is not None:
+        ON_STAGE(name)
     return TIMER.span(name) if TIMER is not None else _NULL
 
 
