@@ -114,6 +114,13 @@ int l3d_chamfer_forward_variant(const float *xyz1, const float *xyz2, int B, int
 int l3d_chamfer_backward(const float *xyz1, const float *xyz2, int B, int N, int M,
                          const float *graddist1, const float *graddist2, const int32_t *idx1,
                          const int32_t *idx2, float *gradxyz1, float *gradxyz2, l3d_stream_t stream);
+/* The same with the kernel choice as an argument (bit-identical results: both add a point's terms in the order of
+ * chamfer_distance.cpp:138-176): variant 0 = scan of the partner cloud's selections per point, 2 = selections sorted by
+ * target in LDS, one binary search per point (N, M <= 32768, else L3D_ERR_UNSUPPORTED), 1 = auto (l3d_chamfer_backward). */
+int l3d_chamfer_backward_variant(const float *xyz1, const float *xyz2, int B, int N, int M,
+                                 const float *graddist1, const float *graddist2, const int32_t *idx1,
+                                 const int32_t *idx2, float *gradxyz1, float *gradxyz2, int variant,
+                                 l3d_stream_t stream);
 /* Loss tail of losses/chamfer_distance.py:38-40, kept on the device (no host sync per step):
  *   l3d_chamfer_partials: partial[0..3] = (sum sqrt(dist1), sum sqrt(dist2), #dist1, #dist2), fp64,
  *       for this rank's shard -- the 32 bytes the multi-GPU path all-gathers over RCCL;

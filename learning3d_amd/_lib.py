@@ -29,6 +29,7 @@ SIGNATURES = {
     "l3d_chamfer_forward": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     "l3d_chamfer_forward_variant": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     "l3d_chamfer_backward": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "l3d_chamfer_backward_variant": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P],
     "l3d_chamfer_partials": [_P, _P, _I, _I, _I, _P, _P],
     "l3d_chamfer_combine": [_P, _I, _P, _P],
     "l3d_chamfer_loss_local": [_P, _P, _I, _I, _I, _P, _P, _P],

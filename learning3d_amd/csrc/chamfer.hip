@@ -356,18 +356,115 @@ __global__ __launch_bounds__(64) void chamfer_bwd_kernel(const float *__restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same gradients from a SORTED selection list.  The scan above does N*M index comparisons per cloud and direction (as
+// many as the forward search does distance evaluations, at a fraction of its rate: 155 us against 18 us at B = 32,
+// N = M = 1024) to find, for every point i, the partner points j with ic[j] == i in ascending j.  Here one 1024-thread
+// workgroup per (cloud, direction) sorts the keys (ic[j] << shift | j) in LDS (bitonic; <= 32768 points = 128 KB), which
+// puts every point's partners next to each other in ascending j; a point then finds its run with one binary search and
+// adds the terms in that order -- the accumulation order of chamfer_distance.cpp:138-176, hence the scan kernel's bits.
+// ---------------------------------------------------------------------------------------------
+#define CB_SORT_MAX 32768
+__global__ __launch_bounds__(1024) void chamfer_bwd_sorted_kernel(const float *__restrict__ xyz1,
+                                                                  const float *__restrict__ xyz2, int N, int M,
+                                                                  const float *__restrict__ gd1,
+                                                                  const float *__restrict__ gd2,
+                                                                  const int32_t *__restrict__ idx1,
+                                                                  const int32_t *__restrict__ idx2,
+                                                                  float *__restrict__ g1, float *__restrict__ g2,
+                                                                  int P1, int P2, int shift1, int shift2)
+{
+    extern __shared__ uint32_t keys[];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int which = blockIdx.y;
+    const float *A = which == 0 ? xyz1 : xyz2;
+    const float *C = which == 0 ? xyz2 : xyz1;
+    const int NA = which == 0 ? N : M;
+    const int NC = which == 0 ? M : N;
+    const int P = which == 0 ? P2 : P1;                     // power of two >= NC
+    const int shift = which == 0 ? shift2 : shift1;         // 2^shift >= NC
+    const float *gdA = (which == 0 ? gd1 : gd2) + (size_t)b * NA;
+    const float *gdC = (which == 0 ? gd2 : gd1) + (size_t)b * NC;
+    const int32_t *ia = (which == 0 ? idx1 : idx2) + (size_t)b * NA;
+    const int32_t *ic = (which == 0 ? idx2 : idx1) + (size_t)b * NC;
+    float *gout = (which == 0 ? g1 : g2) + (size_t)b * NA * 3;
+    const float *Ab = A + (size_t)b * NA * 3, *Cb = C + (size_t)b * NC * 3;
+
+    for (int t = tid; t < P; t += 1024) keys[t] = t < NC ? ((uint32_t)ic[t] << shift) | (uint32_t)t : 0xffffffffu;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (P >> 1); t += 1024) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                const uint32_t x = keys[lo], y = keys[hi];
+                const bool up = (lo & k) == 0;              // ascending block
+                if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    const uint32_t jmask = (1u << shift) - 1u;
+    for (int i = tid; i < NA; i += 1024) {
+        const float ax = Ab[i * 3], ay = Ab[i * 3 + 1], az = Ab[i * 3 + 2];
+        const int j2 = ia[i];
+        const float g = gdA[i] * 2;
+        const float dxd = g * (ax - Cb[j2 * 3]), dyd = g * (ay - Cb[j2 * 3 + 1]), dzd = g * (az - Cb[j2 * 3 + 2]);
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (which == 0) { gx += dxd; gy += dyd; gz += dzd; }
+        // first position whose key is >= (i << shift)
+        const uint32_t want = (uint32_t)i << shift;
+        int lo = 0, hi = NC;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (keys[mid] < want) lo = mid + 1; else hi = mid;
+        }
+        for (int pos = lo; pos < NC; pos++) {
+            const uint32_t key = keys[pos];
+            if ((key >> shift) != (uint32_t)i) break;
+            const int j = (int)(key & jmask);
+            const float gj = gdC[j] * 2;
+            gx -= gj * (Cb[j * 3] - ax);
+            gy -= gj * (Cb[j * 3 + 1] - ay);
+            gz -= gj * (Cb[j * 3 + 2] - az);
+        }
+        if (which == 1) { gx += dxd; gy += dyd; gz += dzd; }
+        gout[i * 3] = gx; gout[i * 3 + 1] = gy; gout[i * 3 + 2] = gz;
+    }
+}
+
+// variant 0 = the scan kernel, 2 = the sorted-list kernel (N, M <= 32768), 1 = auto (what l3d_chamfer_backward does)
+extern "C" int l3d_chamfer_backward_variant(const float *xyz1, const float *xyz2, int B, int N, int M,
+                                            const float *graddist1, const float *graddist2,
+                                            const int32_t *idx1, const int32_t *idx2, float *gradxyz1,
+                                            float *gradxyz2, int variant, l3d_stream_t stream)
+{
+    L3D_REQUIRE(xyz1 && xyz2 && graddist1 && graddist2 && idx1 && idx2 && gradxyz1 && gradxyz2 &&
+                B > 0 && N > 0 && M > 0 && variant >= 0 && variant <= 2);
+    const int mx = N > M ? N : M;
+    const bool sortable = mx <= CB_SORT_MAX;
+    if (variant == 2 && !sortable) return L3D_ERR_UNSUPPORTED;
+    if (variant != 0 && sortable) {
+        int P1 = 2, P2 = 2, s1 = 1, s2 = 1;                  // P1 >= N (keys of idx1: direction 1 sorts the N selections of cloud 1)
+        while (P1 < N) { P1 <<= 1; s1++; }
+        while (P2 < M) { P2 <<= 1; s2++; }
+        const size_t lds = sizeof(uint32_t) * (size_t)(P1 > P2 ? P1 : P2);
+        hipLaunchKernelGGL(chamfer_bwd_sorted_kernel, dim3(B, 2), dim3(1024), lds, (hipStream_t)stream, xyz1, xyz2, N, M,
+                           graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2, P1, P2, s1, s2);
+        return l3d_check_launch();
+    }
+    dim3 grid(l3d_divup(mx, 64), B, 2);
+    hipLaunchKernelGGL(chamfer_bwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, xyz1, xyz2, N, M,
+                       graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2);
+    return l3d_check_launch();
+}
+
 extern "C" int l3d_chamfer_backward(const float *xyz1, const float *xyz2, int B, int N, int M,
                                     const float *graddist1, const float *graddist2,
                                     const int32_t *idx1, const int32_t *idx2, float *gradxyz1,
                                     float *gradxyz2, l3d_stream_t stream)
 {
-    L3D_REQUIRE(xyz1 && xyz2 && graddist1 && graddist2 && idx1 && idx2 && gradxyz1 && gradxyz2 &&
-                B > 0 && N > 0 && M > 0);
-    const int mx = N > M ? N : M;
-    dim3 grid(l3d_divup(mx, 64), B, 2);
-    hipLaunchKernelGGL(chamfer_bwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, xyz1, xyz2, N, M,
-                       graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2);
-    return l3d_check_launch();
+    return l3d_chamfer_backward_variant(xyz1, xyz2, B, N, M, graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2, 1, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

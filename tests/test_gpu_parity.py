@@ -175,6 +175,53 @@ def test_chamfer_packed_kernel_bit_identical():
             assert np.array_equal(x[:1], y), (B, N, M)
 
 
+def test_chamfer_backward_sorted_kernel_bit_identical():
+    """The sorted-list backward (partner selections sorted by target in LDS, one binary search per point) against the scan
+    kernel and the oracle's restatement of chamfer_distance.cpp:138-176: the same bits, including many partners per point
+    (duplicated and collapsed clouds), ragged and non-power-of-two sizes, and PCN's 16384-point clouds."""
+    from learning3d_amd._lib import lib, check, ptr, stream_ptr
+    rng = np.random.default_rng(34)
+    cases = [(rng.uniform(0, 1, (2, 77, 3)), rng.uniform(0, 1, (2, 130, 3))),
+             (rng.uniform(0, 1, (3, 1024, 3)), rng.uniform(0, 1, (3, 1000, 3))),
+             (rng.uniform(0, 1, (1, 2500, 3)), rng.uniform(0, 1, (1, 4099, 3))),
+             (rng.uniform(0, 1, (2, 16384, 3)), rng.uniform(0, 1, (2, 1024, 3))),
+             (rng.uniform(0, 1, (1, 1, 3)), rng.uniform(0, 1, (1, 5, 3)))]
+    dup = rng.uniform(0, 1, (1, 300, 3)); cases.append((rng.uniform(0, 1, (1, 200, 3)), np.concatenate([dup, dup, dup], 1)))
+    cases.append((rng.uniform(0, 1, (2, 500, 3)), np.full((2, 700, 3), 0.25)))
+    for a, b in cases:
+        a, b = a.astype(np.float32), b.astype(np.float32)
+        B, N, M = a.shape[0], a.shape[1], b.shape[1]
+        ta, tb = dev(a), dev(b)
+        d1 = torch.empty(B, N, device="cuda"); d2 = torch.empty(B, M, device="cuda")
+        i1 = torch.empty(B, N, dtype=torch.int32, device="cuda"); i2 = torch.empty(B, M, dtype=torch.int32, device="cuda")
+        check(lib().l3d_chamfer_forward(ptr(ta), ptr(tb), B, N, M, ptr(d1), ptr(d2), ptr(i1), ptr(i2), stream_ptr()), "cd")
+        gd1 = dev(rng.normal(size=(B, N)).astype(np.float32)); gd2 = dev(rng.normal(size=(B, M)).astype(np.float32))
+        res = {}
+        for v in (0, 2, 1):
+            g1 = torch.full((B, N, 3), float("nan"), device="cuda"); g2 = torch.full((B, M, 3), float("nan"), device="cuda")
+            check(lib().l3d_chamfer_backward_variant(ptr(ta), ptr(tb), B, N, M, ptr(gd1), ptr(gd2), ptr(i1), ptr(i2), ptr(g1), ptr(g2),
+                                                     v, stream_ptr()), "cd bwd")
+            res[v] = [g1.cpu().numpy(), g2.cpu().numpy()]
+        for v in (2, 1):
+            for x, y in zip(res[0], res[v]):
+                assert np.array_equal(x, y), (B, N, M, v)
+        if N * M <= 4099 * 2500:
+            o1, o2 = oracle.chamfer_backward(a[:1], b[:1], gd1.cpu().numpy()[:1], gd2.cpu().numpy()[:1],
+                                             i1.cpu().numpy()[:1], i2.cpu().numpy()[:1])
+            np.testing.assert_allclose(res[2][0][:1], o1, rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(res[2][1][:1], o2, rtol=1e-5, atol=1e-6)
+    # beyond the LDS-resident list: variant 2 declines, auto takes the scan kernel
+    a, b = dev(rand((1, 40000, 3), 5)), dev(rand((1, 64, 3), 6))
+    d1 = torch.empty(1, 40000, device="cuda"); d2 = torch.empty(1, 64, device="cuda")
+    i1 = torch.empty(1, 40000, dtype=torch.int32, device="cuda"); i2 = torch.empty(1, 64, dtype=torch.int32, device="cuda")
+    check(lib().l3d_chamfer_forward(ptr(a), ptr(b), 1, 40000, 64, ptr(d1), ptr(d2), ptr(i1), ptr(i2), stream_ptr()), "cd")
+    g1 = torch.empty(1, 40000, 3, device="cuda"); g2 = torch.empty(1, 64, 3, device="cuda")
+    assert lib().l3d_chamfer_backward_variant(ptr(a), ptr(b), 1, 40000, 64, ptr(d1), ptr(d2), ptr(i1), ptr(i2), ptr(g1), ptr(g2),
+                                              2, stream_ptr()) != 0
+    check(lib().l3d_chamfer_backward(ptr(a), ptr(b), 1, 40000, 64, ptr(d1), ptr(d2), ptr(i1), ptr(i2), ptr(g1), ptr(g2), stream_ptr()), "cd bwd")
+    assert torch.isfinite(g1).all() and torch.isfinite(g2).all()
+
+
 def test_chamfer_loss_local_equals_partials_plus_combine():
     from learning3d_amd.losses.chamfer_distance import chamfer_loss_local, chamfer_partials, chamfer_combine
     rng = np.random.default_rng(44)

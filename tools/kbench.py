@@ -62,6 +62,19 @@ def main():
                 (d1.sum() + d2.sum()).backward()
         t = timeit(fwdbwd)
         res["chamfer_fwd+bwd_c2"] = (t, 2 * B * N * N / t / 1e3, "Gpair/s(fwd)")
+        # the backward kernels alone (raw C-ABI calls): scan of the partner's selections vs the LDS-sorted selection list
+        from learning3d_amd._lib import lib as _l, check as _c, ptr as _p, stream_ptr as _s
+        for tag, (Bc, Nc, Mc) in (("c2", (B, N, N)), ("c4_B8_16k", (8, 16384, 16384))):
+            ca, cb = torch.rand(Bc, Nc, 3, device=dev), torch.rand(Bc, Mc, 3, device=dev)
+            d1 = torch.empty(Bc, Nc, device=dev); d2 = torch.empty(Bc, Mc, device=dev)
+            i1 = torch.empty(Bc, Nc, dtype=torch.int32, device=dev); i2 = torch.empty(Bc, Mc, dtype=torch.int32, device=dev)
+            _c(_l().l3d_chamfer_forward(_p(ca), _p(cb), Bc, Nc, Mc, _p(d1), _p(d2), _p(i1), _p(i2), _s()), "cd")
+            g1, g2 = torch.empty_like(ca), torch.empty_like(cb)
+            for name, v in (("scan", 0), ("sorted", 2)):
+                t = timeit(lambda: _c(_l().l3d_chamfer_backward_variant(_p(ca), _p(cb), Bc, Nc, Mc, _p(d1), _p(d2), _p(i1), _p(i2),
+                                                                        _p(g1), _p(g2), v, _s()), "cd bwd"),
+                           warm=2, iters=5 if Nc > 4096 else 50)
+                res[f"chamfer_bwd_{name}_{tag}"] = (t, (Nc + Mc) * Bc / t, "Mpoint/s")
         net = DGCNN(emb_dims=1024).to(dev).eval()
         idx = U.knn(xt, k)
         packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
