@@ -14,11 +14,13 @@ import torch.distributed as dist
 
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract).
-    Returns (rank, world_size, local_rank).  Single-process when WORLD_SIZE is unset or 1."""
+    Returns (rank, world_size, local_rank).  Single-process when WORLD_SIZE is unset or 1 (no process group is created then,
+    unless L3D_INIT_SINGLE_RANK=1 asks for a one-rank group: the collectives below then run through RCCL with one rank --
+    tests/test_gpu_rccl_one_rank.py, the only way to execute them on a one-GPU box)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("L3D_INIT_SINGLE_RANK") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -56,7 +58,7 @@ def allgather_chamfer_loss(partial):
     shard (device tensor for nccl/RCCL, CPU tensor for gloo).  One all_gather of 32 bytes per rank
     (pure latency over xGMI), then the same combine on every rank: returns the whole-batch Chamfer
     loss, identical everywhere.  No host synchronisation."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():          # a one-rank group still runs the collective (RCCL with one rank)
         world = dist.get_world_size()
         flat = torch.empty(world * 4, dtype=torch.float64, device=partial.device)
         dist.all_gather_into_tensor(flat, partial.contiguous())
@@ -76,7 +78,7 @@ class PipelinedChamferLoss:
 
     def __init__(self):
         self._pending = None
-        self._multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self._multi = dist.is_available() and dist.is_initialized()
 
     def submit(self, partial):
         if not self._multi:
