@@ -46,6 +46,29 @@ EDGECONV_FLOP_PER_CLOUD = NPTS * KNN * 2 * (6 * 64 + 64 * 64 + 64 * 128 + 128 * 
 CONV5_FLOP_PER_CLOUD = NPTS * 2 * 512 * EMB
 
 
+def flush_c_stdio():
+    """librccl announces itself through C stdio ("Librccl path : ..."); with stdout a pipe the line sits in libc's buffer until the
+    process exits and would land BEHIND rank 0's JSON line (seen on a one-rank RCCL run).  Every rank pushes it out before the
+    closing barrier; rank 0 prints its line after that barrier, so it is the last line of the job's stdout."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
+def finish(out, rank, multi, local, dist):
+    """closing barrier, then rank 0's ONE JSON line, then the process group goes"""
+    flush_c_stdio()
+    if multi:
+        dist.barrier(device_ids=[local])
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if multi:
+        dist.destroy_process_group()
+
+
 def pmc_record(tag):
     """What the committed rocprofv3 PMC passes measured for one kernel (profiles/round2_traffic.json, produced on the
     GPU box by tools/pmc.sh + tools/traffic_json.py; bench.py cannot run rocprofv3 on itself, so this is the measured
@@ -234,6 +257,7 @@ def c5_cpu_baseline(sample_clouds=4, repeats=1):
 
 
 def main_c5(args, rank, world, local, dev, dist, parallel):
+    multi = world > 1 or dist.is_initialized()      # a one-rank RCCL group (L3D_INIT_SINGLE_RANK=1) takes the N > 1 code path
     from learning3d_amd.models import PointNetSetAbstraction, _fused
     g = torch.Generator().manual_seed(2000 + rank)
     xyz = torch.clamp(torch.randn((B_PER_GPU, 3, C5_N), generator=g), -2, 2).to(dev)      # N(0,1) clipped to [-2,2]
@@ -257,7 +281,7 @@ def main_c5(args, rank, world, local, dev, dist, parallel):
             nf, part = graph_out
         else:
             nf, part = compute()
-        if world > 1:
+        if multi:
             flat = torch.empty(world * 4, dtype=torch.float64, device=dev)
             dist.all_gather_into_tensor(flat, part.clone() if graph is not None and not eager else part)   # 32 B per rank over RCCL
             return nf, flat.view(world, 4).sum(0)
@@ -288,7 +312,7 @@ def main_c5(args, rank, world, local, dev, dist, parallel):
         step()
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
@@ -310,7 +334,7 @@ def main_c5(args, rank, world, local, dev, dist, parallel):
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     per_rank = [t.clone() for _ in range(world)]
-    if world > 1:
+    if multi:
         dist.all_gather(per_rank, t)
     per_rank = torch.stack(per_rank).cpu()
     elapsed = float(per_rank[:, 0].max())
@@ -328,7 +352,7 @@ def main_c5(args, rank, world, local, dev, dist, parallel):
                        "global_batch": world * B_PER_GPU, "num_points": C5_N, "npoint": C5_S, "nsample": C5_K, "radius": C5_R,
                        "launch": "hipGraph replay" if graph is not None else "eager launches",
                        "parallelism": f"batch-sharded x{world}, no data-path collective; one 32-byte all_gather of the shard digest per step"},
-            "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "dist_backend": dist.get_backend() if world > 1 else None,
+            "rccl_ranks": (dist.get_world_size() if multi else 1), "dist_backend": dist.get_backend() if multi else None,
             "per_rank_ms_per_step": [float(v) / args.steps * 1e3 for v in per_rank[:, 0]],
             # the one HBM-bound op of the path: the grouping gather
             "roofline": {"kernel": "group_concat_kernel", "bound": "hbm", "achieved": grp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -342,12 +366,9 @@ def main_c5(args, rank, world, local, dev, dist, parallel):
                         "fps_pair_evals_per_s": B_PER_GPU * C5_S * C5_N / (stage_ms["fps"] * 1e-3) if stage_ms.get("fps") else None},
             "digest": [float(v) for v in digest],
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = c5_cpu_baseline()
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier(device_ids=[local])
-        dist.destroy_process_group()
+    finish(out if rank == 0 else None, rank, multi, local, dist)
 
 
 def main():
@@ -397,6 +418,7 @@ def main():
     _fused.RANGE_POLICY = "async"
 
     rank, world, local = parallel.init_from_env()
+    multi = world > 1 or dist.is_initialized()          # a one-rank RCCL group (L3D_INIT_SINGLE_RANK=1) takes the N > 1 code path
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -404,7 +426,7 @@ def main():
     local = local % torch.cuda.device_count()     # a launcher that narrows visibility leaves one device at index 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if multi:
         # a multi-GPU run is an RCCL run or it is not a measurement: fail before timing anything
         if dist.get_backend() != "nccl" or dist.get_world_size() != args.gpus:
             raise SystemExit(f"[bench] expected {args.gpus} RCCL ranks (backend 'nccl'), got backend {dist.get_backend()!r} with "
@@ -434,7 +456,7 @@ def main():
     def chamfer_branch():
         with _fused.stage("chamfer"):
             d1, d2 = cd(a, b)
-        return chamfer_loss_local(d1, d2) if world == 1 else chamfer_partials(d1, d2)
+        return chamfer_loss_local(d1, d2) if not multi else chamfer_partials(d1, d2)
 
     def compute(fork=True):
         """the step's kernels: knn -> edgeconv -> conv5, Chamfer NN search, and the loss tail's local part.  The Chamfer pair
@@ -477,7 +499,7 @@ def main():
             feat, part = graph_out
         else:
             feat, part = compute(fork=not eager)           # event-carrying steps stay on one stream: clean per-kernel durations
-        if world == 1:
+        if not multi:
             return feat, part                              # the whole loss tail ran in one launch (l3d_chamfer_loss_local)
         if sync_loss:
             loss = parallel.allgather_chamfer_loss(part)   # blocking RCCL all_gather
@@ -517,7 +539,7 @@ def main():
     # of the kernels' own durations (HIP events around each stage), then probes of 20 replayed steps run until one comes
     # within 12 % of that sum (at most 4 probes, 0.25 s apart).
     settle_probes = 0
-    if world == 1:
+    if not multi:
         probe_timer = _fused.StageTimer(only=("knn", "edgeconv_kernel", "conv5", "chamfer"))
         _fused.TIMER = probe_timer
         for _ in range(3):
@@ -540,7 +562,7 @@ def main():
         step(args.sync_loss)
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier(device_ids=[local])           # RCCL barrier on this rank's own device
         torch.cuda.synchronize()
 
@@ -574,7 +596,7 @@ def main():
     # N>1: the other exchange mode over the same K steps, reported beside the headline (the pipelined mode hides
     # exactly the collective latency a scaling curve is meant to show; --sync-loss swaps which one is `value`)
     other = None
-    if world > 1:
+    if multi:
         for _ in range(args.warmup):
             step(not args.sync_loss)
         if args.sync_loss:
@@ -628,14 +650,14 @@ def main():
     # max over ranks (the contract), and every rank's own time for the record
     t = torch.tensor([elapsed, other if other is not None else 0.0], dtype=torch.float64, device=dev)
     per_rank = [t.clone() for _ in range(world)]
-    if world > 1:
+    if multi:
         dist.all_gather(per_rank, t)
     else:
         per_rank = [t]
     per_rank = torch.stack(per_rank).cpu()
     elapsed = float(per_rank[:, 0].max())
     other = float(per_rank[:, 1].max()) if other is not None else None
-    backend = dist.get_backend() if world > 1 else None
+    backend = dist.get_backend() if multi else None
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -665,13 +687,13 @@ def main():
                        "chamfer_branch": ("one stream" if branch is None else
                                           f"second stream, leaves the chain at '{args.fork}', joined at the end of the step"),
                        "parallelism": f"batch-sharded x{world}, all_gather of loss partials only"
-                                      + ("" if args.sync_loss or world == 1 else " (asynchronous, consumed one step later)")},
+                                      + ("" if args.sync_loss or not multi else " (asynchronous, consumed one step later)")},
             # multi-GPU record: ranks that really joined the process group, its backend ("nccl" = RCCL on ROCm),
             # each rank's own wall time for the K steps, and the OTHER loss-exchange mode timed over the same K steps
-            "rccl_ranks": (dist.get_world_size() if world > 1 else 1), "dist_backend": backend,
+            "rccl_ranks": (dist.get_world_size() if multi else 1), "dist_backend": backend,
             "per_rank_ms_per_step": [float(v) / args.steps * 1e3 for v in per_rank[:, 0]],
             "loss_exchange": ("blocking all_gather inside the step" if args.sync_loss else
-                              "asynchronous all_gather, consumed one step later") if world > 1 else "none (1 rank)",
+                              "asynchronous all_gather, consumed one step later") if multi else "none (1 rank)",
             "other_exchange_mode": None if other is None else {
                 "mode": "asynchronous all_gather, consumed one step later" if args.sync_loss else "blocking all_gather inside the step",
                 "ms_per_step": other / args.steps * 1e3, "value": world * B_PER_GPU * args.steps / other},
@@ -696,12 +718,9 @@ def main():
                         ((stage_ms["knn"] + stage_ms["chamfer"]) * 1e-3) / 1e9},
             "loss": float(loss),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier(device_ids=[local])
-        dist.destroy_process_group()
+    finish(out if rank == 0 else None, rank, multi, local, dist)
 
 
 if __name__ == "__main__":

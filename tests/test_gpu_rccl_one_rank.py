@@ -58,3 +58,30 @@ def test_collectives_run_over_rccl_with_one_rank(tmp_path):
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = p.stdout.decode()
     assert p.returncode == 0 and "RCCL_ONE_RANK_OK" in out, out[-3000:]
+
+
+@pytest.mark.parametrize("workload", ["c2", "c5"])
+def test_bench_multi_rank_path_over_rccl_one_rank(workload):
+    """bench.py's N > 1 code path -- RCCL check + all_reduce probe, device barriers around the timed region, the loss exchange inside
+    the replayed step (a copy of the graph's partials buffer handed to the asynchronous all_gather), both exchange modes timed,
+    per-rank times gathered -- executed on a one-rank nccl group (L3D_INIT_SINGLE_RANK=1)."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543" if workload == "c2" else "29545", WORLD_SIZE="1", RANK="0",
+               LOCAL_RANK="0", L3D_INIT_SINGLE_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
+           "--workload", workload]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = p.stdout.decode().strip().splitlines()
+    assert lines[-1].startswith("{"), lines[-3:]                     # the JSON is the LAST line even with librccl's own stdout chatter
+    d = json.loads(lines[-1])
+    assert d["rccl_ranks"] == 1 and d["dist_backend"] == "nccl" and d["n_gpus"] == 1, d
+    assert d["value"] > 0 and len(d["per_rank_ms_per_step"]) == 1
+    if workload == "c2":
+        assert d["loss_exchange"].startswith("asynchronous all_gather") and d["other_exchange_mode"]["mode"].startswith("blocking")
+        assert d["other_exchange_mode"]["ms_per_step"] > 0
+        # the same loss as a plain one-process run of the same seeded step
+        q = subprocess.run(cmd[:-2], env={k: v for k, v in os.environ.items()}, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert q.returncode == 0, q.stderr.decode()[-3000:]
+        e = json.loads(q.stdout.decode().strip().splitlines()[-1])
+        assert e["dist_backend"] is None and abs(e["loss"] - d["loss"]) <= 1e-6 * abs(e["loss"]), (e["loss"], d["loss"])
