@@ -322,6 +322,11 @@ int l3d_layernorm_ref(const float *x, const float *a, const float *b, float eps,
  * (image only). */
 int l3d_layernorm_planes(const float *x, const float *a, const float *b, float eps, long rows, int C, float *y, void *img,
                          l3d_stream_t stream);
+/* The same LayerNorm over the channels of a CHANNEL-FIRST tensor x [B][C][N] (one normalisation per point), output as
+ * y [B][C][N] (or NULL) and / or as the activation image with rows b N + n (img: l3d_f16_act_bytes(B N, C) bytes, or NULL):
+ * the pointer network keeps the [B,C,N] layout its GEMMs write from end to end.  C in {128, 256, 512}. */
+int l3d_layernorm_planes_cf(const float *x, const float *a, const float *b, float eps, int B, int C, int N, float *y,
+                            void *img, l3d_stream_t stream);
 /* Residual connection x + sublayer(norm(x)) of utils/transformer.py:82-88 when the sublayer output is channel-first:
  * out[b][n][c] = x[b][n][c] + y[b][c][n];  x, out fp32 [B,N,C], y fp32 [B,C,N] (tiled transpose through LDS). */
 int l3d_add_transposed(const float *x, const float *y, int B, int N, int C, float *out, l3d_stream_t stream);
@@ -454,6 +459,12 @@ int l3d_split_f16_rows(const float *x, long rows, int C, int channel_first, int 
 int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
                            int shift_bstride, int B, int Cin, int Cout, int N, int relu, float *y,
                            l3d_stream_t stream);
+/* l3d_pointwise_conv_f16 with a residual connection in its epilogue: y = res + act(scale (w x) + shift), res and y
+ * [B][Cout][N] fp32, distinct buffers (utils/transformer.py:82-88: x + sublayer(norm(x)) without a pass over both tensors).
+ * Cout % 256 == 0, N % 256 == 0. */
+int l3d_pointwise_conv_f16_residual(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
+                                    int shift_bstride, int B, int Cin, int Cout, int N, int relu, const float *res, float *y,
+                                    l3d_stream_t stream);
 /* l3d_pointwise_conv_f16 for an activation image whose residual plane is UNSCALED (m = f16(X - h); written by
  * l3d_edgeconv_forward_f16b with out_mode 2): the Hs plane of the weight image is not read (two weight planes, 12 instead of 14
  * LDS fragment reads and 4 instead of 5 DMA pieces per chunk and wave).  Cout % 256 == 0, N % 256 == 0. */

@@ -73,6 +73,7 @@ SIGNATURES = {
     "l3d_layernorm_ref": [_P, _P, _P, _F, _L, _I, _P, _P],
     "l3d_layernorm_planes": [_P, _P, _P, _F, _L, _I, _P, _P, _P],
     "l3d_add_transposed": [_P, _P, _I, _I, _I, _P, _P],
+    "l3d_layernorm_planes_cf": [_P, _P, _P, _F, _I, _I, _I, _P, _P, _P],
     "l3d_edgeconv_packed_floats": [_I, _I, _I, _I],
     "l3d_edgeconv_pack": [_P, _P, _P, _I, _I, _I, _I, _P],
     "l3d_edgeconv_forward": [_P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P],
@@ -95,6 +96,7 @@ SIGNATURES = {
     "l3d_split_f16_rows": [_P, _L, _I, _I, _I, _P, _P, _P],
     "l3d_pointwise_conv_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_pointwise_conv_f16_2p": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "l3d_pointwise_conv_f16_residual": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "l3d_pointwise_conv_f16_planes": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "l3d_pointwise_conv_f16_absmax": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "l3d_pointwise_conv_f16_pool": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P],

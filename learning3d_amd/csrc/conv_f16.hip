@@ -241,7 +241,11 @@ __device__ long long *g_cf_timeline;
 #else
 #define CFM(i)
 #endif
-template <bool NARROW, bool AMAX, bool GROUP, int NPW = 3>
+// RESID (its own instantiation; wide tile, fp32 output, three weight planes): y = res + act(...), res [B][Cout][N] -- the residual
+// connection of the pointer network's sublayers (utils/transformer.py:131-140 of the reference) in the GEMM's epilogue instead
+// of a pass over both tensors.  The residual pointer travels in `obs`, which the fp32 epilogue does not otherwise read: the
+// kernel's signature, and with it the other instantiations' code, stays as it was.
+template <bool NARROW, bool AMAX, bool GROUP, int NPW = 3, bool RESID = false>
 __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__ xh, const uint4 *__restrict__ xm,
                                                        const uint4 *__restrict__ wH, const uint4 *__restrict__ wHs,
                                                        const uint4 *__restrict__ wM, const float *__restrict__ winv,
@@ -254,6 +258,7 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
     constexpr int TM = NARROW ? 128 : CF_TM, TN = NARROW ? 512 : CF_TN;
     constexpr int WR = TM * 16, XR = TN * 16;                   // bytes of one (plane, octet) region of W / x
     static_assert(NPW == 3 || (NPW == 2 && !NARROW && !AMAX && !GROUP), "two weight planes: wide tile, fp32 output");
+    static_assert(!RESID || (NPW == 3 && !NARROW && !AMAX && !GROUP), "residual epilogue: wide tile, fp32 output");
     constexpr int WBYTES = 2 * NPW * WR, STAGE = WBYTES + 4 * XR;
     constexpr int NPIECE = NARROW ? 6 : (NPW == 3 ? 5 : 4);     // DMA instructions per wave and chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -534,6 +539,7 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
         return;
     }
     float *yb = y + (size_t)b * Cout * N;
+    const float *rb = RESID ? obs + (size_t)b * Cout * N : nullptr;
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -545,6 +551,7 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
             for (int c = 0; c < 4; c++) {
                 float v = acc[a][c][r] * sc + sh;
                 if (relu) v = l3d_act(v, relu);
+                if constexpr (RESID) v = rb[(size_t)co * N + n0 + wn * 128 + c * 32 + (lane & 31)] + v;
                 yb[(size_t)co * N + n0 + wn * 128 + c * 32 + (lane & 31)] = v;
                 if constexpr (AMAX) acc[a][c][r] = fabsf(v);     // kept for the maximum below (the accumulator is dead)
             }
@@ -648,7 +655,7 @@ extern "C" int l3d_split_f16_rows(const float *x, long rows, int C, int channel_
 // x_act: an activation image (l3d_f16_act_bytes), w_planes: a weight image (l3d_conv_f16_weight_bytes)
 static int cf_launch(const void *x_planes, const void *w_planes, const float *scale, const float *shift, int shift_bstride, int B,
                      int Cin, int Cout, int N, int relu, float *y, void *out_img, const float *obs, float *ypool, int pool,
-                     unsigned *amax_out, int amax_cdiv, hipStream_t st, bool two_plane = false)
+                     unsigned *amax_out, int amax_cdiv, hipStream_t st, bool two_plane = false, const float *resid = nullptr)
 {
     // wide tile (256 x 256) when Cout allows it, else the narrow one (128 x 512)
     const bool narrow = Cout % CF_TM != 0;
@@ -669,6 +676,12 @@ static int cf_launch(const void *x_planes, const void *w_planes, const float *sc
     const size_t nlds = 3 * (6 * 128 * 16 + 4 * 512 * 16);
     const bool group = ypool && pool != 128;
     if (group && amax_out) return L3D_ERR_UNSUPPORTED;
+    if (resid) {
+        if (narrow || group || amax_out || ypool || out_img || !y || two_plane) return L3D_ERR_UNSUPPORTED;
+        obs = resid;
+        hipLaunchKernelGGL((conv_f16_kernel<false, false, false, 3, true>), grid, block, CF_LDS, st, CF_ARGS);
+        return l3d_check_launch();
+    }
     if (two_plane) {
         if (narrow || group || amax_out || ypool || out_img || !y) return L3D_ERR_UNSUPPORTED;
         hipLaunchKernelGGL((conv_f16_kernel<false, false, false, 2>), grid, block, 3 * (4 * CF_TM * 16 + 4 * CF_TN * 16), st, CF_ARGS);
@@ -690,6 +703,16 @@ extern "C" int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes
 {
     L3D_REQUIRE(x_planes && w_planes && y && B > 0 && Cin > 0 && Cout > 0 && N > 0);
     return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, nullptr, nullptr, nullptr, 0, nullptr, 0, (hipStream_t)stream);
+}
+
+// y = res + act(scale (w x) + shift): res and y [B][Cout][N] fp32, distinct buffers.  Cout % 256 == 0, N % 256 == 0.
+extern "C" int l3d_pointwise_conv_f16_residual(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
+                                               int shift_bstride, int B, int Cin, int Cout, int N, int relu, const float *res,
+                                               float *y, l3d_stream_t stream)
+{
+    L3D_REQUIRE(x_planes && w_planes && y && res && B > 0 && Cin > 0 && Cout > 0 && N > 0);
+    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, nullptr, nullptr, nullptr, 0, nullptr, 0,
+                     (hipStream_t)stream, false, res);
 }
 
 // l3d_pointwise_conv_f16 for an activation image whose residual plane is UNSCALED (m = f16(X - h): l3d_edgeconv_forward_f16b with

@@ -447,6 +447,114 @@ __global__ __launch_bounds__(256) void layernorm_planes_kernel(const float *__re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same LayerNorm on a CHANNEL-FIRST tensor x [B][C][N] (normalised over C for every point), output as the activation
+// image and / or as y [B][C][N]: with it the pointer network keeps the layout its GEMMs write ([B,Cout,N]) from end to end --
+// no transposed residual adds, no .contiguous() copies around the sublayers (utils/transformer.py, Transformer._forward_cf).
+// A workgroup takes 64 consecutive points; wave w of NW holds channels [w C/NW, (w+1) C/NW) of them in registers (one read of x,
+// 256-byte runs per channel; 64 channels per wave keep three waves on a SIMD), the partial sums of a point meet in LDS (fp64: the mean and the variance are the
+// correctly rounded ones), and every lane writes whole 16-byte plane cells (64 consecutive rows of an octet = 1 KB per
+// wave store).  Same scale rule as above.
+// ---------------------------------------------------------------------------------------------
+template <int CPW /* channels per wave */, int NW /* waves */>
+__global__ __launch_bounds__(64 * NW) void layernorm_planes_cf_kernel(const float *__restrict__ x, const float *__restrict__ a,
+                                                                  const float *__restrict__ bb, float eps, int Bn, int N,
+                                                                  float *__restrict__ y, uint4 *__restrict__ ph, uint4 *__restrict__ pm,
+                                                                  float *__restrict__ inv_out)
+{
+    constexpr int C = NW * CPW;
+    __shared__ double red[2][NW][64];
+    __shared__ float scr[NW];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);   // uniform: row pointers in SGPRs
+    const int b = blockIdx.y, n = blockIdx.x * 64 + lane;
+    const bool ok = n < N;
+    const int c0 = wave * CPW;
+    // ---- plane scale from the layer's parameters
+    float up = 1.f;
+    if (ph) {
+        float hm = 0.f;
+        const float rt = sqrtf((float)(C - 1));
+        for (int c = t; c < C; c += 64 * NW) hm = fmaxf(hm, fmaf(fabsf(a[c]), rt, fabsf(bb[c])));
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) hm = fmaxf(hm, __shfl_xor(hm, d, 64));
+        if (lane == 0) scr[wave] = hm;
+        __syncthreads();
+        hm = scr[0];
+#pragma unroll
+        for (int w = 1; w < NW; w++) hm = fmaxf(hm, scr[w]);
+        hm *= 1.000001f;
+        int e = 0;
+        if (hm > 0.f && hm < 3.0e38f) (void)frexpf(hm, &e);
+        up = ldexpf(1.f, 12 - e);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) *inv_out = ldexpf(1.f, e - 12);
+    }
+    // buffer loads: the wave's channel block as the resource (wave-uniform), the channel row as the scalar offset, the point as
+    // the only per-lane part of the address -- one VGPR instead of a 64-bit address per load; points beyond N read 0
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(x + ((size_t)b * C + c0) * N), 0, (int)((size_t)CPW * N * 4), 0x00020000);
+    const int voff = ok ? n * 4 : 0x7ffffff0;
+    float v[CPW];
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < CPW; i++) {
+        v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, i * N * 4, 0));
+        s += (double)v[i];
+    }
+    red[0][wave][lane] = s;
+    __syncthreads();
+    double tot = red[0][0][lane];
+#pragma unroll
+    for (int w = 1; w < NW; w++) tot += red[0][w][lane];
+    const float mean = (float)(tot / (double)C);
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < CPW; i++) { const float d = v[i] - mean; ss += (double)d * (double)d; }    // (fp32 difference as in the row kernel; keeping 64 converted values alive would cost 128 registers)
+    red[1][wave][lane] = ss;
+    __syncthreads();
+    tot = red[1][0][lane];
+#pragma unroll
+    for (int w = 1; w < NW; w++) tot += red[1][w][lane];
+    const float var = (float)(tot / (double)(C - 1));
+    const float inv = 1.f / (sqrtf(var) + eps);
+    const size_t rows = (size_t)Bn * N, row = (size_t)b * N + n;
+#pragma unroll
+    for (int o = 0; o < CPW / 8; o++) {
+        _Float16 h[8], m[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = o * 8 + k;
+            const float val = a[c0 + i] * (v[i] - mean) * inv + bb[c0 + i];
+            if (y && ok) (y + ((size_t)b * C + c0 + i) * N)[n] = val;
+            const float X = val * up;
+            h[k] = (_Float16)X;
+            m[k] = (_Float16)((X - (float)h[k]) * 4096.0f);
+        }
+        if (ph && ok) {
+            const size_t cell = (size_t)(c0 / 8 + o) * rows + row;
+            ph[cell] = *(const uint4 *)h;
+            pm[cell] = *(const uint4 *)m;
+        }
+    }
+}
+
+// x [B][C][N] -> y [B][C][N] (or NULL) and / or img = the activation image of y with rows b N + n (l3d_f16_act_bytes(B N, C)
+// bytes; or NULL).  C in {128, 256, 512}.
+extern "C" int l3d_layernorm_planes_cf(const float *x, const float *a, const float *b, float eps, int B, int C, int N, float *y,
+                                       void *img, l3d_stream_t stream)
+{
+    L3D_REQUIRE(x && a && b && (y || img) && B > 0 && N > 0 && C > 1);
+    if ((C != 128 && C != 256 && C != 512) || B > 65535 || (((size_t)img) & 15)) return L3D_ERR_UNSUPPORTED;
+    const size_t rows = (size_t)B * N, pb = (size_t)(C / 8) * rows * 16;
+    unsigned char *d = (unsigned char *)img;
+    uint4 *ph = d ? (uint4 *)d : nullptr, *pm = d ? (uint4 *)(d + pb) : nullptr;
+    float *inv = d ? (float *)(d + 2 * pb) : nullptr;
+    dim3 grid((unsigned)l3d_divup(N, 64), (unsigned)B);
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 512)      hipLaunchKernelGGL((layernorm_planes_cf_kernel<64, 8>), grid, dim3(512), 0, st, x, a, b, eps, B, N, y, ph, pm, inv);
+    else if (C == 256) hipLaunchKernelGGL((layernorm_planes_cf_kernel<64, 4>), grid, dim3(256), 0, st, x, a, b, eps, B, N, y, ph, pm, inv);
+    else               hipLaunchKernelGGL((layernorm_planes_cf_kernel<32, 4>), grid, dim3(256), 0, st, x, a, b, eps, B, N, y, ph, pm, inv);
+    return l3d_check_launch();
+}
+
 // y as l3d_layernorm_ref (or NULL: planes only -- every consumer of the pointer network's sublayer norms reads the image, and the
 // fp32 copy is a third of this kernel's traffic), plus img = the activation image of y (l3d_f16_act_bytes(rows, C) bytes)
 extern "C" int l3d_layernorm_planes(const float *x, const float *a, const float *b, float eps, long rows, int C, float *y,

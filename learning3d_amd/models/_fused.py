@@ -286,7 +286,7 @@ def f16_eligible(Cin, Cout, N):
 
 
 def pointwise_conv_f16(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=None, relu=False, out_planes=False, amax=None,
-                       unscaled=False):
+                       unscaled=False, residual=None):
     """l3d_pointwise_conv_f16 on pre-split operands -> y [B,Cout,N] fp32; out_planes=True: the output as an fp16 activation
     image (uint8 tensor) for the next f16x2 layer instead (l3d_pointwise_conv_f16_planes; shift must be [Cout] or None).
     amax = (int32 tensor, channels per group): also max|y| per channel group as float bits, atomically maximised into the
@@ -305,6 +305,14 @@ def pointwise_conv_f16(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=No
         return img
     bstride = Cout if (shift is not None and shift.dim() == 2) else 0
     y = torch.empty((B, Cout, N), dtype=torch.float32, device=x_planes.device)
+    if residual is not None:
+        # y = residual + layer(x): the sublayer's residual connection in the GEMM's epilogue (l3d_pointwise_conv_f16_residual)
+        if amax is not None or unscaled or tuple(residual.shape) != (B, Cout, N) or not (Cout % 256 == 0 and N % 256 == 0):
+            raise ValueError("residual epilogue: residual [B,Cout,N], Cout % 256 == 0, N % 256 == 0, no absmax / two-plane input")
+        check(lib().l3d_pointwise_conv_f16_residual(ptr(x_planes), ptr(w_planes), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N,
+                                                    int(relu), ptr(f32c(residual)), ptr(y), stream_ptr()),
+              "l3d_pointwise_conv_f16_residual")
+        return y
     if unscaled:
         # the image's residual plane is unscaled (edgeconv_forward(..., planes=True, unscaled=True)): two weight planes
         if amax is not None or not (Cout % 256 == 0 and N % 256 == 0):

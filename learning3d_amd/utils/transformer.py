@@ -18,6 +18,7 @@ FLASH_ATTENTION = True      # l3d_attention_forward for d_k in {32, 64, 128}; Fa
 DEFER_LN_VALUES = True      # sublayer norms write only their fp16 plane image; fp32 values on demand (_ln_values)
 PROJECTION_MAXIMA = True    # the f16x2 q|k|v projections report max|q|, |k|, |v| from their epilogues (False: a pass over q, k, v)
 ATTENTION_F16B = True       # f16x2 attention on the restructured kernel (attention_f16b.hip); False: attention_f16.hip
+CHANNEL_FIRST_PASS = True   # a whole encoder-decoder pass in the [B,C,N] layout the GEMMs write (Transformer._pass_cf); False: module by module
 
 _ATT_WS = {}
 
@@ -60,7 +61,7 @@ def _fast_linear_ok(lin, x, n_points):
             and _fused.split_eligible(lin.in_features, lin.out_features, n_points))
 
 
-def _linear_cf(lin, x, channel_last, relu=False, out_scale=None, planes=None, out_planes=False, amax=None):
+def _linear_cf(lin, x, channel_last, relu=False, out_scale=None, planes=None, out_planes=False, amax=None, residual=None):
     """Linear over points as a 1x1 conv: x [B,N,Cin] (channel_last) or [B,Cin,N] -> [B,Cout,N];
     out_scale multiplies the whole result (weights and bias) in the kernel's epilogue.
     planes = (image, B, N): the input exists only as an fp16 plane image (x is None); out_planes: return (image, B, N) of the
@@ -92,9 +93,12 @@ def _linear_cf(lin, x, channel_last, relu=False, out_scale=None, planes=None, ou
             y = _fused.pointwise_conv_f16(img, nb_, np_, c16[1], lin.in_features, lin.out_features, scale, bias, relu=relu, amax=amax)
             y._l3d_amax = True
             return y
-        return _fused.pointwise_conv_f16(img, nb_, np_, c16[1], lin.in_features, lin.out_features, scale, bias, relu=relu)
+        return _fused.pointwise_conv_f16(img, nb_, np_, c16[1], lin.in_features, lin.out_features, scale, bias, relu=relu,
+                                         residual=residual)
     if out_planes:
         return None
+    if residual is not None:
+        raise RuntimeError("_linear_cf: the residual epilogue exists on the f16x2 plane route only")
     x = _ln_values(x)
     key = (lin.weight.data_ptr(), lin.weight._version, str(lin.weight.device))
     cache = getattr(lin, "_l3d_split", None)
@@ -406,7 +410,102 @@ class Transformer(nn.Module):
         from ..models import _fused
         return _fused.checkpointed(self, self._forward, input[0], input[1])
 
+    # ------------------------------------------------------------------------------------------------------------------
+    # One encoder-decoder pass with every tensor in the layout the GEMMs write, [B,C,N]: LayerNorm over the channels of a
+    # channel-first tensor straight to the fp16 plane image (l3d_layernorm_planes_cf), q|k|v / q, k|v projections with their
+    # maxima, attention with its context as planes, output projection and the feed-forward's second layer with the
+    # sublayer's residual connection in their epilogues (l3d_pointwise_conv_f16_residual).  Against the module-by-module
+    # route this drops, per pass, five transposed residual adds, the .contiguous() copies around the pass and the fp32
+    # LayerNorm outputs nobody reads (reference: utils/transformer.py:131-140 SublayerConnection, :163-217, :236-243).
+    # ------------------------------------------------------------------------------------------------------------------
+    def _cf_pass_ok(self, src, tgt):
+        from ..models import _fused
+        C = self.emb_dims
+        if not (CHANNEL_FIRST_PASS and FLASH_ATTENTION and ATTENTION_F16B and PROJECTION_MAXIMA and _fused.gemm_arith() == "f16x2"):
+            return False
+        if not (src.is_cuda and tgt.is_cuda and src.dtype == torch.float32 and tgt.dtype == torch.float32 and src.dim() == 3
+                and tgt.dim() == 3 and src.size(1) == C and tgt.size(1) == C and src.size(0) == tgt.size(0)):
+            return False
+        if C not in (256, 512) or self.ff_dims % 256 or src.size(2) % 256 or tgt.size(2) % 256 or C // self.n_heads not in (32, 64, 128):
+            return False
+        if torch.is_grad_enabled() and (src.requires_grad or tgt.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return False
+        m = self.model
+        if any(len(e) for e in (m.src_embed, m.tgt_embed, m.generator)):
+            return False
+        stock = {EncoderDecoder, Encoder, Decoder, EncoderLayer, DecoderLayer, SublayerConnection, LayerNorm, MultiHeadedAttention,
+                 PositionwiseFeedForward, nn.Linear, nn.Sequential, nn.ModuleList}
+        for mod in m.modules():                    # subclasses, overrides and hooks see the module-by-module route
+            if type(mod) not in stock or mod._forward_hooks or mod._forward_pre_hooks:
+                return False
+        return all(_fused.f16_eligible(a, b, n) for a, b, n in ((C, C, src.size(2)), (C, C, tgt.size(2)), (C, self.ff_dims, src.size(2)),
+                                                               (self.ff_dims, C, tgt.size(2))))
+
+    @staticmethod
+    def _ln_cf(norm, x, values=False, planes=True):
+        """LayerNorm over the channels of x [B,C,N] -> (fp32 [B,C,N] or None, plane image or None)"""
+        from .._lib import check, lib, ptr, stream_ptr
+        B, C, N = x.shape
+        y = torch.empty_like(x) if values else None
+        img = torch.empty(lib().l3d_f16_act_bytes(B * N, C), dtype=torch.uint8, device=x.device) if planes else None
+        check(lib().l3d_layernorm_planes_cf(ptr(x), ptr(norm.a_2.detach().contiguous()), ptr(norm.b_2.detach().contiguous()),
+                                            float(norm.eps), B, C, N, ptr(y) if values else None, ptr(img) if planes else None,
+                                            stream_ptr()), "l3d_layernorm_planes_cf")
+        return y, img
+
+    def _attn_block_cf(self, norm, attn, x, memory):
+        """x + attn(norm(x), m, m) with m = norm(x) (self-attention, memory None) or the encoder's output image (memory = (img, N_m))"""
+        from .._lib import check, lib, ptr, stream_ptr
+        B, C, N = x.shape
+        _, img = self._ln_cf(norm, x)
+        ws = _attention_workspace(x.device)
+        ws.zero_()
+        if memory is None:
+            qkv = _linear_cf(attn._fused_linear(0, 3), None, True, planes=(img, B, N), amax=(ws, C))
+            q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+            have_max, M = getattr(qkv, "_l3d_amax", False), N
+        else:
+            mem_img, M = memory
+            q = _linear_cf(attn.linears[0], None, True, planes=(img, B, N), amax=(ws, C))
+            kv = _linear_cf(attn._fused_linear(1, 3), None, True, planes=(mem_img, B, M), amax=(ws[1:], C))
+            k, v = kv[:, :C], kv[:, C:]
+            have_max = getattr(q, "_l3d_amax", False) and getattr(kv, "_l3d_amax", False)
+        attn.attn = None                                           # the [B,h,N,M] map is never formed
+        ctx = torch.empty(lib().l3d_f16_act_bytes(B * N, C), dtype=torch.uint8, device=x.device)
+        check(lib().l3d_attention_forward_f16b(ptr(q), ptr(k), ptr(v), B, attn.h, attn.d_k, N, M, q.stride(0), k.stride(0), v.stride(0),
+                                               1.0 / math.sqrt(attn.d_k), ptr(ws), int(bool(have_max)), None, ptr(ctx), stream_ptr()),
+              "l3d_attention_forward_f16b")
+        return _linear_cf(attn.linears[-1], None, True, planes=(ctx, B, N), residual=x)
+
+    def _ffn_block_cf(self, norm, ff, x):
+        B, C, N = x.shape
+        _, img = self._ln_cf(norm, x)
+        hidden = _linear_cf(ff.w_1, None, True, planes=(img, B, N), relu=True, out_planes=True)      # fp16 planes, never fp32
+        return _linear_cf(ff.w_2, None, True, planes=hidden, residual=x)
+
+    def _pass_cf(self, src, tgt):
+        """self.model(src^T, tgt^T, None, None)^T for channel-first src, tgt [B,C,N]: the decoder's output [B,C,N_tgt]"""
+        from .._lib import f32c
+        enc, dec = self.model.encoder, self.model.decoder
+        x = f32c(src)
+        for layer in enc.layers:
+            x = self._attn_block_cf(layer.sublayer[0].norm, layer.self_attn, x, None)
+            x = self._ffn_block_cf(layer.sublayer[1].norm, layer.feed_forward, x)
+        _, mem = self._ln_cf(enc.norm, x)                          # the memory is only ever read by the k|v projections
+        y = f32c(tgt)
+        for layer in dec.layers:
+            y = self._attn_block_cf(layer.sublayer[0].norm, layer.self_attn, y, None)
+            y = self._attn_block_cf(layer.sublayer[1].norm, layer.src_attn, y, (mem, x.size(2)))
+            y = self._ffn_block_cf(layer.sublayer[2].norm, layer.feed_forward, y)
+        return self._ln_cf(dec.norm, y, values=True, planes=False)[0]
+
     def _forward(self, *input):
+        if self._cf_pass_ok(input[0], input[1]):
+            from .._lib import on_device_of
+            with on_device_of(input[0], input[1]):
+                tgt_embedding = self._pass_cf(input[0], input[1])
+                src_embedding = self._pass_cf(input[1], input[0])
+            return src_embedding, tgt_embedding
         src = input[0].transpose(2, 1).contiguous()
         tgt = input[1].transpose(2, 1).contiguous()
         tgt_embedding = self.model(src, tgt, None, None).transpose(2, 1).contiguous()

@@ -476,7 +476,9 @@ def test_transforms_take_the_reference_datasets_cpu_inputs_and_hooks_see_layerno
         h = net.model.encoder.layers[0].sublayer[1].norm.register_forward_hook(lambda m, i, o: seen.append(o.clone()))
         got = net(x, x)
         h.remove()
-    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    # the hooked module runs module by module, the plain one as a channel-first pass (Transformer._pass_cf): same values to fp32 rounding
+    for g_, w_ in zip(got, want):
+        assert (g_ - w_).abs().max().item() <= 2e-5 * w_.abs().max().item()
     ln = net.model.encoder.layers[0].sublayer[1].norm
     assert len(seen) == 2 and all(torch.isfinite(o).all() for o in seen)
     assert all(abs(float(o.mean())) < 0.1 and 0.5 < float(o.std()) < 2.0 for o in seen)     # normalised values, not scratch memory

@@ -1129,6 +1129,74 @@ def test_transformer_fast_linear_path_matches_torch_path():
         np.testing.assert_allclose(g_.cpu().numpy(), w_.numpy(), rtol=1e-4, atol=1e-5)
 
 
+def test_transformer_channel_first_pass():
+    """utils/transformer.py, Transformer._pass_cf: a whole encoder-decoder pass in the [B,C,N] layout of the GEMMs (channel-first
+    LayerNorm straight to planes, residual connections in the epilogues of the output projection and the feed-forward's second
+    layer) against the module-by-module route and against the reference's op sequence in fp64 (utils/transformer.py:14-243);
+    the pieces too: l3d_layernorm_planes_cf vs the row kernel's formula in fp64, l3d_pointwise_conv_f16_residual vs conv + add."""
+    import copy
+    from learning3d_amd._lib import check, lib, ptr, stream_ptr
+    from learning3d_amd.models import _fused
+    from learning3d_amd.utils import transformer as T
+    rng = np.random.default_rng(77)
+    # ---- LayerNorm over the channels of a channel-first tensor
+    for (B, C, N) in [(2, 512, 256), (1, 256, 320), (3, 128, 70)]:
+        x = (rng.standard_normal((B, C, N)) * rng.uniform(0.1, 3.0, (B, 1, N)) + rng.uniform(-2, 2, (B, 1, N))).astype(np.float32)
+        a = rng.uniform(0.5, 1.5, C).astype(np.float32); b = rng.uniform(-0.5, 0.5, C).astype(np.float32)
+        x64 = x.astype(np.float64)
+        want = a[None, :, None] * (x64 - x64.mean(1, keepdims=True)) / (x64.std(1, ddof=1, keepdims=True) + 1e-6) + b[None, :, None]
+        y = torch.empty((B, C, N), device="cuda"); img = torch.empty(lib().l3d_f16_act_bytes(B * N, C), dtype=torch.uint8, device="cuda")
+        tx, ta, tb = dev(x), dev(a), dev(b)                       # held: a temporary's block would be handed to the next allocation
+        check(lib().l3d_layernorm_planes_cf(ptr(tx), ptr(ta), ptr(tb), 1e-6, B, C, N, ptr(y), ptr(img), stream_ptr()), "ln cf")
+        np.testing.assert_allclose(y.cpu().numpy(), want, rtol=2e-6, atol=2e-6)
+        # the image against the row kernel's image of the same values laid out [B,N,C]
+        rows = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 1))).cuda()
+        y2 = torch.empty_like(rows); img2 = torch.empty_like(img)
+        check(lib().l3d_layernorm_planes(ptr(rows), ptr(ta), ptr(tb), 1e-6, B * N, C, ptr(y2), ptr(img2), stream_ptr()), "ln rows")
+        pb = (C // 8) * B * N * 16
+        h1 = img[:pb].view(torch.float16).float(); h2 = img2[:pb].view(torch.float16).float()
+        assert torch.equal(img[2 * pb:2 * pb + 4], img2[2 * pb:2 * pb + 4])                      # the same plane scale
+        assert (h1 - h2).abs().max().item() <= 2.0 ** -10 * h2.abs().max().item()               # high planes: at most one fp16 ulp apart
+    # ---- residual epilogue
+    B, N, C0, C1 = 2, 512, 512, 256
+    x = rng.standard_normal((B, N, C0)).astype(np.float32)
+    ximg = _fused.split_rows_f16(dev(x))
+    w = (rng.standard_normal((C1, C0)) / C0 ** 0.5).astype(np.float32); sh = (rng.standard_normal(C1) * 0.3).astype(np.float32)
+    wimg = _fused.split_weights_f16(dev(w))
+    res = dev(rng.standard_normal((B, C1, N)).astype(np.float32))
+    plain = _fused.pointwise_conv_f16(ximg, B, N, wimg, C0, C1, None, dev(sh))
+    fused = _fused.pointwise_conv_f16(ximg, B, N, wimg, C0, C1, None, dev(sh), residual=res)
+    assert torch.equal(fused, res + plain)
+    # ---- the whole pass
+    torch.manual_seed(12)
+    net = T.Transformer(512, 1, 0.0, 1024, 4).eval()
+    for prm in net.parameters():
+        if prm.dim() == 1 and prm.numel() == 512:
+            prm.data.add_(torch.randn(512) * 0.1)
+    ref = copy.deepcopy(net).double()
+    a_ = rng.standard_normal((2, 512, 256)).astype(np.float32); b_ = rng.standard_normal((2, 512, 512)).astype(np.float32)
+    net = net.cuda()
+    import learning3d_amd._lib as _lib
+    with torch.no_grad():
+        want = ref(torch.from_numpy(a_).double(), torch.from_numpy(b_).double())
+        _lib.LAUNCH_LOG = log = []
+        try:
+            got = net(dev(a_), dev(b_))
+        finally:
+            _lib.LAUNCH_LOG = None
+        assert "l3d_layernorm_planes_cf" in log and "l3d_pointwise_conv_f16_residual" in log and "l3d_add_transposed" not in log, sorted(set(log))
+        T.CHANNEL_FIRST_PASS = False
+        try:
+            mod = net(dev(a_), dev(b_))
+        finally:
+            T.CHANNEL_FIRST_PASS = True
+    for g_, m_, w_ in zip(got, mod, want):
+        assert g_.shape == w_.shape and g_.is_contiguous()
+        np.testing.assert_allclose(g_.cpu().numpy(), w_.numpy(), rtol=1e-4, atol=2e-5)
+        assert (g_ - m_).abs().max().item() <= 2e-5 * m_.abs().max().item()
+    _fused.check_range(sync=True)
+
+
 def test_flownet3d_set_abstraction_vs_oracle():
     """BASELINE config 5's layer (sa1: npoint=1024 -> here 128, r=0.5, K=16, mlp [32,32,64]) against the
     oracle composition FPS -> gather -> ball query -> group -> torch-CPU conv stack."""
