@@ -454,6 +454,11 @@ size_t l3d_f16_plane_bytes(long rows, int cols);
 size_t l3d_f16_act_bytes(long rows, int cols);
 size_t l3d_conv_f16_weight_bytes(int Cout, int Cin);
 int l3d_conv_f16_split_weights(const float *w, int Cout, int Cin, void *dst, l3d_stream_t stream);
+/* nn.Linear over a handful of rows (PCN's fully connected decoder, models/pcn.py:132-137: rows = clouds):
+ * y [R][Cout] = act(x [R][Cin] w [Cout][Cin]^T + bias), fp32 fmaf chains in ascending k; the weight matrix is read once.
+ * Cin % 256 == 0 (else L3D_ERR_UNSUPPORTED). */
+int l3d_linear_rows(const float *x, const float *w, const float *bias, int R, int Cin, int Cout, int relu, float *y,
+                    l3d_stream_t stream);
 int l3d_split_f16_rows(const float *x, long rows, int C, int channel_first, int Npts, void *dst, int *range_flag,
                        l3d_stream_t stream);
 int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes, const float *scale, const float *shift,

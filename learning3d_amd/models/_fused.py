@@ -451,9 +451,16 @@ def pointwise_conv(x, w, scale=None, shift=None, relu=False, channel_last=False,
 
 
 def linear_rows(x, lin, relu=False):
-    """nn.Linear over rows x [R, Cin] -> [R, Cout] (+ ReLU) on the conv kernels: the rows are the points of one cloud"""
+    """nn.Linear over a handful of rows x [R, Cin] -> [R, Cout] (+ ReLU): l3d_linear_rows (the weight matrix read once); shapes
+    it does not take (Cin % 256 != 0) go through the conv kernels with the rows as the points of one cloud"""
     w, _, b = fold_conv_bn(lin)
-    return pointwise_conv(f32c(x).unsqueeze(0), w, None, b, relu=relu, channel_last=True)[0].t()
+    x = f32c(x)
+    R, Cin = x.shape
+    if Cin % 256 == 0:
+        y = torch.empty((R, w.shape[0]), dtype=torch.float32, device=x.device)
+        check(lib().l3d_linear_rows(ptr(x), ptr(w), ptr(b), R, Cin, w.shape[0], int(relu), ptr(y), stream_ptr()), "l3d_linear_rows")
+        return y
+    return pointwise_conv(x.unsqueeze(0), w, None, b, relu=relu, channel_last=True)[0].t()
 
 
 class EdgeConvParams:
