@@ -585,6 +585,11 @@ int l3d_bn_act_backward(const float *dy, const float *z, const float *scale, con
 /* tot[j] = part[0][j] + part[1][j] + ... + part[B-1][j]: per-cloud fp64 partials [B][M] added left to right, i.e. in
  * global cloud order whatever B's factorisation into ranks was. */
 int l3d_sum_clouds_f64(const double *part, int B, long M, double *tot, l3d_stream_t stream);
+/* Max over the last, contiguous axis with its arg-max and the backward of it (the max over the k neighbours behind every
+ * EdgeConv layer of a training step, models/dgcnn.py:36-46): v [R] = max_k x [R][K], idx [R] = the FIRST k that attains it
+ * (torch's rule; one byte, K <= 256); gx [R][K] = g [R] at idx [R] and zero elsewhere, one dense pass. */
+int l3d_max_last(const float *x, long R, int K, float *v, unsigned char *idx, l3d_stream_t stream);
+int l3d_max_last_backward(const float *g, const unsigned char *idx, long R, int K, float *gx, l3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight gradient of a 1x1 conv / Linear over points (wgrad.hip; the autograd of nn.Conv1d / Conv2d(k=1) in

@@ -73,6 +73,8 @@ SIGNATURES = {
     "l3d_layernorm_ref": [_P, _P, _P, _F, _L, _I, _P, _P],
     "l3d_layernorm_planes": [_P, _P, _P, _F, _L, _I, _P, _P, _P],
     "l3d_add_transposed": [_P, _P, _I, _I, _I, _P, _P],
+    "l3d_max_last": [_P, _L, _I, _P, _P, _P],
+    "l3d_max_last_backward": [_P, _P, _L, _I, _P, _P],
     "l3d_linear_rows": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "l3d_layernorm_planes_cf": [_P, _P, _P, _F, _I, _I, _I, _P, _P, _P],
     "l3d_edgeconv_packed_floats": [_I, _I, _I, _I],

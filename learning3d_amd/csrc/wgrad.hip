@@ -7,7 +7,7 @@
 // The reduction axis is B*P (655 360 for DGCNN's EdgeConv layers at B = 32): one GEMM whose K axis is split into
 // (cloud, chunk of PC points) pieces.  wgrad_partial_kernel: a 64 (co) x 64 (ci) tile per workgroup and piece on
 // v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation over <= PC terms), partial sums to a workspace
-// [pieces][Cout][Cin].  wgrad_reduce_kernel: adds the pieces in piece order in fp64 and rounds once.  No atomics: two
+// [pieces][Cout][Cin].  wgrad_reduce_kernel: adds the pieces in a fixed order in fp64 and rounds once.  No atomics: two
 // runs give the same bits, and the error is that of <= PC fp32 accumulations plus one rounding, not of B*P.
 #include "common.h"
 
@@ -81,13 +81,32 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(const float *__restr
     }
 }
 
+// 64 elements per workgroup, four threads per element: thread (g, e) adds pieces [g q, (g+1) q) of element e in piece order
+// (fp64, eight independent loads in flight), the four partial sums meet in LDS and are added in g order -- a fixed tree, the same
+// bits every run.  (One thread per element walking all 320 pieces of a DGCNN layer one dependent trip at a time took as long
+// as the MFMA kernel that produced them.)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, long elems, int pieces, float *__restrict__ dw)
 {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= elems) return;
+    __shared__ double sums[4][64];
+    const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long i = (long)blockIdx.x * 64 + e;
+    const int q = (pieces + 3) / 4, k0 = g * q, k1 = min(pieces, k0 + q);
     double s = 0.0;
-    for (int k = 0; k < pieces; k++) s += (double)part[(size_t)k * elems + i];
-    dw[i] = (float)s;
+    if (i < elems) {
+        const float *src = part + i;
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = src[(size_t)(k + u) * elems];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += (double)v[u];
+        }
+        for (; k < k1; k++) s += (double)src[(size_t)k * elems];
+    }
+    sums[g][e] = s;
+    __syncthreads();
+    if (g == 0 && i < elems) dw[i] = (float)(((sums[0][e] + sums[1][e]) + sums[2][e]) + sums[3][e]);
 }
 
 static inline int wgrad_chunk(long P, int pc)
@@ -118,7 +137,7 @@ extern "C" int l3d_wgrad(const float *dz, const float *x, int B, int Cout, int C
     int rc = l3d_check_launch();
     if (rc != L3D_OK) return rc;
     const long elems = (long)Cout * Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)l3d_divup(elems, 256)), dim3(256), 0, (hipStream_t)stream, workspace, elems,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)l3d_divup(elems, 64)), dim3(256), 0, (hipStream_t)stream, workspace, elems,
                        (int)pieces, dw);
     return l3d_check_launch();
 }

@@ -21,7 +21,7 @@ The running statistics follow torch.nn.BatchNorm (momentum update with the unbia
 import torch
 import torch.distributed as dist
 
-from .._lib import check, f32c, lib, ptr, stream_ptr
+from .._lib import check, f32c, lib, on_device_of, ptr, stream_ptr
 from . import _fused
 
 
@@ -193,6 +193,39 @@ def linear_act(x, lin, relu=False):
     x3 = x.reshape(-1, shp[-1]).t().unsqueeze(0)                          # [1, Cin, rows] (made contiguous by the Function)
     y = _ConvAffineAct.apply(x3, lin.weight, lin.bias, None, None, None, relu, False, False)
     return y[0].t().reshape(*shp[:-1], y.shape[1])
+
+
+class _MaxLast(torch.autograd.Function):
+    """x.max(dim=-1, keepdim=True)[0] for a contiguous fp32 device tensor: l3d_max_last / l3d_max_last_backward"""
+
+    @staticmethod
+    def forward(ctx, x):
+        K = x.shape[-1]
+        R = x.numel() // K
+        v = torch.empty(x.shape[:-1] + (1,), dtype=torch.float32, device=x.device)
+        idx = torch.empty(R, dtype=torch.uint8, device=x.device)
+        with on_device_of(x):
+            check(lib().l3d_max_last(ptr(x), R, K, ptr(v), ptr(idx), stream_ptr()), "l3d_max_last")
+        ctx.save_for_backward(idx)
+        ctx.shape = x.shape
+        return v
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g = f32c(g)
+        gx = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        with on_device_of(g):
+            check(lib().l3d_max_last_backward(ptr(g), ptr(idx), idx.numel(), ctx.shape[-1], ptr(gx), stream_ptr()), "l3d_max_last_backward")
+        return gx
+
+
+def max_over_last(x):
+    """x.max(dim=-1, keepdim=True)[0] (the max over the k neighbours of an EdgeConv layer, reference models/dgcnn.py:36-46) with a
+    one-pass HIP forward and backward where they apply, torch's otherwise"""
+    if hip_layers_ok(x) and x.is_contiguous() and x.dim() >= 2 and 1 <= x.shape[-1] <= 256 and x.numel() > 0:
+        return _MaxLast.apply(x)
+    return x.max(dim=-1, keepdim=True)[0]
 
 
 def hip_layers_ok(x):

@@ -17,6 +17,7 @@ from .pooling import Pooling
 
 
 FOLD_FUSED = True       # folding decoder as one kernel (l3d_fold_mlp); False: three 1x1-conv launches
+FOLD_FACTORED_TRAIN = True   # autograd live: conv5's global-feature columns as a per-cloud shift (PCN._fine_factored)
 
 
 class PCN(torch.nn.Module):
@@ -78,7 +79,25 @@ class PCN(torch.nn.Module):
         center = coarse.unsqueeze(2).repeat([1, 1, self.grid_size ** 2, 1]).reshape(-1, self.num_fine, 3)
         return grid_feature, center
 
+    def _fine_factored(self, coarse, gfeat):
+        """The folding decoder (pcn.py:84-101) with autograd live, conv5 factored as the fused forward has it: 1024 of its 1029
+        input channels are the cloud's global feature repeated over all fine points, so their product is a per-cloud vector
+        (one addmm, differentiable) and the per-point GEMM is over 5 channels -- not 553 GFLOP forward, as much again in the
+        dgrad and a 1029-column wgrad per step (what made a PCN training step 39 ms).  Same function, fp32 rounding aside."""
+        from ._train import _ConvAffineAct
+        grid_feature, center = self._grid_center(coarse)
+        x5 = torch.cat([grid_feature, center], dim=2).permute(0, 2, 1)                   # [B,5,fine]
+        w5 = self.conv5.weight.reshape(512, 1029)
+        shift = torch.addmm(self.conv5.bias, gfeat, w5[:, 5:].t())                       # [B,512]: W5[:, 5:] g + b5
+        z = _ConvAffineAct.apply(x5, w5[:, :5], None, None, None, None, False, False, False)
+        out = self.relu(z + shift.unsqueeze(2))
+        out = self._layer(self.conv7, self._layer(self.conv6, out, True), False)
+        return out.permute(0, 2, 1) + center
+
     def _fine_torch(self, coarse, gfeat):
+        from ._train import hip_layers_ok
+        if FOLD_FACTORED_TRAIN and hip_layers_ok(coarse) and self.conv5.in_channels == 1029 and self.conv5.out_channels == 512:
+            return self._fine_factored(coarse, gfeat)
         grid_feature, center = self._grid_center(coarse)
         global_feature = gfeat.unsqueeze(1).repeat([1, self.num_fine, 1])
         feature = torch.cat([grid_feature, center, global_feature], dim=2).permute(0, 2, 1)
