@@ -344,7 +344,7 @@ def main_c5(args, rank, world, local, dev, dist, parallel):
         out = {
             "metric": "clouds/sec DGCNN-fwd+Chamfer B=32 N=1024; kNN HBM GB/s vs peak at 1/2/4/8 GPU",
             "value": world * B_PER_GPU * args.steps / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "f32 (index work int32; shared MLP on the fp32 MFMA)", "data": "synthetic",
             "config": {"workload": "configs[4] (NOT the headline config; --workload c5): FlowNet3D sa1 set-conv forward -- furthest "
                                    "point sampling 8192 -> 1024, ball query r=0.5 K=16, grouping, shared MLP 6->32->32->64 + max "
@@ -388,6 +388,10 @@ def main():
     ap.add_argument("--arith", choices=["f16x2", "bf16x3", "fp32"], default=None,
                     help="GEMM arithmetic of the shared-MLP kernels (default f16x2: 3 fp16 MFMA products per fp32 product; "
                          "bf16x3: 6 bf16 products, full fp32 exponent range; fp32 = --fp32-mfma)")
+    ap.add_argument("--strong", nargs="?", type=int, const=0, default=None, metavar="PARTS",
+                    help="strong scaling, for information (SURVEY.md 8(d)): the 32 clouds of ONE batch split over the N GPUs (32 / N each) "
+                         "instead of 32 per GPU; the JSON line says \"scaling\": \"strong\".  PARTS (default: --gpus) lets one GPU run "
+                         "the share it would have in a PARTS-way split")
     ap.add_argument("--no-graph", action="store_true", help="issue every step's launches eagerly instead of replaying a hipGraph")
     ap.add_argument("--fork", choices=["none", "start", "edgeconv", "conv5"], default=FORK_DEFAULT,
                     help="c2: where the step's Chamfer branch (NN search + loss tail; independent of the DGCNN chain) leaves the "
@@ -401,6 +405,12 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(relaunch_under_torchrun(args.gpus))
+    args.strong = None if args.strong is None else (args.strong or args.gpus)
+    if args.strong:
+        global B_PER_GPU
+        if B_PER_GPU % args.strong:
+            raise SystemExit(f"--strong: {B_PER_GPU} clouds do not split evenly {args.strong} ways")
+        B_PER_GPU //= args.strong
 
     from learning3d_amd import parallel
     import torch.distributed as dist
@@ -678,7 +688,7 @@ def main():
             "metric": "clouds/sec DGCNN-fwd+Chamfer B=32 N=1024; kNN HBM GB/s vs peak at 1/2/4/8 GPU",
             "value": clouds_per_s, "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "configs[1]: DGCNN k=20 kNN + EdgeConv forward (emb_dims=1024, eval, random-init "
                                    "weights) + ChamferDistanceLoss, B=32 clouds per GPU, N=1024, inputs resident in HBM",
                        "global_batch": world * B_PER_GPU, "num_points": NPTS, "k": KNN, "emb_dims": EMB,

@@ -36,7 +36,7 @@ def run(name, make, step, iters=5):
 def main():
     which = sys.argv[1:] or ["dgcnn", "pcn", "pointnet"]
     from learning3d_amd.losses import ChamferDistanceLoss
-    from learning3d_amd.models import DGCNN, PCN, PointNet
+    from learning3d_amd.models import DCP, DGCNN, PCN, FlowNet3D, PointNet
     torch.manual_seed(0)
     if "dgcnn" in which:
         def make():
@@ -78,5 +78,39 @@ def main():
         run("PCN train step (B 32, 2048 -> 1024 / 16384, Chamfer on both outputs)", make, step)
 
 
+def extra(which):
+    from learning3d_amd.models import DCP, DGCNN, FlowNet3D
+    if "flownet" in which:
+        def make():
+            net = FlowNet3D().cuda().train()
+            g = torch.Generator().manual_seed(0)
+            p1 = torch.rand(8, 3, 8192, generator=g).cuda(); p2 = torch.rand(8, 3, 8192, generator=g).cuda()
+            return net, torch.optim.Adam(net.parameters(), lr=1e-3), (p1, p2, torch.rand(8, 3, 8192, generator=g).cuda())
+
+        def step(net, opt, data):
+            p1, p2, flow = data
+            opt.zero_grad(set_to_none=True)
+            loss = (net(p1, p2, p1, p2) - flow).square().mean()
+            loss.backward()
+            opt.step()
+        run("FlowNet3D train step (B 8 per GPU, N 8192, train-mode BN; examples/train_flownet.py)", make, step, iters=3)
+    if "dcp" in which:
+        def make():
+            net = DCP(feature_model=DGCNN(emb_dims=512), cycle=False).cuda().train()
+            g = torch.Generator().manual_seed(0)
+            t = (torch.rand(8, 1024, 3, generator=g) - 0.5).cuda()
+            return net, torch.optim.Adam(net.parameters(), lr=1e-3), (t, (t + 0.05).contiguous())
+
+        def step(net, opt, data):
+            t, s_ = data
+            opt.zero_grad(set_to_none=True)
+            out = net(t, s_)
+            loss = (out["est_R"] - torch.eye(3, device="cuda")).square().mean() + out["est_t"].square().mean()
+            loss.backward()
+            opt.step()
+        run("DCP-v2 train step (B 8, N 1024, emb 512; examples/train_dcp.py)", make, step, iters=3)
+
+
 if __name__ == "__main__":
     main()
+    extra(sys.argv[1:])
