@@ -255,6 +255,15 @@ int l3d_group_first_layer(const float *U, const float *V, const float *shift, co
 int l3d_group_first_layer_planes(const float *U, const float *V, const float *shift, const float *wx, const float *xyz,
                                  const float *new_xyz, const int32_t *idx, int B, int N, int S, int K, int C1, int relu,
                                  const float *bound, void *out_img, int *range_flag, l3d_stream_t stream);
+/* The same with the bound formed inside the kernel from block maxima: maxpart = the 4 x 64 floats l3d_absmax4_partials writes for
+ * (U, V, xyz, new_xyz); wxr = max_r sum_d |wx_rd| and shmax = max|shift| come from the layer's parameters.
+ * bound = max|U| + (max|V| or shmax) + wxr (max|xyz| + max|new_xyz|). */
+int l3d_absmax4_partials(const float *p0, size_t n0, const float *p1, size_t n1, const float *p2, size_t n2, const float *p3,
+                         size_t n3, float *out, l3d_stream_t stream);
+int l3d_group_first_layer_planes_auto(const float *U, const float *V, const float *shift, const float *wx, const float *xyz,
+                                      const float *new_xyz, const int32_t *idx, int B, int N, int S, int K, int C1, int relu,
+                                      const float *maxpart, float wxr, float shmax, void *out_img, int *range_flag,
+                                      l3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Batched 3x3 SVD head  == utils/svd.py:29-58 (T6, without the B host syncs)

@@ -42,6 +42,8 @@ SIGNATURES = {
     "l3d_group_concat2": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_group_first_layer": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_group_first_layer_planes": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "l3d_absmax4_partials": [_P, _SZ, _P, _SZ, _P, _SZ, _P, _SZ, _P, _P],
+    "l3d_group_first_layer_planes_auto": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _F, _F, _P, _P, _P],
     "l3d_scatter_add_det_workspace_bytes": [_I, _I, _I],
     "l3d_scatter_add_det": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "l3d_edge_gather_max": [_P, _P, _I, _I, _I, _I, _I, _P, _L, _P],

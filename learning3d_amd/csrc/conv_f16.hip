@@ -858,15 +858,30 @@ __global__ __launch_bounds__(256) void group_first_layer_planes_kernel(const flo
                                                                        const int32_t *__restrict__ idx, int N, int S, int K, int act,
                                                                        const float *__restrict__ bound, uint4 *__restrict__ ph,
                                                                        uint4 *__restrict__ pm, float *__restrict__ oinv,
-                                                                       int *__restrict__ range_flag)
+                                                                       int *__restrict__ range_flag, const float *__restrict__ maxpart,
+                                                                       float wxr, float shmax)
 {
     __shared__ uint4 lh[NO * GFP_STRIDE], lm[NO * GFP_STRIDE];
+    __shared__ float mx4[4];
     constexpr int C1 = NO * 8, RPP = 256 / NO;                   // rows per pass
     const int t = threadIdx.x, b = blockIdx.y;
     const long SK = (long)S * K, e0 = (long)blockIdx.x * GFP_ROWS, rows = (long)gridDim.y * SK;
     int ex = 0;
     {
-        const float bd = *bound * 1.000001f;
+        float bd;
+        if (maxpart) {
+            // the bound from l3d_absmax4_partials' [4][64] block maxima (max|U|, max|V|, max|xyz|, max|new_xyz|): wave j reduces
+            // tensor j; bound = max|U| + (max|V| or max|shift|) + (max_r sum_d |wx_rd|) (max|xyz| + max|new_xyz|)
+            float m = maxpart[t];
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+            if ((t & 63) == 0) mx4[t >> 6] = m;
+            __syncthreads();
+            bd = mx4[0] + (V ? mx4[1] : shmax) + wxr * (mx4[2] + mx4[3]);
+        } else {
+            bd = *bound;
+        }
+        bd *= 1.000001f;
         if (bd > 0.f && bd < 3.0e38f) (void)frexpf(bd, &ex);
     }
     const float up = ldexpf(1.f, 12 - ex);
@@ -931,21 +946,76 @@ __global__ __launch_bounds__(256) void group_first_layer_planes_kernel(const flo
 
 // as l3d_group_first_layer (grouping.hip), output = activation image (l3d_f16_act_bytes(B S K, C1) bytes) instead of fp32 rows;
 // bound: device float >= max|output|.  C1 = 64, 128 or 256.
-extern "C" int l3d_group_first_layer_planes(const float *U, const float *V, const float *shift, const float *wx, const float *xyz,
-                                            const float *new_xyz, const int32_t *idx, int B, int N, int S, int K, int C1, int relu,
-                                            const float *bound, void *out_img, int *range_flag, l3d_stream_t stream)
+static int gfp_launch(const float *U, const float *V, const float *shift, const float *wx, const float *xyz, const float *new_xyz,
+                      const int32_t *idx, int B, int N, int S, int K, int C1, int relu, const float *bound, const float *maxpart,
+                      float wxr, float shmax, void *out_img, int *range_flag, hipStream_t st)
 {
-    L3D_REQUIRE(U && wx && xyz && new_xyz && idx && bound && out_img && B > 0 && N > 0 && S > 0 && K > 0 && C1 > 0);
     if (B > 65535 || (C1 != 64 && C1 != 128 && C1 != 256) || (((size_t)U | (size_t)V | (size_t)out_img) & 15)) return L3D_ERR_UNSUPPORTED;
     const long R = (long)B * S * K;
     const size_t pb = l3d_f16_plane_bytes(R, C1);
     unsigned char *d = (unsigned char *)out_img;
     dim3 grid((unsigned)l3d_divup((long)S * K, GFP_ROWS), B), block(256);
-    hipStream_t st = (hipStream_t)stream;
-#define GFP_ARGS U, V, shift, wx, xyz, new_xyz, idx, N, S, K, relu, bound, (uint4 *)d, (uint4 *)(d + pb), (float *)(d + 2 * pb), range_flag
+#define GFP_ARGS U, V, shift, wx, xyz, new_xyz, idx, N, S, K, relu, bound, (uint4 *)d, (uint4 *)(d + pb), (float *)(d + 2 * pb), range_flag, \
+                 maxpart, wxr, shmax
     if (C1 == 64)       hipLaunchKernelGGL(group_first_layer_planes_kernel<8>, grid, block, 0, st, GFP_ARGS);
     else if (C1 == 128) hipLaunchKernelGGL(group_first_layer_planes_kernel<16>, grid, block, 0, st, GFP_ARGS);
     else                hipLaunchKernelGGL(group_first_layer_planes_kernel<32>, grid, block, 0, st, GFP_ARGS);
 #undef GFP_ARGS
     return l3d_check_launch();
+}
+
+extern "C" int l3d_group_first_layer_planes(const float *U, const float *V, const float *shift, const float *wx, const float *xyz,
+                                            const float *new_xyz, const int32_t *idx, int B, int N, int S, int K, int C1, int relu,
+                                            const float *bound, void *out_img, int *range_flag, l3d_stream_t stream)
+{
+    L3D_REQUIRE(U && wx && xyz && new_xyz && idx && bound && out_img && B > 0 && N > 0 && S > 0 && K > 0 && C1 > 0);
+    return gfp_launch(U, V, shift, wx, xyz, new_xyz, idx, B, N, S, K, C1, relu, bound, nullptr, 0.f, 0.f, out_img, range_flag,
+                      (hipStream_t)stream);
+}
+
+// Block maxima of up to four fp32 tensors in one launch: out[j][blk] = max |p_j| over block blk's stride of tensor j (64 blocks per
+// tensor; zeros for an absent tensor).  No atomics, no pre-zeroing: the consumer reduces the 4 x 64 values itself.
+__global__ __launch_bounds__(256) void absmax4_partials_kernel(const float *__restrict__ p0, size_t n0, const float *__restrict__ p1,
+                                                               size_t n1, const float *__restrict__ p2, size_t n2,
+                                                               const float *__restrict__ p3, size_t n3, float *__restrict__ out)
+{
+    __shared__ float red[4];
+    const int j = blockIdx.y;
+    const float *p = j == 0 ? p0 : (j == 1 ? p1 : (j == 2 ? p2 : p3));
+    const size_t n = j == 0 ? n0 : (j == 1 ? n1 : (j == 2 ? n2 : n3));
+    float m = 0.f;
+    if (p) {
+        const size_t n4 = (((size_t)p & 15) == 0) ? n >> 2 : 0;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            const float4 v = ((const float4 *)p)[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+        for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(p[i]));
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) out[j * 64 + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+extern "C" int l3d_absmax4_partials(const float *p0, size_t n0, const float *p1, size_t n1, const float *p2, size_t n2,
+                                    const float *p3, size_t n3, float *out, l3d_stream_t stream)
+{
+    L3D_REQUIRE(out);
+    hipLaunchKernelGGL(absmax4_partials_kernel, dim3(64, 4), dim3(256), 0, (hipStream_t)stream, p0, n0, p1, n1, p2, n2, p3, n3, out);
+    return l3d_check_launch();
+}
+
+// l3d_group_first_layer_planes with the bound formed inside the kernel: maxpart = l3d_absmax4_partials(U, V, xyz, new_xyz)'s 256
+// floats, wxr = max_r sum_d |wx_rd| and shmax = max|shift| (functions of the layer's parameters) -- one launch in front of the layer
+// instead of a dozen reductions and scalar operations (NaN / inf in an input -> the range flag, as before).
+extern "C" int l3d_group_first_layer_planes_auto(const float *U, const float *V, const float *shift, const float *wx, const float *xyz,
+                                                 const float *new_xyz, const int32_t *idx, int B, int N, int S, int K, int C1, int relu,
+                                                 const float *maxpart, float wxr, float shmax, void *out_img, int *range_flag,
+                                                 l3d_stream_t stream)
+{
+    L3D_REQUIRE(U && wx && xyz && new_xyz && idx && maxpart && out_img && B > 0 && N > 0 && S > 0 && K > 0 && C1 > 0);
+    return gfp_launch(U, V, shift, wx, xyz, new_xyz, idx, B, N, S, K, C1, relu, nullptr, maxpart, wxr, shmax, out_img, range_flag,
+                      (hipStream_t)stream);
 }

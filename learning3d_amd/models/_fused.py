@@ -285,6 +285,25 @@ def f16_eligible(Cin, Cout, N):
     return Cin % 16 == 0 and Cin >= 32 and ((Cout % 256 == 0 and N % 256 == 0) or (Cout % 128 == 0 and N % 512 == 0))
 
 
+_OBS_CACHE = {}
+
+
+def _plane_obs(scale, shift, dev):
+    """{max|shift|, max|scale|} as a device tensor for the plane-output epilogues; a function of the layer's (folded) parameters
+    only, so it is cached per (tensor, version): six tiny launches per layer and call otherwise"""
+    key = (str(dev), None if scale is None else (scale.data_ptr(), scale._version), None if shift is None else (shift.data_ptr(), shift._version))
+    hit = _OBS_CACHE.get(key)
+    if hit is None:
+        if len(_OBS_CACHE) > 4096:
+            _OBS_CACHE.clear()
+        hit = torch.stack([shift.abs().max() if shift is not None else torch.zeros((), device=dev),
+                           scale.abs().max() if scale is not None else torch.ones((), device=dev)]).float()
+        # keep the keyed tensors alive with the entry: a freed tensor's address could be handed to another parameter
+        _OBS_CACHE[key] = (hit, scale, shift)
+        return hit
+    return hit[0]
+
+
 def pointwise_conv_f16(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=None, relu=False, out_planes=False, amax=None,
                        unscaled=False, residual=None):
     """l3d_pointwise_conv_f16 on pre-split operands -> y [B,Cout,N] fp32; out_planes=True: the output as an fp16 activation
@@ -297,8 +316,7 @@ def pointwise_conv_f16(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=No
         if shift is not None and shift.dim() != 1:
             raise ValueError("plane output takes a per-channel shift only")
         dev = x_planes.device
-        obs = torch.stack([shift.abs().max() if shift is not None else torch.zeros((), device=dev),
-                           scale.abs().max() if scale is not None else torch.ones((), device=dev)]).float()
+        obs = _plane_obs(scale, shift, dev)
         img = torch.empty(lib().l3d_f16_act_bytes(B * N, Cout), dtype=torch.uint8, device=dev)
         check(lib().l3d_pointwise_conv_f16_planes(ptr(x_planes), ptr(w_planes), ptr(scale), ptr(shift), ptr(obs), B, Cin, Cout, N,
                                                   int(relu), ptr(img), stream_ptr()), "l3d_pointwise_conv_f16_planes")
@@ -362,8 +380,9 @@ def pointwise_conv_f16_pool(x_planes, B, N, w_planes, Cin, Cout, scale=None, shi
     bstride = Cout if (shift is not None and shift.dim() == 2) else 0
     obs = img = part = None
     if out_planes:
-        obs = torch.stack([shift.abs().max() if shift is not None else torch.zeros((), device=dev),
-                           scale.abs().max() if scale is not None else torch.ones((), device=dev)]).float()
+        # a per-cloud shift [B,Cout] is data (pcn.py's pooled half of conv3): not cached
+        obs = _plane_obs(scale, shift, dev) if (shift is None or shift.dim() == 1) else \
+            torch.stack([shift.abs().max(), scale.abs().max() if scale is not None else torch.ones((), device=dev)]).float()
         img = torch.empty(lib().l3d_f16_act_bytes(B * N, Cout), dtype=torch.uint8, device=dev)
     pk = int(group) if group else 128
     if pool or group:

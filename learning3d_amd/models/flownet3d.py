@@ -17,7 +17,9 @@ FACTOR_FIRST_LAYER = True    # grouped first layers as per-point products + a ga
 # ... and the layers behind them as an f16x2 chain on fp16 plane images (conv_f16.hip's 128 x 512 tile, max over K in the last
 # layer's epilogue).  Correct and tested, but OFF: at config 5's shapes these 128-channel layers have 8 K-chunks per tile and
 # move 0.5 GB each -- 118 us on the narrow f16x2 tile against 165 us on the fp32 MFMA, which the extra bound / scale
-# reductions (21 tiny launches per forward) more than eat: 5.12 -> 5.28 ms (tools/flownet_bench.py, LABLOG R2.4f).
+# reductions (21 tiny launches per forward) more than eat: 5.12 -> 5.28 ms (tools/flownet_bench.py, LABLOG R2.4f).  Round 3: the
+# bound's four data maxima in one launch (l3d_absmax4_partials, finished inside the layer's kernel) and the parameter-only terms
+# cached: 5.00 -> 5.13 ms -- closer, still not a gain; stays off.
 F16_GROUPED_STACK = False
 
 
@@ -96,9 +98,12 @@ def _factored_first_layer(src_xyz_t, centre_xyz_t, src_feat, centre_feat, idx, o
         else:
             wf, wx, wc = w[:, :C], w[:, C:C + 3], w[:, C + 3:]
         wx = (wx * sc[:, None] if sc is not None else wx).contiguous()
-        hit = (key, (wf.contiguous(), wc.contiguous() if Cc else None, wx))
+        # parameter-only terms of the plane route's bound, as Python floats (one sync per parameter version)
+        wxr = float(wx.abs().sum(dim=1).max())
+        shmax = float(sh.abs().max()) if sh is not None else 0.0
+        hit = (key, (wf.contiguous(), wc.contiguous() if Cc else None, wx, wxr, shmax))
         conv.__dict__["_l3d_factored"] = hit
-    wf, wc, wx = hit[1]
+    wf, wc, wx, wxr, shmax = hit[1]
     B, N, _ = src_xyz_t.shape
     S, K = idx.shape[1], idx.shape[2]
     # the per-point products are ordinary 1x1 convs (K times fewer rows than the grouped layer); channel-last for the gather
@@ -109,14 +114,16 @@ def _factored_first_layer(src_xyz_t, centre_xyz_t, src_feat, centre_feat, idx, o
     shp = sh if (V is None and sh is not None) else None
     sx, cx = src_xyz_t.contiguous(), centre_xyz_t.contiguous()
     if planes:
-        # |output| <= max|U| + max|V| (or max|shift|) + max_r sum_d |wx_rd| * (max|src coordinate| + max|centre coordinate|)
-        bound = U.abs().max() + (V.abs().max() if V is not None else (shp.abs().max() if shp is not None else 0.0)) \
-            + wx.abs().sum(dim=1).max() * (sx.abs().max() + cx.abs().max())
-        bound = bound.reshape(1).float()
+        # |output| <= max|U| + max|V| (or max|shift|) + max_r sum_d |wx_rd| * (max|src coordinate| + max|centre coordinate|): the four
+        # data maxima in ONE launch (block maxima; the layer's kernel finishes the reduction and forms the bound itself)
+        part = torch.empty(256, dtype=torch.float32, device=U.device)
+        check(lib().l3d_absmax4_partials(ptr(U), U.numel(), ptr(V), V.numel() if V is not None else 0, ptr(sx), sx.numel(),
+                                         ptr(cx), cx.numel(), ptr(part), stream_ptr()), "l3d_absmax4_partials")
         img = torch.empty(lib().l3d_f16_act_bytes(B * S * K, C1), dtype=torch.uint8, device=U.device)
-        check(lib().l3d_group_first_layer_planes(ptr(U), ptr(V), ptr(shp), ptr(wx), ptr(sx), ptr(cx), ptr(idx.contiguous()),
-                                                 B, N, S, K, C1, 1, ptr(bound), ptr(img), ptr(_fused.range_flag(U.device)),
-                                                 stream_ptr()), "l3d_group_first_layer_planes")
+        check(lib().l3d_group_first_layer_planes_auto(ptr(U), ptr(V), ptr(shp), ptr(wx), ptr(sx), ptr(cx), ptr(idx.contiguous()),
+                                                      B, N, S, K, C1, 1, ptr(part), wxr, shmax if V is None else 0.0, ptr(img),
+                                                      ptr(_fused.range_flag(U.device)), stream_ptr()),
+              "l3d_group_first_layer_planes_auto")
         return img
     out = torch.empty((B, S * K, C1), dtype=torch.float32, device=U.device)
     check(lib().l3d_group_first_layer(ptr(U), ptr(V), ptr(shp), ptr(wx), ptr(sx), ptr(cx), ptr(idx.contiguous()),
