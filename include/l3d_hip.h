@@ -594,6 +594,18 @@ int l3d_bn_act_backward(const float *dy, const float *z, const float *scale, con
 /* tot[j] = part[0][j] + part[1][j] + ... + part[B-1][j]: per-cloud fp64 partials [B][M] added left to right, i.e. in
  * global cloud order whatever B's factorisation into ranks was. */
 int l3d_sum_clouds_f64(const double *part, int B, long M, double *tot, l3d_stream_t stream);
+/* Per-channel finalisation of a layer's statistics in ONE launch each way (models/_train.py did it with ~25 + ~8 scalar-sized torch
+ * operations per layer).  Forward, mode 0 = train-mode BatchNorm from the per-cloud sums part [B][C][2] of the conv output without
+ * its bias (clouds added in cloud order, fp64), running statistics updated as torch.nn.BatchNorm does when given; 1 = eval-mode
+ * BatchNorm (running statistics); 2 = no BatchNorm.  -> mean64, rstd64, gr64 = gamma rstd (fp64), scale, shift (fp32):
+ * y = act(z scale + shift).  Backward: per-cloud (sum g, sum g zhat) of this rank (part_local) and of all ranks (part_all, NULL =
+ * the same) -> the batch means m1, m2 (zeros without batch statistics) and this shard's dbias / dgamma / dbeta (each may be NULL). */
+int l3d_bn_finalize(const double *part, int B, int C, double n, const float *bias, const float *gamma, const float *beta, double eps,
+                    int mode, double momentum, float *running_mean, float *running_var, double *mean64, double *rstd64,
+                    double *gr64, float *scale, float *shift, l3d_stream_t stream);
+int l3d_bn_backward_finalize(const double *part_local, int Bl, const double *part_all, int Ba, int C, double n, int batch_stats,
+                             const double *gr64, double *m1, double *m2, float *dbias, float *dgamma, float *dbeta,
+                             l3d_stream_t stream);
 /* Max over the last, contiguous axis with its arg-max and the backward of it (the max over the k neighbours behind every
  * EdgeConv layer of a training step, models/dgcnn.py:36-46): v [R] = max_k x [R][K], idx [R] = the FIRST k that attains it
  * (torch's rule; one byte, K <= 256); gx [R][K] = g [R] at idx [R] and zero elsewhere, one dense pass. */

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libl3d_hip.so")
 _lib = None
 
-_P, _I, _F, _SZ, _L = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long
+_P, _I, _F, _SZ, _L, _D = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long, C.c_double
 
 # name -> argtypes (restype is int unless listed in _RESTYPE)
 SIGNATURES = {
@@ -76,6 +76,8 @@ SIGNATURES = {
     "l3d_layernorm_planes": [_P, _P, _P, _F, _L, _I, _P, _P, _P],
     "l3d_add_transposed": [_P, _P, _I, _I, _I, _P, _P],
     "l3d_max_last": [_P, _L, _I, _P, _P, _P],
+    "l3d_bn_finalize": [_P, _I, _I, _D, _P, _P, _P, _D, _I, _D, _P, _P, _P, _P, _P, _P, _P, _P],
+    "l3d_bn_backward_finalize": [_P, _I, _P, _I, _I, _D, _I, _P, _P, _P, _P, _P, _P, _P],
     "l3d_max_last_backward": [_P, _P, _L, _I, _P, _P],
     "l3d_linear_rows": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "l3d_layernorm_planes_cf": [_P, _P, _P, _F, _I, _I, _I, _P, _P, _P],

@@ -244,3 +244,103 @@ extern "C" int l3d_max_last_backward(const float *g, const unsigned char *idx, l
                            K, gx);
     return l3d_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Per-channel finalisation of a layer's statistics, forward and backward, one launch each: what models/_train.py did with
+// ~25 (forward) and ~8 (backward) scalar-sized torch operations per layer -- a FlowNet3D training step has 35 such layers and
+// spent a fifth of its launches on them.  Everything in fp64, clouds added in cloud order (as l3d_sum_clouds_f64: the same bits
+// for any sharding of the batch).
+//   mode 0  train-mode BatchNorm: mean / biased variance from part [B][C][2] = per-cloud (sum z, sum z^2) of the conv output
+//           WITHOUT its bias; running statistics updated as torch.nn.BatchNorm does (mean of z + bias, unbiased variance,
+//           momentum `mom`) when running_mean is given;
+//   mode 1  eval-mode BatchNorm: the running statistics (in z-space the mean is running_mean - bias);
+//   mode 2  no BatchNorm: y = act(z + bias).
+// Outputs: mean64, rstd64, gr64 = gamma rstd (fp64, the backward's per-channel constants), scale = (float)gr,
+// shift = (float)(beta - mean gr): y = act(z scale + shift).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double *__restrict__ part, int B, int C, double n, const float *__restrict__ bias,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta, double eps,
+                                                          int mode, double mom, float *__restrict__ running_mean,
+                                                          float *__restrict__ running_var, double *__restrict__ mean64,
+                                                          double *__restrict__ rstd64, double *__restrict__ gr64,
+                                                          float *__restrict__ scale, float *__restrict__ shift)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double b = bias ? (double)bias[c] : 0.0;
+    // (initialised here and overwritten by modes 0 / 1: with the three-way if / else if / else of the first version hipcc 7.2 left
+    // `mean` undefined on the mode-2 path -- the negation of b had been sunk into a block that path skips)
+    double mean = -b, rstd = 1.0;
+    if (mode == 0) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int k = 0; k < B; k++) { t0 += part[((size_t)k * C + c) * 2]; t1 += part[((size_t)k * C + c) * 2 + 1]; }
+        mean = t0 / n;
+        double var = t1 / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        if (running_mean) {
+            const double unbiased = var * (n / (n - 1.0 > 1.0 ? n - 1.0 : 1.0));
+            const float m = (float)mom, keep = (float)(1.0 - mom);
+            running_mean[c] = running_mean[c] * keep + m * (float)(mean + b);
+            running_var[c] = running_var[c] * keep + m * (float)unbiased;
+        }
+        rstd = 1.0 / sqrt(var + eps);
+    }
+    if (mode == 1) {
+        mean = (double)running_mean[c] - b;
+        rstd = 1.0 / sqrt((double)running_var[c] + eps);
+    }
+    const double g = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0, gr = g * rstd;
+    mean64[c] = mean; rstd64[c] = rstd; gr64[c] = gr;
+    scale[c] = (float)gr;
+    shift[c] = (float)(be - mean * gr);
+}
+
+extern "C" int l3d_bn_finalize(const double *part, int B, int C, double n, const float *bias, const float *gamma, const float *beta,
+                               double eps, int mode, double momentum, float *running_mean, float *running_var, double *mean64,
+                               double *rstd64, double *gr64, float *scale, float *shift, l3d_stream_t stream)
+{
+    L3D_REQUIRE(C > 0 && mean64 && rstd64 && gr64 && scale && shift && mode >= 0 && mode <= 2);
+    L3D_REQUIRE(mode != 0 || (part && B > 0 && n > 0.0));
+    L3D_REQUIRE(mode != 1 || (running_mean && running_var));
+    L3D_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)l3d_divup(C, 256)), dim3(256), 0, (hipStream_t)stream, part, B, C, n, bias, gamma,
+                       beta, eps, mode, momentum, running_mean, running_var, mean64, rstd64, gr64, scale, shift);
+    return l3d_check_launch();
+}
+
+// backward: part_local [Bl][C][2] = this rank's per-cloud (sum g, sum g zhat), part_all [Ba][C][2] = every rank's (or NULL: the
+// local ones) ->  m1, m2 = the batch means the BatchNorm backward subtracts (zeros without batch statistics), and the
+// parameter gradients of THIS rank's shard: dbeta = sum g, dgamma = sum g zhat, dbias = 0 with batch statistics (a bias in front
+// of BatchNorm cancels) else gr * sum g.
+__global__ __launch_bounds__(256) void bn_backward_finalize_kernel(const double *__restrict__ part_local, int Bl,
+                                                                   const double *__restrict__ part_all, int Ba, int C, double n,
+                                                                   int batch_stats, const double *__restrict__ gr64,
+                                                                   double *__restrict__ m1, double *__restrict__ m2,
+                                                                   float *__restrict__ dbias, float *__restrict__ dgamma,
+                                                                   float *__restrict__ dbeta)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double l0 = 0.0, l1 = 0.0;
+    for (int k = 0; k < Bl; k++) { l0 += part_local[((size_t)k * C + c) * 2]; l1 += part_local[((size_t)k * C + c) * 2 + 1]; }
+    double t0 = l0, t1 = l1;
+    if (part_all) {
+        t0 = t1 = 0.0;
+        for (int k = 0; k < Ba; k++) { t0 += part_all[((size_t)k * C + c) * 2]; t1 += part_all[((size_t)k * C + c) * 2 + 1]; }
+    }
+    m1[c] = batch_stats ? t0 / n : 0.0;
+    m2[c] = batch_stats ? t1 / n : 0.0;
+    if (dbias) dbias[c] = batch_stats ? 0.f : (float)(gr64[c] * l0);
+    if (dgamma) dgamma[c] = (float)l1;
+    if (dbeta) dbeta[c] = (float)l0;
+}
+
+extern "C" int l3d_bn_backward_finalize(const double *part_local, int Bl, const double *part_all, int Ba, int C, double n,
+                                        int batch_stats, const double *gr64, double *m1, double *m2, float *dbias, float *dgamma,
+                                        float *dbeta, l3d_stream_t stream)
+{
+    L3D_REQUIRE(part_local && Bl > 0 && C > 0 && gr64 && m1 && m2 && (!part_all || Ba > 0) && (!batch_stats || n > 0.0));
+    hipLaunchKernelGGL(bn_backward_finalize_kernel, dim3((unsigned)l3d_divup(C, 256)), dim3(256), 0, (hipStream_t)stream, part_local, Bl,
+                       part_all, Ba, C, n, batch_stats, gr64, m1, m2, dbias, dgamma, dbeta);
+    return l3d_check_launch();
+}

@@ -104,37 +104,36 @@ class _ConvAffineAct(torch.autograd.Function):
         Cout = w.shape[0]
         dev = x.device
         z = _fused.pointwise_conv(x, w)                                  # HIP GEMM, no epilogue
-        b64 = bias.detach().double() if bias is not None else None
         n = float(B) * float(P)
+        # per-channel constants in ONE launch (l3d_bn_finalize): mean / rstd of the batch (clouds added in cloud order, fp64) or the
+        # running statistics or none, the running-statistic update of train mode, gr = gamma rstd, and the fp32 scale / shift
+        bias_f = f32c(bias.detach()) if bias is not None else None
+        gamma_f = f32c(gamma.detach()) if gamma is not None else None
+        beta_f = f32c(beta.detach()) if beta is not None else None
+        mean64 = torch.empty(Cout, dtype=torch.float64, device=dev)
+        rstd64, gr64 = torch.empty_like(mean64), torch.empty_like(mean64)
+        scale = torch.empty(Cout, dtype=torch.float32, device=dev)
+        shift = torch.empty_like(scale)
+        part_ptr, nb, mode, mom, rm, rv = None, 0, 2, 0.0, None, None
+        eps = float(bn.eps) if bn is not None else 0.0
         if bn is not None and batch_stats:
             part = channel_stats(z)
-            pg = gather_cloud_partials(part) if sync else part
-            mean64, var64, n, _ = stats_from_partials(pg, P)             # of z; the layer's bias shifts the mean only
-            with torch.no_grad():                                        # running statistics, as torch.nn.BatchNorm in train mode
-                if bn.track_running_stats and bn.running_mean is not None:
+            pg = (gather_cloud_partials(part) if sync else part).contiguous()
+            nb, n, mode, part_ptr = pg.shape[0], float(pg.shape[0]) * float(P), 0, ptr(pg)
+            if bn.track_running_stats and bn.running_mean is not None:
+                if bn.running_mean.dtype != torch.float32 or not bn.running_mean.is_contiguous():
+                    raise TypeError("the HIP BatchNorm layer updates fp32 running statistics")
+                with torch.no_grad():
                     bn.num_batches_tracked += 1
-                    m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                    unbiased = var64 * (n / max(n - 1.0, 1.0))
-                    mean_in = mean64 + b64 if b64 is not None else mean64
-                    bn.running_mean.mul_(1 - m).add_(mean_in.to(bn.running_mean.dtype), alpha=m)
-                    bn.running_var.mul_(1 - m).add_(unbiased.to(bn.running_var.dtype), alpha=m)
-            rstd64 = torch.rsqrt(var64 + bn.eps)
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                rm, rv = bn.running_mean, bn.running_var
         elif bn is not None:
-            mean64 = bn.running_mean.detach().double()                   # of (z + bias): in z-space the mean is rm - bias
-            if b64 is not None:
-                mean64 = mean64 - b64
-            rstd64 = torch.rsqrt(bn.running_var.detach().double() + bn.eps)
-        else:
-            mean64 = -b64 if b64 is not None else torch.zeros(Cout, dtype=torch.float64, device=dev)
-            rstd64 = torch.ones(Cout, dtype=torch.float64, device=dev)
-        g64 = gamma.detach().double() if gamma is not None else torch.ones(Cout, dtype=torch.float64, device=dev)
-        be64 = beta.detach().double() if beta is not None else torch.zeros(Cout, dtype=torch.float64, device=dev)
-        gr64 = (g64 * rstd64).contiguous()
-        scale = gr64.float().contiguous()
-        shift = (be64 - mean64 * gr64).float().contiguous()
+            mode, rm, rv = 1, f32c(bn.running_mean.detach()), f32c(bn.running_var.detach())
+        check(lib().l3d_bn_finalize(part_ptr, nb, Cout, n, ptr(bias_f), ptr(gamma_f), ptr(beta_f), eps, mode, float(mom), ptr(rm), ptr(rv),
+                                    ptr(mean64), ptr(rstd64), ptr(gr64), ptr(scale), ptr(shift), stream_ptr()), "l3d_bn_finalize")
         y = torch.empty_like(z)
         check(lib().l3d_bn_act_forward(ptr(z), ptr(scale), ptr(shift), B, Cout, P, int(relu), ptr(y), stream_ptr()), "l3d_bn_act_forward")
-        ctx.save_for_backward(x, w, z, scale, shift, mean64.contiguous(), rstd64.contiguous(), gr64)
+        ctx.save_for_backward(x, w, z, scale, shift, mean64, rstd64, gr64)
         ctx.relu, ctx.sync, ctx.n, ctx.wshape = relu, sync, n, weight.shape
         ctx.batch_stats, ctx.has_bn = bool(bn is not None and batch_stats), bn is not None
         return y
@@ -147,28 +146,24 @@ class _ConvAffineAct(torch.autograd.Function):
         part = torch.empty((B, Cout, 2), dtype=torch.float64, device=z.device)
         check(lib().l3d_bn_backward_stats(ptr(dy), ptr(z), ptr(scale), ptr(shift), ptr(mean64), ptr(rstd64), B, Cout, P, int(ctx.relu),
                                           ptr(part), stream_ptr()), "l3d_bn_backward_stats")
-        local = sum_clouds(part)                                         # this rank's (sum g, sum g zhat): the parameter gradients
-        zero = torch.zeros(Cout, dtype=torch.float64, device=z.device)
-        if ctx.batch_stats:
-            tot = sum_clouds(gather_cloud_partials(part)) if ctx.sync else local
-            m1, m2 = (tot[:, 0] / ctx.n).contiguous(), (tot[:, 1] / ctx.n).contiguous()
-        else:
-            m1 = m2 = zero
+        # (sum g, sum g zhat) over this rank's clouds -> parameter gradients; over every rank's -> the batch means: one launch
+        pa = gather_cloud_partials(part).contiguous() if (ctx.batch_stats and ctx.sync) else None
+        m1 = torch.empty(Cout, dtype=torch.float64, device=z.device)
+        m2 = torch.empty_like(m1)
+        dbias = torch.empty(Cout, dtype=torch.float32, device=z.device) if ctx.needs_input_grad[2] else None
+        dgamma = torch.empty(Cout, dtype=torch.float32, device=z.device) if (ctx.has_bn and ctx.needs_input_grad[3]) else None
+        dbeta = torch.empty(Cout, dtype=torch.float32, device=z.device) if (ctx.has_bn and ctx.needs_input_grad[4]) else None
+        check(lib().l3d_bn_backward_finalize(ptr(part), B, ptr(pa), pa.shape[0] if pa is not None else 0, Cout, float(ctx.n),
+                                             int(ctx.batch_stats), ptr(gr64), ptr(m1), ptr(m2), ptr(dbias), ptr(dgamma), ptr(dbeta),
+                                             stream_ptr()), "l3d_bn_backward_finalize")
         dz = torch.empty_like(z)
         check(lib().l3d_bn_act_backward(ptr(dy), ptr(z), ptr(scale), ptr(shift), ptr(mean64), ptr(rstd64), ptr(gr64), ptr(m1), ptr(m2),
                                         B, Cout, P, int(ctx.relu), ptr(dz), stream_ptr()), "l3d_bn_act_backward")
-        dx = dw = dbias = dgamma = dbeta = None
+        dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = _fused.pointwise_conv(dz, w.t().contiguous())           # dgrad: [B, Cin, P]
         if ctx.needs_input_grad[1]:
             dw = wgrad(dz, x).reshape(ctx.wshape)
-        if ctx.needs_input_grad[2]:
-            # batch statistics: a bias in front of BatchNorm cancels; else d/dbias = sum_p dz = gr * sum g
-            dbias = torch.zeros(Cout, dtype=torch.float32, device=z.device) if ctx.batch_stats else (gr64 * local[:, 0]).float()
-        if ctx.has_bn and ctx.needs_input_grad[3]:
-            dgamma = local[:, 1].float()
-        if ctx.has_bn and ctx.needs_input_grad[4]:
-            dbeta = local[:, 0].float()
         return dx, dw, dbias, dgamma, dbeta, None, None, None, None
 
 
