@@ -92,6 +92,74 @@ with torch.no_grad():
         for b in range(B):
             np.add.at(ref[b], (slice(None), idx[b]), src[b].astype(np.float64))
         rec("scatter_add_det vs fp64", got, ref, 1e-5, 2e-5)
+# ---- round 3's kernels ------------------------------------------------------------------------------------------------------
+with torch.no_grad():
+    from learning3d_amd.models import _train
+    for it in range(10):                                            # Chamfer backward: sorted selection list == scan, bit for bit
+        B = int(rng.integers(1, 4)); N = int(rng.integers(1, 3000)); M = int(rng.integers(1, 3000))
+        a = dev(rng.uniform(0, 1, (B, N, 3)).astype(np.float32)); b_ = dev(np.round(rng.uniform(0, 1, (B, M, 3)) * 6).astype(np.float32) / 6)
+        d1 = torch.empty(B, N, device="cuda"); d2 = torch.empty(B, M, device="cuda")
+        i1 = torch.empty(B, N, dtype=torch.int32, device="cuda"); i2 = torch.empty(B, M, dtype=torch.int32, device="cuda")
+        check(lib().l3d_chamfer_forward(ptr(a), ptr(b_), B, N, M, ptr(d1), ptr(d2), ptr(i1), ptr(i2), stream_ptr()), "cd")
+        g1 = dev(rng.standard_normal((B, N)).astype(np.float32)); g2 = dev(rng.standard_normal((B, M)).astype(np.float32))
+        outs = []
+        for v_ in (0, 2):
+            x1 = torch.full((B, N, 3), float("nan"), device="cuda"); x2 = torch.full((B, M, 3), float("nan"), device="cuda")
+            check(lib().l3d_chamfer_backward_variant(ptr(a), ptr(b_), B, N, M, ptr(g1), ptr(g2), ptr(i1), ptr(i2), ptr(x1), ptr(x2), v_,
+                                                     stream_ptr()), "cd bwd")
+            outs.append((x1.cpu().numpy(), x2.cpu().numpy()))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), ("chamfer bwd", B, N, M)
+    worst["chamfer bwd sorted == scan"] = 0.0
+    for it in range(10):                                            # max over the last axis (+ backward) == torch
+        shape = tuple(int(v) for v in rng.integers(1, 40, int(rng.integers(1, 4)))) + (int(rng.integers(1, 257)),)
+        x = torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).cuda().relu()
+        with torch.enable_grad():
+            a_, b_ = x.clone().requires_grad_(), x.clone().requires_grad_()
+            va = _train.max_over_last(a_); vb = b_.max(dim=-1, keepdim=True)[0]
+            w_ = torch.randn_like(va)
+            (va * w_).sum().backward(); (vb * w_).sum().backward()
+        assert torch.equal(va, vb) and torch.equal(a_.grad, b_.grad), ("max_last", shape)
+    worst["max_last == torch.max"] = 0.0
+    for it in range(8):                                             # linear over a handful of rows vs fp64
+        R = int(rng.integers(1, 300)); Cin = 256 * int(rng.integers(1, 5)); Cout = int(rng.integers(1, 700))
+        lin = torch.nn.Linear(Cin, Cout).cuda()
+        x = dev(rng.standard_normal((R, Cin)).astype(np.float32))
+        want = (x.double() @ lin.weight.double().t() + lin.bias.double()).clamp_min(0).cpu().numpy()
+        rec("linear_rows vs fp64", _fused.linear_rows(x, lin, True).cpu().numpy(), want, 1e-5, 1e-5 * max(1.0, float(np.abs(want).max())))
+    for it in range(8):                                             # channel-first LayerNorm vs fp64; residual epilogue == conv + add
+        B = int(rng.integers(1, 4)); C = int(rng.choice([128, 256, 512])); N = int(rng.integers(1, 700))
+        x = (rng.standard_normal((B, C, N)) * rng.uniform(0.01, 30.0) + rng.uniform(-5, 5)).astype(np.float32)
+        a = rng.uniform(0.5, 1.5, C).astype(np.float32); b_ = rng.uniform(-0.5, 0.5, C).astype(np.float32)
+        x64 = x.astype(np.float64)
+        want = a[None, :, None] * (x64 - x64.mean(1, keepdims=True)) / (x64.std(1, ddof=1, keepdims=True) + 1e-6) + b_[None, :, None]
+        tx, ta, tb = dev(x), dev(a), dev(b_)
+        y = torch.empty((B, C, N), device="cuda")
+        check(lib().l3d_layernorm_planes_cf(ptr(tx), ptr(ta), ptr(tb), 1e-6, B, C, N, ptr(y), None, stream_ptr()), "ln cf")
+        rec("layernorm cf vs fp64", y.cpu().numpy(), want, 2e-6, 4e-6)
+        C1 = 256 * int(rng.integers(1, 3)); N2 = 256 * int(rng.integers(1, 4)); C0 = 16 * int(rng.integers(2, 30))
+        xr = rng.standard_normal((B, N2, C0)).astype(np.float32)
+        ximg = _fused.split_rows_f16(dev(xr)); wimg = _fused.split_weights_f16(dev((rng.standard_normal((C1, C0)) / math.sqrt(C0)).astype(np.float32)))
+        res = dev(rng.standard_normal((B, C1, N2)).astype(np.float32)); sh = dev(rng.standard_normal(C1).astype(np.float32))
+        plain = _fused.pointwise_conv_f16(ximg, B, N2, wimg, C0, C1, None, sh)
+        assert torch.equal(_fused.pointwise_conv_f16(ximg, B, N2, wimg, C0, C1, None, sh, residual=res), res + plain), ("residual", B, C0, C1, N2)
+    worst["conv residual == conv + add"] = 0.0
+    net1k = DGCNN(emb_dims=1024).cuda().eval()
+    for it in range(8):                                             # EdgeConv: the two-plane persistent kernel vs the fp32-MFMA one; kNN kernels agree
+        B = int(rng.integers(1, 5)); N = int(rng.integers(21, 1300)); k = 20
+        x = dev(rng.uniform(0, 1, (B, N, 3)).astype(np.float32))
+        idx = U.knn(x.permute(0, 2, 1), k)
+        packed = net1k._packed.get([net1k.conv1, net1k.conv2, net1k.conv3, net1k.conv4], [net1k.bn1, net1k.bn2, net1k.bn3, net1k.bn4], x.device)
+        ref = _fused.edgeconv_forward(x, idx, packed, kernel="chained").cpu().numpy()
+        got = _fused.edgeconv_forward(x, idx, packed, kernel="f16", v2=net1k._packed.v2_ok).cpu().numpy()
+        rec("edgeconv f16b vs fp32 MFMA", got, ref, 1e-5, 2e-5 * float(np.abs(ref).max()))
+        i0 = torch.empty((B, N, k), dtype=torch.int64, device="cuda"); i1_ = torch.empty_like(i0)
+        xc = x.contiguous()
+        if lib().l3d_knn_graph_variant(ptr(xc), B, N, k, ptr(i1_), 2, stream_ptr()) == 0:
+            check(lib().l3d_knn_graph_variant(ptr(xc), B, N, k, ptr(i0), 1, stream_ptr()), "knn")
+            d0 = (xc[:, :, None, :] - torch.gather(xc[:, None].expand(B, N, N, 3), 2, i0[..., None].expand(B, N, k, 3))).square().sum(-1)
+            d1_ = (xc[:, :, None, :] - torch.gather(xc[:, None].expand(B, N, N, 3), 2, i1_[..., None].expand(B, N, k, 3))).square().sum(-1)
+            assert torch.equal(i0, i1_) or torch.allclose(d0, d1_, rtol=0, atol=1e-6), ("knn mfma vs insertion", B, N)
+    _fused.check_range(sync=True)
 for k_, v_ in worst.items():
     print(f"{k_:28s} worst (|err| - rtol|want|) = {v_:.3e}")
 print("fuzz OK")
