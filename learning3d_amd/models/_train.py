@@ -103,7 +103,14 @@ class _ConvAffineAct(torch.autograd.Function):
         w = f32c(weight.reshape(weight.shape[0], -1))
         Cout = w.shape[0]
         dev = x.device
-        z = _fused.pointwise_conv(x, w)                                  # HIP GEMM, no epilogue
+        if bn is None:
+            # no BatchNorm: bias and activation ride in the GEMM's epilogue; what is kept for the backward is y itself -- the
+            # activation's derivative only needs the sign of the pre-activation, which y has (ReLU and LeakyReLU alike) -- so the
+            # layer costs no elementwise forward pass and no second [B,Cout,P] tensor (PCN: 1.5 ms of a 22 ms training step)
+            z = _fused.pointwise_conv(x, w, None, f32c(bias.detach()) if bias is not None else None, relu=relu)
+            bias = None                                                  # the constants below describe y -> y: scale 1, shift 0
+        else:
+            z = _fused.pointwise_conv(x, w)                              # HIP GEMM, no epilogue
         n = float(B) * float(P)
         # per-channel constants in ONE launch (l3d_bn_finalize): mean / rstd of the batch (clouds added in cloud order, fp64) or the
         # running statistics or none, the running-statistic update of train mode, gr = gamma rstd, and the fp32 scale / shift
@@ -131,8 +138,11 @@ class _ConvAffineAct(torch.autograd.Function):
             mode, rm, rv = 1, f32c(bn.running_mean.detach()), f32c(bn.running_var.detach())
         check(lib().l3d_bn_finalize(part_ptr, nb, Cout, n, ptr(bias_f), ptr(gamma_f), ptr(beta_f), eps, mode, float(mom), ptr(rm), ptr(rv),
                                     ptr(mean64), ptr(rstd64), ptr(gr64), ptr(scale), ptr(shift), stream_ptr()), "l3d_bn_finalize")
-        y = torch.empty_like(z)
-        check(lib().l3d_bn_act_forward(ptr(z), ptr(scale), ptr(shift), B, Cout, P, int(relu), ptr(y), stream_ptr()), "l3d_bn_act_forward")
+        if bn is None:
+            y = z
+        else:
+            y = torch.empty_like(z)
+            check(lib().l3d_bn_act_forward(ptr(z), ptr(scale), ptr(shift), B, Cout, P, int(relu), ptr(y), stream_ptr()), "l3d_bn_act_forward")
         ctx.save_for_backward(x, w, z, scale, shift, mean64, rstd64, gr64)
         ctx.relu, ctx.sync, ctx.n, ctx.wshape = relu, sync, n, weight.shape
         ctx.batch_stats, ctx.has_bn = bool(bn is not None and batch_stats), bn is not None
