@@ -324,7 +324,7 @@ def main_c5(args, rank, world, local, dev, dist, parallel):
     t0 = time.perf_counter()
     digest = None
     for i in range(args.steps):
-        sampled = i % stride == 0
+        sampled = i % stride == stride // 2           # mid-stride: the eager step's host work hides behind queued replays
         timer.enabled = sampled
         _, digest = step(eager=sampled)
     sync()
@@ -579,14 +579,16 @@ def main():
     def timed(sync_loss, timer=None):
         """K steps between two (barrier + device sync) brackets; returns (this rank's seconds, last loss)."""
         # steps that carry the live kernel-timing events are issued eagerly (~0.2 ms of extra host time each): at most 8
-        # per run and at most one in twenty, so a 20-step run has 1
+        # per run and at most one in twenty, so a 20-step run has 1 -- in the MIDDLE of its stride, where the host is several
+        # queued replays ahead of the GPU and the eager step's launch work hides behind them (as the first step after the
+        # opening synchronize it stood in the open: 2-3 % of a 20-step run)
         nsamp = max(1, min(8, args.steps // 20))
         stride = max(1, -(-args.steps // nsamp))
         sync()
         t0 = time.perf_counter()
         loss = None
         for i in range(args.steps):
-            sampled = timer is not None and i % stride == 0
+            sampled = timer is not None and i % stride == stride // 2
             if timer is not None:
                 timer.enabled = sampled
             _, loss = step(sync_loss, eager=sampled)
