@@ -1129,6 +1129,27 @@ def test_transformer_fast_linear_path_matches_torch_path():
         np.testing.assert_allclose(g_.cpu().numpy(), w_.numpy(), rtol=1e-4, atol=1e-5)
 
 
+def test_plane_output_bound_cache_follows_parameter_updates():
+    """_fused._plane_obs caches {max|shift|, max|scale|} per (tensor, version): an in-place parameter update (an optimizer step)
+    must be seen -- a stale bound would place the output planes for the OLD magnitudes (overflow or lost precision)."""
+    from learning3d_amd.models import _fused
+    rng = np.random.default_rng(5)
+    B, N, C0, C1 = 1, 256, 64, 256
+    x = rng.standard_normal((B, N, C0)).astype(np.float32)
+    w = (rng.standard_normal((C1, C0)) / C0 ** 0.5).astype(np.float32)
+    ximg = _fused.split_rows_f16(dev(x)); wimg = _fused.split_weights_f16(dev(w))
+    shift = dev(rng.standard_normal(C1).astype(np.float32))
+    w2 = (rng.standard_normal((C1, C1)) / C1 ** 0.5).astype(np.float32); w2img = _fused.split_weights_f16(dev(w2))
+    for scale_up in (1.0, 3000.0, 1e-3):
+        shift.mul_(scale_up)                                           # in place: same storage, new version
+        img = _fused.pointwise_conv_f16(ximg, B, N, wimg, C0, C1, None, shift, relu=True, out_planes=True)
+        y = _fused.pointwise_conv_f16(img, B, N, w2img, C1, C1, None, None)
+        h = np.maximum(x.astype(np.float64) @ w.astype(np.float64).T + shift.cpu().numpy().astype(np.float64), 0)
+        want = (h @ w2.astype(np.float64).T).transpose(0, 2, 1)
+        assert np.abs(y.cpu().numpy() - want).max() <= 2e-5 * np.abs(want).max(), scale_up
+    _fused.check_range(sync=True)
+
+
 def test_linear_rows_kernel():
     """l3d_linear_rows (PCN's fully connected decoder, models/pcn.py:132-137: a Linear over as many rows as there are clouds)
     against fp64: ragged row counts, Cout not a multiple of the workgroup's 16 channels, with and without bias / ReLU."""
