@@ -15,6 +15,13 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
 WORKER = r'''
 import os, sys
 sys.path.insert(0, sys.argv[1])
@@ -53,7 +60,7 @@ print("RCCL_ONE_RANK_OK", got_sync, want)
 def test_collectives_run_over_rccl_with_one_rank(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
                L3D_INIT_SINGLE_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = p.stdout.decode()
@@ -66,7 +73,7 @@ def test_bench_multi_rank_path_over_rccl_one_rank(workload):
     the replayed step (a copy of the graph's partials buffer handed to the asynchronous all_gather), both exchange modes timed,
     per-rank times gathered -- executed on a one-rank nccl group (L3D_INIT_SINGLE_RANK=1)."""
     import json
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543" if workload == "c2" else "29545", WORLD_SIZE="1", RANK="0",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE="1", RANK="0",
                LOCAL_RANK="0", L3D_INIT_SINGLE_RANK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
            "--workload", workload]

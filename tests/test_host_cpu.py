@@ -144,9 +144,13 @@ dist.barrier(); dist.destroy_process_group()
 def test_two_rank_gloo_chamfer_allgather(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    import socket
+    with socket.socket() as sk:                              # a free rendezvous port, not a fixed one
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)]
+           "--master-addr", "127.0.0.1", "--master-port", port, str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("OK") == 2
