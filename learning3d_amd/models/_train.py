@@ -9,10 +9,13 @@ examples/train_pcn.py:70-91; the only multi-GPU hook the reference has is nn.Dat
   forward   z = W x              HIP GEMM (pointwise_conv: bf16x3 / fp32 MFMA by shape, _fused.py)
             batch statistics:    per-cloud (sum z, sum z^2) fp64              l3d_channel_stats
                                  [all_gather of the partials across ranks]    torch.distributed (RCCL on GPUs, gloo in the CPU test)
-                                 added in GLOBAL cloud order -> mean, var     l3d_sum_clouds_f64: same bits whatever the rank count
-            running statistics / no BatchNorm: the layer is the affine map y = scale z + shift
+                                 added in GLOBAL cloud order -> mean, var,    l3d_bn_finalize (one launch: also the running-statistic
+                                 scale / shift, fp64 backward constants        update): same bits whatever the rank count
+            running statistics: the layer is the affine map y = scale z + shift (same kernel, mode 1)
             y = relu(z scale + shift)                                         l3d_bn_act_forward
+            no BatchNorm: bias and activation in the GEMM's epilogue; y itself is what the backward keeps
   backward  per-cloud (sum g, sum g zhat) fp64                                l3d_bn_backward_stats  [+ all_gather], as SyncBatchNorm
+            batch means m1, m2 and dbias / dgamma / dbeta                     l3d_bn_backward_finalize (one launch)
             dz = gr (g - m1 - zhat m2), evaluated in fp64                     l3d_bn_act_backward    (m1 = m2 = 0 without batch statistics)
             dx = W^T dz   (dgrad)                                             HIP GEMM (pointwise_conv with the transposed weight)
             dW = sum_b sum_p dz x^T   (wgrad)                                 l3d_wgrad: split-K on the fp32 MFMA, pieces added in fp64, no atomics
