@@ -525,6 +525,9 @@ __device__ __forceinline__ void ef_gather_xyz(EfGather<MT> &G, int N, const floa
     }
 }
 
+#ifdef EF_WGSPAN
+__device__ long long *g_ef_span;
+#endif
 template <int MT, bool PLANES>
 __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xyz,
                                                               const int64_t *__restrict__ idx, int B, int N, int k,
@@ -541,6 +544,14 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
 #define EF_T(i) tk[i] = __builtin_amdgcn_s_memtime()
 #else
 #define EF_T(i)
+#endif
+#ifdef EF_WGSPAN      // tools/probe_ef_span.hip: when does every persistent workgroup start and end (s_memrealtime, 100 MHz), and where
+    if (threadIdx.x == 0) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        g_ef_span[(size_t)blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime();
+        g_ef_span[(size_t)blockIdx.x * 4 + 2] = id;
+    }
 #endif
     EF_T(0);
     constexpr int CTOT = EC_C1 + EC_C2 + EC_C3 + EC_C4;
@@ -681,6 +692,10 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
     // pooled planes when PLANES; activations are post-ReLU, so the pooled maxima are the maxima.  Not taken while the
     // activations stay within 16x of the magnitude the packer was told; the host re-runs on the bf16x3 kernel if it is.
     if (!(ovf <= 60000.f) && range_flag) *(volatile int *)range_flag = 1; // may live in mapped host memory: plain store
+#ifdef EF_WGSPAN
+    __syncthreads();
+    if (threadIdx.x == 0) g_ef_span[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef EF_TIMING
     if (threadIdx.x == 0)
         for (int i = 0; i < 6; i++) tdbg[(size_t)blockIdx.x * 6 + i] = tk[i];
