@@ -680,7 +680,7 @@ def main():
         ch_gbs = B_PER_GPU * CHAMFER_BYTES_PER_CLOUD / (stage_ms["chamfer"] * 1e-3) / 1e9
         c5_tf = B_PER_GPU * CONV5_FLOP_PER_CLOUD / (stage_ms["conv5"] * 1e-3) / 1e12
         arith = _fused.gemm_arith()
-        dtype = {"f16x2": "f32 (shared-MLP GEMMs as f16x2: fp32 operands carried as an fp16 high part + a 2^12-scaled fp16 residual, "
+        dtype = {"f16x2": "f32 (shared-MLP GEMMs as f16x2: fp32 operands carried as an fp16 high part + an fp16 residual (unscaled between the EdgeConv kernel and conv5, 2^12-scaled elsewhere), "
                           "3 fp16 MFMA products per fp32 product, f32 accumulate, fp32-level error -- tests bound it by 2x the "
                           "fp32-MFMA kernel's own error against fp64; distances/top-k/Chamfer plain f32)",
                  "bf16x3": "f32 (shared-MLP GEMMs as bf16x3: fp32 operands split exactly into 3 bf16 planes, 6 bf16 MFMA "
