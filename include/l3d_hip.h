@@ -591,6 +591,15 @@ int l3d_bn_backward_stats(const float *dy, const float *z, const float *scale, c
 int l3d_bn_act_backward(const float *dy, const float *z, const float *scale, const float *shift, const double *mean,
                         const double *rstd, const double *gr, const double *m1, const double *m2, int B, int C, long P, int act,
                         float *dz, l3d_stream_t stream);
+/* The two backward kernels for a layer whose output y [B][C][P] is ALSO max-pooled over runs of K consecutive positions (the max
+ * over the k neighbours behind an EdgeConv layer): the gradient at y is dy (may be NULL) plus dpool [B][C][P/K] at the position
+ * pidx [B][C][P/K] names (l3d_max_last's arg-max) -- the dense scatter and the add of the two gradient tensors are never formed. */
+int l3d_bn_backward_stats_pool(const float *dy, const float *z, const float *scale, const float *shift, const double *mean,
+                               const double *rstd, int B, int C, long P, int act, double *part, const float *dpool,
+                               const unsigned char *pidx, int K, l3d_stream_t stream);
+int l3d_bn_act_backward_pool(const float *dy, const float *z, const float *scale, const float *shift, const double *mean,
+                             const double *rstd, const double *gr, const double *m1, const double *m2, int B, int C, long P, int act,
+                             float *dz, const float *dpool, const unsigned char *pidx, int K, l3d_stream_t stream);
 /* tot[j] = part[0][j] + part[1][j] + ... + part[B-1][j]: per-cloud fp64 partials [B][M] added left to right, i.e. in
  * global cloud order whatever B's factorisation into ranks was. */
 int l3d_sum_clouds_f64(const double *part, int B, long M, double *tot, l3d_stream_t stream);

@@ -113,7 +113,9 @@ SIGNATURES = {
     "l3d_channel_stats": [_P, _I, _I, _L, _P, _P],
     "l3d_bn_act_forward": [_P, _P, _P, _I, _I, _L, _I, _P, _P],
     "l3d_bn_backward_stats": [_P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P],
+    "l3d_bn_backward_stats_pool": [_P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P, _P, _I, _P],
     "l3d_bn_act_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P],
+    "l3d_bn_act_backward_pool": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P, _P, _I, _P],
     "l3d_sum_clouds_f64": [_P, _I, _L, _P, _P],
     "l3d_wgrad_workspace_bytes": [_I, _I, _I, _L, _I],
     "l3d_wgrad": [_P, _P, _I, _I, _I, _L, _I, _P, _P, _P],

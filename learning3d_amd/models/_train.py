@@ -100,7 +100,10 @@ class _ConvAffineAct(torch.autograd.Function):
     statistics (train mode), else its running statistics (eval mode: an affine map)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, bn, relu, batch_stats, sync):
+    def forward(ctx, x, weight, bias, gamma, beta, bn, relu, batch_stats, sync, pool):
+        """pool = K > 0: the layer's output is also max-pooled over runs of K consecutive positions (an EdgeConv layer: P = N K, the
+        max over the k neighbours); returns (y, ymax [B,Cout,P/K]) and the backward takes both gradients in the two kernels it
+        runs anyway -- no dense scatter of the pooled gradient, no add of two [B,Cout,P] tensors."""
         x = f32c(x)                                                      # [B, Cin, P]
         B, Cin, P = x.shape
         w = f32c(weight.reshape(weight.shape[0], -1))
@@ -146,19 +149,39 @@ class _ConvAffineAct(torch.autograd.Function):
         else:
             y = torch.empty_like(z)
             check(lib().l3d_bn_act_forward(ptr(z), ptr(scale), ptr(shift), B, Cout, P, int(relu), ptr(y), stream_ptr()), "l3d_bn_act_forward")
-        ctx.save_for_backward(x, w, z, scale, shift, mean64, rstd64, gr64)
         ctx.relu, ctx.sync, ctx.n, ctx.wshape = relu, sync, n, weight.shape
         ctx.batch_stats, ctx.has_bn = bool(bn is not None and batch_stats), bn is not None
+        ctx.pool = int(pool)
+        if pool:
+            if P % pool or pool > 256 or P >= (1 << 23):
+                raise ValueError("pooled layer: P must be a multiple of the run length K <= 256 and below 2^23")
+            ymax = torch.empty((B, Cout, P // pool), dtype=torch.float32, device=dev)
+            pidx = torch.empty(B * Cout * (P // pool), dtype=torch.uint8, device=dev)
+            check(lib().l3d_max_last(ptr(y), pidx.numel(), int(pool), ptr(ymax), ptr(pidx), stream_ptr()), "l3d_max_last")
+            ctx.save_for_backward(x, w, z, scale, shift, mean64, rstd64, gr64, pidx)
+            return y, ymax
+        ctx.save_for_backward(x, w, z, scale, shift, mean64, rstd64, gr64)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
-        x, w, z, scale, shift, mean64, rstd64, gr64 = ctx.saved_tensors
-        dy = f32c(dy)
+    def backward(ctx, dy, dmax=None):
+        pidx = None
+        if ctx.pool:
+            x, w, z, scale, shift, mean64, rstd64, gr64, pidx = ctx.saved_tensors
+            dmax = f32c(dmax) if dmax is not None else None
+            if dmax is None:
+                pidx = None
+        else:
+            x, w, z, scale, shift, mean64, rstd64, gr64 = ctx.saved_tensors
+        dy = f32c(dy) if dy is not None else None
         B, Cout, P = z.shape
+        if dy is None and dmax is None:
+            dy = torch.zeros_like(z)
+        K = ctx.pool if pidx is not None else 0
         part = torch.empty((B, Cout, 2), dtype=torch.float64, device=z.device)
-        check(lib().l3d_bn_backward_stats(ptr(dy), ptr(z), ptr(scale), ptr(shift), ptr(mean64), ptr(rstd64), B, Cout, P, int(ctx.relu),
-                                          ptr(part), stream_ptr()), "l3d_bn_backward_stats")
+        check(lib().l3d_bn_backward_stats_pool(ptr(dy), ptr(z), ptr(scale), ptr(shift), ptr(mean64), ptr(rstd64), B, Cout, P,
+                                               int(ctx.relu), ptr(part), ptr(dmax) if pidx is not None else None, ptr(pidx), K,
+                                               stream_ptr()), "l3d_bn_backward_stats")
         # (sum g, sum g zhat) over this rank's clouds -> parameter gradients; over every rank's -> the batch means: one launch
         pa = gather_cloud_partials(part).contiguous() if (ctx.batch_stats and ctx.sync) else None
         m1 = torch.empty(Cout, dtype=torch.float64, device=z.device)
@@ -170,14 +193,15 @@ class _ConvAffineAct(torch.autograd.Function):
                                              int(ctx.batch_stats), ptr(gr64), ptr(m1), ptr(m2), ptr(dbias), ptr(dgamma), ptr(dbeta),
                                              stream_ptr()), "l3d_bn_backward_finalize")
         dz = torch.empty_like(z)
-        check(lib().l3d_bn_act_backward(ptr(dy), ptr(z), ptr(scale), ptr(shift), ptr(mean64), ptr(rstd64), ptr(gr64), ptr(m1), ptr(m2),
-                                        B, Cout, P, int(ctx.relu), ptr(dz), stream_ptr()), "l3d_bn_act_backward")
+        check(lib().l3d_bn_act_backward_pool(ptr(dy), ptr(z), ptr(scale), ptr(shift), ptr(mean64), ptr(rstd64), ptr(gr64), ptr(m1), ptr(m2),
+                                             B, Cout, P, int(ctx.relu), ptr(dz), ptr(dmax) if pidx is not None else None, ptr(pidx), K,
+                                             stream_ptr()), "l3d_bn_act_backward")
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = _fused.pointwise_conv(dz, w.t().contiguous())           # dgrad: [B, Cin, P]
         if ctx.needs_input_grad[1]:
             dw = wgrad(dz, x).reshape(ctx.wshape)
-        return dx, dw, dbias, dgamma, dbeta, None, None, None, None
+        return dx, dw, dbias, dgamma, dbeta, None, None, None, None, None
 
 
 def conv_bn_act(x, conv, bn=None, relu=True, sync=None):
@@ -191,15 +215,28 @@ def conv_bn_act(x, conv, bn=None, relu=True, sync=None):
     shp = x.shape
     x3 = x.reshape(shp[0], shp[1], -1)
     y = _ConvAffineAct.apply(x3, conv.weight, conv.bias, bn.weight if bn is not None else None,
-                             bn.bias if bn is not None else None, bn, relu, batch_stats, sync and batch_stats)
+                             bn.bias if bn is not None else None, bn, relu, batch_stats, sync and batch_stats, 0)
     return y.reshape(shp[0], y.shape[1], *shp[2:])
+
+
+def conv_bn_act_max(x, conv, bn=None, relu=True, sync=None):
+    """conv_bn_act for x [B, Cin, N, K] that ALSO returns the max over K (keepdim): (y [B,Cout,N,K], ymax [B,Cout,N,1]) -- an EdgeConv
+    layer of models/dgcnn.py:34-46 (`x = relu(bn(conv(x))); x1 = x.max(dim=-1, keepdim=True)[0]`) as ONE autograd node."""
+    if sync is None:
+        sync = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    batch_stats = bn is not None and (bn.training or not bn.track_running_stats or bn.running_mean is None)
+    B, _, N, K = x.shape
+    x3 = x.reshape(B, x.shape[1], N * K)
+    y, ymax = _ConvAffineAct.apply(x3, conv.weight, conv.bias, bn.weight if bn is not None else None,
+                                   bn.bias if bn is not None else None, bn, relu, batch_stats, sync and batch_stats, K)
+    return y.reshape(B, y.shape[1], N, K), ymax.unsqueeze(-1)
 
 
 def linear_act(x, lin, relu=False):
     """nn.Linear over the last axis of x [..., Cin] (+ ReLU) through the same Function: the rows are the points of one cloud."""
     shp = x.shape
     x3 = x.reshape(-1, shp[-1]).t().unsqueeze(0)                          # [1, Cin, rows] (made contiguous by the Function)
-    y = _ConvAffineAct.apply(x3, lin.weight, lin.bias, None, None, None, relu, False, False)
+    y = _ConvAffineAct.apply(x3, lin.weight, lin.bias, None, None, None, relu, False, False, 0)
     return y[0].t().reshape(*shp[:-1], y.shape[1])
 
 

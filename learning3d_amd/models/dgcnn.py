@@ -105,7 +105,7 @@ class DGCNN(torch.nn.Module):
             return _fused.run_guarded(input_data.device, lambda: self._fused_forward(input_data, _pooled))
 
         output = get_graph_feature(input_data)
-        from ._train import conv_bn_act, hip_layers_ok, max_over_last
+        from ._train import conv_bn_act, conv_bn_act_max, hip_layers_ok
         if hip_layers_ok(output) and self.conv1.bias is None:
             # autograd is live (train-mode BatchNorm, or the backward recomputation of _fused.checkpointed): conv / dgrad /
             # wgrad on the HIP GEMMs; BatchNorm with per-cloud fp64 partial sums shared across ranks in train mode, its
@@ -113,8 +113,8 @@ class DGCNN(torch.nn.Module):
             output = output.contiguous()
             outs = []
             for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3), (self.conv4, self.bn4)):
-                output = conv_bn_act(output, conv, bn)
-                outs.append(max_over_last(output))
+                output, pooled = conv_bn_act_max(output, conv, bn)   # the layer and its max over k as one autograd node
+                outs.append(pooled)
             output = torch.cat(outs, dim=1)
             output = conv_bn_act(output, self.conv5, self.bn5).view(batch_size, -1, num_points)
             return output.max(dim=2)[0] if _pooled else output

@@ -89,7 +89,7 @@ class PCN(torch.nn.Module):
         x5 = torch.cat([grid_feature, center], dim=2).permute(0, 2, 1)                   # [B,5,fine]
         w5 = self.conv5.weight.reshape(512, 1029)
         shift = torch.addmm(self.conv5.bias, gfeat, w5[:, 5:].t())                       # [B,512]: W5[:, 5:] g + b5
-        z = _ConvAffineAct.apply(x5, w5[:, :5], None, None, None, None, False, False, False)
+        z = _ConvAffineAct.apply(x5, w5[:, :5], None, None, None, None, False, False, False, 0)
         out = self.relu(z + shift.unsqueeze(2))
         out = self._layer(self.conv7, self._layer(self.conv6, out, True), False)
         return out.permute(0, 2, 1) + center

@@ -91,11 +91,11 @@ class DGCNN(torch.nn.Module):
 
         # reference op sequence (prnet.py:76-97); with autograd live on the GPU each Conv2d + BatchNorm + LeakyReLU is the HIP
         # conv / dgrad / wgrad + BatchNorm layer of _train.py
-        from ._train import conv_bn_act, hip_layers_ok, max_over_last
+        from ._train import conv_bn_act, conv_bn_act_max, hip_layers_ok
         if hip_layers_ok(x):
             xs = []
             for conv, bn in ((self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3), (self.conv4, self.bn4)):
-                x = max_over_last(conv_bn_act(get_graph_feature(x).contiguous(), conv, bn, relu=ACT_LRELU))
+                x = conv_bn_act_max(get_graph_feature(x).contiguous(), conv, bn, relu=ACT_LRELU)[1]     # only the pooled output is used
                 xs.append(x)
             x = conv_bn_act(torch.cat(xs, dim=1), self.conv5, self.bn5, relu=ACT_LRELU)
             return x.view(batch_size, -1, num_points)
