@@ -51,6 +51,7 @@ SIGNATURES = {
     "l3d_gather_points_grad": [_I, _I, _I, _I, _P, _P, _P, _P],
     "l3d_furthest_point_sampling": [_I, _I, _I, _P, _P, _P, _P],
     "l3d_knn": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "l3d_knn_variant": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _P],
     "l3d_three_nn": [_I, _I, _I, _P, _P, _P, _P, _P],
     "l3d_three_interpolate": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "l3d_three_interpolate_concat": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],

@@ -514,13 +514,28 @@ extern "C" int l3d_knn_graph(const float *xyz, int B, int N, int k, int64_t *idx
     return l3d_knn_graph_variant(xyz, B, N, k, idx, 0, stream);
 }
 
+// knn_select.hip: a wave per query, k-th distance from bucket minima + rank counting (33 <= k <= 200, m <= 8192)
+bool l3d_knn_select_supported(int Nc, int k);
+int l3d_launch_knn_select(const float *q, const float *c, int B, int Nq, int Nc, int k, int out_mode, void *idx, float *val,
+                          hipStream_t st);
+
+extern "C" int l3d_knn_variant(int b, int n, int m, int k, const float *unknown, const float *known,
+                               float *dist2, int32_t *idx, int variant, l3d_stream_t stream)
+{
+    L3D_REQUIRE(unknown && known && dist2 && idx && b > 0 && n > 0 && m > 0 && k > 0 &&
+                k <= L3D_KNN_MAX_K && variant >= 0 && variant <= 2);
+    const bool sel = l3d_knn_select_supported(m, k);
+    if (variant == 2 && !sel) return L3D_ERR_UNSUPPORTED;
+    if (variant != 1 && sel)
+        return l3d_launch_knn_select(unknown, known, b, n, m, k, OUT_KNN_PAIR, idx, dist2, (hipStream_t)stream);
+    return launch_topk<METRIC_DIRECT>(unknown, known, b, n, m, k, OUT_KNN_PAIR, idx, dist2,
+                                      (hipStream_t)stream);
+}
+
 extern "C" int l3d_knn(int b, int n, int m, int k, const float *unknown, const float *known,
                        float *dist2, int32_t *idx, l3d_stream_t stream)
 {
-    L3D_REQUIRE(unknown && known && dist2 && idx && b > 0 && n > 0 && m > 0 && k > 0 &&
-                k <= L3D_KNN_MAX_K);
-    return launch_topk<METRIC_DIRECT>(unknown, known, b, n, m, k, OUT_KNN_PAIR, idx, dist2,
-                                      (hipStream_t)stream);
+    return l3d_knn_variant(b, n, m, k, unknown, known, dist2, idx, 0, stream);
 }
 
 // pointconv_util.knn_point (utils/pointconv_util.py:107-118): nsample smallest square_distance(new_xyz, xyz)
@@ -546,6 +561,8 @@ extern "C" int l3d_knn_point(int k, const float *pos1, const float *pos2, int B,
 {
     L3D_REQUIRE(pos1 && pos2 && val && idx && B > 0 && N > 0 && M > 0 && k > 0 && k <= N &&
                 k <= L3D_KNN_MAX_K);
+    if (l3d_knn_select_supported(N, k))
+        return l3d_launch_knn_select(pos2, pos1, B, M, N, k, OUT_KNN_POINT, idx, val, (hipStream_t)stream);
     return launch_topk<METRIC_DIRECT>(pos2, pos1, B, M, N, k, OUT_KNN_POINT, idx, val,
                                       (hipStream_t)stream);
 }

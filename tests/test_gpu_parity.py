@@ -2159,3 +2159,45 @@ def test_classifier_pools_inside_the_feature_models_last_conv():
         assert pooled_g is not None and torch.equal(pooled_g.detach(), pooled)
         pooled_g.sum().backward()
         assert torch.isfinite(xg.grad).all() and float(xg.grad.abs().max()) > 0
+
+
+# ------------------------------------------- kNN for large k (knn_select.hip: a wave per query) vs the lane-per-query kernel
+def _knn_pair_variant(q, c, k, variant):
+    from learning3d_amd._lib import check, lib, ptr, stream_ptr
+    q, c = q.contiguous(), c.contiguous()
+    B, n, _ = q.shape
+    m = c.shape[1]
+    d2 = torch.full((B, n, k), -1.0, device=q.device)
+    idx = torch.full((B, n, k), -7, dtype=torch.int32, device=q.device)
+    check(lib().l3d_knn_variant(B, n, m, k, ptr(q), ptr(c), ptr(d2), ptr(idx), variant, stream_ptr()), "l3d_knn_variant")
+    return d2, idx
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,n,m,k", [(2, 300, 1000, 64), (1, 70, 8192, 64), (2, 128, 256, 64), (1, 40, 5000, 200),
+                                     (1, 50, 100, 33), (1, 33, 4097, 100)])
+def test_knn_select_kernel_equals_lane_kernel(B, n, m, k):
+    """The wave-per-query selection kernel (variant 2) returns the lane-per-query kernel's (variant 1) squared distances
+    and indices bit for bit, in the reference's order (ascending, lowest index first on ties): uniform clouds, clouds
+    sorted along x, clouds on a coarse grid (most distances tie — the exact two-bisection path), one repeated point."""
+    g = torch.Generator().manual_seed(m + k)
+    uni = torch.rand((B, m, 3), generator=g)
+    srt = torch.stack([c[torch.argsort(c[:, 0])] for c in torch.rand((B, m, 3), generator=g)])
+    grid = torch.round(torch.rand((B, m, 3), generator=g) * 3) / 3
+    same = torch.full((B, m, 3), 0.25)
+    for name, cl in (("uniform", uni), ("sorted", srt), ("grid", grid), ("same", same)):
+        cl = cl.cuda()
+        q = (torch.rand((B, n, 3), generator=g) if name != "grid" else torch.round(torch.rand((B, n, 3), generator=g) * 3) / 3).cuda()
+        d1, i1 = _knn_pair_variant(q, cl, k, 1)
+        d2, i2 = _knn_pair_variant(q, cl, k, 2)
+        assert torch.equal(i1, i2), name
+        assert torch.equal(d1, d2), name
+        d0, i0 = _knn_pair_variant(q, cl, k, 0)                # the automatic choice is the selection kernel here
+        assert torch.equal(i0, i2) and torch.equal(d0, d2), name
+    # against the definition on one cloud: sorted squared distances with a stable argsort
+    cl, q = uni[:1].cuda(), torch.rand((1, n, 3), generator=g).cuda()
+    d2, i2 = _knn_pair_variant(q, cl, k, 2)
+    dx = q[:, :, None, :] - cl[:, None, :, :]
+    full = (dx[..., 0] * dx[..., 0] + dx[..., 1] * dx[..., 1]) + dx[..., 2] * dx[..., 2]
+    order = torch.argsort(full, dim=-1, stable=True)[..., :k]
+    assert torch.equal(i2.long(), order)

@@ -140,7 +140,8 @@ def test_group_and_gather_equal_reference_kernels(PN):
 
 
 # ------------------------------------------------------------------------------ K13 kNN between two clouds
-@pytest.mark.parametrize("B,N,M,k", [(3, 700, 2000, 64), (2, 1024, 1024, 20), (2, 333, 90, 7), (1, 2048, 8192, 64)])
+@pytest.mark.parametrize("B,N,M,k", [(3, 700, 2000, 64), (2, 1024, 1024, 20), (2, 333, 90, 7), (1, 2048, 8192, 64),
+                                     (2, 300, 4096, 200), (1, 100, 300, 33), (2, 256, 256, 64)])
 def test_knn_pair_equals_reference_kernel(PN, PNF, B, N, M, k):
     from learning3d_amd.utils import pointnet2_utils as P
     unknown, known = dev(clouds(B, N, 5)), dev(clouds(B, M, 6))

@@ -138,6 +138,15 @@ def main():
         res["group_c5"] = (t, 27262976 / t / 1e3, "GB/s(alg)")
         t = timeit(lambda: P.knn(64, new_xyz, xyz), warm=1, iters=3)
         res["knn_pair_k64_c5"] = (t, 32 * 1024 * 8192 / t / 1e3, "Gpair/s")
+        from learning3d_amd._lib import check, lib, ptr, stream_ptr
+        kd = torch.empty((32, 1024, 64), device=dev)
+        ki = torch.empty((32, 1024, 64), dtype=torch.int32, device=dev)
+        t = timeit(lambda: check(lib().l3d_knn_variant(32, 1024, 8192, 64, ptr(new_xyz), ptr(xyz), ptr(kd), ptr(ki), 1,
+                                                       stream_ptr()), "l3d_knn_variant"), warm=1, iters=3)
+        res["knn_pair_k64_c5_lane_kernel"] = (t, 32 * 1024 * 8192 / t / 1e3, "Gpair/s")
+        l2 = new_xyz[:, :256].contiguous()                   # FlowEmbedding's own shape: 256 x 256 points, nsample 64
+        t = timeit(lambda: P.knn(64, l2, l2))
+        res["knn_pair_k64_256x256"] = (t, 32 * 256 * 256 / t / 1e3, "Gpair/s")
     for name, (t, v, u) in res.items():
         print(f"{name:22s} {t:10.1f} us   {v:10.2f} {u}")
     print(json.dumps({k: {"us": v[0], "rate": v[1], "unit": v[2]} for k, v in res.items()}))

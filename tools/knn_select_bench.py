@@ -1,0 +1,42 @@
+"""Times l3d_knn_variant's two kernels (1 = lane per query, knn.hip; 2 = wave per query, knn_select.hip) on a few shapes."""
+import sys, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from learning3d_amd._lib import check, lib, ptr, stream_ptr
+
+
+def timeit(fn, warm=2, iters=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def main():
+    g = torch.Generator().manual_seed(0)
+    for (B, n, m, k, kind) in [(32, 1024, 8192, 64, "normal"), (32, 1024, 8192, 64, "sorted"), (32, 1024, 8192, 64, "grid"),
+                               (32, 256, 256, 64, "normal"), (32, 1024, 8192, 128, "normal"), (32, 1024, 8192, 200, "normal"),
+                               (32, 1024, 2048, 64, "normal"), (32, 1024, 8192, 40, "normal")]:
+        c = torch.clamp(torch.randn((B, m, 3), generator=g), -2, 2)
+        if kind == "sorted":
+            c = torch.stack([x[torch.argsort(x[:, 0])] for x in c])
+        if kind == "grid":
+            c = torch.round(c * 2) / 2
+        c = c.cuda()
+        q = c[:, torch.randperm(m, generator=g)[:n]].contiguous()
+        d = torch.empty((B, n, k), device="cuda")
+        i = torch.empty((B, n, k), dtype=torch.int32, device="cuda")
+        ts = []
+        for v in (1, 2):
+            ts.append(timeit(lambda: check(lib().l3d_knn_variant(B, n, m, k, ptr(q), ptr(c), ptr(d), ptr(i), v, stream_ptr()), "knn")))
+        print(f"B {B} n {n} m {m} k {k} {kind:7s}: lane kernel {ts[0]:9.1f} us   select kernel {ts[1]:9.1f} us", flush=True)
+
+
+if __name__ == "__main__":
+    main()
