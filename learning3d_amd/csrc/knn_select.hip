@@ -1,7 +1,7 @@
-// knn_select.hip -- k nearest of a query among up to 8192 candidates for LARGE k (33 … 200), direct metric.
+// knn_select.hip -- k nearest of a query among up to 8192 candidates, a WAVE per query, direct metric (k <= 200).
 //
-// Replaces, for k > 32:
-//   K13 knn_kernel_fast   utils/lib/src/interpolate_gpu.cu:9-57   (FlowEmbedding's nsample = 64, flownet3d.py:93-123)
+// Replaces, for k > 32 or 1024+ candidates:
+//   K13 knn_kernel_fast   utils/lib/src/interpolate_gpu.cu:9-57   (FlowEmbedding's nsample = 64, flownet3d.py:93-123; three_nn :81-124)
 //   T8  knn_point()       utils/model_common_utils.py:84-100
 //
 // knn.hip keeps a query per LANE with its sorted best-K list in registers; at K = 64 that is 64+ VALU operations per
@@ -29,6 +29,14 @@ enum { KS_OUT_PAIR = 1, KS_OUT_POINT = 2 };          // == OUT_KNN_PAIR / OUT_KN
 
 typedef float ks_f4 __attribute__((ext_vector_type(4)));
 
+// tools/probe_knn_select.hip: shader-clock cycles per phase, summed over a wave's queries (compiled out otherwise)
+#ifdef KS_TIMING
+__device__ long long *g_ks_time;
+#define KS_T(i) { const long long t_ = __builtin_amdgcn_s_memtime(); ks_acc[i] += t_ - ks_last; ks_last = t_; }
+#else
+#define KS_T(i)
+#endif
+
 template <int R>
 __global__ __launch_bounds__(64 * KS_WAVES) void knn_select_kernel(
     const float *__restrict__ qxyz, const float *__restrict__ cxyz, int Nq, int Nc, int k, int qpw, int out_mode,
@@ -36,7 +44,7 @@ __global__ __launch_bounds__(64 * KS_WAVES) void knn_select_kernel(
 {
     constexpr int MP = R * 64;
     __shared__ __attribute__((aligned(16))) float sc[3][MP];
-    __shared__ __attribute__((aligned(16))) uint2 surv[KS_WAVES][KS_CAP + 4];
+    __shared__ __attribute__((aligned(16))) uint2 surv[KS_WAVES][KS_CAP + 8];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -49,6 +57,10 @@ __global__ __launch_bounds__(64 * KS_WAVES) void knn_select_kernel(
     __syncthreads();
 
     uint2 *sv = surv[wave];
+#ifdef KS_TIMING
+    long long ks_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long ks_last = __builtin_amdgcn_s_memtime();
+#endif
     const int q0 = (blockIdx.x * KS_WAVES + wave) * qpw;
 #pragma unroll 1
     for (int qi = 0; qi < qpw; qi++) {
@@ -58,6 +70,10 @@ __global__ __launch_bounds__(64 * KS_WAVES) void knn_select_kernel(
         const float qx = qp[0], qy = qp[1], qz = qp[2];
 
         // ---- all distances of the query, in registers; bucket minima on the way
+        // the query splat in VECTOR registers: with a scalar operand the compiler emits four v_sub_f32 instead of two v_pk_add_f32
+        // (and as an ADDITION of -q: a subtraction is not packed either)
+        ks_f4 q4x = {-qx, -qx, -qx, -qx}, q4y = {-qy, -qy, -qy, -qy}, q4z = {-qz, -qz, -qz, -qz};
+        asm volatile("" : "+v"(q4x), "+v"(q4y), "+v"(q4z));
         unsigned d[R];
         unsigned bm[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         // (reads of group g + 1 are issued before group g's arithmetic; the scheduling fence keeps the compiler from
@@ -72,29 +88,41 @@ __global__ __launch_bounds__(64 * KS_WAVES) void knn_select_kernel(
                 Zn = *(const ks_f4 *)&sc[2][(g + 1) * 256 + lane * 4];
             }
             __builtin_amdgcn_sched_barrier(0);
-            const ks_f4 dx = qx - X, dy = qy - Y, dz = qz - Z;
+            const ks_f4 dx = X + q4x, dy = Y + q4y, dz = Z + q4z;     // c + (-q): (c - q)^2 == (q - c)^2 bit for bit
             const ks_f4 dd = (dx * dx + dy * dy) + dz * dz;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                d[g * 4 + u] = __float_as_uint(dd[u]);
-                bm[u] = min(bm[u], d[g * 4 + u]);
-            }
+            for (int u = 0; u < 4; u++) d[g * 4 + u] = __float_as_uint(dd[u]);
+        }
+        if constexpr (R >= 8) {
+#pragma unroll
+            for (int r = 0; r < R; r += 8)                             // v_min3_u32: two rows per operation
+#pragma unroll
+                for (int u = 0; u < 4; u++) bm[u] = min(bm[u], min(d[r + u], d[r + 4 + u]));
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; u++) bm[u] = d[u];
         }
         // (opaque per query: otherwise all R candidate indices are hoisted out of the query loop into R registers)
         int l4 = lane * 4;
         asm volatile("" : "+v"(l4));
         auto cand_index = [&](int r) { return (r >> 2) * 256 + l4 + (r & 3); };
 
+        KS_T(0)
         // ---- T0: some value with  k <= #(bucket minima <= T0)  (<= k + 8 when the bisection gets there)
         unsigned T0;
         {
-            unsigned lo = 0, hi = 0xffffffffu;
+            // the four compares of a step are issued back to back into four scalar pairs and counted afterwards: left to the
+            // compiler each v_cmp -> s_bcnt1 pair went through vcc, one after the other (165 cycles per step)
+            unsigned lo = 0, hi = 0x7fffffffu;
 #pragma unroll 1
             while (lo < hi) {
                 const unsigned mid = lo + ((hi - lo) >> 1);
-                int c = 0;
-#pragma unroll
-                for (int u = 0; u < 4; u++) c += __popcll(__ballot(bm[u] <= mid));
+                unsigned long long m0, m1, m2, m3;
+                asm volatile("v_cmp_le_u32_e64 %0, %4, %8\n\tv_cmp_le_u32_e64 %1, %5, %8\n\t"
+                             "v_cmp_le_u32_e64 %2, %6, %8\n\tv_cmp_le_u32_e64 %3, %7, %8"
+                             : "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+                             : "v"(bm[0]), "v"(bm[1]), "v"(bm[2]), "v"(bm[3]), "s"(mid));
+                const int c = (__popcll(m0) + __popcll(m1)) + (__popcll(m2) + __popcll(m3));
                 if (c >= k) {
                     hi = mid;
                     if (c <= k + 8) break;
@@ -105,18 +133,61 @@ __global__ __launch_bounds__(64 * KS_WAVES) void knn_select_kernel(
             T0 = hi;
         }
 
-        // ---- survivors -> LDS list.  pred(r): d < T || (d == T && index <= I)
-        int S = 0;
+        KS_T(1)
+        // ---- survivors -> LDS list.  Per lane a bit per row first (two VALU operations per row, no scalar round trip:
+        // the sign of T0 - d is the "not a survivor" bit, shifted into the word), then the lanes pop their few bits together,
+        // four per trip, and RECOMPUTE those candidates' distances from LDS (registers cannot be indexed by a popped bit;
+        // the same operations give the same bits).  A branch per row on a ballot cost 86 cycles per row.
+        constexpr int NW = (R + 31) / 32, RW = R < 32 ? R : 32;
+        unsigned hm[NW];
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const bool p = d[r] <= T0;
-            const unsigned long long m = __ballot(p);
-            if (m != 0) {
+        for (int w = 0; w < NW; w++) {
+            unsigned nm = 0xffffffffu;
+#pragma unroll
+            for (int i = 0; i < RW; i++) nm = __builtin_amdgcn_alignbit(nm, T0 - d[w * 32 + i], 31);   // row 32 w + i -> bit RW-1-i
+            hm[w] = ~nm;
+        }
+        int S = 0;
+#pragma unroll 1
+        for (;;) {
+            unsigned left = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) left |= hm[w];
+            if (__ballot(left != 0) == 0 || S > KS_CAP) break;
+            int jj[4];
+            bool has[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                int r = 0;
+                bool done = false;
+#pragma unroll
+                for (int w = 0; w < NW; w++) {
+                    const bool sel = !done && hm[w] != 0;
+                    r = sel ? w * 32 + RW - 1 - __builtin_ctz(hm[w] | 0x80000000u) : r;
+                    hm[w] = sel ? hm[w] & (hm[w] - 1) : hm[w];
+                    done = done || sel;
+                }
+                has[e] = done;
+                jj[e] = (r >> 2) * 256 + l4 + (r & 3);
+            }
+            float cx[4], cy[4], cz[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { cx[e] = sc[0][jj[e]]; cy[e] = sc[1][jj[e]]; cz[e] = sc[2][jj[e]]; }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float dx = cx[e] - qx, dy = cy[e] - qy, dz = cz[e] - qz;
+                const float dd = (dx * dx + dy * dy) + dz * dz;
+                const unsigned long long m = __ballot(has[e]);
                 const int pos = S + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (p && pos < KS_CAP) sv[pos] = make_uint2(d[r], (unsigned)cand_index(r));
+                if (has[e] && pos < KS_CAP) sv[pos] = make_uint2((unsigned)jj[e], __float_as_uint(dd));
                 S += __popcll(m);
             }
         }
+        KS_T(2)
+#ifdef KS_TIMING
+        ks_acc[6] += S;
+        ks_acc[7] += S > KS_CAP;
+#endif
         if (S > KS_CAP) {
             // exact k-th smallest key: distance bits T, then the index bound I among the candidates at distance T.
             // (the scheduling fences keep at most eight ballots alive; left alone, the scheduler gathered all R compares
@@ -153,46 +224,62 @@ __global__ __launch_bounds__(64 * KS_WAVES) void knn_select_kernel(
                 const unsigned long long m = __ballot(p);
                 if (m != 0) {
                     const int pos = S + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                    if (p) sv[pos] = make_uint2(d[r], (unsigned)cand_index(r));      // exactly k entries
+                    if (p) sv[pos] = make_uint2((unsigned)cand_index(r), d[r]);      // exactly k entries
                     S += __popcll(m);
                 }
             }
         }
-        if (lane < 4) sv[S + lane] = make_uint2(0xffffffffu, 0xffffffffu);           // the rank loop reads in fours
+        KS_T(3)
+        if (lane < 8) sv[S + lane] = make_uint2(0xffffffffu, 0xffffffffu);           // the rank loop reads eight entries per trip
         __builtin_amdgcn_wave_barrier();
 
-        // ---- rank by counting; two of the lane's entries share every broadcast read
+        // ---- rank by counting.  An entry is the 64-bit key (distance bits : index) in memory order; two of the lane's entries
+        // share every broadcast read, eight keys are read per trip (four ds_read_b128 in flight before the compares)
+        typedef unsigned long long ks_u64x2 __attribute__((ext_vector_type(2)));
+        const unsigned long long *kv = (const unsigned long long *)sv;
         const size_t o = ((size_t)b * Nq + q) * k;
 #pragma unroll 1
         for (int t0 = 0; t0 < S; t0 += 128) {
             const int e0 = t0 + lane, e1 = t0 + 64 + lane;
-            const uint2 m0 = sv[min(e0, S)], m1 = sv[min(e1, S)];                    // entry S is a sentinel
-            const unsigned long long k0 = ((unsigned long long)m0.x << 32) | m0.y;
-            const unsigned long long k1 = ((unsigned long long)m1.x << 32) | m1.y;
+            const unsigned long long k0 = kv[min(e0, S)], k1 = kv[min(e1, S)];      // entry S is a sentinel
             int r0 = 0, r1 = 0;
 #pragma unroll 1
-            for (int s = 0; s < S; s += 4) {
-                const uint4 a = *(const uint4 *)&sv[s], c = *(const uint4 *)&sv[s + 2];
-                const unsigned long long o0 = ((unsigned long long)a.x << 32) | a.y, o1 = ((unsigned long long)a.z << 32) | a.w;
-                const unsigned long long o2 = ((unsigned long long)c.x << 32) | c.y, o3 = ((unsigned long long)c.z << 32) | c.w;
-                r0 += (o0 < k0) + (o1 < k0) + (o2 < k0) + (o3 < k0);
-                r1 += (o0 < k1) + (o1 < k1) + (o2 < k1) + (o3 < k1);
+            for (int s = 0; s < S; s += 8) {
+                ks_u64x2 a[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) a[i] = *(const ks_u64x2 *)&kv[s + 2 * i];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    r0 += (a[i][0] < k0) + (a[i][1] < k0);
+                    r1 += (a[i][0] < k1) + (a[i][1] < k1);
+                }
             }
+            const unsigned i0 = (unsigned)k0, i1 = (unsigned)k1;
+            const float v0 = __uint_as_float((unsigned)(k0 >> 32)), v1 = __uint_as_float((unsigned)(k1 >> 32));
             if (out_mode == KS_OUT_PAIR) {
                 int32_t *dst = (int32_t *)idx_out + o;
-                if (e0 < S && r0 < k) { dst[r0] = (int32_t)m0.y; val_out[o + r0] = __uint_as_float(m0.x); }
-                if (e1 < S && r1 < k) { dst[r1] = (int32_t)m1.y; val_out[o + r1] = __uint_as_float(m1.x); }
+                if (e0 < S && r0 < k) { dst[r0] = (int32_t)i0; val_out[o + r0] = v0; }
+                if (e1 < S && r1 < k) { dst[r1] = (int32_t)i1; val_out[o + r1] = v1; }
             } else {
                 int64_t *dst = (int64_t *)idx_out + o;
-                if (e0 < S && r0 < k) { dst[r0] = (int64_t)m0.y; val_out[o + r0] = sqrtf(__uint_as_float(m0.x)); }
-                if (e1 < S && r1 < k) { dst[r1] = (int64_t)m1.y; val_out[o + r1] = sqrtf(__uint_as_float(m1.x)); }
+                if (e0 < S && r0 < k) { dst[r0] = (int64_t)i0; val_out[o + r0] = sqrtf(v0); }
+                if (e1 < S && r1 < k) { dst[r1] = (int64_t)i1; val_out[o + r1] = sqrtf(v1); }
             }
         }
         __builtin_amdgcn_wave_barrier();
+        KS_T(4)
     }
+#ifdef KS_TIMING
+    if (lane == 0)
+        for (int i = 0; i < 8; i++) g_ks_time[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * KS_WAVES + wave) * 8 + i] = ks_acc[i];
+#endif
 }
 
-bool l3d_knn_select_supported(int Nc, int k) { return k > 32 && k <= L3D_KNN_MAX_K && k <= Nc && Nc <= 8192; }
+bool l3d_knn_select_supported(int Nc, int k) { return k >= 1 && k <= L3D_KNN_MAX_K && k <= Nc && Nc <= 8192; }
+// where it is the faster kernel (tools/knn_select_bench.py, LABLOG R3.19): large k, where the lane-per-query kernels pay K
+// operations per insertion, and any k from 1024 candidates up (k = 16 over 8192: 115 us against 291; at 1024 candidates the two
+// meet for k <= 8).  Below that the per-query bisection and ranking outweigh a lane's short insertion list.
+bool l3d_knn_select_preferred(int Nc, int k) { return l3d_knn_select_supported(Nc, k) && (k > 32 || Nc >= 1024); }
 
 int l3d_launch_knn_select(const float *q, const float *c, int B, int Nq, int Nc, int k, int out_mode, void *idx, float *val,
                           hipStream_t st)

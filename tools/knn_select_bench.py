@@ -22,14 +22,19 @@ def main():
     g = torch.Generator().manual_seed(0)
     for (B, n, m, k, kind) in [(32, 1024, 8192, 64, "normal"), (32, 1024, 8192, 64, "sorted"), (32, 1024, 8192, 64, "grid"),
                                (32, 256, 256, 64, "normal"), (32, 1024, 8192, 128, "normal"), (32, 1024, 8192, 200, "normal"),
-                               (32, 1024, 2048, 64, "normal"), (32, 1024, 8192, 40, "normal")]:
+                               (32, 1024, 2048, 64, "normal"), (32, 1024, 8192, 40, "normal"), (32, 1024, 8192, 32, "normal"),
+                               (32, 1024, 8192, 16, "normal"), (32, 1024, 8192, 8, "normal"), (32, 1024, 1024, 32, "normal"),
+                               (32, 1024, 1024, 16, "normal"), (32, 256, 64, 8, "normal"), (32, 8192, 1024, 3, "normal"), (32, 1024, 256, 8, "normal"),
+                               (32, 1024, 8192, 4, "normal"), (32, 2048, 2048, 16, "normal"), (32, 1024, 512, 16, "normal"),
+                               (32, 1024, 1024, 8, "normal"), (32, 1024, 1024, 3, "normal"), (4, 1024, 8192, 16, "normal")]:
         c = torch.clamp(torch.randn((B, m, 3), generator=g), -2, 2)
         if kind == "sorted":
             c = torch.stack([x[torch.argsort(x[:, 0])] for x in c])
         if kind == "grid":
             c = torch.round(c * 2) / 2
         c = c.cuda()
-        q = c[:, torch.randperm(m, generator=g)[:n]].contiguous()
+        q = (c[:, torch.randperm(m, generator=g)[:n]].contiguous() if n <= m
+             else torch.clamp(torch.randn((B, n, 3), generator=g), -2, 2).cuda())
         d = torch.empty((B, n, k), device="cuda")
         i = torch.empty((B, n, k), dtype=torch.int32, device="cuda")
         ts = []
