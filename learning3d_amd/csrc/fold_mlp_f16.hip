@@ -7,6 +7,10 @@
 //   the workgroup computes itself: |h5[n][k]| <= |s5[b][k]| + sum_c |W5g[k][c]| max_tile |g[n][c]| -- no extra pass, no
 //   range flag (the bound cannot be exceeded), and powers of two cancel exactly in the epilogue;
 //   per K chunk a wave reads 12 + 4 fragments and issues 24 MFMAs (bf16x3: 12 + 6 and 48).
+// Round 3: the residual of h5 is carried UNSCALED (m = f16(h5 2^T - h); the tile's maximum sits in [2^11, 2^12), so a subnormal
+// residual costs 2^-25 absolute in plane units, as in edgeconv_f16b.hip) and the Hs = H 2^-12 weight plane is not read: products
+// M h + H m + H h, 8 + 4 fragment reads and 4 instead of 5 cell stores per chunk -- the kernel's LDS port was 87 % busy
+// (16 KB of reads per wave and 40 KB of stores per chunk against 1536 cycles of matrix-pipe time per SIMD).
 #include "common.h"
 #include "split_bf16.h"          // f32x16
 #include "split_f16.h"
@@ -15,7 +19,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define FF_C 512                        // conv5 out = conv6 in = conv6 out
 #define FF_REGION (256 * 16 + 64)
-#define FF_BUF (10 * FF_REGION)         // W: 3 planes x 2 octets, x: 2 planes x 2 octets
+#define FF_BUF (8 * FF_REGION)          // W: 2 planes (H, M) x 2 octets, x: 2 planes x 2 octets
 #define FF_W7OFF (3 * FF_BUF)           // W7 as float4 (w7[0][co], w7[1][co], w7[2][co], 0) per co
 #define FF_SCR (FF_W7OFF + FF_C * 16)   // 64 floats of reduction scratch
 #define FF_LDS (FF_SCR + 256)
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(512) void fold_mlp_f16_kernel(const float *__restri
     const float *s5b = s5 + (size_t)b * FF_C;
     const int wrow = t & 255, wkg = t >> 8;
     const int w_lds = wkg * FF_REGION + wrow * 16;
-    const int x_lds = 6 * FF_REGION + xkg * FF_REGION + xrow * 16;
+    const int x_lds = 4 * FF_REGION + xkg * FF_REGION + xrow * 16;
 
     for (int i = t; i < FF_C; i += 512)
         *(float4 *)(lds + FF_W7OFF + i * 16) = make_float4(w7[i], w7[FF_C + i], w7[2 * FF_C + i], 0.f);
@@ -91,19 +95,19 @@ __global__ __launch_bounds__(512) void fold_mlp_f16_kernel(const float *__restri
         inv = ldexpf(*winv, -T);                                      // 2^-S 2^-T: exact
     }
 
-    uint4 w0, w1, w2, x0, x1;
+    uint4 w0, w2, x0, x1;
     float part[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};           // conv7 partial sums, 2 point columns per lane
 
     const int frag_kg = (lane >> 5) * FF_REGION;
     const int a_off = frag_kg + (wm * 128 + (lane & 31)) * 16;
-    const int b_off = 6 * FF_REGION + frag_kg + (wn * 64 + (lane & 31)) * 16;
+    const int b_off = 4 * FF_REGION + frag_kg + (wn * 64 + (lane & 31)) * 16;
 
 #pragma unroll 1
     for (int half = 0; half < 2; half++) {
         const int co0 = half * 256;
         const size_t wofs = (size_t)wkg * FF_C + co0 + wrow;          // + kc * 2 * 512: cell [octet 2 kc + kg][row]
 
-        // h5 octet of chunk KC for this thread's point -> two fp16 planes (x0 = h, x1 = m') of h5 2^T
+        // h5 octet of chunk KC for this thread's point -> two fp16 planes (x0 = h, x1 = m, unscaled residual) of h5 2^T
 #define FF_GEN_X(KC)                                                                                  \
         do {                                                                                          \
             float hv_[8];                                                                             \
@@ -113,23 +117,21 @@ __global__ __launch_bounds__(512) void fold_mlp_f16_kernel(const float *__restri
                 _Pragma("unroll") for (int c = 0; c < CG; c++) a_ = fmaf(w5g[k_ * CG + c], gv[c], a_); \
                 hv_[e_] = fmaxf(a_, 0.f);                                                             \
             }                                                                                         \
-            af_split_x(hv_[0], hv_[1], up, x0.x, x1.x);                                               \
-            af_split_x(hv_[2], hv_[3], up, x0.y, x1.y);                                               \
-            af_split_x(hv_[4], hv_[5], up, x0.z, x1.z);                                               \
-            af_split_x(hv_[6], hv_[7], up, x0.w, x1.w);                                               \
+            af_split_x_unscaled(hv_[0], hv_[1], up, x0.x, x1.x);                                               \
+            af_split_x_unscaled(hv_[2], hv_[3], up, x0.y, x1.y);                                               \
+            af_split_x_unscaled(hv_[4], hv_[5], up, x0.z, x1.z);                                               \
+            af_split_x_unscaled(hv_[6], hv_[7], up, x0.w, x1.w);                                               \
         } while (0)
 #define FF_LOAD_W(KC)                                                                                 \
         do {                                                                                          \
             w0 = wH[wofs + (size_t)(KC) * 2 * FF_C];                                                  \
-            w1 = wHs[wofs + (size_t)(KC) * 2 * FF_C];                                                 \
             w2 = wM[wofs + (size_t)(KC) * 2 * FF_C];                                                  \
         } while (0)
 #define FF_STORE(BUF)                                                                                 \
         do {                                                                                          \
             unsigned char *base_ = lds + (BUF) * FF_BUF;                                              \
             *(uint4 *)(base_ + w_lds) = w0;                                                           \
-            *(uint4 *)(base_ + w_lds + 2 * FF_REGION) = w1;                                           \
-            *(uint4 *)(base_ + w_lds + 4 * FF_REGION) = w2;                                           \
+            *(uint4 *)(base_ + w_lds + 2 * FF_REGION) = w2;                                           \
             *(uint4 *)(base_ + x_lds) = x0;                                                           \
             *(uint4 *)(base_ + x_lds + 2 * FF_REGION) = x1;                                           \
         } while (0)
@@ -158,12 +160,14 @@ __global__ __launch_bounds__(512) void fold_mlp_f16_kernel(const float *__restri
             for (int p = 0; p < 2; p++)
 #pragma unroll
                 for (int c = 0; c < 2; c++) Bf[c][p] = *(const f16x8 *)(base + b_off + c * 512 + p * 2 * FF_REGION);
+            f16x8 A[4];
 #pragma unroll
-            for (int prod = 0; prod < 3; prod++) {                    // M h, Hs m', H h: smallest first
-                const int pa = prod == 0 ? 2 : (prod == 1 ? 1 : 0), pb = prod == 1 ? 1 : 0;
-                f16x8 A[4];
+            for (int prod = 0; prod < 3; prod++) {                    // M h, H m, H h: smallest first; H is read once for both
+                const int pb = prod == 1 ? 1 : 0;
+                if (prod != 2) {
 #pragma unroll
-                for (int a = 0; a < 4; a++) A[a] = *(const f16x8 *)(base + a_off + a * 512 + pa * 2 * FF_REGION);
+                    for (int a = 0; a < 4; a++) A[a] = *(const f16x8 *)(base + a_off + a * 512 + (prod == 0 ? 2 * FF_REGION : 0));
+                }
 #pragma unroll
                 for (int a = 0; a < 4; a++)
 #pragma unroll

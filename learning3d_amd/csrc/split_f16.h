@@ -32,3 +32,15 @@ __device__ __forceinline__ void af_split_x(float a0, float a1, float c, uint32_t
     asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(m) : "v"(r1), "s"(4096.0f));
 }
 
+// two fp32 -> packed fp16 (h, m) of x c with the UNSCALED residual m = f16(x c - h): for operands placed near 2^11 (a subnormal
+// residual then costs 2^-25 absolute in plane units, edgeconv_f16b.hip "EF_V2") -- the Hs weight plane is not needed
+__device__ __forceinline__ void af_split_x_unscaled(float a0, float a1, float c, uint32_t &h, uint32_t &m)
+{
+    float r0, r1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a0), "v"(c));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(a1), "v"(c));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a0), "v"(c), "v"(h));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(a1), "v"(c), "v"(h));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, 0" : "=v"(m) : "v"(r0));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, 0" : "+v"(m) : "v"(r1));
+}
