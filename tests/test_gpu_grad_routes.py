@@ -101,7 +101,7 @@ def test_eval_with_grad_enabled_runs_the_fused_kernels_other_models(golden):
     dcp = _load(DCP(DGCNN(emb_dims=64)), gd)
     with launch_log() as log:
         o = dcp(dev(gd["template"]), dev(gd["source"]))
-    assert "l3d_soft_correspondence" in log and "l3d_kabsch" in log, log
+    assert any(n.startswith("l3d_soft_correspondence") for n in log) and "l3d_kabsch" in log, log
     np.testing.assert_allclose(o["est_R"].detach().cpu().numpy(), gd["est_R"], atol=1e-5)
     np.testing.assert_allclose(o["est_t"].detach().cpu().numpy(), gd["est_t"], atol=1e-5)
     assert o["est_R"].requires_grad
