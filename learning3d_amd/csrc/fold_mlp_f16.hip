@@ -95,6 +95,9 @@ __global__ __launch_bounds__(512) void fold_mlp_f16_kernel(const float *__restri
         inv = ldexpf(*winv, -T);                                      // 2^-S 2^-T: exact
     }
 
+    float gvu[CG];                                                    // g 2^T: the generated h5 comes out in plane units
+#pragma unroll
+    for (int c = 0; c < CG; c++) gvu[c] = gv[c] * up;
     uint4 w0, w2, x0, x1;
     float part[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};           // conv7 partial sums, 2 point columns per lane
 
@@ -113,14 +116,14 @@ __global__ __launch_bounds__(512) void fold_mlp_f16_kernel(const float *__restri
             float hv_[8];                                                                             \
             _Pragma("unroll") for (int e_ = 0; e_ < 8; e_++) {                                        \
                 const int k_ = (KC) * 16 + xkg * 8 + e_;                /* wave-uniform: scalar loads */ \
-                float a_ = s5b[k_];                                                                   \
-                _Pragma("unroll") for (int c = 0; c < CG; c++) a_ = fmaf(w5g[k_ * CG + c], gv[c], a_); \
+                float a_ = s5b[k_] * up;            /* h5 2^T: every term scaled by the same power of two, exact */ \
+                _Pragma("unroll") for (int c = 0; c < CG; c++) a_ = fmaf(w5g[k_ * CG + c], gvu[c], a_); \
                 hv_[e_] = fmaxf(a_, 0.f);                                                             \
             }                                                                                         \
-            af_split_x_unscaled(hv_[0], hv_[1], up, x0.x, x1.x);                                               \
-            af_split_x_unscaled(hv_[2], hv_[3], up, x0.y, x1.y);                                               \
-            af_split_x_unscaled(hv_[4], hv_[5], up, x0.z, x1.z);                                               \
-            af_split_x_unscaled(hv_[6], hv_[7], up, x0.w, x1.w);                                               \
+            af_split_x_unscaled_cvt(hv_[0], hv_[1], x0.x, x1.x);                                      \
+            af_split_x_unscaled_cvt(hv_[2], hv_[3], x0.y, x1.y);                                      \
+            af_split_x_unscaled_cvt(hv_[4], hv_[5], x0.z, x1.z);                                      \
+            af_split_x_unscaled_cvt(hv_[6], hv_[7], x0.w, x1.w);                                      \
         } while (0)
 #define FF_LOAD_W(KC)                                                                                 \
         do {                                                                                          \

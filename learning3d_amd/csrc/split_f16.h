@@ -44,3 +44,17 @@ __device__ __forceinline__ void af_split_x_unscaled(float a0, float a1, float c,
     asm("v_fma_mixlo_f16 %0, %1, 1.0, 0" : "=v"(m) : "v"(r0));
     asm("v_fma_mixhi_f16 %0, %1, 1.0, 0" : "+v"(m) : "v"(r1));
 }
+// the same for operands that are ALREADY in plane units (x = a, no scale): v_cvt_pk_f16_f32 (gfx950) rounds the pair, the rounded
+// halves are subtracted back (exact) and rounded again -- six full-rate VALU instructions where the v_fma_mix* forms above cost
+// about 2.4x a plain VALU instruction each beside an MFMA stream (LABLOG R2.2; edgeconv_f16b.hip's split).
+// s_nop: VALU write -> SDWA read of the same VGPR, a hazard the compiler does not see inside asm.
+__device__ __forceinline__ void af_split_x_unscaled_cvt(float a0, float a1, uint32_t &h, uint32_t &m)
+{
+    float f0, f1, r0, r1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a0), "v"(a1));
+    asm("v_cvt_f32_f16_e32 %0, %1" : "=v"(f0) : "v"(h));
+    asm("s_nop 0\n\tv_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f1) : "v"(h));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r0) : "v"(a0), "v"(f0));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r1) : "v"(a1), "v"(f1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(m) : "v"(r0), "v"(r1));
+}
