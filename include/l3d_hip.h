@@ -626,6 +626,14 @@ int l3d_bn_backward_finalize(const double *part_local, int Bl, const double *par
 int l3d_max_last(const float *x, long R, int K, float *v, unsigned char *idx, l3d_stream_t stream);
 int l3d_max_last_backward(const float *g, const unsigned char *idx, long R, int K, float *gx, l3d_stream_t stream);
 
+/* Backward of the pointer network's LayerNorm (utils/transformer.py:109-119: unbiased std, eps added to std; forward =
+ * l3d_layernorm_ref): x, g = dL/dy, dx [rows][C]; a [C]; da, db [C] summed over the rows in a fixed order (workgroup partials in
+ * the workspace, then fp64 in workgroup order).  workspace: l3d_layernorm_backward_workspace_floats(rows, C) floats.
+ * C % 4 == 0, C <= 2048, 16-byte aligned pointers. */
+size_t l3d_layernorm_backward_workspace_floats(long rows, int C);
+int l3d_layernorm_ref_backward(const float *x, const float *a, const float *g, float eps, long rows, int C, float *dx,
+                               float *workspace, float *da, float *db, l3d_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Weight gradient of a 1x1 conv / Linear over points (wgrad.hip; the autograd of nn.Conv1d / Conv2d(k=1) in
  * models/dgcnn.py:34-48, models/pcn.py:110-153, models/pointnet.py:51-73 under examples/train_pcn.py:70-91):

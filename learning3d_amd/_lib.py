@@ -67,6 +67,8 @@ SIGNATURES = {
     "l3d_kabsch": [_P, _P, _I, _I, _P, _P, _P, _P],
     "l3d_svd3x3_rotation": [_P, _I, _P, _P],
     "l3d_soft_correspondence_workspace_floats": [_I, _I, _I],
+    "l3d_layernorm_backward_workspace_floats": [C.c_long, _I],
+    "l3d_layernorm_ref_backward": [_P, _P, _P, _F, C.c_long, _I, _P, _P, _P, _P, _P],
     "l3d_soft_correspondence": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
     "l3d_attention_forward": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P],
     "l3d_attention_forward_strided": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _P],
@@ -129,7 +131,7 @@ SIGNATURES = {
     "l3d_emd_backward": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
 }
 _RESTYPE = {"l3d_status_string": C.c_char_p, "l3d_edgeconv_packed_floats": _SZ, "l3d_split_bytes": _SZ,
-            "l3d_soft_correspondence_workspace_floats": _SZ, "l3d_knn_feature_workspace_bytes": _SZ,
+            "l3d_soft_correspondence_workspace_floats": _SZ, "l3d_layernorm_backward_workspace_floats": _SZ, "l3d_knn_feature_workspace_bytes": _SZ,
             "l3d_scatter_add_det_workspace_bytes": _SZ, "l3d_chamfer_loss_local_ws_bytes": _SZ, "l3d_f16_plane_bytes": _SZ, "l3d_f16_act_bytes": _SZ, "l3d_conv_f16_weight_bytes": _SZ,
             "l3d_wgrad_workspace_bytes": _SZ}
 

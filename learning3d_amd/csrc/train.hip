@@ -470,3 +470,164 @@ extern "C" int l3d_bn_backward_finalize(const double *part_local, int Bl, const 
                        part_all, Ba, C, n, batch_stats, gr64, m1, m2, dbias, dgamma, dbeta);
     return l3d_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Backward of the pointer network's LayerNorm (utils/transformer.py:109-119: y = a (x - mean) / (std + eps) + b with the UNBIASED
+// std and eps added to std) -- the torch composition is ~8 launches forward and ~20 backward over [rows, C]; forward is
+// l3d_layernorm_ref (softcorr.hip), this is its backward in one pass over x and g:
+//   xc = x - mean, s = std, d = s + eps, dz = g a
+//   dxc_i = dz_i / d - (sum_j dz_j xc_j) xc_i / (d^2 (C-1) s),   dx_i = dxc_i - mean_j dxc_j
+//   da_c = sum_rows g z,  db_c = sum_rows g          (z = xc / d)
+// A wave per row (the row in registers), a workgroup's rows strided by the grid; every wave keeps da / db partial sums for its
+// lane's channels, the four waves of a workgroup are added in wave order through LDS, the workgroups' partials
+// [G][2][C] in workgroup order (fp64) by a second kernel: deterministic, no atomics.
+// ---------------------------------------------------------------------------------------------
+template <int VPL /* float4 per lane */>
+__global__ __launch_bounds__(256) void layernorm_ref_backward_kernel(const float *__restrict__ x, const float *__restrict__ a,
+                                                                     const float *__restrict__ g, float eps, long rows, int C,
+                                                                     float *__restrict__ dx, float *__restrict__ partial)
+{
+    extern __shared__ float ln_red[];                 // [3 waves][2][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4 = C >> 2;
+    float4 ga[VPL], sda[VPL], sdb[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; i++) {
+        const int q = lane + 64 * i;
+        ga[i] = q < c4 ? ((const float4 *)a)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        sda[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sdb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const float4 *xr = (const float4 *)(x + row * C), *gr = (const float4 *)(g + row * C);
+        float4 v[VPL], gv[VPL];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+            const int q = lane + 64 * i;
+            v[i] = q < c4 ? xr[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            gv[i] = q < c4 ? gr[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        const float mean = s / (float)C;
+        float ss = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+            if (lane + 64 * i < c4) {
+                v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;                 // xc
+                ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+                t1 += (gv[i].x * ga[i].x * v[i].x + gv[i].y * ga[i].y * v[i].y) + (gv[i].z * ga[i].z * v[i].z + gv[i].w * ga[i].w * v[i].w);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { ss += __shfl_xor(ss, off, 64); t1 += __shfl_xor(t1, off, 64); }
+        const float sd = sqrtf(ss / (float)(C - 1)), d = sd + eps, inv = 1.f / d;
+        const float k2 = sd > 0.f ? t1 * inv * inv / ((float)(C - 1) * sd) : 0.f;
+        float t2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+            if (lane + 64 * i < c4) {
+                // da / db partial sums first (they need g and z), then g is overwritten by dxc
+                sda[i].x += gv[i].x * (v[i].x * inv); sda[i].y += gv[i].y * (v[i].y * inv);
+                sda[i].z += gv[i].z * (v[i].z * inv); sda[i].w += gv[i].w * (v[i].w * inv);
+                sdb[i].x += gv[i].x; sdb[i].y += gv[i].y; sdb[i].z += gv[i].z; sdb[i].w += gv[i].w;
+                gv[i].x = gv[i].x * ga[i].x * inv - k2 * v[i].x; gv[i].y = gv[i].y * ga[i].y * inv - k2 * v[i].y;
+                gv[i].z = gv[i].z * ga[i].z * inv - k2 * v[i].z; gv[i].w = gv[i].w * ga[i].w * inv - k2 * v[i].w;
+                t2 += (gv[i].x + gv[i].y) + (gv[i].z + gv[i].w);
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t2 += __shfl_xor(t2, off, 64);
+        const float m2 = t2 / (float)C;
+        float4 *dr = (float4 *)(dx + row * C);
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+            const int q = lane + 64 * i;
+            if (q < c4) dr[q] = make_float4(gv[i].x - m2, gv[i].y - m2, gv[i].z - m2, gv[i].w - m2);
+        }
+    }
+    // the workgroup's partial: waves 1..3 park theirs in LDS, wave 0 adds them in wave order and writes [2][C]
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+            const int q = lane + 64 * i;
+            if (q < c4) {
+                ((float4 *)(ln_red + ((size_t)(wave - 1) * 2) * C))[q] = sda[i];
+                ((float4 *)(ln_red + ((size_t)(wave - 1) * 2 + 1) * C))[q] = sdb[i];
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float *out = partial + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+            const int q = lane + 64 * i;
+            if (q < c4) {
+                float4 da = sda[i], db = sdb[i];
+                for (int w = 0; w < 3; w++) {
+                    const float4 pa = ((const float4 *)(ln_red + ((size_t)w * 2) * C))[q], pb = ((const float4 *)(ln_red + ((size_t)w * 2 + 1) * C))[q];
+                    da.x += pa.x; da.y += pa.y; da.z += pa.z; da.w += pa.w;
+                    db.x += pb.x; db.y += pb.y; db.z += pb.z; db.w += pb.w;
+                }
+                ((float4 *)out)[q] = da;
+                ((float4 *)(out + C))[q] = db;
+            }
+        }
+    }
+}
+
+// 64 columns of the [G][2 C] partials per workgroup; thread (column, part) adds workgroups part, part + 4, ... (eight loads in
+// flight -- one thread per column walked 256 dependent loads, 63 us), the four parts are added in order through LDS: a fixed order
+__global__ __launch_bounds__(256) void layernorm_param_reduce_kernel(const float *__restrict__ partial, int G, int C, float *__restrict__ da,
+                                                                     float *__restrict__ db)
+{
+    __shared__ double red[3][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    double s = 0.0;
+    if (c < 2 * C) {
+        int k = part;
+        for (; k + 28 < G; k += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = partial[(size_t)(k + 4 * u) * 2 * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += v[u];
+        }
+        for (; k < G; k += 4) s += partial[(size_t)k * 2 * C + c];
+    }
+    if (part > 0) red[part - 1][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && c < 2 * C) {
+        s = ((s + red[0][threadIdx.x]) + red[1][threadIdx.x]) + red[2][threadIdx.x];
+        if (c < C) da[c] = (float)s;
+        else db[c - C] = (float)s;
+    }
+}
+
+static int ln_bwd_groups(long rows) { return (int)(rows + 3) / 4 < 256 ? (int)((rows + 3) / 4) : 256; }
+
+extern "C" size_t l3d_layernorm_backward_workspace_floats(long rows, int C) { return (size_t)ln_bwd_groups(rows) * 2 * C; }
+
+// x, g [rows][C]; a [C]; dx [rows][C]; da, db [C]; workspace: l3d_layernorm_backward_workspace_floats(rows, C) floats
+extern "C" int l3d_layernorm_ref_backward(const float *x, const float *a, const float *g, float eps, long rows, int C, float *dx,
+                                          float *workspace, float *da, float *db, l3d_stream_t stream)
+{
+    L3D_REQUIRE(x && a && g && dx && workspace && da && db && rows > 0 && C > 1);
+    if (C % 4 || C > 2048 || ((((size_t)x) | ((size_t)g) | ((size_t)dx) | ((size_t)a) | ((size_t)workspace)) & 15)) return L3D_ERR_UNSUPPORTED;
+    const int G = ln_bwd_groups(rows);
+    dim3 grid((unsigned)G), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)3 * 2 * C * sizeof(float);
+    const int vpl = (C / 4 + 63) / 64;
+    if (vpl <= 1)      hipLaunchKernelGGL(layernorm_ref_backward_kernel<1>, grid, block, lds, st, x, a, g, eps, rows, C, dx, workspace);
+    else if (vpl <= 2) hipLaunchKernelGGL(layernorm_ref_backward_kernel<2>, grid, block, lds, st, x, a, g, eps, rows, C, dx, workspace);
+    else if (vpl <= 4) hipLaunchKernelGGL(layernorm_ref_backward_kernel<4>, grid, block, lds, st, x, a, g, eps, rows, C, dx, workspace);
+    else               hipLaunchKernelGGL(layernorm_ref_backward_kernel<8>, grid, block, lds, st, x, a, g, eps, rows, C, dx, workspace);
+    int rc = l3d_check_launch();
+    if (rc != L3D_OK) return rc;
+    hipLaunchKernelGGL(layernorm_param_reduce_kernel, dim3((unsigned)l3d_divup(2 * C, 64)), dim3(256), 0, st, workspace, G, C, da, db);
+    return l3d_check_launch();
+}

@@ -273,6 +273,49 @@ def max_over_last(x):
     return x.max(dim=-1, keepdim=True)[0]
 
 
+class _LayerNormRef(torch.autograd.Function):
+    """The pointer network's LayerNorm (reference utils/transformer.py:109-119: unbiased std, eps added to std) over the last
+    axis: l3d_layernorm_ref forward, l3d_layernorm_ref_backward (one pass over x and dy; da / db summed in a fixed order)."""
+
+    @staticmethod
+    def forward(ctx, x, a, b, eps):
+        xc = f32c(x)
+        C_ = xc.shape[-1]
+        rows = xc.numel() // C_
+        y = torch.empty_like(xc)
+        ac, bc = f32c(a.detach()), f32c(b.detach())
+        with on_device_of(xc):
+            check(lib().l3d_layernorm_ref(ptr(xc), ptr(ac), ptr(bc), float(eps), rows, C_, ptr(y), stream_ptr()), "l3d_layernorm_ref")
+        ctx.save_for_backward(xc, ac)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, ac = ctx.saved_tensors
+        g = f32c(g)
+        C_ = xc.shape[-1]
+        rows = xc.numel() // C_
+        dx = torch.empty_like(xc)
+        da = torch.empty(C_, dtype=torch.float32, device=xc.device)
+        db = torch.empty(C_, dtype=torch.float32, device=xc.device)
+        ws = torch.empty(lib().l3d_layernorm_backward_workspace_floats(rows, C_), dtype=torch.float32, device=xc.device)
+        with on_device_of(xc):
+            check(lib().l3d_layernorm_ref_backward(ptr(xc), ptr(ac), ptr(g), ctx.eps, rows, C_, ptr(dx), ptr(ws), ptr(da), ptr(db),
+                                                   stream_ptr()), "l3d_layernorm_ref_backward")
+        return dx, da, db, None
+
+
+def layer_norm_ref(x, a, b, eps):
+    """a * (x - mean) / (std + eps) + b over the last axis (unbiased std), differentiable, on the HIP kernels where they apply"""
+    C_ = x.shape[-1]
+    if hip_layers_ok(x) and C_ % 4 == 0 and 1 < C_ <= 2048 and x.numel() > 0:
+        return _LayerNormRef.apply(x, a, b, eps)
+    mean = x.mean(-1, keepdim=True)
+    std = x.std(-1, keepdim=True)
+    return a * (x - mean) / (std + eps) + b
+
+
 def hip_layers_ok(x):
     """the HIP differentiable layers apply: fp32 tensors on the GPU, switched on (_fused.TRAIN_HIP)"""
     return _fused.TRAIN_HIP and x.is_cuda and x.dtype == torch.float32

@@ -7,6 +7,7 @@ epilogue; its [B,Cout,N] output layout is consumed as is (heads become [B,h,d_k,
 matmuls take the transposes for free), the attention itself is one flash-style kernel
 (`l3d_attention_forward`, no [B,h,N,N] score tensor) and LayerNorm one fused kernel (`l3d_layernorm_ref`)."""
 import copy
+import os
 import math
 
 import torch
@@ -18,6 +19,11 @@ FLASH_ATTENTION = True      # l3d_attention_forward for d_k in {32, 64, 128}; Fa
 DEFER_LN_VALUES = True      # sublayer norms write only their fp16 plane image; fp32 values on demand (_ln_values)
 PROJECTION_MAXIMA = True    # the f16x2 q|k|v projections report max|q|, |k|, |v| from their epilogues (False: a pass over q, k, v)
 ATTENTION_F16B = True       # f16x2 attention on the restructured kernel (attention_f16b.hip); False: attention_f16.hip
+# autograd live: the nn.Linear layers of the torch route on the HIP conv / dgrad / wgrad kernels (_train.linear_act).  Correct and
+# tested, but OFF: a DCP training step (B 8, N 1024, emb 512) takes 25.6 ms with it against 20.4 ms on rocBLAS -- the layers are
+# [rows, C] x [C, C'] with rows in the last axis' place, and the two transposed copies per layer and direction cost more than the
+# GEMMs save (LABLOG R3.22).  LayerNorm's HIP forward / backward is independent of this switch.
+TRAIN_LINEAR_HIP = os.environ.get("L3D_TRAIN_LINEAR_HIP", "0") != "0"
 CHANNEL_FIRST_PASS = True   # a whole encoder-decoder pass in the [B,C,N] layout the GEMMs write (Transformer._pass_cf); False: module by module
 
 _ATT_WS = {}
@@ -161,6 +167,10 @@ class LayerNorm(nn.Module):
             check(lib().l3d_layernorm_ref(ptr(xc), ptr(self.a_2.detach().contiguous()), ptr(self.b_2.detach().contiguous()),
                                           float(self.eps), rows, C, ptr(y), stream_ptr()), "l3d_layernorm_ref")
             return y
+        if x.is_cuda:
+            # autograd live (a training step, or the recompute of a checkpointed forward): HIP forward + one-pass HIP backward
+            from ..models._train import layer_norm_ref
+            return layer_norm_ref(x, self.a_2, self.b_2, self.eps)
         mean = x.mean(-1, keepdim=True)
         std = x.std(-1, keepdim=True)
         return self.a_2 * (x - mean) / (std + self.eps) + self.b_2
@@ -194,6 +204,17 @@ class SublayerConnection(nn.Module):
                   "l3d_add_transposed")
             return out
         return x + y
+
+
+def _lin(lin, x, relu=False):
+    """lin(x) (+ ReLU) where autograd is live (a training step, or the recompute behind a checkpointed forward): the GEMM, its
+    dgrad and its wgrad on the HIP layer kernels when they apply (models/_train.linear_act), torch's otherwise."""
+    if TRAIN_LINEAR_HIP and x.is_cuda and torch.is_grad_enabled() and type(lin) is nn.Linear and lin.bias is not None:
+        from ..models._train import hip_layers_ok, linear_act
+        if hip_layers_ok(x) and x.numel() > 0:
+            return linear_act(x, lin, relu=relu)
+    y = lin(x)
+    return F.relu(y) if relu else y
 
 
 class MultiHeadedAttention(nn.Module):
@@ -290,11 +311,11 @@ class MultiHeadedAttention(nn.Module):
                 p = F.softmax(torch.matmul(qh.transpose(-2, -1), kh) / math.sqrt(self.d_k), dim=-1)   # [B,h,N,M]
                 ctx = torch.matmul(vh, p.transpose(-2, -1)).reshape(nb, C_, n_q)
             return _linear_cf(self.linears[-1], ctx, False).transpose(1, 2)                       # [B,N,C] view
-        q, k, v = [lin(_ln_values(x)).view(nb, -1, self.h, self.d_k).transpose(1, 2)
+        q, k, v = [_lin(lin, _ln_values(x)).view(nb, -1, self.h, self.d_k).transpose(1, 2)
                    for lin, x in zip(self.linears, (query, key, value))]
         x, self.attn = attention(q, k, v, mask=mask, dropout=self.dropout)
         x = x.transpose(1, 2).contiguous().view(nb, -1, self.h * self.d_k)
-        return self.linears[-1](x)
+        return _lin(self.linears[-1], x)
 
 
 class PositionwiseFeedForward(nn.Module):
@@ -316,7 +337,7 @@ class PositionwiseFeedForward(nn.Module):
                     return _linear_cf(self.w_2, None, True, planes=hp).transpose(1, 2)
             h = _linear_cf(self.w_1, x, True, relu=True)                  # [B,d_ff,N]
             return _linear_cf(self.w_2, h, False).transpose(1, 2)         # [B,N,d_model] view
-        return self.w_2(F.relu(self.w_1(_ln_values(x))))
+        return _lin(self.w_2, _lin(self.w_1, _ln_values(x), relu=True))
 
 
 class EncoderLayer(nn.Module):

@@ -156,6 +156,81 @@ def test_max_over_last_matches_torch():
     assert torch.isnan(_train.max_over_last(nanrow)).all()
 
 
+def test_layernorm_hip_forward_backward_vs_fp64():
+    """The pointer network's LayerNorm with autograd live (utils/transformer.py:109-119: unbiased std, eps added to std): HIP forward
+    + one-pass HIP backward (_train._LayerNormRef) against the reference's op sequence differentiated in fp64 -- y, dx, da, db within
+    1e-5 of their scale -- and against the same sequence in fp32 torch ops; da / db bit-identical from run to run."""
+    from learning3d_amd.utils.transformer import LayerNorm
+    g = torch.Generator().manual_seed(5)
+    for shape in [(2, 256, 512), (3, 77, 64), (1, 5, 2048), (4, 100, 12), (8, 1024, 512)]:
+        C_ = shape[-1]
+        ln = LayerNorm(C_).cuda()
+        with torch.no_grad():
+            ln.a_2.copy_(torch.randn(C_, generator=g) * 0.5 + 1.0)
+            ln.b_2.copy_(torch.randn(C_, generator=g) * 0.3)
+        x = (torch.randn(shape, generator=g) * 2.0 + 0.7).cuda().requires_grad_()
+        w = torch.randn(shape, generator=g).cuda()
+        with _lib_log() as log:
+            y = ln(x)
+            (y * w).sum().backward()
+        assert log == ["l3d_layernorm_ref", "l3d_layernorm_ref_backward"], log
+        x64 = x.detach().double().requires_grad_()
+        a64, b64 = ln.a_2.detach().double().requires_grad_(), ln.b_2.detach().double().requires_grad_()
+        y64 = a64 * (x64 - x64.mean(-1, keepdim=True)) / (x64.std(-1, keepdim=True) + ln.eps) + b64
+        (y64 * w.double()).sum().backward()
+        for name, got, want in (("y", y.detach(), y64.detach()), ("dx", x.grad, x64.grad), ("da", ln.a_2.grad, a64.grad),
+                                ("db", ln.b_2.grad, b64.grad)):
+            err = float((got.double() - want).abs().max())
+            assert err <= 1e-5 * float(want.abs().max()), (shape, name, err, float(want.abs().max()))
+        da1, db1 = ln.a_2.grad.clone(), ln.b_2.grad.clone()
+        ln.zero_grad(); x.grad = None
+        (ln(x) * w).sum().backward()
+        assert torch.equal(da1, ln.a_2.grad) and torch.equal(db1, ln.b_2.grad)
+    # switched off: the reference's torch ops
+    from learning3d_amd.models import _fused
+    old = _fused.TRAIN_HIP
+    _fused.TRAIN_HIP = False
+    try:
+        with _lib_log() as log:
+            (ln(x) * w).sum().backward()
+        assert log == [], log
+    finally:
+        _fused.TRAIN_HIP = old
+
+
+@pytest.mark.parametrize("linear_hip", [False, True])
+def test_pointer_network_training_gradients_vs_fp64(linear_hip, monkeypatch):
+    """utils/transformer.py Transformer with autograd live (examples/train_dcp.py): LayerNorm on its HIP forward / backward kernels,
+    the nn.Linear layers on rocBLAS (default) or on the HIP layer kernels (TRAIN_LINEAR_HIP: forward, dgrad, wgrad), the attention
+    core on torch ops.  Outputs and every parameter / input gradient against the same module in fp64 (its torch route, which is the
+    reference's op sequence): within 2e-5 of the gradient's scale (gradients that are zero by symmetry -- the key projection's bias
+    under the softmax -- against the largest gradient)."""
+    import copy
+    from learning3d_amd.utils import transformer as T
+    monkeypatch.setattr(T, "TRAIN_LINEAR_HIP", linear_hip)
+    torch.manual_seed(11)
+    net = T.Transformer(64, 1, 0.0, 128, 4).cuda().train()
+    net64 = copy.deepcopy(net).double()
+    g = torch.Generator().manual_seed(12)
+    src = torch.randn((2, 64, 256), generator=g).cuda().requires_grad_()
+    tgt = torch.randn((2, 64, 256), generator=g).cuda().requires_grad_()
+    w0, w1 = torch.randn((2, 64, 256), generator=g).cuda(), torch.randn((2, 64, 256), generator=g).cuda()
+    with _lib_log() as log:
+        a, b = net(src, tgt)
+        ((a * w0).sum() + (b * w1).sum()).backward()
+    assert "l3d_layernorm_ref_backward" in log and ("l3d_wgrad" in log) == linear_hip, log
+    s64, t64 = src.detach().double().requires_grad_(), tgt.detach().double().requires_grad_()
+    a64, b64 = net64(s64, t64)
+    ((a64 * w0.double()).sum() + (b64 * w1.double()).sum()).backward()
+    gmax = max(float(q.grad.abs().max()) for q in net64.parameters())
+    for name, got, want in [("src_emb", a.detach(), a64.detach()), ("tgt_emb", b.detach(), b64.detach()), ("d src", src.grad, s64.grad),
+                            ("d tgt", tgt.grad, t64.grad)] + [(n, p.grad, q.grad) for (n, p), (_, q) in
+                                                              zip(net.named_parameters(), net64.named_parameters())]:
+        assert got is not None and want is not None, name
+        err = float((got.double() - want).abs().max())
+        assert err <= 2e-5 * float(want.abs().max()) + 1e-7 * gmax, (name, err, float(want.abs().max()), gmax)
+
+
 class _lib_log:
     def __enter__(self):
         from learning3d_amd import _lib

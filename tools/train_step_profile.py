@@ -112,5 +112,6 @@ def extra(which):
 
 
 if __name__ == "__main__":
-    main()
-    extra(sys.argv[1:])
+    if "--only" not in sys.argv:                   # `--only dcp flownet`: just the named extra steps
+        main()
+    extra([a for a in sys.argv[1:] if a != "--only"])
