@@ -71,6 +71,12 @@ with torch.no_grad():
         d2, ii = P.knn(kk, dev(xyz), dev(other))
         od2, oi = oracle.knn_pair(kk, xyz, other)
         assert np.array_equal(ii.cpu().numpy(), oi) and np.array_equal(d2.cpu().numpy(), od2), ("knn_pair", B, N, M, kk); ok("knn_pair")
+        # the wave-per-query selection kernel's range (knn_select.hip: >= 1024 candidates or k > 32, k up to 200), few queries
+        Mb = int(rng.choice([1024, 1100, 2500, 4097, 8192])); big = cloud(B, Mb, int(rng.integers(0, 4)))
+        kb = int(rng.choice([1, 3, 16, 33, 64, 100, 200])); qn = xyz[:, :min(N, 150)]
+        d2b, iib = P.knn(kb, dev(qn), dev(big))
+        od2b, oib = oracle.knn_pair(kb, np.ascontiguousarray(qn), big)
+        assert np.array_equal(iib.cpu().numpy(), oib) and np.array_equal(d2b.cpu().numpy(), od2b), ("knn_pair big", B, N, Mb, kb); ok("knn_pair_select")
         d3, i3 = P.three_nn(dev(xyz), dev(other))
         od3, oi3 = oracle.three_nn(xyz, other)
         assert np.array_equal(i3.cpu().numpy(), oi3) and np.allclose(d3.cpu().numpy(), od3, rtol=0, atol=0), ("three_nn", B, N, M); ok("three_nn")
