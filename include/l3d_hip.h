@@ -174,9 +174,10 @@ int l3d_furthest_point_sampling(int b, int n, int m, const float *points, float 
  *   ascending, lowest index first on ties; slots beyond m hold (+inf, 0). k <= 200. */
 int l3d_knn(int b, int n, int m, int k, const float *unknown, const float *known, float *dist2,
             int32_t *idx, l3d_stream_t stream);
-/* the same with the kernel named: variant 0 = automatic (the wave-per-query selection kernel of knn_select.hip when
- * k <= m <= 8192 and (k > 32 or m >= 1024), the lane-per-query kernels of knn.hip otherwise), 1 = lane-per-query,
- * 2 = selection kernel (L3D_ERR_UNSUPPORTED unless k <= m <= 8192).  Results are identical; tests and tools use it. */
+/* the same with the kernel named: variant 0 = automatic (k <= 4 and >= 65 536 queries: the four-slot kernel of knn_small.hip; otherwise the
+ * wave-per-query selection kernel of knn_select.hip when k <= m <= 8192 and (k > 32 or m >= 1024), the lane-per-query kernels
+ * of knn.hip for the rest), 1 = lane-per-query, 2 = selection kernel (L3D_ERR_UNSUPPORTED unless k <= m <= 8192), 3 = four-slot
+ * kernel (k <= 4).  Results are identical; tests and tools use it. */
 int l3d_knn_variant(int b, int n, int m, int k, const float *unknown, const float *known, float *dist2,
                     int32_t *idx, int variant, l3d_stream_t stream);
 /* three_nn_wrapper(b,n,m,unknown,known,dist2,idx)   K14 interpolate_gpu.cu:81-124 */

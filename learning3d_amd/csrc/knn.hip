@@ -517,6 +517,10 @@ extern "C" int l3d_knn_graph(const float *xyz, int B, int N, int k, int64_t *idx
 // knn_select.hip: a wave per query, k-th distance from bucket minima + rank counting (33 <= k <= 200, m <= 8192)
 bool l3d_knn_select_supported(int Nc, int k);
 bool l3d_knn_select_preferred(int Nc, int k);
+// knn_small.hip: k <= 4 (three_nn), a query per lane with four sorted slots and a 32-candidate hit mask
+bool l3d_knn_small_supported(int Nc, int k);
+bool l3d_knn_small_preferred(long queries, int Nc, int k);
+int l3d_launch_knn_small(const float *q, const float *c, int B, int Nq, int Nc, int k, int out_mode, void *idx, float *val, hipStream_t st);
 int l3d_launch_knn_select(const float *q, const float *c, int B, int Nq, int Nc, int k, int out_mode, void *idx, float *val,
                           hipStream_t st);
 
@@ -524,8 +528,11 @@ extern "C" int l3d_knn_variant(int b, int n, int m, int k, const float *unknown,
                                float *dist2, int32_t *idx, int variant, l3d_stream_t stream)
 {
     L3D_REQUIRE(unknown && known && dist2 && idx && b > 0 && n > 0 && m > 0 && k > 0 &&
-                k <= L3D_KNN_MAX_K && variant >= 0 && variant <= 2);
+                k <= L3D_KNN_MAX_K && variant >= 0 && variant <= 3);
     if (variant == 2 && !l3d_knn_select_supported(m, k)) return L3D_ERR_UNSUPPORTED;
+    if (variant == 3 && !l3d_knn_small_supported(m, k)) return L3D_ERR_UNSUPPORTED;
+    if (variant == 3 || (variant == 0 && l3d_knn_small_preferred((long)b * n, m, k)))
+        return l3d_launch_knn_small(unknown, known, b, n, m, k, OUT_KNN_PAIR, idx, dist2, (hipStream_t)stream);
     if (variant == 2 || (variant == 0 && l3d_knn_select_preferred(m, k)))
         return l3d_launch_knn_select(unknown, known, b, n, m, k, OUT_KNN_PAIR, idx, dist2, (hipStream_t)stream);
     return launch_topk<METRIC_DIRECT>(unknown, known, b, n, m, k, OUT_KNN_PAIR, idx, dist2,
@@ -561,6 +568,8 @@ extern "C" int l3d_knn_point(int k, const float *pos1, const float *pos2, int B,
 {
     L3D_REQUIRE(pos1 && pos2 && val && idx && B > 0 && N > 0 && M > 0 && k > 0 && k <= N &&
                 k <= L3D_KNN_MAX_K);
+    if (l3d_knn_small_preferred((long)B * M, N, k))
+        return l3d_launch_knn_small(pos2, pos1, B, M, N, k, OUT_KNN_POINT, idx, val, (hipStream_t)stream);
     if (l3d_knn_select_preferred(N, k))
         return l3d_launch_knn_select(pos2, pos1, B, M, N, k, OUT_KNN_POINT, idx, val, (hipStream_t)stream);
     return launch_topk<METRIC_DIRECT>(pos2, pos1, B, M, N, k, OUT_KNN_POINT, idx, val,

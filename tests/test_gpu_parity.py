@@ -2201,3 +2201,33 @@ def test_knn_select_kernel_equals_lane_kernel(B, n, m, k):
     full = (dx[..., 0] * dx[..., 0] + dx[..., 1] * dx[..., 1]) + dx[..., 2] * dx[..., 2]
     order = torch.argsort(full, dim=-1, stable=True)[..., :k]
     assert torch.equal(i2.long(), order)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,n,m,k", [(2, 300, 1000, 3), (1, 8192, 1024, 3), (3, 257, 64, 1), (1, 100, 4100, 4), (2, 33, 2049, 2),
+                                     (2, 70, 5, 3), (1, 10, 2, 3), (9, 8192, 300, 3)])
+def test_knn_small_kernel_equals_lane_kernel(B, n, m, k):
+    """The four-slot kernel (variant 3: three_nn and knn with k <= 4) returns the lane-per-query kernel's (variant 1) squared
+    distances and indices bit for bit -- ascending, lowest index first on ties, (+inf, 0) in slots beyond the candidate count --
+    on uniform, sorted, gridded and single-point clouds; so does the automatic choice (this kernel from 65 536 queries up)."""
+    g = torch.Generator().manual_seed(m + k)
+    uni = torch.rand((B, m, 3), generator=g)
+    srt = torch.stack([c[torch.argsort(c[:, 0])] for c in torch.rand((B, m, 3), generator=g)])
+    grid = torch.round(torch.rand((B, m, 3), generator=g) * 3) / 3
+    same = torch.full((B, m, 3), 0.25)
+    for name, cl in (("uniform", uni), ("sorted", srt), ("grid", grid), ("same", same)):
+        cl = cl.cuda()
+        q = (torch.rand((B, n, 3), generator=g) if name != "grid" else torch.round(torch.rand((B, n, 3), generator=g) * 3) / 3).cuda()
+        d1, i1 = _knn_pair_variant(q, cl, k, 1)
+        d3, i3 = _knn_pair_variant(q, cl, k, 3)
+        assert torch.equal(i1, i3), name
+        assert torch.equal(d1, d3), name
+        d0, i0 = _knn_pair_variant(q, cl, k, 0)
+        assert torch.equal(i0, i3) and torch.equal(d0, d3), name
+    if m >= k:
+        cl, q = uni[:1].cuda(), torch.rand((1, n, 3), generator=g).cuda()
+        d3, i3 = _knn_pair_variant(q, cl, k, 3)
+        dx = q[:, :, None, :] - cl[:, None, :, :]
+        full = (dx[..., 0] * dx[..., 0] + dx[..., 1] * dx[..., 1]) + dx[..., 2] * dx[..., 2]
+        order = torch.argsort(full, dim=-1, stable=True)[..., :k]
+        assert torch.equal(i3.long(), order)
