@@ -77,6 +77,14 @@ with torch.no_grad():
         d2b, iib = P.knn(kb, dev(qn), dev(big))
         od2b, oib = oracle.knn_pair(kb, np.ascontiguousarray(qn), big)
         assert np.array_equal(iib.cpu().numpy(), oib) and np.array_equal(d2b.cpu().numpy(), od2b), ("knn_pair big", B, N, Mb, kb); ok("knn_pair_select")
+        # the four-slot kernel (knn_small.hip, k <= 4) named explicitly: the automatic choice takes it only from 65 536 queries up
+        from learning3d_amd._lib import check, lib, ptr, stream_ptr
+        ks = int(rng.integers(1, 5)); qd, cd = dev(xyz), dev(other)
+        sd = torch.empty((B, N, ks), device="cuda"); si = torch.empty((B, N, ks), dtype=torch.int32, device="cuda")
+        check(lib().l3d_knn_variant(B, N, M, ks, ptr(qd), ptr(cd), ptr(sd), ptr(si), 3, stream_ptr()), "l3d_knn_variant")
+        osd, osi = oracle.knn_pair(ks, xyz, other)
+        if M >= ks:                                       # (slots beyond the candidate count: (+inf, 0) here, unspecified in the oracle)
+            assert np.array_equal(si.cpu().numpy(), osi) and np.array_equal(np.sqrt(sd.cpu().numpy()), osd), ("knn_small", B, N, M, ks); ok("knn_small")
         d3, i3 = P.three_nn(dev(xyz), dev(other))
         od3, oi3 = oracle.three_nn(xyz, other)
         assert np.array_equal(i3.cpu().numpy(), oi3) and np.allclose(d3.cpu().numpy(), od3, rtol=0, atol=0), ("three_nn", B, N, M); ok("three_nn")

@@ -144,6 +144,8 @@ def main():
         t = timeit(lambda: check(lib().l3d_knn_variant(32, 1024, 8192, 64, ptr(new_xyz), ptr(xyz), ptr(kd), ptr(ki), 1,
                                                        stream_ptr()), "l3d_knn_variant"), warm=1, iters=3)
         res["knn_pair_k64_c5_lane_kernel"] = (t, 32 * 1024 * 8192 / t / 1e3, "Gpair/s")
+        t = timeit(lambda: P.three_nn(xyz, new_xyz))          # the last feature-propagation layer: 8192 queries x 1024 candidates
+        res["three_nn_c5"] = (t, 32 * 8192 * 1024 / t / 1e3, "Gpair/s")
         l2 = new_xyz[:, :256].contiguous()                   # FlowEmbedding's own shape: 256 x 256 points, nsample 64
         t = timeit(lambda: P.knn(64, l2, l2))
         res["knn_pair_k64_256x256"] = (t, 32 * 256 * 256 / t / 1e3, "Gpair/s")
