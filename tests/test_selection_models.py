@@ -1,10 +1,13 @@
-"""CPU models of two round-3 kernels' ALGORITHMS (no GPU, no library call): what the HIP code relies on is checked here in numpy /
+"""CPU models of three round-3 kernels' ALGORITHMS (no GPU, no library call): what the HIP code relies on is checked here in numpy /
 torch-fp64, the kernels themselves in tests/test_gpu_parity.py, test_gpu_ref_kernels.py and test_gpu_grad_routes.py.
 
 * knn_select.hip (pointnet2 `knn_kernel_fast`, utils/lib/src/interpolate_gpu.cu:9-57, for large k or many candidates): the bound from
   256 bucket minima is valid for every cloud (>= k candidates reach it), its bisection ends inside [k, k + 8] buckets or at an exact
   value, the survivors' rank count is the reference's order (ascending squared distance, lowest index first), and the exact
   two-bisection path leaves exactly k survivors under heavy ties.
+* knn_small.hip (three_nn / k <= 4, interpolate_gpu.cu:81-124): a lane's 32-candidate hit mask is built against the k-th best at the TOP of
+  the block (stale inside it), hits are popped lowest index first and inserted with a strict '<' into four sorted slots -- the result is
+  still the stable order, and slots beyond the candidate count keep (+inf, 0).
 * l3d_layernorm_ref_backward (utils/transformer.py:109-119: unbiased std, eps added to std): the closed form the kernel evaluates
   equals autograd of the reference's op sequence."""
 import numpy as np
@@ -128,3 +131,49 @@ def test_layernorm_backward_closed_form():
         assert torch.allclose(dx, x.grad, rtol=1e-10, atol=1e-12)
         assert torch.allclose(da, a.grad, rtol=1e-10, atol=1e-12)
         assert torch.allclose(db, b.grad, rtol=1e-10, atol=1e-12)
+
+
+def _small_model(q, c, k):
+    """one lane of knn_small_kernel"""
+    d2, bits = _dist_bits(q, c)
+    bd = [np.float32(np.inf)] * 4
+    bi = [0] * 4
+    thr = np.uint32(0x7F800000)
+    pops = 0
+    for g0 in range(0, len(c), 32):
+        blk = range(g0, min(g0 + 32, len(c)))
+        hits = [j for j in blk if bits[j] < thr]                           # the mask: against the threshold at the top of the block
+        for j in hits:                                                     # popped highest bit = lowest index first
+            pops += 1
+            d = d2[j]
+            c3, c2, c1, c0 = d < bd[3], d < bd[2], d < bd[1], d < bd[0]
+            bd[3], bi[3] = (bd[2], bi[2]) if c2 else ((d, j) if c3 else (bd[3], bi[3]))
+            bd[2], bi[2] = (bd[1], bi[1]) if c1 else ((d, j) if c2 else (bd[2], bi[2]))
+            bd[1], bi[1] = (bd[0], bi[0]) if c0 else ((d, j) if c1 else (bd[1], bi[1]))
+            bd[0], bi[0] = (d, j) if c0 else (bd[0], bi[0])
+        if hits:
+            thr = np.float32(bd[k - 1]).view(np.uint32)
+    return np.array(bi[:k]), np.array(bd[:k], np.float32), d2, pops
+
+
+def test_knn_small_algorithm_model():
+    rng = np.random.default_rng(9)
+    for (m, k, kind) in [(1024, 3, "uniform"), (1000, 4, "grid"), (300, 1, "uniform"), (70, 2, "same"), (2, 3, "uniform"), (2049, 3, "sorted")]:
+        if kind == "uniform":
+            c = rng.uniform(-1, 1, (m, 3))
+        elif kind == "sorted":
+            c = rng.uniform(-1, 1, (m, 3)); c = c[np.argsort(c[:, 0])]
+        elif kind == "grid":
+            c = rng.integers(0, 4, (m, 3)) / 3.0
+        else:
+            c = np.full((m, 3), 0.25)
+        c = c.astype(np.float32)
+        for qi in range(5):
+            q = c[rng.integers(0, m)] if qi % 2 else rng.uniform(-1, 1, 3).astype(np.float32)
+            idx, val, d2, pops = _small_model(q, c, k)
+            order = np.argsort(d2, kind="stable")[:k]
+            n = min(k, m)
+            assert np.array_equal(idx[:n], order[:n]) and np.array_equal(val[:n], d2[order[:n]]), (m, k, kind)
+            assert all(np.isinf(val[n:])) and all(idx[n:] == 0)            # slots beyond the candidate count: (+inf, 0)
+            if kind == "uniform" and m >= 1024:
+                assert pops <= 32 + 12 * k * int(np.log2(m / 32) + 1)      # the stale threshold costs a few extra pops, not a rescan
