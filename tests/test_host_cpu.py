@@ -58,6 +58,15 @@ def test_argument_validation_without_gpu():
     assert l.l3d_pointwise_conv_f16_absmax(p, p, None, None, 0, 1, 128, 256, 256, 0, p, p, 100, None) == -2        # group size % 256
     assert l.l3d_attention_forward_f16_maxima(None, None, None, 1, 4, 128, 256, 256, 0, 0, 0, 0.1, None, None, None, None) == -1
     assert l.l3d_layernorm_planes(p, p, p, 1e-6, 4, 520, None, p, None) == -2                                      # C > 512
+    # round-3 entry points
+    assert l.l3d_knn_variant(1, 8, 8, 4, p, p, p, p, 7, None) == -1                                                # no such variant
+    assert l.l3d_knn_variant(1, 8, 8, 4, None, p, p, p, 0, None) == -1
+    assert l.l3d_knn_variant(1, 8, 9000, 64, p, p, p, p, 2, None) == -2                                            # selection kernel: <= 8192 candidates
+    assert l.l3d_knn_variant(1, 8, 64, 5, p, p, p, p, 3, None) == -2                                               # four-slot kernel: k <= 4
+    assert l.l3d_layernorm_ref_backward(None, p, p, 1e-6, 4, 64, p, p, p, p, None) == -1
+    assert l.l3d_layernorm_ref_backward(p, p, p, 1e-6, 4, 66, p, p, p, p, None) == -2                              # C % 4
+    assert l.l3d_layernorm_backward_workspace_floats(8192, 512) == 256 * 2 * 512
+    assert l.l3d_layernorm_backward_workspace_floats(6, 64) == 2 * 2 * 64
 
 
 def test_product_path_fails_loudly_on_cpu_tensors():
