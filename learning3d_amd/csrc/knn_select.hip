@@ -1,7 +1,7 @@
 // knn_select.hip -- k nearest of a query among up to 8192 candidates, a WAVE per query, direct metric (k <= 200).
 //
-// Replaces, for k > 32 or 1024+ candidates:
-//   K13 knn_kernel_fast   utils/lib/src/interpolate_gpu.cu:9-57   (FlowEmbedding's nsample = 64, flownet3d.py:93-123; three_nn :81-124)
+// Replaces, for k > 32 or 1024+ candidates (k <= 4 with very many queries goes to knn_small.hip):
+//   K13 knn_kernel_fast   utils/lib/src/interpolate_gpu.cu:9-57   (FlowEmbedding's nsample = 64, flownet3d.py:93-123)
 //   T8  knn_point()       utils/model_common_utils.py:84-100
 //
 // knn.hip keeps a query per LANE with its sorted best-K list in registers; at K = 64 that is 64+ VALU operations per
@@ -15,8 +15,9 @@
 //   * an upper bound T0 of the k-th smallest distance comes from 256 BUCKET MINIMA (bucket = candidate index mod 256, so a
 //     spatially sorted cloud still spreads over all buckets): k buckets whose minimum is <= T0 are k distinct candidates
 //     <= T0.  T0 is found by bisection on the bit pattern with wave-wide ballot counts (4 compares per step) and stops as
-//     soon as the count lies in [k, k + 8]: about 1.2 k candidates of 8192 survive;
-//   * survivors (d <= T0) are compacted into a per-wave LDS list with ballot prefix positions and ranked by counting:
+//     soon as the count lies in [k, k + 8]: about 1.2 x k candidates survive (79 of 8192 at k = 64);
+//   * survivors (d <= T0) are marked per lane (v_sub + v_alignbit), popped four per trip, recomputed from LDS, appended to a
+//     per-wave LDS list at ballot prefix positions and ranked by counting:
 //     rank = number of survivors with a smaller (distance, index) key; rank < k writes slot `rank` — ascending distance,
 //     lowest index first on ties, the reference's order;
 //   * if more than KS_CAP candidates survive (heavy duplication), the exact k-th key is found by two bisections over the
