@@ -16,6 +16,8 @@
 #include "split_f16.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void *ff_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *ff_gbl_ptr_t;
 
 #define FF_C 512                        // conv5 out = conv6 in = conv6 out
 #define FF_REGION (256 * 16 + 64)
@@ -26,7 +28,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 template <int CG>
 __global__ __launch_bounds__(512) void fold_mlp_f16_kernel(const float *__restrict__ g /*[B][N][CG]*/,
-                                                           const float *w5g /*[512][CG]*/, const float *s5 /*[B][512]*/,
+                                                           const float *__restrict__ w5g /*[512][CG]*/, const float *__restrict__ s5 /*[B][512]*/,
                                                            const uint4 *__restrict__ wH, const uint4 *__restrict__ wHs,
                                                            const uint4 *__restrict__ wM /*planes [64 octets][512 rows]*/,
                                                            const float *__restrict__ winv, const float *__restrict__ b6,
@@ -49,7 +51,10 @@ __global__ __launch_bounds__(512) void fold_mlp_f16_kernel(const float *__restri
     for (int c = 0; c < CG; c++) gv[c] = g[((size_t)b * N + xn) * CG + c];
     const float *s5b = s5 + (size_t)b * FF_C;
     const int wrow = t & 255, wkg = t >> 8;
-    const int w_lds = wkg * FF_REGION + wrow * 16;
+    // W6 cells go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write): a wave's 64 rows of one octet are
+    // 1 KB at a wave-uniform LDS address; the weights of chunk kc + 2 are requested at the top of chunk kc and waited for two
+    // barriers later
+    const int w_lds = __builtin_amdgcn_readfirstlane(wkg * FF_REGION + (wrow & ~63) * 16);
     const int x_lds = 4 * FF_REGION + xkg * FF_REGION + xrow * 16;
 
     for (int i = t; i < FF_C; i += 512)
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(512) void fold_mlp_f16_kernel(const float *__restri
     float gvu[CG];                                                    // g 2^T: the generated h5 comes out in plane units
 #pragma unroll
     for (int c = 0; c < CG; c++) gvu[c] = gv[c] * up;
-    uint4 w0, w2, x0, x1;
+    uint4 x0, x1;
     float part[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};           // conv7 partial sums, 2 point columns per lane
 
     const int frag_kg = (lane >> 5) * FF_REGION;
@@ -125,16 +130,16 @@ __global__ __launch_bounds__(512) void fold_mlp_f16_kernel(const float *__restri
             af_split_x_unscaled_cvt(hv_[4], hv_[5], x0.z, x1.z);                                      \
             af_split_x_unscaled_cvt(hv_[6], hv_[7], x0.w, x1.w);                                      \
         } while (0)
-#define FF_LOAD_W(KC)                                                                                 \
+#define FF_DMA_W(KC, BUF)                                                                             \
         do {                                                                                          \
-            w0 = wH[wofs + (size_t)(KC) * 2 * FF_C];                                                  \
-            w2 = wM[wofs + (size_t)(KC) * 2 * FF_C];                                                  \
+            unsigned char *base_ = lds + (BUF) * FF_BUF + w_lds;                                      \
+            __builtin_amdgcn_global_load_lds((ff_gbl_ptr_t)(wH + wofs + (size_t)(KC) * 2 * FF_C), (ff_lds_ptr_t)base_, 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((ff_gbl_ptr_t)(wM + wofs + (size_t)(KC) * 2 * FF_C),     \
+                                             (ff_lds_ptr_t)(base_ + 2 * FF_REGION), 16, 0, 0);        \
         } while (0)
 #define FF_STORE(BUF)                                                                                 \
         do {                                                                                          \
             unsigned char *base_ = lds + (BUF) * FF_BUF;                                              \
-            *(uint4 *)(base_ + w_lds) = w0;                                                           \
-            *(uint4 *)(base_ + w_lds + 2 * FF_REGION) = w2;                                           \
             *(uint4 *)(base_ + x_lds) = x0;                                                           \
             *(uint4 *)(base_ + x_lds + 2 * FF_REGION) = x1;                                           \
         } while (0)
@@ -148,15 +153,17 @@ __global__ __launch_bounds__(512) void fold_mlp_f16_kernel(const float *__restri
                 for (int r = 0; r < 16; r++) acc[a][c][r] = 0.f;
 
         __syncthreads();                       // previous half's reads of the chunk buffers (and the W7 image) are done / visible
-        FF_LOAD_W(0); FF_GEN_X(0); FF_STORE(0);
-        FF_LOAD_W(1); FF_GEN_X(1); FF_STORE(1);
+        FF_DMA_W(0, 0); FF_DMA_W(1, 1);
+        FF_GEN_X(0); FF_STORE(0);
+        FF_GEN_X(1); FF_STORE(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int buf = 0;
 #pragma unroll 1
         for (int kc = 0; kc < nk; kc++) {
             const bool more = kc + 2 < nk;
             const int wbuf = buf == 0 ? 2 : buf - 1;                  // (kc + 2) % 3
-            if (more) FF_LOAD_W(kc + 2);
+            if (more) FF_DMA_W(kc + 2, wbuf);     // buffer (kc + 2) % 3 was read last in chunk kc - 1: every wave is past that barrier
             const unsigned char *base = lds + buf * FF_BUF;
             f16x8 Bf[2][2];
 #pragma unroll
@@ -176,16 +183,18 @@ __global__ __launch_bounds__(512) void fold_mlp_f16_kernel(const float *__restri
 #pragma unroll
                     for (int c = 0; c < 2; c++)
                         acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a], Bf[c][pb], acc[a][c], 0, 0, 0);
-                if (prod == 1 && more) {        // generate + store chunk kc+2 under the MFMAs
-                    FF_GEN_X(kc + 2);
-                    FF_STORE(wbuf);
-                }
+                if (prod == 1 && more) FF_GEN_X(kc + 2);       // generate chunk kc+2's h5 under the MFMAs ...
             }
+            if (more) FF_STORE(wbuf);                              // ... and store it behind the last product
+            // chunk kc + 1's weights (requested one chunk ago) have landed before anybody reads them; this chunk's two requests may stay in flight
+            if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
             __syncthreads();
             buf = buf == 2 ? 0 : buf + 1;
         }
 #undef FF_GEN_X
-#undef FF_LOAD_W
+#undef FF_DMA_W
 #undef FF_STORE
 
         // ---- conv6 epilogue + conv7: h6 = relu(acc 2^-(S+T) + b6); part[c][j] += W7[j][co] * h6[co][col c]
