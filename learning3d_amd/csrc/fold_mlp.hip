@@ -24,7 +24,7 @@
 
 template <int CG>
 __global__ __launch_bounds__(512) void fold_mlp_kernel(const float *__restrict__ g /*[B][N][CG]*/,
-                                                       const float *w5g /*[512][CG]*/, const float *s5 /*[B][512]*/,
+                                                       const float *__restrict__ w5g /*[512][CG]*/, const float *__restrict__ s5 /*[B][512]*/,
                                                        const uint4 *__restrict__ w6s /*split [32][3][2][512][8]*/,
                                                        const float *__restrict__ b6, const float *__restrict__ w7 /*[3][512]*/,
                                                        const float *__restrict__ b7, const float *__restrict__ centre /*[B][N][3]*/,
