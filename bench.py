@@ -13,8 +13,8 @@ DGCNN(emb_dims=1024).eval() forward on x[32,1024,3] (fused kNN -> fused EdgeConv
 all hand-written HIP) followed by ChamferDistanceLoss()(a[32,1024,3], b[32,1024,3]) including, for
 N>1, the all_gather of the per-shard loss partial sums (weak scaling: 32 clouds per GPU).
 Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (dominant kernel:
-the EdgeConv MFMA kernel; live HIP-event timing) and `cpu_baseline` (the oracle port of the
-reference's CPU path on this box's host cores, bounded sample; N=1 only).
+the EdgeConv MFMA kernel; live HIP-event timing) and `cpu_baseline` (the reference's own CPU
+op sequence -- matmul/topk kNN, torch convs, torch-fallback Chamfer -- on this box's host cores, on rank 0's tensors; N=1 only).
 """
 import argparse
 import json
@@ -136,44 +136,117 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(sample_clouds=B_PER_GPU, repeats=2):
-    """The oracle port of the reference's CPU path (torch CPU ops for the conv stack exactly as
-    models/dgcnn.py does them, C restatement of knn / nnsearch), timed on this box's host cores."""
-    import numpy as np
+def cpu_baseline(sample_clouds=B_PER_GPU, repeats=2, seed=1000):
+    """The reference's own CPU op sequence, timed on this box's host cores: oracle.dgcnn_forward_refops (matmul + topk kNN,
+    utils/model_common_utils.py:3-9; the row-gather / repeat / cat graph feature, :132-156; Conv2d / BatchNorm2d / ReLU / max
+    as models/dgcnn.py:34-48) + oracle.chamfer_loss_refops (the torch fallback of losses/chamfer_distance.py:5-31), on the
+    SAME seeded tensors and weights the GPU side of rank 0 runs (generator seed 1000, torch.manual_seed(1) for the weights).
+    The scalar C restatements (oracle.knn, oracle.chamfer_loss) stay what they are: the checker."""
     import oracle
     ncores = os.cpu_count() or 1
     torch.manual_seed(1)
     from learning3d_amd.models import DGCNN
     net = DGCNN(emb_dims=EMB).eval()
     w = {k: v.numpy() for k, v in net.state_dict().items()}
-    g = torch.Generator().manual_seed(0)
-    x = torch.rand((sample_clouds, NPTS, 3), generator=g).numpy()
-    a = torch.rand((sample_clouds, NPTS, 3), generator=g).numpy()
-    b = torch.rand((sample_clouds, NPTS, 3), generator=g).numpy()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand((B_PER_GPU, NPTS, 3), generator=g)[:sample_clouds].numpy()
+    a = torch.rand((B_PER_GPU, NPTS, 3), generator=g)[:sample_clouds].numpy()
+    b = torch.rand((B_PER_GPU, NPTS, 3), generator=g)[:sample_clouds].numpy()
+    loss = [None]
+
     def run(xs, as_, bs):
         t0 = time.perf_counter()
-        oracle.dgcnn_forward_torch(xs, w, k=KNN)
-        oracle.chamfer_loss(as_, bs)
+        oracle.dgcnn_forward_refops(xs, w, k=KNN)
+        loss[0] = float(oracle.chamfer_loss_refops(as_, bs))
         return time.perf_counter() - t0
 
     with torch.no_grad():
-        # pick the torch thread count that serves the reference's CPU path best on this host
-        # (all cores is not it: at 256 threads the small conv/BN ops oversubscribe)
+        # the torch thread count that serves the reference's CPU path best on this host, all logical CPUs included
+        # (on a 256-thread host the small conv / BN ops oversubscribe at 256; the reference user would set OMP_NUM_THREADS too)
         tried = {}
-        for nthr in sorted({ncores, max(1, ncores // 2), 64, 32, 16, 8} & set(range(1, ncores + 1)), reverse=True):
+        for nthr in sorted({ncores, max(1, ncores // 2), max(1, ncores // 4), 64, 32, 16, 8} & set(range(1, ncores + 1)), reverse=True):
             torch.set_num_threads(nthr)
-            run(x[:2], a[:2], b[:2])
-            tried[nthr] = run(x[:2], a[:2], b[:2])
+            run(x[:4], a[:4], b[:4])
+            tried[nthr] = run(x[:4], a[:4], b[:4])
         nthr = min(tried, key=tried.get)
         torch.set_num_threads(nthr)
         best = float("inf")
         for _ in range(1 + repeats):              # first iteration is the warm-up
             best = min(best, run(x, a, b))
-    return {"value": sample_clouds / best, "unit": "clouds/s", "cores": nthr, "kind": "port",
-            "host_cpus": ncores, "cpu_model": cpu_model(),
-            "sample": f"{sample_clouds} clouds x N={NPTS} (DGCNN emb={EMB} fwd via torch-CPU ops + C kNN, "
-                      f"Chamfer via C nnsearch restatement), min of {1 + repeats} runs, torch threads={nthr} "
-                      f"(best of {sorted(tried)} on a 2-cloud probe; host has {ncores} logical CPUs)"}
+    return {"value": sample_clouds / best, "unit": "clouds/s", "cores": nthr, "kind": "reference-op-sequence",
+            "host_cpus": ncores, "cpu_model": cpu_model(), "loss": loss[0],
+            "sample": f"{sample_clouds} clouds x N={NPTS}, the tensors and weights of rank 0's GPU step (seed {seed}): the reference's "
+                      f"op sequence on torch CPU -- matmul+topk kNN, gather/repeat/cat graph feature, Conv2d/BatchNorm2d/ReLU/max, "
+                      f"conv5 (emb={EMB}); Chamfer = its torch fallback (broadcast difference [B,N,N,3], min, sqrt, mean); "
+                      f"min of {1 + repeats} runs, torch threads={nthr} (best of {sorted(tried)} on a 4-cloud probe; host has "
+                      f"{ncores} logical CPUs)"}
+
+
+def other_configs(dev, iters=10, warm=3):
+    """UNTIMED companion of the c2 line (N = 1 only; not part of `value`): BASELINE.json's configs[2..4] at their own sizes, a few
+    steps each between two HIP events on torch's current stream (every launch of these models goes out on it), so that the
+    driver's one line also carries a driver-run figure for them.  Synthetic inputs, random-init weights, eval, no_grad, eager
+    launches (no hipGraph: these are end-to-end model forwards, launch overhead included)."""
+    from learning3d_amd.losses import ChamferDistanceLoss
+    from learning3d_amd.models import DCP, DGCNN, PCN, PointNetSetAbstraction
+    from learning3d_amd.models.flownet3d import FlowNet3D
+
+    def ms(fn):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    out = {"note": f"untimed extras, {iters} eager steps each after {warm} warm-up steps, HIP events around the batch of steps; "
+                   "not part of `value`"}
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        try:        # configs[2]: DCP-v2 registration forward (DGCNN embed + Transformer + batched 3x3 SVD head), B 32, N 1024
+            torch.manual_seed(2)
+            dcp = DCP(feature_model=DGCNN(emb_dims=512), pointer_="transformer", head="svd").to(dev).eval()
+            tpl = (torch.rand((32, 1024, 3), generator=g) - 0.5).to(dev)
+            src = (torch.rand((32, 1024, 3), generator=g) - 0.5).to(dev)
+            t = ms(lambda: dcp(tpl, src))
+            out["c3_dcp_v2_forward"] = {"ms_per_step": t, "clouds_per_s": 32 / t * 1e3, "shape": "B=32 pairs, N=1024, emb 512, 4 heads"}
+            del dcp
+        except Exception as exc:                                 # an extra must never cost the headline line
+            out["c3_dcp_v2_forward"] = {"error": f"{type(exc).__name__}: {exc}"}
+        try:        # configs[3]: PCN completion forward + Chamfer loss, B 64, partial 2048 -> dense 16384
+            torch.manual_seed(3)
+            pcn = PCN(emb_dims=1024, num_coarse=1024, grid_size=4, detailed_output=True).to(dev).eval()
+            part = (torch.rand((64, 2048, 3), generator=g) - 0.5).to(dev)
+            gt = (torch.rand((64, 16384, 3), generator=g) - 0.5).to(dev)
+            cdl = ChamferDistanceLoss()
+            t_f = ms(lambda: pcn(part))
+            t = ms(lambda: cdl(gt, pcn(part)["fine_output"]))
+            out["c4_pcn_forward_chamfer"] = {"ms_per_step": t, "clouds_per_s": 64 / t * 1e3, "pcn_forward_ms": t_f,
+                                             "shape": "B=64, partial 2048 -> coarse 1024 -> fine 16384; Chamfer 16384 x 16384 per cloud"}
+            del pcn, gt
+        except Exception as exc:
+            out["c4_pcn_forward_chamfer"] = {"error": f"{type(exc).__name__}: {exc}"}
+        try:        # configs[4] per GPU: FlowNet3D sa1 set-conv and the whole FlowNet3D forward, B 32, N 8192
+            torch.manual_seed(1)
+            sa = PointNetSetAbstraction(npoint=C5_S, radius=C5_R, nsample=C5_K, in_channel=3, mlp=list(C5_MLP), group_all=False).to(dev).eval()
+            xyz = torch.clamp(torch.randn((32, 3, C5_N), generator=g), -2, 2).to(dev)
+            feat = torch.rand((32, 3, C5_N), generator=g).to(dev)
+            t = ms(lambda: sa(xyz, feat))
+            out["c5_sa1_setconv"] = {"ms_per_step": t, "clouds_per_s": 32 / t * 1e3, "shape": "32 clouds per GPU, N=8192 -> 1024, r=0.5, K=16, mlp 32/32/64"}
+            torch.manual_seed(4)
+            fn3 = FlowNet3D().to(dev).eval()
+            pc2 = (xyz + 0.05 * torch.randn((32, 3, C5_N), generator=g).to(dev)).contiguous()
+            f2 = torch.rand((32, 3, C5_N), generator=g).to(dev)
+            t = ms(lambda: fn3(xyz, pc2, feat, f2))
+            out["c5_flownet3d_forward"] = {"ms_per_step": t, "clouds_per_s": 32 / t * 1e3, "shape": "32 cloud pairs per GPU, N=8192"}
+        except Exception as exc:
+            out["c5_flownet3d"] = {"error": f"{type(exc).__name__}: {exc}"}
+    torch.cuda.synchronize()
+    return out
 
 
 def relaunch_under_torchrun(ngpus):
@@ -381,6 +454,8 @@ def main():
                          "c5: BASELINE configs[4]'s sharded layer, FlowNet3D sa1 set-conv (FPS + ball query + grouping + "
                          "3-layer shared MLP), 32 clouds x 8192 points per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the untimed configs[2..4] extras (DCP-v2 forward, PCN + Chamfer, FlowNet3D sa1 / forward) of the c2 line")
     ap.add_argument("--sync-loss", action="store_true",
                     help="N>1: make the blocking exchange the headline (default: pipelined; both are always reported)")
     ap.add_argument("--fp32-mfma", action="store_true",
@@ -730,8 +805,11 @@ def main():
                         ((stage_ms["knn"] + stage_ms["chamfer"]) * 1e-3) / 1e9},
             "loss": float(loss),
         }
+        if not multi and not args.no_other_configs:
+            out["other_configs"] = other_configs(dev)
         if not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"]["loss_matches_gpu_step"] = abs(out["cpu_baseline"]["loss"] - out["loss"]) < 1e-6
     finish(out if rank == 0 else None, rank, multi, local, dist)
 
 

@@ -366,6 +366,51 @@ def dgcnn_forward_torch(x_bn3, weights, k=20, eps=1e-5):
     return h.view(B, -1, N)
 
 
+def dgcnn_forward_refops(x_bn3, weights, k=20, eps=1e-5):
+    """The reference's OWN op sequence for models/dgcnn.py:25-49 on torch CPU, all threads -- the CPU baseline bench.py times
+    (kind "reference-op-sequence"); dgcnn_forward_torch above is the checker (C kNN with the documented tie order).
+      knn               utils/model_common_utils.py:3-9    -2 * matmul(x^T, x), sum(x**2), -xx - inner - xx^T, topk
+      get_graph_feature utils/model_common_utils.py:132-156  idx + idx_base, flat row gather, repeat, cat, permute
+      conv/bn/relu/max  models/dgcnn.py:34-46, cat :46, conv5 :48
+    Module objects are replaced by their functional forms (F.conv2d / F.batch_norm in eval mode: the same ATen kernels)."""
+    import torch
+    import torch.nn.functional as F
+    x = torch.as_tensor(np.asarray(x_bn3, dtype=np.float32)).permute(0, 2, 1)      # "bnc" -> [B,3,N], dgcnn.py:26-27
+    B, C, N = x.shape
+    inner = -2 * torch.matmul(x.transpose(2, 1).contiguous(), x)
+    xx = torch.sum(x ** 2, dim=1, keepdim=True)
+    pd = -xx - inner - xx.transpose(2, 1).contiguous()
+    idx = pd.topk(k=k, dim=-1)[1]
+    idx = (idx + torch.arange(0, B).view(-1, 1, 1) * N).view(-1)
+    xt = x.transpose(2, 1).contiguous()
+    feature = xt.view(B * N, -1)[idx, :].view(B, N, k, C)
+    xr = xt.view(B, N, 1, C).repeat(1, 1, k, 1)
+    h = torch.cat((feature, xr), dim=3).permute(0, 3, 1, 2)
+
+    def block(h, i):
+        h = F.conv2d(h, torch.as_tensor(weights[f"conv{i}.weight"]))
+        h = F.batch_norm(h, torch.as_tensor(weights[f"bn{i}.running_mean"]), torch.as_tensor(weights[f"bn{i}.running_var"]),
+                         torch.as_tensor(weights[f"bn{i}.weight"]), torch.as_tensor(weights[f"bn{i}.bias"]), False, 0.0, eps)
+        return F.relu(h)
+
+    outs = []
+    for i in (1, 2, 3, 4):
+        h = block(h, i)
+        outs.append(h.max(dim=-1, keepdim=True)[0])
+    return block(torch.cat(outs, dim=1), 5).view(B, -1, N)
+
+
+def chamfer_loss_refops(template, source):
+    """losses/chamfer_distance.py:5-31, the reference's torch fallback (what its `except:` branch runs on a CPU host, where the
+    `cuda.chamfer_distance` extension cannot build): the [m,n,n,3] broadcast difference, abs, pow 2, sum, min over both axes,
+    sqrt, means.  bench.py's CPU baseline; chamfer_loss above (C nnsearch) is the checker."""
+    import torch
+    a = torch.as_tensor(np.asarray(template, dtype=np.float32))
+    b = torch.as_tensor(np.asarray(source, dtype=np.float32))
+    M = (a.unsqueeze(2) - b.unsqueeze(1)).abs().pow(2).sum(3)
+    return (torch.mean(torch.sqrt(M.min(1)[0])) + torch.mean(torch.sqrt(M.min(2)[0]))) / 2.0
+
+
 def knn_feature(x_bcn, k):
     """utils/model_common_utils.py:3-9 for a feature map x [B,C,N] (any C): the reference's own op sequence in
     torch CPU fp32 (matmul -> MKL sgemm, topk) -- what models/prnet.py:76-97 calls per layer."""
