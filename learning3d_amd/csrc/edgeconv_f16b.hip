@@ -47,17 +47,31 @@
 #include "split_bf16.h"      // f32x2 / f32x4 typedefs
 
 #define EF_V2 1
-// EF_W4_LDS (two-plane persistent kernel): layer 4's weight fragments (128 KB as two planes) are copied to LDS once per
-// workgroup and read from there by every tile -- a ds_read_b128 beside the MFMA stream costs about half of a
-// global_load_dwordx4 (LABLOG R2.2: +19 vs +43 cycles per 5 MFMAs) and layer 4 issues 128 of them per tile.
-#ifndef EF_W4_LDS
-#if !defined(EF_TIMING)
-#define EF_W4_LDS 1
-#else
-#define EF_W4_LDS 0
-#endif
-#endif
+// Layer 4's weight fragments (128 KB as two planes) are copied to LDS once per workgroup and read from there by every tile -- a
+// ds_read_b128 beside the MFMA stream costs about half of a global_load_dwordx4 (LABLOG R2.2: +19 vs +43 cycles per 5 MFMAs) and
+// layer 4 issues 128 of them per tile.
 #define EF_W4_BYTES ((EC_C4 / 16) * (EC_C3 / 32) * 2 * 1024)
+// LDS of a workgroup (dynamic, 159 808 of the CU's 163 840 bytes):
+//   [0, EF_PAR_BYTES)  the packed block's tail, copied once: layer 4's fragments (128 KB) | b2 | b3 | b4 | W1 | b1 | scales
+//                      (contiguous in the fifth copy, edgeconv_layout.h) -- every bias and layer 1's weights are read from
+//                      here with ds_read, so that NO parameter of layers 1 and 4 travels through vmcnt (a global load's
+//                      s_waitcnt also waits for every store issued before it: vmcnt is one in-order counter)
+//   EF_STG_A           per wave 4 KB: the pooled planes of layers 1-3 of the current tile, [plane 2][cell row 32][point 4][8 f16]
+//   EF_STG_B           per wave 2 x 1 KB: the pooled planes of two layer-4 pairs each, [slot 2][plane 2][cell row 4][point 4][8 f16]
+// The staged values leave as 16-byte stores from inside layer 4 (64 two-byte stores per wave and tile before).
+#define EF_PAR_FLOATS (EC5_OFF_SC + 16 - EC5_OFF_W4)
+#define EF_PAR_BYTES (EF_PAR_FLOATS * 4)
+#define EF_LOFF_B2 (EF_W4_BYTES)
+#define EF_LOFF_B3 (EF_LOFF_B2 + 4 * EC_C2)
+#define EF_LOFF_B4 (EF_LOFF_B3 + 4 * EC_C3)
+#define EF_LOFF_W1 (EF_LOFF_B4 + 4 * EC_C4)
+#define EF_LOFF_B1 (EF_LOFF_W1 + 4 * 8 * EC_C1)
+#define EF_STG_A (EF_PAR_BYTES)
+#define EF_STG_B (EF_STG_A + 4 * 4096)
+#define EF_LDS_BYTES (EF_STG_B + 4 * 2048)
+static_assert(EC5_OFF_B2 == EC5_OFF_W4 + EF_W4_BYTES / 4 && EC5_OFF_B1 == EC5_OFF_W1 + 8 * EC_C1 && EC5_OFF_SC == EC5_OFF_B1 + EC_C1,
+              "the fifth copy's tail is one contiguous run");
+static_assert(EF_PAR_BYTES % 16 == 0 && EF_LDS_BYTES <= 163840, "LDS budget");
 #define EF_NPL 2
 #define EFO_W2 EC5_OFF_W2
 #define EFO_W3 EC5_OFF_W3
@@ -75,6 +89,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct EfBase { const char *p; };     // the packed parameter block
 typedef __attribute__((address_space(3))) const char *ef_lds_t;
+typedef __attribute__((address_space(3))) const float *ef_ldsf_t;     // parameters that live in LDS (biases, layer 1's weights)
+typedef __attribute__((address_space(3))) char *ef_ldsw_t;            // the pooled-output staging areas
 typedef EfBase ef_rsrc_t;
 
 // ---------------------------------------------------------------------------------------------
@@ -172,9 +188,9 @@ struct EfLane {
     bool odd, hi;            // q & 1, q & 2
     unsigned laneoff;        // lane * 16: byte offset of the lane's 16 bytes inside a 1 KB fragment
     ef_rsrc_t rs;            // the packed parameter block
-    ef_lds_t w4lds;          // EF_W4_LDS: layer 4's fragment block in LDS
+    ef_lds_t w4lds;          // layer 4's fragment block in LDS
     float *prow;             // out_mode 0: pooled + (b N + point) CTOT + 4 g + {0,2,1,3}[q]
-    _Float16 *ph;            // out_mode 1, 2: the h plane's cell of (this lane's channel within a 16-channel M-tile, its point)
+    ef_ldsw_t stgA, stgB;    // out_mode 1, 2: this lane's 2-byte cell of its wave's staging areas (channel cl within an M-tile, its point)
     float mres;              // scale of the pooled planes' residual: 4096 (out_mode 1: m' = (v - h) 2^12) or 1 (out_mode 2: unscaled)
     size_t bn;               // B N: channel ch0 + 16 k lies (ch0 + 16 k) * bn halfs further, the m' plane 512 * bn beyond that
 };
@@ -258,9 +274,17 @@ __device__ __forceinline__ void ef_micro(f32x4 (&h)[2][MT], f16x8 (&pl)[2][MT], 
                 ovf = ef_vmax(ovf, v);
                 const _Float16 hh = (_Float16)v;
                 const _Float16 mm = (_Float16)((v - (float)hh) * L.mres);
-                _Float16 *d = L.ph + (size_t)(ch0 + 16 * k) * L.bn;
-                d[0] = hh;
-                d[(size_t)512 * L.bn] = mm;
+                typedef __attribute__((address_space(3))) _Float16 *lh_t;
+                if constexpr (!LAST) {                       // layers 1-3: area A, cell row (ch0 + 16 k) / 8 (+ 1 inside the lane part)
+                    const int off = ((ch0 + 16 * k) >> 3) * 64;
+                    *(lh_t)(L.stgA + off) = hh;
+                    *(lh_t)(L.stgA + off + 2048) = mm;
+                } else {                                     // layer 4, pair m: area B, chunk (m >> 1) & 1, slot m & 1, cell rows 2 k (+ 1)
+                    const int m = (ch0 - (EC_C1 + EC_C2 + EC_C3)) >> 5;
+                    const int off = ((m >> 1) & 1) * 1024 + (m & 1) * 512 + (2 * k) * 64;
+                    *(lh_t)(L.stgB + off) = hh;
+                    *(lh_t)(L.stgB + off + 256) = mm;
+                }
             } else {
                 L.prow[ch0 + 16 * k] = v;
             }
@@ -304,7 +328,7 @@ struct EfRing {
 };
 struct EfNext {              // where the pair executed after this one finds its fragments / bias
     int woff;                // byte offset of the layer's fragment block inside the packed parameters
-    const float *bias;       // layer's scaled bias + 4 g
+    ef_ldsf_t bias;          // layer's scaled bias + 4 g (LDS)
     int mp;                  // pair index inside that layer
     int steps;               // 2 S of that layer
 };
@@ -324,14 +348,14 @@ __device__ __forceinline__ u32x4 ef_ldfrag_lds(ef_lds_t base, int frag, unsigned
     return *(__attribute__((address_space(3))) const u32x4 *)(base + frag * 1024 + laneoff);
 }
 
-__device__ __forceinline__ void ef_ring_fill(EfRing &R, ef_rsrc_t rs, int woff, const float *bias4g, int mp, int steps, int lane)
+__device__ __forceinline__ void ef_ring_fill(EfRing &R, ef_rsrc_t rs, int woff, ef_ldsf_t bias4g, int mp, int steps, int lane)
 {
 #pragma unroll
     for (int d = 0; d < EF_PD; d++)
 #pragma unroll
         for (int p = 0; p < EF_NPL; p++) R.a[d][p] = ef_ldfrag(rs, woff, (mp * steps + d) * EF_NPL + p, (unsigned)lane * 16u);
-    R.bv[0] = *(const f32x4 *)(bias4g + 32 * mp);
-    R.bv[1] = *(const f32x4 *)(bias4g + 32 * mp + 16);
+    R.bv[0] = *(__attribute__((address_space(3))) const f32x4 *)(bias4g + 32 * mp);
+    R.bv[1] = *(__attribute__((address_space(3))) const f32x4 *)(bias4g + 32 * mp + 16);
 }
 
 // One output M-tile pair of a dense layer: 2 x S steps (k-step outer, M-tile inner -- the order the
@@ -398,8 +422,8 @@ __device__ __forceinline__ void ef_pair(int mp, const EfNext &nx, const f16x8 (&
             });
         });
         if constexpr (r == 1) {                                       // both M-tiles have consumed their bias: fetch the next pair's
-            R.bv[0] = *(const f32x4 *)(nx.bias + 32 * nx.mp);
-            R.bv[1] = *(const f32x4 *)(nx.bias + 32 * nx.mp + 16);
+            R.bv[0] = *(__attribute__((address_space(3))) const f32x4 *)(nx.bias + 32 * nx.mp);
+            R.bv[1] = *(__attribute__((address_space(3))) const f32x4 *)(nx.bias + 32 * nx.mp + 16);
             EF_PIN();
         }
 #pragma unroll
@@ -420,11 +444,11 @@ __device__ __forceinline__ void ef_pair(int mp, const EfNext &nx, const f16x8 (&
 // array is indexed by the pair): this workgroup starts at pair `rot`.
 // IN_RAW: accB on entry was produced by asm MFMAs (layers >= 2) rather than builtins (layer 1).
 // c_in / c_own: 2^-S of the previous layer (whose last pair is finished here) and of this layer; bias is pre-scaled.
-struct EfNoHook { __device__ __forceinline__ void operator()(int) const {} };
+struct EfNoHook { template <class I> __device__ __forceinline__ void operator()(I) const {} };
 
 template <int MT, int S, int NPAIR, bool LAST, bool UNROLL, bool IN_RAW, bool PLANES, class HOOK = EfNoHook, bool OWN_LDS = false, bool AFTER_LDS = false>
 __device__ __forceinline__ void ef_layer(const f16x8 (&pin)[S][2][MT], f16x8 (&pout)[LAST ? 1 : NPAIR][2][MT],
-                                         int woff, const float *bias4g, const EfNext &after, EfRing &R, int ch_own,
+                                         int woff, ef_ldsf_t bias4g, const EfNext &after, EfRing &R, int ch_own,
                                          f32x4 (&accA)[2][MT], f32x4 (&accB)[2][MT], int ch_in,
                                          int *mp_out, const EfLane &L, int rot, const EfScale &c_in, const EfScale &c_own, float &ovf,
                                          HOOK &&hook = EfNoHook())
@@ -449,24 +473,24 @@ __device__ __forceinline__ void ef_layer(const f16x8 (&pin)[S][2][MT], f16x8 (&p
         }
         *mp_out = NPAIR - 1;
     } else {
-        const int q0 = rot % NPAIR, q1 = (1 + rot) % NPAIR, q2 = (2 + rot) % NPAIR;
-        ef_pair<MT, S, false, IN_RAW, PLANES, NSD, OWN_LDS, OWN_LDS>(q0, in_layer(q1), pin, last, woff, R, accA, accB, last, ch_in, L, c_in, ovf);
-        ef_pair<MT, S, LAST, true, PLANES, NS, OWN_LDS, OWN_LDS>(q1, in_layer(q2), pin, last, woff, R, accB, accA, pout[0], ch_own + 32 * q0, L, c_own, ovf);
-        int mpB = q1;                                                   // pair whose results sit in accB
-#pragma unroll 1
-        for (int i = 2; i < NPAIR; i += 2) {
-            hook(i);                                                        // persistent kernel: the next tile's gather loads
-            const int m0 = (i + rot) % NPAIR, m1 = (i + 1 + rot) % NPAIR, m2 = (i + 2 + rot) % NPAIR;
-            ef_pair<MT, S, LAST, true, PLANES, NS, OWN_LDS, OWN_LDS>(m0, in_layer(m1), pin, last, woff, R, accA, accB, pout[0], ch_own + 32 * mpB, L, c_own, ovf);
-            if (i + 2 < NPAIR)
-                ef_pair<MT, S, LAST, true, PLANES, NS, OWN_LDS, OWN_LDS>(m1, in_layer(m2), pin, last, woff, R, accB, accA, pout[0],
-                                                                         ch_own + 32 * m0, L, c_own, ovf);
+        // the last layer, written out over its NPAIR pairs too (no register array is indexed by the pair, so a loop would do --
+        // but a rolled loop whose body differs per trip (hook) made the compiler merge its memory counters at every join:
+        // `s_waitcnt vmcnt(0)` inside the MFMA stream, behind all stores in flight).  hook(i) runs in front of pair i.
+        (void)rot;
+        ef_pair<MT, S, false, IN_RAW, PLANES, NSD, OWN_LDS, OWN_LDS>(0, in_layer(1), pin, last, woff, R, accA, accB, last, ch_in, L, c_in, ovf);
+        ef_static_for<1, NPAIR>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            hook(ic);
+            constexpr bool more = i + 1 < NPAIR;
+            const EfNext nx = more ? in_layer(i + 1) : after;
+            if constexpr (i & 1)
+                ef_pair<MT, S, LAST, true, PLANES, NS, OWN_LDS, more ? OWN_LDS : AFTER_LDS>(i, nx, pin, last, woff, R, accB, accA, pout[0],
+                                                                                          ch_own + 32 * (i - 1), L, c_own, ovf);
             else
-                ef_pair<MT, S, LAST, true, PLANES, NS, OWN_LDS, AFTER_LDS>(m1, after, pin, last, woff, R, accB, accA, pout[0],
-                                                                           ch_own + 32 * m0, L, c_own, ovf);
-            mpB = m1;
-        }
-        *mp_out = mpB;
+                ef_pair<MT, S, LAST, true, PLANES, NS, OWN_LDS, more ? OWN_LDS : AFTER_LDS>(i, nx, pin, last, woff, R, accA, accB, pout[0],
+                                                                                          ch_own + 32 * (i - 1), L, c_own, ovf);
+        });
+        *mp_out = NPAIR - 1;
     }
 }
 
@@ -479,80 +503,60 @@ __device__ __forceinline__ void ef_layer(const f16x8 (&pin)[S][2][MT], f16x8 (&p
 // from inside layer 4 of the current one (indices at its second pair, coordinates at its fourth) and consumed a tile later.
 // The weight ring is handed across tiles like across layers: layer 4's last pair prefetches layer 2's first fragments.
 // (the three-plane kernel, edgeconv_f16.hip, keeps one workgroup per tile: with its 36-register ring the prefetched gather spills)
-#ifndef EF_PERSIST
-#if defined(EF_TIMING)
-#define EF_PERSIST 0
-#else
-#define EF_PERSIST 1
-#endif
-#endif
 
+// EF_GATHER1: what a lane needs of a tile before its first MFMA is ONE dword per row tile -- layer 1's B operand of k-step 0 is
+// component g of the neighbour (g < 3) or the centre's x (g == 3), of k-step 1 the centre's y / z (g = 0 / 1) or zero -- so the lane
+// selects the ADDRESS and issues one unconditional load.  (Loading the neighbour's three coordinates and selecting the value, as the
+// first version did, was compiled into exec-masked branches per lane group with an `s_waitcnt vmcnt(0)` in each: five serialised
+// memory round trips in the middle of layer 4's MFMA stream, behind every store in flight.)
 template <int MT>
 struct EfGather {                      // what a lane needs of a tile before its first MFMA
-    long long nb[MT];                  // neighbour indices of its MT rows
-    float c[3];                        // its point's coordinates
-    float b1[MT][2];                   // layer 1's B operands (after the second trip)
+    int nb[MT];                        // neighbour indices of its MT rows (< N: the low dword of the int64)
+    float c;                           // centre y (g == 0) / z (g >= 1)
+    float b1[MT];                      // layer 1's B operand, k-step 0 (after the second trip)
     int b, nc;
 };
 
 template <int MT>
 __device__ __forceinline__ void ef_gather_idx(EfGather<MT> &G, int tile, int tiles_per_cloud, int N, int k, const float *__restrict__ xyz,
-                                              const int64_t *__restrict__ idx, int wave, int j)
+                                              const int64_t *__restrict__ idx, int wave, int j, int g)
 {
-    const int b = tile / tiles_per_cloud, xb = tile - b * tiles_per_cloud;
+    const int b = tile / tiles_per_cloud, xb = tile - b * tiles_per_cloud;     // uniform: a tile lies inside one cloud
     const int n = (xb * 4 + wave) * 4 + (j >> 2);
     const int nc = min(n, N - 1);                                   // lanes past N recompute point N-1
     G.b = b;
     G.nc = nc;
-    const float *pc = xyz + ((size_t)b * N + nc) * 3;
-    G.c[0] = pc[0]; G.c[1] = pc[1]; G.c[2] = pc[2];
+    const float *cloud = xyz + (size_t)b * N * 3;                   // scalar base + 32-bit lane offsets
+    G.c = cloud[nc * 3 + (g == 0 ? 1 : 2)];
+    const int64_t *row = idx + (size_t)b * N * k;
 #pragma unroll
     for (int t = 0; t < MT; t++) {
         const int jj = 4 * t + (j & 3);
-        G.nb[t] = idx[((size_t)b * N + nc) * k + (jj < k ? jj : 0)];   // pad k up to 4*MT with a duplicate
+        G.nb[t] = (int)row[nc * k + (jj < k ? jj : 0)];             // pad k up to 4*MT with a duplicate
     }
 }
 
 template <int MT>
 __device__ __forceinline__ void ef_gather_xyz(EfGather<MT> &G, int N, const float *__restrict__ xyz, int g)
 {
+    const float *cloud = xyz + (size_t)G.b * N * 3;
+    const int comp = g < 3 ? g : 0;
 #pragma unroll
     for (int t = 0; t < MT; t++) {
-        const float *pn = xyz + ((size_t)G.b * N + G.nb[t]) * 3;
-        const float nx = pn[0], ny = pn[1], nz = pn[2];
-        G.b1[t][0] = g == 0 ? nx : (g == 1 ? ny : (g == 2 ? nz : G.c[0]));
-        G.b1[t][1] = g == 0 ? G.c[1] : (g == 1 ? G.c[2] : 0.f);
+        int r = g < 3 ? G.nb[t] : G.nc;
+        asm("" : "+v"(r));                                          // one address, one load: keep the select off the loaded values
+        G.b1[t] = cloud[r * 3 + comp];
     }
 }
 
-#ifdef EF_WGSPAN
-__device__ long long *g_ef_span;
-#endif
 template <int MT, bool PLANES>
 __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xyz,
                                                               const int64_t *__restrict__ idx, int B, int N, int k,
                                                               const float *packed,
                                                               float *__restrict__ pooled,
-                                                              int *__restrict__ range_flag, float mres
-#ifdef EF_TIMING
-                                                              , unsigned long long *tdbg
-#endif
-)
+                                                              int *__restrict__ range_flag, float mres)
 {
-#ifdef EF_TIMING
-    unsigned long long tk[6];
-#define EF_T(i) tk[i] = __builtin_amdgcn_s_memtime()
-#else
 #define EF_T(i)
-#endif
-#ifdef EF_WGSPAN      // tools/probe_ef_span.hip: when does every persistent workgroup start and end (s_memrealtime, 100 MHz), and where
-    if (threadIdx.x == 0) {
-        unsigned id;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-        g_ef_span[(size_t)blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime();
-        g_ef_span[(size_t)blockIdx.x * 4 + 2] = id;
-    }
-#endif
     EF_T(0);
     constexpr int CTOT = EC_C1 + EC_C2 + EC_C3 + EC_C4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -568,19 +572,23 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
     const int cl = 4 * g + ((j & 1) * 2 + ((j >> 1) & 1));       // this lane's channel inside a 16-channel M-tile
     L.bn = (size_t)B * N;
     L.mres = mres;
-#if EF_W4_LDS
-    extern __shared__ __attribute__((aligned(16))) unsigned char ef_w4[];
-    L.w4lds = (ef_lds_t)ef_w4;
-    {   // layer 4's fragments -> LDS, once per workgroup; the barrier stands in front of the first tile's layer 4
+    extern __shared__ __attribute__((aligned(16))) unsigned char ef_lds[];
+    L.w4lds = (ef_lds_t)ef_lds;
+    {   // the parameter tail -> LDS, once per workgroup
         const uint4 *src = (const uint4 *)(packed + EFO_W4);
-        uint4 *dst = (uint4 *)ef_w4;
-#pragma unroll 4
-        for (int i = threadIdx.x; i < EF_W4_BYTES / 16; i += 256) dst[i] = src[i];
+        uint4 *dst = (uint4 *)ef_lds;
+#pragma unroll 8
+        for (int i = threadIdx.x; i < EF_PAR_BYTES / 16; i += 256) dst[i] = src[i];
     }
-    bool w4_ready = false;
-#else
-    L.w4lds = nullptr;
-#endif
+    // this lane's 2-byte cell inside its wave's staging areas: cell row (cl >> 3), point j >> 2, channel cl & 7
+    {
+        const int cell = (cl >> 3) * 64 + (j >> 2) * 16 + (cl & 7) * 2;
+        L.stgA = (ef_ldsw_t)ef_lds + EF_STG_A + wave * 4096 + cell;
+        L.stgB = (ef_ldsw_t)ef_lds + EF_STG_B + wave * 2048 + cell;
+    }
+    typedef __attribute__((address_space(3))) const u32x4 *ef_ldsq_t;
+    const ef_ldsq_t rdA = (ef_ldsq_t)((ef_lds_t)ef_lds + EF_STG_A + wave * 4096 + lane * 16);     // read-out: 16 bytes per lane, 1 KB per trip
+    const ef_ldsq_t rdB = (ef_ldsq_t)((ef_lds_t)ef_lds + EF_STG_B + wave * 2048 + lane * 16);
     if (PLANES && blockIdx.x == 0 && threadIdx.x == 0)
         *(float *)((_Float16 *)pooled + 2 * 512 * L.bn) = packed[EFO_SC + 12];        // the image's 2^-T_out
     // power-of-two scales of the four layers' accumulators (uniform: scalar loads), see edgeconv_layout.h
@@ -589,39 +597,40 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
                   s3 = {packed[EFO_SC + 2], packed[EFO_SC + po + 2]}, s4 = {1.0f, packed[EFO_SC + po + 3]};
     float ovf = 0.f;
     constexpr int w2 = EFO_W2 * 4, w3 = EFO_W3 * 4, w4 = EFO_W4 * 4;      // byte offsets inside the descriptor
-    const float *bs2 = packed + EFO_B2 + 4 * g, *bs3 = packed + EFO_B3 + 4 * g, *bs4 = packed + EFO_B4 + 4 * g;
-#ifndef EF_ROT
-#define EF_ROT 1
-#endif
+    const ef_ldsf_t bs2 = (ef_ldsf_t)((ef_lds_t)ef_lds + EF_LOFF_B2) + 4 * g, bs3 = (ef_ldsf_t)((ef_lds_t)ef_lds + EF_LOFF_B3) + 4 * g,
+                    bs4 = (ef_ldsf_t)((ef_lds_t)ef_lds + EF_LOFF_B4) + 4 * g;
 
-    int tile = blockIdx.x;
-    if (tile >= ntiles) return;
+    int tile = blockIdx.x;                                      // grid <= ntiles: every workgroup has a first tile
     // the first tile's gather stands in the open; its index loads go out before the weight ring's so that the dependent
     // coordinate loads do not queue behind 8 KB of fragments
     EfGather<MT> G;
-    ef_gather_idx<MT>(G, tile, tiles_per_cloud, N, k, xyz, idx, wave, j);
+    ef_gather_idx<MT>(G, tile, tiles_per_cloud, N, k, xyz, idx, wave, j, g);
     EF_PIN();
+    __syncthreads();                                            // the parameter tail is in LDS
     // layer 2's first fragments and bias: requested before the gather's second trip so that their latency hides behind it
     EfRing R;
-    ef_ring_fill(R, L.rs, EFO_W2 * 4, packed + EFO_B2 + 4 * g, 0, 2 * (EC_C1 / 32), lane);
+    ef_ring_fill(R, L.rs, EFO_W2 * 4, bs2, 0, 2 * (EC_C1 / 32), lane);
     EF_PIN();
     ef_gather_xyz<MT>(G, N, xyz, g);
+    // the gathered values count as arrived on BOTH edges into the loop (here, and in front of layer 4's pair 7 for the next
+    // tile): otherwise the loop header merges "loads pending" with "nothing pending" into an `s_waitcnt vmcnt(0)` at the top
+    // of every tile, which also waits for the 16-byte stores the previous tile issued last
+#pragma unroll
+    for (int t = 0; t < MT; t++) asm volatile("" : "+v"(G.b1[t]));
+    asm volatile("" : "+v"(G.c));
 
-#if EF_PERSIST
     for (; tile < ntiles; tile += gridDim.x) {
-#else
-    {
-#endif
     const int b = G.b;
     L.prow = pooled + ((size_t)b * N + G.nc) * CTOT + cl;
-    L.ph = (_Float16 *)pooled + ((size_t)(cl >> 3) * L.bn + (size_t)b * N + G.nc) * 8 + (cl & 7);
+    // read-out addresses of this tile: lane -> (row of the image = plane * 64 + cell row, point lane & 3); rows times B N * 16 bytes
+    const int n_st = min(((tile - b * tiles_per_cloud) * 4 + wave) * 4 + (lane & 3), N - 1);
+    char *const img_pt = (char *)pooled + ((size_t)b * N + n_st) * 16;
+    const size_t row_bytes = L.bn * 16;
     float b1[MT][2];
 #pragma unroll
-    for (int t = 0; t < MT; t++) { b1[t][0] = G.b1[t][0]; b1[t][1] = G.b1[t][1]; }
-#if EF_PERSIST
+    for (int t = 0; t < MT; t++) { b1[t][0] = G.b1[t]; b1[t][1] = g < 2 ? G.c : 0.f; }
     const int tile_next = tile + (int)gridDim.x;
     const bool has_next = tile_next < ntiles;                    // uniform
-#endif
 
     // ---- layer 1 on the fp32 MFMA (as edgeconv2.hip): graph feature rows as B operands, k-step s,
     //      lane group g -> channel 4s + g of (neighbour xyz, centre xyz, 0, 0)          dgcnn.py:32
@@ -629,21 +638,26 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
     f16x8 p1[EC_C1 / 32][2][MT];
     f32x4 accA[2][MT], accB[2][MT];                    // accB: the pair whose finish is pending
     {
-        const f32x2 *w1 = (const f32x2 *)(packed + EFO_W1);
+        typedef __attribute__((address_space(3))) const f32x2 *lw1_t;
+        typedef __attribute__((address_space(3))) const f32x4 *lb1_t;
+        const lw1_t w1 = (lw1_t)((ef_lds_t)ef_lds + EF_LOFF_W1);
+        const ef_ldsf_t b1p = (ef_ldsf_t)((ef_lds_t)ef_lds + EF_LOFF_B1) + 4 * g;
+        f32x2 a1[EC_C1 / 16];
+        f32x4 bv1[EC_C1 / 16];
+#pragma unroll
+        for (int m = 0; m < EC_C1 / 16; m++) { a1[m] = w1[m * 64 + lane]; bv1[m] = *(lb1_t)(b1p + 16 * m); }
 #pragma unroll
         for (int mp = 0; mp < EC_C1 / 32; mp++) {
 #pragma unroll
             for (int mm = 0; mm < 2; mm++) {
                 const int m = 2 * mp + mm;
-                const f32x4 bv = *(const f32x4 *)(packed + EFO_B1 + 16 * m + 4 * g);
-                const f32x2 a = w1[m * 64 + lane];
 #pragma unroll
-                for (int t = 0; t < MT; t++) accB[mm][t] = bv;
+                for (int t = 0; t < MT; t++) accB[mm][t] = bv1[m];
 #pragma unroll
                 for (int s = 0; s < 2; s++)
 #pragma unroll
                     for (int t = 0; t < MT; t++)
-                        accB[mm][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b1[t][s], accB[mm][t], 0, 0, 0);
+                        accB[mm][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[m][s], b1[t][s], accB[mm][t], 0, 0, 0);
             }
             if (mp + 1 < EC_C1 / 32) ef_finish_all<MT, false, false, PLANES>(accB, p1[mp], 32 * mp, L, s1, ovf);
         }
@@ -651,62 +665,70 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
     int mp_last;
 
     EF_T(2);
-    const int rot = EF_ROT ? (int)(((unsigned)tile >> 3) % (EC_C4 / 32)) : 0;   // >>3: ids = XCD mod 8
     // ---- layer 2: 64 -> 64   (its first pair hides the finish of layer 1's last pair, and so on down)
     f16x8 p2[EC_C2 / 32][2][MT];
     ef_layer<MT, EC_C1 / 32, EC_C2 / 32, false, true, false, PLANES>(
         p1, p2, w2, bs2, EfNext{w3, bs3, 0, 2 * (EC_C2 / 32)}, R, EC_C1, accA, accB,
         32 * (EC_C1 / 32 - 1), &mp_last, L, 0, s1, s2, ovf);
     EF_T(3);
-    // ---- layer 3: 64 -> 128
+    // ---- layer 3: 64 -> 128; its last pair prefetches layer 4's first fragments from LDS
     f16x8 p3[EC_C3 / 32][2][MT];
-#if EF_W4_LDS
-    if (!w4_ready) { __syncthreads(); w4_ready = true; }        // layer 3's last pair prefetches layer 4's first fragments from LDS
-#endif
-    ef_layer<MT, EC_C2 / 32, EC_C3 / 32, false, true, true, PLANES, EfNoHook, false, EF_W4_LDS != 0>(
-        p2, p3, w3, bs3, EfNext{w4, bs4, rot, 2 * (EC_C3 / 32)}, R, EC_C1 + EC_C2, accA, accB,
+    ef_layer<MT, EC_C2 / 32, EC_C3 / 32, false, true, true, PLANES, EfNoHook, false, true>(
+        p2, p3, w3, bs3, EfNext{w4, bs4, 0, 2 * (EC_C3 / 32)}, R, EC_C1 + EC_C2, accA, accB,
         EC_C1 + 32 * (EC_C2 / 32 - 1), &mp_last, L, 0, s2, s3, ovf);
     EF_T(4);
-    // ---- layer 4: 128 -> 256, only max-pooled; its last pair prefetches layer 2's first fragments for the next tile
+    // ---- layer 4: 128 -> 256, only max-pooled; its last pair prefetches layer 2's first fragments for the next tile.
+    // In front of its pairs (hook): the staged pooled planes of this tile leave as 16-byte stores -- one ds_read_b128 per trip,
+    // stored one pair later (area A: layers 1-3, complete once pair 0 has finished layer 3's last pair; area B: two layer-4
+    // pairs per 1 KB chunk, chunk (m >> 1) & 1) -- and the next tile's gather goes out (indices before pair 2, the coordinates they
+    // point to before pair 6), waited for before pair 7, where every count is known, instead of behind the loop's back edge.
     f16x8 dummy[1][2][MT];
-#if EF_PERSIST
-    auto hook = [&](int i) {
+    u32x4 X;                                                     // the 16 bytes on their way from LDS to the image
+    auto st_a = [&](int c) { *(u32x4 *)(img_pt + (size_t)((c >> 1) * 64 + (c & 1) * 16 + (lane >> 2)) * row_bytes) = X; EF_PIN(); };
+    auto st_b = [&](int m0) {                                    // chunk of pairs m0, m0 + 1: lane -> slot, plane, cell row, point
+        const int row = ((lane >> 4) & 1) * 64 + (EC_C1 + EC_C2 + EC_C3) / 8 + 4 * (m0 + (lane >> 5)) + ((lane >> 2) & 3);
+        *(u32x4 *)(img_pt + (size_t)row * row_bytes) = X;
+        EF_PIN();
+    };
+    auto hook = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (PLANES) {
+            if constexpr (i >= 2 && i <= 5) st_a(i - 2);
+            if constexpr (i == 6) st_b(0);
+            if constexpr (i == 7) st_b(2);
+            if constexpr (i >= 1 && i <= 4) X = rdA[(i - 1) * 64];
+            if constexpr (i == 5 || i == 7) X = rdB[0];
+            if constexpr (i == 6) X = rdB[64];
+            EF_PIN();
+        }
         if (has_next) {
-            if (i == 2) { ef_gather_idx<MT>(G, tile_next, tiles_per_cloud, N, k, xyz, idx, wave, j); EF_PIN(); }
-            if (i == 6) { ef_gather_xyz<MT>(G, N, xyz, g); EF_PIN(); }
+            if constexpr (i == 2) { ef_gather_idx<MT>(G, tile_next, tiles_per_cloud, N, k, xyz, idx, wave, j, g); EF_PIN(); }
+            if constexpr (i == 6) { ef_gather_xyz<MT>(G, N, xyz, g); EF_PIN(); }
+            if constexpr (i == 7) {
+#pragma unroll
+                for (int t = 0; t < MT; t++) asm volatile("" : "+v"(G.b1[t]));       // a use: the compiler's counted wait lands here
+                asm volatile("" : "+v"(G.c));
+            }
         }
     };
-    ef_layer<MT, EC_C3 / 32, EC_C4 / 32, true, false, true, PLANES, decltype(hook) &, EF_W4_LDS != 0, false>(
+    ef_layer<MT, EC_C3 / 32, EC_C4 / 32, true, false, true, PLANES, decltype(hook) &, true, false>(
         p3, dummy, w4, bs4, EfNext{w2, bs2, 0, 2 * (EC_C1 / 32)}, R, EC_C1 + EC_C2 + EC_C3, accA, accB,
-        EC_C1 + EC_C2 + 32 * (EC_C3 / 32 - 1), &mp_last, L, rot, s3, s4, ovf, hook);
-#else
-    ef_layer<MT, EC_C3 / 32, EC_C4 / 32, true, false, true, PLANES>(
-        p3, dummy, w4, bs4, EfNext{w4, bs4, 0, 2 * (EC_C3 / 32)}, R, EC_C1 + EC_C2 + EC_C3, accA, accB,
-        EC_C1 + EC_C2 + 32 * (EC_C3 / 32 - 1), &mp_last, L, rot, s3, s4, ovf);
-#endif
+        EC_C1 + EC_C2 + 32 * (EC_C3 / 32 - 1), &mp_last, L, 0, s3, s4, ovf, hook);
+    if constexpr (PLANES) st_b(4);                              // pairs 4, 5 (read before pair 7)
     asm volatile("s_nop 15\n\ts_nop 15");                       // the last asm MFMAs must have written accB (no compiler padding)
     ef_finish_all<MT, true, true, PLANES>(accB, dummy[0], EC_C1 + EC_C2 + EC_C3 + 32 * mp_last, L, s4, ovf);
+    if constexpr (PLANES) { X = rdB[64]; st_b(6); }             // pairs 6, 7
     EF_T(5);
     }
     // fp16 range guard: ovf = the largest value (in plane units) this lane handed to fp16 planes -- layers 1-3, and the
     // pooled planes when PLANES; activations are post-ReLU, so the pooled maxima are the maxima.  Not taken while the
     // activations stay within 16x of the magnitude the packer was told; the host re-runs on the bf16x3 kernel if it is.
     if (!(ovf <= 60000.f) && range_flag) *(volatile int *)range_flag = 1; // may live in mapped host memory: plain store
-#ifdef EF_WGSPAN
-    __syncthreads();
-    if (threadIdx.x == 0) g_ef_span[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-#endif
-#ifdef EF_TIMING
-    if (threadIdx.x == 0)
-        for (int i = 0; i < 6; i++) tdbg[(size_t)blockIdx.x * 6 + i] = tk[i];
-#endif
 }
 
-#ifndef EF_TIMING
 // workgroups to launch: one per CU (persistent), or one per tile
 static int ef_grid(int ntiles)
 {
-#if EF_PERSIST
     static thread_local int cus[16] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
@@ -716,9 +738,6 @@ static int ef_grid(int ntiles)
         cus[dev] = n;
     }
     return ntiles < cus[dev] ? ntiles : cus[dev];
-#else
-    return ntiles;
-#endif
 }
 
 extern "C" int EF_ENTRY(const float *xyz, const int64_t *idx, int B, int N, int k,
@@ -732,7 +751,7 @@ extern "C" int EF_ENTRY(const float *xyz, const int64_t *idx, int B, int N, int 
     dim3 grid(ef_grid((int)ntiles)), block(256);
     hipStream_t st = (hipStream_t)stream;
     float *o = (float *)out;
-    const size_t lds = EF_W4_LDS ? EF_W4_BYTES : 0;
+    const size_t lds = EF_LDS_BYTES;
     if (out_mode == 0) {
         if (k <= 16) hipLaunchKernelGGL((EF_KERNEL<4, false>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag, mres);
         else              hipLaunchKernelGGL((EF_KERNEL<5, false>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag, mres);
@@ -742,4 +761,3 @@ extern "C" int EF_ENTRY(const float *xyz, const int64_t *idx, int B, int N, int 
     }
     return l3d_check_launch();
 }
-#endif

@@ -121,26 +121,29 @@ def run(fam, names):
                       f"bytes identical to product: {same} ({nd} differ)", flush=True)
     else:
         flop = B * N * 2 * 512 * 1024
-        import inspect
-        src = inspect.getsource(_fused.pointwise_conv_f16)
-        print("cf: driving through _fused.pointwise_conv_f16 with lib() swapped; see tools/conv5_bench.py for the raw call")
-        import learning3d_amd._lib as _l
-        prod = _l.lib()
-        variants = [("product", None)] + [(n, os.path.join(BIN, f"lib{fam}_{n}.so")) for n in names]
+        y = torch.empty_like(ref5)
+        s5c, b5c = _fused.f32c(s5), _fused.f32c(b5)
+
+        def call5(fn):
+            rc = fn(ptr(img), ptr(w5f), ptr(s5c), ptr(b5c), 0, B, 512, 1024, N, 1, ptr(y), stream_ptr())
+            assert rc == 0, rc
+        variants = [("product", lib().l3d_pointwise_conv_f16_2p)]
+        for n in names:
+            Lb = ctypes.CDLL(os.path.join(BIN, f"lib{fam}_{n}.so"))
+            fn = Lb.l3d_pointwise_conv_f16_2p
+            fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 6 + [ctypes.c_void_p] * 2
+            fn.restype = ctypes.c_int
+            variants.append((n, fn))
         for rnd in range(2):
-            for n, path in variants:
-                if path is None:
-                    _fused.CONV_F16_LIB = None
-                else:
-                    _fused.CONV_F16_LIB = ctypes.CDLL(path)
-                o = _fused.pointwise_conv_f16(img, B, N, w5f, 512, 1024, s5, b5, relu=True, unscaled=True)
+            for n, fn in variants:
+                y.zero_()
+                call5(fn)
                 torch.cuda.synchronize()
-                same = bool(torch.equal(o, ref5))
-                nd = int((o != ref5).sum())
-                t = timeit(lambda: _fused.pointwise_conv_f16(img, B, N, w5f, 512, 1024, s5, b5, relu=True, unscaled=True), warm=150 if rnd == 0 else 50, iters=100)
+                same = bool(torch.equal(y, ref5))
+                nd = int((y != ref5).sum())
+                t = timeit(lambda: call5(fn), warm=150 if rnd == 0 else 50, iters=100)
                 print(f"round {rnd}  {n:24s} {t:8.1f} us  {flop / t / 1e6:7.1f} TF fp32-equiv  frac {flop / t / 1e6 / 833.3:5.3f}   "
                       f"identical to product: {same} ({nd} differ)", flush=True)
-        _fused.CONV_F16_LIB = None
     _fused.check_range(x.device, sync=True)
     return 0
 
