@@ -73,7 +73,7 @@ def pmc_record(tag):
     """What the committed rocprofv3 PMC passes measured for one kernel (profiles/round2_traffic.json, produced on the
     GPU box by tools/pmc.sh + tools/traffic_json.py; bench.py cannot run rocprofv3 on itself, so this is the measured
     figure of the same kernel at the same shapes).  {} if not collected."""
-    for name in ("round3_traffic.json", "round2_traffic.json", "round1_traffic.json"):
+    for name in ("round4_traffic.json", "round3_traffic.json", "round2_traffic.json", "round1_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f).get(tag)
@@ -82,6 +82,12 @@ def pmc_record(tag):
         except (OSError, ValueError):
             pass
     return {}
+
+
+def pmc_source(tag):
+    """where `traffic` comes from: the committed rocprofv3 --pmc pass of this kernel at these shapes -- NOT measured in this run"""
+    src = pmc_record(tag).get("source")
+    return f"profiles/{src} (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of this kernel at these shapes, tools/pmc.sh; read from the committed file, not measured in this run)" if src else None
 
 
 def pmc_traffic(tag):
@@ -110,14 +116,15 @@ def edgeconv_roofline(ec_tf, ec_ms, arith):
     alg = B_PER_GPU * EDGECONV_FLOP_PER_CLOUD
     if arith == "fp32":
         return {"kernel": "edgeconv2_kernel<5>", "bound": "mfma", "achieved": ec_tf, "peak": MFMA_F32_PEAK_TF,
-                "unit": "TFLOP/s", "frac": ec_tf / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("edgeconv"),
+                "unit": "TFLOP/s", "frac": ec_tf / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("edgeconv"), "traffic_source": pmc_source("edgeconv"),
                 "avg_launch_ms": ec_ms, "algorithmic_flop_per_launch": alg}
     prods = SPLIT_PRODUCTS[arith]
     peak = MFMA_BF16_PEAK_TF / prods
     l1 = B_PER_GPU * NPTS * KNN * 2 * 6 * 64                       # layer 1 stays on the fp32 MFMA
-    name = "edgeconv_f16b_kernel<5,true>" if arith == "f16x2" else "edgeconv_split_kernel<5>"
+    name = "edgeconv_f16b_kernel<3,true>" if arith == "f16x2" else "edgeconv_split_kernel<5>"
     return {"kernel": name, "bound": "mfma", "achieved": ec_tf, "peak": peak,
             "unit": "TFLOP/s", "frac": ec_tf / peak, "traffic": pmc_traffic("edgeconv_f16b" if arith == "f16x2" else "edgeconv_split") or pmc_traffic("edgeconv_f16"),
+            "traffic_source": pmc_source("edgeconv_f16b" if arith == "f16x2" else "edgeconv_split") or pmc_source("edgeconv_f16"),
             "avg_launch_ms": ec_ms, "algorithmic_flop_per_launch": alg,
             "peak_note": f"fp32-equivalent ceiling = dense fp16/bf16 MFMA peak 2500 TFLOP/s / {prods} products per fp32 product "
                          "(the fp32 MFMA peak is 157.3 TFLOP/s)",
@@ -332,53 +339,105 @@ def c5_cpu_baseline(sample_clouds=4, repeats=1):
 def main_c5(args, rank, world, local, dev, dist, parallel):
     multi = world > 1 or dist.is_initialized()      # a one-rank RCCL group (L3D_INIT_SINGLE_RANK=1) takes the N > 1 code path
     from learning3d_amd.models import PointNetSetAbstraction, _fused
+    pipelined = not args.c5_serial
+    # two resident input batches, consumed alternately (a stream of batches; the pipelined mode samples batch i + 1 while batch i's
+    # ball query / grouping / MLP run, so consecutive steps must not be the same tensor)
     g = torch.Generator().manual_seed(2000 + rank)
-    xyz = torch.clamp(torch.randn((B_PER_GPU, 3, C5_N), generator=g), -2, 2).to(dev)      # N(0,1) clipped to [-2,2]
-    feat = torch.rand((B_PER_GPU, 3, C5_N), generator=g).to(dev)
+    xyzs = [torch.clamp(torch.randn((B_PER_GPU, 3, C5_N), generator=g), -2, 2).to(dev) for _ in range(2)]   # N(0,1) clipped to [-2,2]
+    feats = [torch.rand((B_PER_GPU, 3, C5_N), generator=g).to(dev) for _ in range(2)]
     torch.manual_seed(1)
     sa = PointNetSetAbstraction(npoint=C5_S, radius=C5_R, nsample=C5_K, in_channel=3, mlp=list(C5_MLP), group_all=False).to(dev).eval()
+    side = torch.cuda.Stream()
 
-    def compute():
+    def digest(new_xyz, new_feat):
+        # the shard's digest (sum, sum of squares, count, centroid checksum): where a training loop's per-shard loss partials go
+        f64 = new_feat.double()
+        return torch.stack([f64.sum(), (f64 * f64).sum(), f64.new_full((), float(f64.numel())), new_xyz.double().sum()])
+
+    def compute_serial(cur):
         with torch.no_grad():
-            new_xyz, new_feat = sa(xyz, feat)
-            # the shard's digest (sum, sum of squares, count, centroid checksum): where a training loop's per-shard loss partials go
-            f64 = new_feat.double()
-            part = torch.stack([f64.sum(), (f64 * f64).sum(), f64.new_full((), float(f64.numel())), new_xyz.double().sum()])
-        return new_feat, part
+            new_xyz, new_feat = sa(xyzs[cur], feats[cur])
+            return new_feat, digest(new_xyz, new_feat)
 
-    graph, graph_out = None, None
+    def compute_pipe(cur, fps_cur, fps_out=None):
+        """batch `cur` from its sampled indices on the main stream; batch 1 - cur's furthest point sampling (1024 dependent rounds,
+        one workgroup per cloud = 32 of 256 CUs) beside it on the side stream; joined at the end of the step"""
+        main = torch.cuda.current_stream()
+        with torch.no_grad():
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                nxt = sa.sample(xyzs[1 - cur])
+                if fps_out is not None:
+                    fps_out.copy_(nxt)
+                    nxt = fps_out
+            new_xyz, new_feat = sa(xyzs[cur], feats[cur], fps_idx=fps_cur)
+            part = digest(new_xyz, new_feat)
+            main.wait_stream(side)
+        return new_feat, part, nxt
 
-    def step(eager=False):
-        if graph is not None and not eager:
-            graph.replay()
-            nf, part = graph_out
-        else:
-            nf, part = compute()
+    graphs, graph_outs = None, None
+    state = {"cur": 0, "fps": None}
+    if pipelined:
+        with torch.no_grad():
+            state["fps"] = sa.sample(xyzs[0])
+
+    def exchange(part, cloned):
         if multi:
             flat = torch.empty(world * 4, dtype=torch.float64, device=dev)
-            dist.all_gather_into_tensor(flat, part.clone() if graph is not None and not eager else part)   # 32 B per rank over RCCL
-            return nf, flat.view(world, 4).sum(0)
-        return nf, part
+            dist.all_gather_into_tensor(flat, part.clone() if cloned else part)   # 32 B per rank over RCCL
+            return flat.view(world, 4).sum(0)
+        return part
+
+    def step():
+        cur = state["cur"]
+        state["cur"] = 1 - cur
+        if graphs is not None:
+            graphs[cur].replay()
+            nf, part = graph_outs[cur]
+            return nf, exchange(part, True)
+        if pipelined:
+            nf, part, state["fps"] = compute_pipe(cur, state["fps"])
+        else:
+            nf, part = compute_serial(cur)
+        return nf, exchange(part, False)
 
     for _ in range(20):
         step()
     if not args.no_graph:
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    compute()
-            torch.cuda.current_stream().wait_stream(side)
-            g_ = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_):
-                graph_out = compute()
-            graph = g_
-            for _ in range(5):
+            torch.cuda.synchronize()
+            warm = torch.cuda.Stream()
+            warm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(warm):
+                for _ in range(4):
+                    step()
+            torch.cuda.current_stream().wait_stream(warm)
+            torch.cuda.synchronize()
+            gs, outs = [], []
+            if pipelined:
+                # graph c: batch c from the static index buffer F[c], batch 1 - c sampled into F[1 - c]
+                with torch.no_grad():
+                    F = [sa.sample(xyzs[0]), sa.sample(xyzs[1])]
+                torch.cuda.synchronize()
+                for c in (0, 1):
+                    g_ = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_):
+                        nf, part, _ = compute_pipe(c, F[c], fps_out=F[1 - c])
+                    gs.append(g_)
+                    outs.append((nf, part))
+            else:
+                for c in (0, 1):
+                    g_ = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_):
+                        outs.append(compute_serial(c))
+                    gs.append(g_)
+            state["cur"] = 0
+            graphs, graph_outs = gs, outs
+            for _ in range(6):
                 step()
             torch.cuda.synchronize()
         except Exception as exc:
-            graph = None
+            graphs = None
             if rank == 0:
                 print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eager", file=sys.stderr)
     for _ in range(args.warmup):
@@ -389,21 +448,32 @@ def main_c5(args, rank, world, local, dev, dist, parallel):
             dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
-    timer = _fused.StageTimer(only=("group_kernel", "fps", "ball_query", "mlp"))
-    _fused.TIMER = timer
-    nsamp = max(1, min(8, args.steps // 10))
-    stride = max(1, -(-args.steps // nsamp))
     sync()
     t0 = time.perf_counter()
-    digest = None
+    digest_v = None
     for i in range(args.steps):
-        sampled = i % stride == stride // 2           # mid-stride: the eager step's host work hides behind queued replays
-        timer.enabled = sampled
-        _, digest = step(eager=sampled)
+        _, digest_v = step()
     sync()
     elapsed = time.perf_counter() - t0
+
+    # untimed: the kernels' own durations (HIP events around the stages of a few SERIAL eager steps on one stream) and the
+    # serial step itself (sampling, then the rest, back to back: one batch's latency)
+    timer = _fused.StageTimer(only=("group_kernel", "fps", "ball_query", "mlp"))
+    _fused.TIMER = timer
+    for c in (0, 1, 0, 1):
+        compute_serial(c)
+    torch.cuda.synchronize()
     _fused.TIMER = None
     stage_ms = timer.mean_ms()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for c in (0, 1):
+        compute_serial(c)
+    e0.record()
+    for c in (0, 1) * 5:
+        compute_serial(c)
+    e1.record()
+    torch.cuda.synchronize()
+    serial_ms = e0.elapsed_time(e1) / 10
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     per_rank = [t.clone() for _ in range(world)]
@@ -415,29 +485,36 @@ def main_c5(args, rank, world, local, dev, dist, parallel):
         grp_ms = stage_ms["group_kernel"]
         grp_gbs = B_PER_GPU * C5_GROUP_BYTES_PER_CLOUD / (grp_ms * 1e-3) / 1e9
         out = {
-            "metric": "clouds/sec DGCNN-fwd+Chamfer B=32 N=1024; kNN HBM GB/s vs peak at 1/2/4/8 GPU",
+            "metric": "clouds/sec FlowNet3D sa1 set-conv (FPS + ball query + grouping + shared MLP) B=32 per GPU N=8192 -- BASELINE configs[4], "
+                      "NOT the headline metric (that is the default --workload c2 line)",
             "value": world * B_PER_GPU * args.steps / elapsed, "unit": "clouds/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "f32 (index work int32; shared MLP on the fp32 MFMA)", "data": "synthetic",
             "config": {"workload": "configs[4] (NOT the headline config; --workload c5): FlowNet3D sa1 set-conv forward -- furthest "
                                    "point sampling 8192 -> 1024, ball query r=0.5 K=16, grouping, shared MLP 6->32->32->64 + max "
-                                   "over K, eval, random-init weights; 32 clouds per GPU, inputs resident in HBM",
+                                   "over K, eval, random-init weights; 32 clouds per GPU, two resident input batches consumed alternately",
                        "global_batch": world * B_PER_GPU, "num_points": C5_N, "npoint": C5_S, "nsample": C5_K, "radius": C5_R,
-                       "launch": "hipGraph replay" if graph is not None else "eager launches",
+                       "launch": "hipGraph replay" if graphs is not None else "eager launches",
+                       "pipeline": ("batch i + 1's furthest point sampling (one workgroup per cloud: 32 of 256 CUs) on a second stream beside "
+                                    "batch i's ball query / grouping / MLP, joined at the end of every step; every step still produces one "
+                                    "batch's complete output" if pipelined else "none: sampling, then the rest, on one stream"),
                        "parallelism": f"batch-sharded x{world}, no data-path collective; one 32-byte all_gather of the shard digest per step"},
             "rccl_ranks": (dist.get_world_size() if multi else 1), "dist_backend": dist.get_backend() if multi else None,
             "per_rank_ms_per_step": [float(v) / args.steps * 1e3 for v in per_rank[:, 0]],
+            "serial_ms_per_step": serial_ms,
             # the one HBM-bound op of the path: the grouping gather
             "roofline": {"kernel": "group_concat_kernel", "bound": "hbm", "achieved": grp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": grp_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("group_c5"), "avg_launch_ms": grp_ms,
+                         "frac": grp_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("group_c5"),
+                         "traffic_source": pmc_source("group_c5"), "avg_launch_ms": grp_ms,
                          "algorithmic_bytes_per_launch": B_PER_GPU * C5_GROUP_BYTES_PER_CLOUD,
-                         "note": "13 us of a ~1.2 ms step: the step is bound by furthest point sampling's 1024 dependent rounds "
+                         "note": "microseconds of a ~1 ms step: the step is bound by furthest point sampling's 1024 dependent rounds "
                                  "(latency, one workgroup per cloud), see kernels.fps_ms"},
             "kernels": {"fps_ms": stage_ms.get("fps"), "ball_query_ms": stage_ms.get("ball_query"), "group_ms": grp_ms,
                         "mlp_ms": stage_ms.get("mlp"),
                         "mlp_tflops": B_PER_GPU * C5_MLP_FLOP_PER_CLOUD / (stage_ms["mlp"] * 1e-3) / 1e12 if stage_ms.get("mlp") else None,
-                        "fps_pair_evals_per_s": B_PER_GPU * C5_S * C5_N / (stage_ms["fps"] * 1e-3) if stage_ms.get("fps") else None},
-            "digest": [float(v) for v in digest],
+                        "fps_pair_evals_per_s": B_PER_GPU * C5_S * C5_N / (stage_ms["fps"] * 1e-3) if stage_ms.get("fps") else None,
+                        "note": "HIP events around the stages of serial eager steps after the timed region"},
+            "digest": [float(v) for v in digest_v],
         }
         if not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = c5_cpu_baseline()
@@ -454,6 +531,9 @@ def main():
                          "c5: BASELINE configs[4]'s sharded layer, FlowNet3D sa1 set-conv (FPS + ball query + grouping + "
                          "3-layer shared MLP), 32 clouds x 8192 points per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--c5-serial", action="store_true",
+                    help="--workload c5: sampling and the rest of each batch on one stream (default: batch i + 1's furthest point "
+                         "sampling runs on a second stream beside batch i's ball query / grouping / MLP)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the untimed configs[2..4] extras (DCP-v2 forward, PCN + Chamfer, FlowNet3D sa1 / forward) of the c2 line")
     ap.add_argument("--sync-loss", action="store_true",
@@ -790,6 +870,7 @@ def main():
             "roofline_knn": {"kernel": "knn_mfma_kernel<8>", "bound": "hbm", "achieved": knn_gbs,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": knn_gbs / HBM_PEAK_GBS,
                              "traffic": pmc_traffic("knn_mfma") or pmc_traffic("knn"),
+                             "traffic_source": pmc_source("knn_mfma") or pmc_source("knn"),
                              "avg_launch_ms": stage_ms["knn"],
                              "algorithmic_bytes_per_launch": B_PER_GPU * KNN_BYTES_PER_CLOUD,
                              "note": "VALU-bound by construction (33.5 M pair evaluations per 5.6 MB; ranking values come from the fp32 matrix cores, selection is VALU work), see DESIGN.md",

@@ -261,15 +261,6 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
     static_assert(!RESID || (NPW == 3 && !NARROW && !AMAX && !GROUP), "residual epilogue: wide tile, fp32 output");
     constexpr int WBYTES = 2 * NPW * WR, STAGE = WBYTES + 4 * XR;
     constexpr int NPIECE = NARROW ? 6 : (NPW == 3 ? 5 : 4);     // DMA instructions per wave and chunk
-    // SWAP (the two-plane instantiation = DGCNN's conv5, fp32 output only): x fragments as the MFMA's A operand and W fragments
-    // as its B operand -- the same LDS reads, the transposed accumulator tile D[n][co].  A lane then holds FOUR CONSECUTIVE POINTS
-    // of one channel per register quad, and the 134 MB epilogue is 32 global_store_dwordx4 per lane instead of 128
-    // global_store_dword: the store tail is bound by the number of store INSTRUCTIONS (a CU takes ~16 cycles per wave-store
-    // whatever its width, cdna_hip_programming.md T21), not by bytes.  scale / shift become one value per lane and M-tile.
-#ifndef CF_SWAP
-#define CF_SWAP 1
-#endif
-    constexpr bool SWAP = CF_SWAP && NPW == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = NARROW ? (wave & 1) : (wave & 3), wn = NARROW ? (wave >> 1) : (wave >> 2);
@@ -388,8 +379,7 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
             const int prod = n >> 3, a = (n >> 2) & 1, c = n & 3;
             const int pa = NPW == 3 ? (prod == 0 ? 2 : (prod == 1 ? 1 : 0)) : (prod == 0 ? 1 : 0);      // M, Hs | H, H
             const int pb = prod == 1 ? 1 : 0;
-            if constexpr (SWAP) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bf[c][pb], A[a][pa], acc[a][c], 0, 0, 0);
-            else acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][pa], Bf[c][pb], acc[a][c], 0, 0, 0);
+            acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[a][pa], Bf[c][pb], acc[a][c], 0, 0, 0);
             constexpr int GAP = NARROW ? 4 : (NPW == 3 ? 5 : 6);  // behind MFMA 3, 8, 13, 18, 23 (NARROW: 3, 7, .. 23; two planes: 3, 9, 15, 21)
             if (n % GAP == 3) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -550,29 +540,6 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
     }
     float *yb = y + (size_t)b * Cout * N;
     const float *rb = RESID ? obs + (size_t)b * Cout * N : nullptr;
-    if constexpr (SWAP) {
-        // D[n = 32 c + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][co = 32 a + (lane & 31)]: registers 4 q .. 4 q + 3 are 16 contiguous bytes of y
-#pragma unroll
-        for (int a = 0; a < 2; a++) {
-            const int co = co0 + wm * 64 + a * 32 + (lane & 31);
-            const float sc = (scale ? scale[co] : 1.f) * inv;
-            const float sh = shift ? shift[(size_t)b * shift_bstride + co] : 0.f;
-            float *row = yb + (size_t)co * N + n0 + wn * 128 + 4 * (lane >> 5);
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    f32x4 v;
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        v[u] = acc[a][c][4 * q + u] * sc + sh;
-                        if (relu) v[u] = l3d_act(v[u], relu);
-                    }
-                    *(f32x4 *)(row + c * 32 + 8 * q) = v;
-                }
-        }
-        return;
-    }
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll

@@ -194,11 +194,19 @@ class PointNetSetAbstraction(nn.Module):
             last_channel = out_channel
         self.queryandgroup = pointutils.GroupAll() if group_all else pointutils.QueryAndGroup(radius, nsample)
 
-    def forward(self, xyz, points):
+    def sample(self, xyz):
+        """The furthest-point-sampling indices forward() would draw for `xyz` [B,3,N] (int32 [B,S]).  Sampling is 1024 dependent
+        rounds on ONE workgroup per cloud (32 of 256 CUs at config 5) and depends on the coordinates only: a caller that streams
+        batches can issue it for batch i + 1 on a second stream while batch i's ball query / grouping / MLP fill the other CUs,
+        and hand the result to forward(..., fps_idx=...) (bench.py --workload c5 does)."""
+        return pointutils.furthest_point_sample(xyz.permute(0, 2, 1).contiguous(), self.npoint)
+
+    def forward(self, xyz, points, fps_idx=None):
         xyz_t = xyz.permute(0, 2, 1).contiguous()
         if not self.group_all:
-            with _fused.stage("fps"):
-                fps_idx = pointutils.furthest_point_sample(xyz_t, self.npoint)
+            if fps_idx is None:
+                with _fused.stage("fps"):
+                    fps_idx = pointutils.furthest_point_sample(xyz_t, self.npoint)
             new_xyz = pointutils.gather_operation(xyz.contiguous(), fps_idx)          # [B,3,S]
         else:
             new_xyz = xyz

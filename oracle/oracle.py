@@ -117,6 +117,26 @@ def query_ball_point(radius, nsample, xyz, new_xyz, get_cnt=False):
     return (idx, cnt) if get_cnt else idx
 
 
+def query_ball_point_itself(radius, nsample, xyz, new_xyz, itself_indices):
+    """utils/ppfnet_util.py:96-131 with itself_indices: the centre's own index is taken out of its neighbourhood (:116-119, set to
+    N before the radius test), the first nsample hits in index order are kept (sort, :122) and short rows are padded with the
+    centre's index (:123-128).  numpy on top of square_distance (the expanded fp32 form the reference's square_distance computes)."""
+    x, q = _f(xyz), _f(new_xyz)
+    it = np.asarray(itself_indices, dtype=np.int64)
+    B, N, _ = x.shape
+    S = q.shape[1]
+    d2 = square_distance(q, x)
+    idx = np.empty((B, S, nsample), np.int64)
+    r2 = np.float32(radius ** 2)                              # `radius ** 2` is a Python float; the comparison promotes it to fp32
+    for b in range(B):
+        for s in range(S):
+            hits = np.nonzero(~(d2[b, s] > r2))[0]
+            hits = hits[hits != it[b, s]][:nsample]
+            idx[b, s, :len(hits)] = hits
+            idx[b, s, len(hits):] = it[b, s]
+    return idx
+
+
 # --------------------------------------------------------------------------- a5
 def index_points(points, idx):
     """utils/model_common_utils.py:40-56."""

@@ -2231,3 +2231,54 @@ def test_knn_small_kernel_equals_lane_kernel(B, n, m, k):
         full = (dx[..., 0] * dx[..., 0] + dx[..., 1] * dx[..., 1]) + dx[..., 2] * dx[..., 2]
         order = torch.argsort(full, dim=-1, stable=True)[..., :k]
         assert torch.equal(i3.long(), order)
+
+
+# ------------------------------------------------------------------ round 4: fixtures held by the reference
+def test_ppfnet_query_ball_and_sample_and_group_multi_reference_golden(golden, monkeypatch):
+    """utils/ppfnet_util.py:96-131 (query_ball_point with itself_indices) and :193-243 (sample_and_group_multi) against
+    fixtures generated from the imported reference (tests/golden/make_golden_r4.py).  The reference samples its centres from a
+    random start (:84), so the fixture's centres take the place of farthest_point_sample on both sides."""
+    import learning3d_amd.utils.ppfnet_util as PP
+    from learning3d_amd.utils import query_ball_point
+    g = golden("ppfnet_util")
+    xyz, nrm = dev(g["xyz"]), dev(g["normals"])
+    fps = dev(g["fps"]).long()
+    r, K = float(g["radius"]), int(g["nsample"])
+    new_xyz = PP.index_points(xyz, fps)
+    assert np.array_equal(query_ball_point(r, K, xyz, new_xyz, itself_indices=fps).cpu().numpy(), g["idx_itself"])
+    assert np.array_equal(query_ball_point(r, K, xyz, new_xyz).cpu().numpy(), g["idx_plain"])
+    assert np.array_equal(query_ball_point(0.02, K, xyz, new_xyz, itself_indices=fps).cpu().numpy(), g["idx_tiny"])
+    monkeypatch.setattr(PP, "farthest_point_sample", lambda x, n: fps)
+    S = fps.shape[1]
+    out, grouped, fps_ret = PP.sample_and_group_multi(S, r, K, xyz, nrm, returnfps=True)
+    assert torch.equal(fps_ret, fps)
+    np.testing.assert_array_equal(out["xyz"].cpu().numpy(), g["multi_xyz"])
+    np.testing.assert_array_equal(out["dxyz"].cpu().numpy(), g["multi_dxyz"])
+    np.testing.assert_array_equal(grouped.cpu().numpy(), g["multi_grouped"])
+    np.testing.assert_allclose(out["ppf"].cpu().numpy(), g["multi_ppf"], rtol=1e-5, atol=2e-6)     # atan2 / norm: libm vs device
+    nx, npts = PP.sample_and_group(S, r, K, xyz, nrm)
+    np.testing.assert_array_equal(nx.cpu().numpy(), g["sg_new_xyz"])
+    np.testing.assert_array_equal(npts.cpu().numpy(), g["sg_new_points"])
+    out_all = PP.sample_and_group_multi(-1, r, K, xyz[:, :64].contiguous(), nrm[:, :64].contiguous())
+    np.testing.assert_array_equal(out_all["dxyz"].cpu().numpy(), g["all_dxyz"])
+    np.testing.assert_allclose(out_all["ppf"].cpu().numpy(), g["all_ppf"], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("tag,use_bn", [("ipcrnet", False), ("pnlk", True)])
+def test_pointnet_trained_checkpoints_f16x2(golden, tag, use_bn):
+    """The reference's two other trained PointNet feature extractors (pretrained/exp_ipcrnet and exp_pnlk, best_ptnet_model.t7)
+    through the f16x2 route (and bf16x3): trained weight magnitudes beyond config 1's classifier checkpoint.  Features against
+    the reference's own forward, rtol 1e-4 / atol 1e-5 of the feature scale."""
+    from learning3d_amd.models import PointNet, _fused
+    g = golden("ptnet_checkpoints")
+    sd = {k[len(tag) + 3:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith(tag + ".w.")}
+    net = PointNet(emb_dims=1024, use_bn=use_bn)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    want = g[tag + ".out"]
+    scale = float(np.abs(want).max())
+    for arith in ("f16x2", "bf16x3"):
+        with _fused.arith(arith):
+            got = net(dev(g["x"])).detach().cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5 * max(1.0, scale), err_msg=f"{tag} {arith}")
+    _fused.check_range(sync=True)

@@ -38,6 +38,16 @@ def test_query_ball_point(golden):
     assert np.array_equal(far, g["idx_far"]) and (far == g["xyz"].shape[1]).all()
 
 
+def test_query_ball_point_itself_indices(golden):
+    """ppfnet_util.py:96-131 with itself_indices, pinned by the reference-generated fixture (tests/golden/make_golden_r4.py)"""
+    g = golden("ppfnet_util")
+    new_xyz = oracle.index_points(g["xyz"], g["fps"].astype(np.int64))
+    for key, r in (("idx_itself", float(g["radius"])), ("idx_tiny", 0.02)):
+        got = oracle.query_ball_point_itself(r, int(g["nsample"]), g["xyz"], new_xyz, g["fps"])
+        assert np.array_equal(got, g[key]), key
+    assert np.array_equal(oracle.query_ball_point(float(g["radius"]), int(g["nsample"]), g["xyz"], new_xyz), g["idx_plain"])
+
+
 def test_index_points(golden):
     g = golden("index_points")
     assert np.array_equal(oracle.index_points(g["points"], g["idx2"]), g["out2"])

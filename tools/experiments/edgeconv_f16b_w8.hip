@@ -47,9 +47,6 @@
 #include "split_bf16.h"      // f32x2 / f32x4 typedefs
 
 #define EF_V2 1
-#ifndef EF_SPLIT_MIX
-#define EF_SPLIT_MIX 0
-#endif
 // Layer 4's weight fragments (128 KB as two planes) are copied to LDS once per workgroup and read from there by every tile -- a
 // ds_read_b128 beside the MFMA stream costs about half of a global_load_dwordx4 (LABLOG R2.2: +19 vs +43 cycles per 5 MFMAs) and
 // layer 4 issues 128 of them per tile.
@@ -59,9 +56,9 @@
 //                      (contiguous in the fifth copy, edgeconv_layout.h) -- every bias and layer 1's weights are read from
 //                      here with ds_read, so that NO parameter of layers 1 and 4 travels through vmcnt (a global load's
 //                      s_waitcnt also waits for every store issued before it: vmcnt is one in-order counter)
-//   EF_STG_A           per wave 4 KB: the pooled planes of layers 1-3 of the current tile, [plane 2][cell row 32][point 4][8 f16]
-//   EF_STG_B           per wave 2 x 1 KB: the pooled planes of two layer-4 pairs each, [slot 2][plane 2][cell row 4][point 4][8 f16]
-// The staged values leave as 16-byte stores from inside layer 4 (64 two-byte stores per wave and tile before).
+//   EF_STG_A           per wave 2 KB: the pooled planes of layers 1-3 of the current tile, [plane 2][cell row 32][point 2][8 f16]
+//   EF_STG_B           per wave 1 KB: the pooled planes of four layer-4 pairs, [slot 4][plane 2][cell row 4][point 2][8 f16]
+// The staged values leave as 16-byte stores, four per wave and tile (64 two-byte stores per wave and tile in round 3).
 #define EF_PAR_FLOATS (EC5_OFF_SC + 16 - EC5_OFF_W4)
 #define EF_PAR_BYTES (EF_PAR_FLOATS * 4)
 #define EF_LOFF_B2 (EF_W4_BYTES)
@@ -69,9 +66,12 @@
 #define EF_LOFF_B4 (EF_LOFF_B3 + 4 * EC_C3)
 #define EF_LOFF_W1 (EF_LOFF_B4 + 4 * EC_C4)
 #define EF_LOFF_B1 (EF_LOFF_W1 + 4 * 8 * EC_C1)
+#define EF_NW 8                        // waves per workgroup: two per SIMD
+#define EF_PTS 2                       // points per wave; a row tile of 16 rows = EF_PTS points x 8 neighbours
+#define EF_CR (EF_PTS * 16)            // bytes of one (plane, cell row) of a wave's staging area: EF_PTS points x 8 channels x fp16
 #define EF_STG_A (EF_PAR_BYTES)
-#define EF_STG_B (EF_STG_A + 4 * 4096)
-#define EF_LDS_BYTES (EF_STG_B + 4 * 2048)
+#define EF_STG_B (EF_STG_A + EF_NW * 64 * EF_CR)
+#define EF_LDS_BYTES (EF_STG_B + EF_NW * 32 * EF_CR)
 static_assert(EC5_OFF_B2 == EC5_OFF_W4 + EF_W4_BYTES / 4 && EC5_OFF_B1 == EC5_OFF_W1 + 8 * EC_C1 && EC5_OFF_SC == EC5_OFF_B1 + EC_C1,
               "the fifth copy's tail is one contiguous run");
 static_assert(EF_PAR_BYTES % 16 == 0 && EF_LDS_BYTES <= 163840, "LDS budget");
@@ -110,7 +110,7 @@ typedef EfBase ef_rsrc_t;
 // MFMA that wrote it (see the unit order), and the two places where that does not hold by construction carry s_nop.
 // ---------------------------------------------------------------------------------------------
 #ifndef EF_AHOME
-#define EF_AHOME 1          // weight fragments (MFMA A operand): 0 = VGPRs, 1 = AGPRs (global_load writes them directly)
+#define EF_AHOME 0          // weight fragments (MFMA A operand): 0 = VGPRs, 1 = AGPRs (global_load writes them directly)
 #endif
 #if EF_AHOME
 #define EF_ACON "a"
@@ -161,6 +161,15 @@ __device__ __forceinline__ float ef_dpp_max_x2(float give, float keep)
     return r;
 }
 
+// d[lane] = max(v[lane], v[lane ^ 7 within its group of 8]): the first step of the max over a row tile's 8 neighbours -- afterwards
+// both quads of the group hold, between them, every pair (i, 7 - i), and the quad reduce below completes the maximum in each
+__device__ __forceinline__ float ef_dpp_max_half_mirror(float v)
+{
+    float r;
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    return r;
+}
+
 // relu'd accumulators (scaled domain: a = 2^S y) of one value pair -> packed fp16 (h, m') words of y = a c:
 //   h = f16(a c) (c = 2^-S: the product is exact, one rounding), r = a c - h (exact), m' = f16(r 2^12)
 __device__ __forceinline__ void ef_split_pair(float a0, float a1, float c, uint32_t &h, uint32_t &m)
@@ -170,14 +179,6 @@ __device__ __forceinline__ void ef_split_pair(float a0, float a1, float c, uint3
     // residuals.  s_nop: VALU write -> SDWA read of the same VGPR, not seen by the hazard recogniser inside asm.
     float f0, f1;
     asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(a0), "v"(a1));
-#if EF_SPLIT_MIX
-    // three instructions per value pair instead of six: v_fma_mixlo/hi_f16 form a * 1.0 - f32(h half) in fp32 (exact: a - h is
-    // representable) and round it to the fp16 half of m in the same instruction -- the same bits as convert, subtract, convert
-    asm volatile("s_nop 0\n\tv_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(m) : "v"(a0), "v"(h));
-    asm volatile("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(m) : "v"(a1), "v"(h));
-    (void)c; (void)f0; (void)f1; (void)r0; (void)r1;
-    return;
-#endif
     asm volatile("v_cvt_f32_f16_e32 %0, %1" : "=v"(f0) : "v"(h));
     asm volatile("s_nop 0\n\tv_cvt_f32_f16_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f1) : "v"(h));
     asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r0) : "v"(a0), "v"(f0));
@@ -256,18 +257,18 @@ __device__ __forceinline__ void ef_micro(f32x4 (&h)[2][MT], f16x8 (&pl)[2][MT], 
         }
     } else if constexpr (U < NT + 8) {                       // max over the row tiles (= 4 MT neighbours), one register
         constexpr int k = (U - NT) / 4, r = (U - NT) % 4;
-        static_assert(MT >= 3 && MT <= 5, "row tiles per wave");
+        static_assert(MT >= 2 && MT <= 3, "row tiles per wave");
+        float m;
         if constexpr (RAW) {
-            float m = ef_vmax3(h[k][0][r], h[k][1][r], h[k][2][r]);
-            if constexpr (MT == 4) m = ef_vmax(m, h[k][3][r]);
-            if constexpr (MT == 5) m = ef_vmax3(m, h[k][3][r], h[k][4][r]);
-            T.mx[k][r] = m;
+            if constexpr (MT == 2) m = ef_vmax(h[k][0][r], h[k][1][r]);
+            else m = ef_vmax3(h[k][0][r], h[k][1][r], h[k][2][r]);
         } else {
-            float m = h[k][0][r];
+            m = h[k][0][r];
 #pragma unroll
             for (int t = 1; t < MT; t++) m = fmaxf(m, h[k][t][r]);
-            T.mx[k][r] = m;
+            asm volatile("" : "+v"(m));                      // the DPP below reads it: a compiler-visible producer must be done (hazard padding)
         }
+        T.mx[k][r] = ef_dpp_max_half_mirror(m);
     } else {                                                 // transposing quad reduce, ReLU (LAST), scale, store
         constexpr int k = (U - NT - 8) / 2, part = (U - NT - 8) % 2;
         if constexpr (part == 0) {
@@ -287,14 +288,14 @@ __device__ __forceinline__ void ef_micro(f32x4 (&h)[2][MT], f16x8 (&pl)[2][MT], 
                 const _Float16 mm = (_Float16)((v - (float)hh) * L.mres);
                 typedef __attribute__((address_space(3))) _Float16 *lh_t;
                 if constexpr (!LAST) {                       // layers 1-3: area A, cell row (ch0 + 16 k) / 8 (+ 1 inside the lane part)
-                    const int off = ((ch0 + 16 * k) >> 3) * 64;
+                    const int off = ((ch0 + 16 * k) >> 3) * EF_CR;
                     *(lh_t)(L.stgA + off) = hh;
-                    *(lh_t)(L.stgA + off + 2048) = mm;
-                } else {                                     // layer 4, pair m: area B, chunk (m >> 1) & 1, slot m & 1, cell rows 2 k (+ 1)
+                    *(lh_t)(L.stgA + off + 32 * EF_CR) = mm;
+                } else {                                     // layer 4, pair m: area B, slot m & 3, cell rows 2 k (+ 1)
                     const int m = (ch0 - (EC_C1 + EC_C2 + EC_C3)) >> 5;
-                    const int off = ((m >> 1) & 1) * 1024 + (m & 1) * 512 + (2 * k) * 64;
+                    const int off = (m & 3) * 8 * EF_CR + (2 * k) * EF_CR;
                     *(lh_t)(L.stgB + off) = hh;
-                    *(lh_t)(L.stgB + off + 256) = mm;
+                    *(lh_t)(L.stgB + off + 4 * EF_CR) = mm;
                 }
             } else {
                 L.prow[ch0 + 16 * k] = v;
@@ -331,7 +332,7 @@ __device__ __forceinline__ void ef_finish_all(f32x4 (&h)[2][MT], f16x8 (&pl)[2][
 // pair and from layer to layer.  A step is only 3 x MT MFMAs (~250 cycles): two steps ahead (what the bf16x3 kernel,
 // with 6 x MT MFMAs per step, gets away with) is less than an L2 hit under load and stalled every step.
 #ifndef EF_PD
-#define EF_PD 4
+#define EF_PD 2
 #endif
 struct EfRing {
     u32x4 a[EF_PD][EF_NPL];  // fragments (H, Hs, M planes; EF_V2: H, M) of the next EF_PD steps
@@ -349,9 +350,15 @@ struct EfNext {              // where the pair executed after this one finds its
 // compiler spends ~50 VALU per 240 MFMAs on 64-bit address arithmetic); a buffer descriptor with scalar offsets
 // (no VALU at all) 20.9 k -- the cost beside the MFMAs is the issue of the load itself (one global_load_dwordx4 per
 // 5 MFMAs costs the stream ~40 cycles, tools/probe_mfma_filler.hip), not its address.
+// With two waves per SIMD (256 registers each) the address must NOT be loop-invariant code: left to itself the compiler hoists
+// one 64-bit VGPR address per fragment of layers 2 and 3 out of the tile loop (48 of them) and spills them.  The uniform part is
+// therefore formed in SGPRs behind an opaque barrier and the lane offset added at the load.
 __device__ __forceinline__ u32x4 ef_ldfrag(ef_rsrc_t rs, int byte_off, int frag, unsigned laneoff)
 {
-    return *(const u32x4 *)(rs.p + (size_t)byte_off + (size_t)frag * 1024 + laneoff);
+    typedef const __attribute__((address_space(1))) char *gptr_t;
+    gptr_t b = (gptr_t)rs.p + ((size_t)byte_off + (size_t)frag * 1024);
+    asm volatile("" : "+s"(b));
+    return *(const __attribute__((address_space(1))) u32x4 *)(b + laneoff);
 }
 
 __device__ __forceinline__ u32x4 ef_ldfrag_lds(ef_lds_t base, int frag, unsigned laneoff)
@@ -533,7 +540,7 @@ __device__ __forceinline__ void ef_gather_idx(EfGather<MT> &G, int tile, int til
                                               const int64_t *__restrict__ idx, int wave, int j, int g)
 {
     const int b = tile / tiles_per_cloud, xb = tile - b * tiles_per_cloud;     // uniform: a tile lies inside one cloud
-    const int n = (xb * 4 + wave) * 4 + (j >> 2);
+    const int n = (xb * EF_NW + wave) * EF_PTS + (j >> 3);
     const int nc = min(n, N - 1);                                   // lanes past N recompute point N-1
     G.b = b;
     G.nc = nc;
@@ -542,8 +549,8 @@ __device__ __forceinline__ void ef_gather_idx(EfGather<MT> &G, int tile, int til
     const int64_t *row = idx + (size_t)b * N * k;
 #pragma unroll
     for (int t = 0; t < MT; t++) {
-        const int jj = 4 * t + (j & 3);
-        G.nb[t] = (int)row[nc * k + (jj < k ? jj : 0)];             // pad k up to 4*MT with a duplicate
+        const int jj = 8 * t + (j & 7);
+        G.nb[t] = (int)row[nc * k + (jj < k ? jj : 0)];             // pad k up to 8*MT with a duplicate
     }
 }
 
@@ -561,7 +568,7 @@ __device__ __forceinline__ void ef_gather_xyz(EfGather<MT> &G, int N, const floa
 }
 
 template <int MT, bool PLANES>
-__global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xyz,
+__global__ __launch_bounds__(64 * EF_NW, 1) void EF_KERNEL(const float *__restrict__ xyz,
                                                               const int64_t *__restrict__ idx, int B, int N, int k,
                                                               const float *packed,
                                                               float *__restrict__ pooled,
@@ -589,17 +596,17 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
         const uint4 *src = (const uint4 *)(packed + EFO_W4);
         uint4 *dst = (uint4 *)ef_lds;
 #pragma unroll 8
-        for (int i = threadIdx.x; i < EF_PAR_BYTES / 16; i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < EF_PAR_BYTES / 16; i += 64 * EF_NW) dst[i] = src[i];
     }
     // this lane's 2-byte cell inside its wave's staging areas: cell row (cl >> 3), point j >> 2, channel cl & 7
     {
-        const int cell = (cl >> 3) * 64 + (j >> 2) * 16 + (cl & 7) * 2;
-        L.stgA = (ef_ldsw_t)ef_lds + EF_STG_A + wave * 4096 + cell;
-        L.stgB = (ef_ldsw_t)ef_lds + EF_STG_B + wave * 2048 + cell;
+        const int cell = (cl >> 3) * EF_CR + (j >> 3) * 16 + (cl & 7) * 2;
+        L.stgA = (ef_ldsw_t)ef_lds + EF_STG_A + wave * 64 * EF_CR + cell;
+        L.stgB = (ef_ldsw_t)ef_lds + EF_STG_B + wave * 32 * EF_CR + cell;
     }
     typedef __attribute__((address_space(3))) const u32x4 *ef_ldsq_t;
-    const ef_ldsq_t rdA = (ef_ldsq_t)((ef_lds_t)ef_lds + EF_STG_A + wave * 4096 + lane * 16);     // read-out: 16 bytes per lane, 1 KB per trip
-    const ef_ldsq_t rdB = (ef_ldsq_t)((ef_lds_t)ef_lds + EF_STG_B + wave * 2048 + lane * 16);
+    const ef_ldsq_t rdA = (ef_ldsq_t)((ef_lds_t)ef_lds + EF_STG_A + wave * 64 * EF_CR + lane * 16);  // read-out: 16 bytes per lane, 1 KB per trip
+    const ef_ldsq_t rdB = (ef_ldsq_t)((ef_lds_t)ef_lds + EF_STG_B + wave * 32 * EF_CR + lane * 16);
     if (PLANES && blockIdx.x == 0 && threadIdx.x == 0)
         *(float *)((_Float16 *)pooled + 2 * 512 * L.bn) = packed[EFO_SC + 12];        // the image's 2^-T_out
     // power-of-two scales of the four layers' accumulators (uniform: scalar loads), see edgeconv_layout.h
@@ -634,7 +641,7 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
     const int b = G.b;
     L.prow = pooled + ((size_t)b * N + G.nc) * CTOT + cl;
     // read-out addresses of this tile: lane -> (row of the image = plane * 64 + cell row, point lane & 3); rows times B N * 16 bytes
-    const int n_st = min(((tile - b * tiles_per_cloud) * 4 + wave) * 4 + (lane & 3), N - 1);
+    const int n_st = min(((tile - b * tiles_per_cloud) * EF_NW + wave) * EF_PTS + (lane % EF_PTS), N - 1);
     char *const img_pt = (char *)pooled + ((size_t)b * N + n_st) * 16;
     const size_t row_bytes = L.bn * 16;
     float b1[MT][2];
@@ -695,21 +702,24 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
     // point to before pair 6), waited for before pair 7, where every count is known, instead of behind the loop's back edge.
     f16x8 dummy[1][2][MT];
     u32x4 X;                                                     // the 16 bytes on their way from LDS to the image
-    auto st_a = [&](int c) { *(u32x4 *)(img_pt + (size_t)((c >> 1) * 64 + (c & 1) * 16 + (lane >> 2)) * row_bytes) = X; EF_PIN(); };
-    auto st_b = [&](int m0) {                                    // chunk of pairs m0, m0 + 1: lane -> slot, plane, cell row, point
-        const int row = ((lane >> 4) & 1) * 64 + (EC_C1 + EC_C2 + EC_C3) / 8 + 4 * (m0 + (lane >> 5)) + ((lane >> 2) & 3);
+    auto st_a = [&](int pl) {                                    // area A, trip = plane: lane -> cell row lane / EF_PTS, point lane % EF_PTS
+        *(u32x4 *)(img_pt + (size_t)(pl * 64 + lane / EF_PTS) * row_bytes) = X;
+        EF_PIN();
+    };
+    auto st_b = [&](int m0) {                                    // area B holding pairs m0 .. m0 + 3: lane -> slot, plane, cell row, point
+        const int row = ((lane / (4 * EF_PTS)) & 1) * 64 + (EC_C1 + EC_C2 + EC_C3) / 8 + 4 * (m0 + lane / (8 * EF_PTS)) + ((lane / EF_PTS) & 3);
         *(u32x4 *)(img_pt + (size_t)row * row_bytes) = X;
         EF_PIN();
     };
     auto hook = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
         if constexpr (PLANES) {
-            if constexpr (i >= 2 && i <= 5) st_a(i - 2);
-            if constexpr (i == 6) st_b(0);
-            if constexpr (i == 7) st_b(2);
-            if constexpr (i >= 1 && i <= 4) X = rdA[(i - 1) * 64];
-            if constexpr (i == 5 || i == 7) X = rdB[0];
-            if constexpr (i == 6) X = rdB[64];
+            if constexpr (i == 2) st_a(0);
+            if constexpr (i == 3) st_a(1);
+            if constexpr (i == 6) st_b(0);                       // pairs 0 .. 3, complete once pair 4 has finished pair 3
+            if constexpr (i == 1) X = rdA[0];                    // area A is complete once pair 0 has finished layer 3's last pair
+            if constexpr (i == 2) X = rdA[64];
+            if constexpr (i == 5) X = rdB[0];
             EF_PIN();
         }
         if (has_next) {
@@ -725,10 +735,9 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
     ef_layer<MT, EC_C3 / 32, EC_C4 / 32, true, false, true, PLANES, decltype(hook) &, true, false>(
         p3, dummy, w4, bs4, EfNext{w2, bs2, 0, 2 * (EC_C1 / 32)}, R, EC_C1 + EC_C2 + EC_C3, accA, accB,
         EC_C1 + EC_C2 + 32 * (EC_C3 / 32 - 1), &mp_last, L, 0, s3, s4, ovf, hook);
-    if constexpr (PLANES) st_b(4);                              // pairs 4, 5 (read before pair 7)
     asm volatile("s_nop 15\n\ts_nop 15");                       // the last asm MFMAs must have written accB (no compiler padding)
     ef_finish_all<MT, true, true, PLANES>(accB, dummy[0], EC_C1 + EC_C2 + EC_C3 + 32 * mp_last, L, s4, ovf);
-    if constexpr (PLANES) { X = rdB[64]; st_b(6); }             // pairs 6, 7
+    if constexpr (PLANES) { X = rdB[0]; st_b(4); }              // pairs 4 .. 7
     EF_T(5);
     }
     // fp16 range guard: ovf = the largest value (in plane units) this lane handed to fp16 planes -- layers 1-3, and the
@@ -759,16 +768,16 @@ extern "C" int EF_ENTRY(const float *xyz, const int64_t *idx, int B, int N, int 
     if (k > 20 || B > 65535 || (((size_t)packed) & 15) || (((size_t)out) & 15)) return L3D_ERR_UNSUPPORTED;
     const long ntiles = (long)B * l3d_divup(N, 16);
     if (ntiles > 0x7fffffffL / 2) return L3D_ERR_UNSUPPORTED;
-    dim3 grid(ef_grid((int)ntiles)), block(256);
+    dim3 grid(ef_grid((int)ntiles)), block(64 * EF_NW);
     hipStream_t st = (hipStream_t)stream;
     float *o = (float *)out;
     const size_t lds = EF_LDS_BYTES;
     if (out_mode == 0) {
-        if (k <= 16) hipLaunchKernelGGL((EF_KERNEL<4, false>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag, mres);
-        else              hipLaunchKernelGGL((EF_KERNEL<5, false>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag, mres);
+        if (k <= 16) hipLaunchKernelGGL((EF_KERNEL<2, false>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag, mres);
+        else              hipLaunchKernelGGL((EF_KERNEL<3, false>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag, mres);
     } else {
-        if (k <= 16) hipLaunchKernelGGL((EF_KERNEL<4, true>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag, mres);
-        else              hipLaunchKernelGGL((EF_KERNEL<5, true>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag, mres);
+        if (k <= 16) hipLaunchKernelGGL((EF_KERNEL<2, true>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag, mres);
+        else              hipLaunchKernelGGL((EF_KERNEL<3, true>), grid, block, lds, st, xyz, idx, B, N, k, packed, o, range_flag, mres);
     }
     return l3d_check_launch();
 }
