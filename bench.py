@@ -256,6 +256,25 @@ def other_configs(dev, iters=10, warm=3):
     return out
 
 
+def pin_rank_to_cores(local, nlocal):
+    """N launcher processes on one host: give every rank its own contiguous share of the cores this job may use and cap torch's
+    CPU thread pool to it.  Unpinned, eight Python launch loops (plus eight default-sized intra-op pools) migrate over the same
+    cores and the slowest rank's launch jitter becomes the step time.  Returns what was done, for the JSON line."""
+    info = {"cores": None, "torch_threads": None}
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+        if nlocal > 1 and len(avail) >= nlocal:
+            share = len(avail) // nlocal
+            mine = avail[local * share:(local + 1) * share]
+            os.sched_setaffinity(0, mine)
+            info["cores"] = f"{mine[0]}-{mine[-1]} ({len(mine)} of {len(avail)})"
+            torch.set_num_threads(max(1, min(8, len(mine))))
+        info["torch_threads"] = torch.get_num_threads()
+    except (AttributeError, OSError):
+        pass
+    return info
+
+
 def relaunch_under_torchrun(ngpus):
     """`python bench.py --gpus N` with no launcher around it: start N ranks of this very command under
     torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 with a free port) and return its exit code."""
@@ -277,6 +296,37 @@ def selftest_cpu(args, parallel, dist):
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     part = torch.tensor([10.0 * (rank + 1), 20.0 * (rank + 1), 100.0, 200.0], dtype=torch.float64)
+    placement = pin_rank_to_cores(local, world)
+    if args.workload == "c5":
+        # --workload c5's exchange: all_gather_into_tensor of the 4-value shard digest, summed over ranks
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        tot = None
+        for _ in range(args.steps):
+            flat = torch.empty(world * 4, dtype=torch.float64)
+            if world > 1:
+                dist.all_gather_into_tensor(flat, part)
+            else:
+                flat.copy_(part)
+            tot = flat.view(world, 4).sum(0)
+        if world > 1:
+            dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        per_rank = [t.clone() for _ in range(world)]
+        if world > 1:
+            dist.all_gather(per_rank, t)
+        if rank == 0:
+            sr = sum(range(1, world + 1))
+            print(json.dumps({"metric": "SELFTEST (control flow only, not a measurement)", "workload": "c5", "n_gpus": world,
+                              "steps": args.steps, "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+                              "dist_backend": dist.get_backend() if world > 1 else None, "digest": [float(v) for v in tot],
+                              "digest_expected": [10.0 * sr, 20.0 * sr, 100.0 * world, 200.0 * world],
+                              "rank0_placement": placement, "per_rank_s": [float(v) for v in per_rank]}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     pipe = parallel.PipelinedChamferLoss()
     if world > 1:
         dist.barrier()
@@ -298,6 +348,7 @@ def selftest_cpu(args, parallel, dist):
                           "rccl_ranks": dist.get_world_size() if world > 1 else 1,
                           "dist_backend": dist.get_backend() if world > 1 else None,
                           "loss_sync": float(loss_sync), "loss_pipelined": float(loss_pipe), "loss_expected": want,
+                          "rank0_placement": placement,
                           "per_rank_s": [float(v) for v in per_rank]}), flush=True)
     if world > 1:
         dist.barrier()
@@ -501,6 +552,8 @@ def main_c5(args, rank, world, local, dev, dist, parallel):
                        "parallelism": f"batch-sharded x{world}, no data-path collective; one 32-byte all_gather of the shard digest per step"},
             "rccl_ranks": (dist.get_world_size() if multi else 1), "dist_backend": dist.get_backend() if multi else None,
             "per_rank_ms_per_step": [float(v) / args.steps * 1e3 for v in per_rank[:, 0]],
+            "rank0_placement": getattr(args, "placement", None),
+            "multi_gpu_note": "no N > 1 number has been measured by the builder in any round (a gpurun box has one GPU)",
             "serial_ms_per_step": serial_ms,
             # the one HBM-bound op of the path: the grouping gather
             "roofline": {"kernel": "group_concat_kernel", "bound": "hbm", "achieved": grp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -588,6 +641,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    placement = pin_rank_to_cores(local, world)     # before the device index is folded: `local` is the rank's slot on this host
     local = local % torch.cuda.device_count()     # a launcher that narrows visibility leaves one device at index 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -601,6 +655,7 @@ def main():
         if abs(float(probe) - world * (world + 1) / 2) > 0:
             raise SystemExit(f"[bench] RCCL all_reduce probe returned {float(probe)}, expected {world * (world + 1) / 2}")
     if args.workload == "c5":
+        args.placement = placement
         return main_c5(args, rank, world, local, dev, dist, parallel)
 
     # synthetic, seeded, already resident (weak scaling: 32 clouds per GPU; rank-specific seed)
@@ -703,26 +758,31 @@ def main():
     # of round 2).  The K timed steps should measure the steady state, not that transient: a few eager steps give the sum
     # of the kernels' own durations (HIP events around each stage), then probes of 20 replayed steps run until one comes
     # within 12 % of that sum (at most 4 probes, 0.25 s apart).
+    # N > 1: every rank runs the same probes (a step contains a collective, so the ranks must agree on how many steps they run):
+    # the decision to probe again is itself an all_reduce -- any rank still unsettled keeps all of them probing.
     settle_probes = 0
-    if not multi:
-        probe_timer = _fused.StageTimer(only=("knn", "edgeconv_kernel", "conv5", "chamfer"))
-        _fused.TIMER = probe_timer
-        for _ in range(3):
-            step(args.sync_loss, eager=True)
+    probe_timer = _fused.StageTimer(only=("knn", "edgeconv_kernel", "conv5", "chamfer"))
+    _fused.TIMER = probe_timer
+    for _ in range(3):
+        step(args.sync_loss, eager=True)
+    torch.cuda.synchronize()
+    _fused.TIMER = None
+    kernel_ms = probe_timer.mean_ms()                          # this rank's kernels, each between its own pair of HIP events
+    kernel_sum_ms = sum(kernel_ms.values())
+    while settle_probes < 4:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            step(args.sync_loss)
+        e1.record()
         torch.cuda.synchronize()
-        _fused.TIMER = None
-        kernel_sum_ms = sum(probe_timer.mean_ms().values())
-        while settle_probes < 4:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20):
-                step(args.sync_loss)
-            e1.record()
-            torch.cuda.synchronize()
-            settle_probes += 1
-            if e0.elapsed_time(e1) / 20 <= 1.12 * kernel_sum_ms:
-                break
-            time.sleep(0.25)
+        settle_probes += 1
+        unsettled = torch.tensor([1.0 if e0.elapsed_time(e1) / 20 > 1.12 * kernel_sum_ms else 0.0], device=dev)
+        if multi:
+            dist.all_reduce(unsettled, op=dist.ReduceOp.MAX)
+        if float(unsettled) == 0.0:
+            break
+        time.sleep(0.25)
     for _ in range(args.warmup):
         step(args.sync_loss)
 
@@ -815,7 +875,8 @@ def main():
         _fused.check_range(sync=True)                 # no activation left the fp16 range during the run
 
     # max over ranks (the contract), and every rank's own time for the record
-    t = torch.tensor([elapsed, other if other is not None else 0.0], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, other if other is not None else 0.0, kernel_ms.get("knn", 0.0), kernel_ms.get("edgeconv_kernel", 0.0),
+                      kernel_ms.get("conv5", 0.0), kernel_ms.get("chamfer", 0.0)], dtype=torch.float64, device=dev)
     per_rank = [t.clone() for _ in range(world)]
     if multi:
         dist.all_gather(per_rank, t)
@@ -850,6 +911,8 @@ def main():
                                    "weights) + ChamferDistanceLoss, B=32 clouds per GPU, N=1024, inputs resident in HBM",
                        "global_batch": world * B_PER_GPU, "num_points": NPTS, "k": KNN, "emb_dims": EMB,
                        "untimed_precondition_steps": PRECONDITION_STEPS, "untimed_settle_probes_of_20_steps": settle_probes,
+                       "settle_rule": "probes of 20 replayed steps until one is within 12 % of the kernels' own sum (max 4); for N > 1 all "
+                                      "ranks probe until every rank is settled (all_reduce of the verdict)",
                        "launch": "hipGraph replay of the step's 5 kernels" if graph is not None else "eager launches",
                        "chamfer_branch": ("one stream" if branch is None else
                                           f"second stream, leaves the chain at '{args.fork}', joined at the end of the step"),
@@ -859,6 +922,13 @@ def main():
             # each rank's own wall time for the K steps, and the OTHER loss-exchange mode timed over the same K steps
             "rccl_ranks": (dist.get_world_size() if multi else 1), "dist_backend": backend,
             "per_rank_ms_per_step": [float(v) / args.steps * 1e3 for v in per_rank[:, 0]],
+            # every rank's own kernels (eager steps before the timed region, one pair of HIP events per stage): with the per-rank step
+            # times above, a scaling loss splits into slowest rank vs exchange vs host
+            "per_rank_kernel_ms": [{"knn": float(r[2]), "edgeconv": float(r[3]), "conv5": float(r[4]), "chamfer_and_loss_tail": float(r[5]),
+                                    "sum": float(r[2] + r[3] + r[4] + r[5])} for r in per_rank],
+            "rank0_placement": placement,
+            "multi_gpu_note": "no N > 1 number has been measured by the builder in any round (a gpurun box has one GPU); the N > 1 code "
+                              "path has run over RCCL with one rank and over gloo with two",
             "loss_exchange": ("blocking all_gather inside the step" if args.sync_loss else
                               "asynchronous all_gather, consumed one step later") if multi else "none (1 rank)",
             "other_exchange_mode": None if other is None else {

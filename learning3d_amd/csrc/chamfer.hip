@@ -451,7 +451,10 @@ extern "C" int l3d_chamfer_backward_variant(const float *xyz1, const float *xyz2
         const size_t lds = sizeof(uint32_t) * (size_t)(P1 > P2 ? P1 : P2);
         hipLaunchKernelGGL(chamfer_bwd_sorted_kernel, dim3(B, 2), dim3(1024), lds, (hipStream_t)stream, xyz1, xyz2, N, M,
                            graddist1, graddist2, idx1, idx2, gradxyz1, gradxyz2, P1, P2, s1, s2);
-        return l3d_check_launch();
+        const int rc = l3d_check_launch();
+        // auto mode: a launch that the device refuses (up to 128 KB of dynamic LDS at 32 768 points) falls back to the scan
+        // kernel -- same bits, slower -- instead of failing clouds the scan kernel has always taken
+        if (rc == L3D_OK || variant == 2) return rc;
     }
     dim3 grid(l3d_divup(mx, 64), B, 2);
     hipLaunchKernelGGL(chamfer_bwd_kernel, grid, dim3(64), 0, (hipStream_t)stream, xyz1, xyz2, N, M,

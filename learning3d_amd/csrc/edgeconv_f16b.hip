@@ -48,7 +48,7 @@
 
 #define EF_V2 1
 #ifndef EF_SPLIT_MIX
-#define EF_SPLIT_MIX 0
+#define EF_SPLIT_MIX 1
 #endif
 // Layer 4's weight fragments (128 KB as two planes) are copied to LDS once per workgroup and read from there by every tile -- a
 // ds_read_b128 beside the MFMA stream costs about half of a global_load_dwordx4 (LABLOG R2.2: +19 vs +43 cycles per 5 MFMAs) and
@@ -585,12 +585,6 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
     L.mres = mres;
     extern __shared__ __attribute__((aligned(16))) unsigned char ef_lds[];
     L.w4lds = (ef_lds_t)ef_lds;
-    {   // the parameter tail -> LDS, once per workgroup
-        const uint4 *src = (const uint4 *)(packed + EFO_W4);
-        uint4 *dst = (uint4 *)ef_lds;
-#pragma unroll 8
-        for (int i = threadIdx.x; i < EF_PAR_BYTES / 16; i += 256) dst[i] = src[i];
-    }
     // this lane's 2-byte cell inside its wave's staging areas: cell row (cl >> 3), point j >> 2, channel cl & 7
     {
         const int cell = (cl >> 3) * 64 + (j >> 2) * 16 + (cl & 7) * 2;
@@ -612,17 +606,36 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
                     bs4 = (ef_ldsf_t)((ef_lds_t)ef_lds + EF_LOFF_B4) + 4 * g;
 
     int tile = blockIdx.x;                                      // grid <= ntiles: every workgroup has a first tile
-    // the first tile's gather stands in the open; its index loads go out before the weight ring's so that the dependent
-    // coordinate loads do not queue behind 8 KB of fragments
+    // Prologue, once per workgroup: the first tile's neighbour indices are requested first, then the parameter tail (135 KB) as
+    // LDS-DMA (as eight-load batches through registers behind `s_waitcnt vmcnt(0)` the copy took five memory round trips), the
+    // coordinates the indices point to in between: their trip overlaps the copy.
     EfGather<MT> G;
     ef_gather_idx<MT>(G, tile, tiles_per_cloud, N, k, xyz, idx, wave, j, g);
     EF_PIN();
+    ef_gather_xyz<MT>(G, N, xyz, g);                             // vmcnt is one in-order counter: behind the DMA block these would wait for all of it
+    EF_PIN();
+    {
+        // LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes -> 1 KB of LDS per instruction, no registers, no ds_write): wave w
+        // moves chunks w, w + 4, ... -- 33 instructions per wave, all in flight behind the index loads; the 64-byte remainder by hand
+        typedef const __attribute__((address_space(1))) void *gp_t;
+        typedef __attribute__((address_space(3))) void *lp_t;
+        constexpr int NCH = EF_PAR_BYTES / 1024;                 // full 1 KB chunks
+        const char *src = (const char *)(packed + EFO_W4);
+#pragma unroll
+        for (int c = 0; c < (NCH + 3) / 4; c++) {
+            const int ch = c * 4 + wave;
+            if (ch < NCH) __builtin_amdgcn_global_load_lds((gp_t)(src + ch * 1024 + lane * 16), (lp_t)(ef_lds + ch * 1024), 16, 0, 0);
+        }
+        EF_PIN();
+        constexpr int REM = EF_PAR_BYTES - NCH * 1024;           // 64 bytes: the scale constants' tail
+        static_assert(REM % 16 == 0 && REM < 1024, "remainder in 16-byte pieces");
+        if (threadIdx.x < REM / 16) ((uint4 *)(ef_lds + NCH * 1024))[threadIdx.x] = ((const uint4 *)(src + NCH * 1024))[threadIdx.x];
+    }
     __syncthreads();                                            // the parameter tail is in LDS
-    // layer 2's first fragments and bias: requested before the gather's second trip so that their latency hides behind it
+    // layer 2's first fragments and bias
     EfRing R;
     ef_ring_fill(R, L.rs, EFO_W2 * 4, bs2, 0, 2 * (EC_C1 / 32), lane);
     EF_PIN();
-    ef_gather_xyz<MT>(G, N, xyz, g);
     // the gathered values count as arrived on BOTH edges into the loop (here, and in front of layer 4's pair 7 for the next
     // tile): otherwise the loop header merges "loads pending" with "nothing pending" into an `s_waitcnt vmcnt(0)` at the top
     // of every tile, which also waits for the 16-byte stores the previous tile issued last
@@ -657,28 +670,36 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
         f32x4 bv1[EC_C1 / 16];
 #pragma unroll
         for (int m = 0; m < EC_C1 / 16; m++) { a1[m] = w1[m * 64 + lane]; bv1[m] = *(lb1_t)(b1p + 16 * m); }
+        // pair 0 -> accA, pair 1 -> accB; pair 0's finish (ReLU, split into p1[0], pooling: 6 MT + 12 micro-units) rides on pair 1's
+        // MFMAs -- a v_mfma_f32_16x16x4_f32 holds the matrix pipe for 32 cycles -- instead of standing between the two pairs
+        static_assert(EC_C1 == 64, "layer 1 is two M-tile pairs");
+        auto mfma1 = [&](f32x4 &d, float a, float b, const f32x4 &c, bool first) {
+            if (first) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+            else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+        };
+        asm volatile("s_nop 3");                                 // b1 comes from VALU selects: no hazard padding in front of an asm MFMA
 #pragma unroll
-        for (int mp = 0; mp < EC_C1 / 32; mp++) {
+        for (int mm = 0; mm < 2; mm++)
 #pragma unroll
-            for (int mm = 0; mm < 2; mm++) {
-                const int m = 2 * mp + mm;
+            for (int s = 0; s < 2; s++)
 #pragma unroll
-                for (int t = 0; t < MT; t++) accB[mm][t] = bv1[m];
-#pragma unroll
-                for (int s = 0; s < 2; s++)
-#pragma unroll
-                    for (int t = 0; t < MT; t++)
-                        accB[mm][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[m][s], b1[t][s], accB[mm][t], 0, 0, 0);
-            }
-            if (mp + 1 < EC_C1 / 32) ef_finish_all<MT, false, false, PLANES>(accB, p1[mp], 32 * mp, L, s1, ovf);
-        }
+                for (int t = 0; t < MT; t++) mfma1(accA[mm][t], a1[mm][s], b1[t][s], bv1[mm], s == 0);
+        constexpr int NU1 = EfN<MT, false>::UNITS, NSL1 = 4 * MT;
+        EfTmp T1;
+        ef_static_for<0, NSL1>([&](auto sc) {
+            constexpr int slot = decltype(sc)::value, mm = slot / (2 * MT), s = (slot / MT) % 2, t = slot % MT;
+            mfma1(accB[mm][t], a1[2 + mm][s], b1[t][s], bv1[2 + mm], s == 0);
+            ef_static_for<slot * NU1 / NSL1, (slot + 1) * NU1 / NSL1>([&](auto u) {
+                ef_micro<MT, false, true, PLANES, decltype(u)::value>(accA, p1[0], T1, 0, L, s1, ovf);
+            });
+        });
     }
     int mp_last;
 
     EF_T(2);
     // ---- layer 2: 64 -> 64   (its first pair hides the finish of layer 1's last pair, and so on down)
     f16x8 p2[EC_C2 / 32][2][MT];
-    ef_layer<MT, EC_C1 / 32, EC_C2 / 32, false, true, false, PLANES>(
+    ef_layer<MT, EC_C1 / 32, EC_C2 / 32, false, true, true, PLANES>(
         p1, p2, w2, bs2, EfNext{w3, bs3, 0, 2 * (EC_C2 / 32)}, R, EC_C1, accA, accB,
         32 * (EC_C1 / 32 - 1), &mp_last, L, 0, s1, s2, ovf);
     EF_T(3);

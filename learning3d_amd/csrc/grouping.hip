@@ -577,6 +577,18 @@ __global__ __launch_bounds__(PPT >= 8 ? 512 : 1024) void fps_kernel(int n, int m
     }
     __syncthreads();
     const int wave = tid >> 6, lane = tid & 63;
+    // Equal maxima.  OUT64 (the torch twin, model_common_utils.py:58-82: torch.max): the lowest index.  !OUT64 (pointnet2's
+    // kernel, sampling_gpu.cu:86-205): its thread `tid` scans k = tid, tid + T, ... with a strict '>', and its tree merges slot s
+    // with slot s + h (h = T/2 ... 1) keeping the lower slot's candidate unless the other is strictly larger -- two tied
+    // candidates meet where their thread ids first agree modulo h and the one with bit h clear survives, so the winner is the
+    // smallest (bit-reversed (k mod T), k), T = opt_n_threads(n) = min(2^floor(log2 n), 1024) (cuda_utils.h:6-14).  Clipped clouds
+    // (config 5) put duplicate points on the corners of the box, exactly where sampling goes first.  tkey() orders candidates
+    // accordingly; it is only evaluated on the (rare) tie paths, and the per-thread scan visits its slots in tkey order (for 512
+    // threads and T = 1024: k mod 1024 = tid + 512 (u & 1), bit 9 decides last -- even slots, then odd ones).
+    const int lt = OUT64 ? 0 : min(31 - __builtin_clz(n | 1), 10);
+    auto brev = [&](int x) { return lt ? (int)(__builtin_bitreverse32((unsigned)x) >> (32 - lt)) : 0; };
+    auto tkey = [&](int k) { return OUT64 ? k : ((brev(k & ((1 << lt) - 1)) << 15) | (k >> lt)); };
+    auto tinv = [&](int p) { return OUT64 ? p : (((p & 0x7fff) << lt) | brev(p >> 15)); };
     for (int j = 1; j < m; j++) {
         float x1, y1, z1;                       // wave-uniform
         if (LDS_XYZ) { x1 = sxyz[old]; y1 = sxyz[n + old]; z1 = sxyz[2 * n + old]; }
@@ -592,15 +604,19 @@ __global__ __launch_bounds__(PPT >= 8 ? 512 : 1024) void fps_kernel(int n, int m
             for (int u = 0; u < PPT; u += 2) {
                 const f32x2 dx = f32x2{px[u], px[u + 1]} - x2, dy = f32x2{py[u], py[u + 1]} - y2, dz = f32x2{pz[u], pz[u + 1]} - z2;
                 const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+                dmin[u] = fminf(d[0], dmin[u]);
+                dmin[u + 1] = fminf(d[1], dmin[u + 1]);
+            }
+            // arg-max over the thread's slots with a strict '>', visited in the tie order above: ascending k, except for the
+            // pointnet2 op at 512 threads (n >= 4096: the reference runs 1024 threads), where k mod 1024 = tid + 512 (u & 1)
+            constexpr bool EVEN_FIRST = !OUT64 && PPT >= 8;
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const float d2 = fminf(d[h], dmin[u + h]);
-                    dmin[u + h] = d2;
-                    const int key = __builtin_bit_cast(int, d2);
-                    const bool gt = key > best;         // ascending k within a thread: lowest index wins
-                    best = gt ? key : best;
-                    besti = gt ? tid + (u + h) * nthr : besti;
-                }
+            for (int s = 0; s < PPT; s++) {
+                const int u = EVEN_FIRST ? (s < PPT / 2 ? 2 * s : 2 * (s - PPT / 2) + 1) : s;
+                const int key = __builtin_bit_cast(int, dmin[u]);
+                const bool gt = key > best;
+                best = gt ? key : best;
+                besti = gt ? tid + u * nthr : besti;
             }
         } else {
 #pragma unroll
@@ -625,7 +641,7 @@ __global__ __launch_bounds__(PPT >= 8 ? 512 : 1024) void fps_kernel(int n, int m
         if (__builtin_popcountll(hit) == 1)
             widx = __builtin_amdgcn_readlane(besti, __builtin_ctzll(hit));
         else
-            widx = wave_min_i(best == wmax ? besti : 0x7fffffff);
+            widx = tinv(wave_min_i(best == wmax ? tkey(besti) : 0x7fffffff));
         const int buf = j & 1;
         if (lane == 0) { wv[buf][wave] = wmax; wi[buf][wave] = widx; }
         __syncthreads();
@@ -635,7 +651,7 @@ __global__ __launch_bounds__(PPT >= 8 ? 512 : 1024) void fps_kernel(int n, int m
         if (__builtin_popcount(hit16) == 1)
             old = __builtin_amdgcn_readlane(ei, __builtin_ctz(hit16));
         else
-            old = __builtin_amdgcn_readfirstlane(row16_min_i(ev == bmax ? ei : 0x7fffffff));
+            old = __builtin_amdgcn_readfirstlane(tinv(row16_min_i(ev == bmax ? tkey(ei) : 0x7fffffff)));
         if (tid == 0) {
             if (OUT64) ((int64_t *)out)[(size_t)b * m + j] = old; else ((int32_t *)out)[(size_t)b * m + j] = old;
         }

@@ -117,7 +117,7 @@ __device__ __forceinline__ float tr_grad_in(const float *__restrict__ dy, const 
 {
     float g = dy ? dy[base + p] : 0.f;
     if (dpool) {
-        const long n = (long)(((float)p + 0.5f) * kinv);                 // p / K, exact for p < 2^23
+        const long n = (long)(((float)p + 0.5f) * kinv);                 // p / K: exact for every K <= 256 when p < 2^22 (brute force; from p = 4 243 964 on, K = 255 and 81 other K fail)
         if ((int)(p - n * K) == (int)pidx[pbase + n]) g = g + dpool[pbase + n];
     }
     return g;
@@ -176,13 +176,13 @@ __global__ __launch_bounds__(256) void bn_backward_stats_kernel(const float *__r
 }
 
 // dy may be NULL when dpool is given (a layer whose output is only pooled); dpool [B][C][P/K], pidx [B][C][P/K] (l3d_max_last's
-// arg-max), K = the pooled run length: P % K == 0, P < 2^23
+// arg-max), K = the pooled run length: P % K == 0, P < 2^22
 extern "C" int l3d_bn_backward_stats_pool(const float *dy, const float *z, const float *scale, const float *shift, const double *mean,
                                           const double *rstd, int B, int C, long P, int act, double *part, const float *dpool,
                                           const unsigned char *pidx, int K, l3d_stream_t stream)
 {
     L3D_REQUIRE((dy || dpool) && z && scale && shift && mean && rstd && part && B > 0 && C > 0 && P > 0 && B <= 65535);
-    L3D_REQUIRE(!dpool || (pidx && K > 0 && K <= 256 && P % K == 0 && P < (1L << 23)));
+    L3D_REQUIRE(!dpool || (pidx && K > 0 && K <= 256 && P % K == 0 && P < (1L << 22)));
     const bool vec = P % 4 == 0 && (!dpool || K % 4 == 0) && ((((size_t)dy) | ((size_t)z)) & 15) == 0;
     if (vec)
         hipLaunchKernelGGL(bn_backward_stats_kernel<true>, dim3(C, B), dim3(256), 0, (hipStream_t)stream, dy, z, scale, shift, mean, rstd, C,
@@ -249,7 +249,7 @@ extern "C" int l3d_bn_act_backward_pool(const float *dy, const float *z, const f
 {
     L3D_REQUIRE((dy || dpool) && z && scale && shift && mean && rstd && gr && m1 && m2 && dz && B > 0 && C > 0 && P > 0 && B <= 65535 &&
                 C <= 65535);
-    L3D_REQUIRE(!dpool || (pidx && K > 0 && K <= 256 && P % K == 0 && P < (1L << 23)));
+    L3D_REQUIRE(!dpool || (pidx && K > 0 && K <= 256 && P % K == 0 && P < (1L << 22)));
     const bool vec = P % 4 == 0 && (!dpool || K % 4 == 0) && ((((size_t)dy) | ((size_t)z) | ((size_t)dz)) & 15) == 0;
     if (vec)
         hipLaunchKernelGGL(bn_act_backward_kernel<true>, dim3((unsigned)l3d_divup(P, 1024), C, B), dim3(256), 0, (hipStream_t)stream, dy, z,

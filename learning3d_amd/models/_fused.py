@@ -215,20 +215,32 @@ class _Recompute(torch.autograd.Function):
 def checkpointed(module, impl, *tensors):
     """Run `impl(*tensors)` (a module's forward body) so that the fused kernels serve the forward whatever the grad mode:
     nothing to differentiate -> impl directly; batch statistics / dropout -> impl directly (its call sites pick the per-layer
-    route); otherwise inside _Recompute.  Outputs: a tensor, or a tuple / list / dict of tensors."""
+    route); otherwise inside _Recompute.  Outputs: a tensor, or a tuple / list / dict of tensors.
+    Every route runs under run_guarded: whichever f16x2 kernel a model's forward reaches (PointNet's split rows, the pointer
+    network's projections, the SVD head), its range verdict is read inside this call and an overflowing forward is repeated on
+    bf16x3 -- no model leaves a raised flag behind for an unrelated later call to trip over."""
     from .._lib import on_device_of
+    dev = next((t.device for t in tensors if isinstance(t, torch.Tensor) and t.is_cuda), None)
+
+    def guarded(fn):
+        return run_guarded(dev, fn) if dev is not None else fn()
+
     if not torch.is_grad_enabled() or recomputing() or _stochastic_or_batch_dependent(module):
         with on_device_of(*tensors):                 # tensors on a GPU that is not the current one: switch for the call
-            return impl(*tensors)
+            return guarded(lambda: impl(*tensors))
     params = [p for p in module.parameters() if p.requires_grad]
     if not params and not any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
-        return impl(*tensors)
+        return guarded(lambda: impl(*tensors))
     if not all(t.is_cuda for t in tensors if isinstance(t, torch.Tensor)):
         return impl(*tensors)
-    holder = {}
-    with on_device_of(*tensors):
+
+    def apply():
+        holder = {}
         outs = _Recompute.apply(impl, holder, len(tensors), *tensors, *params)
-    return holder["rebuild"](list(outs))
+        return holder["rebuild"](list(outs))
+
+    with on_device_of(*tensors):
+        return guarded(apply)
 
 
 # Training (module.train() with BatchNorm, or autograd through the conv stack): True = conv / dgrad / wgrad on the HIP
@@ -562,9 +574,14 @@ class L3DRangeError(RuntimeError):
 _RANGE_FLAGS = {}
 
 
+_RANGE_USES = 0           # how often a launch wrapper fetched a range flag (run_guarded: no fetch during a call = nothing to wait for)
+
+
 def range_flag(device):
     """One int32 in pinned (device-mapped) host memory per GPU.  A f16x2 kernel stores 1 into it when an activation
     leaves fp16's range (never for BatchNorm'd networks); the host reads it without a device sync."""
+    global _RANGE_USES
+    _RANGE_USES += 1                                 # a kernel is about to be handed the flag: this call can raise it
     key = torch.device(device).index or 0
     f = _RANGE_FLAGS.get(key)
     if f is None:
@@ -601,24 +618,34 @@ def range_raised(device, clear=True):
     return hit
 
 
+_GUARD_DEPTH = 0          # run_guarded is re-entrant: the OUTERMOST call owns the verdict (one wait per model call, not per sub-module)
+
+
 def run_guarded(device, run):
     """run() launches a model's fused forward under the arithmetic gemm_arith() reports and returns its outputs.  With f16x2
-    the call's range verdict is read before returning (RANGE_POLICY) and an overflowing call is repeated on bf16x3."""
-    global RANGE_RETRIES
-    if gemm_arith() != "f16x2":
+    the call's range verdict is read before returning (RANGE_POLICY) and an overflowing call is repeated on bf16x3.  Nested
+    calls (DCP -> DGCNN / Transformer / SVDHead, Classifier -> PointNet) run straight through: the outermost one -- every
+    model's forward enters through `checkpointed`, which calls this -- waits once and repeats the WHOLE forward if needed."""
+    global RANGE_RETRIES, _GUARD_DEPTH
+    if gemm_arith() != "f16x2" or _GUARD_DEPTH > 0:
         return run()
     if _capturing() or RANGE_POLICY == "async":
         if not _capturing():
             check_range(device)                      # an earlier call's verdict, if it has completed
         return run()
-    out = run()
-    if range_raised(device):
-        if RANGE_POLICY == "raise":
-            raise L3DRangeError("an activation left the fp16 range (|x| > 60000) inside a f16x2 matrix-core kernel "
-                                "(_fused.RANGE_POLICY = 'raise')")
-        RANGE_RETRIES += 1
-        with arith("bf16x3"):
-            out = run()
+    _GUARD_DEPTH += 1
+    try:
+        uses = _RANGE_USES
+        out = run()
+        if _RANGE_USES != uses and range_raised(device):      # no f16x2 launch took the flag (FlowNet3D's fp32 stacks): no wait
+            if RANGE_POLICY == "raise":
+                raise L3DRangeError("an activation left the fp16 range (|x| > 60000) inside a f16x2 matrix-core kernel "
+                                    "(_fused.RANGE_POLICY = 'raise')")
+            RANGE_RETRIES += 1
+            with arith("bf16x3"):
+                out = run()
+    finally:
+        _GUARD_DEPTH -= 1
     return out
 
 

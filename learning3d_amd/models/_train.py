@@ -28,22 +28,39 @@ from .._lib import check, f32c, lib, on_device_of, ptr, stream_ptr
 from . import _fused
 
 
+_SHARD_SIZES = None      # clouds per rank, in rank order, when the shards of the global batch are NOT all equal (declare_shard_sizes)
+
+
+def declare_shard_sizes(sizes):
+    """Tell the BatchNorm statistics exchange how many clouds every rank holds (list in rank order; None: equal shards, the
+    default).  Equal shards are what torch's DistributedSampler hands out and need no declaration; a caller that cuts one global
+    batch with parallel.shard_bounds (remainder on the first ranks: the last batch of an epoch) declares the sizes once per step --
+    parallel.declare_global_batch(B) does -- instead of every layer asking every rank (an all_reduce plus a host read per
+    BatchNorm layer, forward and backward, stalled the launch pipeline ~70 times per FlowNet3D step)."""
+    global _SHARD_SIZES
+    _SHARD_SIZES = None if sizes is None else [int(v) for v in sizes]
+
+
 def gather_cloud_partials(part):
     """part [B_local, C, 2] fp64 (this rank's clouds) -> [B_global, C, 2] in global cloud order (ranks hold contiguous
-    shards, parallel.shard_bounds; shard sizes may differ: the last batch of an epoch).  Single process: returned as is."""
+    shards, parallel.shard_bounds).  One collective, no host synchronisation: equal shards go out as they are; declared unequal
+    shards (declare_shard_sizes) are padded to the largest one and cut back after the gather -- same code on RCCL and gloo.
+    Single process: returned as is."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        world = dist.get_world_size()
-        sizes = torch.zeros(world, dtype=torch.int64, device=part.device)
-        sizes[dist.get_rank()] = part.shape[0]
-        dist.all_reduce(sizes)                                           # every rank's shard size (uneven last batch)
-        sizes = [int(s) for s in sizes.tolist()]
-        if len(set(sizes)) == 1:
+        world, rank = dist.get_world_size(), dist.get_rank()
+        sizes = _SHARD_SIZES
+        if sizes is not None and (len(sizes) != world or sizes[rank] != part.shape[0]):
+            raise ValueError(f"declared shard sizes {sizes} do not match this rank's {part.shape[0]} clouds (rank {rank} of {world})")
+        part = part.contiguous()
+        if sizes is None or len(set(sizes)) == 1:
             flat = torch.empty((world * part.shape[0],) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
-            dist.all_gather_into_tensor(flat, part.contiguous())         # concatenation along dim 0 in rank order
+            dist.all_gather_into_tensor(flat, part)                      # concatenation along dim 0 in rank order
             return flat
-        bufs = [torch.empty((s,) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device) for s in sizes]
-        dist.all_gather(bufs, part.contiguous())
-        return torch.cat(bufs, dim=0)
+        big = max(sizes)
+        padded = part if part.shape[0] == big else torch.cat([part, part.new_zeros((big - part.shape[0],) + tuple(part.shape[1:]))])
+        flat = torch.empty((world * big,) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
+        dist.all_gather_into_tensor(flat, padded.contiguous())
+        return torch.cat([flat[r * big:r * big + sizes[r]] for r in range(world)], dim=0)
     return part
 
 
@@ -153,8 +170,8 @@ class _ConvAffineAct(torch.autograd.Function):
         ctx.batch_stats, ctx.has_bn = bool(bn is not None and batch_stats), bn is not None
         ctx.pool = int(pool)
         if pool:
-            if P % pool or pool > 256 or P >= (1 << 23):
-                raise ValueError("pooled layer: P must be a multiple of the run length K <= 256 and below 2^23")
+            if P % pool or pool > 256 or P >= (1 << 22):
+                raise ValueError("pooled layer: P must be a multiple of the run length K <= 256 and below 2^22")
             ymax = torch.empty((B, Cout, P // pool), dtype=torch.float32, device=dev)
             pidx = torch.empty(B * Cout * (P // pool), dtype=torch.uint8, device=dev)
             check(lib().l3d_max_last(ptr(y), pidx.numel(), int(pool), ptr(ymax), ptr(pidx), stream_ptr()), "l3d_max_last")

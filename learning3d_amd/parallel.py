@@ -38,6 +38,17 @@ def shard_bounds(global_batch, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def declare_global_batch(global_batch, world=None):
+    """Once per step, when shard_bounds cuts a global batch that the rank count does not divide: tells the train-mode BatchNorm
+    exchange every rank's shard size (models/_train.declare_shard_sizes).  None restores the default (equal shards)."""
+    from .models import _train
+    if global_batch is None:
+        return _train.declare_shard_sizes(None)
+    world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+    spans = [shard_bounds(global_batch, r, world) for r in range(world)]
+    _train.declare_shard_sizes([hi - lo for lo, hi in spans])
+
+
 def shard(tensor, rank, world):
     lo, hi = shard_bounds(tensor.shape[0], rank, world)
     return tensor[lo:hi]

@@ -354,15 +354,38 @@ void orc_gather_points_grad(int B, int C, int N, int S, const float *grad_out,
 
 /* ------------------------------------------------------------------------- */
 /* K12: furthest_point_sampling_kernel -- sampling_gpu.cu:93-209             */
-/*   start at 0; temp[k] = min(d, temp[k]); arg-max with '>' (lowest index   */
-/*   wins among equals within a thread's strided scan AND in the tree).      */
-/*   The block-tree + strided scan picks, among equal maxima, the candidate  */
-/*   that survives "v2 > v1 ? i2 : i1" -- i.e. the lowest thread id, and     */
-/*   within a thread the lowest k; for tie-free data that is plain arg-max.  */
+/*   start at 0; temp[k] = min(d, temp[k]); arg-max with '>'.                */
+/*   TIES (round 4: the restatement now follows the kernel here too; before  */
+/*   it took the lowest index, which the reference does only for tie-free    */
+/*   data): thread tid scans k = tid, tid + T, ... with a strict '>' (lowest */
+/*   k of the thread wins); the tree merges slot s with slot s + h for       */
+/*   h = T/2, T/4, ... 1 and keeps i1 unless v2 > v1 (:86-91).  Two tied     */
+/*   candidates meet at the level h where their thread ids first agree       */
+/*   modulo h, and the one whose bit h is CLEAR survives: the winner is the  */
+/*   smallest (bit-reversed (k mod T), k), T = opt_n_threads(N) = the        */
+/*   largest power of two <= N, at most 1024 (cuda_utils.h:6-14); checked    */
+/*   against a thread-by-thread emulation of the kernel in                   */
+/*   tests/test_oracle_golden.py.  Clouds clipped to                         */
+/*   a box (config 5: N(0,1) clipped to [-2,2]) put duplicate points on its  */
+/*   corners, the first places FPS visits: 32 such clouds of 8192 points     */
+/*   differ from the lowest-index rule in about two clouds out of three.     */
 /*   temp is caller-initialised to 1e10 (pointnet2_utils.py:26).             */
 /* ------------------------------------------------------------------------- */
+static int orc_brev(int x, int bits)
+{
+    int r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
 void orc_furthest_point_sampling(int B, int N, int S, const float *xyz, float *temp, int32_t *idxs)
 {
+    int pow_2 = (int)(log((double)N) / log(2.0));                /* cuda_utils.h:11-13 */
+    int T = 1 << pow_2;
+    if (T > 1024) T = 1024;
+    if (T < 1) T = 1;
+    int bits = 0;
+    while ((1 << bits) < T) bits++;
     for (int b = 0; b < B; b++) {
         const float *p = xyz + (size_t)b * N * 3;
         float *t = temp + (size_t)b * N;
@@ -377,7 +400,7 @@ void orc_furthest_point_sampling(int B, int N, int S, const float *xyz, float *t
                 float d = (dx * dx + dy * dy) + dz * dz;
                 float d2 = d < t[k] ? d : t[k];
                 t[k] = d2;
-                if (d2 > best) { best = d2; besti = k; }
+                if (d2 > best || (d2 == best && orc_brev(k % T, bits) < orc_brev(besti % T, bits))) { best = d2; besti = k; }
             }
             old = besti; o[j] = old;
         }

@@ -590,3 +590,4 @@ def test_transforms_take_the_reference_datasets_cpu_inputs_and_hooks_see_layerno
     ln = net.model.encoder.layers[0].sublayer[1].norm
     assert len(seen) == 2 and all(torch.isfinite(o).all() for o in seen)
     assert all(abs(float(o.mean())) < 0.1 and 0.5 < float(o.std()) < 2.0 for o in seen)     # normalised values, not scratch memory
+

@@ -185,6 +185,7 @@ def test_chamfer_backward_sorted_kernel_bit_identical():
              (rng.uniform(0, 1, (3, 1024, 3)), rng.uniform(0, 1, (3, 1000, 3))),
              (rng.uniform(0, 1, (1, 2500, 3)), rng.uniform(0, 1, (1, 4099, 3))),
              (rng.uniform(0, 1, (2, 16384, 3)), rng.uniform(0, 1, (2, 1024, 3))),
+             (rng.uniform(0, 1, (1, 32768, 3)), rng.uniform(0, 1, (1, 20000, 3))),      # the sorted kernel's largest clouds: 128 KB of LDS
              (rng.uniform(0, 1, (1, 1, 3)), rng.uniform(0, 1, (1, 5, 3)))]
     dup = rng.uniform(0, 1, (1, 300, 3)); cases.append((rng.uniform(0, 1, (1, 200, 3)), np.concatenate([dup, dup, dup], 1)))
     cases.append((rng.uniform(0, 1, (2, 500, 3)), np.full((2, 700, 3), 0.25)))

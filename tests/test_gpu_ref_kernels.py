@@ -324,3 +324,22 @@ def test_config5_fps_and_ball_query_all_32_clouds_equal_reference_kernels(PN):
     PN.ref_ball_query(B, N, S, _F(r), K, p(new_xyz), p(xyz), p(wq), s0())
     torch.cuda.synchronize()
     assert torch.equal(gq, wq)
+
+
+@pytest.mark.parametrize("N,S", [(300, 64), (1100, 128), (2500, 200), (8192, 256), (16384, 64)])
+def test_fps_ties_resolve_like_the_reference_kernel(PN, N, S):
+    """Clouds clipped hard (N(0,1) to [-1,1]: hundreds of duplicated corner / edge points) tie in almost every early round of
+    furthest point sampling.  The reference kernel resolves a tie by its block tree (bit-reversed thread id, then index), not by
+    the lowest index: indices bit for bit against the kernel itself and against the oracle's restatement of the rule."""
+    import oracle
+    from learning3d_amd.utils import pointnet2_utils as P
+    rng = np.random.default_rng(N)
+    x = np.clip(rng.standard_normal((3, N, 3)), -1.0, 1.0).astype(np.float32)
+    xyz = dev(x)
+    temp = torch.full((3, N), 1e10, dtype=torch.float32, device="cuda")
+    want = torch.zeros((3, S), dtype=torch.int32, device="cuda")
+    PN.ref_furthest_point_sampling(3, N, S, p(xyz), p(temp), p(want), s0())
+    got = P.furthest_point_sample(xyz, S)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert np.array_equal(got.cpu().numpy(), oracle.furthest_point_sampling(x, S))

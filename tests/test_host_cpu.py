@@ -241,9 +241,16 @@ def test_bench_self_launches_two_ranks_gloo():
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and len(j["per_rank_s"]) == 2
     assert abs(j["loss_sync"] - j["loss_expected"]) < 1e-6 and abs(j["loss_pipelined"] - j["loss_expected"]) < 1e-6
+    assert j["rank0_placement"]["torch_threads"] >= 1
+    # --workload c5's exchange (all_gather_into_tensor of the shard digest) through the same launcher
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--selftest-cpu",
+                          "--workload", "c5"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["workload"] == "c5" and j["rccl_ranks"] == 2 and j["digest"] == j["digest_expected"]
 
 
-def _bn_stats_rank(rank, world, port, q):
+def _bn_stats_rank(rank, world, port, q, NB=8):
     import os
     import numpy as np
     import torch
@@ -253,8 +260,10 @@ def _bn_stats_rank(rank, world, port, q):
     from learning3d_amd import parallel
     from learning3d_amd.models import _train
     rng = np.random.default_rng(5)
-    z = rng.standard_normal((8, 16, 300)).astype(np.float32)               # the WHOLE batch, same on every rank
+    z = rng.standard_normal((NB, 16, 300)).astype(np.float32)              # the WHOLE batch, same on every rank
     lo, hi = parallel.shard_bounds(z.shape[0], rank, world)
+    if NB % world:
+        parallel.declare_global_batch(NB, world)                              # uneven shards are declared, not asked for per layer
     zs = z[lo:hi].astype(np.float64)
     # per-cloud fp64 partial sums of this rank's shard: the stand-in for l3d_channel_stats (tested on the GPU against numpy)
     part = torch.from_numpy(np.stack([zs.sum(-1), (zs ** 2).sum(-1)], axis=-1))
@@ -264,9 +273,11 @@ def _bn_stats_rank(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_batchnorm_statistics_bit_identical():
+@pytest.mark.parametrize("NB", [8, 7])
+def test_two_rank_gloo_batchnorm_statistics_bit_identical(NB):
     """train-mode BatchNorm statistics over a batch sharded across 2 ranks (gloo) equal the
-    single-process statistics BIT FOR BIT: per-cloud fp64 partial sums, all_gather, addition in global cloud order."""
+    single-process statistics BIT FOR BIT: per-cloud fp64 partial sums, all_gather, addition in global cloud order.
+    NB = 7: an uneven last batch (4 + 3 clouds), declared with parallel.declare_global_batch, padded for the gather."""
     import socket
     import numpy as np
     import torch
@@ -277,7 +288,7 @@ def test_two_rank_gloo_batchnorm_statistics_bit_identical():
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_bn_stats_rank, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_bn_stats_rank, args=(r, 2, port, q, NB)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in range(2)]
@@ -285,7 +296,7 @@ def test_two_rank_gloo_batchnorm_statistics_bit_identical():
         p.join(timeout=60)
         assert p.exitcode == 0
     rng = np.random.default_rng(5)
-    z = rng.standard_normal((8, 16, 300)).astype(np.float32).astype(np.float64)
+    z = rng.standard_normal((NB, 16, 300)).astype(np.float32).astype(np.float64)
     part = torch.from_numpy(np.stack([z.sum(-1), (z ** 2).sum(-1)], axis=-1))
     mean, var, n, tot = _train.stats_from_partials(part, 300)
     for rank, pg, t, m, v, nn_ in got:

@@ -249,3 +249,50 @@ def test_flownet3d_sa1_config5_shape_oracle(golden):
     new_xyz, new_feat = oracle.set_abstraction_forward_torch(xyz, feat, w, "", 1024, 0.5, 16)
     assert np.array_equal(new_xyz, g["new_xyz"])
     np.testing.assert_allclose(new_feat, g["new_feat"], rtol=0, atol=1e-6)
+
+
+def _fps_block_tree(xyz, S):
+    """sampling_gpu.cu:93-209 emulated thread by thread (numpy, small clouds): strided per-thread scan with '>' and the block
+    tree's `v2 > v1 ? i2 : i1` merge -- the tie behaviour the oracle's one-line rule (smallest (k mod T, k)) claims to equal."""
+    N = xyz.shape[0]
+    T = min(1 << int(np.log(float(N)) / np.log(2.0)), 1024)
+    temp = np.full(N, 1e10, np.float32)
+    out = [0]
+    old = 0
+    for _ in range(1, S):
+        d = xyz - xyz[old]
+        d = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        temp = np.minimum(d.astype(np.float32), temp)
+        best = np.full(T, -1.0, np.float32)
+        besti = np.zeros(T, np.int64)
+        for tid in range(T):
+            for k in range(tid, N, T):
+                if temp[k] > best[tid]:
+                    best[tid], besti[tid] = temp[k], k
+        half = T // 2
+        while half >= 1:
+            for tid in range(half):
+                v1, v2 = best[tid], best[tid + half]
+                besti[tid] = besti[tid + half] if v2 > v1 else besti[tid]
+                best[tid] = max(v1, v2)
+            half //= 2
+        old = int(besti[0])
+        out.append(old)
+    return np.array(out, np.int32)
+
+
+def test_fps_tie_rule_follows_the_reference_kernels_tree():
+    """Duplicate points (a clipped cloud's corners) make exact ties in furthest point sampling; the reference kernel resolves them
+    by thread id, not by index.  The oracle's rule against a thread-by-thread emulation of the kernel, on clouds built to tie."""
+    rng = np.random.default_rng(3)
+    for N in (300, 1100, 2500):
+        xyz = np.clip(rng.standard_normal((N, 3)), -1.0, 1.0).astype(np.float32)      # heavy clipping: many corner duplicates
+        far = np.array([5.0, 5.0, 5.0], np.float32)
+        T = min(1 << int(np.log(float(N)) / np.log(2.0)), 1024)
+        i, j = 5, T + 2                                   # i < j, but thread 5 (bit 0 set) loses the tree's first tie to thread 2
+        xyz[i] = far
+        xyz[j] = far
+        got = oracle.furthest_point_sampling(xyz[None], 24)[0]
+        want = _fps_block_tree(xyz, 24)
+        assert np.array_equal(got, want), N
+        assert got[1] == j                                                                # the later index wins this tie

@@ -80,7 +80,7 @@ def run(fam, names):
     from learning3d_amd.models import DGCNN, _fused
     names = names or sorted(f[len(fam) + 4:-3] for f in os.listdir(BIN) if f.startswith(f"lib{fam}_") and f.endswith(".so"))
     g = torch.Generator().manual_seed(1000)
-    B, N, k = 32, 1024, 20
+    B, N, k = int(os.environ.get("L3D_LAB_B", "32")), 1024, 20
     x = torch.rand((B, N, 3), generator=g).cuda()
     torch.manual_seed(1)
     net = DGCNN(emb_dims=1024).cuda().eval()
