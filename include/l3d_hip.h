@@ -255,7 +255,7 @@ int l3d_group_first_layer(const float *U, const float *V, const float *shift, co
                           const float *new_xyz, const int32_t *idx, int B, int N, int S, int K, int C1, int relu,
                           float *out, l3d_stream_t stream);
 /* The same layer written as the fp16 activation image of the next f16x2 layer (l3d_f16_act_bytes(B S K, C1) bytes, rows
- * (b, s, k)) instead of fp32: the rest of the grouped MLP then runs on l3d_pointwise_conv_f16_planes / _pool with no fp32
+ * (b, s, k)) instead of fp32: the rest of the grouped MLP then runs on l3d_pointwise_conv_f16 (out_img / ypool) with no fp32
  * activation.  bound: device float >= max|output| (fixes the plane scale; *range_flag is raised if it was exceeded).
  * C1 = 64, 128 or 256. */
 int l3d_group_first_layer_planes(const float *U, const float *V, const float *shift, const float *wx, const float *xyz,
@@ -315,7 +315,7 @@ int l3d_attention_forward_f16(const float *q, const float *k, const float *v, in
                               long q_bstride, long k_bstride, long v_bstride, float scale, void *workspace, float *ctx,
                               void *ctx_img, l3d_stream_t stream);
 /* The same with the three operand maxima already in `maxima` (uint32 float bits of upper bounds of max|q|, |k|, |v|, e.g. from
- * l3d_pointwise_conv_f16_absmax): the pass over q, k, v is not run. */
+ * l3d_pointwise_conv_f16 with amax_out): the pass over q, k, v is not run. */
 int l3d_attention_forward_f16_maxima(const float *q, const float *k, const float *v, int B, int H, int D, int N, int M,
                                      long q_bstride, long k_bstride, long v_bstride, float scale, const void *maxima,
                                      float *ctx, void *ctx_img, l3d_stream_t stream);
@@ -393,7 +393,7 @@ int l3d_edgeconv_forward_f16(const float *xyz, const int64_t *idx, int B, int N,
  * unscaled activation residual (fifth packed copy, csrc/edgeconv_layout.h).  Usable only when the packer could place every
  * layer's weights (packed[l3d_edgeconv_packed_v2_flag_index()] == 1 in the HOST copy of the packed block).
  * out_mode 2: the pooled values as an fp16 activation image like out_mode 1, but with the residual plane unscaled, the
- * x operand of l3d_pointwise_conv_f16_2p. */
+ * x operand of l3d_pointwise_conv_f16 with L3D_CONV_F16_TWO_PLANE. */
 int l3d_edgeconv_forward_f16b(const float *xyz, const int64_t *idx, int B, int N, int k, const float *packed, void *out,
                              int out_mode, int *range_flag, l3d_stream_t stream);
 int l3d_edgeconv_packed_v2_flag_index(void);
@@ -476,41 +476,31 @@ int l3d_linear_rows(const float *x, const float *w, const float *bias, int R, in
                     l3d_stream_t stream);
 int l3d_split_f16_rows(const float *x, long rows, int C, int channel_first, int Npts, void *dst, int *range_flag,
                        l3d_stream_t stream);
+/* THE f16x2 layer (round 3 exported six spellings of it).  Outputs, in the combinations the kernel family offers
+ * (fp32 rows, OR an image and / or pooled maxima):
+ *   y         fp32 [B][Cout][N], or NULL
+ *   residual  y = residual + act(scale (w x) + shift): residual and y distinct [B][Cout][N] buffers (utils/transformer.py:82-88:
+ *             x + sublayer(norm(x)) without a pass over both tensors); Cout % 256 == 0, N % 256 == 0
+ *   out_img   the output as the activation image of the NEXT f16x2 layer (l3d_f16_act_bytes(B N, Cout) bytes): chains of Linear /
+ *             1x1-conv layers stay on the fp16 matrix cores with no split pass in between.  Needs obs = two device floats
+ *             {max|shift| over every (b, co), max|scale|} (max|scale| = 1 without a scale); with the weight image's row-sum
+ *             maximum and the input image's scale the kernel bounds its outputs and fixes the plane scale itself
+ *   ypool     [B][Cout][N/pool] fp32 = the maxima over runs of `pool` (8, 16, 32, 64, 128) consecutive points: pool = 128 for a
+ *             global max-pool (models/pooling.py:9-12 after pcn.py:115,124 / pointnet.py:49; a reduce over N/128 values per
+ *             channel finishes it), pool = K for the max over a group's K neighbours (models/flownet3d.py:179, :234); the
+ *             layer's [B,Cout,N] output is then never written
+ *   amax_out  with y: max|y| per group of amax_cdiv output channels (amax_cdiv % 256 == 0) into amax_out[Cout / amax_cdiv]
+ *             (uint32 float bits, atomic maximum: the caller zeroes them first): the operand maxima
+ *             l3d_attention_forward_f16b wants, from the projection's own epilogue (utils/transformer.py:183-189)
+ * flags     L3D_CONV_F16_TWO_PLANE: the input image's residual plane is UNSCALED (m = f16(X - h); written by
+ *           l3d_edgeconv_forward_f16b with out_mode 2): the Hs plane of the weight image is not read (12 instead of 14 LDS fragment
+ *           reads and 4 instead of 5 DMA pieces per chunk and wave).  y only; Cout % 256 == 0, N % 256 == 0.
+ * shift may be per cloud (shift_bstride = Cout, else 0). */
+#define L3D_CONV_F16_TWO_PLANE 1
 int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
-                           int shift_bstride, int B, int Cin, int Cout, int N, int relu, float *y,
-                           l3d_stream_t stream);
-/* l3d_pointwise_conv_f16 with a residual connection in its epilogue: y = res + act(scale (w x) + shift), res and y
- * [B][Cout][N] fp32, distinct buffers (utils/transformer.py:82-88: x + sublayer(norm(x)) without a pass over both tensors).
- * Cout % 256 == 0, N % 256 == 0. */
-int l3d_pointwise_conv_f16_residual(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
-                                    int shift_bstride, int B, int Cin, int Cout, int N, int relu, const float *res, float *y,
-                                    l3d_stream_t stream);
-/* l3d_pointwise_conv_f16 for an activation image whose residual plane is UNSCALED (m = f16(X - h); written by
- * l3d_edgeconv_forward_f16b with out_mode 2): the Hs plane of the weight image is not read (two weight planes, 12 instead of 14
- * LDS fragment reads and 4 instead of 5 DMA pieces per chunk and wave).  Cout % 256 == 0, N % 256 == 0. */
-int l3d_pointwise_conv_f16_2p(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
-                           int shift_bstride, int B, int Cin, int Cout, int N, int relu, float *y,
-                           l3d_stream_t stream);
-/* The same layer with its OUTPUT written as an activation image (l3d_f16_act_bytes(B N, Cout) bytes) for the next f16x2
- * layer instead of fp32 [B,Cout,N]: chains of Linear / 1x1-conv layers stay on the fp16 matrix cores with no split pass in
- * between.  obs: two device floats {max|shift|, max|scale|} (max|scale| = 1 without a scale); with the weight image's
- * row-sum maximum and the input image's scale the kernel bounds its outputs and fixes the plane scale itself. */
-int l3d_pointwise_conv_f16_planes(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
-                                  const float *obs, int B, int Cin, int Cout, int N, int relu, void *out_img, l3d_stream_t stream);
-/* l3d_pointwise_conv_f16 that also reports max|y| per group of amax_cdiv output channels (amax_cdiv % 256 == 0) into
- * amax_out[Cout / amax_cdiv] (uint32 float bits, atomic maximum: the caller zeroes them first): the operand maxima
- * l3d_attention_forward_f16_maxima wants, from the projection's own epilogue (utils/transformer.py:183-189). */
-int l3d_pointwise_conv_f16_absmax(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
-                                  int shift_bstride, int B, int Cin, int Cout, int N, int relu, float *y,
-                                  void *amax_out, int amax_cdiv, l3d_stream_t stream);
-/* The layer with either or both of: its output as an activation image (out_img; obs as above, max|shift| taken over every
- * (b, co) when the shift is per cloud, shift_bstride = Cout), and ypool [B][Cout][N/pool] fp32 = the maxima over runs of
- * `pool` (8, 16, 32, 64, 128) consecutive points: pool = 128 for a global max-pool (models/pooling.py:9-12 after
- * pcn.py:115,124 / pointnet.py:49; a reduce over N/128 values per channel finishes it), pool = K for the max over a group's
- * K neighbours (models/flownet3d.py:179, :234).  The layer's [B,Cout,N] output is never written. */
-int l3d_pointwise_conv_f16_pool(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
-                                int shift_bstride, const float *obs, int B, int Cin, int Cout, int N, int relu,
-                                void *out_img, float *ypool, int pool, l3d_stream_t stream);
+                           int shift_bstride, int B, int Cin, int Cout, int N, int relu, int flags, float *y,
+                           const float *residual, void *out_img, const float *obs, float *ypool, int pool,
+                           void *amax_out, int amax_cdiv, l3d_stream_t stream);
 /* First layer of a per-point MLP (Cin <= 8; pcn.py:26-33 conv1 3 -> 128, pointnet.py:42) written straight as an activation
  * image: x [B][N][Cin] (channel_last) or [B][Cin][N], w [Cout][Cin], shift [Cout] or NULL, xmax = device float >= max|x|
  * (the plane scale follows from max_r(|shift_r| + xmax sum_c |w_rc|)); raises *range_flag if xmax was not a bound. */

@@ -697,70 +697,32 @@ static int cf_launch(const void *x_planes, const void *w_planes, const float *sc
     return l3d_check_launch();
 }
 
+// THE entry point of the f16x2 layer (one kernel family, one name; round 3 had six spellings of it).  Outputs, any combination
+// the kernel family offers:
+//   y         fp32 [B][Cout][N], or NULL
+//   residual  y = residual + act(...): residual and y [B][Cout][N] fp32, distinct buffers (wide tile, fp32 output only)
+//   out_img   the output as the activation image of the NEXT f16x2 layer (l3d_f16_act_bytes(B N, Cout) bytes) instead of / beside
+//             ypool; needs obs = two device floats {max|shift| over every (b, co), max|scale|} (max|scale| = 1 without a scale)
+//             from which, with the weight image's row-sum maximum and the input image's scale, the kernel fixes the plane scale
+//   ypool     [B][Cout][N/pool] fp32 maxima over runs of `pool` (8, 16, 32, 64 or 128) consecutive points: pool = 128 makes a
+//             global max-pool a reduce over N/128 values per channel (pcn.py:110-124), pool = K the max over a group's K
+//             neighbours (flownet3d.py:179, :234); the [B,Cout,N] output is then never written
+//   amax_out  max|y| per group of amax_cdiv output channels (amax_cdiv % 256 == 0) as float bits, atomicMax into
+//             amax_out[Cout / amax_cdiv] (the caller zeroes them; needs y): transformer.py:183-189's fused q|k|v projection
+//             hands the attention kernel its operand maxima
+// flags: L3D_CONV_F16_TWO_PLANE -- the input image's residual plane is UNSCALED (m = f16(X - h), written by
+//        l3d_edgeconv_forward_f16b with out_mode 2): the Hs plane of the weight image is not read (wide tile, y only).
+// shift may be per cloud (shift_bstride = Cout).  Cin % 16 == 0; Cout % 256 == 0 and N % 256 == 0, or Cout % 128 == 0 and N % 512 == 0.
 extern "C" int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
-                                      int shift_bstride, int B, int Cin, int Cout, int N, int relu, float *y,
-                                      l3d_stream_t stream)
+                                      int shift_bstride, int B, int Cin, int Cout, int N, int relu, int flags, float *y,
+                                      const float *residual, void *out_img, const float *obs, float *ypool, int pool,
+                                      void *amax_out, int amax_cdiv, l3d_stream_t stream)
 {
-    L3D_REQUIRE(x_planes && w_planes && y && B > 0 && Cin > 0 && Cout > 0 && N > 0);
-    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, nullptr, nullptr, nullptr, 0, nullptr, 0, (hipStream_t)stream);
-}
-
-// y = res + act(scale (w x) + shift): res and y [B][Cout][N] fp32, distinct buffers.  Cout % 256 == 0, N % 256 == 0.
-extern "C" int l3d_pointwise_conv_f16_residual(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
-                                               int shift_bstride, int B, int Cin, int Cout, int N, int relu, const float *res,
-                                               float *y, l3d_stream_t stream)
-{
-    L3D_REQUIRE(x_planes && w_planes && y && res && B > 0 && Cin > 0 && Cout > 0 && N > 0);
-    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, nullptr, nullptr, nullptr, 0, nullptr, 0,
-                     (hipStream_t)stream, false, res);
-}
-
-// l3d_pointwise_conv_f16 for an activation image whose residual plane is UNSCALED (m = f16(X - h): l3d_edgeconv_forward_f16b with
-// out_mode 2): the Hs plane of the weight image is not read.  Cout % 256 == 0, N % 256 == 0.
-extern "C" int l3d_pointwise_conv_f16_2p(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
-                                         int shift_bstride, int B, int Cin, int Cout, int N, int relu, float *y,
-                                         l3d_stream_t stream)
-{
-    L3D_REQUIRE(x_planes && w_planes && y && B > 0 && Cin > 0 && Cout > 0 && N > 0);
-    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, nullptr, nullptr, nullptr, 0, nullptr, 0,
-                     (hipStream_t)stream, true);
-}
-
-// The same layer with its OUTPUT written as an activation image (l3d_f16_act_bytes(B N, Cout) bytes) for the next f16x2 layer
-// instead of fp32 [B,Cout,N].  obs: two device floats {max|shift|, max|scale|} (max|scale| = 1 without a scale) from which, with
-// the weight image's row-sum maximum and the input image's scale, the kernel bounds its outputs and fixes the plane scale.
-extern "C" int l3d_pointwise_conv_f16_planes(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
-                                             const float *obs, int B, int Cin, int Cout, int N, int relu, void *out_img,
-                                             l3d_stream_t stream)
-{
-    L3D_REQUIRE(x_planes && w_planes && out_img && obs && B > 0 && Cin > 0 && Cout > 0 && N > 0);
-    return cf_launch(x_planes, w_planes, scale, shift, 0, B, Cin, Cout, N, relu, nullptr, out_img, obs, nullptr, 0, nullptr, 0, (hipStream_t)stream);
-}
-
-// l3d_pointwise_conv_f16 that also reports max|y| per group of amax_cdiv output channels into amax_out[Cout / amax_cdiv] (float
-// bits, atomicMax: the caller zeroes them; amax_cdiv % 256 == 0).  transformer.py:183-189: the fused q|k|v projection hands the
-// attention kernel its operand maxima.
-extern "C" int l3d_pointwise_conv_f16_absmax(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
-                                             int shift_bstride, int B, int Cin, int Cout, int N, int relu, float *y,
-                                             void *amax_out, int amax_cdiv, l3d_stream_t stream)
-{
-    L3D_REQUIRE(x_planes && w_planes && y && amax_out && B > 0 && Cin > 0 && Cout > 0 && N > 0 && amax_cdiv > 0);
-    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, nullptr, nullptr, nullptr, 0,
-                     (unsigned *)amax_out, amax_cdiv, (hipStream_t)stream);
-}
-
-// The layer with either or both of: its output as an activation image (out_img, needs obs = {max|shift| over every (b, co), max|scale|}),
-// and ypool [B][Cout][N/pool] fp32 = the maxima over runs of `pool` (8, 16, 32, 64 or 128) consecutive points: with pool = 128 a global
-// max-pool is a reduce over N/128 values per channel (pcn.py:110-124: conv2 -> (pool, conv3 with the pooled half of W3 as a per-cloud
-// shift) -> conv4 -> pool); with pool = K it is the max over a group's K neighbours (flownet3d.py:179, :234).  The [B,Cout,N] output
-// is never written.  shift may be per cloud (shift_bstride = Cout).
-extern "C" int l3d_pointwise_conv_f16_pool(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
-                                           int shift_bstride, const float *obs, int B, int Cin, int Cout, int N, int relu,
-                                           void *out_img, float *ypool, int pool, l3d_stream_t stream)
-{
-    L3D_REQUIRE(x_planes && w_planes && (out_img || ypool) && (!out_img || obs) && B > 0 && Cin > 0 && Cout > 0 && N > 0);
-    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, nullptr, out_img, obs, ypool, pool, nullptr, 0,
-                     (hipStream_t)stream);
+    L3D_REQUIRE(x_planes && w_planes && (y || out_img || ypool) && (!out_img || obs) && (!residual || y) && (!amax_out || (y && amax_cdiv > 0)) &&
+                B > 0 && Cin > 0 && Cout > 0 && N > 0 && (flags & ~1) == 0);
+    if (y && (out_img || ypool)) return L3D_ERR_UNSUPPORTED;                  // the epilogue writes fp32 rows OR planes / pooled maxima
+    return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, out_img, obs, ypool, pool,
+                     (unsigned *)amax_out, amax_cdiv, (hipStream_t)stream, (flags & 1) != 0, residual);
 }
 
 // ---------------------------------------------------------------------------------------------

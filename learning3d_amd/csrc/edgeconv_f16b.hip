@@ -631,6 +631,9 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
         static_assert(REM % 16 == 0 && REM < 1024, "remainder in 16-byte pieces");
         if (threadIdx.x < REM / 16) ((uint4 *)(ef_lds + NCH * 1024))[threadIdx.x] = ((const uint4 *)(src + NCH * 1024))[threadIdx.x];
     }
+    // the compiler does not wait for LDS-DMA in front of a barrier (waves 1-3 skip the remainder branch and with it the only
+    // vmcnt(0) it emitted): every wave's own DMA pieces have landed, then the barrier publishes them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                            // the parameter tail is in LDS
     // layer 2's first fragments and bias
     EfRing R;
@@ -677,7 +680,12 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
             if (first) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
             else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
         };
-        asm volatile("s_nop 3");                                 // b1 comes from VALU selects: no hazard padding in front of an asm MFMA
+        // b1 comes from VALU selects and nothing pads a VALU write in front of an asm MFMA that reads it (the compiler had placed the
+        // v_cndmask of b1[.][1] directly in front of the first k-step-1 MFMA: stale operand, 15 % of the pooled values wrong): the
+        // operands are inputs of the s_nop, so they are computed before it
+#pragma unroll
+        for (int t = 0; t < MT; t++) asm volatile("" ::"v"(b1[t][0]), "v"(b1[t][1]));
+        asm volatile("s_nop 3");
 #pragma unroll
         for (int mm = 0; mm < 2; mm++)
 #pragma unroll
@@ -693,6 +701,11 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
                 ef_micro<MT, false, true, PLANES, decltype(u)::value>(accA, p1[0], T1, 0, L, s1, ovf);
             });
         });
+        // An MFMA reads its C operand over its passes, and nothing pads an asm MFMA: the bias registers must not be handed out as
+        // VALU temporaries while the last init MFMAs are in flight (the compiler did exactly that with bv1[3], three instructions
+        // behind the MFMA reading it: 15 % of the image wrong).  A use behind the last slot keeps all four alive until then.
+#pragma unroll
+        for (int m = 0; m < EC_C1 / 16; m++) asm volatile("" ::"v"(bv1[m]), "v"(a1[m]));
     }
     int mp_last;
 

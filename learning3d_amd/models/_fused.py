@@ -316,12 +316,25 @@ def _plane_obs(scale, shift, dev):
     return hit[0]
 
 
+def _conv_f16(label, x_planes, w_planes, scale, shift, bstride, B, Cin, Cout, N, relu, flags=0, y=None, residual=None, img=None,
+              obs=None, ypool=None, pool=0, amax=None, amax_cdiv=0):
+    """the one C entry point of the f16x2 layer (l3d_pointwise_conv_f16); `label` names the variant in the launch log"""
+    rc = lib().l3d_pointwise_conv_f16(ptr(x_planes), ptr(w_planes), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N, int(relu),
+                                      flags, ptr(y), ptr(residual), ptr(img), ptr(obs), ptr(ypool), int(pool), ptr(amax),
+                                      int(amax_cdiv), stream_ptr())
+    check(rc, label)
+
+
+CONV_F16_TWO_PLANE = 1        # include/l3d_hip.h: L3D_CONV_F16_TWO_PLANE
+
+
 def pointwise_conv_f16(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=None, relu=False, out_planes=False, amax=None,
                        unscaled=False, residual=None):
     """l3d_pointwise_conv_f16 on pre-split operands -> y [B,Cout,N] fp32; out_planes=True: the output as an fp16 activation
-    image (uint8 tensor) for the next f16x2 layer instead (l3d_pointwise_conv_f16_planes; shift must be [Cout] or None).
+    image (uint8 tensor) for the next f16x2 layer instead (shift must be [Cout] or None).
     amax = (int32 tensor, channels per group): also max|y| per channel group as float bits, atomically maximised into the
-    (pre-zeroed) tensor (l3d_pointwise_conv_f16_absmax)."""
+    (pre-zeroed) tensor.  unscaled: the input image carries an unscaled residual plane (the two-plane EdgeConv kernel's).
+    residual: y = residual + layer(x)."""
     scale = f32c(scale) if scale is not None else None
     shift = f32c(shift) if shift is not None else None
     if out_planes:
@@ -330,35 +343,30 @@ def pointwise_conv_f16(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=No
         dev = x_planes.device
         obs = _plane_obs(scale, shift, dev)
         img = torch.empty(lib().l3d_f16_act_bytes(B * N, Cout), dtype=torch.uint8, device=dev)
-        check(lib().l3d_pointwise_conv_f16_planes(ptr(x_planes), ptr(w_planes), ptr(scale), ptr(shift), ptr(obs), B, Cin, Cout, N,
-                                                  int(relu), ptr(img), stream_ptr()), "l3d_pointwise_conv_f16_planes")
+        _conv_f16("l3d_pointwise_conv_f16[planes]", x_planes, w_planes, scale, shift, 0, B, Cin, Cout, N, relu, img=img, obs=obs)
         return img
     bstride = Cout if (shift is not None and shift.dim() == 2) else 0
     y = torch.empty((B, Cout, N), dtype=torch.float32, device=x_planes.device)
     if residual is not None:
-        # y = residual + layer(x): the sublayer's residual connection in the GEMM's epilogue (l3d_pointwise_conv_f16_residual)
+        # y = residual + layer(x): the sublayer's residual connection in the GEMM's epilogue
         if amax is not None or unscaled or tuple(residual.shape) != (B, Cout, N) or not (Cout % 256 == 0 and N % 256 == 0):
             raise ValueError("residual epilogue: residual [B,Cout,N], Cout % 256 == 0, N % 256 == 0, no absmax / two-plane input")
-        check(lib().l3d_pointwise_conv_f16_residual(ptr(x_planes), ptr(w_planes), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N,
-                                                    int(relu), ptr(f32c(residual)), ptr(y), stream_ptr()),
-              "l3d_pointwise_conv_f16_residual")
+        _conv_f16("l3d_pointwise_conv_f16[residual]", x_planes, w_planes, scale, shift, bstride, B, Cin, Cout, N, relu, y=y,
+                  residual=f32c(residual))
         return y
     if unscaled:
         # the image's residual plane is unscaled (edgeconv_forward(..., planes=True, unscaled=True)): two weight planes
         if amax is not None or not (Cout % 256 == 0 and N % 256 == 0):
             raise ValueError("the two-plane conv kernel takes Cout % 256 == 0, N % 256 == 0 and no absmax output")
         with stage("conv5_kernel"):
-            rc = lib().l3d_pointwise_conv_f16_2p(ptr(x_planes), ptr(w_planes), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N, int(relu),
-                                                 ptr(y), stream_ptr())
-        check(rc, "l3d_pointwise_conv_f16_2p")
+            _conv_f16("l3d_pointwise_conv_f16[two-plane]", x_planes, w_planes, scale, shift, bstride, B, Cin, Cout, N, relu,
+                      flags=CONV_F16_TWO_PLANE, y=y)
         return y
     if amax is not None:
-        check(lib().l3d_pointwise_conv_f16_absmax(ptr(x_planes), ptr(w_planes), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N,
-                                                  int(relu), ptr(y), ptr(amax[0]), int(amax[1]), stream_ptr()),
-              "l3d_pointwise_conv_f16_absmax")
+        _conv_f16("l3d_pointwise_conv_f16[absmax]", x_planes, w_planes, scale, shift, bstride, B, Cin, Cout, N, relu, y=y,
+                  amax=amax[0], amax_cdiv=int(amax[1]))
         return y
-    check(lib().l3d_pointwise_conv_f16(ptr(x_planes), ptr(w_planes), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N, int(relu),
-                                       ptr(y), stream_ptr()), "l3d_pointwise_conv_f16")
+    _conv_f16("l3d_pointwise_conv_f16", x_planes, w_planes, scale, shift, bstride, B, Cin, Cout, N, relu, y=y)
     return y
 
 
@@ -382,7 +390,7 @@ def first_layer_f16_planes(x, w, shift, relu, channel_last):
 
 def pointwise_conv_f16_pool(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=None, relu=False, out_planes=False, pool=True,
                             group=None):
-    """l3d_pointwise_conv_f16_pool: the layer's output as an activation image (out_planes) and / or its maximum over all N points
+    """l3d_pointwise_conv_f16 with pooled / image outputs: the layer's output as an activation image (out_planes) and / or its maximum over all N points
     [B,Cout] (pool; per-128-point maxima from the kernel's epilogue, then a reduce over N/128) -- or, with group=K (8, 16, 32, 64),
     the maximum over every K consecutive points [B,Cout,N/K] (a grouped layer's max over its K neighbours).
     shift [Cout] or per cloud [B,Cout].  Returns (img or None, pooled or None)."""
@@ -399,8 +407,8 @@ def pointwise_conv_f16_pool(x_planes, B, N, w_planes, Cin, Cout, scale=None, shi
     pk = int(group) if group else 128
     if pool or group:
         part = torch.empty((B, Cout, N // pk), dtype=torch.float32, device=dev)
-    check(lib().l3d_pointwise_conv_f16_pool(ptr(x_planes), ptr(w_planes), ptr(scale), ptr(shift), bstride, ptr(obs), B, Cin, Cout, N,
-                                            int(relu), ptr(img), ptr(part), pk, stream_ptr()), "l3d_pointwise_conv_f16_pool")
+    _conv_f16("l3d_pointwise_conv_f16[pool]", x_planes, w_planes, scale, shift, bstride, B, Cin, Cout, N, relu, img=img, obs=obs,
+              ypool=part, pool=pk)
     if group:
         return img, part
     return img, (part.max(dim=2)[0] if pool else None)

@@ -435,7 +435,7 @@ class Transformer(nn.Module):
     # One encoder-decoder pass with every tensor in the layout the GEMMs write, [B,C,N]: LayerNorm over the channels of a
     # channel-first tensor straight to the fp16 plane image (l3d_layernorm_planes_cf), q|k|v / q, k|v projections with their
     # maxima, attention with its context as planes, output projection and the feed-forward's second layer with the
-    # sublayer's residual connection in their epilogues (l3d_pointwise_conv_f16_residual).  Against the module-by-module
+    # sublayer's residual connection in their epilogues (l3d_pointwise_conv_f16 with a residual).  Against the module-by-module
     # route this drops, per pass, five transposed residual adds, the .contiguous() copies around the pass and the fp32
     # LayerNorm outputs nobody reads (reference: utils/transformer.py:131-140 SublayerConnection, :163-217, :236-243).
     # ------------------------------------------------------------------------------------------------------------------

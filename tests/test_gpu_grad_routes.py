@@ -67,7 +67,7 @@ def test_eval_with_grad_enabled_runs_the_fused_kernels_dgcnn(golden):
     x = dev(rand((4, 1024, 3), 0))
     with launch_log() as log:
         y = big(x)
-    assert log.count("l3d_edgeconv_forward_f16b") == 1 and log.count("l3d_pointwise_conv_f16_2p") == 1, log    # the two-plane kernels
+    assert log.count("l3d_edgeconv_forward_f16b") == 1 and log.count("l3d_pointwise_conv_f16[two-plane]") == 1, log    # the two-plane kernels
     with torch.no_grad():
         assert torch.equal(big(x), y.detach())
 
@@ -89,7 +89,7 @@ def test_eval_with_grad_enabled_runs_the_fused_kernels_other_models(golden):
     xp = dev(rand((2, 512, 3), 4, -0.5, 0.5))
     with launch_log() as log:
         out = pcn(xp)
-    assert "l3d_first_layer_f16_planes" in log and "l3d_pointwise_conv_f16_pool" in log and "l3d_fold_mlp_f16" in log, log
+    assert "l3d_first_layer_f16_planes" in log and "l3d_pointwise_conv_f16[pool]" in log and "l3d_fold_mlp_f16" in log, log
     assert "l3d_bn_act_forward" not in log
     assert out["fine_output"].requires_grad and pcn.coarse_output is out["coarse_output"]
     with torch.no_grad():

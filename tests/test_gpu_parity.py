@@ -647,7 +647,7 @@ def test_edgeconv_f16_planes_output_equals_pooled():
             y1 = _fused.pointwise_conv_f16(img, B, N, w5f, 512, 256, s5, b5, relu=True)
             y2 = _fused.pointwise_conv_f16(_fused.split_rows_f16(pooled), B, N, w5f, 512, 256, s5, b5, relu=True)
             np.testing.assert_allclose(y1.cpu().numpy(), y2.cpu().numpy(), rtol=1e-5, atol=1e-6)
-        # out_mode 2: the same pooled values with an UNSCALED residual plane, for the two-plane conv kernel (l3d_pointwise_conv_f16_2p)
+        # out_mode 2: the same pooled values with an UNSCALED residual plane, for the two-plane conv kernel (l3d_pointwise_conv_f16 with L3D_CONV_F16_TWO_PLANE)
         img2 = _fused.edgeconv_forward(x, idx, packed, planes=True, v2=True, unscaled=True)
         raw2 = img2.cpu().numpy()
         h2 = raw2[:pb].view(np.float16).reshape(64, B * N, 8).astype(np.float64)
@@ -1175,7 +1175,7 @@ def test_transformer_channel_first_pass():
     """utils/transformer.py, Transformer._pass_cf: a whole encoder-decoder pass in the [B,C,N] layout of the GEMMs (channel-first
     LayerNorm straight to planes, residual connections in the epilogues of the output projection and the feed-forward's second
     layer) against the module-by-module route and against the reference's op sequence in fp64 (utils/transformer.py:14-243);
-    the pieces too: l3d_layernorm_planes_cf vs the row kernel's formula in fp64, l3d_pointwise_conv_f16_residual vs conv + add."""
+    the pieces too: l3d_layernorm_planes_cf vs the row kernel's formula in fp64, l3d_pointwise_conv_f16's residual epilogue vs conv + add."""
     import copy
     from learning3d_amd._lib import check, lib, ptr, stream_ptr
     from learning3d_amd.models import _fused
@@ -1226,7 +1226,7 @@ def test_transformer_channel_first_pass():
             got = net(dev(a_), dev(b_))
         finally:
             _lib.LAUNCH_LOG = None
-        assert "l3d_layernorm_planes_cf" in log and "l3d_pointwise_conv_f16_residual" in log and "l3d_add_transposed" not in log, sorted(set(log))
+        assert "l3d_layernorm_planes_cf" in log and "l3d_pointwise_conv_f16[residual]" in log and "l3d_add_transposed" not in log, sorted(set(log))
         T.CHANNEL_FIRST_PASS = False
         try:
             mod = net(dev(a_), dev(b_))
@@ -1851,7 +1851,7 @@ def test_attention_f16_context_planes_feed_conv_f16():
 
 @pytest.mark.gpu
 def test_conv_f16_plane_output_chains():
-    """Two f16x2 layers chained through an fp16 plane image (l3d_pointwise_conv_f16_planes -> l3d_pointwise_conv_f16): the
+    """Two f16x2 layers chained through an fp16 plane image (l3d_pointwise_conv_f16 with out_img -> l3d_pointwise_conv_f16): the
     hidden layer is never written in fp32; its plane scale comes from a bound the kernel derives from the weights' row
     sums and the input image's scale.  Against fp64, with hidden activations from tiny to large."""
     from learning3d_amd.models import _fused
@@ -1947,7 +1947,7 @@ def test_pcn_encoder_f16_chain_matches_reference_order_path():
 
 
 def test_conv_f16_absmax_feeds_attention_maxima():
-    """The fused q|k|v projection reports max|q|, |k|, |v| from its own epilogue (l3d_pointwise_conv_f16_absmax) and
+    """The fused q|k|v projection reports max|q|, |k|, |v| from its own epilogue (l3d_pointwise_conv_f16 with amax_out) and
     l3d_attention_forward_f16_maxima takes them instead of a pass over the three tensors: the maxima equal torch's, and the
     attention output is bit-identical to the entry point that measures them itself (utils/transformer.py:183-189)."""
     from learning3d_amd._lib import check, lib, ptr, stream_ptr

@@ -51,11 +51,13 @@ def test_argument_validation_without_gpu():
     assert l.l3d_group_first_layer(p, None, None, p, p, p, p, 1, 8, 4, 2, 30, 1, p, None) == -2          # C1 % 4
     assert l.l3d_first_layer_f16_planes(None, 1, None, None, None, 1, 3, 128, 256, 1, None, None, None) == -1
     assert l.l3d_first_layer_f16_planes(p, 1, p, None, p, 1, 9, 128, 256, 1, p, None, None) == -2         # Cin > 8
-    assert l.l3d_pointwise_conv_f16_pool(p, p, None, None, 0, None, 1, 128, 256, 256, 0, None, None, 128, None) == -1   # no output asked for
-    assert l.l3d_pointwise_conv_f16_pool(p, p, None, None, 0, None, 1, 128, 256, 256, 0, p, None, 128, None) == -1      # image without obs
-    assert l.l3d_pointwise_conv_f16_pool(p, p, None, None, 0, None, 1, 128, 256, 256, 0, None, p, 24, None) == -2       # pool not a supported run length
-    assert l.l3d_pointwise_conv_f16_pool(p, p, None, None, 0, None, 1, 128, 128, 256, 0, None, p, 8, None) == -2        # narrow tile wants N % 512
-    assert l.l3d_pointwise_conv_f16_absmax(p, p, None, None, 0, 1, 128, 256, 256, 0, p, p, 100, None) == -2        # group size % 256
+    assert l.l3d_pointwise_conv_f16(p, p, None, None, 0, 1, 128, 256, 256, 0, 0, None, None, None, None, None, 128, None, 0, None) == -1   # no output asked for
+    assert l.l3d_pointwise_conv_f16(p, p, None, None, 0, 1, 128, 256, 256, 0, 0, None, None, p, None, None, 128, None, 0, None) == -1      # image without obs
+    assert l.l3d_pointwise_conv_f16(p, p, None, None, 0, 1, 128, 256, 256, 0, 0, None, None, None, None, p, 24, None, 0, None) == -2       # pool not a supported run length
+    assert l.l3d_pointwise_conv_f16(p, p, None, None, 0, 1, 128, 128, 256, 0, 0, None, None, None, None, p, 8, None, 0, None) == -2        # narrow tile wants N % 512
+    assert l.l3d_pointwise_conv_f16(p, p, None, None, 0, 1, 128, 256, 256, 0, 0, p, None, None, None, None, 0, p, 100, None) == -2        # group size % 256
+    assert l.l3d_pointwise_conv_f16(p, p, None, None, 0, 1, 128, 256, 256, 0, 0, p, None, p, p, None, 0, None, 0, None) == -2          # fp32 rows AND an image
+    assert l.l3d_pointwise_conv_f16(p, p, None, None, 0, 1, 128, 256, 256, 0, 2, p, None, None, None, None, 0, None, 0, None) == -1     # unknown flag
     assert l.l3d_attention_forward_f16_maxima(None, None, None, 1, 4, 128, 256, 256, 0, 0, 0, 0.1, None, None, None, None) == -1
     assert l.l3d_layernorm_planes(p, p, p, 1e-6, 4, 520, None, p, None) == -2                                      # C > 512
     # round-3 entry points

@@ -14,7 +14,7 @@ int main()
     void *x, *w; float *y;
     hipMalloc(&x, xb); hipMalloc(&w, wb); hipMalloc(&y, (size_t)B * Cout * N * 4);
     hipMemset(x, 0x11, xb); hipMemset(w, 0x11, wb);
-    for (int it = 0; it < 3; it++) l3d_pointwise_conv_f16(x, w, nullptr, nullptr, 0, B, Cin, Cout, N, 1, y, nullptr);
+    for (int it = 0; it < 3; it++) l3d_pointwise_conv_f16(x, w, nullptr, nullptr, 0, B, Cin, Cout, N, 1, 0, y, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr);
     hipDeviceSynchronize();
     const int nw = 512 * 8;
     std::vector<long long> t((size_t)nw * 8);

@@ -37,7 +37,7 @@ int main()
     }
     hipMemcpyToSymbol(HIP_SYMBOL(g_cb_timeline), &tl, sizeof(tl));
     hipMemset(y0, 0xff, ny * 4); hipMemset(y1, 0xee, ny * 4);
-    int rc0 = l3d_pointwise_conv_f16_2p(x, w, sc, sh, 0, B, Cin, Cout, N, 1, y0, nullptr);
+    int rc0 = l3d_pointwise_conv_f16(x, w, sc, sh, 0, B, Cin, Cout, N, 1, 1, y0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr);
     int rc1 = l3d_pointwise_conv_f16b(x, w, sc, sh, 0, B, Cin, Cout, N, 1, y1, nullptr);
     hipDeviceSynchronize();
     printf("rc %d %d, hip error %s\n", rc0, rc1, hipGetErrorString(hipGetLastError()));
@@ -56,10 +56,10 @@ int main()
     for (int which = 0; which < 2; which++) {
         for (int rep = 0; rep < 3; rep++) {
             for (int it = 0; it < 20; it++) which ? l3d_pointwise_conv_f16b(x, w, sc, sh, 0, B, Cin, Cout, N, 1, y1, nullptr)
-                                                  : l3d_pointwise_conv_f16_2p(x, w, sc, sh, 0, B, Cin, Cout, N, 1, y0, nullptr);
+                                                  : l3d_pointwise_conv_f16(x, w, sc, sh, 0, B, Cin, Cout, N, 1, 1, y0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr);
             hipEventRecord(e0, nullptr);
             for (int it = 0; it < 50; it++) which ? l3d_pointwise_conv_f16b(x, w, sc, sh, 0, B, Cin, Cout, N, 1, y1, nullptr)
-                                                  : l3d_pointwise_conv_f16_2p(x, w, sc, sh, 0, B, Cin, Cout, N, 1, y0, nullptr);
+                                                  : l3d_pointwise_conv_f16(x, w, sc, sh, 0, B, Cin, Cout, N, 1, 1, y0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr);
             hipEventRecord(e1, nullptr);
             hipDeviceSynchronize();
             float ms; hipEventElapsedTime(&ms, e0, e1);

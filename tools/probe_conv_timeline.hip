@@ -19,9 +19,9 @@ int main()
     hipMemset(x, 0x11, xb); hipMemset(w, 0x11, wb);
     hipMemcpyToSymbol(HIP_SYMBOL(g_cf_timeline), &tl, sizeof(tl));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int it = 0; it < 20; it++) l3d_pointwise_conv_f16_2p(x, w, nullptr, nullptr, 0, B, Cin, Cout, N, 1, y, nullptr);
+    for (int it = 0; it < 20; it++) l3d_pointwise_conv_f16(x, w, nullptr, nullptr, 0, B, Cin, Cout, N, 1, 1, y, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr);
     hipEventRecord(e0, nullptr);
-    for (int it = 0; it < 20; it++) l3d_pointwise_conv_f16_2p(x, w, nullptr, nullptr, 0, B, Cin, Cout, N, 1, y, nullptr);
+    for (int it = 0; it < 20; it++) l3d_pointwise_conv_f16(x, w, nullptr, nullptr, 0, B, Cin, Cout, N, 1, 1, y, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr);
     hipEventRecord(e1, nullptr);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
