@@ -861,7 +861,7 @@ def main():
         arith_ = _fused.gemm_arith()
         w5_, s5_, b5_, w5s_, w5f_ = net._conv5_folded()
         if arith_ == "f16x2":
-            v2_ = net._packed.v2_ok and _fused.EDGECONV_F16_TWO_PLANE
+            v2_ = net._packed.v2_ok
             img_ = _fused.edgeconv_forward(x, idx_, packed_, planes=True, v2=v2_, unscaled=v2_)
             stage_ms["conv5"] = per_launch_ms(lambda: _fused.pointwise_conv_f16(img_, B_PER_GPU, NPTS, w5f_, 512, EMB, s5_, b5_, relu=True,
                                                                                   unscaled=v2_))

@@ -311,14 +311,8 @@ int l3d_attention_forward_strided(const float *q, const float *k, const float *v
  * them.  Same shapes and strides as l3d_attention_forward_strided.  Output: ctx (fp32, may be NULL) and / or ctx_img, the
  * context as the fp16 activation image of l3d_pointwise_conv_f16 (l3d_f16_act_bytes(B N, H D) bytes; may be NULL): the
  * output projection then needs no split pass (|ctx| <= max|v| fixes the plane scale). */
-int l3d_attention_forward_f16(const float *q, const float *k, const float *v, int B, int H, int D, int N, int M,
-                              long q_bstride, long k_bstride, long v_bstride, float scale, void *workspace, float *ctx,
-                              void *ctx_img, l3d_stream_t stream);
 /* The same with the three operand maxima already in `maxima` (uint32 float bits of upper bounds of max|q|, |k|, |v|, e.g. from
  * l3d_pointwise_conv_f16 with amax_out): the pass over q, k, v is not run. */
-int l3d_attention_forward_f16_maxima(const float *q, const float *k, const float *v, int B, int H, int D, int N, int M,
-                                     long q_bstride, long k_bstride, long v_bstride, float scale, const void *maxima,
-                                     float *ctx, void *ctx_img, l3d_stream_t stream);
 
 /* The same computation on the restructured kernel (attention_f16b.hip: 256 queries per workgroup, Q fragments in registers, the
  * probabilities handed from the score accumulators to the second product without leaving registers, one barrier per 32-key
@@ -368,8 +362,6 @@ int l3d_edgeconv_forward(const float *xyz, const int64_t *idx, int B, int N, int
 /* Same computation, same packed block, same output; a second kernel design (edgeconv2.hip) that
  * keeps the activations in registers through all four layers (no LDS, no barriers) by chaining the
  * MFMA accumulator layout of one layer into the B operand of the next.  k <= 20. */
-int l3d_edgeconv_forward_chained(const float *xyz, const int64_t *idx, int B, int N, int k,
-                                 const float *packed, float *pooled, l3d_stream_t stream);
 /* Same computation, same packed block (its third weight copy), same output layout; layers 2-4 run on
  * the bf16 matrix cores with every fp32 operand split exactly into three bf16 planes and six bf16
  * products per fp32 product ("bf16x3", fp32 accumulate; edgeconv_split.hip) -- fp32-level error at a
@@ -387,8 +379,6 @@ int l3d_edgeconv_forward_split(const float *xyz, const int64_t *idx, int B, int 
  * Range contract: activations must stay below 16x the expected magnitude (fp16 tops out at 65504); the kernel watches
  * the pooled maxima it forms anyway and stores 1 to *range_flag (device or mapped host memory, may be NULL) when a
  * plane value exceeds 60000 -- the outputs are then invalid and the caller re-runs l3d_edgeconv_forward_split.  k <= 20. */
-int l3d_edgeconv_forward_f16(const float *xyz, const int64_t *idx, int B, int N, int k, const float *packed, void *out,
-                             int out_mode, int *range_flag, l3d_stream_t stream);
 /* The two-plane variant (edgeconv_f16b.hip): same arguments and outputs; two fp16 weight planes per fragment step and an
  * unscaled activation residual (fifth packed copy, csrc/edgeconv_layout.h).  Usable only when the packer could place every
  * layer's weights (packed[l3d_edgeconv_packed_v2_flag_index()] == 1 in the HOST copy of the packed block).

@@ -72,8 +72,6 @@ SIGNATURES = {
     "l3d_soft_correspondence": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
     "l3d_attention_forward": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P],
     "l3d_attention_forward_strided": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _P],
-    "l3d_attention_forward_f16": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _P, _P, _P],
-    "l3d_attention_forward_f16_maxima": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _P, _P, _P],
     "l3d_attention_forward_f16b": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _I, _P, _P, _P],
     "l3d_layernorm_ref": [_P, _P, _P, _F, _L, _I, _P, _P],
     "l3d_layernorm_planes": [_P, _P, _P, _F, _L, _I, _P, _P, _P],
@@ -87,9 +85,7 @@ SIGNATURES = {
     "l3d_edgeconv_packed_floats": [_I, _I, _I, _I],
     "l3d_edgeconv_pack": [_P, _P, _P, _I, _I, _I, _I, _P],
     "l3d_edgeconv_forward": [_P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P],
-    "l3d_edgeconv_forward_chained": [_P, _P, _I, _I, _I, _P, _P, _P],
     "l3d_edgeconv_forward_split": [_P, _P, _I, _I, _I, _P, _P, _P],
-    "l3d_edgeconv_forward_f16": [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P],
     "l3d_edgeconv_forward_f16b": [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P],
     "l3d_edgeconv_packed_v2_flag_index": [],
     "l3d_edgeconv_pack_mag": [_P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -378,10 +378,50 @@ __global__ __launch_bounds__(512) void attention_f16b_kernel(const float *__rest
     }
 }
 
-// max|q|, |k|, |v| into amax[0..2] (attention_f16.hip's reduction kernel, behind a host function: kernels do not link across
-// translation units without -fgpu-rdc)
-int l3d_attention_absmax3(const float *q, const float *k, const float *v, long q_bs, long k_bs, long v_bs, long q_span, long kv_span,
-                          int B, unsigned *amax, hipStream_t st);
+// max|x| of q, k, v (blockIdx.y picks the tensor) as float bits, into out[0..2] (zeroed by the caller)
+__global__ __launch_bounds__(256) void at_absmax3_kernel(const float *__restrict__ q, const float *__restrict__ k,
+                                                         const float *__restrict__ v, long q_bs, long k_bs, long v_bs,
+                                                         long q_span, long kv_span, int B, unsigned *__restrict__ out)
+{
+    const int which = blockIdx.y;
+    const float *p = which == 0 ? q : which == 1 ? k : v;
+    const long bs = which == 0 ? q_bs : which == 1 ? k_bs : v_bs, span = which == 0 ? q_span : kv_span;
+    float m = 0.f;
+    const bool vec = (span & 3) == 0 && (bs & 3) == 0 && (((size_t)p) & 15) == 0;
+    for (int b = 0; b < B; b++) {
+        const float *pb = p + (size_t)b * bs;
+        if (vec) {
+            const long n4 = span / 4, step = (long)gridDim.x * 256;
+            long i = (long)blockIdx.x * 256 + threadIdx.x;
+            for (; i + 3 * step < n4; i += 4 * step) {                       // four loads in flight per thread
+                const f32x4 x0 = *(const f32x4 *)(pb + 4 * i), x1 = *(const f32x4 *)(pb + 4 * (i + step)),
+                            x2 = *(const f32x4 *)(pb + 4 * (i + 2 * step)), x3 = *(const f32x4 *)(pb + 4 * (i + 3 * step));
+#pragma unroll
+                for (int e = 0; e < 4; e++) m = fmaxf(fmaxf(m, fmaxf(fabsf(x0[e]), fabsf(x1[e]))), fmaxf(fabsf(x2[e]), fabsf(x3[e])));
+            }
+            for (; i < n4; i += step) {
+                const f32x4 x = *(const f32x4 *)(pb + 4 * i);
+                m = fmaxf(fmaxf(m, fmaxf(fabsf(x[0]), fabsf(x[1]))), fmaxf(fabsf(x[2]), fabsf(x[3])));
+            }
+        } else {
+            for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < span; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(pb[i]));
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+    __shared__ float wmax[4];                        // ONE atomic per workgroup: thousands of atomics on three words serialise
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out + which, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+}
+
+static int l3d_attention_absmax3(const float *q, const float *k, const float *v, long q_bs, long k_bs, long v_bs, long q_span, long kv_span,
+                                 int B, unsigned *amax, hipStream_t st)
+{
+    if (hipMemsetAsync(amax, 0, 16, st) != hipSuccess) return L3D_ERR_LAUNCH;
+    hipLaunchKernelGGL(at_absmax3_kernel, dim3(512, 3), dim3(256), 0, st, q, k, v, q_bs, k_bs, v_bs, q_span, kv_span, B, amax);
+    return l3d_check_launch();
+}
 
 // workspace: 16 bytes of device memory (the three maxima; maxima_ready != 0: already there, e.g. from
 // l3d_pointwise_conv_f16_absmax); ctx [B, H D, N] fp32 and / or ctx_img = the context as an fp16 activation image

@@ -676,51 +676,48 @@ def check_range(device=None, sync=False):
                                 "fp32 exponent range) and run again.")
 
 
-# EdgeConv kernel choice: "f16" / "split" / "chained" are the register-chained kernels in the three arithmetics above
-# (k <= 20); "lds" = the LDS-staged fp32-MFMA kernel (mlp.hip, any k <= 32).  None: by gemm_arith().
+# EdgeConv kernel choice: "f16" (f16x2, two weight planes, edgeconv_f16b.hip) and "split" (bf16x3, edgeconv_split.hip) are the
+# register-chained kernels (k <= 20, DGCNN's widths); "lds" = the LDS-staged fp32-MFMA kernel (mlp.hip: any k <= 32, any widths,
+# plain fp32 arithmetic).  None: by gemm_arith().  One kernel per arithmetic: the three-plane f16 kernel and the register-chained
+# fp32 kernel of rounds 1-2 live under tools/experiments/ with the notes on why they were superseded.
 EDGECONV_KERNEL = None
-
-
-# f16x2 EdgeConv kernel: True = the two-plane kernel (edgeconv_f16b.hip: H, M weight planes, unscaled residual, conversion-only
-# split) whenever the packed block allows it; False = the three-plane kernel (edgeconv_f16.hip)
-EDGECONV_F16_TWO_PLANE = True
 
 
 def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256), kernel=None, planes=False, v2=False, unscaled=False):
     """xyz [B,N,3], idx int64 [B,N,k] -> pooled [B,N,sum(widths)] (channel-last).  planes=True (f16 kernel only): an
-    fp16 activation image of the pooled values instead (uint8 tensor), the x operand of pointwise_conv_f16.
-    v2: the packed block's two-plane copy is usable (EdgeConvParams.v2_ok) -> the f16 kernel is the two-plane one."""
-    v2 = bool(v2) and EDGECONV_F16_TWO_PLANE
-    if unscaled and not (planes and v2):
-        raise ValueError("an image with an unscaled residual plane is written by the two-plane f16 kernel only (planes=True, v2=True)")
+    fp16 activation image of the pooled values instead (uint8 tensor), the x operand of pointwise_conv_f16; unscaled: with an
+    unscaled residual plane (for the two-plane conv kernel).
+    v2: the packed block's two-plane copy is usable (EdgeConvParams.v2_ok) -- what the f16 kernel runs on; without it "f16" falls
+    back to the bf16x3 kernel (full fp32 exponent range)."""
+    v2 = bool(v2)
     require_gpu(xyz_bn3, idx, packed)
     B, N, _ = xyz_bn3.shape
     k = idx.shape[2]
     if planes:
-        if not (k <= 20 and tuple(widths) == (64, 64, 128, 256)):
-            raise ValueError("planes output is produced by the f16 EdgeConv kernel only (k <= 20, 64/64/128/256)")
+        if not (v2 and k <= 20 and tuple(widths) == (64, 64, 128, 256)):
+            raise ValueError("planes output is produced by the f16 EdgeConv kernel only (usable two-plane block, k <= 20, 64/64/128/256)")
         out = torch.empty(lib().l3d_f16_act_bytes(B * N, sum(widths)), dtype=torch.uint8, device=xyz_bn3.device)
         args = (ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), ptr(out), 2 if unscaled else 1, ptr(range_flag(xyz_bn3.device)), stream_ptr())
-        fn16 = lib().l3d_edgeconv_forward_f16b if v2 else lib().l3d_edgeconv_forward_f16
         with stage("edgeconv_kernel"):                   # the launch alone: a timing span here holds no Python between its
-            rc = fn16(*args)                             # first event and the kernel (bench.py's live roofline timing)
-        check(rc, "l3d_edgeconv_forward_f16b" if v2 else "l3d_edgeconv_forward_f16")
+            rc = lib().l3d_edgeconv_forward_f16b(*args)  # first event and the kernel (bench.py's live roofline timing)
+        check(rc, "l3d_edgeconv_forward_f16b")
         return out
+    if unscaled:
+        raise ValueError("an unscaled residual plane belongs to the plane image (planes=True)")
     pooled = torch.empty((B, N, sum(widths)), dtype=torch.float32, device=xyz_bn3.device)
     if kernel is None:
-        kernel = EDGECONV_KERNEL or {"f16x2": "f16", "bf16x3": "split", "fp32": "chained"}[gemm_arith()]
-    if kernel not in ("f16", "split", "chained", "lds"):
+        kernel = EDGECONV_KERNEL or {"f16x2": "f16", "bf16x3": "split", "fp32": "lds"}[gemm_arith()]
+    if kernel not in ("f16", "split", "lds"):
         raise ValueError(f"unknown EdgeConv kernel {kernel!r}")
     if kernel != "lds" and (k > 20 or tuple(widths) != (64, 64, 128, 256)):
         kernel = "lds"
+    if kernel == "f16" and not v2:
+        kernel = "split"
     if kernel == "f16":
-        fn, name = (lib().l3d_edgeconv_forward_f16b, "l3d_edgeconv_forward_f16b") if v2 else (lib().l3d_edgeconv_forward_f16, "l3d_edgeconv_forward_f16")
+        fn, name = lib().l3d_edgeconv_forward_f16b, "l3d_edgeconv_forward_f16b"
         args = (ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), ptr(pooled), 0, ptr(range_flag(xyz_bn3.device)), stream_ptr())
     elif kernel == "split":
         fn, name = lib().l3d_edgeconv_forward_split, "l3d_edgeconv_forward_split"
-        args = (ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), ptr(pooled), stream_ptr())
-    elif kernel == "chained":
-        fn, name = lib().l3d_edgeconv_forward_chained, "l3d_edgeconv_forward_chained"
         args = (ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), ptr(pooled), stream_ptr())
     else:
         fn, name = lib().l3d_edgeconv_forward, "l3d_edgeconv_forward"

@@ -69,18 +69,18 @@ class DGCNN(torch.nn.Module):
         w5, s5, b5, w5_split, w5_f16 = self._conv5_folded()
         f16_route = (_fused.gemm_arith() == "f16x2" and _fused.EDGECONV_KERNEL in (None, "f16") and w5_f16 is not None
                      and _fused.f16_eligible(512, self.emb_dims, num_points))
+        packed = self._packed.get([self.conv1, self.conv2, self.conv3, self.conv4],
+                                  [self.bn1, self.bn2, self.bn3, self.bn4], input_data.device)
+        f16_route = f16_route and self._packed.v2_ok       # plane exponents that cannot be chained: the bf16x3 kernels take the call
         xyz = _as_bn3(input_data)                                   # [B,N,3] (no copy for "bnc")
         with _fused.stage("knn"):
             idx = knn(input_data, k=20)                             # dgcnn.py:32 (k=20 default)
-        packed = self._packed.get([self.conv1, self.conv2, self.conv3, self.conv4],
-                                  [self.bn1, self.bn2, self.bn3, self.bn4], xyz.device)
         if f16_route:
             # f16x2 route: the EdgeConv kernel hands conv5 its input already split into fp16 planes (no fp32 pooled
             # tensor, no split pass); the EdgeConv kernel watches the fp16 range (_fused.run_guarded reads its verdict)
-            v2 = self._packed.v2_ok and _fused.EDGECONV_F16_TWO_PLANE
-            two_plane = v2 and not _pooled and self.emb_dims % 256 == 0 and num_points % 256 == 0   # conv5 on two weight planes too
+            two_plane = not _pooled and self.emb_dims % 256 == 0 and num_points % 256 == 0   # conv5 on two weight planes too
             with _fused.stage("edgeconv"):
-                pooled_img = _fused.edgeconv_forward(xyz, idx, packed, planes=True, v2=v2, unscaled=two_plane)   # dgcnn.py:34-46
+                pooled_img = _fused.edgeconv_forward(xyz, idx, packed, planes=True, v2=True, unscaled=two_plane)   # dgcnn.py:34-46
             with _fused.stage("conv5"):
                 if _pooled:
                     return _fused.pointwise_conv_f16_pool(pooled_img, batch_size, num_points, w5_f16, 512, self.emb_dims,

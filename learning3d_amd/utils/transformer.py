@@ -18,7 +18,6 @@ import torch.nn.functional as F
 FLASH_ATTENTION = True      # l3d_attention_forward for d_k in {32, 64, 128}; False: torch matmul + softmax + matmul
 DEFER_LN_VALUES = True      # sublayer norms write only their fp16 plane image; fp32 values on demand (_ln_values)
 PROJECTION_MAXIMA = True    # the f16x2 q|k|v projections report max|q|, |k|, |v| from their epilogues (False: a pass over q, k, v)
-ATTENTION_F16B = True       # f16x2 attention on the restructured kernel (attention_f16b.hip); False: attention_f16.hip
 # autograd live: the nn.Linear layers of the torch route on the HIP conv / dgrad / wgrad kernels (_train.linear_act).  Correct and
 # tested, but OFF: a DCP training step (B 8, N 1024, emb 512) takes 25.6 ms with it against 20.4 ms on rocBLAS -- the layers are
 # [rows, C] x [C, C'] with rows in the last axis' place, and the two transposed copies per layer and direction cost more than the
@@ -30,7 +29,7 @@ _ATT_WS = {}
 
 
 def _attention_workspace(device):
-    """16 bytes per device for l3d_attention_forward_f16's operand maxima (written and read on the launch stream)."""
+    """16 bytes per device for l3d_attention_forward_f16b's operand maxima (written and read on the launch stream)."""
     key = str(device)
     ws = _ATT_WS.get(key)
     if ws is None:
@@ -280,28 +279,17 @@ class MultiHeadedAttention(nn.Module):
                     # both GEMMs as f16x2 (operand scales from the tensors' maxima); the context leaves the kernel as the
                     # fp16 plane image of the f16x2 conv kernel, so the output projection needs no split pass either
                     img = torch.empty(lib().l3d_f16_act_bytes(nb * n_q, C_), dtype=torch.uint8, device=q.device)
-                    if ATTENTION_F16B:
-                        check(lib().l3d_attention_forward_f16b(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
-                                                               q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),
-                                                               ptr(ws), int(bool(have_max)), None, ptr(img), stream_ptr()),
-                              "l3d_attention_forward_f16b")
-                    else:
-                        att = lib().l3d_attention_forward_f16_maxima if have_max else lib().l3d_attention_forward_f16
-                        check(att(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
-                                  q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),
-                                  ptr(ws), None, ptr(img), stream_ptr()), "l3d_attention_forward_f16")
+                    check(lib().l3d_attention_forward_f16b(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
+                                                           q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),
+                                                           ptr(ws), int(bool(have_max)), None, ptr(img), stream_ptr()),
+                          "l3d_attention_forward_f16b")
                     return _linear_cf(out_lin, None, True, planes=(img, nb, n_q)).transpose(1, 2)     # [B,N,C] view
                 ctx = torch.empty((nb, C_, n_q), dtype=torch.float32, device=q.device)
-                if _fused.gemm_arith() == "f16x2" and ATTENTION_F16B:
+                if _fused.gemm_arith() == "f16x2":
                     check(lib().l3d_attention_forward_f16b(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
                                                            q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),
                                                            ptr(ws), int(bool(have_max)), ptr(ctx), None, stream_ptr()),
                           "l3d_attention_forward_f16b")
-                elif _fused.gemm_arith() == "f16x2":
-                    att = lib().l3d_attention_forward_f16_maxima if have_max else lib().l3d_attention_forward_f16
-                    check(att(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
-                              q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),
-                              ptr(ws), ptr(ctx), None, stream_ptr()), "l3d_attention_forward_f16")
                 else:
                     check(lib().l3d_attention_forward_strided(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
                                                               q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),
@@ -442,7 +430,7 @@ class Transformer(nn.Module):
     def _cf_pass_ok(self, src, tgt):
         from ..models import _fused
         C = self.emb_dims
-        if not (CHANNEL_FIRST_PASS and FLASH_ATTENTION and ATTENTION_F16B and PROJECTION_MAXIMA and _fused.gemm_arith() == "f16x2"):
+        if not (CHANNEL_FIRST_PASS and FLASH_ATTENTION and PROJECTION_MAXIMA and _fused.gemm_arith() == "f16x2"):
             return False
         if not (src.is_cuda and tgt.is_cuda and src.dtype == torch.float32 and tgt.dtype == torch.float32 and src.dim() == 3
                 and tgt.dim() == 3 and src.size(1) == C and tgt.size(1) == C and src.size(0) == tgt.size(0)):

@@ -559,7 +559,7 @@ def test_dgcnn_full_size_vs_oracle_port():
 
 def test_edgeconv_all_kernels_agree_and_ragged():
     """LDS-staged (mlp.hip), register-chained fp32-MFMA (edgeconv2.hip), register-chained bf16x3
-    (edgeconv_split.hip) and register-chained f16x2 (edgeconv_f16.hip) EdgeConv kernels against a torch fp64
+    (edgeconv_split.hip) and register-chained f16x2 (edgeconv_f16b.hip) EdgeConv kernels against a torch fp64
     evaluation, including N not a multiple of 16 and k < 20.  The matrix-core kernels (bf16x3: six bf16 products per
     fp32 product; f16x2: three fp16 products) must be as close to fp64 as the fp32-MFMA kernels are: max error
     <= 2x, rms error <= 1.5x the fp32-MFMA kernel's own.  Also with activations scaled down 1000x / up 100x through
@@ -579,15 +579,16 @@ def test_edgeconv_all_kernels_agree_and_ragged():
             idx = U.knn(x.permute(0, 2, 1), k)
             packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
             a = _fused.edgeconv_forward(x, idx, packed, kernel="lds")
-            c = _fused.edgeconv_forward(x, idx, packed, kernel="chained")
+            c = a                                           # the fp32-MFMA kernel: the yardstick of the error bars below
             sp = _fused.edgeconv_forward(x, idx, packed, kernel="split")
-            f16 = _fused.edgeconv_forward(x, idx, packed, kernel="f16")
-            # the two-plane kernel (edgeconv_f16b.hip) where its block is usable: always for BatchNorm magnitudes that say what
-            # the activations are (gain 1); with bn1 scaled down 1000x the chained plane exponents would leave a layer below
-            # 2^4, the packer marks the block unusable and the host runs the three-plane kernel (gain 30 still fits)
+            # the f16x2 kernel (edgeconv_f16b.hip) where its block is usable: always for BatchNorm magnitudes that say what the
+            # activations are (gain 1); with bn1 scaled down 1000x the chained plane exponents would leave a layer below 2^4,
+            # the packer marks the block unusable and "f16" is served by the bf16x3 kernel (gain 30 still fits)
             assert net._packed.v2_ok or gain != 1.0
             assert not (net._packed.v2_ok and gain == 1e-3), "plane exponents 10 binades apart cannot be chained"
             f16b = _fused.edgeconv_forward(x, idx, packed, kernel="f16", v2=net._packed.v2_ok)
+            if not net._packed.v2_ok:
+                assert torch.equal(f16b, sp)                # the fallback IS the bf16x3 kernel
             _fused.check_range(x.device, sync=True)
             # fp64 torch evaluation of dgcnn.py:32-46 on the same graph
             nb = torch.gather(x.unsqueeze(1).expand(B, N, N, 3), 2, idx.unsqueeze(-1).expand(B, N, k, 3))
@@ -600,12 +601,10 @@ def test_edgeconv_all_kernels_agree_and_ragged():
             want = torch.cat(outs, dim=1).permute(0, 2, 1).float().cpu().numpy()
             want64 = torch.cat(outs, dim=1).permute(0, 2, 1).cpu().numpy()
         np.testing.assert_allclose(a.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(c.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(sp.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(f16.cpu().numpy(), want, rtol=1e-4, atol=1e-5 * max(1.0, gain))
         np.testing.assert_allclose(f16b.cpu().numpy(), want, rtol=1e-4, atol=1e-5 * max(1.0, gain))
         e_c = np.abs(c.cpu().numpy() - want64)
-        for name, got in (("bf16x3", sp), ("f16x2", f16), ("f16x2-two-plane", f16b)):
+        for name, got in (("bf16x3", sp), ("f16x2", f16b)):
             e_s = np.abs(got.cpu().numpy() - want64)
             print(f"edgeconv {name} B={B} N={N} k={k} gain={gain}: max err {e_s.max():.3e} ({e_s.max() / e_c.max():.2f}x fp32-MFMA), "
                   f"rms {np.sqrt((e_s ** 2).mean()):.3e} ({np.sqrt((e_s ** 2).mean()) / np.sqrt((e_c ** 2).mean()):.2f}x)")
@@ -630,7 +629,8 @@ def test_edgeconv_f16_planes_output_equals_pooled():
     with torch.no_grad():
         idx = U.knn(x.permute(0, 2, 1), k)
         packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
-        for v2 in (False, True):                        # three-plane kernel, two-plane kernel (edgeconv_f16b.hip)
+        assert net._packed.v2_ok
+        for v2 in (True,):
             pooled = _fused.edgeconv_forward(x, idx, packed, kernel="f16", v2=v2)
             img = _fused.edgeconv_forward(x, idx, packed, planes=True, v2=v2)
             _fused.check_range(sync=True)
@@ -663,7 +663,6 @@ def test_edgeconv_f16_planes_output_equals_pooled():
         e3, e2 = (y1.double() - ref).abs(), (y3.double() - ref).abs()
         assert float(e2.max()) <= 1.5 * float(e3.max()) + 1e-9 and float((e2 ** 2).mean().sqrt()) <= 1.25 * float((e3 ** 2).mean().sqrt()) + 1e-12
         # and the model's own forward takes this route (the two-plane kernels by default)
-        assert net._packed.v2_ok and _fused.EDGECONV_F16_TWO_PLANE
         out = net(x)
         np.testing.assert_allclose(out.cpu().numpy(), y3.cpu().numpy(), rtol=0, atol=0)
 
@@ -679,10 +678,12 @@ def test_edgeconv_f16_range_flag():
     with torch.no_grad():
         idx = U.knn(x.permute(0, 2, 1), 20)
         get = lambda: net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
-        _fused.edgeconv_forward(x, idx, get(), kernel="f16")
+        _fused.edgeconv_forward(x, idx, get(), kernel="f16", v2=True)
         _fused.check_range(x.device, sync=True)                         # fine
         net.bn2.weight.fill_(1e6)                                        # layer-2 outputs ~1e5: beyond fp16
-        _fused.edgeconv_forward(x, idx, get(), kernel="f16")
+        packed_big = get()
+        assert net._packed.v2_ok, "a scaled BatchNorm weight moves the plane exponents, the block stays usable"
+        _fused.edgeconv_forward(x, idx, packed_big, kernel="f16", v2=True)
         with pytest.raises(_fused.L3DRangeError):
             _fused.check_range(x.device, sync=True)
         _fused.check_range(x.device, sync=True)                         # the flag was cleared by the raise
@@ -1048,17 +1049,10 @@ def test_flash_attention_vs_fp64():
         check(lib().l3d_attention_forward(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, float(1 / np.sqrt(D)), ptr(out),
                                           stream_ptr()), "l3d_attention_forward")
         np.testing.assert_allclose(out.cpu().numpy().reshape(B, H, D, N), want, rtol=1e-5, atol=2e-6)
-        # the f16x2 kernel: same bar, and its error against fp64 within 2x (max) / 1.5x (rms) of the bf16x3 kernel's own
+        # the f16x2 kernel (attention_f16b.hip): same bar, its error against fp64 within 2x (max) / 1.5x (rms) of the bf16x3
+        # kernel's own; fp32 context and the plane image of it
         ws = torch.zeros(4, dtype=torch.int32, device=qd.device)
-        out16 = torch.empty_like(qd)
-        check(lib().l3d_attention_forward_f16(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, H * D * N, H * D * M, H * D * M,
-                                              float(1 / np.sqrt(D)), ptr(ws), ptr(out16), None, stream_ptr()), "l3d_attention_forward_f16")
-        got16 = out16.cpu().numpy().reshape(B, H, D, N)
-        np.testing.assert_allclose(got16, want, rtol=1e-5, atol=2e-6)
-        e3, e16 = out.cpu().numpy().reshape(B, H, D, N) - want, got16 - want
-        assert np.abs(e16).max() <= 2.0 * np.abs(e3).max() + 1e-9 and np.sqrt((e16 ** 2).mean()) <= 1.5 * np.sqrt((e3 ** 2).mean()) + 1e-10
-        # the restructured kernel (attention_f16b.hip): same bars; fp32 context and the plane image of it
-        ws.zero_()
+        e3 = out.cpu().numpy().reshape(B, H, D, N) - want
         outb = torch.empty_like(qd)
         imgb = torch.empty(lib().l3d_f16_act_bytes(B * N, H * D), dtype=torch.uint8, device=qd.device)
         check(lib().l3d_attention_forward_f16b(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, H * D * N, H * D * M, H * D * M,
@@ -1088,10 +1082,6 @@ def test_flash_attention_vs_fp64():
         want = np.einsum("bhdm,bhnm->bhdn", v.astype(np.float64), s)
         qd, kd, vd = dev(q.reshape(B, H * D, N)), dev(k.reshape(B, H * D, M)), dev(v.reshape(B, H * D, M))
         ws = torch.zeros(4, dtype=torch.int32, device=qd.device)
-        out16 = torch.empty_like(qd)
-        check(lib().l3d_attention_forward_f16(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, H * D * N, H * D * M, H * D * M,
-                                              float(sc), ptr(ws), ptr(out16), None, stream_ptr()), "l3d_attention_forward_f16")
-        np.testing.assert_allclose(out16.cpu().numpy().reshape(B, H, D, N), want, rtol=2e-5, atol=2e-6 * sv)
         outb = torch.empty_like(qd)
         check(lib().l3d_attention_forward_f16b(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, H * D * N, H * D * M, H * D * M,
                                                float(sc), ptr(ws), 0, ptr(outb), None, stream_ptr()), "l3d_attention_forward_f16b")
@@ -1828,7 +1818,7 @@ def test_layernorm_planes_matches_layernorm_and_feeds_conv_f16():
 
 @pytest.mark.gpu
 def test_attention_f16_context_planes_feed_conv_f16():
-    """l3d_attention_forward_f16 can hand its context to the output projection as an fp16 plane image (scale from max|v|):
+    """l3d_attention_forward_f16b can hand its context to the output projection as an fp16 plane image (scale from max|v|):
     the f16x2 conv on that image must equal the projection of the fp32 context to fp32-level accuracy."""
     from learning3d_amd._lib import check, lib, ptr, stream_ptr
     from learning3d_amd.models import _fused
@@ -1840,8 +1830,8 @@ def test_attention_f16_context_planes_feed_conv_f16():
         ws = torch.zeros(4, dtype=torch.int32, device="cuda")
         ctx = torch.empty((B, C, N), dtype=torch.float32, device="cuda")
         img = torch.empty(lib().l3d_f16_act_bytes(B * N, C), dtype=torch.uint8, device="cuda")
-        check(lib().l3d_attention_forward_f16(ptr(q), ptr(k), ptr(v), B, H, D, N, M, C * N, C * M, C * M, float(1 / np.sqrt(D)),
-                                              ptr(ws), ptr(ctx), ptr(img), stream_ptr()), "att")
+        check(lib().l3d_attention_forward_f16b(ptr(q), ptr(k), ptr(v), B, H, D, N, M, C * N, C * M, C * M, float(1 / np.sqrt(D)),
+                                               ptr(ws), 0, ptr(ctx), ptr(img), stream_ptr()), "att")
         w = dev((rng.standard_normal((256, C)) / C ** 0.5).astype(np.float32))
         got = _fused.pointwise_conv_f16(img, B, N, _fused.split_weights_f16(w), C, 256).cpu().numpy()
         want = np.einsum("oc,bcn->bon", w.cpu().numpy().astype(np.float64), ctx.cpu().numpy().astype(np.float64))
@@ -1948,8 +1938,8 @@ def test_pcn_encoder_f16_chain_matches_reference_order_path():
 
 def test_conv_f16_absmax_feeds_attention_maxima():
     """The fused q|k|v projection reports max|q|, |k|, |v| from its own epilogue (l3d_pointwise_conv_f16 with amax_out) and
-    l3d_attention_forward_f16_maxima takes them instead of a pass over the three tensors: the maxima equal torch's, and the
-    attention output is bit-identical to the entry point that measures them itself (utils/transformer.py:183-189)."""
+    l3d_attention_forward_f16b (maxima_ready = 1) takes them instead of a pass over the three tensors: the maxima equal torch's,
+    and the attention output is bit-identical to the call that measures them itself (utils/transformer.py:183-189)."""
     from learning3d_amd._lib import check, lib, ptr, stream_ptr
     from learning3d_amd.models import _fused
     rng = np.random.default_rng(41)
@@ -1966,10 +1956,10 @@ def test_conv_f16_absmax_feeds_attention_maxima():
     assert np.array_equal(got, want), (got, want)
     q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
     outs = []
-    for fn, wsp in ((lib().l3d_attention_forward_f16_maxima, ws), (lib().l3d_attention_forward_f16, torch.zeros(4, dtype=torch.int32, device="cuda"))):
+    for ready, wsp in ((1, ws), (0, torch.zeros(4, dtype=torch.int32, device="cuda"))):
         ctx = torch.empty((B, C, N), dtype=torch.float32, device="cuda")
-        check(fn(ptr(q), ptr(k), ptr(v), B, H, C // H, N, N, q.stride(0), k.stride(0), v.stride(0), 1.0 / (C // H) ** 0.5,
-                 ptr(wsp), ptr(ctx), None, stream_ptr()), "attention")
+        check(lib().l3d_attention_forward_f16b(ptr(q), ptr(k), ptr(v), B, H, C // H, N, N, q.stride(0), k.stride(0), v.stride(0),
+                                               1.0 / (C // H) ** 0.5, ptr(wsp), ready, ptr(ctx), None, stream_ptr()), "attention")
         outs.append(ctx)
     assert torch.equal(outs[0], outs[1])
     _fused.check_range(sync=True)

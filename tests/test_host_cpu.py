@@ -58,7 +58,6 @@ def test_argument_validation_without_gpu():
     assert l.l3d_pointwise_conv_f16(p, p, None, None, 0, 1, 128, 256, 256, 0, 0, p, None, None, None, None, 0, p, 100, None) == -2        # group size % 256
     assert l.l3d_pointwise_conv_f16(p, p, None, None, 0, 1, 128, 256, 256, 0, 0, p, None, p, p, None, 0, None, 0, None) == -2          # fp32 rows AND an image
     assert l.l3d_pointwise_conv_f16(p, p, None, None, 0, 1, 128, 256, 256, 0, 2, p, None, None, None, None, 0, None, 0, None) == -1     # unknown flag
-    assert l.l3d_attention_forward_f16_maxima(None, None, None, 1, 4, 128, 256, 256, 0, 0, 0, 0.1, None, None, None, None) == -1
     assert l.l3d_layernorm_planes(p, p, p, 1e-6, 4, 520, None, p, None) == -2                                      # C > 512
     # round-3 entry points
     assert l.l3d_knn_variant(1, 8, 8, 4, p, p, p, p, 7, None) == -1                                                # no such variant
@@ -354,7 +353,6 @@ def test_hot_kernels_compile_without_scratch():
            "_Z15conv_f16_kernelILb1ELb0ELb0ELi3ELb0EE": 224,    # narrow tile
            "_Z15conv_f16_kernelILb0ELb0ELb0ELi3ELb1EE": 224,    # residual epilogue (the pointer network's sublayers)
            "_Z26layernorm_planes_cf_kernelILi64ELi8EE": 128,
-           "_Z19edgeconv_f16_kernelILi5ELb1EE": 512,
            "_Z20edgeconv_f16b_kernelILi5ELb1EE": 512,       # the two-plane, persistent kernel of the benchmark step
            "_Z20edgeconv_f16b_kernelILi5ELb0EE": 512,
            "_Z15knn_mfma_kernelILi8EE": 256,

@@ -13,13 +13,6 @@ for _ in range(30): fn()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 30
 print(f"attention B={B} H={H} D={D} N={N}: {dt*1e6:.1f} us  {4.0*B*H*N*N*D/dt/1e12:.1f} TFLOP/s fp32-equiv")
 ws = torch.zeros(4, dtype=torch.int32, device="cuda")
-fn16 = lambda: check(lib().l3d_attention_forward_f16(ptr(q), ptr(k), ptr(v), B, H, D, N, N, H * D * N, H * D * N, H * D * N, 1.0 / D ** 0.5, ptr(ws), ptr(ctx), None, stream_ptr()), "att16")
-for _ in range(10): fn16()
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(30): fn16()
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 30
-print(f"attention f16x2 (incl. the absmax pass) : {dt*1e6:.1f} us  {4.0*B*H*N*N*D/dt/1e12:.1f} TFLOP/s fp32-equiv")
-
 img = torch.empty(lib().l3d_f16_act_bytes(B * N, H * D), dtype=torch.uint8, device="cuda")
 for name, kw in (("f16x2 restructured (attention_f16b), fp32 ctx, incl. absmax", dict(mr=0, c=ctx, im=None)),
                  ("f16x2 restructured, maxima ready, plane image out (DCP's call)", dict(mr=1, c=None, im=img))):
@@ -30,9 +23,3 @@ for name, kw in (("f16x2 restructured (attention_f16b), fp32 ctx, incl. absmax",
     for _ in range(30): fnb()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 30
     print(f"attention {name}: {dt*1e6:.1f} us  {4.0*B*H*N*N*D/dt/1e12:.1f} TFLOP/s fp32-equiv")
-fnm = lambda: check(lib().l3d_attention_forward_f16_maxima(ptr(q), ptr(k), ptr(v), B, H, D, N, N, H * D * N, H * D * N, H * D * N, 1.0 / D ** 0.5, ptr(ws), None, ptr(img), stream_ptr()), "att16m")
-for _ in range(10): fnm()
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(30): fnm()
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 30
-print(f"attention f16x2 (attention_f16), maxima ready, plane image out: {dt*1e6:.1f} us")

@@ -20,9 +20,9 @@ def main():
     with torch.no_grad():
         idx = U.knn(x.permute(0, 2, 1), k)
         packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
-        ref = _fused.edgeconv_forward(x, idx, packed, kernel="chained")
+        ref = _fused.edgeconv_forward(x, idx, packed, kernel="lds")
         flop = B * N * k * 2 * (6 * 64 + 64 * 64 + 64 * 128 + 128 * 256)
-        for kern in sys.argv[1:] or ("f16b", "f16b-planes", "f16", "f16-planes", "split", "chained"):
+        for kern in sys.argv[1:] or ("f16b", "f16b-planes", "split", "lds"):
             name, planes = (kern[:-7], True) if kern.endswith("-planes") else (kern, False)
             kw = dict(kernel="f16", v2=True) if name == "f16b" else dict(kernel=name)
             if planes:

@@ -14,7 +14,7 @@ with torch.no_grad():
     idx = U.knn(xt, 20)
     packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
     w5, s5, b5, w5s, w5f = net._conv5_folded()
-    img = _fused.edgeconv_forward(x, idx, packed, planes=True)
+    img = _fused.edgeconv_forward(x, idx, packed, planes=True, v2=True)
     big = torch.empty(256 * 1024 * 1024 // 4, device="cuda")
     pre = {"nothing": lambda: None, "knn": lambda: U.knn(xt, 20), "conv5": lambda: _fused.pointwise_conv_f16(img, 32, 1024, w5f, 512, 1024, s5, b5, relu=True),
            "chamfer": lambda: cd(a, b), "1 GB memset": lambda: big.zero_(),
@@ -25,7 +25,7 @@ with torch.no_grad():
             fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             timer = _fused.StageTimer(only=("edgeconv_kernel",)); _fused.TIMER = timer
-            _fused.edgeconv_forward(x, idx, packed, planes=True)
+            _fused.edgeconv_forward(x, idx, packed, planes=True, v2=True)
             _fused.TIMER = None
             torch.cuda.synchronize()
             ts.append(list(timer.mean_ms().values())[0] * 1e3)

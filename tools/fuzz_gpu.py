@@ -27,7 +27,7 @@ with torch.no_grad():
         packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
         a = _fused.edgeconv_forward(x, idx, packed, kernel="lds").cpu().numpy()
         s = _fused.edgeconv_forward(x, idx, packed, kernel="split").cpu().numpy()
-        c = _fused.edgeconv_forward(x, idx, packed, kernel="chained").cpu().numpy()
+        c = _fused.edgeconv_forward(x, idx, packed, kernel="lds").cpu().numpy()
         rec("edgeconv split vs lds", s, a, 1e-5, 2e-6); rec("edgeconv chained vs lds", c, a, 1e-5, 2e-6)
     for it in range(12):                                            # 1x1 conv: bf16x3 vs fp32-MFMA vs fp64
         B = int(rng.integers(1, 4)); Cin = 16 * int(rng.integers(2, 40)); Cout = 256 * int(rng.integers(1, 4)); N = 128 * int(rng.integers(1, 9))
@@ -149,7 +149,7 @@ with torch.no_grad():
         x = dev(rng.uniform(0, 1, (B, N, 3)).astype(np.float32))
         idx = U.knn(x.permute(0, 2, 1), k)
         packed = net1k._packed.get([net1k.conv1, net1k.conv2, net1k.conv3, net1k.conv4], [net1k.bn1, net1k.bn2, net1k.bn3, net1k.bn4], x.device)
-        ref = _fused.edgeconv_forward(x, idx, packed, kernel="chained").cpu().numpy()
+        ref = _fused.edgeconv_forward(x, idx, packed, kernel="lds").cpu().numpy()
         got = _fused.edgeconv_forward(x, idx, packed, kernel="f16", v2=net1k._packed.v2_ok).cpu().numpy()
         rec("edgeconv f16b vs fp32 MFMA", got, ref, 1e-5, 2e-5 * float(np.abs(ref).max()))
         i0 = torch.empty((B, N, k), dtype=torch.int64, device="cuda"); i1_ = torch.empty_like(i0)

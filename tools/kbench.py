@@ -80,17 +80,17 @@ def main():
         packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
         t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, kernel="lds"))
         res["edgeconv_lds_c2"] = (t, B * N * k * 2 * 45440 / t / 1e6, "TFLOP/s")
-        t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, kernel="chained"))
+        t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, kernel="lds"))
         res["edgeconv_chained_c2"] = (t, B * N * k * 2 * 45440 / t / 1e6, "TFLOP/s")
         t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, kernel="split"))
         res["edgeconv_bf16x3_c2"] = (t, B * N * k * 2 * 45440 / t / 1e6, "TFLOP/s(fp32-equiv)")
         pooled = _fused.edgeconv_forward(x, idx, packed)
         w5, s5, b5, w5s, w5f = net._conv5_folded()
-        t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, kernel="f16"))
+        t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, kernel="f16", v2=True))
         res["edgeconv_f16x2_c2"] = (t, B * N * k * 2 * 45440 / t / 1e6, "TFLOP/s(fp32-equiv)")
-        t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, kernel="f16", planes=True))
+        t = timeit(lambda: _fused.edgeconv_forward(x, idx, packed, planes=True, v2=True))
         res["edgeconv_f16x2_planes_c2"] = (t, B * N * k * 2 * 45440 / t / 1e6, "TFLOP/s(fp32-equiv)")
-        img = _fused.edgeconv_forward(x, idx, packed, kernel="f16", planes=True)
+        img = _fused.edgeconv_forward(x, idx, packed, planes=True, v2=True)
         t = timeit(lambda: _fused.pointwise_conv_f16(img, B, N, w5f, 512, 1024, s5, b5, relu=True))
         res["conv5_f16x2_c2"] = (t, B * N * 2 * 512 * 1024 / t / 1e6, "TFLOP/s(fp32-equiv)")
         t = timeit(lambda: _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True, split=False))

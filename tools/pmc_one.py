@@ -13,9 +13,9 @@ net = DGCNN(emb_dims=1024).cuda().eval()
 with torch.no_grad():
     idx = U.knn(x.permute(0, 2, 1), 20)
     packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
-    pooled = _fused.edgeconv_forward(x, idx, packed)
+    pooled = _fused.edgeconv_forward(x, idx, packed, kernel="split")
     w5, s5, b5, w5s, w5f = net._conv5_folded()
-    img = _fused.edgeconv_forward(x, idx, packed, kernel="f16", planes=True)
+    img = _fused.edgeconv_forward(x, idx, packed, planes=True, v2=True)
     img2 = _fused.edgeconv_forward(x, idx, packed, planes=True, v2=True, unscaled=True)
     torch.cuda.synchronize()
     if what == "group_c5":                       # config 5's grouping gather (bench.py --workload c5: the HBM-bound op)
@@ -32,9 +32,8 @@ with torch.no_grad():
     for _ in range(5):
         if what == "knn": U.knn(x.permute(0, 2, 1), 20)
         elif what == "chamfer": ChamferDistance()(a, b)
-        elif what == "edgeconv": _fused.edgeconv_forward(x, idx, packed, kernel="chained")            # fp32 MFMA
+        elif what == "edgeconv": _fused.edgeconv_forward(x, idx, packed, kernel="lds")            # fp32 MFMA
         elif what == "edgeconv_split": _fused.edgeconv_forward(x, idx, packed, kernel="split")        # bf16x3
-        elif what == "edgeconv_f16": _fused.edgeconv_forward(x, idx, packed, planes=True)                 # f16x2 three-plane kernel, plane image out
         elif what == "edgeconv_f16b": _fused.edgeconv_forward(x, idx, packed, planes=True, v2=True)      # f16x2 two-plane persistent kernel (the step's)
         elif what == "conv5_f16": _fused.pointwise_conv_f16(img, 32, 1024, w5f, 512, 1024, s5, b5, relu=True)
         elif what == "conv5_f16_2p": _fused.pointwise_conv_f16(img2, 32, 1024, w5f, 512, 1024, s5, b5, relu=True, unscaled=True)   # the step's conv5

@@ -13,7 +13,7 @@ xt = x.permute(0, 2, 1)
 packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)
 w5, s5, b5, w5s, w5f = net._conv5_folded()
 knn = lambda st: st.__setitem__("idx", U.knn(xt, 20))
-ec = lambda st: st.__setitem__("img", _fused.edgeconv_forward(x, st["idx"], packed, planes=True))
+ec = lambda st: st.__setitem__("img", _fused.edgeconv_forward(x, st["idx"], packed, planes=True, v2=True))
 c5 = lambda st: st.__setitem__("feat", _fused.pointwise_conv_f16(st["img"], 32, 1024, w5f, 512, 1024, s5, b5, relu=True))
 ch = lambda st: st.__setitem__("d", cd(a, b))
 ls = lambda st: st.__setitem__("part", chamfer_loss_local(*st["d"]))
