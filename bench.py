@@ -36,7 +36,7 @@ MFMA_BF16_PEAK_TF = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA peak (2.
 FORK_DEFAULT = "none"             # see --fork
 PRECONDITION_STEPS = 150         # untimed, before the --warmup steps (~80 ms of GPU work)
 SPLIT_PRODUCTS = {"f16x2": 3, "bf16x3": 6}    # low-precision MFMA products per fp32 product
-VALU_PEAK_LANEOPS = 256 * 4 * 16 * 2.4e9     # 39.3 T lane-ops/s: 256 CUs x 4 SIMD16 x 2.4 GHz (an fma counts once)
+VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9     # 78.6 T lane-ops/s: 256 CUs x 4 SIMD-32 x 2.4 GHz, an fma counts once (= 157.3 TFLOP/s vector fp32; SURVEY.md 8(d)'s denominator)
 KNN_LANEOPS_PER_PAIR = 7         # 2 fma + 1 mul + 2 sub + compare/insert
 CHAMFER_LANEOPS_PER_PAIR = 8
 # algorithmic work per cloud (restated in DESIGN.md)
@@ -121,7 +121,7 @@ def edgeconv_roofline(ec_tf, ec_ms, arith):
     prods = SPLIT_PRODUCTS[arith]
     peak = MFMA_BF16_PEAK_TF / prods
     l1 = B_PER_GPU * NPTS * KNN * 2 * 6 * 64                       # layer 1 stays on the fp32 MFMA
-    name = "edgeconv_f16b_kernel<3,true>" if arith == "f16x2" else "edgeconv_split_kernel<5>"
+    name = "edgeconv_f16b_kernel<5,true>" if arith == "f16x2" else "edgeconv_split_kernel<5>"
     return {"kernel": name, "bound": "mfma", "achieved": ec_tf, "peak": peak,
             "unit": "TFLOP/s", "frac": ec_tf / peak, "traffic": pmc_traffic("edgeconv_f16b" if arith == "f16x2" else "edgeconv_split") or pmc_traffic("edgeconv_f16"),
             "traffic_source": pmc_source("edgeconv_f16b" if arith == "f16x2" else "edgeconv_split") or pmc_source("edgeconv_f16"),

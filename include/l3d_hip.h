@@ -53,10 +53,6 @@ int l3d_last_hip_error(void);
  *   xyz [B,N,3] fp32, idx [B,N,k] int64.   k <= min(N, L3D_KNN_MAX_K)
  * ------------------------------------------------------------------------------------------- */
 int l3d_knn_graph(const float *xyz, int B, int N, int k, int64_t *idx, l3d_stream_t stream);
-/* The same with the kernel named explicitly: variant 0 = by shape (what l3d_knn_graph does), 1 = the two-pass insertion
- * kernel (any N, k <= 200), 2 = ranking values on the fp32 matrix cores + selection by rank counting (k <= 24,
- * 256 <= N <= 2048; L3D_ERR_UNSUPPORTED otherwise).  Identical results (lowest index first under exact ties). */
-int l3d_knn_graph_variant(const float *xyz, int B, int N, int k, int64_t *idx, int variant, l3d_stream_t stream);
 
 /* Deterministic backward of the gather-type ops (replaces the fp32-atomicAdd scatters of
  * group_points_grad_kernel, group_points_gpu.cu:8-28; gather_points_grad, sampling_gpu.cu:37-52;
@@ -106,21 +102,9 @@ int l3d_graph_feature(const float *x, const int64_t *idx, int B, int N, int C, i
  * ------------------------------------------------------------------------------------------- */
 int l3d_chamfer_forward(const float *xyz1, const float *xyz2, int B, int N, int M, float *dist1,
                         float *dist2, int32_t *idx1, int32_t *idx2, l3d_stream_t stream);
-/* The same with the kernel choice as an ARGUMENT (results are bit-identical either way; tests compare them):
- * variant 0 = one (query, candidate) pair per instruction sequence, 1 = auto (what l3d_chamfer_forward does),
- * 2 = always the packed-fp32 kernel (two queries per lane, argmin per chunk of 8). */
-int l3d_chamfer_forward_variant(const float *xyz1, const float *xyz2, int B, int N, int M, float *dist1,
-                                float *dist2, int32_t *idx1, int32_t *idx2, int variant, l3d_stream_t stream);
 int l3d_chamfer_backward(const float *xyz1, const float *xyz2, int B, int N, int M,
                          const float *graddist1, const float *graddist2, const int32_t *idx1,
                          const int32_t *idx2, float *gradxyz1, float *gradxyz2, l3d_stream_t stream);
-/* The same with the kernel choice as an argument (bit-identical results: both add a point's terms in the order of
- * chamfer_distance.cpp:138-176): variant 0 = scan of the partner cloud's selections per point, 2 = selections sorted by
- * target in LDS, one binary search per point (N, M <= 32768, else L3D_ERR_UNSUPPORTED), 1 = auto (l3d_chamfer_backward). */
-int l3d_chamfer_backward_variant(const float *xyz1, const float *xyz2, int B, int N, int M,
-                                 const float *graddist1, const float *graddist2, const int32_t *idx1,
-                                 const int32_t *idx2, float *gradxyz1, float *gradxyz2, int variant,
-                                 l3d_stream_t stream);
 /* Loss tail of losses/chamfer_distance.py:38-40, kept on the device (no host sync per step):
  *   l3d_chamfer_partials: partial[0..3] = (sum sqrt(dist1), sum sqrt(dist2), #dist1, #dist2), fp64,
  *       for this rank's shard -- the 32 bytes the multi-GPU path all-gathers over RCCL;
@@ -129,10 +113,6 @@ int l3d_chamfer_backward_variant(const float *xyz1, const float *xyz2, int B, in
 int l3d_chamfer_partials(const float *dist1, const float *dist2, int B, int N, int M, double *partial,
                          l3d_stream_t stream);
 int l3d_chamfer_combine(const double *partials, int world, float *loss, l3d_stream_t stream);
-/* The loss tail of ONE rank in one launch: partial[4] exactly as l3d_chamfer_partials writes it, and
- * loss = (partial[0]/partial[2] + partial[1]/partial[3]) / 2 as l3d_chamfer_combine(partial, 1, loss) would. */
-int l3d_chamfer_loss_local(const float *dist1, const float *dist2, int B, int N, int M, double *partial, float *loss,
-                           l3d_stream_t stream);
 /* The same over up to 64 workgroups (the one-workgroup form is a chain of dependent load latencies: 12 us at B=32,
  * N=1024; this one ~4): per-workgroup fp64 partial sums in ws, added in workgroup order by the workgroup that finishes
  * last (deterministic; agrees with l3d_chamfer_loss_local to fp64 rounding of the sum order).  ws:
@@ -174,12 +154,6 @@ int l3d_furthest_point_sampling(int b, int n, int m, const float *points, float 
  *   ascending, lowest index first on ties; slots beyond m hold (+inf, 0). k <= 200. */
 int l3d_knn(int b, int n, int m, int k, const float *unknown, const float *known, float *dist2,
             int32_t *idx, l3d_stream_t stream);
-/* the same with the kernel named: variant 0 = automatic (k <= 4 and >= 65 536 queries: the four-slot kernel of knn_small.hip; otherwise the
- * wave-per-query selection kernel of knn_select.hip when k <= m <= 8192 and (k > 32 or m >= 1024), the lane-per-query kernels
- * of knn.hip for the rest), 1 = lane-per-query, 2 = selection kernel (L3D_ERR_UNSUPPORTED unless k <= m <= 8192), 3 = four-slot
- * kernel (k <= 4).  Results are identical; tests and tools use it. */
-int l3d_knn_variant(int b, int n, int m, int k, const float *unknown, const float *known, float *dist2,
-                    int32_t *idx, int variant, l3d_stream_t stream);
 /* three_nn_wrapper(b,n,m,unknown,known,dist2,idx)   K14 interpolate_gpu.cu:81-124 */
 int l3d_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
                  int32_t *idx, l3d_stream_t stream);
@@ -199,11 +173,8 @@ int l3d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out
  * torch-level primitives of utils/model_common_utils.py, fused (T4, T7, T8; int64 indices)
  * ------------------------------------------------------------------------------------------- */
 /* square_distance(src,dst) :19-38 -> dist [B,N,M] (expanded form, reference rounding order) */
-int l3d_square_distance(const float *src, const float *dst, int B, int N, int M, float *dist,
+int l3d_square_distance(const float *src, const float *dst, int B, int N, int M, int C, float *dist,
                         l3d_stream_t stream);
-/* the same for C != 3 (the reference body is generic in C); dot product = fma chain over channels in order */
-int l3d_square_distance_c(const float *src, const float *dst, int B, int N, int M, int C, float *dist,
-                          l3d_stream_t stream);
 /* compute_density(xyz, bandwidth) utils/pointconv_util.py:194-203, fused (no [B,N,N] tensor):
  *   density[b][i] = mean_j exp(-square_distance(xyz,xyz)[i][j] / (2 bw^2)) / (2.5 bw).  xyz [B,N,3] -> density [B,N] */
 int l3d_gaussian_density(const float *xyz, int B, int N, float bandwidth, float *density, l3d_stream_t stream);
@@ -254,13 +225,6 @@ int l3d_group_concat2(const float *xyz, const float *new_xyz, const float *featu
 int l3d_group_first_layer(const float *U, const float *V, const float *shift, const float *wx, const float *xyz,
                           const float *new_xyz, const int32_t *idx, int B, int N, int S, int K, int C1, int relu,
                           float *out, l3d_stream_t stream);
-/* The same layer written as the fp16 activation image of the next f16x2 layer (l3d_f16_act_bytes(B S K, C1) bytes, rows
- * (b, s, k)) instead of fp32: the rest of the grouped MLP then runs on l3d_pointwise_conv_f16 (out_img / ypool) with no fp32
- * activation.  bound: device float >= max|output| (fixes the plane scale; *range_flag is raised if it was exceeded).
- * C1 = 64, 128 or 256. */
-int l3d_group_first_layer_planes(const float *U, const float *V, const float *shift, const float *wx, const float *xyz,
-                                 const float *new_xyz, const int32_t *idx, int B, int N, int S, int K, int C1, int relu,
-                                 const float *bound, void *out_img, int *range_flag, l3d_stream_t stream);
 /* The same with the bound formed inside the kernel from block maxima: maxpart = the 4 x 64 floats l3d_absmax4_partials writes for
  * (U, V, xyz, new_xyz); wxr = max_r sum_d |wx_rd| and shmax = max|shift| come from the layer's parameters.
  * bound = max|U| + (max|V| or shmax) + wxr (max|xyz| + max|new_xyz|). */
@@ -292,14 +256,6 @@ size_t l3d_soft_correspondence_workspace_floats(int B, int N, int M);
 int l3d_soft_correspondence(const float *src_emb, const float *tgt_emb, const float *tgt, int B, int C, int N,
                             int M, float scale, float *workspace, float *src_corr, l3d_stream_t stream);
 
-/* Scaled-dot-product attention of DCP's pointer network == utils/transformer.py:17-25 (mask = None, no
- * dropout), flash-style (attention.hip):  q [B, H*D, N], k, v [B, H*D, M] (channel-first: head h is rows
- * h*D .. h*D+D-1) -> ctx [B, H*D, N],
- *   ctx[b][h*D+d][i] = sum_j softmax_j(scale * <q[b][h*D+:][i], k[b][h*D+:][j]>) * v[b][h*D+d][j].
- * The [B,H,N,M] scores are never materialised; both GEMMs run as bf16x3 (fp32-level error).
- * D must be 32, 64 or 128, else L3D_ERR_UNSUPPORTED. */
-int l3d_attention_forward(const float *q, const float *k, const float *v, int B, int H, int D, int N, int M,
-                          float scale, float *ctx, l3d_stream_t stream);
 /* the same with explicit batch strides (in floats) for q, k, v: they may then be channel slices of ONE fused
  * projection output [B, 3*H*D, N] (self-attention) or [B, 2*H*D, M] (keys + values of cross-attention). */
 int l3d_attention_forward_strided(const float *q, const float *k, const float *v, int B, int H, int D, int N,
@@ -347,9 +303,11 @@ int l3d_add_transposed(const float *x, const float *y, int B, int N, int C, floa
 size_t l3d_edgeconv_packed_floats(int c1, int c2, int c3, int c4);
 /* Pack + fold (host side, CPU pointers): conv{i}.weight [ci, c(i-1)] row-major and the
  * eval-mode BatchNorm affine (scale[ci], shift[ci]: y = scale * conv + shift) into the
- * fragment-ordered block the kernel streams.  == models/dgcnn.py:13-22 parameters. */
+ * fragment-ordered block the kernel streams.  == models/dgcnn.py:13-22 parameters.
+ * act_mag[4]: the magnitude (a few standard deviations) expected of each layer's post-ReLU activations (BatchNorm statistics
+ * give them); NULL or non-positive entries mean 1.  Only the f16x2 kernel's plane exponents use it. */
 int l3d_edgeconv_pack(const float *const w[4], const float *const scale[4], const float *const shift[4],
-                      int c1, int c2, int c3, int c4, float *packed);
+                      const float *act_mag, int c1, int c2, int c3, int c4, float *packed);
 /* Fused EdgeConv stack == models/dgcnn.py:32-46 in eval mode:
  *   graph feature (neighbour, centre) -> 4 x relu(bn(conv1x1)) -> max over k after each ->
  *   concat.  xyz [B,N,3], idx [B,N,k] int64 (k <= 32; DGCNN uses 20), packed from
@@ -372,7 +330,7 @@ int l3d_edgeconv_forward_split(const float *xyz, const int64_t *idx, int B, int 
  * (edgeconv_f16.hip): activations X = x 2^T as h = f16(X), m' = f16((X - h) 2^12), weights scaled by a per-layer power of
  * two and split the same way, THREE fp16 MFMA products per fp32 product into one fp32 accumulator -- fp32-level error
  * (tests hold it to the bf16x3 bar) at half of bf16x3's matrix-core work.  T per layer is fixed when the block is packed,
- * from the activation magnitudes the caller expects (l3d_edgeconv_pack_mag; BatchNorm statistics give them).
+ * from the activation magnitudes the caller expects (l3d_edgeconv_pack's act_mag; BatchNorm statistics give them).
  *   out_mode 0: out = pooled [B,N,512] fp32, channel-last (as the other EdgeConv entry points)
  *   out_mode 1: out = an fp16 activation image of the pooled values (l3d_f16_act_bytes(B*N, 512)), the x operand of
  *               l3d_pointwise_conv_f16 -- conv5 then runs without any split pass
@@ -387,10 +345,6 @@ int l3d_edgeconv_forward_split(const float *xyz, const int64_t *idx, int B, int 
 int l3d_edgeconv_forward_f16b(const float *xyz, const int64_t *idx, int B, int N, int k, const float *packed, void *out,
                              int out_mode, int *range_flag, l3d_stream_t stream);
 int l3d_edgeconv_packed_v2_flag_index(void);
-/* l3d_edgeconv_pack with act_mag[4]: the magnitude (a few standard deviations) expected of each layer's post-ReLU
- * activations; NULL or non-positive entries mean 1.  Only the f16x2 kernel uses it. */
-int l3d_edgeconv_pack_mag(const float *const w[4], const float *const scale[4], const float *const shift[4],
-                          const float *act_mag, int c1, int c2, int c3, int c4, float *packed);
 /* Per-point linear layer (Conv1d/Conv2d 1x1 + folded BN + optional ReLU):
  *   y[b][co][n] = act(scale[co] * sum_ci w[co][ci] x[b][ci][n] + shift[co])
  *   x [B,Cin,N] (x_channel_last = 0, torch Conv1d layout) or [B,N,Cin] (x_channel_last = 1),
@@ -400,18 +354,14 @@ int l3d_edgeconv_pack_mag(const float *const w[4], const float *const scale[4], 
  *   models/pcn.py:117-119,98-101, becomes a per-cloud shift instead of Cin extra channels).
  *   == models/dgcnn.py:48, models/pointnet.py:22-49, models/pcn.py:84-125 *
  * relu is an activation code for every conv entry point below: 0 none, 1 ReLU, any value > 1 = the IEEE-754 bits
- * of a LeakyReLU negative slope in (0,1) (0.2f -> 0x3E4CCCCD). */
+ * of a LeakyReLU negative slope in (0,1) (0.2f -> 0x3E4CCCCD).
+ * pool = 0: y [B,Cout,N].  pool = 8, 16, 32, 64: the max over every `pool` consecutive points in the epilogue, y [B,Cout,N/pool]
+ * (N % pool == 0): a grouped layer's max over its K neighbours, or -- with 64 and a tiny reduce over the N/64 partial maxima -- a
+ * conv followed by a global max-pool whose [B,Cout,N] output is never written. */
 int l3d_pointwise_conv(const float *x, int x_channel_last, const float *w, const float *scale,
                        const float *shift, int shift_bstride, int B, int Cin, int Cout, int N,
-                       int relu, float *y, l3d_stream_t stream);
+                       int relu, int pool, float *y, l3d_stream_t stream);
 
-/* l3d_pointwise_conv with a fused max over every `pool` consecutive points (pool = 8, 16, 32, 64;
- * N % pool == 0): y [B, Cout, N / pool].  With x = the grouped features [B, Cin, S*K] of a PointNet++ layer
- * and pool = K this is the last conv + BN + ReLU + max-over-neighbours of models/flownet3d.py:118-122 /
- * :170-176 / :231-232 without the [B,Cout,S,K] activation or a reduction launch. */
-int l3d_pointwise_conv_maxpool(const float *x, int x_channel_last, const float *w, const float *scale,
-                               const float *shift, int shift_bstride, int B, int Cin, int Cout, int N, int relu,
-                               int pool, float *y, l3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The same per-point linear layer on the bf16 matrix cores with fp32-equivalent results ("bf16x3"):
@@ -430,13 +380,7 @@ size_t l3d_split_bytes(int rows, int cols);
 int l3d_split_rows(const float *src, int rows, int cols, void *dst, l3d_stream_t stream);
 int l3d_pointwise_conv_split(const void *x, int x_mode, const void *w_split, const float *scale,
                              const float *shift, int shift_bstride, int B, int Cin, int Cout, int N,
-                             int relu, float *y, l3d_stream_t stream);
-/* the same with the max over every `pool` (8/16/32/64) consecutive points in the epilogue: y [B,Cout,N/pool]
- * (N % 256 == 0).  With pool = 64 and a tiny reduction over the N/64 partial maxima this is a conv followed
- * by a GLOBAL max-pool (models/pcn.py:68-70, models/pooling.py) without the [B,Cout,N] activation. */
-int l3d_pointwise_conv_split_maxpool(const void *x, int x_mode, const void *w_split, const float *scale,
-                                     const float *shift, int shift_bstride, int B, int Cin, int Cout, int N,
-                                     int relu, int pool, float *y, l3d_stream_t stream);
+                             int relu, int pool, float *y, l3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The same 1x1 conv as "f16x2" on the fp16 matrix cores (conv_f16.hip): three fp16 MFMA products per fp32 product --
@@ -569,23 +513,19 @@ int l3d_sceneflow_batch(const float *points1, const float *points2, const float 
 int l3d_channel_stats(const float *z, int B, int C, long P, double *part, l3d_stream_t stream);
 int l3d_bn_act_forward(const float *z, const float *scale, const float *shift, int B, int C, long P, int act, float *y,
                        l3d_stream_t stream);
-int l3d_bn_backward_stats(const float *dy, const float *z, const float *scale, const float *shift, const double *mean,
-                          const double *rstd, int B, int C, long P, int act, double *part, l3d_stream_t stream);
 /* mean, rstd, gr, m1, m2 [C] are fp64 and dz is evaluated in fp64 and rounded once (sum_p dz = 0 by construction: an
  * fp32-rounded m1 is a systematic error the weight gradient multiplies by the point count).  m1 = m2 = 0: eval-mode
- * BatchNorm or a plain bias layer (the statistics do not depend on z). */
+ * BatchNorm or a plain bias layer (the statistics do not depend on z).
+ * dpool / pidx / K (NULL / NULL / 0: none): for a layer whose output y [B][C][P] is ALSO max-pooled over runs of K consecutive
+ * positions (the max over the k neighbours behind an EdgeConv layer) the gradient at y is dy (may then be NULL) plus dpool
+ * [B][C][P/K] at the position pidx [B][C][P/K] names (l3d_max_last's arg-max) -- the dense scatter and the add of the two gradient
+ * tensors are never formed.  K <= 256, P % K == 0, P < 2^22. */
+int l3d_bn_backward_stats(const float *dy, const float *z, const float *scale, const float *shift, const double *mean,
+                          const double *rstd, int B, int C, long P, int act, double *part, const float *dpool,
+                          const unsigned char *pidx, int K, l3d_stream_t stream);
 int l3d_bn_act_backward(const float *dy, const float *z, const float *scale, const float *shift, const double *mean,
                         const double *rstd, const double *gr, const double *m1, const double *m2, int B, int C, long P, int act,
-                        float *dz, l3d_stream_t stream);
-/* The two backward kernels for a layer whose output y [B][C][P] is ALSO max-pooled over runs of K consecutive positions (the max
- * over the k neighbours behind an EdgeConv layer): the gradient at y is dy (may be NULL) plus dpool [B][C][P/K] at the position
- * pidx [B][C][P/K] names (l3d_max_last's arg-max) -- the dense scatter and the add of the two gradient tensors are never formed. */
-int l3d_bn_backward_stats_pool(const float *dy, const float *z, const float *scale, const float *shift, const double *mean,
-                               const double *rstd, int B, int C, long P, int act, double *part, const float *dpool,
-                               const unsigned char *pidx, int K, l3d_stream_t stream);
-int l3d_bn_act_backward_pool(const float *dy, const float *z, const float *scale, const float *shift, const double *mean,
-                             const double *rstd, const double *gr, const double *m1, const double *m2, int B, int C, long P, int act,
-                             float *dz, const float *dpool, const unsigned char *pidx, int K, l3d_stream_t stream);
+                        float *dz, const float *dpool, const unsigned char *pidx, int K, l3d_stream_t stream);
 /* tot[j] = part[0][j] + part[1][j] + ... + part[B-1][j]: per-cloud fp64 partials [B][M] added left to right, i.e. in
  * global cloud order whatever B's factorisation into ranks was. */
 int l3d_sum_clouds_f64(const double *part, int B, long M, double *tot, l3d_stream_t stream);

@@ -32,7 +32,6 @@ SIGNATURES = {
     "l3d_chamfer_backward_variant": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P],
     "l3d_chamfer_partials": [_P, _P, _I, _I, _I, _P, _P],
     "l3d_chamfer_combine": [_P, _I, _P, _P],
-    "l3d_chamfer_loss_local": [_P, _P, _I, _I, _I, _P, _P, _P],
     "l3d_chamfer_loss_local_ws_bytes": [],
     "l3d_chamfer_loss_local_mb": [_P, _P, _I, _I, _I, _P, _P, _P, _P],
     "l3d_ball_query": [_I, _I, _I, _F, _I, _P, _P, _P, _P],
@@ -41,7 +40,6 @@ SIGNATURES = {
     "l3d_group_concat": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_group_concat2": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_group_first_layer": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
-    "l3d_group_first_layer_planes": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "l3d_absmax4_partials": [_P, _SZ, _P, _SZ, _P, _SZ, _P, _SZ, _P, _P],
     "l3d_group_first_layer_planes_auto": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _F, _F, _P, _P, _P],
     "l3d_scatter_add_det_workspace_bytes": [_I, _I, _I],
@@ -56,8 +54,7 @@ SIGNATURES = {
     "l3d_three_interpolate": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "l3d_three_interpolate_concat": [_I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
     "l3d_three_interpolate_grad": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
-    "l3d_square_distance": [_P, _P, _I, _I, _I, _P, _P],
-    "l3d_square_distance_c": [_P, _P, _I, _I, _I, _I, _P, _P],
+    "l3d_square_distance": [_P, _P, _I, _I, _I, _I, _P, _P],
     "l3d_gaussian_density": [_P, _I, _I, _F, _P, _P],
     "l3d_query_ball_point": [_F, _I, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "l3d_index_points": [_P, _P, _I, _I, _I, _I, _P, _P],
@@ -70,7 +67,6 @@ SIGNATURES = {
     "l3d_layernorm_backward_workspace_floats": [C.c_long, _I],
     "l3d_layernorm_ref_backward": [_P, _P, _P, _F, C.c_long, _I, _P, _P, _P, _P, _P],
     "l3d_soft_correspondence": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
-    "l3d_attention_forward": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P],
     "l3d_attention_forward_strided": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _P],
     "l3d_attention_forward_f16b": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _I, _P, _P, _P],
     "l3d_layernorm_ref": [_P, _P, _P, _F, _L, _I, _P, _P],
@@ -83,18 +79,15 @@ SIGNATURES = {
     "l3d_linear_rows": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "l3d_layernorm_planes_cf": [_P, _P, _P, _F, _I, _I, _I, _P, _P, _P],
     "l3d_edgeconv_packed_floats": [_I, _I, _I, _I],
-    "l3d_edgeconv_pack": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "l3d_edgeconv_pack": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "l3d_edgeconv_forward": [_P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P],
     "l3d_edgeconv_forward_split": [_P, _P, _I, _I, _I, _P, _P, _P],
     "l3d_edgeconv_forward_f16b": [_P, _P, _I, _I, _I, _P, _P, _I, _P, _P],
     "l3d_edgeconv_packed_v2_flag_index": [],
-    "l3d_edgeconv_pack_mag": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "l3d_pointwise_conv": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
-    "l3d_pointwise_conv_maxpool": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "l3d_pointwise_conv": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_split_bytes": [_I, _I],
     "l3d_split_rows": [_P, _I, _I, _P, _P],
-    "l3d_pointwise_conv_split": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
-    "l3d_pointwise_conv_split_maxpool": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "l3d_pointwise_conv_split": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_f16_plane_bytes": [_L, _I],
     "l3d_f16_act_bytes": [_L, _I],
     "l3d_conv_f16_weight_bytes": [_I, _I],
@@ -106,10 +99,8 @@ SIGNATURES = {
     "l3d_fold_mlp_f16": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P],
     "l3d_channel_stats": [_P, _I, _I, _L, _P, _P],
     "l3d_bn_act_forward": [_P, _P, _P, _I, _I, _L, _I, _P, _P],
-    "l3d_bn_backward_stats": [_P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P],
-    "l3d_bn_backward_stats_pool": [_P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P, _P, _I, _P],
-    "l3d_bn_act_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P],
-    "l3d_bn_act_backward_pool": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P, _P, _I, _P],
+    "l3d_bn_backward_stats": [_P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P, _P, _I, _P],
+    "l3d_bn_act_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _L, _I, _P, _P, _P, _I, _P],
     "l3d_sum_clouds_f64": [_P, _I, _L, _P, _P],
     "l3d_wgrad_workspace_bytes": [_I, _I, _I, _L, _I],
     "l3d_wgrad": [_P, _P, _I, _I, _I, _L, _I, _P, _P, _P],

@@ -259,9 +259,3 @@ extern "C" int l3d_attention_forward_strided(const float *q, const float *k, con
     return l3d_check_launch();
 }
 
-extern "C" int l3d_attention_forward(const float *q, const float *k, const float *v, int B, int H, int D, int N,
-                                     int M, float scale, float *ctx, l3d_stream_t stream)
-{
-    return l3d_attention_forward_strided(q, k, v, B, H, D, N, M, (long)H * D * N, (long)H * D * M, (long)H * D * M, scale,
-                                         ctx, stream);
-}

@@ -512,47 +512,8 @@ extern "C" int l3d_chamfer_partials(const float *dist1, const float *dist2, int 
     return l3d_check_launch();
 }
 
-// Single-rank tail in ONE launch: both sqrt-sums (same thread mapping and summation order as sqrt_sum_kernel, so
-// the partials are bit-identical to l3d_chamfer_partials') and the combine, by one 1024-thread workgroup.
-__global__ __launch_bounds__(1024) void chamfer_loss_local_kernel(const float *__restrict__ d1, size_t n1,
-                                                                  const float *__restrict__ d2, size_t n2,
-                                                                  double *__restrict__ partial, float *__restrict__ loss)
-{
-    __shared__ double part[2][16];
-    double tot[2];
-    // both directions in ONE loop (their loads overlap; each keeps sqrt_sum_kernel's per-thread order, so the
-    // partial sums are the same bits)
-    double acc1 = 0.0, acc2 = 0.0;
-    const size_t a4 = n1 >> 2, b4 = n2 >> 2, m4 = a4 > b4 ? a4 : b4;
-    for (size_t i = threadIdx.x; i < m4; i += blockDim.x) {
-        if (i < a4) {
-            const float4 v = ((const float4 *)d1)[i];
-            acc1 += ((double)sqrtf(v.x) + (double)sqrtf(v.y)) + ((double)sqrtf(v.z) + (double)sqrtf(v.w));
-        }
-        if (i < b4) {
-            const float4 v = ((const float4 *)d2)[i];
-            acc2 += ((double)sqrtf(v.x) + (double)sqrtf(v.y)) + ((double)sqrtf(v.z) + (double)sqrtf(v.w));
-        }
-    }
-    for (size_t i = (a4 << 2) + threadIdx.x; i < n1; i += blockDim.x) acc1 += (double)sqrtf(d1[i]);
-    for (size_t i = (b4 << 2) + threadIdx.x; i < n2; i += blockDim.x) acc2 += (double)sqrtf(d2[i]);
-    for (int off = 32; off > 0; off >>= 1) { acc1 += __shfl_down(acc1, off, 64); acc2 += __shfl_down(acc2, off, 64); }
-    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = acc1; part[1][threadIdx.x >> 6] = acc2; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int which = 0; which < 2; which++) {
-            double t = 0.0;
-            for (int w = 0; w < 16; w++) t += part[which][w];
-            tot[which] = t;
-        }
-        partial[0] = tot[0]; partial[1] = tot[1]; partial[2] = (double)n1; partial[3] = (double)n2;
-        loss[0] = (float)((tot[0] / (double)n1 + tot[1] / (double)n2) / 2.0);
-    }
-}
-
-// The same tail spread over up to 64 workgroups: the one-workgroup kernel above is a chain of 16 dependent-latency
-// loop trips per thread (12 us for 2 x 32 K values); here every thread loads its one or two float4 at once, each
+// Single-rank tail in ONE launch over up to 64 workgroups (a one-workgroup kernel was a chain of 16 dependent-latency loop trips
+// per thread, 12 us for 2 x 32 K values): both sqrt-sums and the combine; every thread loads its one or two float4 at once, each
 // workgroup writes its two fp64 partial sums to ws, and the workgroup that draws the last ticket adds them with a
 // fixed shuffle tree (deterministic) and re-arms the ticket for the next call on the stream.
 //   ws: CHAMFER_LL_WS_BYTES bytes, the first 8 of them zero before the first call.
@@ -626,14 +587,6 @@ extern "C" int l3d_chamfer_loss_local_mb(const float *dist1, const float *dist2,
     return l3d_check_launch();
 }
 
-extern "C" int l3d_chamfer_loss_local(const float *dist1, const float *dist2, int B, int N, int M, double *partial,
-                                      float *loss, l3d_stream_t stream)
-{
-    L3D_REQUIRE(dist1 && dist2 && partial && loss && B > 0 && N > 0 && M > 0);
-    hipLaunchKernelGGL(chamfer_loss_local_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, dist1, (size_t)B * N,
-                       dist2, (size_t)B * M, partial, loss);
-    return l3d_check_launch();
-}
 
 __global__ void chamfer_combine_kernel(const double *__restrict__ partials, int world,
                                        float *__restrict__ loss)

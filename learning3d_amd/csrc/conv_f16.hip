@@ -926,15 +926,6 @@ static int gfp_launch(const float *U, const float *V, const float *shift, const 
     return l3d_check_launch();
 }
 
-extern "C" int l3d_group_first_layer_planes(const float *U, const float *V, const float *shift, const float *wx, const float *xyz,
-                                            const float *new_xyz, const int32_t *idx, int B, int N, int S, int K, int C1, int relu,
-                                            const float *bound, void *out_img, int *range_flag, l3d_stream_t stream)
-{
-    L3D_REQUIRE(U && wx && xyz && new_xyz && idx && bound && out_img && B > 0 && N > 0 && S > 0 && K > 0 && C1 > 0);
-    return gfp_launch(U, V, shift, wx, xyz, new_xyz, idx, B, N, S, K, C1, relu, bound, nullptr, 0.f, 0.f, out_img, range_flag,
-                      (hipStream_t)stream);
-}
-
 // Block maxima of up to four fp32 tensors in one launch: out[j][blk] = max |p_j| over block blk's stride of tensor j (64 blocks per
 // tensor; zeros for an absent tensor).  No atomics, no pre-zeroing: the consumer reduces the 4 x 64 values itself.
 __global__ __launch_bounds__(256) void absmax4_partials_kernel(const float *__restrict__ p0, size_t n0, const float *__restrict__ p1,

@@ -545,19 +545,12 @@ static int launch_conv_split(const void *x, int x_mode, const void *w_split, con
     return l3d_check_launch();
 }
 
+// pool = 0: y [B,Cout,N]; pool = 8, 16, 32, 64: the max over every `pool` consecutive points in the epilogue, y [B,Cout,N/pool]
 extern "C" int l3d_pointwise_conv_split(const void *x, int x_mode, const void *w_split, const float *scale,
                                         const float *shift, int shift_bstride, int B, int Cin, int Cout,
-                                        int N, int relu, float *y, l3d_stream_t stream)
+                                        int N, int relu, int pool, float *y, l3d_stream_t stream)
 {
-    L3D_REQUIRE(x && w_split && y && B > 0 && Cin > 0 && Cout > 0 && N > 0 && x_mode >= 0 && x_mode <= 2);
-    return launch_conv_split(x, x_mode, w_split, scale, shift, shift_bstride, B, Cin, Cout, N, relu, 0, y, (hipStream_t)stream);
-}
-
-extern "C" int l3d_pointwise_conv_split_maxpool(const void *x, int x_mode, const void *w_split, const float *scale,
-                                                const float *shift, int shift_bstride, int B, int Cin, int Cout,
-                                                int N, int relu, int pool, float *y, l3d_stream_t stream)
-{
-    L3D_REQUIRE(x && w_split && y && B > 0 && Cin > 0 && Cout > 0 && N > 0 && x_mode >= 0 && x_mode <= 2);
-    if (pool != 8 && pool != 16 && pool != 32 && pool != 64) return L3D_ERR_UNSUPPORTED;
+    L3D_REQUIRE(x && w_split && y && B > 0 && Cin > 0 && Cout > 0 && N > 0 && x_mode >= 0 && x_mode <= 2 && pool >= 0);
+    if (pool && pool != 8 && pool != 16 && pool != 32 && pool != 64) return L3D_ERR_UNSUPPORTED;
     return launch_conv_split(x, x_mode, w_split, scale, shift, shift_bstride, B, Cin, Cout, N, relu, pool, y, (hipStream_t)stream);
 }

@@ -319,15 +319,6 @@ __global__ __launch_bounds__(256) void square_distance_kernel(const float *__res
     out[((size_t)b * N + i) * M + j] = (-2.0f * dot + ss) + dd;
 }
 
-extern "C" int l3d_square_distance(const float *src, const float *dst, int B, int N, int M,
-                                   float *dist, l3d_stream_t stream)
-{
-    L3D_REQUIRE(src && dst && dist && B > 0 && N > 0 && M > 0 && N <= 65535 && B <= 65535);
-    hipLaunchKernelGGL(square_distance_kernel, dim3(l3d_divup(M, 256), N, B), dim3(256), 0,
-                       (hipStream_t)stream, src, dst, N, M, dist);
-    return l3d_check_launch();
-}
-
 // square_distance for C != 3 (the reference body is generic in C, model_common_utils.py:34-37): the dot product is an
 // fma chain over the channels in ascending order (MKL's blocking for K > 3 is not restated: ~1 ulp of the dot).
 __global__ __launch_bounds__(256) void square_distance_c_kernel(const float *__restrict__ src,
@@ -349,12 +340,15 @@ __global__ __launch_bounds__(256) void square_distance_c_kernel(const float *__r
     out[((size_t)b * N + i) * M + j] = (-2.0f * dot + ss) + dd;
 }
 
-extern "C" int l3d_square_distance_c(const float *src, const float *dst, int B, int N, int M, int C,
-                                     float *dist, l3d_stream_t stream)
+extern "C" int l3d_square_distance(const float *src, const float *dst, int B, int N, int M, int C,
+                                   float *dist, l3d_stream_t stream)
 {
     L3D_REQUIRE(src && dst && dist && B > 0 && N > 0 && M > 0 && C > 0 && N <= 65535 && B <= 65535);
-    hipLaunchKernelGGL(square_distance_c_kernel, dim3(l3d_divup(M, 256), N, B), dim3(256), 0,
-                       (hipStream_t)stream, src, dst, N, M, C, dist);
+    if (C == 3)                                     // the xyz form: the reference's rounding sequence for three coordinates
+        hipLaunchKernelGGL(square_distance_kernel, dim3(l3d_divup(M, 256), N, B), dim3(256), 0, (hipStream_t)stream, src, dst, N, M, dist);
+    else
+        hipLaunchKernelGGL(square_distance_c_kernel, dim3(l3d_divup(M, 256), N, B), dim3(256), 0,
+                           (hipStream_t)stream, src, dst, N, M, C, dist);
     return l3d_check_launch();
 }
 

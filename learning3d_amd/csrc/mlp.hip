@@ -81,7 +81,7 @@ static void pack_layer(const float *w /*[cout][cin]*/, const float *scale, int c
                 }
 }
 
-extern "C" int l3d_edgeconv_pack_mag(const float *const w[4], const float *const scale[4],
+extern "C" int l3d_edgeconv_pack(const float *const w[4], const float *const scale[4],
                                      const float *const shift[4], const float *act_mag, int c1, int c2, int c3, int c4,
                                      float *packed)
 {
@@ -297,13 +297,6 @@ extern "C" int l3d_edgeconv_pack_mag(const float *const w[4], const float *const
 }
 
 extern "C" int l3d_edgeconv_packed_v2_flag_index(void) { return EC5_OFF_SC + 13; }
-
-extern "C" int l3d_edgeconv_pack(const float *const w[4], const float *const scale[4],
-                                 const float *const shift[4], int c1, int c2, int c3, int c4,
-                                 float *packed)
-{
-    return l3d_edgeconv_pack_mag(w, scale, shift, nullptr, c1, c2, c3, c4, packed);
-}
 
 // One layer for one wave: acc[mt][i] += A(act rows) x B(weight fragments of this wave's N-tiles)
 //   act   : LDS, [4*MT*4 rows][CIN + 2] (the +2 skew makes the 16-row x 2-k ds_read_b32 pattern
@@ -832,29 +825,24 @@ static int launch_pointwise_conv(const float *x, int x_channel_last, const float
     return l3d_check_launch();
 }
 
+// pool = 0: y [B,Cout,N]; pool = 8, 16, 32, 64: the max over every `pool` consecutive points in the epilogue, y [B,Cout,N/pool]
 extern "C" int l3d_pointwise_conv(const float *x, int x_channel_last, const float *w,
                                   const float *scale, const float *shift, int shift_bstride, int B,
-                                  int Cin, int Cout, int N, int relu, float *y, l3d_stream_t stream)
+                                  int Cin, int Cout, int N, int relu, int pool, float *y, l3d_stream_t stream)
 {
-    L3D_REQUIRE(x && w && y && B > 0 && Cin > 0 && Cout > 0 && N > 0);
+    L3D_REQUIRE(x && w && y && B > 0 && Cin > 0 && Cout > 0 && N > 0 && pool >= 0);
     if (B > 65535) return L3D_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    if (pool) {
+        if ((pool != 8 && pool != 16 && pool != 32 && pool != 64) || N % pool) return L3D_ERR_UNSUPPORTED;
+        if (stream_shape(x_channel_last, Cin, Cout, N, pool))
+            return launch_stream<true>(x, w, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, pool, st);
+        return launch_pointwise_conv<true>(x, x_channel_last, w, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, pool, st);
+    }
     if (Cout <= 8 && B <= 65535)
         return x_channel_last ? launch_narrow<true>(x, w, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, st)
                               : launch_narrow<false>(x, w, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, st);
     if (stream_shape(x_channel_last, Cin, Cout, N, 0))
         return launch_stream<false>(x, w, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, 0, st);
     return launch_pointwise_conv<false>(x, x_channel_last, w, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, 0, st);
-}
-
-extern "C" int l3d_pointwise_conv_maxpool(const float *x, int x_channel_last, const float *w, const float *scale,
-                                          const float *shift, int shift_bstride, int B, int Cin, int Cout, int N,
-                                          int relu, int pool, float *y, l3d_stream_t stream)
-{
-    L3D_REQUIRE(x && w && y && B > 0 && Cin > 0 && Cout > 0 && N > 0);
-    if (B > 65535 || (pool != 8 && pool != 16 && pool != 32 && pool != 64) || N % pool) return L3D_ERR_UNSUPPORTED;
-    if (stream_shape(x_channel_last, Cin, Cout, N, pool))
-        return launch_stream<true>(x, w, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, pool, (hipStream_t)stream);
-    return launch_pointwise_conv<true>(x, x_channel_last, w, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, pool,
-                                       (hipStream_t)stream);
 }

@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void bn_backward_stats_kernel(const float *__r
 
 // dy may be NULL when dpool is given (a layer whose output is only pooled); dpool [B][C][P/K], pidx [B][C][P/K] (l3d_max_last's
 // arg-max), K = the pooled run length: P % K == 0, P < 2^22
-extern "C" int l3d_bn_backward_stats_pool(const float *dy, const float *z, const float *scale, const float *shift, const double *mean,
+// dpool / pidx / K: the pooled gradient of a layer whose output is also max-pooled over runs of K (NULL / NULL / 0: none)
+extern "C" int l3d_bn_backward_stats(const float *dy, const float *z, const float *scale, const float *shift, const double *mean,
                                           const double *rstd, int B, int C, long P, int act, double *part, const float *dpool,
                                           const unsigned char *pidx, int K, l3d_stream_t stream)
 {
@@ -193,12 +194,6 @@ extern "C" int l3d_bn_backward_stats_pool(const float *dy, const float *z, const
     return l3d_check_launch();
 }
 
-extern "C" int l3d_bn_backward_stats(const float *dy, const float *z, const float *scale, const float *shift, const double *mean,
-                                     const double *rstd, int B, int C, long P, int act, double *part, l3d_stream_t stream)
-{
-    L3D_REQUIRE(dy != nullptr);
-    return l3d_bn_backward_stats_pool(dy, z, scale, shift, mean, rstd, B, C, P, act, part, nullptr, nullptr, 0, stream);
-}
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void bn_act_backward_kernel(const float *__restrict__ dy, const float *__restrict__ z,
@@ -243,7 +238,8 @@ __global__ __launch_bounds__(256) void bn_act_backward_kernel(const float *__res
     }
 }
 
-extern "C" int l3d_bn_act_backward_pool(const float *dy, const float *z, const float *scale, const float *shift, const double *mean,
+// dpool / pidx / K: the pooled gradient of a layer whose output is also max-pooled over runs of K (NULL / NULL / 0: none)
+extern "C" int l3d_bn_act_backward(const float *dy, const float *z, const float *scale, const float *shift, const double *mean,
                                         const double *rstd, const double *gr, const double *m1, const double *m2, int B, int C, long P,
                                         int act, float *dz, const float *dpool, const unsigned char *pidx, int K, l3d_stream_t stream)
 {
@@ -260,13 +256,6 @@ extern "C" int l3d_bn_act_backward_pool(const float *dy, const float *z, const f
     return l3d_check_launch();
 }
 
-extern "C" int l3d_bn_act_backward(const float *dy, const float *z, const float *scale, const float *shift, const double *mean,
-                                   const double *rstd, const double *gr, const double *m1, const double *m2, int B, int C, long P,
-                                   int act, float *dz, l3d_stream_t stream)
-{
-    L3D_REQUIRE(dy != nullptr);
-    return l3d_bn_act_backward_pool(dy, z, scale, shift, mean, rstd, gr, m1, m2, B, C, P, act, dz, nullptr, nullptr, 0, stream);
-}
 
 __global__ __launch_bounds__(256) void sum_clouds_f64_kernel(const double *__restrict__ part, int B, long M, double *__restrict__ tot)
 {

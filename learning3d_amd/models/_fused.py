@@ -434,12 +434,12 @@ def pointwise_conv_maxpool(x, w, scale, shift, relu, pool, w_split=None, channel
     if split_eligible(Cin, Cout, N) and N % 256 == 0:
         if w_split is None:
             w_split = split_rows(w)
-        check(lib().l3d_pointwise_conv_split_maxpool(ptr(x), int(channel_last), ptr(w_split), ptr(scale), ptr(shift), bstride, B, Cin, Cout,
-                                                     N, int(relu), pool, ptr(y), stream_ptr()),
-              "l3d_pointwise_conv_split_maxpool")
+        check(lib().l3d_pointwise_conv_split(ptr(x), int(channel_last), ptr(w_split), ptr(scale), ptr(shift), bstride, B, Cin, Cout,
+                                             N, int(relu), pool, ptr(y), stream_ptr()),
+              "l3d_pointwise_conv_split[maxpool]")
         return y
-    check(lib().l3d_pointwise_conv_maxpool(ptr(x), int(channel_last), ptr(w), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N, int(relu),
-                                           pool, ptr(y), stream_ptr()), "l3d_pointwise_conv_maxpool")
+    check(lib().l3d_pointwise_conv(ptr(x), int(channel_last), ptr(w), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N, int(relu),
+                                   pool, ptr(y), stream_ptr()), "l3d_pointwise_conv[maxpool]")
     return y
 
 
@@ -481,11 +481,11 @@ def pointwise_conv(x, w, scale=None, shift=None, relu=False, channel_last=False,
         if w_split is None:
             w_split = split_rows(w)
         check(lib().l3d_pointwise_conv_split(ptr(x), int(channel_last), ptr(w_split), ptr(scale), ptr(shift), bstride,
-                                             B, Cin, Cout, N, int(relu), ptr(y), stream_ptr()),
+                                             B, Cin, Cout, N, int(relu), 0, ptr(y), stream_ptr()),
               "l3d_pointwise_conv_split")
         return y
     check(lib().l3d_pointwise_conv(ptr(x), int(channel_last), ptr(w), ptr(scale), ptr(shift), bstride, B, Cin, Cout, N,
-                                   int(relu), ptr(y), stream_ptr()), "l3d_pointwise_conv")
+                                   int(relu), 0, ptr(y), stream_ptr()), "l3d_pointwise_conv")
     return y
 
 
@@ -531,8 +531,8 @@ class EdgeConvParams:
                 raise NotImplementedError(f"EdgeConv channel widths {cs} are not built (64/64/128/256 only)")
             packed = torch.empty(nfl, dtype=torch.float32)
             arr = lambda ts: (C.c_void_p * 4)(*[t.data_ptr() for t in ts])
-            check(lib().l3d_edgeconv_pack_mag(arr(ws), arr(scs), arr(shs), (C.c_float * 4)(*mags), *cs, ptr(packed)),
-                  "l3d_edgeconv_pack_mag")
+            check(lib().l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), (C.c_float * 4)(*mags), *cs, ptr(packed)),
+                  "l3d_edgeconv_pack")
             # the two-plane f16x2 kernel's block is usable when every layer's weights fit its scaling window
             self.v2_ok = bool(packed[lib().l3d_edgeconv_packed_v2_flag_index()] == 1.0)
             self.packed = packed.to(device)

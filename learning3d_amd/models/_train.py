@@ -196,7 +196,7 @@ class _ConvAffineAct(torch.autograd.Function):
             dy = torch.zeros_like(z)
         K = ctx.pool if pidx is not None else 0
         part = torch.empty((B, Cout, 2), dtype=torch.float64, device=z.device)
-        check(lib().l3d_bn_backward_stats_pool(ptr(dy), ptr(z), ptr(scale), ptr(shift), ptr(mean64), ptr(rstd64), B, Cout, P,
+        check(lib().l3d_bn_backward_stats(ptr(dy), ptr(z), ptr(scale), ptr(shift), ptr(mean64), ptr(rstd64), B, Cout, P,
                                                int(ctx.relu), ptr(part), ptr(dmax) if pidx is not None else None, ptr(pidx), K,
                                                stream_ptr()), "l3d_bn_backward_stats")
         # (sum g, sum g zhat) over this rank's clouds -> parameter gradients; over every rank's -> the batch means: one launch
@@ -210,7 +210,7 @@ class _ConvAffineAct(torch.autograd.Function):
                                              int(ctx.batch_stats), ptr(gr64), ptr(m1), ptr(m2), ptr(dbias), ptr(dgamma), ptr(dbeta),
                                              stream_ptr()), "l3d_bn_backward_finalize")
         dz = torch.empty_like(z)
-        check(lib().l3d_bn_act_backward_pool(ptr(dy), ptr(z), ptr(scale), ptr(shift), ptr(mean64), ptr(rstd64), ptr(gr64), ptr(m1), ptr(m2),
+        check(lib().l3d_bn_act_backward(ptr(dy), ptr(z), ptr(scale), ptr(shift), ptr(mean64), ptr(rstd64), ptr(gr64), ptr(m1), ptr(m2),
                                              B, Cout, P, int(ctx.relu), ptr(dz), ptr(dmax) if pidx is not None else None, ptr(pidx), K,
                                              stream_ptr()), "l3d_bn_act_backward")
         dx = dw = None

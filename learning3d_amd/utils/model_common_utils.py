@@ -67,10 +67,7 @@ def square_distance(src, dst):
         raise RuntimeError(f"square_distance: channel mismatch {Cc} vs {dst.shape[2]}")
     s, d = f32c(src), f32c(dst)
     out = torch.empty((B, N, M), dtype=torch.float32, device=src.device)
-    if Cc == 3:
-        check(lib().l3d_square_distance(ptr(s), ptr(d), B, N, M, ptr(out), stream_ptr()), "l3d_square_distance")
-    else:                                                   # the reference body is generic in C
-        check(lib().l3d_square_distance_c(ptr(s), ptr(d), B, N, M, Cc, ptr(out), stream_ptr()), "l3d_square_distance_c")
+    check(lib().l3d_square_distance(ptr(s), ptr(d), B, N, M, Cc, ptr(out), stream_ptr()), "l3d_square_distance")   # any C
     return out
 
 

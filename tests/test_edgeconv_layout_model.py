@@ -80,8 +80,8 @@ def test_edgeconv_fragment_layout_and_row_mapping():
     assert n == 2 * (8 * C1 + C1 * C2 + C2 * C3 + C3 * C4) + C1 + C2 + C3 + C4 + 2 * SPLIT_FLOATS + (C2 + C3 + C4) + 16 + V2_FLOATS
     packed = np.zeros(n, np.float32)
     arr = lambda xs: (C.c_void_p * 4)(*[x.ctypes.data for x in xs])
-    assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), C1, C2, C3, C4, packed.ctypes.data) == 0
-    assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), 32, 32, 64, 128, packed.ctypes.data) == -2
+    assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), None, C1, C2, C3, C4, packed.ctypes.data) == 0
+    assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), None, 32, 32, 64, 128, packed.ctypes.data) == -2
 
     # one tile: 4 points, 20 neighbours each
     N, k = 16, 20
@@ -135,7 +135,7 @@ def test_edgeconv_chained_register_layout():
     assert n == v1 + 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4 + 2 * SPLIT_FLOATS + (C2 + C3 + C4) + 16 + V2_FLOATS
     packed = np.zeros(n, np.float32)
     arr = lambda xs: (C.c_void_p * 4)(*[x.ctypes.data for x in xs])
-    assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), C1, C2, C3, C4, packed.ctypes.data) == 0
+    assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), None, C1, C2, C3, C4, packed.ctypes.data) == 0
     pk = packed.astype(np.float64)
     o_b = [8 * C1 + C1 * C2 + C2 * C3 + C3 * C4]
     o_b += [o_b[0] + C1, o_b[0] + C1 + C2, o_b[0] + C1 + C2 + C3]
@@ -252,7 +252,7 @@ def test_edgeconv_split_bf16x3_layout():
     n = lib.l3d_edgeconv_packed_floats(C1, C2, C3, C4)
     packed = np.zeros(n, np.float32)
     arr = lambda xs: (C.c_void_p * 4)(*[x.ctypes.data for x in xs])
-    assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), C1, C2, C3, C4, packed.ctypes.data) == 0
+    assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), None, C1, C2, C3, C4, packed.ctypes.data) == 0
     v1 = 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4 + C1 + C2 + C3 + C4
     o_b = [8 * C1 + C1 * C2 + C2 * C3 + C3 * C4]
     o_b += [o_b[0] + C1, o_b[0] + C1 + C2, o_b[0] + C1 + C2 + C3]
@@ -380,7 +380,7 @@ def test_edgeconv_f16x2_pack():
     Hs = f16(H 2^-12), M = f16(W - H) in the fragment order of the bf16x3 copy, H + M = W to 2^-22 |W| worst case
     (two 11-bit roundings; + fp16's subnormal floor); biases in accumulator units; the 16 power-of-two scale constants tie the layers together
     (cs_l = 2^T_l / A_l, cp_l = 1 / A_l, co_l = 2^T_out / A_l, A_l = 2^(S_l + T_(l-1)), A_1 = 1) with T_l taken from the
-    expected activation magnitudes handed to l3d_edgeconv_pack_mag."""
+    expected activation magnitudes handed to l3d_edgeconv_pack."""
     lib = _lib.lib()
     rng = np.random.default_rng(3)
     ws = [rng.standard_normal((C1, 6)).astype(np.float32), rng.standard_normal((C2, C1)).astype(np.float32) * 0.2,
@@ -391,7 +391,7 @@ def test_edgeconv_f16x2_pack():
     n = lib.l3d_edgeconv_packed_floats(C1, C2, C3, C4)
     packed = np.zeros(n, np.float32)
     arr = lambda xs: (C.c_void_p * 4)(*[x.ctypes.data for x in xs])
-    assert lib.l3d_edgeconv_pack_mag(arr(ws), arr(scs), arr(shs), mags.ctypes.data, C1, C2, C3, C4, packed.ctypes.data) == 0
+    assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), mags.ctypes.data, C1, C2, C3, C4, packed.ctypes.data) == 0
     v1 = 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4 + C1 + C2 + C3 + C4
     o4 = v1 + 8 * C1 + C1 * C2 + C2 * C3 + C3 * C4 + SPLIT_FLOATS
     o_b4 = o4 + SPLIT_FLOATS
@@ -455,7 +455,7 @@ def test_edgeconv_f16x2_two_plane_pack():
     def pack(mags):
         packed = np.zeros(n, np.float32)
         m = np.asarray(mags, np.float32)
-        assert lib.l3d_edgeconv_pack_mag(arr(ws), arr(scs), arr(shs), m.ctypes.data, C1, C2, C3, C4, packed.ctypes.data) == 0
+        assert lib.l3d_edgeconv_pack(arr(ws), arr(scs), arr(shs), m.ctypes.data, C1, C2, C3, C4, packed.ctypes.data) == 0
         return packed
     mags = [3.0, 5.0, 0.7, 40.0]
     packed = pack(mags)
@@ -531,5 +531,5 @@ def test_edgeconv_f16x2_two_plane_pack():
     ones = [np.ones(c, np.float32) for c in (C1, C2, C3, C4)]
     packed = np.zeros(n, np.float32)
     m4 = np.full(4, 4.0, np.float32)
-    assert lib.l3d_edgeconv_pack_mag(arr(ws_d), arr(ones), arr(shs), m4.ctypes.data, C1, C2, C3, C4, packed.ctypes.data) == 0
+    assert lib.l3d_edgeconv_pack(arr(ws_d), arr(ones), arr(shs), m4.ctypes.data, C1, C2, C3, C4, packed.ctypes.data) == 0
     assert packed[flag] == 1.0

@@ -62,6 +62,5 @@ def test_new_entry_points_validate_arguments():
     assert l.l3d_scatter_add_det(None, None, None, 1, 1, 1, 1, 1, None, None, None) == -1
     assert l.l3d_group_concat2(None, None, None, None, None, 1, 1, 1, 1, 1, 0, 0, None, None) == -1
     assert l.l3d_add_transposed(None, None, 1, 1, 1, None, None) == -1
-    assert l.l3d_chamfer_loss_local(None, None, 1, 1, 1, None, None, None) == -1
     assert l.l3d_three_interpolate_concat(1, 1, 1, 1, None, None, None, None, 0, None, None) == -1
     assert l.l3d_knn_feature_workspace_bytes(2, 64, 300) == 2 * 64 * 384 * 6 + 2 * 384 * 4

@@ -14,9 +14,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_symbols():
-    text = open(os.path.join(ROOT, "include", "l3d_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(l3d_[a-z0-9_]+)\s*\(", text)))
+    """every entry point include/*.h declares: the boundary (l3d_hip.h) and the kernel-selection hooks (l3d_hip_testing.h)"""
+    out = set()
+    for name in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if name.endswith(".h"):
+            text = open(os.path.join(ROOT, "include", name)).read()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            out |= set(re.findall(r"\b(l3d_[a-z0-9_]+)\s*\(", text))
+    return sorted(out)
 
 
 def test_library_exports_every_declared_symbol():
@@ -28,6 +33,8 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(handle, s), f"{s} declared in include/l3d_hip.h but not exported"
     assert set(syms) == set(_lib.SIGNATURES), "ctypes table and header disagree"
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "l3d_hip.h")).read(), flags=re.S)
+    assert len(set(re.findall(r"\b(l3d_[a-z0-9_]+)\s*\(", text))) <= 90, "the boundary header grew past 90 entry points"
     l = _lib.lib()
     assert l.l3d_version() >= 100
     assert b"invalid" in l.l3d_status_string(-1)

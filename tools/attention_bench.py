@@ -6,7 +6,7 @@ from learning3d_amd._lib import lib, check, ptr, stream_ptr
 B, H, D, N = 32, 4, 128, 1024
 q, k, v = (torch.randn(B, H * D, N, device="cuda") for _ in range(3))
 ctx = torch.empty_like(q)
-fn = lambda: check(lib().l3d_attention_forward(ptr(q), ptr(k), ptr(v), B, H, D, N, N, 1.0 / D ** 0.5, ptr(ctx), stream_ptr()), "att")
+fn = lambda: check(lib().l3d_attention_forward_strided(ptr(q), ptr(k), ptr(v), B, H, D, N, N, H * D * N, H * D * N, H * D * N, 1.0 / D ** 0.5, ptr(ctx), stream_ptr()), "att")
 for _ in range(10): fn()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(30): fn()

@@ -10,7 +10,7 @@ xt = x.transpose(1, 2).contiguous().view(B * N, Cin)
 xs = _fused.split_rows(xt)
 y = torch.empty(B, Cout, N, device="cuda")
 def run(mode, xin):
-    return lambda: check(lib().l3d_pointwise_conv_split(ptr(xin), mode, ptr(ws), None, None, 0, B, Cin, Cout, N, 1, ptr(y), stream_ptr()), "c")
+    return lambda: check(lib().l3d_pointwise_conv_split(ptr(xin), mode, ptr(ws), None, None, 0, B, Cin, Cout, N, 1, 0, ptr(y), stream_ptr()), "c")
 for name, fn in (("x_mode 0 (fp32 channel-first)", run(0, x)), ("x_mode 2 (pre-split)", run(2, xs))):
     for _ in range(600): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -59,7 +59,7 @@ with torch.no_grad():
         want = np.einsum("bhdm,bhnm->bhdn", va.astype(np.float64), s)
         qd, kd, vd = dev(qa.reshape(B, H * D, N)), dev(ka.reshape(B, H * D, M)), dev(va.reshape(B, H * D, M))
         out = torch.empty_like(qd)
-        check(lib().l3d_attention_forward(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, 1 / math.sqrt(D), ptr(out), stream_ptr()), "att")
+        check(lib().l3d_attention_forward_strided(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, H * D * N, H * D * M, H * D * M, 1 / math.sqrt(D), ptr(out), stream_ptr()), "att")
         rec("attention vs fp64", out.cpu().numpy().reshape(B, H, D, N), want, 1e-5, 4e-6)
     for it in range(10):                                            # Chamfer: packed kernel == per-candidate kernel, bit for bit
         B = int(rng.integers(1, 4)); N = int(rng.integers(1, 3000)); M = int(rng.integers(1, 3000))

@@ -30,7 +30,7 @@ with torch.no_grad():
     qc, kc, vc = [z.reshape(B, H * D, N).contiguous() for z in (q, k, v)]
     out = torch.empty_like(qc)
     def flash():
-        check(lib().l3d_attention_forward(ptr(qc), ptr(kc), ptr(vc), B, H, D, N, N, 1 / math.sqrt(D), ptr(out), stream_ptr()), "att")
+        check(lib().l3d_attention_forward_strided(ptr(qc), ptr(kc), ptr(vc), B, H, D, N, N, H * D * N, H * D * N, H * D * N, 1 / math.sqrt(D), ptr(out), stream_ptr()), "att")
     print("flash attention (l3d)  %8.1f us" % timeit(flash))
     from learning3d_amd.models import _fused
     w = torch.randn(512, 512, device="cuda"); bias = torch.randn(512, device="cuda")
