@@ -390,15 +390,14 @@ def c5_cpu_baseline(sample_clouds=4, repeats=1):
 def main_c5(args, rank, world, local, dev, dist, parallel):
     multi = world > 1 or dist.is_initialized()      # a one-rank RCCL group (L3D_INIT_SINGLE_RANK=1) takes the N > 1 code path
     from learning3d_amd.models import PointNetSetAbstraction, _fused
-    pipelined = not args.c5_serial
-    # two resident input batches, consumed alternately (a stream of batches; the pipelined mode samples batch i + 1 while batch i's
-    # ball query / grouping / MLP run, so consecutive steps must not be the same tensor)
+    depth = 0 if args.c5_serial else max(1, args.c5_depth)
+    pipelined = depth > 0
+    # two resident input batches, consumed alternately (a stream of batches: batch i is xyzs[i % 2])
     g = torch.Generator().manual_seed(2000 + rank)
     xyzs = [torch.clamp(torch.randn((B_PER_GPU, 3, C5_N), generator=g), -2, 2).to(dev) for _ in range(2)]   # N(0,1) clipped to [-2,2]
     feats = [torch.rand((B_PER_GPU, 3, C5_N), generator=g).to(dev) for _ in range(2)]
     torch.manual_seed(1)
     sa = PointNetSetAbstraction(npoint=C5_S, radius=C5_R, nsample=C5_K, in_channel=3, mlp=list(C5_MLP), group_all=False).to(dev).eval()
-    side = torch.cuda.Stream()
 
     def digest(new_xyz, new_feat):
         # the shard's digest (sum, sum of squares, count, centroid checksum): where a training loop's per-shard loss partials go
@@ -410,27 +409,38 @@ def main_c5(args, rank, world, local, dev, dist, parallel):
             new_xyz, new_feat = sa(xyzs[cur], feats[cur])
             return new_feat, digest(new_xyz, new_feat)
 
-    def compute_pipe(cur, fps_cur, fps_out=None):
-        """batch `cur` from its sampled indices on the main stream; batch 1 - cur's furthest point sampling (1024 dependent rounds,
-        one workgroup per cloud = 32 of 256 CUs) beside it on the side stream; joined at the end of the step"""
-        main = torch.cuda.current_stream()
-        with torch.no_grad():
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                nxt = sa.sample(xyzs[1 - cur])
-                if fps_out is not None:
-                    fps_out.copy_(nxt)
-                    nxt = fps_out
-            new_xyz, new_feat = sa(xyzs[cur], feats[cur], fps_idx=fps_cur)
-            part = digest(new_xyz, new_feat)
-            main.wait_stream(side)
-        return new_feat, part, nxt
-
-    graphs, graph_outs = None, None
-    state = {"cur": 0, "fps": None}
+    # Pipelined mode.  Furthest point sampling is 1024 DEPENDENT rounds on one workgroup per cloud -- 32 of 256 CUs busy for ~0.9 ms,
+    # three times what the rest of the batch (ball query, grouping, MLP: every CU) takes -- and it is a function of the input
+    # coordinates alone.  So it is issued `depth` batches ahead, each batch's sampling on its own stream: `depth` sampling kernels
+    # (depth x 32 workgroups) are resident beside the batch being computed.  F is a ring of index buffers (even length, so that a
+    # slot always holds indices of the same input parity); a slot's sampling waits for the compute that last read the slot
+    # (ev_done), a batch's compute waits for its slot's sampling (ev_fps).  Every step consumes one batch and issues one sampling.
+    ring = depth + 1 + ((depth + 1) % 2) if pipelined else 0
+    sides = [torch.cuda.Stream() for _ in range(depth)]
+    ev_fps = [torch.cuda.Event() for _ in range(ring)]
+    ev_done = [torch.cuda.Event() for _ in range(ring)]
+    done_valid = [False] * ring
+    F = []
     if pipelined:
         with torch.no_grad():
-            state["fps"] = sa.sample(xyzs[0])
+            F = [sa.sample(xyzs[r % 2]) for r in range(ring)]
+        torch.cuda.synchronize()
+
+    def issue_sampling(j):
+        s_, r = sides[j % depth], j % ring
+        with torch.cuda.stream(s_), torch.no_grad():
+            if done_valid[r]:
+                s_.wait_event(ev_done[r])
+            F[r].copy_(sa.sample(xyzs[j % 2]))
+            ev_fps[r].record(s_)
+
+    def compute_from(r):
+        with torch.no_grad():
+            new_xyz, new_feat = sa(xyzs[r % 2], feats[r % 2], fps_idx=F[r])
+            return new_feat, digest(new_xyz, new_feat)
+
+    graphs, graph_outs = None, None
+    state = {"i": 0}
 
     def exchange(part, cloned):
         if multi:
@@ -439,19 +449,36 @@ def main_c5(args, rank, world, local, dev, dist, parallel):
             return flat.view(world, 4).sum(0)
         return part
 
-    def step():
-        cur = state["cur"]
-        state["cur"] = 1 - cur
-        if graphs is not None:
-            graphs[cur].replay()
-            nf, part = graph_outs[cur]
-            return nf, exchange(part, True)
-        if pipelined:
-            nf, part, state["fps"] = compute_pipe(cur, state["fps"])
-        else:
-            nf, part = compute_serial(cur)
-        return nf, exchange(part, False)
+    def prime():
+        """the first `depth` batches' sampling (nothing to run beside yet)"""
+        state["i"] = 0
+        for j in range(depth):
+            issue_sampling(j)
 
+    def step():
+        i = state["i"]
+        state["i"] = i + 1
+        if not pipelined:
+            if graphs is not None:
+                graphs[i % 2].replay()
+                nf, part = graph_outs[i % 2]
+                return nf, exchange(part, True)
+            nf, part = compute_serial(i % 2)
+            return nf, exchange(part, False)
+        issue_sampling(i + depth)
+        r = i % ring
+        main = torch.cuda.current_stream()
+        main.wait_event(ev_fps[r])
+        if graphs is not None:
+            graphs[r].replay()
+            nf, part = graph_outs[r]
+        else:
+            nf, part = compute_from(r)
+        ev_done[r].record(main)
+        done_valid[r] = True
+        return nf, exchange(part, graphs is not None)
+
+    prime()
     for _ in range(20):
         step()
     if not args.no_graph:
@@ -459,31 +486,21 @@ def main_c5(args, rank, world, local, dev, dist, parallel):
             torch.cuda.synchronize()
             warm = torch.cuda.Stream()
             warm.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(warm):
-                for _ in range(4):
-                    step()
+            with torch.cuda.stream(warm), torch.no_grad():
+                for r in range(max(ring, 2)):
+                    compute_from(r) if pipelined else compute_serial(r)
             torch.cuda.current_stream().wait_stream(warm)
             torch.cuda.synchronize()
             gs, outs = [], []
-            if pipelined:
-                # graph c: batch c from the static index buffer F[c], batch 1 - c sampled into F[1 - c]
-                with torch.no_grad():
-                    F = [sa.sample(xyzs[0]), sa.sample(xyzs[1])]
-                torch.cuda.synchronize()
-                for c in (0, 1):
-                    g_ = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g_):
-                        nf, part, _ = compute_pipe(c, F[c], fps_out=F[1 - c])
-                    gs.append(g_)
-                    outs.append((nf, part))
-            else:
-                for c in (0, 1):
-                    g_ = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g_):
-                        outs.append(compute_serial(c))
-                    gs.append(g_)
-            state["cur"] = 0
+            for r in range(max(ring, 2)):       # graph r: the batch whose indices sit in F[r] (serial mode: input r, sampling included)
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_):
+                    outs.append(compute_from(r) if pipelined else compute_serial(r))
+                gs.append(g_)
             graphs, graph_outs = gs, outs
+            torch.cuda.synchronize()
+            done_valid = [False] * ring
+            prime()
             for _ in range(6):
                 step()
             torch.cuda.synchronize()
@@ -546,9 +563,12 @@ def main_c5(args, rank, world, local, dev, dist, parallel):
                                    "over K, eval, random-init weights; 32 clouds per GPU, two resident input batches consumed alternately",
                        "global_batch": world * B_PER_GPU, "num_points": C5_N, "npoint": C5_S, "nsample": C5_K, "radius": C5_R,
                        "launch": "hipGraph replay" if graphs is not None else "eager launches",
-                       "pipeline": ("batch i + 1's furthest point sampling (one workgroup per cloud: 32 of 256 CUs) on a second stream beside "
-                                    "batch i's ball query / grouping / MLP, joined at the end of every step; every step still produces one "
-                                    "batch's complete output" if pipelined else "none: sampling, then the rest, on one stream"),
+                       "pipeline": (f"furthest point sampling (a function of the input coordinates alone; one workgroup per cloud = 32 of 256 CUs "
+                                    f"for 1024 dependent rounds) is issued {depth} batch(es) ahead, each on its own stream, beside the batch "
+                                    "being computed (ball query / grouping / MLP from a ring of index buffers, event-ordered); every step "
+                                    "issues one batch's sampling and produces one batch's complete output; the timed region ends when the "
+                                    "last issued sampling has ended too" if pipelined else "none: sampling, then the rest, on one stream"),
+                       "pipeline_depth": depth,
                        "parallelism": f"batch-sharded x{world}, no data-path collective; one 32-byte all_gather of the shard digest per step"},
             "rccl_ranks": (dist.get_world_size() if multi else 1), "dist_backend": dist.get_backend() if multi else None,
             "per_rank_ms_per_step": [float(v) / args.steps * 1e3 for v in per_rank[:, 0]],
@@ -587,6 +607,8 @@ def main():
     ap.add_argument("--c5-serial", action="store_true",
                     help="--workload c5: sampling and the rest of each batch on one stream (default: batch i + 1's furthest point "
                          "sampling runs on a second stream beside batch i's ball query / grouping / MLP)")
+    ap.add_argument("--c5-depth", type=int, default=2,
+                    help="--workload c5: how many batches ahead furthest point sampling is issued (one stream each; 1 = only the next batch's)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the untimed configs[2..4] extras (DCP-v2 forward, PCN + Chamfer, FlowNet3D sa1 / forward) of the c2 line")
     ap.add_argument("--sync-loss", action="store_true",

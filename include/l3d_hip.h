@@ -265,7 +265,7 @@ int l3d_attention_forward_strided(const float *q, const float *k, const float *v
  * six, fp32-level accuracy; attention_f16.hip).  fp16's range is handled inside: one extra pass reads max|q|, max|k|, max|v|
  * into `workspace` (>= 16 bytes of device memory, contents irrelevant) and the operands are scaled by powers of two from
  * them.  Same shapes and strides as l3d_attention_forward_strided.  Output: ctx (fp32, may be NULL) and / or ctx_img, the
- * context as the fp16 activation image of l3d_pointwise_conv_f16 (l3d_f16_act_bytes(B N, H D) bytes; may be NULL): the
+ * context as the fp16 activation image of l3d_pointwise_conv_f16 (l3d_f16_image_bytes(1, B N, H D) bytes; may be NULL): the
  * output projection then needs no split pass (|ctx| <= max|v| fixes the plane scale). */
 /* The same with the three operand maxima already in `maxima` (uint32 float bits of upper bounds of max|q|, |k|, |v|, e.g. from
  * l3d_pointwise_conv_f16 with amax_out): the pass over q, k, v is not run. */
@@ -282,13 +282,13 @@ int l3d_attention_forward_f16b(const float *q, const float *k, const float *v, i
 int l3d_layernorm_ref(const float *x, const float *a, const float *b, float eps, long rows, int C, float *y,
                       l3d_stream_t stream);
 /* The same, and additionally the output as the fp16 activation image l3d_pointwise_conv_f16 consumes (img:
- * l3d_f16_act_bytes(rows, C) bytes): the Linear layers behind a LayerNorm then run as f16x2 with no split pass.  The
+ * l3d_f16_image_bytes(1, rows, C) bytes): the Linear layers behind a LayerNorm then run as f16x2 with no split pass.  The
  * plane scale comes from the layer's parameters (|y_c| <= |a_c| sqrt(C-1) + |b_c|).  C % 8 == 0, C <= 512.  y may be NULL
  * (image only). */
 int l3d_layernorm_planes(const float *x, const float *a, const float *b, float eps, long rows, int C, float *y, void *img,
                          l3d_stream_t stream);
 /* The same LayerNorm over the channels of a CHANNEL-FIRST tensor x [B][C][N] (one normalisation per point), output as
- * y [B][C][N] (or NULL) and / or as the activation image with rows b N + n (img: l3d_f16_act_bytes(B N, C) bytes, or NULL):
+ * y [B][C][N] (or NULL) and / or as the activation image with rows b N + n (img: l3d_f16_image_bytes(1, B N, C) bytes, or NULL):
  * the pointer network keeps the [B,C,N] layout its GEMMs write from end to end.  C in {128, 256, 512}. */
 int l3d_layernorm_planes_cf(const float *x, const float *a, const float *b, float eps, int B, int C, int N, float *y,
                             void *img, l3d_stream_t stream);
@@ -332,7 +332,7 @@ int l3d_edgeconv_forward_split(const float *xyz, const int64_t *idx, int B, int 
  * (tests hold it to the bf16x3 bar) at half of bf16x3's matrix-core work.  T per layer is fixed when the block is packed,
  * from the activation magnitudes the caller expects (l3d_edgeconv_pack's act_mag; BatchNorm statistics give them).
  *   out_mode 0: out = pooled [B,N,512] fp32, channel-last (as the other EdgeConv entry points)
- *   out_mode 1: out = an fp16 activation image of the pooled values (l3d_f16_act_bytes(B*N, 512)), the x operand of
+ *   out_mode 1: out = an fp16 activation image of the pooled values (l3d_f16_image_bytes(1, B*N, 512)), the x operand of
  *               l3d_pointwise_conv_f16 -- conv5 then runs without any split pass
  * Range contract: activations must stay below 16x the expected magnitude (fp16 tops out at 65504); the kernel watches
  * the pooled maxima it forms anyway and stores 1 to *range_flag (device or mapped host memory, may be NULL) when a
@@ -389,19 +389,17 @@ int l3d_pointwise_conv_split(const void *x, int x_mode, const void *w_split, con
  * planes in the tiled layout plane[k / 8][row][8 fp16] (rows = Cout for W, B*N for x), so the kernel moves them
  * global -> LDS by DMA with no registers and no VALU.  Range contract: |x| < 65504 (producers raise *range_flag
  * beyond 60000; results are then invalid and the caller falls back to l3d_pointwise_conv_split).
- *   l3d_f16_plane_bytes(rows, cols)          bytes of one plane
- *   l3d_f16_act_bytes(rows, cols)            bytes of an activation image (h | m' planes + 16 bytes: 2^-T, scratch), the
- *                                            activations being stored times 2^T (T per tensor: see conv_f16.hip)
- *   l3d_conv_f16_weight_bytes(Cout, Cin)     bytes of a split weight image (H | Hs | M planes + 16 bytes: 2^-S, scratch)
+ *   l3d_f16_image_bytes(kind, rows, cols)    kind 0: bytes of one plane; kind 1: of an activation image (h | m' planes + 16
+ *                                            bytes: 2^-T, scratch), the activations being stored times 2^T (T per tensor: see
+ *                                            conv_f16.hip); kind 2: of a split weight image of [rows = Cout][cols = Cin]
+ *                                            (H | Hs | M planes + 16 bytes: 2^-S, scratch)
  *   l3d_conv_f16_split_weights               w [Cout][Cin] fp32 (device) -> that image (device); two small launches
  *   l3d_split_f16_rows                       x [rows][C] fp32, or [B][C][Npts] with channel_first -> activation image
  *   l3d_pointwise_conv_f16                   y[b][co][n] = act(scale[co] sum_k w[co][k] x[b][n][k] + shift[(b,)co]);
  *                                            Cin % 16 == 0 and (Cout % 256 == 0, N % 256 == 0) or (Cout % 128 == 0,
  *                                            N % 512 == 0: the narrow tile), else L3D_ERR_UNSUPPORTED
  * ------------------------------------------------------------------------------------------- */
-size_t l3d_f16_plane_bytes(long rows, int cols);
-size_t l3d_f16_act_bytes(long rows, int cols);
-size_t l3d_conv_f16_weight_bytes(int Cout, int Cin);
+size_t l3d_f16_image_bytes(int kind, long rows, int cols);
 int l3d_conv_f16_split_weights(const float *w, int Cout, int Cin, void *dst, l3d_stream_t stream);
 /* nn.Linear over a handful of rows (PCN's fully connected decoder, models/pcn.py:132-137: rows = clouds):
  * y [R][Cout] = act(x [R][Cin] w [Cout][Cin]^T + bias), fp32 fmaf chains in ascending k; the weight matrix is read once.
@@ -415,7 +413,7 @@ int l3d_split_f16_rows(const float *x, long rows, int C, int channel_first, int 
  *   y         fp32 [B][Cout][N], or NULL
  *   residual  y = residual + act(scale (w x) + shift): residual and y distinct [B][Cout][N] buffers (utils/transformer.py:82-88:
  *             x + sublayer(norm(x)) without a pass over both tensors); Cout % 256 == 0, N % 256 == 0
- *   out_img   the output as the activation image of the NEXT f16x2 layer (l3d_f16_act_bytes(B N, Cout) bytes): chains of Linear /
+ *   out_img   the output as the activation image of the NEXT f16x2 layer (l3d_f16_image_bytes(1, B N, Cout) bytes): chains of Linear /
  *             1x1-conv layers stay on the fp16 matrix cores with no split pass in between.  Needs obs = two device floats
  *             {max|shift| over every (b, co), max|scale|} (max|scale| = 1 without a scale); with the weight image's row-sum
  *             maximum and the input image's scale the kernel bounds its outputs and fixes the plane scale itself
@@ -554,6 +552,22 @@ int l3d_max_last_backward(const float *g, const unsigned char *idx, long R, int 
 size_t l3d_layernorm_backward_workspace_floats(long rows, int C);
 int l3d_layernorm_ref_backward(const float *x, const float *a, const float *g, float eps, long rows, int C, float *dx,
                                float *workspace, float *da, float *db, l3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Strided batched fp32 GEMM and row softmax (bmm.hip): the TRAINING path of the pointer network and the SVD head -- the
+ * products of `attention` (utils/transformer.py:127-132), of its nn.Linear layers (:183-189, :228-238), of the SVD head's scores
+ * (utils/svd.py:27-31) and of square_distance (utils/model_common_utils.py:34-37), forward and what autograd derives for them,
+ * read where the tensors lie (a transposed operand is its strides swapped).
+ *   C[i][j] = act(alpha A[i][j] B[i][j] + bias) (+ C[i][j]),  A [M x K], B [K x N], C [M x N], i < nb1, j < nb2
+ *   *_strides: four element strides {batch1, batch2, row, column} (host arrays); flags: 1 accumulate into C, 2 ReLU, 4 bias[n],
+ *   8 bias[m]; parts > 1: K split into `parts` ranges through `workspace` (nb1 nb2 parts M N floats), summed in ascending order
+ *   (weight gradients: few output tiles, K = every row of the batch).  fp32 MFMA: an exact fma chain per element, ascending k.
+ * l3d_softmax_rows: dp == NULL: y = softmax(scale x) over the last axis of [rows][cols]; dp given: y = scale p (dp - sum_j p_j dp_j)
+ * with p = x (the backward through the softmax and the score scale).  y may alias x / dp.  cols <= 8192. */
+int l3d_bmm_f32(const float *A, const long *a_strides, const float *B, const long *b_strides, float *C, const long *c_strides,
+                int nb1, int nb2, int M, int N, int K, float alpha, int flags, const float *bias, int parts, float *workspace,
+                l3d_stream_t stream);
+int l3d_softmax_rows(const float *x, const float *dp, long rows, int cols, float scale, float *y, l3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight gradient of a 1x1 conv / Linear over points (wgrad.hip; the autograd of nn.Conv1d / Conv2d(k=1) in

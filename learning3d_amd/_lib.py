@@ -70,6 +70,8 @@ SIGNATURES = {
     "l3d_attention_forward_strided": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _P],
     "l3d_attention_forward_f16b": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _I, _P, _P, _P],
     "l3d_layernorm_ref": [_P, _P, _P, _F, _L, _I, _P, _P],
+    "l3d_bmm_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _I, _P, _P],
+    "l3d_softmax_rows": [_P, _P, _L, _I, _F, _P, _P],
     "l3d_layernorm_planes": [_P, _P, _P, _F, _L, _I, _P, _P, _P],
     "l3d_add_transposed": [_P, _P, _I, _I, _I, _P, _P],
     "l3d_max_last": [_P, _L, _I, _P, _P, _P],
@@ -88,9 +90,7 @@ SIGNATURES = {
     "l3d_split_bytes": [_I, _I],
     "l3d_split_rows": [_P, _I, _I, _P, _P],
     "l3d_pointwise_conv_split": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
-    "l3d_f16_plane_bytes": [_L, _I],
-    "l3d_f16_act_bytes": [_L, _I],
-    "l3d_conv_f16_weight_bytes": [_I, _I],
+    "l3d_f16_image_bytes": [_I, _L, _I],
     "l3d_conv_f16_split_weights": [_P, _I, _I, _P, _P],
     "l3d_split_f16_rows": [_P, _L, _I, _I, _I, _P, _P, _P],
     "l3d_pointwise_conv_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _I, _P],
@@ -114,7 +114,7 @@ SIGNATURES = {
 }
 _RESTYPE = {"l3d_status_string": C.c_char_p, "l3d_edgeconv_packed_floats": _SZ, "l3d_split_bytes": _SZ,
             "l3d_soft_correspondence_workspace_floats": _SZ, "l3d_layernorm_backward_workspace_floats": _SZ, "l3d_knn_feature_workspace_bytes": _SZ,
-            "l3d_scatter_add_det_workspace_bytes": _SZ, "l3d_chamfer_loss_local_ws_bytes": _SZ, "l3d_f16_plane_bytes": _SZ, "l3d_f16_act_bytes": _SZ, "l3d_conv_f16_weight_bytes": _SZ,
+            "l3d_scatter_add_det_workspace_bytes": _SZ, "l3d_chamfer_loss_local_ws_bytes": _SZ, "l3d_f16_image_bytes": _SZ,
             "l3d_wgrad_workspace_bytes": _SZ}
 
 

@@ -1,0 +1,325 @@
+// bmm.hip -- strided batched fp32 GEMM on the fp32 matrix cores, for the TRAINING path of the pointer network and the SVD head
+// (SURVEY.md 8 row f3): C[i][j] = act(alpha * A[i][j] B[i][j] + bias) (+ C[i][j]) over a two-level batch (cloud i, head j), every
+// operand addressed through four element strides {batch1, batch2, row, column} -- so q k^T, p v, p^T dO, dS^T q, x W^T, dy W and
+// dy^T x (reference utils/transformer.py:127-132 `attention`, :183-189 the nn.Linear layers; utils/svd.py:27-31 the SVD head's
+// scores; utils/model_common_utils.py:19-38 square_distance -- and what autograd derives for them) are all the same kernel reading
+// the tensors where they lie: no transposed copies.
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 -- an exact fp32 fma chain per output element, ascending k (split-K: ascending k within a
+// part, parts summed in ascending order by the reduction kernel): deterministic, and the fp32 result torch's own matmul is compared
+// against in tests/test_gpu_grad_routes.py.  Peak 157.3 TFLOP/s (MI355X_MICROARCH.md); this is not an inference kernel -- the
+// inference path's GEMMs are the f16x2 kernels of conv_f16.hip / attention_f16b.hip.
+//
+// Workgroup: 256 threads, tile 128 x 128, four waves of 64 x 64 (2 x 2 MFMA tiles, 64 accumulator registers), K in chunks of 16
+// through LDS ([k][m] and [k][n], pitch 160 floats, two buffers); the next chunk's values are in flight in registers while the
+// current one is multiplied.  A thread's 8 values run along whichever axis of the operand is contiguous (two 16-byte loads when the
+// host says the operand is 16-byte aligned along it, scalars otherwise and at the edges).
+#include "common.h"
+#include "split_bf16.h"          // f32x16
+
+#define BM_T 128
+#define BM_K 16
+#define BM_P (BM_T + 32)          // pitch 160: the two k rows a wave reads per MFMA operand fall on disjoint bank halves
+
+struct BmOperand {
+    const float *p;
+    long s1, s2, sr, sc;         // element strides: batch level 1, batch level 2, row, column
+    int vec;                     // 1: 16-byte loads along k are safe; 2: along the operand's rows (m of A, n of B); 0: scalars
+};
+
+// V values (8 or 4) of a [16 V rows x 16 k] operand tile for thread t: along k (mode 1 or 0) -- 16 / V threads per row; along rows
+// (mode 2, or rows contiguous but unaligned) -- k = t >> 4, rows (t & 15) V .. + V - 1.  `sr` / `sc` = the stride along the
+// operand's rows / along k (for B, which is given as [K x N], the caller passes them swapped).
+template <int V>
+struct BmFrag { float v[V]; };
+
+template <int V>
+__device__ __forceinline__ BmFrag<V> bm_fetch(const float *__restrict__ base, long sr, long sc, int vec, int r0, int k0, int R, int K, int t)
+{
+    BmFrag<V> f;
+    if (vec == 2 || sr == 1) {
+        const int k = k0 + (t >> 4), r = r0 + (t & 15) * V;
+        if (vec == 2 && k < K && r + V - 1 < R) {
+#pragma unroll
+            for (int j = 0; j < V; j += 4) {
+                const float4 a = *(const float4 *)(base + (long)k * sc + r + j);
+                f.v[j] = a.x; f.v[j + 1] = a.y; f.v[j + 2] = a.z; f.v[j + 3] = a.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < V; i++) f.v[i] = (k < K && r + i < R) ? base[(long)k * sc + (long)(r + i) * sr] : 0.f;
+        }
+    } else {
+        constexpr int TPR = 16 / V;                     // threads per row
+        const int r = r0 + t / TPR, k = k0 + (t % TPR) * V;
+        if (vec == 1 && r < R && k + V - 1 < K) {
+#pragma unroll
+            for (int j = 0; j < V; j += 4) {
+                const float4 a = *(const float4 *)(base + (long)r * sr + k + j);
+                f.v[j] = a.x; f.v[j + 1] = a.y; f.v[j + 2] = a.z; f.v[j + 3] = a.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < V; i++) f.v[i] = (r < R && k + i < K) ? base[(long)r * sr + (long)(k + i) * sc] : 0.f;
+        }
+    }
+    return f;
+}
+
+// ... and where they go in the [k][row] LDS tile
+template <int V>
+__device__ __forceinline__ void bm_stash(float (*__restrict__ tile)[BM_P], const BmFrag<V> &f, long sr, int vec, int t)
+{
+    if (vec == 2 || sr == 1) {
+        const int k = t >> 4, r = (t & 15) * V;
+#pragma unroll
+        for (int j = 0; j < V; j += 4) *(float4 *)&tile[k][r + j] = make_float4(f.v[j], f.v[j + 1], f.v[j + 2], f.v[j + 3]);
+    } else {
+        constexpr int TPR = 16 / V;
+        const int r = t / TPR, k = (t % TPR) * V;
+#pragma unroll
+        for (int i = 0; i < V; i++) tile[k + i][r] = f.v[i];
+    }
+}
+
+// grid: x = column tiles, y = row tiles, z = (batch1 * nb2 + batch2) * parts + part.  parts > 1: every part writes the raw sums of
+// its K range into ws [z][M][N]; bm_reduce_kernel finishes.
+// YT = 32-column MFMA tiles per wave: 2 -> workgroup tile 128 x 128 (64 accumulators), 1 -> 128 x 64 (32) for products whose
+// 128 x 128 tiling would leave CUs with a single workgroup (a Linear layer over 8192 rows x 512 channels is 256 tiles).
+// LDS is double-buffered: one barrier per chunk (chunk i + 1 is stashed into the other buffer behind chunk i's MFMAs; every wave
+// has passed the barrier in front of chunk i, so nobody still reads that buffer).
+template <int YT>
+__global__ __launch_bounds__(256, 2) void bmm_f32_kernel(BmOperand A, BmOperand B, float *__restrict__ C, long c1, long c2, long cr, long cc,
+                                                      int nb2, int M, int N, int K, float alpha, int flags,
+                                                      const float *__restrict__ bias, int parts, float *__restrict__ ws)
+{
+    constexpr int TN = 64 * YT, VB = 4 * YT;
+    __shared__ __attribute__((aligned(16))) float As[2][BM_K][BM_P];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BM_K][BM_P];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int part = blockIdx.z % parts, bz = blockIdx.z / parts;
+    const int i1 = bz / nb2, i2 = bz % nb2;
+    const int m0 = blockIdx.y * BM_T, n0 = blockIdx.x * TN;
+    const float *__restrict__ a = A.p + (long)i1 * A.s1 + (long)i2 * A.s2;
+    const float *__restrict__ b = B.p + (long)i1 * B.s1 + (long)i2 * B.s2;
+    // this part's K range: chunks of 16, split evenly
+    const int nchunk = (K + BM_K - 1) / BM_K;
+    const int cpp = (nchunk + parts - 1) / parts;
+    const int kbeg = part * cpp * BM_K, kend = min(K, kbeg + cpp * BM_K);
+
+    f32x16 acc[2][YT];
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int y = 0; y < YT; y++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[x][y][r] = 0.f;
+
+    // B is [K x N]: as a [N rows x K] operand its row stride is sc and its k stride sr
+    if (kbeg < kend) {
+        const BmFrag<8> fa = bm_fetch<8>(a, A.sr, A.sc, A.vec, m0, kbeg, M, kend, t);
+        const BmFrag<VB> fb = bm_fetch<VB>(b, B.sc, B.sr, B.vec, n0, kbeg, N, kend, t);
+        bm_stash<8>(As[0], fa, A.sr, A.vec, t);
+        bm_stash<VB>(Bs[0], fb, B.sc, B.vec, t);
+    }
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BM_K) {
+        __syncthreads();                                  // chunk k0 is in buffer `cur`; buffer cur ^ 1 is free
+        const bool more = k0 + BM_K < kend;
+        BmFrag<8> fa;
+        BmFrag<VB> fb;
+        if (more) {
+            fa = bm_fetch<8>(a, A.sr, A.sc, A.vec, m0, k0 + BM_K, M, kend, t);
+            fb = bm_fetch<VB>(b, B.sc, B.sr, B.vec, n0, k0 + BM_K, N, kend, t);
+        }
+        const int kl = lane >> 5, rl = lane & 31;
+#pragma unroll
+        for (int kk = 0; kk < BM_K; kk += 2) {
+            float av[2], bv[YT];
+#pragma unroll
+            for (int x = 0; x < 2; x++) av[x] = As[cur][kk + kl][wm * 64 + 32 * x + rl];
+#pragma unroll
+            for (int y = 0; y < YT; y++) bv[y] = Bs[cur][kk + kl][wn * 32 * YT + 32 * y + rl];
+#pragma unroll
+            for (int x = 0; x < 2; x++)
+#pragma unroll
+                for (int y = 0; y < YT; y++) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], bv[y], acc[x][y], 0, 0, 0);
+        }
+        if (more) {
+            bm_stash<8>(As[cur ^ 1], fa, A.sr, A.vec, t);
+            bm_stash<VB>(Bs[cur ^ 1], fb, B.sc, B.vec, t);
+        }
+        cur ^= 1;
+    }
+
+    // D[m = 32x + (r&3) + 8(r>>2) + 4(lane>>5)][n = 32y + (lane&31)]
+    float *__restrict__ c = parts > 1 ? ws + (size_t)blockIdx.z * M * N : C + (long)i1 * c1 + (long)i2 * c2;
+    const long sr = parts > 1 ? N : cr, sc = parts > 1 ? 1 : cc;
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = m0 + wm * 64 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m >= M) continue;
+#pragma unroll
+            for (int y = 0; y < YT; y++) {
+                const int n = n0 + wn * 32 * YT + 32 * y + (lane & 31);
+                if (n >= N) continue;
+                float v = acc[x][y][r];
+                if (parts == 1) {
+                    v = alpha * v;
+                    if (flags & 4) v = v + bias[n];
+                    if (flags & 8) v = v + bias[m];
+                    if (flags & 2) v = fmaxf(v, 0.f);
+                    if (flags & 1) v = c[(long)m * sr + (long)n * sc] + v;
+                }
+                c[(long)m * sr + (long)n * sc] = v;
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void bm_reduce_kernel(const float *__restrict__ ws, int parts, float *__restrict__ C, long c1, long c2,
+                                                        long cr, long cc, int nb2, int M, int N, float alpha, int flags,
+                                                        const float *__restrict__ bias)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x, per = (long)M * N;
+    const int bz = blockIdx.y;
+    if (e >= per) return;
+    const int m = (int)(e / N), n = (int)(e % N);
+    float s = 0.f;
+    for (int p = 0; p < parts; p++) s += ws[((size_t)bz * parts + p) * per + e];
+    float v = alpha * s;
+    if (flags & 4) v = v + bias[n];
+    if (flags & 8) v = v + bias[m];
+    if (flags & 2) v = fmaxf(v, 0.f);
+    float *c = C + (long)(bz / nb2) * c1 + (long)(bz % nb2) * c2 + (long)m * cr + (long)n * cc;
+    if (flags & 1) v = *c + v;
+    *c = v;
+}
+
+static int bm_vec(const float *p, const long s[4], long rows_extent_unused)
+{
+    (void)rows_extent_unused;
+    const bool al = (((size_t)p) & 15) == 0 && s[0] % 4 == 0 && s[1] % 4 == 0;
+    if (s[3] == 1 && al && s[2] % 4 == 0) return 1;
+    if (s[2] == 1 && al && s[3] % 4 == 0) return 2;
+    return 0;
+}
+
+// C[i][j] = act(alpha A[i][j] B[i][j] + bias) (+ C[i][j]),  A [M x K], B [K x N], C [M x N], i < nb1, j < nb2;
+// *_strides = {batch1, batch2, row, column} in elements (a transposed operand is its strides swapped; a broadcast one has batch
+// strides 0).  flags: 1 accumulate into C, 2 ReLU, 4 bias[n], 8 bias[m].  parts > 1: split K into `parts` ranges whose partial
+// products go through `workspace` (nb1 nb2 parts M N floats) and are summed in ascending order -- for products with few output
+// tiles and a long K (weight gradients: K = every row of the batch).
+extern "C" int l3d_bmm_f32(const float *A, const long *a_strides, const float *B, const long *b_strides, float *C,
+                           const long *c_strides, int nb1, int nb2, int M, int N, int K, float alpha, int flags,
+                           const float *bias, int parts, float *workspace, l3d_stream_t stream)
+{
+    L3D_REQUIRE(A && B && C && a_strides && b_strides && c_strides && nb1 > 0 && nb2 > 0 && M > 0 && N > 0 && K > 0 &&
+                (flags & ~15) == 0 && (!(flags & 12) || bias) && parts >= 1 && (parts == 1 || workspace));
+    const long nz = (long)nb1 * nb2 * parts;
+    if (nz > 65535 || l3d_divup(M, BM_T) > 65535) return L3D_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    BmOperand a{A, a_strides[0], a_strides[1], a_strides[2], a_strides[3], bm_vec(A, a_strides, 0)};
+    // B as a [N rows x K] operand: "along k" is its row stride, "along rows" its column stride
+    const long bsw[4] = {b_strides[0], b_strides[1], b_strides[3], b_strides[2]};
+    BmOperand b{B, b_strides[0], b_strides[1], b_strides[2], b_strides[3], bm_vec(B, bsw, 0)};
+    // 128 x 128 tiles when they fill the chip twice over, 128 x 64 otherwise
+    const long wide = (long)l3d_divup(N, 128) * l3d_divup(M, BM_T) * nz;
+    if (wide >= 512 && N > 64) {
+        dim3 grid((unsigned)l3d_divup(N, 128), (unsigned)l3d_divup(M, BM_T), (unsigned)nz);
+        hipLaunchKernelGGL(bmm_f32_kernel<2>, grid, dim3(256), 0, st, a, b, C, c_strides[0], c_strides[1], c_strides[2], c_strides[3], nb2, M,
+                           N, K, alpha, flags, bias, parts, workspace);
+    } else {
+        dim3 grid((unsigned)l3d_divup(N, 64), (unsigned)l3d_divup(M, BM_T), (unsigned)nz);
+        hipLaunchKernelGGL(bmm_f32_kernel<1>, grid, dim3(256), 0, st, a, b, C, c_strides[0], c_strides[1], c_strides[2], c_strides[3], nb2, M,
+                           N, K, alpha, flags, bias, parts, workspace);
+    }
+    if (parts > 1) {
+        if (l3d_check_launch() != 0) return L3D_ERR_LAUNCH;
+        dim3 rg((unsigned)l3d_divup((long)M * N, 256), (unsigned)(nb1 * nb2));
+        hipLaunchKernelGGL(bm_reduce_kernel, rg, dim3(256), 0, st, (const float *)workspace, parts, C, c_strides[0], c_strides[1],
+                           c_strides[2], c_strides[3], nb2, M, N, alpha, flags, bias);
+    }
+    return l3d_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// softmax over the last axis of [rows][cols] (reference utils/transformer.py:131, utils/svd.py:29), in place or not, and its
+// backward ds = p (dp - sum_j p_j dp_j): one workgroup per row, values in registers (cols <= 256 * SM_PER), fixed-order
+// reductions (a wave's butterfly, then the four waves in order).
+// ---------------------------------------------------------------------------------------------
+#define SM_PER 32
+__device__ __forceinline__ float sm_block_reduce(float v, bool is_max, float *red)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const float o = __shfl_xor(v, d, 64);
+        v = is_max ? fmaxf(v, o) : v + o;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : ((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float *__restrict__ x, long rows, int cols, float scale, float *__restrict__ y)
+{
+    __shared__ float red[4];
+    const long row = blockIdx.x;
+    const float *xr = x + row * cols;
+    float v[SM_PER], big = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SM_PER; i++) {
+        const int c = i * 256 + threadIdx.x;
+        v[i] = c < cols ? xr[c] * scale : -INFINITY;
+        big = fmaxf(big, v[i]);
+    }
+    big = sm_block_reduce(big, true, red);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < SM_PER; i++) {
+        v[i] = i * 256 + (int)threadIdx.x < cols ? expf(v[i] - big) : 0.f;
+        sum += v[i];
+    }
+    sum = sm_block_reduce(sum, false, red);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < SM_PER; i++) {
+        const int c = i * 256 + threadIdx.x;
+        if (c < cols) y[row * cols + c] = v[i] * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float *__restrict__ p, const float *__restrict__ dp, long rows, int cols,
+                                                               float scale, float *__restrict__ ds)
+{
+    __shared__ float red[4];
+    const long row = blockIdx.x;
+    float pv[SM_PER], gv[SM_PER], dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < SM_PER; i++) {
+        const int c = i * 256 + threadIdx.x;
+        pv[i] = c < cols ? p[row * cols + c] : 0.f;
+        gv[i] = c < cols ? dp[row * cols + c] : 0.f;
+        dot += pv[i] * gv[i];
+    }
+    dot = sm_block_reduce(dot, false, red);
+#pragma unroll
+    for (int i = 0; i < SM_PER; i++) {
+        const int c = i * 256 + threadIdx.x;
+        if (c < cols) ds[row * cols + c] = scale * (pv[i] * (gv[i] - dot));
+    }
+}
+
+// forward (dp == NULL): y = softmax(scale * x) over the last axis; backward (dp given): y = scale * p (dp - sum p dp) with p = x.
+// y may alias x (forward) or dp (backward).  cols <= 8192.
+extern "C" int l3d_softmax_rows(const float *x, const float *dp, long rows, int cols, float scale, float *y, l3d_stream_t stream)
+{
+    L3D_REQUIRE(x && y && rows > 0 && cols > 0);
+    if (cols > 256 * SM_PER || rows > 2147483647L) return L3D_ERR_UNSUPPORTED;
+    if (dp) hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, dp, rows, cols, scale, y);
+    else hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, rows, cols, scale, y);
+    return l3d_check_launch();
+}

@@ -28,6 +28,11 @@ static inline int l3d_check_launch() {
 
 static inline int l3d_divup(long a, long b) { return (int)((a + b - 1) / b); }
 
+// sizes of the f16x2 plane images (conv_f16.hip; exported as l3d_f16_image_bytes(kind, rows, cols))
+static inline size_t l3d_f16_plane_bytes(long rows, int cols) { return (size_t)((cols + 7) / 8) * (size_t)rows * 16; }   // one plane, tiled layout
+static inline size_t l3d_f16_act_bytes(long rows, int cols) { return 2 * l3d_f16_plane_bytes(rows, cols) + 16; }         // h | m' + {2^-T, scratch}
+static inline size_t l3d_conv_f16_weight_bytes(int Cout, int Cin) { return 3 * l3d_f16_plane_bytes(Cout, Cin) + 16; }    // H | Hs | M + {2^-S, maxima}
+
 // -------------------------------------------------------------------------------------------
 // Per-lane sorted top-K list kept entirely in VGPRs (K is a compile-time constant so every
 // index below is static).  Keys are "larger is better"; equal keys keep insertion order, so

@@ -589,19 +589,18 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
     }
 }
 
-// bytes of ONE fp16 plane of a [rows][cols] matrix in the tiled layout
-extern "C" size_t l3d_f16_plane_bytes(long rows, int cols)
+#ifdef CF_HALF       // tools/experiments/conv_f16_half.inc: 256-thread workgroups, two per CU (LABLOG R4.4; measured, not faster)
+#include "../../tools/experiments/conv_f16_half.inc"
+#endif
+// Sizes of the plane images (common.h: l3d_f16_plane_bytes / l3d_f16_act_bytes / l3d_conv_f16_weight_bytes), one exported spelling:
+// kind 0 = ONE fp16 plane of a [rows][cols] matrix in the tiled layout; 1 = an activation image (h | m' planes + 16 bytes:
+// 2^-T, scratch); 2 = a weight image of [rows = Cout][cols = Cin] (H | Hs | M planes + 16 bytes: 2^-S, |w| maximum, row-sum maximum)
+extern "C" size_t l3d_f16_image_bytes(int kind, long rows, int cols)
 {
-    return (size_t)((cols + 7) / 8) * (size_t)rows * 16;
+    return kind == 0 ? l3d_f16_plane_bytes(rows, cols) : (kind == 1 ? l3d_f16_act_bytes(rows, cols) : l3d_conv_f16_weight_bytes((int)rows, cols));
 }
 
-// weights [Cout][Cin] fp32 -> dst = H | Hs | M planes (3 x l3d_f16_plane_bytes) followed by 16 bytes holding 2^-S (fp32)
-// then the |w| maximum's bits (scratch) and max_r sum_c |w_rc| (fp32, for layers that write fp16 planes)
-extern "C" size_t l3d_conv_f16_weight_bytes(int Cout, int Cin)
-{
-    return 3 * l3d_f16_plane_bytes(Cout, Cin) + 16;
-}
-
+// weights [Cout][Cin] fp32 -> dst = the weight image (device); two small launches
 extern "C" int l3d_conv_f16_split_weights(const float *w, int Cout, int Cin, void *dst, l3d_stream_t stream)
 {
     L3D_REQUIRE(w && dst && Cout > 0 && Cin > 0);
@@ -619,12 +618,6 @@ extern "C" int l3d_conv_f16_split_weights(const float *w, int Cout, int Cin, voi
     hipLaunchKernelGGL(cf_split_w_kernel, dim3((unsigned)l3d_divup(cells, 256)), dim3(256), 0, st, w, Cout, Cin, (const unsigned *)amax,
                        (uint4 *)d, (uint4 *)(d + pb), (uint4 *)(d + 2 * pb), inv);
     return l3d_check_launch();
-}
-
-// an activation image: h | m' planes (2 x l3d_f16_plane_bytes) followed by 16 bytes holding 2^-T (fp32) and scratch
-extern "C" size_t l3d_f16_act_bytes(long rows, int cols)
-{
-    return 2 * l3d_f16_plane_bytes(rows, cols) + 16;
 }
 
 // activations: x [rows][C] (channel_first = 0) or [B][C][Npts] (channel_first = 1, rows = B*Npts) -> dst = activation image
@@ -684,7 +677,13 @@ static int cf_launch(const void *x_planes, const void *w_planes, const float *sc
     }
     if (two_plane) {
         if (narrow || group || amax_out || ypool || out_img || !y) return L3D_ERR_UNSUPPORTED;
+#ifdef CF_HALF
+        hipLaunchKernelGGL(conv_f16_half_kernel, dim3((unsigned)((size_t)(N / CFH_TN) * (Cout / CFH_TM) * B)), dim3(256), CFH_LDS, st,
+                           (const uint4 *)xp, (const uint4 *)(xp + xpb), (const uint4 *)wp, (const uint4 *)(wp + 2 * wpb),
+                           (const float *)(wp + 3 * wpb), (const float *)(xp + 2 * xpb), scale, shift, shift_bstride, B, Cin, Cout, N, relu, y);
+#else
         hipLaunchKernelGGL((conv_f16_kernel<false, false, false, 2>), grid, block, 3 * (4 * CF_TM * 16 + 4 * CF_TN * 16), st, CF_ARGS);
+#endif
         return l3d_check_launch();
     }
     if (narrow && group)         hipLaunchKernelGGL((conv_f16_kernel<true, false, true>), grid, block, nlds, st, CF_ARGS);

@@ -271,7 +271,7 @@ def split_weights_f16(w):
     require_gpu(w)
     w = f32c(w)
     Cout, Cin = w.shape
-    out = torch.empty(lib().l3d_conv_f16_weight_bytes(Cout, Cin), dtype=torch.uint8, device=w.device)
+    out = torch.empty(lib().l3d_f16_image_bytes(2, Cout, Cin), dtype=torch.uint8, device=w.device)
     check(lib().l3d_conv_f16_split_weights(ptr(w), Cout, Cin, ptr(out), stream_ptr()), "l3d_conv_f16_split_weights")
     return out
 
@@ -286,7 +286,7 @@ def split_rows_f16(x, channel_first=False):
     else:
         B, N, C = x.shape
     rows = B * N
-    out = torch.empty(lib().l3d_f16_act_bytes(rows, C), dtype=torch.uint8, device=x.device)
+    out = torch.empty(lib().l3d_f16_image_bytes(1, rows, C), dtype=torch.uint8, device=x.device)
     check(lib().l3d_split_f16_rows(ptr(x), rows, C, int(channel_first), N, ptr(out), ptr(range_flag(x.device)), stream_ptr()),
           "l3d_split_f16_rows")
     return out
@@ -342,7 +342,7 @@ def pointwise_conv_f16(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=No
             raise ValueError("plane output takes a per-channel shift only")
         dev = x_planes.device
         obs = _plane_obs(scale, shift, dev)
-        img = torch.empty(lib().l3d_f16_act_bytes(B * N, Cout), dtype=torch.uint8, device=dev)
+        img = torch.empty(lib().l3d_f16_image_bytes(1, B * N, Cout), dtype=torch.uint8, device=dev)
         _conv_f16("l3d_pointwise_conv_f16[planes]", x_planes, w_planes, scale, shift, 0, B, Cin, Cout, N, relu, img=img, obs=obs)
         return img
     bstride = Cout if (shift is not None and shift.dim() == 2) else 0
@@ -382,7 +382,7 @@ def first_layer_f16_planes(x, w, shift, relu, channel_last):
     Cout = w.shape[0]
     shift = f32c(shift) if shift is not None else None
     xmax = x.abs().max().reshape(1)
-    img = torch.empty(lib().l3d_f16_act_bytes(B * N, Cout), dtype=torch.uint8, device=x.device)
+    img = torch.empty(lib().l3d_f16_image_bytes(1, B * N, Cout), dtype=torch.uint8, device=x.device)
     check(lib().l3d_first_layer_f16_planes(ptr(x), int(channel_last), ptr(w), ptr(shift), ptr(xmax), B, Cin, Cout, N, int(relu),
                                            ptr(img), ptr(range_flag(x.device)), stream_ptr()), "l3d_first_layer_f16_planes")
     return img
@@ -403,7 +403,7 @@ def pointwise_conv_f16_pool(x_planes, B, N, w_planes, Cin, Cout, scale=None, shi
         # a per-cloud shift [B,Cout] is data (pcn.py's pooled half of conv3): not cached
         obs = _plane_obs(scale, shift, dev) if (shift is None or shift.dim() == 1) else \
             torch.stack([shift.abs().max(), scale.abs().max() if scale is not None else torch.ones((), device=dev)]).float()
-        img = torch.empty(lib().l3d_f16_act_bytes(B * N, Cout), dtype=torch.uint8, device=dev)
+        img = torch.empty(lib().l3d_f16_image_bytes(1, B * N, Cout), dtype=torch.uint8, device=dev)
     pk = int(group) if group else 128
     if pool or group:
         part = torch.empty((B, Cout, N // pk), dtype=torch.float32, device=dev)
@@ -696,7 +696,7 @@ def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256), kernel=Non
     if planes:
         if not (v2 and k <= 20 and tuple(widths) == (64, 64, 128, 256)):
             raise ValueError("planes output is produced by the f16 EdgeConv kernel only (usable two-plane block, k <= 20, 64/64/128/256)")
-        out = torch.empty(lib().l3d_f16_act_bytes(B * N, sum(widths)), dtype=torch.uint8, device=xyz_bn3.device)
+        out = torch.empty(lib().l3d_f16_image_bytes(1, B * N, sum(widths)), dtype=torch.uint8, device=xyz_bn3.device)
         args = (ptr(xyz_bn3), ptr(idx), B, N, k, ptr(packed), ptr(out), 2 if unscaled else 1, ptr(range_flag(xyz_bn3.device)), stream_ptr())
         with stage("edgeconv_kernel"):                   # the launch alone: a timing span here holds no Python between its
             rc = lib().l3d_edgeconv_forward_f16b(*args)  # first event and the kernel (bench.py's live roofline timing)

@@ -1,0 +1,250 @@
+"""Differentiable matrix products, row softmax, nn.Linear over rows, square_distance and index_points on the HIP kernels -- the
+TRAINING path of the pointer network and the SVD head.  Everything here is l3d_bmm_f32 (strided batched GEMM
+on the fp32 matrix cores: an exact fp32 fma chain per output element, no transposed copies) and l3d_softmax_rows, forward and
+backward; the forward-only inference path uses the f16x2 kernels instead (utils/transformer.py, utils/svd.py).
+
+reference: utils/transformer.py:127-132 (`attention`: matmul, scale, softmax, matmul), :183-189 / :228-238 (nn.Linear layers),
+utils/svd.py:27-31 (scores -> softmax -> src_corr), utils/model_common_utils.py:19-38 (square_distance), :40-56 (index_points);
+the gradients are what torch.autograd derives for those op sequences.
+"""
+import ctypes as C
+
+import torch
+
+from .._lib import check, f32c, lib, on_device_of, ptr, stream_ptr
+
+_ONES = {}
+
+
+def _ones(n, dev):
+    key = (n, str(dev))
+    t = _ONES.get(key)
+    if t is None:
+        if len(_ONES) > 32:
+            _ONES.clear()
+        t = _ONES[key] = torch.ones(n, dtype=torch.float32, device=dev)
+    return t
+
+
+def _as4(t):
+    while t.dim() < 4:
+        t = t.unsqueeze(0)
+    if t.dim() != 4:
+        raise ValueError(f"bmm: at most two batch axes, got shape {tuple(t.shape)}")
+    return t
+
+
+def _st(t):
+    return (C.c_long * 4)(*[int(s) for s in t.stride()])
+
+
+def bmm(a, b, alpha=1.0, out=None, relu=False, bias=None, bias_axis="n", accumulate=False, parts=1):
+    """a [..., M, K] @ b [..., K, N] (same number of axes, up to two batch axes, any strides -- transposed, sliced or expanded
+    views are read in place) -> act(alpha a b + bias) [..., M, N] fp32.  out: a tensor (any strides) to write / accumulate into."""
+    if a.dtype != torch.float32 or b.dtype != torch.float32 or a.dim() != b.dim() or a.dim() < 2:
+        raise ValueError("bmm: fp32 operands with the same number of axes")
+    a4, b4 = _as4(a), _as4(b)
+    nb1, nb2 = max(a4.shape[0], b4.shape[0]), max(a4.shape[1], b4.shape[1])
+    M, K = a4.shape[2:]
+    K2, N = b4.shape[2:]
+    if K != K2:
+        raise RuntimeError(f"bmm: inner dimensions {K} and {K2} differ")
+    a4, b4 = a4.expand(nb1, nb2, M, K), b4.expand(nb1, nb2, K, N)
+    if out is None:
+        out = torch.empty(tuple(torch.broadcast_shapes(a.shape[:-2], b.shape[:-2])) + (M, N), dtype=torch.float32, device=a.device)
+    if min(M, N, K, nb1, nb2) == 0:
+        return out.zero_() if not accumulate else out
+    o4 = _as4(out)
+    if tuple(o4.shape) != (nb1, nb2, M, N):
+        raise ValueError(f"bmm: out has shape {tuple(out.shape)}, expected batch {nb1} x {nb2} of {M} x {N}")
+    ws = None
+    if parts > 1:
+        ws = torch.empty(nb1 * nb2 * parts * M * N, dtype=torch.float32, device=a.device)
+    flags = (1 if accumulate else 0) | (2 if relu else 0) | ((4 if bias_axis == "n" else 8) if bias is not None else 0)
+    if bias is not None:
+        bias = f32c(bias)
+    with on_device_of(a):
+        check(lib().l3d_bmm_f32(ptr(a4), _st(a4), ptr(b4), _st(b4), ptr(o4), _st(o4), nb1, nb2, M, N, K, float(alpha), flags, ptr(bias),
+                                int(parts), ptr(ws), stream_ptr()), "l3d_bmm_f32")
+    return out
+
+
+def _split_parts(M, N, K):
+    """K ranges for a product with few output tiles and a long K (a weight gradient): enough workgroups for the chip, >= 256 of K each"""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    return max(1, min(K // 256, (512 + tiles - 1) // tiles, 64))
+
+
+class _MatMul(torch.autograd.Function):
+    """alpha a @ b for operands with equal batch shapes; da = alpha g b^T, db = alpha a^T g -- read through transposed strides"""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        ctx.save_for_backward(a, b)
+        ctx.alpha = alpha
+        return bmm(a, b, alpha)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g if g.dtype == torch.float32 else g.float()
+        ga = bmm(g, b.transpose(-1, -2), ctx.alpha) if ctx.needs_input_grad[0] else None
+        gb = bmm(a.transpose(-1, -2), g, ctx.alpha) if ctx.needs_input_grad[1] else None
+        return ga, gb, None
+
+
+def matmul(a, b, alpha=1.0):
+    """differentiable alpha * (a @ b) on the HIP GEMM; a [..., M, K], b [..., K, N] with the same batch shape (no broadcasting)"""
+    if a.shape[:-2] != b.shape[:-2]:
+        raise ValueError("matmul: equal batch shapes (a broadcast operand's gradient would need a reduction)")
+    return _MatMul.apply(a.float(), b.float(), float(alpha))
+
+
+class _SoftmaxRows(torch.autograd.Function):
+    """p = softmax(scale x) over the last axis; dx = scale p (g - sum_j p_j g_j)"""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        xc = f32c(x)
+        cols = xc.shape[-1]
+        p = torch.empty_like(xc)
+        with on_device_of(xc):
+            check(lib().l3d_softmax_rows(ptr(xc), None, xc.numel() // cols, cols, float(scale), ptr(p), stream_ptr()), "l3d_softmax_rows")
+        ctx.save_for_backward(p)
+        ctx.scale = float(scale)
+        return p
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        g = f32c(g)
+        cols = p.shape[-1]
+        dx = torch.empty_like(p)
+        with on_device_of(p):
+            check(lib().l3d_softmax_rows(ptr(p), ptr(g), p.numel() // cols, cols, ctx.scale, ptr(dx), stream_ptr()), "l3d_softmax_rows")
+        return dx, None
+
+
+def softmax_rows(x, scale=1.0):
+    return _SoftmaxRows.apply(x, float(scale))
+
+
+def rows_ok(*tensors):
+    """the HIP route applies: device fp32 tensors, rows of at most 8192 values for the softmax"""
+    return all(t.is_cuda and t.dtype == torch.float32 for t in tensors)
+
+
+def attention_core(query, key, value, scale):
+    """softmax(scale q k^T) v and the attention map (reference utils/transformer.py:127-132 without mask / dropout):
+    q [..., N, d], k [..., M, d], v [..., M, dv] -> ([..., N, dv], p [..., N, M])"""
+    p = softmax_rows(matmul(query, key.transpose(-1, -2)), scale)
+    return matmul(p, value), p
+
+
+class _LinearRows(torch.autograd.Function):
+    """y = act(x W^T + b) over rows x [R, Cin]; dx = g W, dW = g^T x (split-K, parts summed in order), db = 1^T g"""
+
+    @staticmethod
+    def forward(ctx, x, w, b, relu):
+        y = bmm(x, w.t(), bias=b, bias_axis="n", relu=relu)
+        ctx.relu = relu
+        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y = ctx.saved_tensors
+        g = g if g.dtype == torch.float32 else g.float()
+        if ctx.relu:
+            g = g * (y > 0)
+        R = x.shape[0]
+        gx = bmm(g, w) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1]:
+            gw = bmm(g.t(), x, parts=_split_parts(w.shape[0], w.shape[1], R))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = bmm(_ones(R, g.device).view(1, R), g, parts=_split_parts(1, g.shape[1], R)).view(-1)
+        return gx, gw, gb, None
+
+
+def linear(x, lin, relu=False):
+    """lin(x) (+ ReLU) for x [..., Cin]: rows where they lie (no transposed copies), forward and backward on l3d_bmm_f32"""
+    shp = x.shape
+    x2 = x.reshape(-1, shp[-1])
+    if x2.dtype != torch.float32:
+        x2 = x2.float()
+    y = _LinearRows.apply(x2, lin.weight, lin.bias, bool(relu))
+    return y.view(*shp[:-1], y.shape[1])
+
+
+class _SquareDistance(torch.autograd.Function):
+    """d[b,n,m] = |src_n - dst_m|^2 in the reference's rounding order (l3d_square_distance);
+    dsrc = 2 (rowsum(G) src - G dst), ddst = 2 (colsum(G) dst - G^T src)"""
+
+    @staticmethod
+    def forward(ctx, src, dst):
+        s, d = f32c(src), f32c(dst)
+        B, N, Cc = s.shape
+        M = d.shape[1]
+        out = torch.empty((B, N, M), dtype=torch.float32, device=s.device)
+        with on_device_of(s):
+            check(lib().l3d_square_distance(ptr(s), ptr(d), B, N, M, Cc, ptr(out), stream_ptr()), "l3d_square_distance")
+        ctx.save_for_backward(s, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        s, d = ctx.saved_tensors
+        g = f32c(g)
+        B, N, M = g.shape
+        gs = gd = None
+        if ctx.needs_input_grad[0]:
+            rs = bmm(g, _ones(M, g.device).view(1, M, 1).expand(B, M, 1))                    # [B,N,1]
+            gs = bmm(g, d, alpha=-2.0)
+            gs.addcmul_(rs, s, value=2.0)
+        if ctx.needs_input_grad[1]:
+            cs = bmm(g.transpose(1, 2), _ones(N, g.device).view(1, N, 1).expand(B, N, 1))    # [B,M,1]
+            gd = bmm(g.transpose(1, 2), s, alpha=-2.0)
+            gd.addcmul_(cs, d, value=2.0)
+        return gs, gd
+
+
+def square_distance(src, dst):
+    return _SquareDistance.apply(src, dst)
+
+
+class _IndexPoints(torch.autograd.Function):
+    """points[b, idx[b, ...], :] (l3d_index_points); backward: the deterministic scatter-add (l3d_scatter_add_det: entries of
+    one target summed in ascending entry order)"""
+
+    @staticmethod
+    def forward(ctx, points, idx):
+        p = f32c(points)
+        B, N, Cc = p.shape
+        ix = idx.to(torch.int64).contiguous().view(B, -1)
+        S = ix.shape[1]
+        out = torch.empty((B, S, Cc), dtype=torch.float32, device=p.device)
+        with on_device_of(p):
+            check(lib().l3d_index_points(ptr(p), ptr(ix), B, N, Cc, S, ptr(out), stream_ptr()), "l3d_index_points")
+        ctx.save_for_backward(ix)
+        ctx.n = N
+        return out.view(*idx.shape, Cc)
+
+    @staticmethod
+    def backward(ctx, g):
+        (ix,) = ctx.saved_tensors
+        B, S = ix.shape
+        Cc = g.shape[-1]
+        src = f32c(g.reshape(B, S, Cc).transpose(1, 2))                                      # [B,C,S]
+        i32 = ix.to(torch.int32)
+        dst = torch.empty((B, Cc, ctx.n), dtype=torch.float32, device=g.device)
+        with on_device_of(src):
+            ws = torch.empty(lib().l3d_scatter_add_det_workspace_bytes(B, ctx.n, S), dtype=torch.uint8, device=g.device)
+            check(lib().l3d_scatter_add_det(ptr(src), ptr(i32), None, B, Cc, ctx.n, S, 1, ptr(ws), ptr(dst), stream_ptr()),
+                  "l3d_scatter_add_det")
+        return dst.transpose(1, 2), None
+
+
+def index_points(points, idx):
+    return _IndexPoints.apply(points, idx)

@@ -119,7 +119,7 @@ def _factored_first_layer(src_xyz_t, centre_xyz_t, src_feat, centre_feat, idx, o
         part = torch.empty(256, dtype=torch.float32, device=U.device)
         check(lib().l3d_absmax4_partials(ptr(U), U.numel(), ptr(V), V.numel() if V is not None else 0, ptr(sx), sx.numel(),
                                          ptr(cx), cx.numel(), ptr(part), stream_ptr()), "l3d_absmax4_partials")
-        img = torch.empty(lib().l3d_f16_act_bytes(B * S * K, C1), dtype=torch.uint8, device=U.device)
+        img = torch.empty(lib().l3d_f16_image_bytes(1, B * S * K, C1), dtype=torch.uint8, device=U.device)
         check(lib().l3d_group_first_layer_planes_auto(ptr(U), ptr(V), ptr(shp), ptr(wx), ptr(sx), ptr(cx), ptr(idx.contiguous()),
                                                       B, N, S, K, C1, 1, ptr(part), wxr, shmax if V is None else 0.0, ptr(img),
                                                       ptr(_fused.range_flag(U.device)), stream_ptr()),

@@ -55,7 +55,10 @@ def square_distance(src, dst):
     """reference: utils/model_common_utils.py:19-38.  [B,N,3],[B,M,3] -> [B,N,M] fp32."""
     require_gpu(src, dst)
     if torch.is_grad_enabled() and (src.requires_grad or dst.requires_grad):
-        # differentiable like the reference's matmul form (:34-37): its own op sequence through torch
+        # differentiable like the reference's matmul form (:34-37): the forward kernel below, the gradients on l3d_bmm_f32
+        if src.dtype == torch.float32 and dst.dtype == torch.float32 and src.shape[2] == dst.shape[2]:
+            from ..models import _rows
+            return _rows.square_distance(src, dst)
         B, N, _ = src.shape
         M = dst.shape[1]
         dist = -2 * torch.matmul(src, dst.permute(0, 2, 1))
@@ -76,7 +79,11 @@ def index_points(points, idx):
     -> [B,S,C] / [B,S,K,C]."""
     require_gpu(points, idx)
     if torch.is_grad_enabled() and points.requires_grad:
-        # the reference's advanced indexing is differentiable w.r.t. points (:50-55); keep that through torch
+        # the reference's advanced indexing is differentiable w.r.t. points (:50-55): gather kernel forward, deterministic
+        # scatter-add backward
+        if points.dtype == torch.float32 and points.dim() == 3:
+            from ..models import _rows
+            return _rows.index_points(points, idx)
         B = points.shape[0]
         view_shape = [B] + [1] * (idx.dim() - 1)
         batch_indices = torch.arange(B, dtype=torch.long, device=points.device).view(view_shape).expand_as(idx)

@@ -135,9 +135,17 @@ class SVDHead(nn.Module):
         if fused:
             src_corr = soft_correspondence(src_embedding, tgt_embedding, tgt)
         else:
-            scores = torch.matmul(src_embedding.transpose(2, 1).contiguous(), tgt_embedding) / math.sqrt(d_k)
-            scores = torch.softmax(scores, dim=2)
-            src_corr = torch.matmul(tgt, scores.transpose(2, 1).contiguous())
+            if src_embedding.is_cuda and all(z.dtype == torch.float32 for z in (src_embedding, tgt_embedding, tgt)) \
+                    and tgt_embedding.size(2) <= 8192:
+                # autograd live: the reference's op sequence (:27-31) on l3d_bmm_f32 / l3d_softmax_rows, forward and backward,
+                # the transposed operands read through their strides (models/_rows.py)
+                from ..models import _rows
+                scores = _rows.softmax_rows(_rows.matmul(src_embedding.transpose(2, 1), tgt_embedding), 1.0 / math.sqrt(d_k))
+                src_corr = _rows.matmul(tgt, scores.transpose(2, 1))
+            else:
+                scores = torch.matmul(src_embedding.transpose(2, 1).contiguous(), tgt_embedding) / math.sqrt(d_k)
+                scores = torch.softmax(scores, dim=2)
+                src_corr = torch.matmul(tgt, scores.transpose(2, 1).contiguous())
         if torch.is_grad_enabled() and (src_corr.requires_grad or src.requires_grad):
             R, t = _KabschFunction.apply(src, src_corr)
         else:

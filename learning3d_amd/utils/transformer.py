@@ -18,11 +18,12 @@ import torch.nn.functional as F
 FLASH_ATTENTION = True      # l3d_attention_forward for d_k in {32, 64, 128}; False: torch matmul + softmax + matmul
 DEFER_LN_VALUES = True      # sublayer norms write only their fp16 plane image; fp32 values on demand (_ln_values)
 PROJECTION_MAXIMA = True    # the f16x2 q|k|v projections report max|q|, |k|, |v| from their epilogues (False: a pass over q, k, v)
-# autograd live: the nn.Linear layers of the torch route on the HIP conv / dgrad / wgrad kernels (_train.linear_act).  Correct and
-# tested, but OFF: a DCP training step (B 8, N 1024, emb 512) takes 25.6 ms with it against 20.4 ms on rocBLAS -- the layers are
-# [rows, C] x [C, C'] with rows in the last axis' place, and the two transposed copies per layer and direction cost more than the
-# GEMMs save (LABLOG R3.22).  LayerNorm's HIP forward / backward is independent of this switch.
-TRAIN_LINEAR_HIP = os.environ.get("L3D_TRAIN_LINEAR_HIP", "0") != "0"
+# autograd live (a training step, or the recompute behind a checkpointed forward): the nn.Linear layers and the attention core
+# (q k^T, softmax, p v) on l3d_bmm_f32 / l3d_softmax_rows, forward and backward, the tensors read where they lie (models/_rows.py).
+# "conv": the Linear layers through the channel-first conv / dgrad / wgrad kernels instead (two transposed copies per layer and
+# direction: a DCP training step took 25.6 ms with it against 20.4 ms on rocBLAS, LABLOG R3.22 -- kept as a cross-check);
+# "torch": nn.Linear and torch matmul / softmax (rocBLAS).  LayerNorm's HIP forward / backward is independent of this switch.
+TRAIN_LINEAR = os.environ.get("L3D_TRAIN_LINEAR", "rows")
 CHANNEL_FIRST_PASS = True   # a whole encoder-decoder pass in the [B,C,N] layout the GEMMs write (Transformer._pass_cf); False: module by module
 
 _ATT_WS = {}
@@ -125,6 +126,10 @@ def clones(module, N):
 
 def attention(query, key, value, mask=None, dropout=None):
     d_k = query.size(-1)
+    if mask is None and dropout is None and TRAIN_LINEAR == "rows" and query.is_cuda and query.dtype == torch.float32 \
+            and key.size(-2) <= 8192 and query.shape[:-2] == key.shape[:-2] == value.shape[:-2]:
+        from ..models import _rows
+        return _rows.attention_core(query, key, value, 1.0 / math.sqrt(d_k))          # differentiable, HIP forward and backward
     scores = torch.matmul(query, key.transpose(-2, -1)) / math.sqrt(d_k)
     if mask is not None:
         scores = scores.masked_fill(mask == 0, -1e9)
@@ -155,7 +160,7 @@ class LayerNorm(nn.Module):
             if (_fused.gemm_arith() == "f16x2" and x.dim() == 3 and C % 16 == 0 and C <= 512 and x.size(1) % 256 == 0):
                 # also emit y as the fp16 plane image of the f16x2 conv kernel: the Linear layers that read this output
                 # (_linear_cf) then need no split pass; the image rides on the tensor object
-                img = torch.empty(lib().l3d_f16_act_bytes(rows, C), dtype=torch.uint8, device=xc.device)
+                img = torch.empty(lib().l3d_f16_image_bytes(1, rows, C), dtype=torch.uint8, device=xc.device)
                 check(lib().l3d_layernorm_planes(ptr(xc), ptr(self.a_2.detach().contiguous()), ptr(self.b_2.detach().contiguous()),
                                                  float(self.eps), rows, C, ptr(y) if values else None, ptr(img), stream_ptr()),
                       "l3d_layernorm_planes")
@@ -207,11 +212,15 @@ class SublayerConnection(nn.Module):
 
 def _lin(lin, x, relu=False):
     """lin(x) (+ ReLU) where autograd is live (a training step, or the recompute behind a checkpointed forward): the GEMM, its
-    dgrad and its wgrad on the HIP layer kernels when they apply (models/_train.linear_act), torch's otherwise."""
-    if TRAIN_LINEAR_HIP and x.is_cuda and torch.is_grad_enabled() and type(lin) is nn.Linear and lin.bias is not None:
-        from ..models._train import hip_layers_ok, linear_act
-        if hip_layers_ok(x) and x.numel() > 0:
-            return linear_act(x, lin, relu=relu)
+    dgrad and its wgrad on l3d_bmm_f32 over the rows as they lie (models/_rows.linear); TRAIN_LINEAR picks the other routes."""
+    if x.is_cuda and torch.is_grad_enabled() and type(lin) is nn.Linear and x.numel() > 0 and x.dtype == torch.float32:
+        if TRAIN_LINEAR == "rows":
+            from ..models import _rows
+            return _rows.linear(x, lin, relu=relu)
+        if TRAIN_LINEAR == "conv" and lin.bias is not None:
+            from ..models._train import hip_layers_ok, linear_act
+            if hip_layers_ok(x):
+                return linear_act(x, lin, relu=relu)
     y = lin(x)
     return F.relu(y) if relu else y
 
@@ -278,7 +287,7 @@ class MultiHeadedAttention(nn.Module):
                         and _fused.f16_eligible(out_lin.in_features, out_lin.out_features, n_q)):
                     # both GEMMs as f16x2 (operand scales from the tensors' maxima); the context leaves the kernel as the
                     # fp16 plane image of the f16x2 conv kernel, so the output projection needs no split pass either
-                    img = torch.empty(lib().l3d_f16_act_bytes(nb * n_q, C_), dtype=torch.uint8, device=q.device)
+                    img = torch.empty(lib().l3d_f16_image_bytes(1, nb * n_q, C_), dtype=torch.uint8, device=q.device)
                     check(lib().l3d_attention_forward_f16b(ptr(q), ptr(k), ptr(v), nb, self.h, self.d_k, n_q, n_k,
                                                            q.stride(0), k.stride(0), v.stride(0), 1.0 / math.sqrt(self.d_k),
                                                            ptr(ws), int(bool(have_max)), None, ptr(img), stream_ptr()),
@@ -456,7 +465,7 @@ class Transformer(nn.Module):
         from .._lib import check, lib, ptr, stream_ptr
         B, C, N = x.shape
         y = torch.empty_like(x) if values else None
-        img = torch.empty(lib().l3d_f16_act_bytes(B * N, C), dtype=torch.uint8, device=x.device) if planes else None
+        img = torch.empty(lib().l3d_f16_image_bytes(1, B * N, C), dtype=torch.uint8, device=x.device) if planes else None
         check(lib().l3d_layernorm_planes_cf(ptr(x), ptr(norm.a_2.detach().contiguous()), ptr(norm.b_2.detach().contiguous()),
                                             float(norm.eps), B, C, N, ptr(y) if values else None, ptr(img) if planes else None,
                                             stream_ptr()), "l3d_layernorm_planes_cf")
@@ -480,7 +489,7 @@ class Transformer(nn.Module):
             k, v = kv[:, :C], kv[:, C:]
             have_max = getattr(q, "_l3d_amax", False) and getattr(kv, "_l3d_amax", False)
         attn.attn = None                                           # the [B,h,N,M] map is never formed
-        ctx = torch.empty(lib().l3d_f16_act_bytes(B * N, C), dtype=torch.uint8, device=x.device)
+        ctx = torch.empty(lib().l3d_f16_image_bytes(1, B * N, C), dtype=torch.uint8, device=x.device)
         check(lib().l3d_attention_forward_f16b(ptr(q), ptr(k), ptr(v), B, attn.h, attn.d_k, N, M, q.stride(0), k.stride(0), v.stride(0),
                                                1.0 / math.sqrt(attn.d_k), ptr(ws), int(bool(have_max)), None, ptr(ctx), stream_ptr()),
               "l3d_attention_forward_f16b")

@@ -198,16 +198,17 @@ def test_layernorm_hip_forward_backward_vs_fp64():
         _fused.TRAIN_HIP = old
 
 
-@pytest.mark.parametrize("linear_hip", [False, True])
-def test_pointer_network_training_gradients_vs_fp64(linear_hip, monkeypatch):
-    """utils/transformer.py Transformer with autograd live (examples/train_dcp.py): LayerNorm on its HIP forward / backward kernels,
-    the nn.Linear layers on rocBLAS (default) or on the HIP layer kernels (TRAIN_LINEAR_HIP: forward, dgrad, wgrad), the attention
-    core on torch ops.  Outputs and every parameter / input gradient against the same module in fp64 (its torch route, which is the
-    reference's op sequence): within 2e-5 of the gradient's scale (gradients that are zero by symmetry -- the key projection's bias
-    under the softmax -- against the largest gradient)."""
+@pytest.mark.parametrize("route", ["rows", "conv", "torch"])
+def test_pointer_network_training_gradients_vs_fp64(route, monkeypatch):
+    """utils/transformer.py Transformer with autograd live (examples/train_dcp.py): LayerNorm on its HIP forward / backward kernels;
+    the nn.Linear layers and the attention core (q k^T, softmax, p v) on l3d_bmm_f32 / l3d_softmax_rows, forward and backward
+    (TRAIN_LINEAR "rows", the default), or the Linear layers on the channel-first conv / dgrad / wgrad kernels ("conv"), or both on
+    torch / rocBLAS ("torch").  Outputs and every parameter / input gradient against the same module in fp64 (its torch route, which
+    is the reference's op sequence): within 2e-5 of the gradient's scale (gradients that are zero by symmetry -- the key
+    projection's bias under the softmax -- against the largest gradient)."""
     import copy
     from learning3d_amd.utils import transformer as T
-    monkeypatch.setattr(T, "TRAIN_LINEAR_HIP", linear_hip)
+    monkeypatch.setattr(T, "TRAIN_LINEAR", route)
     torch.manual_seed(11)
     net = T.Transformer(64, 1, 0.0, 128, 4).cuda().train()
     net64 = copy.deepcopy(net).double()
@@ -218,7 +219,12 @@ def test_pointer_network_training_gradients_vs_fp64(linear_hip, monkeypatch):
     with _lib_log() as log:
         a, b = net(src, tgt)
         ((a * w0).sum() + (b * w1).sum()).backward()
-    assert "l3d_layernorm_ref_backward" in log and ("l3d_wgrad" in log) == linear_hip, log
+    assert "l3d_layernorm_ref_backward" in log and ("l3d_wgrad" in log) == (route == "conv"), log
+    assert ("l3d_bmm_f32" in log and "l3d_softmax_rows" in log) == (route == "rows"), log
+    if route == "rows":
+        # 12 Linear layers x (forward, dgrad, wgrad, bias) + 3 attention cores x 2 passes x (2 forward + 4 backward products)
+        assert log.count("l3d_bmm_f32") >= 12 * 2 * 4 + 6 * 6, log.count("l3d_bmm_f32")
+        assert log.count("l3d_softmax_rows") >= 12, log.count("l3d_softmax_rows")      # 6 cores, forward and backward (+ a recompute)
     s64, t64 = src.detach().double().requires_grad_(), tgt.detach().double().requires_grad_()
     a64, b64 = net64(s64, t64)
     ((a64 * w0.double()).sum() + (b64 * w1.double()).sum()).backward()
@@ -229,6 +235,142 @@ def test_pointer_network_training_gradients_vs_fp64(linear_hip, monkeypatch):
         assert got is not None and want is not None, name
         err = float((got.double() - want).abs().max())
         assert err <= 2e-5 * float(want.abs().max()) + 1e-7 * gmax, (name, err, float(want.abs().max()), gmax)
+
+
+def test_bmm_kernel_every_layout_vs_fp64():
+    """l3d_bmm_f32 (bmm.hip): operands read through their strides -- plain, transposed, sliced, head-split and broadcast views --
+    at tile-edge shapes, with bias / ReLU / accumulate and split K.  An exact fp32 fma chain per element: against fp64 within the
+    fp32 dot-product bound (K eps |a|.|b|), and no worse than torch's own fp32 matmul by more than 4x."""
+    from learning3d_amd.models import _rows
+    g = torch.Generator().manual_seed(5)
+
+    def rnd(*shape):
+        return torch.randn(shape, generator=g).cuda()
+
+    cases = []
+    a, b = rnd(3, 200, 70), rnd(3, 70, 150)
+    cases.append(("plain", a, b))
+    cases.append(("a transposed", rnd(3, 70, 200).transpose(1, 2), b))
+    cases.append(("b transposed", a, rnd(3, 150, 70).transpose(1, 2)))
+    cases.append(("both transposed, 2-D", rnd(129, 257).t(), rnd(130, 129).t()))
+    big = rnd(2, 300, 4 * 32)                                                    # [B, N, h d] -> [B, h, N, d] views (attention heads)
+    q = big.view(2, 300, 4, 32).transpose(1, 2)
+    k = rnd(2, 260, 4 * 32).view(2, 260, 4, 32).transpose(1, 2)
+    cases.append(("heads q k^T", q, k.transpose(-1, -2)))
+    cases.append(("sliced", rnd(2, 100, 96)[:, 3:77, 5:69], rnd(2, 64, 40)))
+    cases.append(("thin N=1", rnd(2, 500, 333), rnd(2, 333, 1)))
+    cases.append(("thin M=1", rnd(1, 1, 1000), rnd(1, 1000, 48)))
+    cases.append(("K=3", rnd(4, 3, 77).transpose(1, 2), rnd(4, 3, 90)))
+    for name, x, y in cases:
+        got = _rows.bmm(x, y)
+        want = torch.matmul(x.double(), y.double())
+        ref = torch.matmul(x, y)
+        bound = torch.matmul(x.double().abs(), y.double().abs()) * (x.shape[-1] * 2.0 ** -24) + 1e-30
+        err, err_t = (got.double() - want).abs(), (ref.double() - want).abs()
+        assert bool((err <= bound).all()), (name, float((err / bound).max()))
+        assert float(err.max()) <= 4 * float(err_t.max()) + 1e-6 * float(want.abs().max()), (name, float(err.max()), float(err_t.max()))
+    # epilogue flags
+    x, w, bias = rnd(300, 96), rnd(80, 96), rnd(80)
+    got = _rows.bmm(x, w.t(), bias=bias, relu=True)
+    want = torch.relu(x.double() @ w.double().t() + bias.double())
+    assert float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    got = _rows.bmm(w, x.t(), bias=bias, bias_axis="m", alpha=0.5)
+    want = 0.5 * (w.double() @ x.double().t()) + bias.double()[:, None]
+    assert float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    acc = rnd(300, 80)
+    want = acc.double() + x.double() @ w.double().t()
+    _rows.bmm(x, w.t(), out=acc, accumulate=True)
+    assert float((acc.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    # a strided destination (columns of a wider tensor)
+    wide = torch.zeros((300, 200), device="cuda")
+    _rows.bmm(x, w.t(), out=wide[:, 40:120])
+    assert float((wide[:, 40:120].double() - x.double() @ w.double().t()).abs().max()) <= 1e-5 * float(want.abs().max())
+    assert float(wide[:, :40].abs().max()) == 0 and float(wide[:, 120:].abs().max()) == 0
+    # split K (a weight gradient: K = rows): same value every run, and within the bound
+    gy, xx = rnd(5000, 96), rnd(5000, 64)
+    want = gy.double().t() @ xx.double()
+    r1 = _rows.bmm(gy.t(), xx, parts=_rows._split_parts(96, 64, 5000))
+    r2 = _rows.bmm(gy.t(), xx, parts=_rows._split_parts(96, 64, 5000))
+    assert _rows._split_parts(96, 64, 5000) > 1 and torch.equal(r1, r2)
+    assert float((r1.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+def test_softmax_rows_forward_backward_vs_fp64():
+    from learning3d_amd.models import _rows
+    g = torch.Generator().manual_seed(6)
+    for rows, cols, scale in ((37, 1024, 0.0884), (5, 3, 1.0), (3, 8192, 0.5), (64, 300, 2.0)):
+        x = (torch.randn((rows, cols), generator=g) * 3).cuda().requires_grad_()
+        w = torch.randn((rows, cols), generator=g).cuda()
+        p = _rows.softmax_rows(x, scale)
+        (p * w).sum().backward()
+        x64 = x.detach().double().requires_grad_()
+        p64 = torch.softmax(x64 * scale, dim=-1)
+        (p64 * w.double()).sum().backward()
+        assert float((p.double() - p64).abs().max()) <= 1e-6
+        assert float((x.grad.double() - x64.grad).abs().max()) <= 1e-5 * float(x64.grad.abs().max()) + 1e-9
+
+
+def test_square_distance_index_points_and_svd_head_gradients_on_hip():
+    """utils/model_common_utils.square_distance / index_points and the SVD head's score route with autograd live: forward through
+    the kernels, gradients through l3d_bmm_f32 / l3d_scatter_add_det; against torch autograd on the reference's op sequence in fp64."""
+    from learning3d_amd.utils import model_common_utils as M
+    from learning3d_amd.utils.svd import SVDHead
+    g = torch.Generator().manual_seed(7)
+    src = torch.randn((3, 200, 3), generator=g).cuda().requires_grad_()
+    dst = torch.randn((3, 150, 3), generator=g).cuda().requires_grad_()
+    w = torch.randn((3, 200, 150), generator=g).cuda()
+    with _lib_log() as log:
+        d = M.square_distance(src, dst)
+        (d * w).sum().backward()
+    assert "l3d_square_distance" in log and log.count("l3d_bmm_f32") == 4, log
+    s64, d64 = src.detach().double().requires_grad_(), dst.detach().double().requires_grad_()
+    ref = -2 * torch.matmul(s64, d64.permute(0, 2, 1)) + (s64 ** 2).sum(-1).view(3, 200, 1) + (d64 ** 2).sum(-1).view(3, 1, 150)
+    (ref * w.double()).sum().backward()
+    assert float((d.double() - ref).abs().max()) <= 1e-5
+    for got, want in ((src.grad, s64.grad), (dst.grad, d64.grad)):
+        assert float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    # index_points: duplicates in idx (the scatter adds them up, in a fixed order)
+    pts = torch.randn((2, 50, 7), generator=g).cuda().requires_grad_()
+    idx = torch.randint(0, 50, (2, 30, 4), generator=g).cuda()
+    wv = torch.randn((2, 30, 4, 7), generator=g).cuda()
+    with _lib_log() as log:
+        out = M.index_points(pts, idx)
+        (out * wv).sum().backward()
+    assert "l3d_index_points" in log and "l3d_scatter_add_det" in log, log
+    p64 = pts.detach().double().requires_grad_()
+    bi = torch.arange(2, device="cuda").view(2, 1, 1).expand_as(idx)
+    ref = p64[bi, idx, :]
+    (ref * wv.double()).sum().backward()
+    assert torch.equal(out.detach(), ref.float()) and float((pts.grad.double() - p64.grad).abs().max()) <= 1e-6
+    # the SVD head with gradients flowing into the embeddings (examples/train_dcp.py)
+    head = SVDHead(emb_dims=64, input_shape="bnc").cuda()
+    se = torch.randn((2, 64, 128), generator=g).cuda().requires_grad_()
+    te = torch.randn((2, 64, 128), generator=g).cuda().requires_grad_()
+    xs, xt = torch.randn((2, 128, 3), generator=g).cuda(), torch.randn((2, 128, 3), generator=g).cuda()
+    with _lib_log() as log:
+        R, t = head(se, te, xs, xt)
+        ((R * torch.arange(9., device="cuda").view(1, 3, 3)).sum() + t.sum()).backward()
+    assert "l3d_bmm_f32" in log and "l3d_softmax_rows" in log, log
+    import math
+    s2, t2 = se.detach().double().requires_grad_(), te.detach().double().requires_grad_()
+    scores = torch.softmax(torch.matmul(s2.transpose(2, 1), t2) / math.sqrt(64), dim=2)
+    corr = torch.matmul(xt.double().permute(0, 2, 1), scores.transpose(2, 1))
+    sd = xs.double().permute(0, 2, 1)
+    sc_, cc_ = sd - sd.mean(2, keepdim=True), corr - corr.mean(2, keepdim=True)
+    H = sc_ @ cc_.transpose(2, 1)
+    Rs = []
+    for i in range(2):                                                       # utils/svd.py:38-49 of the reference
+        u, _, v = torch.svd(H[i])
+        r = v @ u.t()
+        if float(torch.det(r.detach())) < 0:
+            r = (v @ torch.diag(torch.tensor([1.0, 1.0, -1.0], dtype=torch.float64, device="cuda"))) @ u.t()
+        Rs.append(r)
+    R2 = torch.stack(Rs)
+    tt2 = (torch.matmul(-R2, sd.mean(2, keepdim=True)) + corr.mean(2, keepdim=True)).view(2, 3)
+    ((R2 * torch.arange(9., device="cuda", dtype=torch.float64).view(1, 3, 3)).sum() + tt2.sum()).backward()
+    assert float((R.double() - R2).abs().max()) <= 1e-5
+    for got, want in ((se.grad, s2.grad), (te.grad, t2.grad)):
+        assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-9
 
 
 class _lib_log:

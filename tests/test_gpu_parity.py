@@ -1071,7 +1071,7 @@ def test_flash_attention_vs_fp64():
         ws = torch.zeros(4, dtype=torch.int32, device=qd.device)
         e3 = out.cpu().numpy().reshape(B, H, D, N) - want
         outb = torch.empty_like(qd)
-        imgb = torch.empty(lib().l3d_f16_act_bytes(B * N, H * D), dtype=torch.uint8, device=qd.device)
+        imgb = torch.empty(lib().l3d_f16_image_bytes(1, B * N, H * D), dtype=torch.uint8, device=qd.device)
         check(lib().l3d_attention_forward_f16b(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, H * D * N, H * D * M, H * D * M,
                                                float(1 / np.sqrt(D)), ptr(ws), 0, ptr(outb), ptr(imgb), stream_ptr()), "l3d_attention_forward_f16b")
         gotb = outb.cpu().numpy().reshape(B, H, D, N)
@@ -1194,7 +1194,7 @@ def test_transformer_channel_first_pass():
         a = rng.uniform(0.5, 1.5, C).astype(np.float32); b = rng.uniform(-0.5, 0.5, C).astype(np.float32)
         x64 = x.astype(np.float64)
         want = a[None, :, None] * (x64 - x64.mean(1, keepdims=True)) / (x64.std(1, ddof=1, keepdims=True) + 1e-6) + b[None, :, None]
-        y = torch.empty((B, C, N), device="cuda"); img = torch.empty(lib().l3d_f16_act_bytes(B * N, C), dtype=torch.uint8, device="cuda")
+        y = torch.empty((B, C, N), device="cuda"); img = torch.empty(lib().l3d_f16_image_bytes(1, B * N, C), dtype=torch.uint8, device="cuda")
         tx, ta, tb = dev(x), dev(a), dev(b)                       # held: a temporary's block would be handed to the next allocation
         check(lib().l3d_layernorm_planes_cf(ptr(tx), ptr(ta), ptr(tb), 1e-6, B, C, N, ptr(y), ptr(img), stream_ptr()), "ln cf")
         np.testing.assert_allclose(y.cpu().numpy(), want, rtol=2e-6, atol=2e-6)
@@ -1819,7 +1819,7 @@ def test_layernorm_planes_matches_layernorm_and_feeds_conv_f16():
         y0 = torch.empty_like(x)
         check(lib().l3d_layernorm_ref(ptr(x), ptr(a), ptr(b), 1e-6, B * N, C, ptr(y0), stream_ptr()), "ln")
         y1 = torch.empty_like(x)
-        img = torch.empty(lib().l3d_f16_act_bytes(B * N, C), dtype=torch.uint8, device="cuda")
+        img = torch.empty(lib().l3d_f16_image_bytes(1, B * N, C), dtype=torch.uint8, device="cuda")
         check(lib().l3d_layernorm_planes(ptr(x), ptr(a), ptr(b), 1e-6, B * N, C, ptr(y1), ptr(img), stream_ptr()), "lnp")
         assert torch.equal(y0, y1)
         w = dev((rng.standard_normal((256, C)) / C ** 0.5).astype(np.float32))
@@ -1846,7 +1846,7 @@ def test_attention_f16_context_planes_feed_conv_f16():
         v = dev((rng.standard_normal((B, C, M)) * vs).astype(np.float32))
         ws = torch.zeros(4, dtype=torch.int32, device="cuda")
         ctx = torch.empty((B, C, N), dtype=torch.float32, device="cuda")
-        img = torch.empty(lib().l3d_f16_act_bytes(B * N, C), dtype=torch.uint8, device="cuda")
+        img = torch.empty(lib().l3d_f16_image_bytes(1, B * N, C), dtype=torch.uint8, device="cuda")
         check(lib().l3d_attention_forward_f16b(ptr(q), ptr(k), ptr(v), B, H, D, N, M, C * N, C * M, C * M, float(1 / np.sqrt(D)),
                                                ptr(ws), 0, ptr(ctx), ptr(img), stream_ptr()), "att")
         w = dev((rng.standard_normal((256, C)) / C ** 0.5).astype(np.float32))
@@ -2108,7 +2108,7 @@ def test_group_first_layer_planes_equals_fp32_rows():
         want = g + (V[:, :, None, :] if with_v else sh) + d @ wx.t()
         np.testing.assert_allclose(rows.view(B, S, K, C1).cpu().numpy(), torch.relu(want).cpu().numpy(), rtol=1e-5, atol=1e-5)
         bound = (U.abs().max() + (V.abs().max() if with_v else sh.abs().max()) + wx.abs().sum(1).max() * (xyz.abs().max() + cen.abs().max())).reshape(1)
-        img = torch.empty(lib().l3d_f16_act_bytes(B * S * K, C1), dtype=torch.uint8, device="cuda")
+        img = torch.empty(lib().l3d_f16_image_bytes(1, B * S * K, C1), dtype=torch.uint8, device="cuda")
         part = torch.empty(256, dtype=torch.float32, device="cuda")
         check(lib().l3d_absmax4_partials(ptr(U), U.numel(), ptr(V), V.numel() if with_v else 0, ptr(xyz), xyz.numel(), ptr(cen), cen.numel(),
                                          ptr(part), stream_ptr()), "absmax4")

@@ -13,7 +13,7 @@ for _ in range(30): fn()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 30
 print(f"attention B={B} H={H} D={D} N={N}: {dt*1e6:.1f} us  {4.0*B*H*N*N*D/dt/1e12:.1f} TFLOP/s fp32-equiv")
 ws = torch.zeros(4, dtype=torch.int32, device="cuda")
-img = torch.empty(lib().l3d_f16_act_bytes(B * N, H * D), dtype=torch.uint8, device="cuda")
+img = torch.empty(lib().l3d_f16_image_bytes(1, B * N, H * D), dtype=torch.uint8, device="cuda")
 for name, kw in (("f16x2 restructured (attention_f16b), fp32 ctx, incl. absmax", dict(mr=0, c=ctx, im=None)),
                  ("f16x2 restructured, maxima ready, plane image out (DCP's call)", dict(mr=1, c=None, im=img))):
     fnb = lambda: check(lib().l3d_attention_forward_f16b(ptr(q), ptr(k), ptr(v), B, H, D, N, N, H * D * N, H * D * N, H * D * N, 1.0 / D ** 0.5,
