@@ -550,8 +550,25 @@ def main_c5(args, rank, world, local, dev, dist, parallel):
     per_rank = torch.stack(per_rank).cpu()
     elapsed = float(per_rank[:, 0].max())
     if rank == 0:
-        grp_ms = stage_ms["group_kernel"]
-        grp_gbs = B_PER_GPU * C5_GROUP_BYTES_PER_CLOUD / (grp_ms * 1e-3) / 1e9
+        fused = "group_kernel" not in stage_ms          # sa_fused.hip: gather + three layers + max in one launch (the "mlp" stage)
+        mlp_tf = B_PER_GPU * C5_MLP_FLOP_PER_CLOUD / (stage_ms["mlp"] * 1e-3) / 1e12 if stage_ms.get("mlp") else None
+        if fused:
+            roof = {"kernel": "sa_mlp3_kernel<8,32,32,64>", "bound": "mfma", "achieved": mlp_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": mlp_tf / MFMA_F32_PEAK_TF if mlp_tf else None, "traffic": pmc_traffic("sa_mlp3"), "traffic_source": pmc_source("sa_mlp3"),
+                    "avg_launch_ms": stage_ms.get("mlp"), "algorithmic_flop_per_launch": B_PER_GPU * C5_MLP_FLOP_PER_CLOUD,
+                    # indices in, six gathered values per (centroid, neighbour), 64 maxima per centroid out
+                    "algorithmic_bytes_per_launch": B_PER_GPU * (C5_S * C5_K * 4 + C5_S * C5_K * 6 * 4 + 64 * C5_S * 4),
+                    "note": "the set-abstraction layer behind the ball query as one kernel (gather, 6 -> 32 -> 32 -> 64 on the fp32 MFMA, max over "
+                            "K): exact fp32 fma chains, priced against the fp32 matrix peak; the step itself is bound by furthest point "
+                            "sampling's 1024 dependent rounds (one workgroup per cloud) packed beside it, see kernels.fps_ms and config.pipeline"}
+        else:
+            grp_ms = stage_ms["group_kernel"]
+            grp_gbs = B_PER_GPU * C5_GROUP_BYTES_PER_CLOUD / (grp_ms * 1e-3) / 1e9
+            roof = {"kernel": "group_concat_kernel", "bound": "hbm", "achieved": grp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": grp_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("group_c5"), "traffic_source": pmc_source("group_c5"),
+                    "avg_launch_ms": grp_ms, "algorithmic_bytes_per_launch": B_PER_GPU * C5_GROUP_BYTES_PER_CLOUD,
+                    "note": "microseconds of the step: the step is bound by furthest point sampling's 1024 dependent rounds "
+                            "(latency, one workgroup per cloud), see kernels.fps_ms"}
         out = {
             "metric": "clouds/sec FlowNet3D sa1 set-conv (FPS + ball query + grouping + shared MLP) B=32 per GPU N=8192 -- BASELINE configs[4], "
                       "NOT the headline metric (that is the default --workload c2 line)",
@@ -559,8 +576,8 @@ def main_c5(args, rank, world, local, dev, dist, parallel):
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "f32 (index work int32; shared MLP on the fp32 MFMA)", "data": "synthetic",
             "config": {"workload": "configs[4] (NOT the headline config; --workload c5): FlowNet3D sa1 set-conv forward -- furthest "
-                                   "point sampling 8192 -> 1024, ball query r=0.5 K=16, grouping, shared MLP 6->32->32->64 + max "
-                                   "over K, eval, random-init weights; 32 clouds per GPU, two resident input batches consumed alternately",
+                                   "point sampling 8192 -> 1024, ball query r=0.5 K=16, grouping + shared MLP 6->32->32->64 + max "
+                                   "over K (one fused kernel), eval, random-init weights; 32 clouds per GPU, two resident input batches consumed alternately",
                        "global_batch": world * B_PER_GPU, "num_points": C5_N, "npoint": C5_S, "nsample": C5_K, "radius": C5_R,
                        "launch": "hipGraph replay" if graphs is not None else "eager launches",
                        "pipeline": (f"furthest point sampling (a function of the input coordinates alone; one workgroup per cloud = 32 of 256 CUs "
@@ -575,16 +592,9 @@ def main_c5(args, rank, world, local, dev, dist, parallel):
             "rank0_placement": getattr(args, "placement", None),
             "multi_gpu_note": "no N > 1 number has been measured by the builder in any round (a gpurun box has one GPU)",
             "serial_ms_per_step": serial_ms,
-            # the one HBM-bound op of the path: the grouping gather
-            "roofline": {"kernel": "group_concat_kernel", "bound": "hbm", "achieved": grp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": grp_gbs / HBM_PEAK_GBS, "traffic": pmc_traffic("group_c5"),
-                         "traffic_source": pmc_source("group_c5"), "avg_launch_ms": grp_ms,
-                         "algorithmic_bytes_per_launch": B_PER_GPU * C5_GROUP_BYTES_PER_CLOUD,
-                         "note": "microseconds of a ~1 ms step: the step is bound by furthest point sampling's 1024 dependent rounds "
-                                 "(latency, one workgroup per cloud), see kernels.fps_ms"},
-            "kernels": {"fps_ms": stage_ms.get("fps"), "ball_query_ms": stage_ms.get("ball_query"), "group_ms": grp_ms,
-                        "mlp_ms": stage_ms.get("mlp"),
-                        "mlp_tflops": B_PER_GPU * C5_MLP_FLOP_PER_CLOUD / (stage_ms["mlp"] * 1e-3) / 1e12 if stage_ms.get("mlp") else None,
+            "roofline": roof,
+            "kernels": {"fps_ms": stage_ms.get("fps"), "ball_query_ms": stage_ms.get("ball_query"), "group_ms": stage_ms.get("group_kernel"),
+                        "mlp_ms": stage_ms.get("mlp"), "mlp_tflops": mlp_tf, "set_abstraction_fused": fused,
                         "fps_pair_evals_per_s": B_PER_GPU * C5_S * C5_N / (stage_ms["fps"] * 1e-3) if stage_ms.get("fps") else None,
                         "note": "HIP events around the stages of serial eager steps after the timed region"},
             "digest": [float(v) for v in digest_v],
@@ -607,7 +617,7 @@ def main():
     ap.add_argument("--c5-serial", action="store_true",
                     help="--workload c5: sampling and the rest of each batch on one stream (default: batch i + 1's furthest point "
                          "sampling runs on a second stream beside batch i's ball query / grouping / MLP)")
-    ap.add_argument("--c5-depth", type=int, default=2,
+    ap.add_argument("--c5-depth", type=int, default=3,
                     help="--workload c5: how many batches ahead furthest point sampling is issued (one stream each; 1 = only the next batch's)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the untimed configs[2..4] extras (DCP-v2 forward, PCN + Chamfer, FlowNet3D sa1 / forward) of the c2 line")

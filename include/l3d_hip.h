@@ -278,13 +278,11 @@ int l3d_attention_forward_f16b(const float *q, const float *k, const float *v, i
                                float *ctx, void *ctx_img, l3d_stream_t stream);
 
 /* LayerNorm of DCP's pointer network == utils/transformer.py:109-119 (unbiased std, eps added to std):
- *   y[r][:] = a * (x[r][:] - mean_r) / (std_r + eps) + b,   x, y [rows][C] fp32, C % 4 == 0, C <= 2048. */
-int l3d_layernorm_ref(const float *x, const float *a, const float *b, float eps, long rows, int C, float *y,
-                      l3d_stream_t stream);
-/* The same, and additionally the output as the fp16 activation image l3d_pointwise_conv_f16 consumes (img:
- * l3d_f16_image_bytes(1, rows, C) bytes): the Linear layers behind a LayerNorm then run as f16x2 with no split pass.  The
- * plane scale comes from the layer's parameters (|y_c| <= |a_c| sqrt(C-1) + |b_c|).  C % 8 == 0, C <= 512.  y may be NULL
- * (image only). */
+ *   y[r][:] = a * (x[r][:] - mean_r) / (std_r + eps) + b,   x, y [rows][C] fp32.
+ * img == NULL: the fp32 values only (C % 4 == 0, C <= 2048).  img given: additionally (or, with y == NULL, only) the output as the
+ * fp16 activation image l3d_pointwise_conv_f16 consumes (l3d_f16_image_bytes(1, rows, C) bytes): the Linear layers behind a
+ * LayerNorm then run as f16x2 with no split pass; the plane scale comes from the layer's parameters
+ * (|y_c| <= |a_c| sqrt(C-1) + |b_c|); C % 8 == 0, C <= 512; y bit-identical to the img == NULL call. */
 int l3d_layernorm_planes(const float *x, const float *a, const float *b, float eps, long rows, int C, float *y, void *img,
                          l3d_stream_t stream);
 /* The same LayerNorm over the channels of a CHANNEL-FIRST tensor x [B][C][N] (one normalisation per point), output as
@@ -546,12 +544,23 @@ int l3d_max_last(const float *x, long R, int K, float *v, unsigned char *idx, l3
 int l3d_max_last_backward(const float *g, const unsigned char *idx, long R, int K, float *gx, l3d_stream_t stream);
 
 /* Backward of the pointer network's LayerNorm (utils/transformer.py:109-119: unbiased std, eps added to std; forward =
- * l3d_layernorm_ref): x, g = dL/dy, dx [rows][C]; a [C]; da, db [C] summed over the rows in a fixed order (workgroup partials in
+ * l3d_layernorm_planes): x, g = dL/dy, dx [rows][C]; a [C]; da, db [C] summed over the rows in a fixed order (workgroup partials in
  * the workspace, then fp64 in workgroup order).  workspace: l3d_layernorm_backward_workspace_floats(rows, C) floats.
  * C % 4 == 0, C <= 2048, 16-byte aligned pointers. */
 size_t l3d_layernorm_backward_workspace_floats(long rows, int C);
 int l3d_layernorm_ref_backward(const float *x, const float *a, const float *g, float eps, long rows, int C, float *dx,
                                float *workspace, float *da, float *db, l3d_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * A whole narrow set-abstraction layer behind the ball query in one kernel (sa_fused.hip; models/flownet3d.py:108-122
+ * PointNetSetAbstraction.forward at sa1 = 3+3 -> 32 -> 32 -> 64, K 16, flownet3d.py:272; pointnet2's 3+D -> 64 -> 64 -> 128):
+ *   out [B][C3][S] = max_k relu(s3 (W3 relu(s2 (W2 relu(s1 (W1 [xyz[idx] - new_xyz | feat[idx]]) + t1)) + t2)) + t3)
+ * xyz [B][N][3], new_xyz [B][S][3], feat [B][D][N] (NULL when D == 0; 3 + D <= 16), idx int32 [B][S][K] (K in {8, 16, 32, 64}),
+ * (C1, C2, C3) in {(32, 32, 64), (64, 64, 128)}, else L3D_ERR_UNSUPPORTED.  params (device floats, 16-byte aligned): per layer the
+ * weights as [Cout][4][Cin / 4] (element [n][g][s] = w[n][4 s + g]; layer 1's input channels zero-padded to 8 when 3 + D <= 8,
+ * else to 16) followed by scale [Cout] and shift [Cout] (the folded eval-mode BatchNorm).  fp32 MFMA: an exact fp32 fma chain. */
+int l3d_sa_mlp3_fused(const float *xyz, const float *new_xyz, const float *feat, const int32_t *idx, const float *params, int B,
+                      int N, int S, int K, int D, int C1, int C2, int C3, float *out, l3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Strided batched fp32 GEMM and row softmax (bmm.hip): the TRAINING path of the pointer network and the SVD head -- the

@@ -69,7 +69,7 @@ SIGNATURES = {
     "l3d_soft_correspondence": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P],
     "l3d_attention_forward_strided": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _P],
     "l3d_attention_forward_f16b": [_P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _F, _P, _I, _P, _P, _P],
-    "l3d_layernorm_ref": [_P, _P, _P, _F, _L, _I, _P, _P],
+    "l3d_sa_mlp3_fused": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_bmm_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _I, _P, _P],
     "l3d_softmax_rows": [_P, _P, _L, _I, _F, _P, _P],
     "l3d_layernorm_planes": [_P, _P, _P, _F, _L, _I, _P, _P, _P],

@@ -288,8 +288,9 @@ __global__ __launch_bounds__(256) void layernorm_ref_kernel(const float *__restr
     }
 }
 
-extern "C" int l3d_layernorm_ref(const float *x, const float *a, const float *b, float eps, long rows, int C,
-                                 float *y, l3d_stream_t stream)
+// fp32 values only (C % 4 == 0, C <= 2048): l3d_layernorm_planes with img == NULL
+static int layernorm_values(const float *x, const float *a, const float *b, float eps, long rows, int C,
+                            float *y, l3d_stream_t stream)
 {
     L3D_REQUIRE(x && a && b && y && rows > 0 && C > 1);
     if (C % 4 || C > 2048 || ((((size_t)x) | ((size_t)y) | ((size_t)a) | ((size_t)b)) & 15)) return L3D_ERR_UNSUPPORTED;
@@ -560,7 +561,8 @@ extern "C" int l3d_layernorm_planes_cf(const float *x, const float *a, const flo
 extern "C" int l3d_layernorm_planes(const float *x, const float *a, const float *b, float eps, long rows, int C, float *y,
                                     void *img, l3d_stream_t stream)
 {
-    L3D_REQUIRE(x && a && b && img && rows > 0 && C > 1);
+    L3D_REQUIRE(x && a && b && (img || y) && rows > 0 && C > 1);
+    if (!img) return layernorm_values(x, a, b, eps, rows, C, y, stream);
     if (C % 8 || C > 512 || ((((size_t)x) | ((size_t)y) | ((size_t)a) | ((size_t)b) | ((size_t)img)) & 15)) return L3D_ERR_UNSUPPORTED;
     const size_t pb = (size_t)(C / 8) * (size_t)rows * 16;
     unsigned char *d = (unsigned char *)img;

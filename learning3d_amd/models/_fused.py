@@ -726,3 +726,53 @@ def edgeconv_forward(xyz_bn3, idx, packed, widths=(64, 64, 128, 256), kernel=Non
         rc = fn(*args)
     check(rc, name)
     return pooled
+
+
+SA_FUSED = True      # narrow three-layer set-abstraction stacks behind a ball query as ONE kernel (sa_fused.hip); False: group + conv launches
+
+
+def sa_mlp3_params(convs, bns, dev):
+    """The parameter block of l3d_sa_mlp3_fused for three conv + BatchNorm layers (eval mode), cached on the first conv per
+    parameter / statistic version; None when the kernel does not take the stack (widths other than 32-32-64 / 64-64-128, more
+    than 16 input channels, a layer without BatchNorm scale)."""
+    if len(convs) != 3 or len(bns) != 3:
+        return None
+    folded = [fold_conv_bn(c, b) for c, b in zip(convs, bns)]
+    c0 = folded[0][0].shape[1]
+    widths = [f[0].shape[0] for f in folded]
+    if c0 < 3 or folded[1][0].shape[1] != widths[0] or folded[2][0].shape[1] != widths[1]:
+        return None
+    if c0 > 16 or tuple(widths) not in ((32, 32, 64), (64, 64, 128)):          # the instantiations of sa_fused.hip
+        return None
+    key = tuple(id(f[0]) for f in folded) + (str(dev),)
+    hit = convs[0].__dict__.get("_l3d_sa3")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    parts = []
+    c0p = 8 if c0 <= 8 else 16
+    for i, (w, sc, sh) in enumerate(folded):
+        w = w.to(dev)
+        cout, cin = w.shape
+        if i == 0 and cin < c0p:
+            w = torch.nn.functional.pad(w, (0, c0p - cin))
+            cin = c0p
+        parts.append(w.view(cout, cin // 4, 4).permute(0, 2, 1).contiguous().view(-1))      # [n][g][s] = w[n][4 s + g]
+        parts.append((sc if sc is not None else torch.ones(cout, device=dev)).to(dev).float().view(-1))
+        parts.append((sh if sh is not None else torch.zeros(cout, device=dev)).to(dev).float().view(-1))
+    block = torch.cat(parts).contiguous()
+    convs[0].__dict__["_l3d_sa3"] = (key, (block, c0 - 3, widths))
+    return block, c0 - 3, widths
+
+
+def sa_mlp3_fused(xyz_bn3, new_xyz_bs3, feat_bdn, idx, params):
+    """max over K of the three-layer shared MLP on [xyz[idx] - new_xyz | feat[idx]] -> [B, C3, S]: one launch, no grouped tensor.
+    xyz [B,N,3], new_xyz [B,S,3], feat [B,D,N] or None, idx int32 [B,S,K]; params from sa_mlp3_params."""
+    block, D, widths = params
+    B, N, _ = xyz_bn3.shape
+    S, K = idx.shape[1], idx.shape[2]
+    x, q = f32c(xyz_bn3), f32c(new_xyz_bs3)
+    f = f32c(feat_bdn) if D > 0 else None
+    out = torch.empty((B, widths[2], S), dtype=torch.float32, device=x.device)
+    check(lib().l3d_sa_mlp3_fused(ptr(x), ptr(q), ptr(f), ptr(idx.contiguous()), ptr(block), B, N, S, K, D, widths[0], widths[1], widths[2],
+                                  ptr(out), stream_ptr()), "l3d_sa_mlp3_fused")
+    return out

@@ -52,14 +52,21 @@ def gather_cloud_partials(part):
         if sizes is not None and (len(sizes) != world or sizes[rank] != part.shape[0]):
             raise ValueError(f"declared shard sizes {sizes} do not match this rank's {part.shape[0]} clouds (rank {rank} of {world})")
         part = part.contiguous()
+        # device tensors on a gloo group (two ranks sharing one GPU in tests/test_gpu_two_ranks.py; RCCL wants a device per rank):
+        # the few KB go through the host for the collective only
+        staged = part.is_cuda and dist.get_backend() == "gloo"
+
+        def gather(src, rows):
+            src = src.cpu() if staged else src
+            flat = torch.empty((world * rows,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+            dist.all_gather_into_tensor(flat, src)                       # concatenation along dim 0 in rank order
+            return flat.to(part.device) if staged else flat
+
         if sizes is None or len(set(sizes)) == 1:
-            flat = torch.empty((world * part.shape[0],) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
-            dist.all_gather_into_tensor(flat, part)                      # concatenation along dim 0 in rank order
-            return flat
+            return gather(part, part.shape[0])
         big = max(sizes)
         padded = part if part.shape[0] == big else torch.cat([part, part.new_zeros((big - part.shape[0],) + tuple(part.shape[1:]))])
-        flat = torch.empty((world * big,) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
-        dist.all_gather_into_tensor(flat, padded.contiguous())
+        flat = gather(padded.contiguous(), big)
         return torch.cat([flat[r * big:r * big + sizes[r]] for r in range(world)], dim=0)
     return part
 
@@ -302,7 +309,7 @@ class _LayerNormRef(torch.autograd.Function):
         y = torch.empty_like(xc)
         ac, bc = f32c(a.detach()), f32c(b.detach())
         with on_device_of(xc):
-            check(lib().l3d_layernorm_ref(ptr(xc), ptr(ac), ptr(bc), float(eps), rows, C_, ptr(y), stream_ptr()), "l3d_layernorm_ref")
+            check(lib().l3d_layernorm_planes(ptr(xc), ptr(ac), ptr(bc), float(eps), rows, C_, ptr(y), None, stream_ptr()), "l3d_layernorm_planes[values]")
         ctx.save_for_backward(xc, ac)
         ctx.eps = float(eps)
         return y

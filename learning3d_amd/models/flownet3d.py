@@ -210,6 +210,16 @@ class PointNetSetAbstraction(nn.Module):
             new_xyz = pointutils.gather_operation(xyz.contiguous(), fps_idx)          # [B,3,S]
         else:
             new_xyz = xyz
+        if (_fused.SA_FUSED and not self.group_all and self.queryandgroup.use_xyz and self.queryandgroup.nsample in (8, 16, 32, 64)
+                and xyz.is_cuda and _fused.can_fuse(self, xyz, points)):
+            # a narrow stack (sa1: 6 -> 32 -> 32 -> 64): gather, three layers and the max over K in one kernel (sa_fused.hip)
+            params = _fused.sa_mlp3_params(list(self.mlp_convs), list(self.mlp_bns), xyz.device)
+            if params is not None and params[1] == (0 if points is None else points.shape[1]):
+                new_xyz_t = new_xyz.transpose(2, 1).contiguous()
+                with _fused.stage("ball_query"):
+                    idx = pointutils.ball_query(self.queryandgroup.radius, self.queryandgroup.nsample, xyz_t, new_xyz_t)
+                with _fused.stage("mlp"):
+                    return new_xyz, _fused.sa_mlp3_fused(xyz_t, new_xyz_t, points, idx, params)
         new_points = self.queryandgroup(xyz_t, new_xyz.transpose(2, 1).contiguous(), points)   # [B,3+D,S,K]
         with _fused.stage("mlp"):
             return new_xyz, _mlp_stack(new_points, self.mlp_convs, self.mlp_bns, self, pool=True)

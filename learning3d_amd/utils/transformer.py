@@ -5,7 +5,7 @@ two feed-forward blocks of a pass (62 % of its FLOPs) run on the bf16x3 1x1-conv
 (`l3d_pointwise_conv_split`: a Linear over points IS a 1x1 conv) with bias and ReLU folded into its
 epilogue; its [B,Cout,N] output layout is consumed as is (heads become [B,h,d_k,N] views, the attention
 matmuls take the transposes for free), the attention itself is one flash-style kernel
-(`l3d_attention_forward`, no [B,h,N,N] score tensor) and LayerNorm one fused kernel (`l3d_layernorm_ref`)."""
+(`l3d_attention_forward`, no [B,h,N,N] score tensor) and LayerNorm one fused kernel (`l3d_layernorm_planes`)."""
 import copy
 import os
 import math
@@ -48,8 +48,8 @@ def _ln_values(t):
         from .._lib import check, lib, ptr, stream_ptr
         xc, ln = pend
         C = xc.size(-1)
-        check(lib().l3d_layernorm_ref(ptr(xc), ptr(ln.a_2.detach().contiguous()), ptr(ln.b_2.detach().contiguous()),
-                                      float(ln.eps), xc.numel() // C, C, ptr(t), stream_ptr()), "l3d_layernorm_ref")
+        check(lib().l3d_layernorm_planes(ptr(xc), ptr(ln.a_2.detach().contiguous()), ptr(ln.b_2.detach().contiguous()),
+                                      float(ln.eps), xc.numel() // C, C, ptr(t), None, stream_ptr()), "l3d_layernorm_planes[values]")
         t._l3d_pending = None
     return t
 
@@ -168,8 +168,8 @@ class LayerNorm(nn.Module):
                 if not values:
                     y._l3d_pending = (xc, self)
                 return y
-            check(lib().l3d_layernorm_ref(ptr(xc), ptr(self.a_2.detach().contiguous()), ptr(self.b_2.detach().contiguous()),
-                                          float(self.eps), rows, C, ptr(y), stream_ptr()), "l3d_layernorm_ref")
+            check(lib().l3d_layernorm_planes(ptr(xc), ptr(self.a_2.detach().contiguous()), ptr(self.b_2.detach().contiguous()),
+                                          float(self.eps), rows, C, ptr(y), None, stream_ptr()), "l3d_layernorm_planes[values]")
             return y
         if x.is_cuda:
             # autograd live (a training step, or the recompute of a checkpointed forward): HIP forward + one-pass HIP backward

@@ -1276,6 +1276,69 @@ def test_flownet3d_set_abstraction_vs_oracle():
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
 
 
+class _lib_log:
+    """`with _lib_log() as log:` -- the names of the C-ABI calls made inside"""
+
+    def __enter__(self):
+        from learning3d_amd import _lib
+        _lib.LAUNCH_LOG = []
+        return _lib.LAUNCH_LOG
+
+    def __exit__(self, *exc):
+        from learning3d_amd import _lib
+        _lib.LAUNCH_LOG = None
+
+
+def test_fused_set_abstraction_kernel_every_instantiation_vs_fp64():
+    """l3d_sa_mlp3_fused (sa_fused.hip): gather + three conv / BatchNorm / ReLU layers + max over K in one kernel, for D = 0, 3 and 9
+    feature channels (input padded to 8 / 16), both width triples, K = 8, 16, 32 and 64 (two centroids per row tile, one, and a
+    running maximum over two / four tiles), S not a multiple of the 64 centroids of a workgroup.  Against the grouped input pushed
+    through the same layers in fp64: an fp32 fma chain per output, held to rtol 1e-5 / atol 1e-6 here (the path's bar is 1e-4 /
+    1e-5); and the module's two routes (fused, group + conv launches) against each other."""
+    from learning3d_amd.models import PointNetSetAbstraction, _fused
+    from learning3d_amd.utils import pointnet2_utils as P
+    rng = np.random.default_rng(77)
+    B, N = 2, 700
+    for D, widths, K, S in ((3, [32, 32, 64], 16, 100), (0, [32, 32, 64], 8, 64), (9, [32, 32, 64], 32, 70), (3, [64, 64, 128], 64, 65),
+                            (12, [64, 64, 128], 16, 130), (3, [64, 64, 128], 8, 31)):
+        torch.manual_seed(D + K)
+        sa = PointNetSetAbstraction(npoint=S, radius=0.6, nsample=K, in_channel=D, mlp=list(widths), group_all=False).eval()
+        for m in sa.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.2, 0.2); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.uniform_(-0.3, 0.3)
+        sa = sa.cuda()
+        xyz = dev(np.clip(rng.standard_normal((B, 3, N)), -2, 2).astype(np.float32))
+        feat = dev(rng.uniform(-1, 1, (B, D, N)).astype(np.float32)) if D else None
+        with _lib_log() as log, torch.no_grad():
+            new_xyz, got = sa(xyz, feat)
+        assert "l3d_sa_mlp3_fused" in log and "l3d_group_concat" not in log, log
+        with torch.no_grad():
+            xyz_t = xyz.permute(0, 2, 1).contiguous()
+            idx = P.ball_query(0.6, K, xyz_t, new_xyz.transpose(1, 2).contiguous())
+            h = (P.grouping_operation(xyz, idx) - new_xyz.unsqueeze(-1)).double()
+            if D:
+                h = torch.cat([h, P.grouping_operation(feat, idx).double()], 1)
+            for conv, bn in zip(sa.mlp_convs, sa.mlp_bns):
+                w, sc, sh = _fused.fold_conv_bn(conv, bn)
+                h = torch.relu(torch.einsum("oc,bcsk->bosk", w.double(), h) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+            want = h.max(-1)[0]
+            np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=str((D, widths, K, S)))
+            old = _fused.SA_FUSED
+            _fused.SA_FUSED = False
+            try:
+                with _lib_log() as log2:
+                    _, unfused = sa(xyz, feat)
+            finally:
+                _fused.SA_FUSED = old
+            assert "l3d_sa_mlp3_fused" not in log2 and "l3d_group_concat" in log2, log2
+            np.testing.assert_allclose(got.cpu().numpy(), unfused.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    # a stack the kernel does not take goes to the layer kernels
+    sa = PointNetSetAbstraction(npoint=32, radius=0.6, nsample=16, in_channel=3, mlp=[32, 48, 64], group_all=False).eval().cuda()
+    with _lib_log() as log, torch.no_grad():
+        sa(xyz, dev(rng.uniform(-1, 1, (B, 3, N)).astype(np.float32)))
+    assert "l3d_sa_mlp3_fused" not in log, log
+
+
 def test_group_concat2_matches_composition():
     """l3d_group_concat2 == grouping_operation x2 + broadcast subtraction + repeat + torch.cat (flownet3d.py:125-180,
     :182-242), both channel orders, with and without the broadcast centre features."""
@@ -1807,7 +1870,7 @@ def test_resident_registration_feed():
 
 @pytest.mark.gpu
 def test_layernorm_planes_matches_layernorm_and_feeds_conv_f16():
-    """l3d_layernorm_planes: y equals l3d_layernorm_ref bit for bit, and its fp16 plane image drives l3d_pointwise_conv_f16
+    """l3d_layernorm_planes: y equals the values-only call (img NULL) bit for bit, and its fp16 plane image drives l3d_pointwise_conv_f16
     to the same result as the f16x2 conv on a split of y (the image is y 2^T with T from the layer's parameters)."""
     from learning3d_amd._lib import check, lib, ptr, stream_ptr
     from learning3d_amd.models import _fused
@@ -1817,7 +1880,7 @@ def test_layernorm_planes_matches_layernorm_and_feeds_conv_f16():
         a = dev((rng.standard_normal(C) * 0.5 + 1).astype(np.float32))
         b = dev((rng.standard_normal(C) * 0.2).astype(np.float32))
         y0 = torch.empty_like(x)
-        check(lib().l3d_layernorm_ref(ptr(x), ptr(a), ptr(b), 1e-6, B * N, C, ptr(y0), stream_ptr()), "ln")
+        check(lib().l3d_layernorm_planes(ptr(x), ptr(a), ptr(b), 1e-6, B * N, C, ptr(y0), None, stream_ptr()), "ln")
         y1 = torch.empty_like(x)
         img = torch.empty(lib().l3d_f16_image_bytes(1, B * N, C), dtype=torch.uint8, device="cuda")
         check(lib().l3d_layernorm_planes(ptr(x), ptr(a), ptr(b), 1e-6, B * N, C, ptr(y1), ptr(img), stream_ptr()), "lnp")
