@@ -9,6 +9,8 @@
   ptnet_checkpoints.npz  the reference's two other trained PointNet feature extractors (pretrained/exp_ipcrnet, exp_pnlk:
                          best_ptnet_model.t7, use_bn False / True) with their features on a seeded cloud: trained magnitudes for
                          the f16x2 arithmetic beyond config 1's checkpoint.
+  prnet_dgcnn_full.npz   models/prnet.py:62-97 DGCNN(emb_dims=512) on 2 clouds of 1024 points with seeded weights: the full-size
+                         check of the feature-space kNN chain against the reference instead of against this package's other route.
 """
 import os
 import sys
@@ -63,6 +65,16 @@ def main():
             for k, v in ckpt.items():
                 arrs[f"{tag}.w.{k}"] = v
         MG.save("ptnet_checkpoints", **arrs)
+        # ---- PRNet's DGCNN at full size (N 1024, emb 512: feature-space kNN at C 64 / 64 / 128, layers 3-4 on the GEMM kernels):
+        #      seeded_params() by state_dict key instead of 1.4 MB of stored weights; of the [2, 512, 1024] output every 8th channel
+        #      x every 4th point is kept, plus every channel's sum and maximum over the points (all 512 channels pinned)
+        from learning3d.models.prnet import DGCNN as PRNetDGCNN
+        torch.manual_seed(8)
+        pr = MG.seeded_params(PRNetDGCNN(emb_dims=512).eval(), 720)
+        xb = MG.rand((2, 3, 1024), 31)
+        ob = pr(xb)
+        MG.save("prnet_dgcnn_full", x=xb, out_strided=ob[:, ::8, ::4].contiguous(), out_sum=ob.double().sum(-1), out_max=ob.max(-1)[0],
+                seed=720)
 
 
 if __name__ == "__main__":
