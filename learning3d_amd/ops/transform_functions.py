@@ -27,10 +27,21 @@ def euler_transform(template, euler_zyx, translation):
 
 def _on_gpu(t):
     """The reference's Dataset.__getitem__ hands these transforms CPU tensors [N,3] (data_utils/dataloaders.py:290-296): they are
-    moved to the current GPU, transformed there, and the results handed back on the CPU; device tensors stay where they are."""
+    moved to the current GPU, transformed there, and the results handed back on the CPU; device tensors stay where they are.
+    From a fork-started DataLoader worker the device cannot be opened: that raises with the ways out (below)."""
     if t.is_cuda:
         return t, False
-    return t.cuda(), True
+    try:
+        return t.cuda(), True
+    except RuntimeError as exc:
+        if "forked subprocess" in str(exc):
+            # a DataLoader worker started by fork (num_workers > 0 with the default start method) cannot open the device, and
+            # this package has no CPU implementation to fall back to (by design: nothing on the path computes on the host)
+            raise RuntimeError(
+                "learning3d_amd transforms run on the GPU: call them from the main process (DataLoader num_workers=0), start the "
+                "workers with multiprocessing_context='spawn', or -- what they are built for -- hand them whole device batches "
+                "(data_utils.device_feed.RegistrationFeed / ResidentRegistrationFeed)") from exc
+        raise
 
 
 class DCPTransform:

@@ -1,5 +1,5 @@
 """Run one kernel a few times (for rocprofv3 --pmc passes).
-usage: pmc_one.py knn|chamfer|edgeconv|edgeconv_split|edgeconv_f16|edgeconv_f16b|conv5|conv5_split|conv5_f16|group_c5"""
+usage: pmc_one.py knn|chamfer|edgeconv|edgeconv_split|edgeconv_f16b|conv5|conv5_split|conv5_f16|conv5_f16_2p|group_c5|sa_mlp3"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -29,12 +29,23 @@ with torch.no_grad():
             qg(xyz5, new5, feat5)
         torch.cuda.synchronize()
         sys.exit(0)
+    if what == "sa_mlp3":                        # config 5's fused set-abstraction layer (sa_fused.hip), behind a ball query
+        from learning3d_amd.models import PointNetSetAbstraction
+        gq = torch.Generator().manual_seed(0)
+        xyz5 = torch.clamp(torch.randn((32, 3, 8192), generator=gq), -2, 2).cuda()
+        feat5 = torch.rand((32, 3, 8192), generator=gq).cuda()
+        sa = PointNetSetAbstraction(npoint=1024, radius=0.5, nsample=16, in_channel=3, mlp=[32, 32, 64], group_all=False).cuda().eval()
+        fps = sa.sample(xyz5)
+        for _ in range(5):
+            sa(xyz5, feat5, fps_idx=fps)
+        torch.cuda.synchronize()
+        sys.exit(0)
     for _ in range(5):
         if what == "knn": U.knn(x.permute(0, 2, 1), 20)
         elif what == "chamfer": ChamferDistance()(a, b)
         elif what == "edgeconv": _fused.edgeconv_forward(x, idx, packed, kernel="lds")            # fp32 MFMA
         elif what == "edgeconv_split": _fused.edgeconv_forward(x, idx, packed, kernel="split")        # bf16x3
-        elif what == "edgeconv_f16b": _fused.edgeconv_forward(x, idx, packed, planes=True, v2=True)      # f16x2 two-plane persistent kernel (the step's)
+        elif what == "edgeconv_f16b": _fused.edgeconv_forward(x, idx, packed, planes=True, v2=True, unscaled=True)      # f16x2 two-plane persistent kernel, out_mode 2 (the step's launch)
         elif what == "conv5_f16": _fused.pointwise_conv_f16(img, 32, 1024, w5f, 512, 1024, s5, b5, relu=True)
         elif what == "conv5_f16_2p": _fused.pointwise_conv_f16(img2, 32, 1024, w5f, 512, 1024, s5, b5, relu=True, unscaled=True)   # the step's conv5
         elif what == "conv5": _fused.pointwise_conv(pooled, w5, s5, b5, relu=True, channel_last=True, split=False)
