@@ -34,7 +34,7 @@ SIGNATURES = {
     "l3d_chamfer_combine": [_P, _I, _P, _P],
     "l3d_chamfer_loss_local_ws_bytes": [],
     "l3d_chamfer_loss_local_mb": [_P, _P, _I, _I, _I, _P, _P, _P, _P],
-    "l3d_ball_query": [_I, _I, _I, _F, _I, _P, _P, _P, _P],
+    "l3d_ball_query": [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P],
     "l3d_group_points": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "l3d_group_points_grad": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "l3d_group_concat": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],

@@ -22,11 +22,27 @@
 
 #define SA_CENT 64               // centroids per workgroup
 
+// Where channel c of row `row` sits in a wave's [16 rows x C] activation tile: the next layer's A operand of lane (m = row, g) is the
+// channels 4 s + g, s = 0 .. C / 4 - 1, which it reads as C / 16 float4 runs over s -- so the tile is [g][s / 4][row'][s % 4] with
+// row' = row rotated within its group of four by g.  Both access patterns are then conflict-free: a 16-lane phase of the b128 read
+// (g fixed, m = 0 .. 15) touches 16 consecutive float4, and the 64 lanes of a b32 write (4 rows x 16 channels: bank = 16 (row / 4)
+// + 4 ((row + g) % 4) + s % 4) touch 64 different banks.  (The first layout, [row][g][s] with a padded pitch, measured 55 % of its
+// LDS cycles as bank conflicts: profiles/round4_pmc_sa_mlp3.txt.)
 template <int C>
-__device__ __forceinline__ int sa_pos(int c) { return (c & 3) * (C / 4) + (c >> 2); }
+__device__ __forceinline__ int sa_pos(int row, int c)
+{
+    const int g = c & 3, s = c >> 2;
+    return ((g * (C / 16) + (s >> 2)) * 16 + ((row & ~3) | ((row + g) & 3))) * 4 + (s & 3);
+}
+// ... and the float4 run q of lane (m, g)
+template <int C>
+__device__ __forceinline__ int sa_run(int m, int g, int q) { return ((g * (C / 16) + q) * 16 + ((m & ~3) | ((m + g) & 3))) * 4; }
 
-// one layer on a 16-row tile: A fragments a[C_IN / 4] (channel 4 s + lane / 16 of row lane % 16), weights at w (LDS, [C_OUT][4][C_IN / 4]),
-// scale / shift at ss (LDS, [2][C_OUT]); result v[ct][r] = act value of row 4 (lane / 16) + r, column 16 ct + lane % 16
+// one layer on a 16-row tile: A fragments a[C_IN / 4] (channel 4 s + lane / 16 of row lane % 16), weights at w (LDS,
+// [4][C_IN / 4 / RUN][CP][RUN] with RUN = min(4, C_IN / 4) and CP = C_OUT (+ 16 when RUN == 2): element (n, k = 4 s + g) at
+// ((g (NS / RUN) + s / RUN) CP + n) RUN + s % RUN -- consecutive output channels are consecutive 16-byte (8-byte) cells, so the B
+// operand of a column tile is conflict-free ds_read_b128 (b64) runs over s), scale / shift at ss (LDS, [2][C_OUT]);
+// result v[ct][r] = act value of row 4 (lane / 16) + r, column 16 ct + lane % 16
 template <int C_IN, int C_OUT>
 __device__ __forceinline__ void sa_layer(const float *a, const float *__restrict__ w, const float *__restrict__ ss, int lane, float (*v)[4])
 {
@@ -37,17 +53,17 @@ __device__ __forceinline__ void sa_layer(const float *a, const float *__restrict
     for (int ct = 0; ct < NCT; ct++) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s0 = 0; s0 < NS; s0 += 4) {
-        constexpr int RUN = NS < 4 ? NS : 4;
+        constexpr int RUN = NS < 4 ? NS : 4, CP = C_OUT + (RUN == 2 ? 16 : 0);
 #pragma unroll
         for (int ct = 0; ct < NCT; ct++) {
             float b[RUN];
-            const float *wp = w + ((16 * ct + n) * 4 + g) * NS + s0;
+            const float *wp = w + ((g * (NS / RUN) + s0 / RUN) * CP + 16 * ct + n) * RUN;
             if constexpr (RUN == 4) {
                 const float4 q = *(const float4 *)wp;
                 b[0] = q.x; b[1] = q.y; b[2] = q.z; b[3] = q.w;
             } else {
-#pragma unroll
-                for (int i = 0; i < RUN; i++) b[i] = wp[i];
+                const float2 q = *(const float2 *)wp;
+                b[0] = q.x; b[1] = q.y;
             }
 #pragma unroll
             for (int i = 0; i < RUN; i++) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s0 + i], b[i], acc[ct], 0, 0, 0);
@@ -61,25 +77,29 @@ __device__ __forceinline__ void sa_layer(const float *a, const float *__restrict
     }
 }
 
-// params (device, floats): W1 [C1][4][C0P/4] | ss1 [2][C1] | W2 [C2][4][C1/4] | ss2 [2][C2] | W3 [C3][4][C2/4] | ss3 [2][C3]
+// params (device, floats): W1 | ss1 [2][C1] | W2 | ss2 [2][C2] | W3 | ss3 [2][C3], the weights in sa_layer's LDS order (W1 of a
+// C0P = 8 stack carries 16 pad rows per lane group: sa_w1_floats)
+template <int C0P, int C1>
+constexpr int sa_w1_floats() { return C0P == 8 ? 4 * (C1 + 16) * 2 : C1 * C0P; }
+
 template <int C0P, int C1, int C2, int C3>
 __global__ __launch_bounds__(256) void sa_mlp3_kernel(const float *__restrict__ xyz, const float *__restrict__ new_xyz,
                                                       const float *__restrict__ feat, const int *__restrict__ idx,
                                                       const float *__restrict__ params, int N, int S, int K, int D,
                                                       float *__restrict__ out)
 {
-    constexpr int NPAR = C1 * C0P + 2 * C1 + C2 * C1 + 2 * C2 + C3 * C2 + 2 * C3;
-    constexpr int CM = C1 > C2 ? C1 : C2, TP = CM + 4;                 // activation tile pitch
+    constexpr int NPAR = sa_w1_floats<C0P, C1>() + 2 * C1 + C2 * C1 + 2 * C2 + C3 * C2 + 2 * C3;
+    constexpr int CM = C1 > C2 ? C1 : C2;                             // activation tile: 16 rows x CM floats
     extern __shared__ __attribute__((aligned(16))) float sa_lds[];
     float *par = sa_lds;
-    float *tiles = sa_lds + ((NPAR + 3) & ~3);                         // [4 waves][16][TP]
-    float *stage = tiles + 4 * 16 * TP;                                // [C3][SA_CENT + 1]
+    float *tiles = sa_lds + ((NPAR + 3) & ~3);                         // [4 waves][16 CM]
+    float *stage = tiles + 4 * 16 * CM;                                // [C3][SA_CENT + 1]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int b = blockIdx.y, s0 = blockIdx.x * SA_CENT;
     for (int i = t; i < NPAR / 4; i += 256) ((float4 *)par)[i] = ((const float4 *)params)[i];
     __syncthreads();
-    const float *w1 = par, *ss1 = w1 + C1 * C0P, *w2 = ss1 + 2 * C1, *ss2 = w2 + C2 * C1, *w3 = ss2 + 2 * C2, *ss3 = w3 + C3 * C2;
-    float *T = tiles + wave * 16 * TP;
+    const float *w1 = par, *ss1 = w1 + sa_w1_floats<C0P, C1>(), *w2 = ss1 + 2 * C1, *ss2 = w2 + C2 * C1, *w3 = ss2 + 2 * C2, *ss3 = w3 + C3 * C2;
+    float *T = tiles + wave * 16 * CM;
     const int g = lane >> 4, m = lane & 15;
     const float *cloud = xyz + (size_t)b * N * 3;
     const float *fb = feat ? feat + (size_t)b * D * N : nullptr;
@@ -108,12 +128,12 @@ __global__ __launch_bounds__(256) void sa_mlp3_kernel(const float *__restrict__ 
 #pragma unroll
         for (int ct = 0; ct < C1 / 16; ct++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) T[(4 * g + r) * TP + sa_pos<C1>(16 * ct + m)] = v1[ct][r];
+            for (int r = 0; r < 4; r++) T[sa_pos<C1>(4 * g + r, 16 * ct + m)] = v1[ct][r];
         // ---- layer 2
         float a1[C1 / 4];
 #pragma unroll
         for (int q = 0; q < C1 / 16; q++) {
-            const float4 x = *(const float4 *)&T[m * TP + g * (C1 / 4) + 4 * q];
+            const float4 x = *(const float4 *)&T[sa_run<C1>(m, g, q)];
             a1[4 * q] = x.x; a1[4 * q + 1] = x.y; a1[4 * q + 2] = x.z; a1[4 * q + 3] = x.w;
         }
         float v2[C2 / 16][4];
@@ -121,12 +141,12 @@ __global__ __launch_bounds__(256) void sa_mlp3_kernel(const float *__restrict__ 
 #pragma unroll
         for (int ct = 0; ct < C2 / 16; ct++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) T[(4 * g + r) * TP + sa_pos<C2>(16 * ct + m)] = v2[ct][r];
+            for (int r = 0; r < 4; r++) T[sa_pos<C2>(4 * g + r, 16 * ct + m)] = v2[ct][r];
         // ---- layer 3 and the maximum over the rows of a centroid
         float a2[C2 / 4];
 #pragma unroll
         for (int q = 0; q < C2 / 16; q++) {
-            const float4 x = *(const float4 *)&T[m * TP + g * (C2 / 4) + 4 * q];
+            const float4 x = *(const float4 *)&T[sa_run<C2>(m, g, q)];
             a2[4 * q] = x.x; a2[4 * q + 1] = x.y; a2[4 * q + 2] = x.z; a2[4 * q + 3] = x.w;
         }
         float v3[C3 / 16][4];
@@ -160,9 +180,9 @@ template <int C0P, int C1, int C2, int C3>
 static int sa_launch(const float *xyz, const float *new_xyz, const float *feat, const int *idx, const float *params, int B, int N, int S,
                      int K, int D, float *out, hipStream_t st)
 {
-    constexpr int NPAR = C1 * C0P + 2 * C1 + C2 * C1 + 2 * C2 + C3 * C2 + 2 * C3;
+    constexpr int NPAR = sa_w1_floats<C0P, C1>() + 2 * C1 + C2 * C1 + 2 * C2 + C3 * C2 + 2 * C3;
     constexpr int CM = C1 > C2 ? C1 : C2;
-    const size_t lds = (size_t)(((NPAR + 3) & ~3) + 4 * 16 * (CM + 4) + C3 * (SA_CENT + 1)) * sizeof(float);
+    const size_t lds = (size_t)(((NPAR + 3) & ~3) + 4 * 16 * CM + C3 * (SA_CENT + 1)) * sizeof(float);
     hipLaunchKernelGGL((sa_mlp3_kernel<C0P, C1, C2, C3>), dim3((unsigned)l3d_divup(S, SA_CENT), (unsigned)B), dim3(256), lds, st, xyz, new_xyz,
                        feat, idx, params, N, S, K, D, out);
     return l3d_check_launch();
@@ -176,13 +196,14 @@ static size_t l3d_sa_mlp3_param_floats(int D, int C1, int C2, int C3)
     const bool a = C1 == 32 && C2 == 32 && C3 == 64, b = C1 == 64 && C2 == 64 && C3 == 128;
     if (!a && !b) return 0;
     const int c0p = c0 <= 8 ? 8 : 16;
-    return (size_t)C1 * c0p + 2 * C1 + (size_t)C2 * C1 + 2 * C2 + (size_t)C3 * C2 + 2 * C3;
+    return (size_t)(c0p == 8 ? 4 * (C1 + 16) * 2 : C1 * c0p) + 2 * C1 + (size_t)C2 * C1 + 2 * C2 + (size_t)C3 * C2 + 2 * C3;
 }
 
 // out [B][C3][S] = max_k relu(s3 (W3 relu(s2 (W2 relu(s1 (W1 [xyz[idx] - new_xyz | feat[idx]]) + t1)) + t2)) + t3)
 // xyz [B][N][3], new_xyz [B][S][3], feat [B][D][N] (NULL when D == 0), idx int32 [B][S][K] (K in {8, 16, 32, 64});
-// params: per layer the weights as [Cout][4][Cin / 4] (element [n][g][s] =
-// w[n][4 s + g], layer 1's input channels zero-padded to 8 or 16) followed by scale [Cout] and shift [Cout] (the folded BatchNorm).
+// params: per layer the weights in the order sa_layer reads them -- element w[n][k = 4 s + g] at ((g (NS / RUN) + s / RUN) CP + n) RUN
+// + s % RUN, NS = Cin / 4, RUN = min(4, NS), CP = Cout (+ 16 zero rows when RUN == 2), layer 1's input channels zero-padded to 8 or
+// 16 -- followed by scale [Cout] and shift [Cout] (the folded BatchNorm).
 extern "C" int l3d_sa_mlp3_fused(const float *xyz, const float *new_xyz, const float *feat, const int32_t *idx, const float *params,
                                  int B, int N, int S, int K, int D, int C1, int C2, int C3, float *out, l3d_stream_t stream)
 {

@@ -756,7 +756,12 @@ def sa_mlp3_params(convs, bns, dev):
         if i == 0 and cin < c0p:
             w = torch.nn.functional.pad(w, (0, c0p - cin))
             cin = c0p
-        parts.append(w.view(cout, cin // 4, 4).permute(0, 2, 1).contiguous().view(-1))      # [n][g][s] = w[n][4 s + g]
+        ns = cin // 4
+        run = min(4, ns)
+        wl = w.view(cout, ns // run, run, 4).permute(3, 1, 0, 2)                           # [g][s / run][n][s % run] = w[n][4 s + g]
+        if run == 2:
+            wl = torch.nn.functional.pad(wl, (0, 0, 0, 16))                                  # 16 zero rows per (g, run): bank spread
+        parts.append(wl.contiguous().view(-1))
         parts.append((sc if sc is not None else torch.ones(cout, device=dev)).to(dev).float().view(-1))
         parts.append((sh if sh is not None else torch.zeros(cout, device=dev)).to(dev).float().view(-1))
     block = torch.cat(parts).contiguous()

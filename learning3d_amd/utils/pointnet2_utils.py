@@ -204,6 +204,9 @@ class GroupingOperation(Function):
 grouping_operation = GroupingOperation.apply
 
 
+BALL_QUERY_CELLS = True      # ball_query on clouds of >= 2048 points through a per-cloud cell list; False: the scanning kernels
+
+
 class BallQuery(Function):
     """reference: pointnet2_utils.py:225-253 -> K7 ball_query_kernel_fast."""
 
@@ -215,7 +218,9 @@ class BallQuery(Function):
         B, N, _ = xyz.size()
         npoint = new_xyz.size(1)
         idx = torch.empty((B, npoint, nsample), dtype=torch.int32, device=xyz.device)
-        check(lib().l3d_ball_query(B, N, npoint, C.c_float(radius), nsample, ptr(new_xyz), ptr(xyz), ptr(idx),
+        # large clouds: scratch for the cell-list kernels (grouping.hip; the same indices as the scanning kernels)
+        ws = torch.empty(B * (16 * N + 16448), dtype=torch.uint8, device=xyz.device) if BALL_QUERY_CELLS and N >= 2048 and nsample <= 64 else None
+        check(lib().l3d_ball_query(B, N, npoint, C.c_float(radius), nsample, ptr(new_xyz), ptr(xyz), ptr(idx), ptr(ws),
                                    stream_ptr()), "l3d_ball_query")
         ctx.mark_non_differentiable(idx)
         return idx

@@ -1298,6 +1298,51 @@ class _lib_log:
         _lib.LAUNCH_LOG = None
 
 
+def test_ball_query_cell_list_equals_scanning_kernels():
+    """l3d_ball_query with scratch (grouping.hip bq_cells_*: counting sort of the cloud into cells of edge >= r, a wave per centroid
+    over its 27 cells keeping the nsample smallest hit indices) against the scanning kernels it replaces for n >= 2048: the same
+    int32 indices in the same order with the same padding -- Gaussian / uniform / clipped (duplicate points) / flat (one cell
+    thick) clouds, radii from "every ball empty" to "every ball holds the whole cloud", nsample 1 ... 64, centroids that are cloud
+    points, arbitrary points and points far outside the cloud's box, a ragged centroid count."""
+    from learning3d_amd.utils import pointnet2_utils as P
+    rng = np.random.default_rng(123)
+    cases = []
+    for (B, N, S, K, r, kind) in [(2, 8192, 1024, 16, 0.5, "gauss"), (3, 2048, 333, 32, 0.2, "uniform"), (2, 4096, 257, 64, 0.35, "clip"),
+                                  (1, 3000, 100, 1, 0.1, "uniform"), (2, 2500, 64, 8, 1e-4, "uniform"), (1, 2048, 50, 16, 50.0, "gauss"),
+                                  (2, 6000, 200, 16, 0.3, "flat"), (1, 5000, 77, 24, 0.25, "outside")]:
+        if kind == "gauss":
+            xyz = rng.standard_normal((B, N, 3))
+        elif kind == "clip":
+            xyz = np.clip(rng.standard_normal((B, N, 3)), -0.7, 0.7)
+        elif kind == "flat":
+            xyz = rng.uniform(-1, 1, (B, N, 3)); xyz[:, :, 2] = 0.25
+        else:
+            xyz = rng.uniform(-1, 1, (B, N, 3))
+        xyz = xyz.astype(np.float32)
+        if kind == "outside":
+            new = rng.uniform(-3, 3, (B, S, 3)).astype(np.float32)
+            new[:, :5] = 1.0e6
+        else:
+            new = np.stack([xyz[b][rng.choice(N, S, replace=False)] for b in range(B)])
+            new[:, ::7] += rng.uniform(-0.05, 0.05, new[:, ::7].shape).astype(np.float32)
+        cases.append((dev(xyz), dev(new), K, r, kind))
+    for xyz, new, K, r, kind in cases:
+        old = P.BALL_QUERY_CELLS
+        try:
+            P.BALL_QUERY_CELLS = True
+            a = P.ball_query(r, K, xyz, new)
+            P.BALL_QUERY_CELLS = False
+            b = P.ball_query(r, K, xyz, new)
+        finally:
+            P.BALL_QUERY_CELLS = old
+        assert a.dtype == torch.int32 and torch.equal(a, b), (kind, tuple(xyz.shape), K, r, int((a != b).sum()))
+    # and something was actually found / not found where it should be
+    xyz, new, K, r, _ = cases[0]
+    idx = P.ball_query(r, K, xyz, new).long()
+    d = (xyz.gather(1, idx.reshape(2, -1, 1).expand(-1, -1, 3)).view(2, 1024, K, 3) - new.unsqueeze(2)).square().sum(-1)
+    assert bool(((d < r * r) | (idx == 0)).all())
+
+
 def test_fused_set_abstraction_kernel_every_instantiation_vs_fp64():
     """l3d_sa_mlp3_fused (sa_fused.hip): gather + three conv / BatchNorm / ReLU layers + max over K in one kernel, for D = 0, 3 and 9
     feature channels (input padded to 8 / 16), both width triples, K = 8, 16, 32 and 64 (two centroids per row tile, one, and a

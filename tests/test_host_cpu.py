@@ -46,7 +46,7 @@ def test_argument_validation_without_gpu():
     # null pointers / bad sizes are rejected before any launch
     assert l.l3d_knn_graph(None, 1, 8, 4, None, None) == -1
     assert l.l3d_chamfer_forward(None, None, 1, 1, 1, None, None, None, None, None) == -1
-    assert l.l3d_ball_query(1, 0, 1, 0.5, 4, None, None, None, None) == -1
+    assert l.l3d_ball_query(1, 0, 1, 0.5, 4, None, None, None, None, None) == -1
     # + the f16x2 copy, its biases, 16 scales; + the two-plane copy (2/3 of the planes), its biases, layer 1 scaled, 16 constants
     assert l.l3d_edgeconv_packed_floats(64, 64, 128, 256) == 46080 + 45568 + 67584 + 67584 + 448 + 16 + (45056 + 448 + 512 + 64 + 16)
     assert l.l3d_edgeconv_packed_floats(32, 32, 64, 128) == 0
