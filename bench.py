@@ -553,7 +553,7 @@ def main_c5(args, rank, world, local, dev, dist, parallel):
         fused = "group_kernel" not in stage_ms          # sa_fused.hip: gather + three layers + max in one launch (the "mlp" stage)
         mlp_tf = B_PER_GPU * C5_MLP_FLOP_PER_CLOUD / (stage_ms["mlp"] * 1e-3) / 1e12 if stage_ms.get("mlp") else None
         if fused:
-            roof = {"kernel": "sa_mlp3_kernel<8,32,32,64>", "bound": "mfma", "achieved": mlp_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+            roof = {"kernel": "sa_mlp3_kernel<8,32,32,64,2>", "bound": "mfma", "achieved": mlp_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                     "frac": mlp_tf / MFMA_F32_PEAK_TF if mlp_tf else None, "traffic": pmc_traffic("sa_mlp3"), "traffic_source": pmc_source("sa_mlp3"),
                     "avg_launch_ms": stage_ms.get("mlp"), "algorithmic_flop_per_launch": B_PER_GPU * C5_MLP_FLOP_PER_CLOUD,
                     # indices in, six gathered values per (centroid, neighbour), 64 maxima per centroid out

@@ -43,14 +43,17 @@ __device__ __forceinline__ int sa_run(int m, int g, int q) { return ((g * (C / 1
 // ((g (NS / RUN) + s / RUN) CP + n) RUN + s % RUN -- consecutive output channels are consecutive 16-byte (8-byte) cells, so the B
 // operand of a column tile is conflict-free ds_read_b128 (b64) runs over s), scale / shift at ss (LDS, [2][C_OUT]);
 // result v[ct][r] = act value of row 4 (lane / 16) + r, column 16 ct + lane % 16
-template <int C_IN, int C_OUT>
-__device__ __forceinline__ void sa_layer(const float *a, const float *__restrict__ w, const float *__restrict__ ss, int lane, float (*v)[4])
+template <int C_IN, int C_OUT, int SA_TT>
+__device__ __forceinline__ void sa_layer(const float (*a)[C_IN / 4], const float *__restrict__ w, const float *__restrict__ ss, int lane,
+                                         float (*v)[C_OUT / 16][4])
 {
     constexpr int NS = C_IN / 4, NCT = C_OUT / 16;
     const int g = lane >> 4, n = lane & 15;
-    f32x4 acc[NCT];
+    f32x4 acc[SA_TT][NCT];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ct++) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tt = 0; tt < SA_TT; tt++)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ct++) acc[tt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s0 = 0; s0 < NS; s0 += 4) {
         constexpr int RUN = NS < 4 ? NS : 4, CP = C_OUT + (RUN == 2 ? 16 : 0);
@@ -65,15 +68,22 @@ __device__ __forceinline__ void sa_layer(const float *a, const float *__restrict
                 const float2 q = *(const float2 *)wp;
                 b[0] = q.x; b[1] = q.y;
             }
+            // the row tiles share the weight fragment: SA_TT NCT independent accumulation chains keep the matrix pipe fed (a chain's
+            // next MFMA waits for its previous one's eight passes)
 #pragma unroll
-            for (int i = 0; i < RUN; i++) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s0 + i], b[i], acc[ct], 0, 0, 0);
+            for (int i = 0; i < RUN; i++)
+#pragma unroll
+                for (int tt = 0; tt < SA_TT; tt++)
+                    acc[tt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt][s0 + i], b[i], acc[tt][ct], 0, 0, 0);
         }
     }
 #pragma unroll
     for (int ct = 0; ct < NCT; ct++) {
         const float sc = ss[16 * ct + n], sh = ss[C_OUT + 16 * ct + n];
 #pragma unroll
-        for (int r = 0; r < 4; r++) v[ct][r] = fmaxf(acc[ct][r] * sc + sh, 0.f);
+        for (int tt = 0; tt < SA_TT; tt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) v[tt][ct][r] = fmaxf(acc[tt][ct][r] * sc + sh, 0.f);
     }
 }
 
@@ -82,7 +92,10 @@ __device__ __forceinline__ void sa_layer(const float *a, const float *__restrict
 template <int C0P, int C1>
 constexpr int sa_w1_floats() { return C0P == 8 ? 4 * (C1 + 16) * 2 : C1 * C0P; }
 
-template <int C0P, int C1, int C2, int C3>
+// SA_TT = 16-row tiles a wave works on at once (1 or 2; K, the tile count of a wave, is even): 2 for the 32-32-64 stack, whose layers
+// have only two column tiles (two accumulation chains do not keep the matrix pipe fed: 64 -> 56 us at config 5); 1 for 64-64-128,
+// which would not fit two waves per SIMD otherwise
+template <int C0P, int C1, int C2, int C3, int SA_TT = (C1 <= 32 ? 2 : 1)>
 __global__ __launch_bounds__(256) void sa_mlp3_kernel(const float *__restrict__ xyz, const float *__restrict__ new_xyz,
                                                       const float *__restrict__ feat, const int *__restrict__ idx,
                                                       const float *__restrict__ params, int N, int S, int K, int D,
@@ -92,14 +105,14 @@ __global__ __launch_bounds__(256) void sa_mlp3_kernel(const float *__restrict__ 
     constexpr int CM = C1 > C2 ? C1 : C2;                             // activation tile: 16 rows x CM floats
     extern __shared__ __attribute__((aligned(16))) float sa_lds[];
     float *par = sa_lds;
-    float *tiles = sa_lds + ((NPAR + 3) & ~3);                         // [4 waves][16 CM]
-    float *stage = tiles + 4 * 16 * CM;                                // [C3][SA_CENT + 1]
+    float *tiles = sa_lds + ((NPAR + 3) & ~3);                         // [4 waves][SA_TT][16 CM]
+    float *stage = tiles + 4 * SA_TT * 16 * CM;                        // [C3][SA_CENT + 1]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int b = blockIdx.y, s0 = blockIdx.x * SA_CENT;
     for (int i = t; i < NPAR / 4; i += 256) ((float4 *)par)[i] = ((const float4 *)params)[i];
     __syncthreads();
     const float *w1 = par, *ss1 = w1 + sa_w1_floats<C0P, C1>(), *w2 = ss1 + 2 * C1, *ss2 = w2 + C2 * C1, *w3 = ss2 + 2 * C2, *ss3 = w3 + C3 * C2;
-    float *T = tiles + wave * 16 * CM;
+    float *T = tiles + wave * SA_TT * 16 * CM;
     const int g = lane >> 4, m = lane & 15;
     const float *cloud = xyz + (size_t)b * N * 3;
     const float *fb = feat ? feat + (size_t)b * D * N : nullptr;
@@ -107,65 +120,113 @@ __global__ __launch_bounds__(256) void sa_mlp3_kernel(const float *__restrict__ 
     float run[C3 / 16];
 #pragma unroll
     for (int ct = 0; ct < C3 / 16; ct++) run[ct] = -INFINITY;
-    const int ntile = K;                                               // 16 centroids x K rows / 16
-    for (int j = 0; j < ntile; j++) {
-        // ---- gather: row R of this wave's 16 K rows
-        const int R = 16 * j + m, cs = R / K, kk = R - cs * K;
-        const int sg = min(s0 + wave * 16 + cs, S - 1);                // clamped: a partial last workgroup computes on the last centroid
-        const int nb = idx[((size_t)b * S + sg) * K + kk];
-        float a0[C0P / 4];
+    const int ntile = K;                                               // 16 centroids x K rows / 16 (even)
+    // The gather runs ahead of the MFMAs: the next pair of tiles' values and the pair after that's neighbour indices (two dependent
+    // trips to memory) are in flight while this pair is computed.  One load per value from a SELECTED address and an arithmetic
+    // select on what comes back: a `?:` between loaded values or pointers becomes exec-masked branches with a full wait behind
+    // each (LABLOG R4.1, R4.11) -- offsets in floats relative to the cloud, opaque to the optimiser.
+    auto tile_index = [&](int j, int &sg) {
+        const int R = 16 * min(j, ntile - 1) + m, cs = R / K, kk = R - cs * K;
+        sg = min(s0 + wave * 16 + cs, S - 1);                          // clamped: a partial last workgroup computes on the last centroid
+        return idx[((size_t)b * S + sg) * K + kk];
+    };
+    const long fdelta = fb ? (long)(((intptr_t)fb - (intptr_t)cloud) / 4) : 0;
+    float fx[C0P / 4], fv[C0P / 4];                                    // 1 where the lane's channel is a coordinate / is anything at all
+#pragma unroll
+    for (int st = 0; st < C0P / 4; st++) {
+        const int c = 4 * st + g;
+        fx[st] = c < 3 ? 1.f : 0.f;
+        fv[st] = c < 3 + D ? 1.f : 0.f;
+    }
+    auto tile_gather = [&](int nb, int sg, float *a) {
 #pragma unroll
         for (int st = 0; st < C0P / 4; st++) {
             const int c = 4 * st + g;
-            float val = 0.f;
-            if (c < 3) val = cloud[(size_t)nb * 3 + c] - new_xyz[((size_t)b * S + sg) * 3 + c];
-            else if (c - 3 < D) val = fb[(size_t)(c - 3) * N + nb];
-            a0[st] = val;
+            long off = c < 3 ? (long)nb * 3 + c : (c - 3 < D ? fdelta + (long)(c - 3) * N + nb : 0);
+            long coff = ((long)b * S + sg) * 3 + min(c, 2);
+            asm volatile("" : "+v"(off), "+v"(coff));
+            a[st] = (cloud[off] - new_xyz[coff] * fx[st]) * fv[st];   // exact: x 1 and - 0 change nothing; unused channels x 0
+        }
+    };
+    float a0[SA_TT][C0P / 4], a_nxt[SA_TT][C0P / 4];
+    int nb_nxt[SA_TT], sg_nxt[SA_TT];
+#pragma unroll
+    for (int tt = 0; tt < SA_TT; tt++) {
+        int sg;
+        const int nb = tile_index(tt, sg);
+        tile_gather(nb, sg, a0[tt]);
+        nb_nxt[tt] = tile_index(SA_TT + tt, sg_nxt[tt]);
+    }
+    for (int j = 0; j < ntile; j += SA_TT) {
+        int nb_n2[SA_TT], sg_n2[SA_TT];
+#pragma unroll
+        for (int tt = 0; tt < SA_TT; tt++) {
+            tile_gather(nb_nxt[tt], sg_nxt[tt], a_nxt[tt]);            // the next pair's values
+            nb_n2[tt] = tile_index(j + 2 * SA_TT + tt, sg_n2[tt]);     // the pair after that's indices
         }
         // ---- layer 1
-        float v1[C1 / 16][4];
-        sa_layer<C0P, C1>(a0, w1, ss1, lane, v1);
+        float v1[SA_TT][C1 / 16][4];
+        sa_layer<C0P, C1, SA_TT>(a0, w1, ss1, lane, v1);
 #pragma unroll
-        for (int ct = 0; ct < C1 / 16; ct++)
+        for (int tt = 0; tt < SA_TT; tt++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) T[sa_pos<C1>(4 * g + r, 16 * ct + m)] = v1[ct][r];
+            for (int ct = 0; ct < C1 / 16; ct++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) T[tt * 16 * CM + sa_pos<C1>(4 * g + r, 16 * ct + m)] = v1[tt][ct][r];
         // ---- layer 2
-        float a1[C1 / 4];
+        float a1[SA_TT][C1 / 4];
 #pragma unroll
-        for (int q = 0; q < C1 / 16; q++) {
-            const float4 x = *(const float4 *)&T[sa_run<C1>(m, g, q)];
-            a1[4 * q] = x.x; a1[4 * q + 1] = x.y; a1[4 * q + 2] = x.z; a1[4 * q + 3] = x.w;
-        }
-        float v2[C2 / 16][4];
-        sa_layer<C1, C2>(a1, w2, ss2, lane, v2);
+        for (int tt = 0; tt < SA_TT; tt++)
 #pragma unroll
-        for (int ct = 0; ct < C2 / 16; ct++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) T[sa_pos<C2>(4 * g + r, 16 * ct + m)] = v2[ct][r];
-        // ---- layer 3 and the maximum over the rows of a centroid
-        float a2[C2 / 4];
-#pragma unroll
-        for (int q = 0; q < C2 / 16; q++) {
-            const float4 x = *(const float4 *)&T[sa_run<C2>(m, g, q)];
-            a2[4 * q] = x.x; a2[4 * q + 1] = x.y; a2[4 * q + 2] = x.z; a2[4 * q + 3] = x.w;
-        }
-        float v3[C3 / 16][4];
-        sa_layer<C2, C3>(a2, w3, ss3, lane, v3);
-        const bool last = K <= 16 || ((16 * j + 16) % K) == 0;         // this tile ends its centroid(s)
-#pragma unroll
-        for (int ct = 0; ct < C3 / 16; ct++) {
-            float mx = fmaxf(fmaxf(v3[ct][0], v3[ct][1]), fmaxf(v3[ct][2], v3[ct][3]));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            if (K >= 16) mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            run[ct] = fmaxf(run[ct], mx);
-            if (last) {
-                if (K >= 16) {
-                    if (g == 0) stage[(16 * ct + m) * (SA_CENT + 1) + wave * 16 + (16 * j) / K] = run[ct];
-                } else if ((g & 1) == 0) {                             // K = 8: lane groups 0, 1 hold centroid 2 j, groups 2, 3 centroid 2 j + 1
-                    stage[(16 * ct + m) * (SA_CENT + 1) + wave * 16 + 2 * j + (g >> 1)] = run[ct];
-                }
-                run[ct] = -INFINITY;
+            for (int q = 0; q < C1 / 16; q++) {
+                const float4 x = *(const float4 *)&T[tt * 16 * CM + sa_run<C1>(m, g, q)];
+                a1[tt][4 * q] = x.x; a1[tt][4 * q + 1] = x.y; a1[tt][4 * q + 2] = x.z; a1[tt][4 * q + 3] = x.w;
             }
+        float v2[SA_TT][C2 / 16][4];
+        sa_layer<C1, C2, SA_TT>(a1, w2, ss2, lane, v2);
+#pragma unroll
+        for (int tt = 0; tt < SA_TT; tt++)
+#pragma unroll
+            for (int ct = 0; ct < C2 / 16; ct++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) T[tt * 16 * CM + sa_pos<C2>(4 * g + r, 16 * ct + m)] = v2[tt][ct][r];
+        // ---- layer 3 and the maximum over the rows of a centroid
+        float a2[SA_TT][C2 / 4];
+#pragma unroll
+        for (int tt = 0; tt < SA_TT; tt++)
+#pragma unroll
+            for (int q = 0; q < C2 / 16; q++) {
+                const float4 x = *(const float4 *)&T[tt * 16 * CM + sa_run<C2>(m, g, q)];
+                a2[tt][4 * q] = x.x; a2[tt][4 * q + 1] = x.y; a2[tt][4 * q + 2] = x.z; a2[tt][4 * q + 3] = x.w;
+            }
+        float v3[SA_TT][C3 / 16][4];
+        sa_layer<C2, C3, SA_TT>(a2, w3, ss3, lane, v3);
+#pragma unroll
+        for (int tt = 0; tt < SA_TT; tt++) {
+            const int jj = j + tt;
+            const bool last = K <= 16 || ((16 * jj + 16) % K) == 0;    // this tile ends its centroid(s)
+#pragma unroll
+            for (int ct = 0; ct < C3 / 16; ct++) {
+                float mx = fmaxf(fmaxf(v3[tt][ct][0], v3[tt][ct][1]), fmaxf(v3[tt][ct][2], v3[tt][ct][3]));
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                if (K >= 16) mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                run[ct] = fmaxf(run[ct], mx);
+                if (last) {
+                    if (K >= 16) {
+                        if (g == 0) stage[(16 * ct + m) * (SA_CENT + 1) + wave * 16 + (16 * jj) / K] = run[ct];
+                    } else if ((g & 1) == 0) {                         // K = 8: lane groups 0, 1 hold centroid 2 j, groups 2, 3 centroid 2 j + 1
+                        stage[(16 * ct + m) * (SA_CENT + 1) + wave * 16 + 2 * jj + (g >> 1)] = run[ct];
+                    }
+                    run[ct] = -INFINITY;
+                }
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < SA_TT; tt++) {
+#pragma unroll
+            for (int st = 0; st < C0P / 4; st++) a0[tt][st] = a_nxt[tt][st];
+            nb_nxt[tt] = nb_n2[tt];
+            sg_nxt[tt] = sg_n2[tt];
         }
     }
     __syncthreads();
@@ -181,8 +242,8 @@ static int sa_launch(const float *xyz, const float *new_xyz, const float *feat, 
                      int K, int D, float *out, hipStream_t st)
 {
     constexpr int NPAR = sa_w1_floats<C0P, C1>() + 2 * C1 + C2 * C1 + 2 * C2 + C3 * C2 + 2 * C3;
-    constexpr int CM = C1 > C2 ? C1 : C2;
-    const size_t lds = (size_t)(((NPAR + 3) & ~3) + 4 * 16 * CM + C3 * (SA_CENT + 1)) * sizeof(float);
+    constexpr int CM = C1 > C2 ? C1 : C2, SA_TT = C1 <= 32 ? 2 : 1;
+    const size_t lds = (size_t)(((NPAR + 3) & ~3) + 4 * SA_TT * 16 * CM + C3 * (SA_CENT + 1)) * sizeof(float);
     hipLaunchKernelGGL((sa_mlp3_kernel<C0P, C1, C2, C3>), dim3((unsigned)l3d_divup(S, SA_CENT), (unsigned)B), dim3(256), lds, st, xyz, new_xyz,
                        feat, idx, params, N, S, K, D, out);
     return l3d_check_launch();
