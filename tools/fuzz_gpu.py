@@ -159,6 +159,55 @@ with torch.no_grad():
             d0 = (xc[:, :, None, :] - torch.gather(xc[:, None].expand(B, N, N, 3), 2, i0[..., None].expand(B, N, k, 3))).square().sum(-1)
             d1_ = (xc[:, :, None, :] - torch.gather(xc[:, None].expand(B, N, N, 3), 2, i1_[..., None].expand(B, N, k, 3))).square().sum(-1)
             assert torch.equal(i0, i1_) or torch.allclose(d0, d1_, rtol=0, atol=1e-6), ("knn mfma vs insertion", B, N)
+    # ---- round 4: the strided batched GEMM, the cell-list ball query and the fused set-abstraction kernel
+    from learning3d_amd.models import _rows, PointNetSetAbstraction
+    from learning3d_amd.utils import pointnet2_utils as P2
+    for it in range(20):                                            # l3d_bmm_f32: random shapes, strides, transposes, head splits
+        nb1, nb2 = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        M, N_, K = int(rng.integers(1, 300)), int(rng.integers(1, 300)), int(rng.integers(1, 400))
+        def operand(r, c):
+            big = dev(rng.standard_normal((nb1, nb2, r + 5, c + 3)).astype(np.float32))
+            mode = int(rng.integers(0, 4))
+            if mode == 0:
+                return big[:, :, :r, :c].contiguous()
+            if mode == 1:
+                return big[:, :, 2:2 + r, 1:1 + c]                                      # a sliced view
+            if mode == 2:
+                return dev(rng.standard_normal((nb1, nb2, c, r)).astype(np.float32)).transpose(-1, -2)   # transposed
+            return dev(rng.standard_normal((nb1, r, nb2, c)).astype(np.float32)).transpose(1, 2)         # head-split layout
+        A_, B_ = operand(M, K), operand(K, N_)
+        parts = int(rng.choice([1, 1, 2, 5]))
+        got = _rows.bmm(A_, B_, alpha=0.75, parts=parts).double().cpu().numpy()
+        want = 0.75 * np.matmul(A_.double().cpu().numpy(), B_.double().cpu().numpy())
+        bound = 0.75 * np.matmul(np.abs(A_.double().cpu().numpy()), np.abs(B_.double().cpu().numpy())) * (K + parts) * 2.0 ** -24 + 1e-30
+        worst["bmm vs fp64 / bound"] = max(worst.get("bmm vs fp64 / bound", 0.0), float((np.abs(got - want) / bound).max()))
+        assert (np.abs(got - want) <= bound).all(), ("bmm", nb1, nb2, M, N_, K, parts)
+    for it in range(10):                                            # ball query: cell list == scanning kernel
+        B = int(rng.integers(1, 4)); N = int(rng.integers(2048, 9000)); S = int(rng.integers(1, 700)); K = int(rng.integers(1, 65))
+        scale = float(rng.choice([0.3, 1.0, 5.0])); r = float(rng.uniform(0.02, 0.8)) * scale
+        xyz = (rng.standard_normal((B, N, 3)) * scale).astype(np.float32)
+        if it % 3 == 0:
+            xyz = np.clip(xyz, -0.8 * scale, 0.8 * scale)
+        new = (rng.standard_normal((B, S, 3)) * scale * 1.3).astype(np.float32)
+        xd, nd = dev(xyz), dev(new)
+        P2.BALL_QUERY_CELLS = True; a = P2.ball_query(r, K, xd, nd)
+        P2.BALL_QUERY_CELLS = False; b_ = P2.ball_query(r, K, xd, nd)
+        P2.BALL_QUERY_CELLS = True
+        assert torch.equal(a, b_), ("ball query cells", B, N, S, K, r, int((a != b_).sum()))
+    worst["ball query cells == scan"] = 0.0
+    for it in range(8):                                             # fused set-abstraction kernel vs group + conv launches
+        B = int(rng.integers(1, 3)); N = int(rng.integers(300, 3000)); S = int(rng.integers(1, 200)); K = int(rng.choice([8, 16, 32, 64]))
+        D = int(rng.choice([0, 1, 3, 5, 13])); widths = [32, 32, 64] if rng.integers(0, 2) else [64, 64, 128]
+        sa = PointNetSetAbstraction(npoint=S, radius=float(rng.uniform(0.2, 0.9)), nsample=K, in_channel=D, mlp=list(widths), group_all=False).cuda().eval()
+        for m in sa.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.2, 0.2); m.running_var.uniform_(0.5, 1.5)
+        xyz = dev(rng.standard_normal((B, 3, N)).astype(np.float32)); feat = dev(rng.uniform(-1, 1, (B, D, N)).astype(np.float32)) if D else None
+        _, f1 = sa(xyz, feat)
+        _fused.SA_FUSED = False
+        _, f0 = sa(xyz, feat)
+        _fused.SA_FUSED = True
+        rec("sa fused vs layer kernels", f1.cpu().numpy(), f0.cpu().numpy(), 1e-4, 1e-5)
     _fused.check_range(sync=True)
 for k_, v_ in worst.items():
     print(f"{k_:28s} worst (|err| - rtol|want|) = {v_:.3e}")
