@@ -382,7 +382,7 @@ __global__ __launch_bounds__(1024) void bq_cells_build_kernel(int n, float radiu
     }
 }
 
-__global__ __launch_bounds__(256) void bq_cells_query_kernel(int n, int m, float r2, int nsample, const float *__restrict__ new_xyz,
+__global__ __launch_bounds__(256, 8) void bq_cells_query_kernel(int n, int m, float r2, int nsample, const float *__restrict__ new_xyz,
                                                              const unsigned char *__restrict__ ws, size_t ws_per_cloud,
                                                              int32_t *__restrict__ idx_out)
 {

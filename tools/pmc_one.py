@@ -29,6 +29,15 @@ with torch.no_grad():
             qg(xyz5, new5, feat5)
         torch.cuda.synchronize()
         sys.exit(0)
+    if what == "bq_cells":                       # config 5's ball query through the cell list (grouping.hip bq_cells_*)
+        from learning3d_amd.utils import pointnet2_utils as P
+        gq = torch.Generator().manual_seed(0)
+        xyz5 = torch.clamp(torch.randn((32, 8192, 3), generator=gq), -2, 2).cuda()
+        new5 = P.gather_operation(xyz5.transpose(1, 2).contiguous(), P.furthest_point_sample(xyz5, 1024)).transpose(1, 2).contiguous()
+        for _ in range(5):
+            P.ball_query(0.5, 16, xyz5, new5)
+        torch.cuda.synchronize()
+        sys.exit(0)
     if what == "sa_mlp3":                        # config 5's fused set-abstraction layer (sa_fused.hip), behind a ball query
         from learning3d_amd.models import PointNetSetAbstraction
         gq = torch.Generator().manual_seed(0)
