@@ -16,6 +16,7 @@
 // host says the operand is 16-byte aligned along it, scalars otherwise and at the edges).
 #include "common.h"
 #include "split_bf16.h"          // f32x16
+#include <type_traits>
 
 #define BM_T 128
 #define BM_K 16
@@ -24,53 +25,63 @@
 struct BmOperand {
     const float *p;
     long s1, s2, sr, sc;         // element strides: batch level 1, batch level 2, row, column
-    int vec;                     // 1: 16-byte loads along k are safe; 2: along the operand's rows (m of A, n of B); 0: scalars
+    int unused;
 };
 
-// V values (8 or 4) of a [16 V rows x 16 k] operand tile for thread t: along k (mode 1 or 0) -- 16 / V threads per row; along rows
-// (mode 2, or rows contiguous but unaligned) -- k = t >> 4, rows (t & 15) V .. + V - 1.  `sr` / `sc` = the stride along the
-// operand's rows / along k (for B, which is given as [K x N], the caller passes them swapped).
+// V values (8 or 4) of a [16 V rows x 16 k] operand tile for thread t.  MODE is a property of the operand, fixed for the launch (a
+// template parameter: with the three forms behind run-time tests every load sat in an exec-masked region with a wait at its end,
+// and nothing was in flight under the MFMAs -- LABLOG R4.8):
+//   1  16-byte loads along k: row t / (16 / V), k (t % (16 / V)) V .. + V - 1; needs sc == 1, alignment, K % 16 == 0
+//   2  16-byte loads along the rows: k = t >> 4, rows (t & 15) V .. + V - 1;   needs sr == 1, alignment, K % 16 == 0, R % 8 == 0
+//   0  anything else: scalar loads, rows fastest when sr == 1
+// In the vector forms nothing is conditional: a row index beyond R is clamped to a valid one -- what is loaded there only reaches
+// output rows / columns beyond M / N, which are not stored.  The scalar form multiplies by a 0 / 1 mask instead of selecting (a
+// select on a loaded value becomes a branch with a wait behind it).  `sr` / `sc` = the stride along the operand's rows / along k
+// (for B, which is given as [K x N], the caller passes them swapped).
 template <int V>
 struct BmFrag { float v[V]; };
 
-template <int V>
-__device__ __forceinline__ BmFrag<V> bm_fetch(const float *__restrict__ base, long sr, long sc, int vec, int r0, int k0, int R, int K, int t)
+template <int V, int MODE>
+__device__ __forceinline__ BmFrag<V> bm_fetch(const float *__restrict__ base, long sr, long sc, int r0, int k0, int R, int K, int t)
 {
     BmFrag<V> f;
-    if (vec == 2 || sr == 1) {
-        const int k = k0 + (t >> 4), r = r0 + (t & 15) * V;
-        if (vec == 2 && k < K && r + V - 1 < R) {
+    if constexpr (MODE == 2) {
+        const int k = k0 + (t >> 4), r = min(r0 + (t & 15) * V, R - V);
 #pragma unroll
-            for (int j = 0; j < V; j += 4) {
-                const float4 a = *(const float4 *)(base + (long)k * sc + r + j);
-                f.v[j] = a.x; f.v[j + 1] = a.y; f.v[j + 2] = a.z; f.v[j + 3] = a.w;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < V; i++) f.v[i] = (k < K && r + i < R) ? base[(long)k * sc + (long)(r + i) * sr] : 0.f;
+        for (int j = 0; j < V; j += 4) {
+            const float4 a = *(const float4 *)(base + (long)k * sc + r + j);
+            f.v[j] = a.x; f.v[j + 1] = a.y; f.v[j + 2] = a.z; f.v[j + 3] = a.w;
         }
-    } else {
+    } else if constexpr (MODE == 1) {
         constexpr int TPR = 16 / V;                     // threads per row
-        const int r = r0 + t / TPR, k = k0 + (t % TPR) * V;
-        if (vec == 1 && r < R && k + V - 1 < K) {
+        const int r = min(r0 + t / TPR, R - 1), k = k0 + (t % TPR) * V;
 #pragma unroll
-            for (int j = 0; j < V; j += 4) {
-                const float4 a = *(const float4 *)(base + (long)r * sr + k + j);
-                f.v[j] = a.x; f.v[j + 1] = a.y; f.v[j + 2] = a.z; f.v[j + 3] = a.w;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < V; i++) f.v[i] = (r < R && k + i < K) ? base[(long)r * sr + (long)(k + i) * sc] : 0.f;
+        for (int j = 0; j < V; j += 4) {
+            const float4 a = *(const float4 *)(base + (long)r * sr + k + j);
+            f.v[j] = a.x; f.v[j + 1] = a.y; f.v[j + 2] = a.z; f.v[j + 3] = a.w;
         }
+    } else if (sr == 1) {
+        const int k = k0 + (t >> 4), r = r0 + (t & 15) * V;
+        const float kin = k < K ? 1.f : 0.f;
+        const long kc = min(k, K - 1);
+#pragma unroll
+        for (int i = 0; i < V; i++) f.v[i] = base[kc * sc + min(r + i, R - 1)] * (r + i < R ? kin : 0.f);
+    } else {
+        constexpr int TPR = 16 / V;
+        const int r = r0 + t / TPR, k = k0 + (t % TPR) * V;
+        const float rin = r < R ? 1.f : 0.f;
+        const long rc = min(r, R - 1);
+#pragma unroll
+        for (int i = 0; i < V; i++) f.v[i] = base[rc * sr + (long)min(k + i, K - 1) * sc] * (k + i < K ? rin : 0.f);
     }
     return f;
 }
 
 // ... and where they go in the [k][row] LDS tile
-template <int V>
-__device__ __forceinline__ void bm_stash(float (*__restrict__ tile)[BM_P], const BmFrag<V> &f, long sr, int vec, int t)
+template <int V, int MODE>
+__device__ __forceinline__ void bm_stash(float (*__restrict__ tile)[BM_P], const BmFrag<V> &f, long sr, int t)
 {
-    if (vec == 2 || sr == 1) {
+    if (MODE == 2 || (MODE == 0 && sr == 1)) {
         const int k = t >> 4, r = (t & 15) * V;
 #pragma unroll
         for (int j = 0; j < V; j += 4) *(float4 *)&tile[k][r + j] = make_float4(f.v[j], f.v[j + 1], f.v[j + 2], f.v[j + 3]);
@@ -88,7 +99,8 @@ __device__ __forceinline__ void bm_stash(float (*__restrict__ tile)[BM_P], const
 // 128 x 128 tiling would leave CUs with a single workgroup (a Linear layer over 8192 rows x 512 channels is 256 tiles).
 // LDS is double-buffered: one barrier per chunk (chunk i + 1 is stashed into the other buffer behind chunk i's MFMAs; every wave
 // has passed the barrier in front of chunk i, so nobody still reads that buffer).
-template <int YT>
+// AM / BM = the fetch form of the two operands (bm_fetch)
+template <int YT, int AM, int BM>
 __global__ __launch_bounds__(256, 2) void bmm_f32_kernel(BmOperand A, BmOperand B, float *__restrict__ C, long c1, long c2, long cr, long cc,
                                                       int nb2, int M, int N, int K, float alpha, int flags,
                                                       const float *__restrict__ bias, int parts, float *__restrict__ ws)
@@ -116,41 +128,50 @@ __global__ __launch_bounds__(256, 2) void bmm_f32_kernel(BmOperand A, BmOperand 
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[x][y][r] = 0.f;
 
-    // B is [K x N]: as a [N rows x K] operand its row stride is sc and its k stride sr
+    // B is [K x N]: as a [N rows x K] operand its row stride is sc and its k stride sr.
+    // Chunk c + 2 is requested while chunk c is multiplied and chunk c + 1 waits in registers: a chunk's MFMAs take ~0.85 us per
+    // wave, less than a trip to HBM under load -- with one chunk of look-ahead the stash at the end of every chunk waited for its
+    // loads (51 % matrix-pipe utilisation at two waves per SIMD, LABLOG R4.8).  Chunk c lives in register set c & 1.
+    BmFrag<8> fa[2];
+    BmFrag<VB> fb[2];
     if (kbeg < kend) {
-        const BmFrag<8> fa = bm_fetch<8>(a, A.sr, A.sc, A.vec, m0, kbeg, M, kend, t);
-        const BmFrag<VB> fb = bm_fetch<VB>(b, B.sc, B.sr, B.vec, n0, kbeg, N, kend, t);
-        bm_stash<8>(As[0], fa, A.sr, A.vec, t);
-        bm_stash<VB>(Bs[0], fb, B.sc, B.vec, t);
-    }
-    int cur = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += BM_K) {
-        __syncthreads();                                  // chunk k0 is in buffer `cur`; buffer cur ^ 1 is free
-        const bool more = k0 + BM_K < kend;
-        BmFrag<8> fa;
-        BmFrag<VB> fb;
-        if (more) {
-            fa = bm_fetch<8>(a, A.sr, A.sc, A.vec, m0, k0 + BM_K, M, kend, t);
-            fb = bm_fetch<VB>(b, B.sc, B.sr, B.vec, n0, k0 + BM_K, N, kend, t);
+        fa[0] = bm_fetch<8, AM>(a, A.sr, A.sc, m0, kbeg, M, kend, t);
+        fb[0] = bm_fetch<VB, BM>(b, B.sc, B.sr, n0, kbeg, N, kend, t);
+        if (kbeg + BM_K < kend) {
+            fa[1] = bm_fetch<8, AM>(a, A.sr, A.sc, m0, kbeg + BM_K, M, kend, t);
+            fb[1] = bm_fetch<VB, BM>(b, B.sc, B.sr, n0, kbeg + BM_K, N, kend, t);
         }
-        const int kl = lane >> 5, rl = lane & 31;
+        bm_stash<8, AM>(As[0], fa[0], A.sr, t);
+        bm_stash<VB, BM>(Bs[0], fb[0], B.sc, t);
+    }
+    const int kl = lane >> 5, rl = lane & 31;
+    auto chunk = [&](int k0, auto parity) {
+        constexpr int P = decltype(parity)::value;        // k0's chunk index & 1; LDS buffer P holds it
+        __syncthreads();                                  // chunk k0 is in buffer P; buffer P ^ 1 is free
+        if (k0 + 2 * BM_K < kend) {                       // register set P is free too (its chunk was stashed): chunk + 2 goes there
+            fa[P] = bm_fetch<8, AM>(a, A.sr, A.sc, m0, k0 + 2 * BM_K, M, kend, t);
+            fb[P] = bm_fetch<VB, BM>(b, B.sc, B.sr, n0, k0 + 2 * BM_K, N, kend, t);
+        }
 #pragma unroll
         for (int kk = 0; kk < BM_K; kk += 2) {
             float av[2], bv[YT];
 #pragma unroll
-            for (int x = 0; x < 2; x++) av[x] = As[cur][kk + kl][wm * 64 + 32 * x + rl];
+            for (int x = 0; x < 2; x++) av[x] = As[P][kk + kl][wm * 64 + 32 * x + rl];
 #pragma unroll
-            for (int y = 0; y < YT; y++) bv[y] = Bs[cur][kk + kl][wn * 32 * YT + 32 * y + rl];
+            for (int y = 0; y < YT; y++) bv[y] = Bs[P][kk + kl][wn * 32 * YT + 32 * y + rl];
 #pragma unroll
             for (int x = 0; x < 2; x++)
 #pragma unroll
                 for (int y = 0; y < YT; y++) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], bv[y], acc[x][y], 0, 0, 0);
         }
-        if (more) {
-            bm_stash<8>(As[cur ^ 1], fa, A.sr, A.vec, t);
-            bm_stash<VB>(Bs[cur ^ 1], fb, B.sc, B.vec, t);
+        if (k0 + BM_K < kend) {                           // chunk + 1 (register set P ^ 1, requested a chunk ago) into the other buffer
+            bm_stash<8, AM>(As[P ^ 1], fa[P ^ 1], A.sr, t);
+            bm_stash<VB, BM>(Bs[P ^ 1], fb[P ^ 1], B.sc, t);
         }
-        cur ^= 1;
+    };
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * BM_K) {
+        chunk(k0, std::integral_constant<int, 0>{});
+        if (k0 + BM_K < kend) chunk(k0 + BM_K, std::integral_constant<int, 1>{});
     }
 
     // D[m = 32x + (r&3) + 8(r>>2) + 4(lane>>5)][n = 32y + (lane&31)]
@@ -198,12 +219,12 @@ __global__ __launch_bounds__(256) void bm_reduce_kernel(const float *__restrict_
     *c = v;
 }
 
-static int bm_vec(const float *p, const long s[4], long rows_extent_unused)
+// the fetch form of an operand seen as [R rows x K] with strides s = {batch1, batch2, row, k} (bm_fetch)
+static int bm_mode(const float *p, const long s[4], int R, int K)
 {
-    (void)rows_extent_unused;
-    const bool al = (((size_t)p) & 15) == 0 && s[0] % 4 == 0 && s[1] % 4 == 0;
+    const bool al = (((size_t)p) & 15) == 0 && s[0] % 4 == 0 && s[1] % 4 == 0 && K % BM_K == 0;
     if (s[3] == 1 && al && s[2] % 4 == 0) return 1;
-    if (s[2] == 1 && al && s[3] % 4 == 0) return 2;
+    if (s[2] == 1 && al && s[3] % 4 == 0 && R % 8 == 0) return 2;
     return 0;
 }
 
@@ -221,21 +242,26 @@ extern "C" int l3d_bmm_f32(const float *A, const long *a_strides, const float *B
     const long nz = (long)nb1 * nb2 * parts;
     if (nz > 65535 || l3d_divup(M, BM_T) > 65535) return L3D_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    BmOperand a{A, a_strides[0], a_strides[1], a_strides[2], a_strides[3], bm_vec(A, a_strides, 0)};
+    BmOperand a{A, a_strides[0], a_strides[1], a_strides[2], a_strides[3], 0};
+    BmOperand b{B, b_strides[0], b_strides[1], b_strides[2], b_strides[3], 0};
     // B as a [N rows x K] operand: "along k" is its row stride, "along rows" its column stride
     const long bsw[4] = {b_strides[0], b_strides[1], b_strides[3], b_strides[2]};
-    BmOperand b{B, b_strides[0], b_strides[1], b_strides[2], b_strides[3], bm_vec(B, bsw, 0)};
+    const int am = bm_mode(A, a_strides, M, K), bm = bm_mode(B, bsw, N, K);
     // 128 x 128 tiles when they fill the chip twice over, 128 x 64 otherwise
     const long wide = (long)l3d_divup(N, 128) * l3d_divup(M, BM_T) * nz;
-    if (wide >= 512 && N > 64) {
-        dim3 grid((unsigned)l3d_divup(N, 128), (unsigned)l3d_divup(M, BM_T), (unsigned)nz);
-        hipLaunchKernelGGL(bmm_f32_kernel<2>, grid, dim3(256), 0, st, a, b, C, c_strides[0], c_strides[1], c_strides[2], c_strides[3], nb2, M,
-                           N, K, alpha, flags, bias, parts, workspace);
-    } else {
-        dim3 grid((unsigned)l3d_divup(N, 64), (unsigned)l3d_divup(M, BM_T), (unsigned)nz);
-        hipLaunchKernelGGL(bmm_f32_kernel<1>, grid, dim3(256), 0, st, a, b, C, c_strides[0], c_strides[1], c_strides[2], c_strides[3], nb2, M,
-                           N, K, alpha, flags, bias, parts, workspace);
-    }
+    const bool yt2 = wide >= 512 && N > 64;
+    dim3 grid((unsigned)l3d_divup(N, yt2 ? 128 : 64), (unsigned)l3d_divup(M, BM_T), (unsigned)nz);
+#define BM_LAUNCH(YT, AM, BMD)                                                                                                             \
+    hipLaunchKernelGGL((bmm_f32_kernel<YT, AM, BMD>), grid, dim3(256), 0, st, a, b, C, c_strides[0], c_strides[1], c_strides[2], c_strides[3], \
+                       nb2, M, N, K, alpha, flags, bias, parts, workspace)
+#define BM_PICK_B(YT, AM)                                                                                                                   \
+    do { if (bm == 1) BM_LAUNCH(YT, AM, 1); else if (bm == 2) BM_LAUNCH(YT, AM, 2); else BM_LAUNCH(YT, AM, 0); } while (0)
+#define BM_PICK_A(YT)                                                                                                                       \
+    do { if (am == 1) BM_PICK_B(YT, 1); else if (am == 2) BM_PICK_B(YT, 2); else BM_PICK_B(YT, 0); } while (0)
+    if (yt2) BM_PICK_A(2); else BM_PICK_A(1);
+#undef BM_PICK_A
+#undef BM_PICK_B
+#undef BM_LAUNCH
     if (parts > 1) {
         if (l3d_check_launch() != 0) return L3D_ERR_LAUNCH;
         dim3 rg((unsigned)l3d_divup((long)M * N, 256), (unsigned)(nb1 * nb2));
