@@ -107,7 +107,7 @@ __global__ __launch_bounds__(512) void attention_f16b_kernel(const float *__rest
     const bool k_item = k_oct < D / 8;
     const int v_oct = t & 3, v_d = t >> 2;
     const bool v_item = v_d < D;
-    const bool v_vec = (M & 3) == 0 && (v_bs & 3) == 0 && ((((size_t)v) & 15) == 0);
+    const bool v_vec8 = (M & 7) == 0 && (v_bs & 3) == 0 && ((((size_t)v) & 15) == 0);     // every 8-key run of a V row: two aligned 16-byte loads
     float kr[8], vr[8];
     // Ablation builds of tools/probe_attention_f16b.hip (timing only, results are garbage): AB_NOLOAD skips the tiles' global loads,
     // AB_NOSTAGE also their splits and LDS writes, AB_NOSOFTMAX the exp2 / split work on the probabilities, AB_NOLDSREAD reads
@@ -116,27 +116,42 @@ __global__ __launch_bounds__(512) void attention_f16b_kernel(const float *__rest
 #if defined(AB_NOLOAD) || defined(AB_NOSTAGE)
         return;
 #endif
-        if (k_item) {
-            const int key = key0 + k_key;
-            const float *src = kb + (size_t)(8 * k_oct) * M + key;
-            if (key0 + AB_TK <= M) {                              // whole tile in range (uniform): no per-element predicates
+        // Nothing here is conditional per lane: a conditional load is an exec-masked branch with a wait at its join, and the tile's
+        // loads then queue up one round trip behind the other instead of flying together under the previous tile's MFMAs (the form
+        // this replaced: `key < M ? src[..] : 0` and a per-lane choice between the 16-byte and the scalar V loads).  Indices beyond
+        // the operand are clamped to valid ones; on the last, partial tile (a wave-uniform branch) the values are zeroed by a
+        // 0 / 1 factor.  Threads without an item (D < 128) load their clamped neighbour's and store nothing.
+        {
+            const int key = key0 + k_key, kc = min(key, M - 1);
+            const float *src = kb + (size_t)(8 * min(k_oct, D / 8 - 1)) * M + kc;
 #pragma unroll
-                for (int e = 0; e < 8; e++) kr[e] = src[(size_t)e * M];
-            } else {
+            for (int e = 0; e < 8; e++) kr[e] = src[(size_t)e * M];
+            if (key0 + AB_TK > M) {
+                const float in = key < M ? 1.f : 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; e++) kr[e] = key < M ? src[(size_t)e * M] : 0.f;
+                for (int e = 0; e < 8; e++) kr[e] *= in;
             }
         }
-        if (v_item) {
+        {
             const int key = key0 + 8 * v_oct;
-            const float *src = vb + (size_t)v_d * M + key;
-            if (v_vec && key + 8 <= M) {
+            const float *row = vb + (size_t)min(v_d, D - 1) * M;
+            if (v_vec8) {                                         // uniform: 16-byte aligned rows and M % 8 == 0
+                const float *src = row + min(key, M - 8);
                 const f32x4 x0 = *(const f32x4 *)src, x1 = *(const f32x4 *)(src + 4);
                 vr[0] = x0[0]; vr[1] = x0[1]; vr[2] = x0[2]; vr[3] = x0[3];
                 vr[4] = x1[0]; vr[5] = x1[1]; vr[6] = x1[2]; vr[7] = x1[3];
+                if (key0 + AB_TK > M) {
+                    const float in = key < M ? 1.f : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) vr[e] *= in;
+                }
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; e++) vr[e] = key + e < M ? src[e] : 0.f;
+                for (int e = 0; e < 8; e++) vr[e] = row[min(key + e, M - 1)];
+                if (key0 + AB_TK > M) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) vr[e] *= key + e < M ? 1.f : 0.f;
+                }
             }
         }
     };
