@@ -56,10 +56,7 @@ __global__ __launch_bounds__(64 * CWAVES) void chamfer_fwd_kernel(const float *_
     for (int c0 = 0; c0 < Nc; c0 += CTILE) {
         const int tn = min(CTILE, Nc - c0);
         __syncthreads();
-        for (int t = tid; t < tn; t += 64 * CWAVES) {
-            const float *cp = cbase + (size_t)(c0 + t) * 3;
-            cand[t] = make_float4(cp[0], cp[1], cp[2], 0.f);
-        }
+        l3d_stage_points<8>(cbase + (size_t)c0 * 3, tn, tid, 64 * CWAVES, [&](int t, float x, float y, float z) { cand[t] = make_float4(x, y, z, 0.f); });
         __syncthreads();
         // this wave's slice of the tile
         const int per = (tn + CWAVES - 1) / CWAVES;
@@ -166,9 +163,22 @@ __global__ __launch_bounds__(64 * CWAVES) void chamfer_fwd_packed_kernel(const f
     for (int c0 = 0; c0 < Nc; c0 += CTILE) {
         const int tn = min(CTILE, Nc - c0);
         __syncthreads();
-        for (int t = tid; t < tn; t += 64 * CWAVES) {
-            const float *cp = cbase + (size_t)(c0 + t) * 3;
-            cand[t] = make_float4(cp[0], cp[1], cp[2], 0.f);
+        {
+            // the tile's loads all in flight before the first LDS write (a rolled load / wait / write loop is one round trip to
+            // memory per 256 points: four of them in a row at N = 1024, a third of this kernel's 16 us): unconditional loads from
+            // clamped indices (a uniform test around a load is still a branch with a wait at its join); only the LDS writes are predicated
+            constexpr int NS = CTILE / (64 * CWAVES);
+            float sx[NS], sy[NS], sz[NS];
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                const float *cp = cbase + (size_t)(c0 + min(tid + i * 64 * CWAVES, tn - 1)) * 3;
+                sx[i] = cp[0]; sy[i] = cp[1]; sz[i] = cp[2];
+            }
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+                const int t = tid + i * 64 * CWAVES;
+                if (t < tn) cand[t] = make_float4(sx[i], sy[i], sz[i], 0.f);
+            }
         }
         __syncthreads();
         const int per = (tn + CWAVES - 1) / CWAVES;

@@ -204,4 +204,30 @@ __device__ __forceinline__ float l3d_group_max(float v, int span)
     if (span >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
     return v;
 }
+
+#ifdef __HIPCC__
+// Stage `tn` packed xyz points (cbase[3 t + c]) into LDS through `put(t, x, y, z)` with `nthreads` threads, UNR points per thread in
+// flight before the first LDS write.  A rolled `for (t = tid; t < tn; t += nthreads) { load; put; }` loop compiles to one round trip
+// to memory per trip (load, wait, write): at 64 threads and a 2048-point tile that is 32 dependent round trips per tile.  The loads
+// are unconditional, from indices clamped into the tile (a conditional load is a branch with a wait at its join); only `put` is
+// predicated.
+template <int UNR, typename Put>
+__device__ __forceinline__ void l3d_stage_points(const float *__restrict__ cbase, int tn, int tid, int nthreads, Put put)
+{
+    for (int tb = 0; tb < tn; tb += UNR * nthreads) {
+        float x[UNR], y[UNR], z[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const float *cp = cbase + (size_t)min(tb + u * nthreads + tid, tn - 1) * 3;
+            x[u] = cp[0]; y[u] = cp[1]; z[u] = cp[2];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            const int t = tb + u * nthreads + tid;
+            if (t < tn) put(t, x[u], y[u], z[u]);
+        }
+    }
+}
+#endif
+
 #endif

@@ -54,14 +54,22 @@ __global__ __launch_bounds__(64) void ball_query_kernel(int n, int m, float r2, 
         const int tn = min(BQ_TILE, n - c0);
         const int tp = (tn + 31) & ~31;              // padded with far-away sentinels (never inside a ball)
         __syncthreads();
-        for (int t = lane; t < tp; t += 64) {
-            float4 v = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 2.7e37f);
-            if (t < tn) {
-                const float *cp = cbase + (size_t)(c0 + t) * 3;
-                const float x = cp[0], y = cp[1], z = cp[2];
-                v = make_float4(x, y, z, (x * x + y * y) + z * z);
+        // eight points per lane in flight before the first LDS write (rolled, this loop was one round trip to memory per 64
+        // points); unconditional loads from clamped indices -- a conditional load is a branch with a wait at its join
+        for (int tb = 0; tb < tp; tb += 512) {
+            float sx[8], sy[8], sz[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const float *cp = cbase + (size_t)(c0 + min(tb + 64 * u + lane, tn - 1)) * 3;
+                sx[u] = cp[0]; sy[u] = cp[1]; sz[u] = cp[2];
             }
-            cand[t] = v;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int t = tb + 64 * u + lane;
+                if (t < tp)
+                    cand[t] = t < tn ? make_float4(sx[u], sy[u], sz[u], (sx[u] * sx[u] + sy[u] * sy[u]) + sz[u] * sz[u])
+                                     : make_float4(3.0e18f, 3.0e18f, 3.0e18f, 2.7e37f);
+            }
         }
         __syncthreads();
         if (!counting && __all(cnt >= nsample || !valid)) break;
@@ -165,14 +173,20 @@ __global__ __launch_bounds__(64 * BQ_W) void ball_query_sliced_kernel(int n, int
     for (int c0 = lo; c0 < hi; c0 += BQ_T4) {
         const int tn = min(BQ_T4, hi - c0);
         const int tp = (tn + 31) & ~31;
-        for (int t = lane; t < tp; t += 64) {
-            float4 v = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 2.7e37f);   // far-away sentinel, never inside a ball
-            if (t < tn) {
-                const float *cp = cbase + (size_t)(c0 + t) * 3;
-                const float x = cp[0], y = cp[1], z = cp[2];
-                v = make_float4(x, y, z, (x * x + y * y) + z * z);
+        {   // the tile's 8 points per lane all in flight before the first LDS write (see ball_query_kernel)
+            float sx[BQ_T4 / 64], sy[BQ_T4 / 64], sz[BQ_T4 / 64];
+#pragma unroll
+            for (int u = 0; u < BQ_T4 / 64; u++) {
+                const float *cp = cbase + (size_t)(c0 + min(64 * u + lane, tn - 1)) * 3;
+                sx[u] = cp[0]; sy[u] = cp[1]; sz[u] = cp[2];
             }
-            cand[t] = v;
+#pragma unroll
+            for (int u = 0; u < BQ_T4 / 64; u++) {
+                const int t = 64 * u + lane;
+                if (t < tp)
+                    cand[t] = t < tn ? make_float4(sx[u], sy[u], sz[u], (sx[u] * sx[u] + sy[u] * sy[u]) + sz[u] * sz[u])
+                                     : make_float4(3.0e18f, 3.0e18f, 3.0e18f, 2.7e37f);   // far-away sentinel, never inside a ball
+            }
         }
         bool stop = false;
         for (int g0 = 0; g0 < tn; g0 += 32) {
@@ -578,10 +592,8 @@ __global__ __launch_bounds__(256) void gaussian_density_kernel(const float *__re
     for (int j0 = 0; j0 < N; j0 += 1024) {
         const int tn = min(1024, N - j0);
         __syncthreads();
-        for (int t = threadIdx.x; t < tn; t += 256) {
-            const float x = base[(j0 + t) * 3], y = base[(j0 + t) * 3 + 1], z = base[(j0 + t) * 3 + 2];
-            tile[t] = make_float4(x, y, z, (x * x + y * y) + z * z);
-        }
+        l3d_stage_points<4>(base + (size_t)j0 * 3, tn, threadIdx.x, 256,
+                            [&](int t, float x, float y, float z) { tile[t] = make_float4(x, y, z, (x * x + y * y) + z * z); });
         __syncthreads();
         for (int t = 0; t < tn; t++) {
             const float4 c = tile[t];

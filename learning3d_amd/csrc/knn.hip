@@ -86,14 +86,12 @@ __global__ __launch_bounds__(64) void topk_scan_kernel(
     for (int c0 = 0; c0 < Nc; c0 += TILE) {
         const int tn = min(TILE, Nc - c0);
         __syncthreads();
-        for (int t = lane; t < tn; t += 64) {
-            const float *cp = cbase + (size_t)(c0 + t) * 3;
-            float x = cp[0], y = cp[1], z = cp[2];
+        l3d_stage_points<8>(cbase + (size_t)c0 * 3, tn, lane, 64, [&](int t, float x, float y, float z) {
             float w = 0.f;
             if (METRIC == METRIC_EXPANDED) w = -((x * x + y * y) + z * z);   // -xx[j]
             if (METRIC == METRIC_EXPANDED_SQ) w = (x * x + y * y) + z * z;
             cand[t] = make_float4(x, y, z, w);
-        }
+        });
         __syncthreads();
         // main loop: CHUNK candidates between queue checks (queue has room for CHUNK more
         // whenever every lane holds <= QCAP - CHUNK entries)

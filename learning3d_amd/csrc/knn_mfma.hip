@@ -98,13 +98,13 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
         float x[4], y[4], z[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const int c = c0 + 256 * u;
-            x[u] = y[u] = z[u] = 0.f;
-            if (c < N) {
-                x[u] = cloud[c * 3 + 0];
-                y[u] = cloud[c * 3 + 1];
-                z[u] = cloud[c * 3 + 2];
-            }
+            // unconditional loads from a clamped index, zeroed by a 0 / 1 factor: `if (c < N) load` is an exec-masked branch with a
+            // wait at its join, and the four loads then leave one round trip behind the other
+            const int c = c0 + 256 * u, cc = min(c, N - 1);
+            const float in = c < N ? 1.f : 0.f;
+            x[u] = cloud[cc * 3 + 0] * in;
+            y[u] = cloud[cc * 3 + 1] * in;
+            z[u] = cloud[cc * 3 + 2] * in;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
