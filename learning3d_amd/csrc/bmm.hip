@@ -290,50 +290,61 @@ __device__ __forceinline__ float sm_block_reduce(float v, bool is_max, float *re
     return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : ((red[0] + red[1]) + (red[2] + red[3]));
 }
 
+// NIT = 256-column chunks a thread holds (cols <= 256 NIT): a template parameter so that the loads are an unrolled batch with no
+// condition around them (clamped column index; the values beyond `cols` are replaced after the loads have all been issued) -- with a
+// run-time bound every load was followed by its own wait (tools/isa_audit.py)
+template <int NIT>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float *__restrict__ x, long rows, int cols, float scale, float *__restrict__ y)
 {
     __shared__ float red[4];
     const long row = blockIdx.x;
     const float *xr = x + row * cols;
-    float v[SM_PER], big = -INFINITY;
+    float v[NIT], big = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < SM_PER; i++) {
-        const int c = i * 256 + threadIdx.x;
-        v[i] = c < cols ? xr[c] * scale : -INFINITY;
+    for (int i = 0; i < NIT; i++) v[i] = xr[min(i * 256 + (int)threadIdx.x, cols - 1)];
+#pragma unroll
+    for (int i = 0; i < NIT; i++) {
+        v[i] = i * 256 + (int)threadIdx.x < cols ? v[i] * scale : -INFINITY;
         big = fmaxf(big, v[i]);
     }
     big = sm_block_reduce(big, true, red);
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < SM_PER; i++) {
+    for (int i = 0; i < NIT; i++) {
         v[i] = i * 256 + (int)threadIdx.x < cols ? expf(v[i] - big) : 0.f;
         sum += v[i];
     }
     sum = sm_block_reduce(sum, false, red);
     const float inv = 1.0f / sum;
 #pragma unroll
-    for (int i = 0; i < SM_PER; i++) {
+    for (int i = 0; i < NIT; i++) {
         const int c = i * 256 + threadIdx.x;
         if (c < cols) y[row * cols + c] = v[i] * inv;
     }
 }
 
+template <int NIT>
 __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float *__restrict__ p, const float *__restrict__ dp, long rows, int cols,
                                                                float scale, float *__restrict__ ds)
 {
     __shared__ float red[4];
     const long row = blockIdx.x;
-    float pv[SM_PER], gv[SM_PER], dot = 0.f;
+    float pv[NIT], gv[NIT], dot = 0.f;
 #pragma unroll
-    for (int i = 0; i < SM_PER; i++) {
-        const int c = i * 256 + threadIdx.x;
-        pv[i] = c < cols ? p[row * cols + c] : 0.f;
-        gv[i] = c < cols ? dp[row * cols + c] : 0.f;
+    for (int i = 0; i < NIT; i++) {
+        const int c = min(i * 256 + (int)threadIdx.x, cols - 1);
+        pv[i] = p[row * cols + c];
+        gv[i] = dp[row * cols + c];
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; i++) {
+        const float in = i * 256 + (int)threadIdx.x < cols ? 1.f : 0.f;
+        pv[i] *= in;
         dot += pv[i] * gv[i];
     }
     dot = sm_block_reduce(dot, false, red);
 #pragma unroll
-    for (int i = 0; i < SM_PER; i++) {
+    for (int i = 0; i < NIT; i++) {
         const int c = i * 256 + threadIdx.x;
         if (c < cols) ds[row * cols + c] = scale * (pv[i] * (gv[i] - dot));
     }
@@ -345,7 +356,15 @@ extern "C" int l3d_softmax_rows(const float *x, const float *dp, long rows, int 
 {
     L3D_REQUIRE(x && y && rows > 0 && cols > 0);
     if (cols > 256 * SM_PER || rows > 2147483647L) return L3D_ERR_UNSUPPORTED;
-    if (dp) hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, dp, rows, cols, scale, y);
-    else hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, rows, cols, scale, y);
+    hipStream_t st = (hipStream_t)stream;
+    const int nit = l3d_divup(cols, 256);
+#define SM_GO(NIT)                                                                                                        \
+    do {                                                                                                                  \
+        if (dp) hipLaunchKernelGGL(softmax_rows_bwd_kernel<NIT>, dim3((unsigned)rows), dim3(256), 0, st, x, dp, rows, cols, scale, y); \
+        else hipLaunchKernelGGL(softmax_rows_kernel<NIT>, dim3((unsigned)rows), dim3(256), 0, st, x, rows, cols, scale, y);            \
+    } while (0)
+    if (nit <= 1) SM_GO(1); else if (nit <= 2) SM_GO(2); else if (nit <= 4) SM_GO(4); else if (nit <= 8) SM_GO(8);
+    else if (nit <= 16) SM_GO(16); else SM_GO(32);
+#undef SM_GO
     return l3d_check_launch();
 }

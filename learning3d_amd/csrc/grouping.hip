@@ -774,12 +774,18 @@ __global__ __launch_bounds__(PPT >= 8 ? 512 : 1024) void fps_kernel(int n, int m
     const float *p = xyz + (size_t)b * n * 3;
     float px[PPT], py[PPT], pz[PPT], dmin[PPT];
 #pragma unroll
+    for (int u = 0; u < PPT; u++) {              // unconditional loads from clamped indices: all PPT points of a thread in flight
+        const int kc = min(tid + u * nthr, n - 1);  // (`ok ? p[..] : 0` is a branch with a wait at its join: PPT round trips in a row)
+        px[u] = p[kc * 3];
+        py[u] = p[kc * 3 + 1];
+        pz[u] = p[kc * 3 + 2];
+    }
+#pragma unroll
     for (int u = 0; u < PPT; u++) {
         const int k = tid + u * nthr;
         const bool ok = k < n;
-        px[u] = ok ? p[k * 3] : 0.f;
-        py[u] = ok ? p[k * 3 + 1] : 0.f;
-        pz[u] = ok ? p[k * 3 + 2] : 0.f;
+        const float in = ok ? 1.f : 0.f;
+        px[u] *= in; py[u] *= in; pz[u] *= in;
         dmin[u] = ok ? 1e10f : -1.f;          // out-of-range slots can never win the arg-max
         if (LDS_XYZ && ok) { sxyz[k] = px[u]; sxyz[n + k] = py[u]; sxyz[2 * n + k] = pz[u]; }
     }
