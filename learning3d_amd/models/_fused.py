@@ -744,7 +744,10 @@ def sa_mlp3_params(convs, bns, dev):
         return None
     if c0 > 16 or tuple(widths) not in ((32, 32, 64), (64, 64, 128)):          # the instantiations of sa_fused.hip
         return None
-    key = tuple(id(f[0]) for f in folded) + (str(dev),)
+    # keyed like fold_conv_bn: by the parameters' and running statistics' storage and version (object ids of the folded tensors could
+    # be recycled after a re-fold)
+    key = tuple((t.data_ptr(), t._version) for m in list(convs) + list(bns) for t in (m.weight, m.bias, getattr(m, "running_mean", None),
+                                                                                     getattr(m, "running_var", None)) if t is not None) + (str(dev),)
     hit = convs[0].__dict__.get("_l3d_sa3")
     if hit is not None and hit[0] == key:
         return hit[1]
