@@ -33,7 +33,7 @@ B_PER_GPU, NPTS, KNN, EMB = 32, 1024, 20, 1024
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
 MFMA_F32_PEAK_TF = 157.3         # MI355X_MICROARCH.md: dense fp32 MFMA peak
 MFMA_BF16_PEAK_TF = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA peak (2.17 PF sustained in tools/probe_mfma_bf16.hip)
-FORK_DEFAULT = "none"             # see --fork
+FORK_DEFAULT = "knn"              # see --fork
 PRECONDITION_STEPS = 150         # untimed, before the --warmup steps (~80 ms of GPU work)
 SPLIT_PRODUCTS = {"f16x2": 3, "bf16x3": 6}    # low-precision MFMA products per fp32 product
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9     # 78.6 T lane-ops/s: 256 CUs x 4 SIMD-32 x 2.4 GHz, an fma counts once (= 157.3 TFLOP/s vector fp32; SURVEY.md 8(d)'s denominator)
@@ -633,11 +633,13 @@ def main():
                          "instead of 32 per GPU; the JSON line says \"scaling\": \"strong\".  PARTS (default: --gpus) lets one GPU run "
                          "the share it would have in a PARTS-way split")
     ap.add_argument("--no-graph", action="store_true", help="issue every step's launches eagerly instead of replaying a hipGraph")
-    ap.add_argument("--fork", choices=["none", "start", "edgeconv", "conv5"], default=FORK_DEFAULT,
-                    help="c2: where the step's Chamfer branch (NN search + loss tail; independent of the DGCNN chain) leaves the "
-                         "main stream: 'none' = one stream, the five kernels back to back; 'start' / 'edgeconv' / 'conv5' = on a "
-                         "second stream from the start of the step / from the moment that stage's kernel is issued, joined at "
-                         "the end of the step (two branches of the replayed hipGraph)")
+    ap.add_argument("--fork", choices=["none", "knn", "start", "edgeconv", "conv5"], default=FORK_DEFAULT,
+                    help="c2: where the step's Chamfer branch (NN search + loss tail; independent of the DGCNN chain) runs: 'knn' (default) "
+                         "= on a second stream beside the kNN kernel only, joined in front of EdgeConv (two branches of the replayed "
+                         "hipGraph: both kernels are VALU / latency bound and the matrix kernels keep the chip to themselves; +1.3 %); "
+                         "'none' = one stream, the five kernels back to back; 'start' / 'edgeconv' / 'conv5' = leaves the main stream at "
+                         "the start of the step / when that stage's kernel is issued and is joined at the END of the step (measured "
+                         "2 % slower than one stream: the matrix kernels lose more than the branch gains)")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="control-flow self test on CPU/gloo (launcher, sharding, collective, max-over-ranks, JSON): "
                          "NO kernels run and the printed line is not a measurement")
@@ -722,7 +724,16 @@ def main():
             main = torch.cuda.current_stream()
             out = []
 
+            joined = []
+
             def leave(name):
+                if args.fork == "knn":
+                    # the Chamfer pair beside kNN only (both VALU / latency bound, a third of the issue slots each), joined again
+                    # in front of EdgeConv: the two matrix kernels keep the chip to themselves
+                    if name == "edgeconv" and not joined:
+                        main.wait_stream(branch)
+                        joined.append(True)
+                    return
                 if name == args.fork and not out:
                     branch.wait_stream(main)
                     with torch.cuda.stream(branch):
@@ -730,12 +741,16 @@ def main():
 
             if args.fork == "start":
                 leave("start")
+            if args.fork == "knn":
+                branch.wait_stream(main)
+                with torch.cuda.stream(branch):
+                    out.append(chamfer_branch())
             prev, _fused.ON_STAGE = _fused.ON_STAGE, leave
             try:
                 feat = net(x)
             finally:
                 _fused.ON_STAGE = prev
-            if not out:
+            if not out or (args.fork == "knn" and not joined):
                 raise SystemExit(f"[bench] --fork {args.fork}: the DGCNN forward never entered that stage")
             main.wait_stream(branch)
         return feat, out[0]
@@ -947,6 +962,8 @@ def main():
                                       "ranks probe until every rank is settled (all_reduce of the verdict)",
                        "launch": "hipGraph replay of the step's 5 kernels" if graph is not None else "eager launches",
                        "chamfer_branch": ("one stream" if branch is None else
+                                          "second stream beside the kNN kernel only, joined in front of EdgeConv (two branches of the replayed hipGraph)"
+                                          if args.fork == "knn" else
                                           f"second stream, leaves the chain at '{args.fork}', joined at the end of the step"),
                        "parallelism": f"batch-sharded x{world}, all_gather of loss partials only"
                                       + ("" if args.sync_loss or not multi else " (asynchronous, consumed one step later)")},
