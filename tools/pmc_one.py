@@ -29,6 +29,20 @@ with torch.no_grad():
             qg(xyz5, new5, feat5)
         torch.cuda.synchronize()
         sys.exit(0)
+    if what == "attention":                      # DCP's attention call: B 32, 4 heads x 128, N = M = 1024, maxima ready, plane image out
+        from learning3d_amd._lib import lib, check, ptr, stream_ptr
+        B_, H_, D_, N_ = 32, 4, 128, 1024
+        q_, k_, v_ = (torch.randn(B_, H_ * D_, N_, device="cuda") for _ in range(3))
+        ws_ = torch.zeros(4, dtype=torch.int32, device="cuda")
+        ctx_ = torch.empty_like(q_)
+        img_ = torch.empty(lib().l3d_f16_image_bytes(1, B_ * N_, H_ * D_), dtype=torch.uint8, device="cuda")
+        check(lib().l3d_attention_forward_f16b(ptr(q_), ptr(k_), ptr(v_), B_, H_, D_, N_, N_, H_ * D_ * N_, H_ * D_ * N_, H_ * D_ * N_, 1.0 / D_ ** 0.5,
+                                               ptr(ws_), 0, ptr(ctx_), None, stream_ptr()), "att")          # leaves the maxima in ws_
+        for _ in range(5):
+            check(lib().l3d_attention_forward_f16b(ptr(q_), ptr(k_), ptr(v_), B_, H_, D_, N_, N_, H_ * D_ * N_, H_ * D_ * N_, H_ * D_ * N_, 1.0 / D_ ** 0.5,
+                                                   ptr(ws_), 1, None, ptr(img_), stream_ptr()), "att")
+        torch.cuda.synchronize()
+        sys.exit(0)
     if what == "bq_cells":                       # config 5's ball query through the cell list (grouping.hip bq_cells_*)
         from learning3d_amd.utils import pointnet2_utils as P
         gq = torch.Generator().manual_seed(0)

@@ -5,7 +5,7 @@ import json, os, re, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 out = {}
-for tag in ("edgeconv", "edgeconv_split", "edgeconv_f16", "edgeconv_f16b", "conv5", "conv5_split", "conv5_f16", "conv5_f16_2p", "knn", "knn_mfma", "chamfer", "group_c5", "sa_mlp3"):
+for tag in ("edgeconv", "edgeconv_split", "edgeconv_f16", "edgeconv_f16b", "conv5", "conv5_split", "conv5_f16", "conv5_f16_2p", "knn", "knn_mfma", "chamfer", "group_c5", "sa_mlp3", "bq_cells", "attention"):
     path = None
     for r in range(rnd, 0, -1):
         cand = os.path.join(root, "profiles", f"round{r}_pmc_{tag}.txt")
