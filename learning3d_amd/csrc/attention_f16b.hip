@@ -67,7 +67,10 @@ __global__ __launch_bounds__(512) void attention_f16b_kernel(const float *__rest
 {
     constexpr int D = 32 * ND, KS = D / 16;                       // channels per head, k-steps of the S^T product
     constexpr int KPL = KS * 2 * 32 * 16;                         // bytes of one K plane of a tile: [k-step][g][key][16 B]
-    constexpr int VPL = 2 * 2 * D * 16;                           // bytes of one V plane of a tile: [PV k-step][g][d][16 B]
+    // bytes of one V plane of a tile: [PV k-step][g][d][16 B], each of the four (k-step, g) blocks followed by 32 bytes: a staging
+    // thread is (key octet t & 3, channel t >> 2), so four consecutive lanes write the four blocks' cells of one channel -- D 16 =
+    // 2048 bytes apart they shared their banks (4-way conflict: 23 % of this kernel's LDS cycles, profiles/round4_pmc_attention.txt)
+    constexpr int VBLK = D * 16 + 32, VPL = 2 * 2 * VBLK;
     constexpr int STAGE = 2 * KPL + 2 * VPL;
     extern __shared__ __attribute__((aligned(16))) unsigned char ab_lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(512) void attention_f16b_kernel(const float *__rest
                 hv[e] = hh;
                 mv[e] = mm;
             }
-            const int off = (((v_oct >> 1) * 2 + (v_oct & 1)) * D + v_d) * 16;
+            const int off = ((v_oct >> 1) * 2 + (v_oct & 1)) * VBLK + v_d * 16;
             *(u32x4 *)(base + 2 * KPL + off) = hv;
             *(u32x4 *)(base + 2 * KPL + VPL + off) = mv;
         }
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(512) void attention_f16b_kernel(const float *__rest
     const int a_ = col >> 3, hb_ = (col >> 2) & 1, b_ = col & 3;
     const int pik = 16 * (a_ >> 1) + 8 * hb_ + 4 * (a_ & 1) + b_;
     const int ka_off = (g * 32 + pik) * 16;                       // + ks * 1024 (+ KPL for the m plane)
-    const int va_off = 2 * KPL + (g * D + col) * 16;              // + s * 2 D 16 + dt * 512 (+ VPL for the m plane)
+    const int va_off = 2 * KPL + g * VBLK + col * 16;             // + s * 2 VBLK + dt * 512 (+ VPL for the m plane)
 
     const int ntile = (M + AB_TK - 1) / AB_TK;
 
@@ -300,8 +303,8 @@ __global__ __launch_bounds__(512) void attention_f16b_kernel(const float *__rest
 #ifdef AB_NOLDSREAD
                 Vh[dt] = Qh[dt]; Vm[dt] = Qm[dt];
 #else
-                Vh[dt] = *(const f16x8 *)(base + va_off + s2 * (2 * D * 16) + dt * 512);
-                Vm[dt] = *(const f16x8 *)(base + VPL + va_off + s2 * (2 * D * 16) + dt * 512);
+                Vh[dt] = *(const f16x8 *)(base + va_off + s2 * (2 * VBLK) + dt * 512);
+                Vm[dt] = *(const f16x8 *)(base + VPL + va_off + s2 * (2 * VBLK) + dt * 512);
 #endif
             }
 #pragma unroll
@@ -458,7 +461,7 @@ extern "C" int l3d_attention_forward_f16b(const float *q, const float *k, const 
         if (rc != L3D_OK) return rc;
     }
     dim3 grid(l3d_divup(N, AB_TQ), H, B), block(512);
-#define AB_LDS(ND_) (3 * (2 * ((32 * ND_) / 16) * 2 * 32 * 16 + 2 * 2 * 2 * (32 * ND_) * 16))
+#define AB_LDS(ND_) (3 * (2 * ((32 * ND_) / 16) * 2 * 32 * 16 + 2 * 2 * 2 * ((32 * ND_) * 16 + 32)))
     if (D == 32)      hipLaunchKernelGGL(attention_f16b_kernel<1>, grid, block, AB_LDS(1), st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax, cph, cpm, cinv);
     else if (D == 64) hipLaunchKernelGGL(attention_f16b_kernel<2>, grid, block, AB_LDS(2), st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax, cph, cpm, cinv);
     else              hipLaunchKernelGGL(attention_f16b_kernel<4>, grid, block, AB_LDS(4), st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax, cph, cpm, cinv);
