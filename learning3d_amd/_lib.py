@@ -109,13 +109,15 @@ SIGNATURES = {
     "l3d_twist_transform": [_P, _P, _I, _I, _P, _P, _P, _P],
     "l3d_quat_transform": [_P, _P, _I, _I, _P, _P],
     "l3d_sceneflow_batch": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "l3d_emd_workspace_bytes": [_I, _I, _I],
     "l3d_emd_forward": [_P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "l3d_emd_forward_split": [_P, _P, _I, _I, _I, _P, _P, _P, _I, _P],
     "l3d_emd_backward": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
 }
 _RESTYPE = {"l3d_status_string": C.c_char_p, "l3d_edgeconv_packed_floats": _SZ, "l3d_split_bytes": _SZ,
             "l3d_soft_correspondence_workspace_floats": _SZ, "l3d_layernorm_backward_workspace_floats": _SZ, "l3d_knn_feature_workspace_bytes": _SZ,
             "l3d_scatter_add_det_workspace_bytes": _SZ, "l3d_chamfer_loss_local_ws_bytes": _SZ, "l3d_f16_image_bytes": _SZ,
-            "l3d_wgrad_workspace_bytes": _SZ}
+            "l3d_wgrad_workspace_bytes": _SZ, "l3d_emd_workspace_bytes": _SZ}
 
 
 class L3DError(RuntimeError):

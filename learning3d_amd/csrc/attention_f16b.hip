@@ -75,7 +75,23 @@ __global__ __launch_bounds__(512) void attention_f16b_kernel(const float *__rest
     extern __shared__ __attribute__((aligned(16))) unsigned char ab_lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int col = lane & 31, g = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * AB_TQ;
+    // Workgroup order (1-D grid).  Workgroup L runs on XCD L % 8, each with its own L2: the query blocks of one (cloud,
+    // head) take consecutive slots of ONE XCD, so that head's K / V come from HBM once instead of once per XCD hosting
+    // one of its query blocks (the plain 3-D grid moved 671 MB for 268 MB of operands, profiles/round4_pmc_attention.txt).
+    int b, h, i0, nB;
+    {
+        const int nq = (N + AB_TQ - 1) / AB_TQ, L = blockIdx.x;
+        int grp, qb_;
+        if (((gridDim.x / nq) & 7) == 0) {
+            const int xcd = L & 7, slot = L >> 3;
+            qb_ = slot % nq;
+            grp = (slot / nq) * 8 + xcd;
+        } else {
+            qb_ = L % nq;
+            grp = L / nq;
+        }
+        b = grp / H; h = grp - b * H; i0 = qb_ * AB_TQ; nB = gridDim.x / nq / H;
+    }
     const float *qb = q + (size_t)b * q_bs + (size_t)h * D * N;
     const float *kb = k + (size_t)b * k_bs + (size_t)h * D * M;
     const float *vb = v + (size_t)b * v_bs + (size_t)h * D * M;
@@ -377,10 +393,10 @@ __global__ __launch_bounds__(512) void attention_f16b_kernel(const float *__rest
     // convex combination of value vectors, so |ctx| <= max|v| and T = Tv puts it below 2^12.  A lane holds 4 consecutive channels
     // of an octet (its partner lane ^ 32 the other 4): each writes its 8-byte half of the 16-byte cell.
     if (cph) {
-        if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && t == 0) *cinv = ldexpf(1.f, -Tv);
+        if (blockIdx.x == 0 && t == 0) *cinv = ldexpf(1.f, -Tv);
         if (i < N) {
             const float invp = 1.f / l_tot;                       // O / l = ctx 2^Tv: already in plane units
-            const size_t rows = (size_t)gridDim.z * N, row = (size_t)b * N + i;
+            const size_t rows = (size_t)nB * N, row = (size_t)b * N + i;
 #pragma unroll
             for (int dt = 0; dt < ND; dt++)
 #pragma unroll
@@ -460,7 +476,7 @@ extern "C" int l3d_attention_forward_f16b(const float *q, const float *k, const 
         const int rc = l3d_attention_absmax3(q, k, v, q_bstride, k_bstride, v_bstride, (long)H * D * N, (long)H * D * M, B, amax, st);
         if (rc != L3D_OK) return rc;
     }
-    dim3 grid(l3d_divup(N, AB_TQ), H, B), block(512);
+    dim3 grid(l3d_divup(N, AB_TQ) * H * B), block(512);
 #define AB_LDS(ND_) (3 * (2 * ((32 * ND_) / 16) * 2 * 32 * 16 + 2 * 2 * 2 * ((32 * ND_) * 16 + 32)))
     if (D == 32)      hipLaunchKernelGGL(attention_f16b_kernel<1>, grid, block, AB_LDS(1), st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax, cph, cpm, cinv);
     else if (D == 64) hipLaunchKernelGGL(attention_f16b_kernel<2>, grid, block, AB_LDS(2), st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax, cph, cpm, cinv);

@@ -247,7 +247,7 @@ def test_emd_equals_reference_kernels(B, n, m):
     b = dev(rng.uniform(0, 1, (B, m, 3)).astype(np.float32))
     match = torch.empty((B, m, n), device="cuda")
     cost = torch.empty((B,), device="cuda")
-    temp = torch.empty((B, 2 * (n + m)), device="cuda")
+    temp = torch.empty((lib().l3d_emd_workspace_bytes(B, n, m),), dtype=torch.uint8, device="cuda")
     check(lib().l3d_emd_forward(p(a), p(b), B, n, m, p(match), p(cost), p(temp), stream_ptr()), "l3d_emd_forward")
     for name, tight in (("libref_emd_nofma.so", True), ("libref_emd.so", False)):
         EMD = _load(name)

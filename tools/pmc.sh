@@ -9,6 +9,7 @@ for CTRS in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU 
             "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH GRBM_GUI_ACTIVE GRBM_COUNT" \
             "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
+  if [ -n "${PMC_SETS:-}" ] && ! echo " $PMC_SETS " | grep -q " $i "; then continue; fi      # PMC_SETS="4 5": only those counter passes
   rm -rf $R/gpurun_out/pmc_tmp
   timeout 300 rocprofv3 --kernel-trace --pmc $CTRS --output-format csv -d $R/gpurun_out/pmc_tmp -o p -- python $R/tools/pmc_one.py $TAG > $R/gpurun_out/pmc_${TAG}_$i.log 2>&1
   f=$(find $R/gpurun_out/pmc_tmp -name "*counter_collection.csv" | head -1)

@@ -29,6 +29,15 @@ with torch.no_grad():
             qg(xyz5, new5, feat5)
         torch.cuda.synchronize()
         sys.exit(0)
+    if what == "emd":                            # EMD forward at B 32, n = m = 1024 (emd.hip: 20 sweeps + match + costsum)
+        from learning3d_amd._lib import lib, check, ptr, stream_ptr
+        B_, n_ = 32, 1024
+        ws_ = torch.empty(lib().l3d_emd_workspace_bytes(B_, n_, n_), dtype=torch.uint8, device="cuda")
+        mt_ = torch.empty((B_, n_, n_), device="cuda"); c_ = torch.empty(B_, device="cuda")
+        for _ in range(3):
+            check(lib().l3d_emd_forward(ptr(a), ptr(b), B_, n_, n_, ptr(mt_), ptr(c_), ptr(ws_), stream_ptr()), "emd")
+        torch.cuda.synchronize()
+        sys.exit(0)
     if what == "attention":                      # DCP's attention call: B 32, 4 heads x 128, N = M = 1024, maxima ready, plane image out
         from learning3d_amd._lib import lib, check, ptr, stream_ptr
         B_, H_, D_, N_ = 32, 4, 128, 1024
