@@ -39,6 +39,7 @@ SPLIT_PRODUCTS = {"f16x2": 3, "bf16x3": 6}    # low-precision MFMA products per 
 VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9     # 78.6 T lane-ops/s: 256 CUs x 4 SIMD-32 x 2.4 GHz, an fma counts once (= 157.3 TFLOP/s vector fp32; SURVEY.md 8(d)'s denominator)
 KNN_LANEOPS_PER_PAIR = 7         # 2 fma + 1 mul + 2 sub + compare/insert
 CHAMFER_LANEOPS_PER_PAIR = 8
+EMD_LANEOPS_PER_PAIR = 490       # emd.cuh:7-185: 10 levels x 3 passes x ~16.3 (8 d2 + 2 scale + 4 for v_exp_f32 at quarter rate + 1-2 weight + 1 add), DESIGN.md
 # algorithmic work per cloud (restated in DESIGN.md)
 KNN_BYTES_PER_CLOUD = NPTS * 3 * 4 + NPTS * KNN * 8                 # 176 128 B
 CHAMFER_BYTES_PER_CLOUD = 2 * NPTS * 3 * 4 + 2 * NPTS * (4 + 4)     # 40 960 B
@@ -252,6 +253,28 @@ def other_configs(dev, iters=10, warm=3):
             out["c5_flownet3d_forward"] = {"ms_per_step": t, "clouds_per_s": 32 / t * 1e3, "shape": "32 cloud pairs per GPU, N=8192"}
         except Exception as exc:
             out["c5_flownet3d"] = {"error": f"{type(exc).__name__}: {exc}"}
+    try:            # north_star's other loss: approximate EMD (losses/emd.py -> emd.hip), forward and backward at B 32, n = m = 1024
+        from learning3d_amd._lib import check, lib, ptr, stream_ptr
+        Be, ne = 32, 1024
+        a = torch.rand((Be, ne, 3), generator=g).to(dev)
+        b = torch.rand((Be, ne, 3), generator=g).to(dev)
+        ws = torch.empty(lib().l3d_emd_workspace_bytes(Be, ne, ne), dtype=torch.uint8, device=dev)
+        match, cost = torch.empty((Be, ne, ne), device=dev), torch.empty(Be, device=dev)
+        g1, g2 = torch.empty_like(a), torch.empty_like(b)
+        t_f = ms(lambda: check(lib().l3d_emd_forward(ptr(a), ptr(b), Be, ne, ne, ptr(match), ptr(cost), ptr(ws), 0, stream_ptr()), "emd"))
+        t_b = ms(lambda: check(lib().l3d_emd_backward(ptr(a), ptr(b), ptr(match), Be, ne, ne, ptr(g1), ptr(g2), stream_ptr()), "emd bwd"))
+        pairs = Be * ne * ne
+        out["emd_c2_shape"] = {
+            "forward_ms": t_f, "backward_ms": t_b, "clouds_per_s_forward": Be / t_f * 1e3, "shape": "B=32, n=m=1024",
+            "roofline": {"bound": "valu", "unit": "T lane-op/s (packed fp32 peak)", "peak": VALU_PEAK_LANEOPS / 1e12,
+                         "achieved": pairs * EMD_LANEOPS_PER_PAIR / (t_f * 1e-3) / 1e12,
+                         "frac": pairs * EMD_LANEOPS_PER_PAIR / (t_f * 1e-3) / VALU_PEAK_LANEOPS,
+                         "note": f"{EMD_LANEOPS_PER_PAIR} lane-op equivalents per pair = the reference's 30 passes x (8 for d2, 2 scale, "
+                                 "v_exp_f32 counted 4 at its quarter rate, 1-2 weight, 1 add); executed here: 29 sweep + 10 match "
+                                 "evaluations per pair, the match matrix written once (134 MB)"},
+            "backward_match_read_gbs": 2 * 4.0 * pairs / (t_b * 1e-3) / 1e9}
+    except Exception as exc:
+        out["emd_c2_shape"] = {"error": f"{type(exc).__name__}: {exc}"}
     torch.cuda.synchronize()
     return out
 

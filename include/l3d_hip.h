@@ -459,14 +459,11 @@ int l3d_fold_mlp_f16(const float *g, int CG, const float *w5g, const float *s5, 
  *   own scratch (pkg/src/cuda/emd.cu:18-22) -- here the caller passes `workspace` of l3d_emd_workspace_bytes(B,n,m) bytes
  *   (the ten levels' ratioL / ratioR, the remainders and the cost partials; no initialisation needed).  22 stream-ordered
  *   launches, no host synchronisation.   emd_backward(xyz1,xyz2,match) -> grad1, grad2.
- *   l3d_emd_forward_split: the same with the lanes-per-row split of the sweeps forced (1, 2, 4; 0 = automatic) -- the
- *   result's bits do not depend on it.
+ *   split: lanes per row in the sweeps, 1, 2 or 4; 0 = chosen from B * min(n, m).  The result's bits do not depend on it.
  * ------------------------------------------------------------------------------------------- */
 size_t l3d_emd_workspace_bytes(int B, int n, int m);
 int l3d_emd_forward(const float *xyz1, const float *xyz2, int B, int n, int m, float *match,
-                    float *cost, void *workspace, l3d_stream_t stream);
-int l3d_emd_forward_split(const float *xyz1, const float *xyz2, int B, int n, int m, float *match,
-                          float *cost, void *workspace, int split, l3d_stream_t stream);
+                    float *cost, void *workspace, int split, l3d_stream_t stream);
 int l3d_emd_backward(const float *xyz1, const float *xyz2, const float *match, int B, int n, int m,
                      float *grad1, float *grad2, l3d_stream_t stream);
 

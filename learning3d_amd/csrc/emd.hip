@@ -262,53 +262,102 @@ __global__ __launch_bounds__(256) void emd_costsum_kernel(int parts, const float
     if (t == 0) cost[b] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
-// grad2[l] = sum_k (p2_l - p1_k) * match[l*n+k] * rsqrt(max(d2, 1e-20))        (K6)
+// grad2[l] = sum_k (p2_l - p1_k) * match[l*n+k] * rsqrt(max(d2, 1e-20))        (K6, emd.cuh:259-299)
+// The reference gives thread t of 256 the k = t, t+256, ... of one l, then folds the 256 partials with a stride-doubling tree
+// (sum[t] += sum[t+j], j = 1, 2, 4 ..): the same 256 partials and the same pairing here (shfl_down inside a wave is that tree,
+// the four waves' results combine as (w0+w1)+(w2+w3)), so the result carries the reference's bits.  EMD_G2_ROWS l per workgroup.
+#define EMD_G2_ROWS 8
 __global__ __launch_bounds__(256) void emd_grad2_kernel(int n, int m, const float *__restrict__ xyz1,
                                                         const float *__restrict__ xyz2,
                                                         const float *__restrict__ match,
                                                         float *__restrict__ grad2)
 {
-    const int b = blockIdx.y;
-    const int l = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (l >= m) return;
-    const float *p1 = xyz1 + (size_t)b * n * 3, *p2 = xyz2 + ((size_t)b * m + l) * 3;
-    const float *mt = match + (size_t)b * n * m + (size_t)l * n;
-    const float x2 = p2[0], y2 = p2[1], z2 = p2[2];
-    float gx = 0, gy = 0, gz = 0;
-    for (int k = lane; k < n; k += 64) {
-        const float dx = x2 - p1[k * 3], dy = y2 - p1[k * 3 + 1], dz = z2 - p1[k * 3 + 2];
-        const float d = mt[k] * rsqrtf(fmaxf((dx * dx + dy * dy) + dz * dz, 1e-20f));
-        gx += dx * d; gy += dy * d; gz += dz * d;
+    __shared__ float part[EMD_G2_ROWS][4][3];
+    const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l0 = blockIdx.x * EMD_G2_ROWS, rows = min(EMD_G2_ROWS, m - l0);
+    const float *p1 = xyz1 + (size_t)b * n * 3;
+    for (int r = 0; r < rows; r++) {
+        const int l = l0 + r;
+        const float *p2 = xyz2 + ((size_t)b * m + l) * 3;
+        const float *mt = match + ((size_t)b * m + l) * n;
+        const float x2 = p2[0], y2 = p2[1], z2 = p2[2];
+        float gx = 0, gy = 0, gz = 0;
+        for (int k = t; k < n; k += 256) {
+            const float dx = x2 - p1[k * 3], dy = y2 - p1[k * 3 + 1], dz = z2 - p1[k * 3 + 2];
+            const float d = mt[k] * rsqrtf(fmaxf((dx * dx + dy * dy) + dz * dz, 1e-20f));
+            gx += dx * d; gy += dy * d; gz += dz * d;
+        }
+        for (int off = 1; off < 64; off <<= 1) {
+            gx += __shfl_down(gx, off, 64); gy += __shfl_down(gy, off, 64); gz += __shfl_down(gz, off, 64);
+        }
+        if (lane == 0) { part[r][wave][0] = gx; part[r][wave][1] = gy; part[r][wave][2] = gz; }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        gx += __shfl_down(gx, off, 64); gy += __shfl_down(gy, off, 64); gz += __shfl_down(gz, off, 64);
-    }
-    if (lane == 0) {
-        float *o = grad2 + ((size_t)b * m + l) * 3;
-        o[0] = gx; o[1] = gy; o[2] = gz;
+    __syncthreads();
+    if (t < rows * 3) {
+        const int r = t / 3, c = t - r * 3;
+        grad2[((size_t)b * m + l0 + r) * 3 + c] = (part[r][0][c] + part[r][1][c]) + (part[r][2][c] + part[r][3][c]);
     }
 }
 
-// grad1[k] = sum_l (p1_k - p2_l) * match[l*n+k] * rsqrt(max(d2, 1e-20))        (K5)
+// grad1[k] = sum_l (p1_k - p2_l) * match[l*n+k] * rsqrt(max(d2, 1e-20))        (K5, emd.cuh:302-323)
+// The reference adds the m terms of one k sequentially in one thread.  Four lanes share a k here (lane q takes l = 4i + q), the
+// terms are added in l order through DPP operands by all four (as in the forward sweeps): the sequential sum's bits, four times
+// the lanes, and EMD_G1_U match values per lane in flight while the previous EMD_G1_U are consumed.
+#define EMD_G1_U 8
 __global__ __launch_bounds__(256) void emd_grad1_kernel(int n, int m, const float *__restrict__ xyz1,
                                                         const float *__restrict__ xyz2,
                                                         const float *__restrict__ match,
                                                         float *__restrict__ grad1)
 {
-    const int b = blockIdx.y;
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const float *p1 = xyz1 + ((size_t)b * n + k) * 3, *p2 = xyz2 + (size_t)b * m * 3;
-    const float *mt = match + (size_t)b * n * m + k;
-    const float x1 = p1[0], y1 = p1[1], z1 = p1[2];
+    extern __shared__ float4 g1_p2[];                      // partner cloud, padded to a multiple of 8 * EMD_G1_U points
+    constexpr int U = EMD_G1_U;
+    const int b = blockIdx.y, t = threadIdx.x, q = t & 3;
+    const int k = blockIdx.x * 64 + (t >> 2);
+    const bool live = k < n;
+    const int mpad = (m + 8 * U - 1) / (8 * U) * (8 * U);
+    const float *p2 = xyz2 + (size_t)b * m * 3;
+    for (int l = t; l < mpad + 4 * U; l += 256)
+        g1_p2[l] = l < m ? make_float4(p2[l * 3], p2[l * 3 + 1], p2[l * 3 + 2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float x1 = 0, y1 = 0, z1 = 0;
+    if (live) { const float *p1 = xyz1 + ((size_t)b * n + k) * 3; x1 = p1[0]; y1 = p1[1]; z1 = p1[2]; }
+    const float *mt = match + (size_t)b * n * m + (live ? k : 0);
+    __syncthreads();
     float gx = 0, gy = 0, gz = 0;
-    for (int l = 0; l < m; l++) {
-        const float dx = x1 - p2[l * 3], dy = y1 - p2[l * 3 + 1], dz = z1 - p2[l * 3 + 2];
-        const float d = mt[(size_t)l * n] * rsqrtf(fmaxf((dx * dx + dy * dy) + dz * dz, 1e-20f));
-        gx += dx * d; gy += dy * d; gz += dz * d;
+    float ma[U], mb[U];
+    auto fetch = [&](float (&v)[U], int l0) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int l = l0 + 4 * u + q;
+            v[u] = mt[(size_t)min(l, m - 1) * n];          // unconditional (no branch per row, the waits stay counted); consume() zeroes rows past m
+        }
+    };
+    auto consume = [&](const float (&v)[U], int l0) {      // rows past m: zero terms, + 0.0f changes no bit of a sum that started at +0
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const float4 c = g1_p2[l0 + 4 * u + q];
+            const float dx = x1 - c.x, dy = y1 - c.y, dz = z1 - c.z;
+            const float mv = l0 + 4 * u + q < m ? v[u] : 0.f;
+            const float d = mv * rsqrtf(fmaxf((dx * dx + dy * dy) + dz * dz, 1e-20f));
+            const float tx = dx * d, ty = dy * d, tz = dz * d;
+            gx += emd_dpp<0x00>(tx); gy += emd_dpp<0x00>(ty); gz += emd_dpp<0x00>(tz);
+            gx += emd_dpp<0x55>(tx); gy += emd_dpp<0x55>(ty); gz += emd_dpp<0x55>(tz);
+            gx += emd_dpp<0xAA>(tx); gy += emd_dpp<0xAA>(ty); gz += emd_dpp<0xAA>(tz);
+            gx += emd_dpp<0xFF>(tx); gy += emd_dpp<0xFF>(ty); gz += emd_dpp<0xFF>(tz);
+        }
+    };
+    fetch(ma, 0);
+    for (int l0 = 0; l0 < mpad; l0 += 8 * U) {
+        fetch(mb, l0 + 4 * U);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(ma, l0);
+        fetch(ma, l0 + 8 * U);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(mb, l0 + 4 * U);
     }
-    float *o = grad1 + ((size_t)b * n + k) * 3;
-    o[0] = gx; o[1] = gy; o[2] = gz;
+    if (live && q == 0) {
+        float *o = grad1 + ((size_t)b * n + k) * 3;
+        o[0] = gx; o[1] = gy; o[2] = gz;
+    }
 }
 
 static inline int emd_cost_parts(int n, int m) { return l3d_divup(n, 512) * l3d_divup(m, EMD_MATCH_LT); }
@@ -327,8 +376,8 @@ static void emd_launch_sweep(const EmdSweep &a, int B, hipStream_t st)
     else hipLaunchKernelGGL((emd_sweep_kernel<S, false>), grid, dim3(256), 0, st, a);
 }
 
-extern "C" int l3d_emd_forward_split(const float *xyz1, const float *xyz2, int B, int n, int m, float *match,
-                                     float *cost, void *workspace, int split, l3d_stream_t stream)
+extern "C" int l3d_emd_forward(const float *xyz1, const float *xyz2, int B, int n, int m, float *match,
+                               float *cost, void *workspace, int split, l3d_stream_t stream)
 {
     L3D_REQUIRE(xyz1 && xyz2 && match && cost && workspace && B > 0 && n > 0 && m > 0);
     L3D_REQUIRE(split == 0 || split == 1 || split == 2 || split == 4);
@@ -336,7 +385,7 @@ extern "C" int l3d_emd_forward_split(const float *xyz1, const float *xyz2, int B
     hipStream_t st = (hipStream_t)stream;
     if (split == 0) {                                      // lanes per row: enough waves for every SIMD of the part (1024)
         const long rows = (long)B * (n < m ? n : m);
-        split = rows >= 4 * 65536 ? 1 : rows >= 65536 ? 2 : 4;
+        split = rows >= 65536 ? 1 : rows >= 32768 ? 2 : 4;         // measured: profiles/round5_emd_bench.txt
     }
     float *ws = (float *)workspace;
     EmdSweep a;
@@ -369,18 +418,17 @@ extern "C" int l3d_emd_forward_split(const float *xyz1, const float *xyz2, int B
     return l3d_check_launch();
 }
 
-extern "C" int l3d_emd_forward(const float *xyz1, const float *xyz2, int B, int n, int m, float *match,
-                               float *cost, void *workspace, l3d_stream_t stream)
-{
-    return l3d_emd_forward_split(xyz1, xyz2, B, n, m, match, cost, workspace, 0, stream);
-}
-
 extern "C" int l3d_emd_backward(const float *xyz1, const float *xyz2, const float *match, int B, int n,
                                 int m, float *grad1, float *grad2, l3d_stream_t stream)
 {
     L3D_REQUIRE(xyz1 && xyz2 && match && grad1 && grad2 && B > 0 && n > 0 && m > 0);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(emd_grad1_kernel, dim3(l3d_divup(n, 256), B), dim3(256), 0, st, n, m, xyz1, xyz2, match, grad1);
-    hipLaunchKernelGGL(emd_grad2_kernel, dim3(l3d_divup(m, 4), B), dim3(256), 0, st, n, m, xyz1, xyz2, match, grad2);
+    L3D_REQUIRE(B <= 65535);
+    const int mpad = l3d_divup(m, 8 * EMD_G1_U) * 8 * EMD_G1_U + 4 * EMD_G1_U;
+    const size_t lds = (size_t)mpad * sizeof(float4);
+    if (lds > 160 * 1024) return L3D_ERR_UNSUPPORTED;     // m <= 10 200 partner points (the reference's own kernels stop at what fits their grid)
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void *)emd_grad1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(emd_grad1_kernel, dim3(l3d_divup(n, 64), B), dim3(256), lds, st, n, m, xyz1, xyz2, match, grad1);
+    hipLaunchKernelGGL(emd_grad2_kernel, dim3(l3d_divup(m, EMD_G2_ROWS), B), dim3(256), 0, st, n, m, xyz1, xyz2, match, grad2);
     return l3d_check_launch();
 }

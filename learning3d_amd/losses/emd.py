@@ -23,7 +23,7 @@ class EMDFunction(torch.autograd.Function):
         match = torch.empty((B, n, m), dtype=torch.float32, device=dev)
         cost = torch.empty((B,), dtype=torch.float32, device=dev)
         ws = torch.empty((lib().l3d_emd_workspace_bytes(B, n, m),), dtype=torch.uint8, device=dev)
-        check(lib().l3d_emd_forward(ptr(xyz1), ptr(xyz2), B, n, m, ptr(match), ptr(cost), ptr(ws), stream_ptr()),
+        check(lib().l3d_emd_forward(ptr(xyz1), ptr(xyz2), B, n, m, ptr(match), ptr(cost), ptr(ws), 0, stream_ptr()),
               "l3d_emd_forward")
         ctx.save_for_backward(xyz1, xyz2, match)
         return cost

@@ -35,7 +35,7 @@ def main():
         outs = {}
         for split in (1, 2, 4):
             match = torch.full((B, m, n), float("nan"), device="cuda"); cost = torch.empty(B, device="cuda")
-            check(L.l3d_emd_forward_split(p(a), p(b), B, n, m, p(match), p(cost), p(ws), split, stream_ptr()), "emd")
+            check(L.l3d_emd_forward(p(a), p(b), B, n, m, p(match), p(cost), p(ws), split, stream_ptr()), "emd")
             outs[f"s{split}"] = (match, cost)
         if V1 is not None:
             match = torch.empty((B, m, n), device="cuda"); cost = torch.empty(B, device="cuda")
@@ -57,6 +57,16 @@ def main():
             dm = float((mt - base[0]).abs().max()); eq = bool(torch.equal(mt, base[0]))
             dc = float(((c - base[1]).abs() / base[1].abs()).max())
             line.append(f"{k}: match {'BIT-EQUAL' if eq else f'maxdiff {dm:.3e}'} cost rel {dc:.2e};")
+        if REF is not None:                                 # backward on the reference's match: gradients bit for bit?
+            wm = outs["ref"][0]
+            g1, g2 = torch.empty_like(a), torch.empty_like(b)
+            check(L.l3d_emd_backward(p(a), p(b), p(wm), B, n, m, p(g1), p(g2), stream_ptr()), "emd bwd")
+            w1, w2 = torch.zeros_like(a), torch.zeros_like(b)
+            torch.cuda.synchronize()
+            REF.ref_emd_backward(B, n, m, p(a), p(b), p(wm), p(w1), p(w2))
+            torch.cuda.synchronize()
+            for nm, got, want in (("grad1", g1, w1), ("grad2", g2, w2)):
+                line.append(f"{nm} {'BIT-EQUAL' if torch.equal(got, want) else f'maxdiff {float((got - want).abs().max()):.3e} of {float(want.abs().max()):.2e}'};")
         print(" ".join(line), flush=True)
 
     print("== time (us per call, best of 3 batches)")
@@ -67,7 +77,7 @@ def main():
         match = torch.empty((B, m, n), device="cuda"); cost = torch.empty(B, device="cuda")
         pairs = B * n * m
         for split in (0, 1, 2, 4):
-            t = timeit(lambda: check(L.l3d_emd_forward_split(p(a), p(b), B, n, m, p(match), p(cost), p(ws), split, stream_ptr()), "emd"),
+            t = timeit(lambda: check(L.l3d_emd_forward(p(a), p(b), B, n, m, p(match), p(cost), p(ws), split, stream_ptr()), "emd"),
                        warm=2, iters=10)
             print(f"emd_fwd_B{B}_n{n}_split{split}  {t:9.1f} us   {39 * pairs / t / 1e3:8.1f} Gexp/s", flush=True)
         g1, g2 = torch.empty_like(a), torch.empty_like(b)

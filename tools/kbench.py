@@ -75,6 +75,16 @@ def main():
                                                                         _p(g1), _p(g2), v, _s()), "cd bwd"),
                            warm=2, iters=5 if Nc > 4096 else 50)
                 res[f"chamfer_bwd_{name}_{tag}"] = (t, (Nc + Mc) * Bc / t, "Mpoint/s")
+        # EMD (emd.hip): forward = 20 sweeps + match + costsum, backward = grad1 + grad2; c2 shape and the c4-coarse shape
+        for tag, (Be, ne) in (("c2", (32, 1024)), ("c4coarse", (64, 1024))):
+            ea, eb = torch.rand(Be, ne, 3, device=dev), torch.rand(Be, ne, 3, device=dev)
+            ews = torch.empty(_l().l3d_emd_workspace_bytes(Be, ne, ne), dtype=torch.uint8, device=dev)
+            em, ec = torch.empty(Be, ne, ne, device=dev), torch.empty(Be, device=dev)
+            eg1, eg2 = torch.empty_like(ea), torch.empty_like(eb)
+            t = timeit(lambda: _c(_l().l3d_emd_forward(_p(ea), _p(eb), Be, ne, ne, _p(em), _p(ec), _p(ews), 0, _s()), "emd"), warm=2, iters=10)
+            res[f"emd_fwd_{tag}"] = (t, 490.0 * Be * ne * ne / t / 1e6, "T lane-op-eq/s (of 78.6 packed)")
+            t = timeit(lambda: _c(_l().l3d_emd_backward(_p(ea), _p(eb), _p(em), Be, ne, ne, _p(eg1), _p(eg2), _s()), "emd bwd"), warm=2, iters=10)
+            res[f"emd_bwd_{tag}"] = (t, 2 * 4.0 * Be * ne * ne / t / 1e3, "GB/s (match read twice)")
         net = DGCNN(emb_dims=1024).to(dev).eval()
         idx = U.knn(xt, k)
         packed = net._packed.get([net.conv1, net.conv2, net.conv3, net.conv4], [net.bn1, net.bn2, net.bn3, net.bn4], x.device)

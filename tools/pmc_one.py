@@ -1,5 +1,5 @@
 """Run one kernel a few times (for rocprofv3 --pmc passes).
-usage: pmc_one.py knn|chamfer|edgeconv|edgeconv_split|edgeconv_f16b|conv5|conv5_split|conv5_f16|conv5_f16_2p|group_c5|sa_mlp3"""
+usage: pmc_one.py emd|emd_sweep|knn|chamfer|edgeconv|edgeconv_split|edgeconv_f16b|conv5|conv5_split|conv5_f16|conv5_f16_2p|group_c5|sa_mlp3"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -29,13 +29,13 @@ with torch.no_grad():
             qg(xyz5, new5, feat5)
         torch.cuda.synchronize()
         sys.exit(0)
-    if what == "emd":                            # EMD forward at B 32, n = m = 1024 (emd.hip: 20 sweeps + match + costsum)
+    if what in ("emd", "emd_sweep"):                            # EMD forward at B 32, n = m = 1024 (emd.hip: 20 sweeps + match + costsum)
         from learning3d_amd._lib import lib, check, ptr, stream_ptr
         B_, n_ = 32, 1024
         ws_ = torch.empty(lib().l3d_emd_workspace_bytes(B_, n_, n_), dtype=torch.uint8, device="cuda")
         mt_ = torch.empty((B_, n_, n_), device="cuda"); c_ = torch.empty(B_, device="cuda")
         for _ in range(3):
-            check(lib().l3d_emd_forward(ptr(a), ptr(b), B_, n_, n_, ptr(mt_), ptr(c_), ptr(ws_), stream_ptr()), "emd")
+            check(lib().l3d_emd_forward(ptr(a), ptr(b), B_, n_, n_, ptr(mt_), ptr(c_), ptr(ws_), 0, stream_ptr()), "emd")
         torch.cuda.synchronize()
         sys.exit(0)
     if what == "attention":                      # DCP's attention call: B 32, 4 heads x 128, N = M = 1024, maxima ready, plane image out
