@@ -250,13 +250,22 @@ __global__ __launch_bounds__(64 * CWAVES) void chamfer_fwd_packed_kernel(const f
     }
 }
 
+// chamfer_mfma.hip: candidates ranked on the fp16 matrix cores, exact by refinement (same bits out)
+int l3d_chamfer_forward_mfma(const float *xyz1, const float *xyz2, int B, int N, int M, float *dist1, float *dist2,
+                             int32_t *idx1, int32_t *idx2, hipStream_t stream);
+
 extern "C" int l3d_chamfer_forward_variant(const float *xyz1, const float *xyz2, int B, int N, int M,
                                            float *dist1, float *dist2, int32_t *idx1, int32_t *idx2,
                                            int variant, l3d_stream_t stream)
 {
-    L3D_REQUIRE(xyz1 && xyz2 && dist1 && dist2 && idx1 && idx2 && B > 0 && N > 0 && M > 0 && variant >= 0 && variant <= 2);
+    L3D_REQUIRE(xyz1 && xyz2 && dist1 && dist2 && idx1 && idx2 && B > 0 && N > 0 && M > 0 && variant >= 0 && variant <= 3);
+    L3D_REQUIRE(B <= 65535);
     const int l3d_chamfer_forward_mode = variant;
     const int mx = N > M ? N : M;
+    // large clouds (from 4096 x 4096 pairs per cloud: 81 vs 96 us at B 16, 2.0 vs 4.9 ms at config 4; below that the per-pair kernel
+    // wins, profiles/round5_chamfer_bench.txt): the matrix-core ranking + exact refinement; variant 3 forces it, 0 and 2 never use it
+    if (variant == 3 || (variant == 1 && (long)N * M >= (1L << 24)))
+        return l3d_chamfer_forward_mfma(xyz1, xyz2, B, N, M, dist1, dist2, idx1, idx2, (hipStream_t)stream);
     // two queries per lane, packed fp32 (chamfer_fwd_packed_kernel) once that still gives every SIMD a wave;
     // tiny problems keep one query per lane for the workgroup count
     const long wgs2 = (long)l3d_divup(mx, 128) * B * 2;

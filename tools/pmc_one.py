@@ -38,6 +38,15 @@ with torch.no_grad():
             check(lib().l3d_emd_forward(ptr(a), ptr(b), B_, n_, n_, ptr(mt_), ptr(c_), ptr(ws_), 0, stream_ptr()), "emd")
         torch.cuda.synchronize()
         sys.exit(0)
+    if what == "chamfer_c4":                     # config 4's Chamfer search at B 8 (l3d_chamfer_forward picks chamfer_mfma_kernel at 16384 x 16384)
+        from learning3d_amd._lib import lib, check, ptr, stream_ptr
+        a_, b_ = torch.rand(8, 16384, 3, device="cuda") - 0.5, torch.rand(8, 16384, 3, device="cuda") - 0.5
+        d1_, d2_ = torch.empty(8, 16384, device="cuda"), torch.empty(8, 16384, device="cuda")
+        i1_, i2_ = torch.empty(8, 16384, dtype=torch.int32, device="cuda"), torch.empty(8, 16384, dtype=torch.int32, device="cuda")
+        for _ in range(3):
+            check(lib().l3d_chamfer_forward(ptr(a_), ptr(b_), 8, 16384, 16384, ptr(d1_), ptr(d2_), ptr(i1_), ptr(i2_), stream_ptr()), "cd")
+        torch.cuda.synchronize()
+        sys.exit(0)
     if what == "attention":                      # DCP's attention call: B 32, 4 heads x 128, N = M = 1024, maxima ready, plane image out
         from learning3d_amd._lib import lib, check, ptr, stream_ptr
         B_, H_, D_, N_ = 32, 4, 128, 1024
