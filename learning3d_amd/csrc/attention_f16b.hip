@@ -458,7 +458,7 @@ static int l3d_attention_absmax3(const float *q, const float *k, const float *v,
 }
 
 // workspace: 16 bytes of device memory (the three maxima; maxima_ready != 0: already there, e.g. from
-// l3d_pointwise_conv_f16_absmax); ctx [B, H D, N] fp32 and / or ctx_img = the context as an fp16 activation image
+// l3d_pointwise_conv_f16 with its amax argument); ctx [B, H D, N] fp32 and / or ctx_img = the context as an fp16 activation image
 // (l3d_f16_act_bytes(B N, H D) bytes) for l3d_pointwise_conv_f16; everything else as l3d_attention_forward_strided
 extern "C" int l3d_attention_forward_f16b(const float *q, const float *k, const float *v, int B, int H, int D, int N, int M,
                                           long q_bstride, long k_bstride, long v_bstride, float scale, void *workspace,

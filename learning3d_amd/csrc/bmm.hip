@@ -62,17 +62,25 @@ __device__ __forceinline__ BmFrag<V> bm_fetch(const float *__restrict__ base, lo
         }
     } else if (sr == 1) {
         const int k = k0 + (t >> 4), r = r0 + (t & 15) * V;
-        const float kin = k < K ? 1.f : 0.f;
+        const bool kin = k < K;
         const long kc = min(k, K - 1);
+        // unconditional loads from clamped indices, then a SELECT on the loaded value (a 0 / 1 factor would turn an Inf / NaN
+        // sitting at the clamped index into NaN inside a tail that torch.matmul does not read)
+        float ld[V];
 #pragma unroll
-        for (int i = 0; i < V; i++) f.v[i] = base[kc * sc + min(r + i, R - 1)] * (r + i < R ? kin : 0.f);
+        for (int i = 0; i < V; i++) ld[i] = base[kc * sc + min(r + i, R - 1)];
+#pragma unroll
+        for (int i = 0; i < V; i++) f.v[i] = (kin && r + i < R) ? ld[i] : 0.f;
     } else {
         constexpr int TPR = 16 / V;
         const int r = r0 + t / TPR, k = k0 + (t % TPR) * V;
-        const float rin = r < R ? 1.f : 0.f;
+        const bool rin = r < R;
         const long rc = min(r, R - 1);
+        float ld[V];
 #pragma unroll
-        for (int i = 0; i < V; i++) f.v[i] = base[rc * sr + (long)min(k + i, K - 1) * sc] * (k + i < K ? rin : 0.f);
+        for (int i = 0; i < V; i++) ld[i] = base[rc * sr + (long)min(k + i, K - 1) * sc];
+#pragma unroll
+        for (int i = 0; i < V; i++) f.v[i] = (rin && k + i < K) ? ld[i] : 0.f;
     }
     return f;
 }

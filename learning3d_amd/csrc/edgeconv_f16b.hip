@@ -789,7 +789,7 @@ extern "C" int EF_ENTRY(const float *xyz, const int64_t *idx, int B, int N, int 
                                         const float *packed, void *out, int out_mode, int *range_flag, l3d_stream_t stream)
 {
     L3D_REQUIRE(xyz && idx && packed && out && B > 0 && N > 0 && k > 0 && out_mode >= 0 && out_mode <= 2);
-    const float mres = out_mode == 2 ? 1.0f : 4096.0f;           // out_mode 2: the image's residual plane unscaled (l3d_pointwise_conv_f16_2p)
+    const float mres = out_mode == 2 ? 1.0f : 4096.0f;           // out_mode 2: the image's residual plane unscaled (l3d_pointwise_conv_f16 with L3D_CONV_F16_TWO_PLANE)
     if (k > 20 || B > 65535 || (((size_t)packed) & 15) || (((size_t)out) & 15)) return L3D_ERR_UNSUPPORTED;
     const long ntiles = (long)B * l3d_divup(N, 16);
     if (ntiles > 0x7fffffffL / 2) return L3D_ERR_UNSUPPORTED;

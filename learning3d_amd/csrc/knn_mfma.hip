@@ -98,14 +98,16 @@ __global__ __launch_bounds__(256, 2) void knn_mfma_kernel(const float *__restric
         float x[4], y[4], z[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            // unconditional loads from a clamped index, zeroed by a 0 / 1 factor: `if (c < N) load` is an exec-masked branch with a
-            // wait at its join, and the four loads then leave one round trip behind the other
-            const int c = c0 + 256 * u, cc = min(c, N - 1);
-            const float in = c < N ? 1.f : 0.f;
-            x[u] = cloud[cc * 3 + 0] * in;
-            y[u] = cloud[cc * 3 + 1] * in;
-            z[u] = cloud[cc * 3 + 2] * in;
+            // unconditional loads from a clamped index (`if (c < N) load` is an exec-masked branch with a wait at its join, and the
+            // four loads then leave one round trip behind the other); padding slots are zeroed by a select further down
+            const int cc = min(c0 + 256 * u, N - 1);
+            x[u] = cloud[cc * 3 + 0];
+            y[u] = cloud[cc * 3 + 1];
+            z[u] = cloud[cc * 3 + 2];
         }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (c0 + 256 * u >= N) { x[u] = 0.f; y[u] = 0.f; z[u] = 0.f; }      // v_cndmask on the loaded values (Inf * 0 would be NaN)
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int c = c0 + 256 * u;

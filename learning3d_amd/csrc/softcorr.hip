@@ -556,7 +556,7 @@ extern "C" int l3d_layernorm_planes_cf(const float *x, const float *a, const flo
     return l3d_check_launch();
 }
 
-// y as l3d_layernorm_ref (or NULL: planes only -- every consumer of the pointer network's sublayer norms reads the image, and the
+// y = the layer norm's fp32 values (or NULL: planes only -- every consumer of the pointer network's sublayer norms reads the image, and the
 // fp32 copy is a third of this kernel's traffic), plus img = the activation image of y (l3d_f16_act_bytes(rows, C) bytes)
 extern "C" int l3d_layernorm_planes(const float *x, const float *a, const float *b, float eps, long rows, int C, float *y,
                                     void *img, l3d_stream_t stream)

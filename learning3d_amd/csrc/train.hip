@@ -463,7 +463,7 @@ extern "C" int l3d_bn_backward_finalize(const double *part_local, int Bl, const 
 // ---------------------------------------------------------------------------------------------
 // Backward of the pointer network's LayerNorm (utils/transformer.py:109-119: y = a (x - mean) / (std + eps) + b with the UNBIASED
 // std and eps added to std) -- the torch composition is ~8 launches forward and ~20 backward over [rows, C]; forward is
-// l3d_layernorm_ref (softcorr.hip), this is its backward in one pass over x and g:
+// l3d_layernorm_planes (softcorr.hip), this is its backward in one pass over x and g:
 //   xc = x - mean, s = std, d = s + eps, dz = g a
 //   dxc_i = dz_i / d - (sum_j dz_j xc_j) xc_i / (d^2 (C-1) s),   dx_i = dxc_i - mean_j dxc_j
 //   da_c = sum_rows g z,  db_c = sum_rows g          (z = xc / d)

@@ -222,12 +222,12 @@ def checkpointed(module, impl, *tensors):
     from .._lib import on_device_of
     dev = next((t.device for t in tensors if isinstance(t, torch.Tensor) and t.is_cuda), None)
 
-    def guarded(fn):
-        return run_guarded(dev, fn) if dev is not None else fn()
+    def guarded(fn, repeatable=True):
+        return run_guarded(dev, fn, repeatable) if dev is not None else fn()
 
     if not torch.is_grad_enabled() or recomputing() or _stochastic_or_batch_dependent(module):
         with on_device_of(*tensors):                 # tensors on a GPU that is not the current one: switch for the call
-            return guarded(lambda: impl(*tensors))
+            return guarded(lambda: impl(*tensors), repeatable=not _stochastic_or_batch_dependent(module))
     params = [p for p in module.parameters() if p.requires_grad]
     if not params and not any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
         return guarded(lambda: impl(*tensors))
@@ -582,14 +582,14 @@ class L3DRangeError(RuntimeError):
 _RANGE_FLAGS = {}
 
 
-_RANGE_USES = 0           # how often a launch wrapper fetched a range flag (run_guarded: no fetch during a call = nothing to wait for)
+# how often a launch wrapper of THIS THREAD fetched a range flag (run_guarded: no fetch during a call = nothing to wait for) lives in
+# _TLS.range_uses, the guard's nesting depth in _TLS.guard_depth: per-GPU threads (DataParallel style) must not see each other's
 
 
 def range_flag(device):
     """One int32 in pinned (device-mapped) host memory per GPU.  A f16x2 kernel stores 1 into it when an activation
     leaves fp16's range (never for BatchNorm'd networks); the host reads it without a device sync."""
-    global _RANGE_USES
-    _RANGE_USES += 1                                 # a kernel is about to be handed the flag: this call can raise it
+    _TLS.range_uses = getattr(_TLS, "range_uses", 0) + 1     # a kernel is about to be handed the flag: this call can raise it
     key = torch.device(device).index or 0
     f = _RANGE_FLAGS.get(key)
     if f is None:
@@ -626,34 +626,36 @@ def range_raised(device, clear=True):
     return hit
 
 
-_GUARD_DEPTH = 0          # run_guarded is re-entrant: the OUTERMOST call owns the verdict (one wait per model call, not per sub-module)
-
-
-def run_guarded(device, run):
+def run_guarded(device, run, repeatable=True):
     """run() launches a model's fused forward under the arithmetic gemm_arith() reports and returns its outputs.  With f16x2
     the call's range verdict is read before returning (RANGE_POLICY) and an overflowing call is repeated on bf16x3.  Nested
     calls (DCP -> DGCNN / Transformer / SVDHead, Classifier -> PointNet) run straight through: the outermost one -- every
-    model's forward enters through `checkpointed`, which calls this -- waits once and repeats the WHOLE forward if needed."""
-    global RANGE_RETRIES, _GUARD_DEPTH
-    if gemm_arith() != "f16x2" or _GUARD_DEPTH > 0:
+    model's forward enters through `checkpointed`, which calls this -- waits once and repeats the WHOLE forward if needed.
+    The guard is re-entrant per THREAD (depth and flag-use counters are thread-local).  repeatable=False (train-mode BatchNorm,
+    dropout: a second run() would update the running statistics and advance the RNG twice for one step): an overflow raises
+    L3DRangeError instead of repeating."""
+    global RANGE_RETRIES
+    if gemm_arith() != "f16x2" or getattr(_TLS, "guard_depth", 0) > 0:
         return run()
     if _capturing() or RANGE_POLICY == "async":
         if not _capturing():
             check_range(device)                      # an earlier call's verdict, if it has completed
         return run()
-    _GUARD_DEPTH += 1
+    _TLS.guard_depth = 1
     try:
-        uses = _RANGE_USES
+        uses = getattr(_TLS, "range_uses", 0)
         out = run()
-        if _RANGE_USES != uses and range_raised(device):      # no f16x2 launch took the flag (FlowNet3D's fp32 stacks): no wait
-            if RANGE_POLICY == "raise":
-                raise L3DRangeError("an activation left the fp16 range (|x| > 60000) inside a f16x2 matrix-core kernel "
-                                    "(_fused.RANGE_POLICY = 'raise')")
+        if getattr(_TLS, "range_uses", 0) != uses and range_raised(device):      # no f16x2 launch took the flag (FlowNet3D's fp32 stacks): no wait
+            if RANGE_POLICY == "raise" or not repeatable:
+                raise L3DRangeError("an activation left the fp16 range (|x| > 60000) inside a f16x2 matrix-core kernel"
+                                    + (" (_fused.RANGE_POLICY = 'raise')" if repeatable else
+                                       " of a forward that cannot be repeated (batch statistics / dropout): run it under "
+                                       "_fused.arith('bf16x3')"))
             RANGE_RETRIES += 1
             with arith("bf16x3"):
                 out = run()
     finally:
-        _GUARD_DEPTH -= 1
+        _TLS.guard_depth = 0
     return out
 
 

@@ -29,28 +29,59 @@ from . import _fused
 
 
 _SHARD_SIZES = None      # clouds per rank, in rank order, when the shards of the global batch are NOT all equal (declare_shard_sizes)
+_SEEN_ROWS = {}          # local cloud count -> every rank's count, as discovered the first time that count was seen undeclared
 
 
 def declare_shard_sizes(sizes):
-    """Tell the BatchNorm statistics exchange how many clouds every rank holds (list in rank order; None: equal shards, the
-    default).  Equal shards are what torch's DistributedSampler hands out and need no declaration; a caller that cuts one global
-    batch with parallel.shard_bounds (remainder on the first ranks: the last batch of an epoch) declares the sizes once per step --
-    parallel.declare_global_batch(B) does -- instead of every layer asking every rank (an all_reduce plus a host read per
-    BatchNorm layer, forward and backward, stalled the launch pipeline ~70 times per FlowNet3D step)."""
+    """Tell the BatchNorm statistics exchange how many clouds every rank holds (list in rank order; None: back to discovery).
+    Equal shards are what torch's DistributedSampler hands out; parallel.shard / parallel.declare_global_batch declare the sizes
+    they cut themselves, every time they are called.  The declaration is STICKY until replaced or cleared
+    (declare_global_batch(None)); a later step whose local cloud count does not match it raises a ValueError on that rank.
+    Without a declaration the exchange DISCOVERS the sizes (gather_cloud_partials)."""
     global _SHARD_SIZES
     _SHARD_SIZES = None if sizes is None else [int(v) for v in sizes]
 
 
+def _discover_sizes(rows, device):
+    """Every rank's cloud count through one all_gather of one integer and ONE host read (the cost round 4 removed from every
+    layer: ~70 stalls per FlowNet3D step).  It runs once per distinct local count (cached), on every call when
+    L3D_CHECK_SHARDS=1 (debugging an exchange that hangs), never when the declared sizes fit.  All ranks take the same branch
+    as long as their counts change together -- which DistributedSampler and parallel.shard guarantee; a loader that changes
+    one rank's count while another rank's stays the same must declare (declare_shard_sizes) or set L3D_CHECK_SHARDS=1."""
+    import os
+    if rows in _SEEN_ROWS and os.environ.get("L3D_CHECK_SHARDS") != "1":
+        return _SEEN_ROWS[rows]
+    world = dist.get_world_size()
+    staged = device.type == "cuda" and dist.get_backend() == "gloo"
+    mine = torch.tensor([rows], dtype=torch.int64, device="cpu" if staged else device)
+    allr = torch.empty(world, dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(allr, mine)
+    sizes = [int(v) for v in allr.tolist()]
+    if os.environ.get("L3D_CHECK_SHARDS") != "1":
+        _SEEN_ROWS[rows] = sizes
+    return sizes
+
+
 def gather_cloud_partials(part):
     """part [B_local, C, 2] fp64 (this rank's clouds) -> [B_global, C, 2] in global cloud order (ranks hold contiguous
-    shards, parallel.shard_bounds).  One collective, no host synchronisation: equal shards go out as they are; declared unequal
-    shards (declare_shard_sizes) are padded to the largest one and cut back after the gather -- same code on RCCL and gloo.
+    shards, parallel.shard_bounds).  One collective per call: equal shards go out as they are; unequal shards are padded to
+    the largest one and cut back after the gather -- same code on RCCL and gloo.  The per-rank sizes come from the
+    declaration (declare_shard_sizes; parallel.shard declares what it cuts), else from a discovery exchange that costs a host
+    read once per distinct local count -- undeclared uneven shards no longer launch a collective with mismatched sizes.
     Single process: returned as is."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         world, rank = dist.get_world_size(), dist.get_rank()
         sizes = _SHARD_SIZES
         if sizes is not None and (len(sizes) != world or sizes[rank] != part.shape[0]):
-            raise ValueError(f"declared shard sizes {sizes} do not match this rank's {part.shape[0]} clouds (rank {rank} of {world})")
+            # a stale declaration cannot be repaired locally (it may still fit the OTHER ranks, who would then enter a different
+            # collective): fail loudly on the rank that sees it; torchrun takes the job down
+            raise ValueError(f"declared shard sizes {sizes} do not match this rank's {part.shape[0]} clouds (rank {rank} of {world}): "
+                             "declare every step (parallel.shard / parallel.declare_global_batch do) or clear it with declare_global_batch(None)")
+        if sizes is None:
+            sizes = _discover_sizes(int(part.shape[0]), part.device)
+            if sizes[rank] != part.shape[0]:
+                raise RuntimeError(f"shard-size discovery is stale: rank {rank} holds {part.shape[0]} clouds, the cached exchange "
+                                   f"says {sizes}; declare the sizes (parallel.declare_global_batch) or set L3D_CHECK_SHARDS=1")
         part = part.contiguous()
         # device tensors on a gloo group (two ranks sharing one GPU in tests/test_gpu_two_ranks.py; RCCL wants a device per rank):
         # the few KB go through the host for the collective only
@@ -62,7 +93,7 @@ def gather_cloud_partials(part):
             dist.all_gather_into_tensor(flat, src)                       # concatenation along dim 0 in rank order
             return flat.to(part.device) if staged else flat
 
-        if sizes is None or len(set(sizes)) == 1:
+        if len(set(sizes)) == 1:
             return gather(part, part.shape[0])
         big = max(sizes)
         padded = part if part.shape[0] == big else torch.cat([part, part.new_zeros((big - part.shape[0],) + tuple(part.shape[1:]))])
@@ -299,7 +330,7 @@ def max_over_last(x):
 
 class _LayerNormRef(torch.autograd.Function):
     """The pointer network's LayerNorm (reference utils/transformer.py:109-119: unbiased std, eps added to std) over the last
-    axis: l3d_layernorm_ref forward, l3d_layernorm_ref_backward (one pass over x and dy; da / db summed in a fixed order)."""
+    axis: l3d_layernorm_planes (img NULL) forward, l3d_layernorm_ref_backward (one pass over x and dy; da / db summed in a fixed order)."""
 
     @staticmethod
     def forward(ctx, x, a, b, eps):

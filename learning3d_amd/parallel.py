@@ -50,7 +50,11 @@ def declare_global_batch(global_batch, world=None):
 
 
 def shard(tensor, rank, world):
+    """This rank's contiguous slice of a global batch.  Also records the sizes it cut (declare_global_batch), so a train-mode
+    BatchNorm exchange behind it knows every rank's cloud count without asking."""
     lo, hi = shard_bounds(tensor.shape[0], rank, world)
+    if world > 1:
+        declare_global_batch(tensor.shape[0], world)
     return tensor[lo:hi]
 
 

@@ -127,7 +127,8 @@ def clones(module, N):
 def attention(query, key, value, mask=None, dropout=None):
     d_k = query.size(-1)
     if mask is None and dropout is None and TRAIN_LINEAR == "rows" and query.is_cuda and query.dtype == torch.float32 \
-            and key.size(-2) <= 8192 and query.shape[:-2] == key.shape[:-2] == value.shape[:-2]:
+            and key.size(-2) <= 8192 and query.shape[:-2] == key.shape[:-2] == value.shape[:-2] and 2 <= query.dim() <= 4 \
+            and math.prod(query.shape[:-2]) <= 65535:         # what _rows / l3d_bmm_f32 take; anything else: the torch ops below
         from ..models import _rows
         return _rows.attention_core(query, key, value, 1.0 / math.sqrt(d_k))          # differentiable, HIP forward and backward
     scores = torch.matmul(query, key.transpose(-2, -1)) / math.sqrt(d_k)

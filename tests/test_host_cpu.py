@@ -258,7 +258,7 @@ def test_bench_self_launches_two_ranks_gloo():
     assert j["workload"] == "c5" and j["rccl_ranks"] == 2 and j["digest"] == j["digest_expected"]
 
 
-def _bn_stats_rank(rank, world, port, q, NB=8):
+def _bn_stats_rank(rank, world, port, q, NB=8, mode="declared"):
     import os
     import numpy as np
     import torch
@@ -270,8 +270,10 @@ def _bn_stats_rank(rank, world, port, q, NB=8):
     rng = np.random.default_rng(5)
     z = rng.standard_normal((NB, 16, 300)).astype(np.float32)              # the WHOLE batch, same on every rank
     lo, hi = parallel.shard_bounds(z.shape[0], rank, world)
-    if NB % world:
+    if mode == "declared" and NB % world:
         parallel.declare_global_batch(NB, world)                              # uneven shards are declared, not asked for per layer
+    elif mode == "shard":
+        assert tuple(parallel.shard(torch.from_numpy(z), rank, world).shape) == (hi - lo, 16, 300)   # shard() declares what it cuts
     zs = z[lo:hi].astype(np.float64)
     # per-cloud fp64 partial sums of this rank's shard: the stand-in for l3d_channel_stats (tested on the GPU against numpy)
     part = torch.from_numpy(np.stack([zs.sum(-1), (zs ** 2).sum(-1)], axis=-1))
@@ -281,11 +283,13 @@ def _bn_stats_rank(rank, world, port, q, NB=8):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("NB", [8, 7])
-def test_two_rank_gloo_batchnorm_statistics_bit_identical(NB):
+@pytest.mark.parametrize("NB,mode", [(8, "declared"), (7, "declared"), (7, "undeclared"), (7, "shard")])
+def test_two_rank_gloo_batchnorm_statistics_bit_identical(NB, mode):
     """train-mode BatchNorm statistics over a batch sharded across 2 ranks (gloo) equal the
     single-process statistics BIT FOR BIT: per-cloud fp64 partial sums, all_gather, addition in global cloud order.
-    NB = 7: an uneven last batch (4 + 3 clouds), declared with parallel.declare_global_batch, padded for the gather."""
+    NB = 7: an uneven last batch (4 + 3 clouds), padded for the gather -- declared with parallel.declare_global_batch, declared by
+    parallel.shard itself, or NOT declared at all (the exchange discovers the sizes, one host read per distinct local count:
+    ADVICE r4 -- undeclared uneven shards used to launch a collective with mismatched sizes)."""
     import socket
     import numpy as np
     import torch
@@ -296,7 +300,7 @@ def test_two_rank_gloo_batchnorm_statistics_bit_identical(NB):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_bn_stats_rank, args=(r, 2, port, q, NB)) for r in range(2)]
+    procs = [ctx.Process(target=_bn_stats_rank, args=(r, 2, port, q, NB, mode)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in range(2)]
