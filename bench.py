@@ -253,6 +253,73 @@ def other_configs(dev, iters=10, warm=3):
             out["c5_flownet3d_forward"] = {"ms_per_step": t, "clouds_per_s": 32 / t * 1e3, "shape": "32 cloud pairs per GPU, N=8192"}
         except Exception as exc:
             out["c5_flownet3d"] = {"error": f"{type(exc).__name__}: {exc}"}
+    # ---- what README / DESIGN quote for BASELINE configs but only builder runs carried until round 4
+    try:            # configs[1] in the reference's own arithmetic: every GEMM on the fp32 matrix cores (what `--arith fp32` times)
+        from learning3d_amd.models import _fused
+        torch.manual_seed(1)
+        net = DGCNN(emb_dims=EMB).to(dev).eval()
+        x = torch.rand((B_PER_GPU, NPTS, 3), generator=g).to(dev)
+        a = torch.rand((B_PER_GPU, NPTS, 3), generator=g).to(dev)
+        b = torch.rand((B_PER_GPU, NPTS, 3), generator=g).to(dev)
+        cdl = ChamferDistanceLoss()
+        prev = _fused.SPLIT_BF16
+        _fused.SPLIT_BF16 = False
+        try:
+            with torch.no_grad():
+                t = ms(lambda: (net(x), cdl(a, b)))
+        finally:
+            _fused.SPLIT_BF16 = prev
+        out["c2_strict_fp32_arith"] = {"ms_per_step": t, "clouds_per_s": B_PER_GPU / t * 1e3,
+                                       "frac_of_fp32_mfma_peak": (EDGECONV_FLOP_PER_CLOUD + CONV5_FLOP_PER_CLOUD) * B_PER_GPU / (t * 1e-3) / (MFMA_F32_PEAK_TF * 1e12),
+                                       "note": "eager launches; the whole step (kNN + EdgeConv + conv5 + Chamfer) over the fp32 MFMA peak"}
+        del net
+    except Exception as exc:
+        out["c2_strict_fp32_arith"] = {"error": f"{type(exc).__name__}: {exc}"}
+    try:            # training steps on the HIP training route (forward + backward + SGD step, train-mode BatchNorm), synthetic data
+        from learning3d_amd.models import DCP, DGCNN, PCN
+        tr = {}
+
+        def train_ms(net, data, loss_fn):
+            opt = torch.optim.SGD(net.parameters(), lr=1e-4)
+
+            def step():
+                opt.zero_grad(set_to_none=True)
+                loss_fn(net, data).backward()
+                opt.step()
+            with torch.enable_grad():
+                return ms(step)
+        torch.manual_seed(5)
+        tr["dgcnn_B32_N1024_emb1024_ms"] = train_ms(DGCNN(emb_dims=EMB).to(dev).train(), torch.rand((32, 1024, 3), generator=g).to(dev),
+                                                    lambda n, d: n(d).max(dim=2)[0].square().mean())
+        cdl = ChamferDistanceLoss()
+        gt = (torch.rand((32, 16384, 3), generator=g) - 0.5).to(dev)
+        tr["pcn_chamfer_B32_2048_to_16384_ms"] = train_ms(PCN(emb_dims=1024, num_coarse=1024, grid_size=4, detailed_output=True).to(dev).train(),
+                                                          (torch.rand((32, 2048, 3), generator=g) - 0.5).to(dev),
+                                                          lambda n, d: cdl(gt, n(d)["fine_output"]))
+        del gt
+        tp, sr = (torch.rand((32, 1024, 3), generator=g) - 0.5).to(dev), (torch.rand((32, 1024, 3), generator=g) - 0.5).to(dev)
+        tr["dcp_v2_B32_N1024_ms"] = train_ms(DCP(feature_model=DGCNN(emb_dims=512), pointer_="transformer", head="svd").to(dev).train(), (tp, sr),
+                                             lambda n, d: (lambda o: o["est_R"].square().mean() + o["est_t"].square().mean())(n(d[0], d[1])))
+        tr["note"] = "forward + backward + SGD step per model, train mode, eager, HIP events around the batch of steps"
+        out["training_steps"] = tr
+    except Exception as exc:
+        out["training_steps"] = {"error": f"{type(exc).__name__}: {exc}"}
+    try:            # configs[4] as a stream of batches (`--workload c5`, its own JSON line): pipelined and serial, one subprocess each
+        import subprocess
+        c5 = {}
+        for tag, extra in (("pipelined", []), ("serial", ["--c5-serial"])):
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "c5", "--gpus", "1", "--steps", "40", "--warmup", "10",
+                                "--no-cpu-baseline", "--no-other-configs"] + extra, capture_output=True, text=True, timeout=240)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode == 0 and line:
+                j = json.loads(line[-1])
+                c5[tag] = {"clouds_per_s": j["value"], "ms_per_step": j["ms_per_step"], "roofline_frac": (j.get("roofline") or {}).get("frac")}
+            else:
+                c5[tag] = {"error": (r.stderr or r.stdout)[-300:]}
+        c5["note"] = "bench.py --workload c5 --steps 40 --warmup 10 in a child process while this one idles: FPS + ball query + fused set-abstraction layer, 32 clouds of 8192 points per step"
+        out["c5_setconv_stream"] = c5
+    except Exception as exc:
+        out["c5_setconv_stream"] = {"error": f"{type(exc).__name__}: {exc}"}
     try:            # north_star's other loss: approximate EMD (losses/emd.py -> emd.hip), forward and backward at B 32, n = m = 1024
         from learning3d_amd._lib import check, lib, ptr, stream_ptr
         Be, ne = 32, 1024

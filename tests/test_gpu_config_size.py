@@ -50,6 +50,30 @@ def test_flownet3d_reference_golden(golden):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
 
 
+def test_flownet3d_whole_model_at_config5_size_vs_oracle():
+    """The WHOLE FlowNet3D forward at config 5's point count, N = 8192 (bench.py's `c5_flownet3d_forward` inputs: clipped normal
+    coordinates, second frame = first + 0.05 noise, uniform features), against oracle.flownet3d_forward_torch (the K7-K16
+    restatements + torch-CPU conv / BatchNorm, itself pinned to the reference model at N = 2048 by test_oracle_golden.py): the
+    routes that only N = 8192 selects -- four-slot 3-NN, cell-list ball query, knn_select, the fused set-abstraction kernel --
+    are compared end to end here, not just timed.  Sampled coordinates bit-exact, features and flow rtol 1e-4 / atol 1e-5."""
+    from learning3d_amd.models import FlowNet3D
+    net = seeded_params(FlowNet3D(), 4).cuda().eval()
+    g = torch.Generator().manual_seed(7)
+    B, N = 2, 8192
+    pc1 = torch.clamp(torch.randn((B, 3, N), generator=g), -2, 2)
+    pc2 = (pc1 + 0.05 * torch.randn((B, 3, N), generator=g)).contiguous()
+    f1, f2 = torch.rand((B, 3, N), generator=g), torch.rand((B, 3, N), generator=g)
+    with torch.no_grad():
+        sf = net(pc1.cuda(), pc2.cuda(), f1.cuda(), f2.cuda())
+        l1_pc1, l1_f1 = net.sa1(pc1.cuda(), f1.cuda())
+    w = {k: v.cpu().numpy() for k, v in net.state_dict().items()}
+    want, inter = oracle.flownet3d_forward_torch(pc1.numpy(), pc2.numpy(), f1.numpy(), f2.numpy(), w, return_intermediates=True)
+    assert np.array_equal(l1_pc1.cpu().numpy(), inter["l1_pc1"])
+    np.testing.assert_allclose(l1_f1.cpu().numpy(), inter["l1_feature1"], rtol=1e-4, atol=1e-5)
+    assert sf.shape == (B, 3, N)
+    np.testing.assert_allclose(sf.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
+
+
 def test_flownet3d_sa1_config5_shape_golden(golden):
     """Config 5's layer at config size: sa1 (npoint 1024 of N 8192, r 0.5, K 16, mlp 32/32/64) against the reference's
     PointNetSetAbstraction.forward on the 4 golden clouds -- alone, and as clouds 0..3 of a 32-cloud batch (the per-GPU shard
