@@ -29,7 +29,7 @@ with torch.no_grad():
             qg(xyz5, new5, feat5)
         torch.cuda.synchronize()
         sys.exit(0)
-    if what in ("emd", "emd_sweep"):                            # EMD forward at B 32, n = m = 1024 (emd.hip: 20 sweeps + match + costsum)
+    if what in ("emd", "emd_sweep", "emd_match"):                            # EMD forward at B 32, n = m = 1024 (emd.hip: 20 sweeps + match + costsum)
         from learning3d_amd._lib import lib, check, ptr, stream_ptr
         B_, n_ = 32, 1024
         ws_ = torch.empty(lib().l3d_emd_workspace_bytes(B_, n_, n_), dtype=torch.uint8, device="cuda")
