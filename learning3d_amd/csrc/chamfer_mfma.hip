@@ -14,9 +14,11 @@
 //     input (DESIGN.md 4.3 adds the terms up); |Q|^2 is constant per query and irrelevant to its argmin.
 //   * queries are the MFMA's COLUMNS: a lane then holds 16 candidates of ONE query, min3-reduced in registers, no cross-lane
 //     traffic.  A wave owns 128 queries (4 column blocks), a workgroup 512; candidates stream through LDS as A fragments.
-//   * pass 1 takes the minimum of s~ per query; pass 2 recomputes the same bits and records every (query, 16-candidate
-//     group) whose minimum lies within CM_BAND of it -- the true minimisers are all among those (band >= 2 x error bound).
-//     About 1.05 records per query on uniform clouds; lattices with many exact ties just record more.
+//   * pass 1 takes the minimum of s~ per query (over every 4th group of 32 candidates when there are >= 8192 of them: an upper
+//     bound of the true minimum is all that is needed); pass 2 recomputes the products and records every (query, 16-candidate
+//     group) whose minimum lies within CM_BAND of the lane's threshold, which tightens with every record -- the true minimisers
+//     are all among the records (band >= 2 x error bound).  1 - 2.5 records per query on uniform clouds; lattices with many
+//     exact ties just record more.
 //   * the records are evaluated EXACTLY, 16 candidates per record by 16 lanes, in the reference's arithmetic
 //     ((dx*dx + dy*dy) + dz*dz, dx = c - q, no contraction), smaller distance then lower index winning: what one sequential
 //     strict-'<' scan over all candidates returns.
@@ -51,6 +53,7 @@ __device__ __forceinline__ float cm_min16(const cm_f32x16 &a, float run)
     return __builtin_fminf(__builtin_fminf(m0, m1), m4);
 }
 
+template <int SUB>
 __global__ __launch_bounds__(256, 2) void chamfer_mfma_kernel(const float *__restrict__ xyz1, const float *__restrict__ xyz2, int N,
                                                            int M, float *__restrict__ dist1, float *__restrict__ dist2,
                                                            int32_t *__restrict__ idx1, int32_t *__restrict__ idx2)
@@ -138,17 +141,28 @@ __global__ __launch_bounds__(256, 2) void chamfer_mfma_kernel(const float *__res
     // chunk's MFMAs (commit): a 512-candidate chunk is ~1 us of matrix work, the same as one trip to memory.
     constexpr int PER = CM_CHUNK / 256;
     float sx[PER], sy[PER], sz[PER];
-    auto fetch = [&](int c0) {
+    // iteration it of the pipeline: it < nch1 = pass 1's virtual chunk it (every sub-th 32-candidate group: group g of the chunk
+    // is real group (16 it + g) sub), else pass 2's chunk it - nch1 (all groups in order)
+    // pass 1 looks at every sub-th group of 32 candidates.  Sampling loosens pass 2's first threshold: ~1 + ln(sub) more records per
+    // query, whatever the cloud size -- per MFMA step that is nothing at 512 steps (config 4: 2.0 -> 1.6 ms) and a slow-path visit
+    // in every step at 32 (N = 1024: 43 -> 86 us), hence SUB = 4 only when both clouds have >= 8192 points (the launcher)
+    constexpr int sub = SUB;               // compile-time: as a kernel argument it costs 880 spilled registers (hipcc 7.2)
+    const int ngroups = (Nc + 31) >> 5;
+    const int nch1 = ((ngroups + sub - 1) / sub + 15) / 16, nch2 = (Nc + CM_CHUNK - 1) / CM_CHUNK, total = nch1 + nch2;
+    auto cand_of = [&](int it, int i) {
+        return it < nch1 ? ((it * 16 + (i >> 5)) * sub) * 32 + (i & 31) : (it - nch1) * CM_CHUNK + i;
+    };
+    auto fetch = [&](int it) {
 #pragma unroll
         for (int u = 0; u < PER; u++) {
-            const size_t j = (size_t)min(c0 + tid + u * 256, Nc - 1) * 3;       // unconditional loads from clamped rows
+            const size_t j = (size_t)min(cand_of(it, tid + u * 256), Nc - 1) * 3;       // unconditional loads from clamped rows
             sx[u] = cb[j]; sy[u] = cb[j + 1]; sz[u] = cb[j + 2];
         }
     };
-    auto commit = [&](int c0, unsigned char *abuf) {
+    auto commit = [&](int it, unsigned char *abuf) {
 #pragma unroll
         for (int u = 0; u < PER; u++) {
-            const int i = tid + u * 256, j = c0 + i;
+            const int i = tid + u * 256, j = cand_of(it, i);
             const float X = (sx[u] - xf.cx) * xf.s, Y = (sy[u] - xf.cy) * xf.s, Z = (sz[u] - xf.cz) * xf.s;
             _Float16 hx, hy, hz, mxx, myy, mzz;
             cm_split(X, hx, mxx); cm_split(Y, hy, myy); cm_split(Z, hz, mzz);
@@ -171,15 +185,15 @@ __global__ __launch_bounds__(256, 2) void chamfer_mfma_kernel(const float *__res
     };
     const int frag_off = half * 512 + col * 16;
     const cm_f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const int nch = (Nc + CM_CHUNK - 1) / CM_CHUNK;        // both passes walk chunks 0 .. nch-1; the pipeline runs through the pass boundary
     int buf = 0;
     fetch(0);
     commit(0, abuf2[0]);
-    fetch(nch > 1 ? CM_CHUNK : 0);                         // chunk 1 of pass 1, or chunk 0 again for pass 2
+    fetch(1);                                              // total >= 2: pass 2 has at least one chunk
 
-    // ---- pass 1: per query (lane: its half of every 32-candidate step) the minimum of s~
+    // ---- pass 1: per query (lane: its half of every 32-candidate step) the minimum of s~ over a 1-in-sub sample of the
+    // candidate groups: an UPPER bound of the query's true minimum, which is all pass 2's first threshold has to be
     float run[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
-    for (int ch = 0; ch < nch; ch++) {
+    for (int it = 0; it < nch1; it++) {
         __syncthreads();                                    // abuf2[buf] written by every wave; abuf2[buf ^ 1] free (its readers passed this barrier's predecessor)
         const unsigned char *afrag = abuf2[buf] + frag_off;
         // Every chunk runs its 16 steps (rows past Nc are padding rows): a fixed trip count, fully unrolled.  Inside a wave the
@@ -205,10 +219,8 @@ __global__ __launch_bounds__(256, 2) void chamfer_mfma_kernel(const float *__res
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        const int nxt = ch + 1 < nch ? ch + 1 : 0;          // after the last chunk: pass 2's chunk 0
-        commit(nxt * CM_CHUNK, abuf2[buf ^ 1]);
-        const int nn = nxt + 1 < nch ? nxt + 1 : 0;
-        fetch(nn * CM_CHUNK);
+        commit(it + 1, abuf2[buf ^ 1]);                      // it + 1 <= nch1 < total: the pipeline runs through the pass boundary
+        fetch(min(it + 2, total - 1));                      // unconditional (a fetch behind a branch costs the kernel 900 spilled registers: hipcc 7.2)
         buf ^= 1;
     }
     float thr[4];
@@ -251,10 +263,10 @@ __global__ __launch_bounds__(256, 2) void chamfer_mfma_kernel(const float *__res
     };
 
     // ---- pass 2: the same products again; record every lane-group whose minimum is inside the band
-    for (int ch = 0; ch < nch; ch++) {
+    for (int it = nch1; it < total; it++) {
         __syncthreads();
         const unsigned char *afrag = abuf2[buf] + frag_off;
-        const int c0 = ch * CM_CHUNK;
+        const int c0 = (it - nch1) * CM_CHUNK;
         cm_f32x16 acc[2][4];
         cm_f16x8 Af[2];                                    // fragment of step s in Af[s & 1], read two steps ahead of its MFMAs
         {
@@ -282,15 +294,18 @@ __global__ __launch_bounds__(256, 2) void chamfer_mfma_kernel(const float *__res
                     const bool hit = mk[k] <= thr[k];
                     const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
                     const int pos = cnt + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0));
-                    if (hit) list[wave][pos] = tile | (half << 7) | (k * 32 + col);
+                    if (hit) {
+                        list[wave][pos] = tile | (half << 7) | (k * 32 + col);
+                        thr[k] = fminf(thr[k], mk[k] + CM_BAND);          // a lane only learns of a lower minimum through a hit: tighten here, nowhere else
+                    }
                     cnt += __builtin_popcountll(bal);
                 }
             }
             if (cnt > CM_LIST - 256) flush();               // a step appends at most 4 x 64
         }
-        if (ch + 1 < nch) {
-            commit((ch + 1) * CM_CHUNK, abuf2[buf ^ 1]);
-            if (ch + 2 < nch) fetch((ch + 2) * CM_CHUNK);
+        if (it + 1 < total) {
+            commit(it + 1, abuf2[buf ^ 1]);
+            fetch(min(it + 2, total - 1));
         }
         buf ^= 1;
     }
@@ -310,7 +325,8 @@ int l3d_chamfer_forward_mfma(const float *xyz1, const float *xyz2, int B, int N,
                              int32_t *idx1, int32_t *idx2, hipStream_t stream)
 {
     const int mx = N > M ? N : M;
-    hipLaunchKernelGGL(chamfer_mfma_kernel, dim3(l3d_divup(mx, CM_QW), B, 2), dim3(256), 0, stream, xyz1, xyz2, N, M, dist1, dist2,
-                       idx1, idx2);
+    const dim3 grid(l3d_divup(mx, CM_QW), B, 2);
+    if ((N < M ? N : M) >= 8192) hipLaunchKernelGGL(chamfer_mfma_kernel<4>, grid, dim3(256), 0, stream, xyz1, xyz2, N, M, dist1, dist2, idx1, idx2);
+    else hipLaunchKernelGGL(chamfer_mfma_kernel<1>, grid, dim3(256), 0, stream, xyz1, xyz2, N, M, dist1, dist2, idx1, idx2);
     return l3d_check_launch();
 }

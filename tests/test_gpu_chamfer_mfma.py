@@ -66,6 +66,28 @@ def test_mfma_ranked_chamfer_equals_exact_kernel(kind, B, N, M):
     same(*clouds(3, B, N, M, kind))
 
 
+@pytest.mark.parametrize("kind", ["uniform", "sorted", "patches", "lattice", "duplicates", "offset"])
+def test_mfma_ranked_chamfer_sampled_first_pass(kind):
+    """From 8192 points per cloud pass 1 only looks at every 4th group of 32 candidates (an upper bound of each query's minimum):
+    clouds whose index order is spatial -- sorted along x, or PCN's fine output (16 consecutive points per coarse centre) -- make
+    that sample unrepresentative for some queries; the answer must not care."""
+    g = torch.Generator().manual_seed(17)
+    N, M = 8192, 9000
+    if kind in ("sorted", "patches"):
+        a, b = torch.rand((1, N, 3), generator=g), torch.rand((1, M, 3), generator=g)
+        if kind == "sorted":
+            a = a[:, torch.argsort(a[0, :, 0])]
+            b = b[:, torch.argsort(b[0, :, 0])]
+        else:
+            ca, cb = torch.rand((1, N // 16, 1, 3), generator=g), torch.rand((1, M // 8, 1, 3), generator=g)
+            a = (ca + 0.01 * torch.rand((1, N // 16, 16, 3), generator=g)).reshape(1, N, 3)
+            b = (cb + 0.01 * torch.rand((1, M // 8, 8, 3), generator=g)).reshape(1, M, 3)
+        a, b = a.cuda().contiguous(), b.cuda().contiguous()
+    else:
+        a, b = clouds(19, 1, N, M, kind)
+    same(a, b)
+
+
 def test_mfma_ranked_chamfer_one_point_and_identical_points():
     a, b = clouds(5, 2, 1, 777, "uniform")
     same(a, b)
