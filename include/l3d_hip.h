@@ -98,7 +98,9 @@ int l3d_graph_feature(const float *x, const int64_t *idx, int B, int N, int C, i
  *   backward: cd.backward_cuda(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2)
  *             (K2, .cu:158-209) -- deterministic here (gather + segmented sum, no fp32 atomics)
  *   xyz1 [B,N,3], xyz2 [B,M,3], dist1/idx1 [B,N], dist2/idx2 [B,M]; idx int32.
- *   d = (dx*dx + dy*dy) + dz*dz, no contraction; strict '<' => lowest index on ties.
+ *   d = (dx*dx + dy*dy) + dz*dz, no contraction; strict '<' => lowest index on ties.  From N * M >= 2^24 pairs per cloud the
+ *   candidates are ranked on the fp16 matrix cores and only those inside the ranking's error band are evaluated this way
+ *   (chamfer_mfma.hip): the same distances and indices, bit for bit.
  * ------------------------------------------------------------------------------------------- */
 int l3d_chamfer_forward(const float *xyz1, const float *xyz2, int B, int N, int M, float *dist1,
                         float *dist2, int32_t *idx1, int32_t *idx2, l3d_stream_t stream);

@@ -14,8 +14,10 @@ extern "C" {
 int l3d_knn_graph_variant(const float *xyz, int B, int N, int k, int64_t *idx, int variant, l3d_stream_t stream);
 
 /* The same with the kernel choice as an ARGUMENT (results are bit-identical either way; tests compare them):
- * variant 0 = one (query, candidate) pair per instruction sequence, 1 = auto (what l3d_chamfer_forward does),
- * 2 = always the packed-fp32 kernel (two queries per lane, argmin per chunk of 8). */
+ * variant 0 = one (query, candidate) pair per instruction sequence, 1 = auto (what l3d_chamfer_forward does: the packed kernel,
+ * and from N * M >= 2^24 pairs per cloud the matrix-core kernel), 2 = always the packed-fp32 kernel (two queries per lane, argmin
+ * per chunk of 8), 3 = always chamfer_mfma.hip (candidates ranked on the fp16 matrix cores, the answer fixed by an exact
+ * re-evaluation of every candidate inside the ranking's error band). */
 int l3d_chamfer_forward_variant(const float *xyz1, const float *xyz2, int B, int N, int M, float *dist1,
                                 float *dist2, int32_t *idx1, int32_t *idx2, int variant, l3d_stream_t stream);
 
