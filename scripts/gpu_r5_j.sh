@@ -1,0 +1,6 @@
+#!/bin/bash
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R; mkdir -p gpurun_out
+timeout 600 python tools/flownet_bench.py > gpurun_out/r5j_flownet_bench.txt 2>&1; cat gpurun_out/r5j_flownet_bench.txt
+timeout 600 python tools/flownet_conv_shapes.py > gpurun_out/r5j_flownet_conv_shapes.txt 2>&1; cat gpurun_out/r5j_flownet_conv_shapes.txt
