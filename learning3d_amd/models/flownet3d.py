@@ -21,6 +21,7 @@ FACTOR_FIRST_LAYER = True    # grouped first layers as per-point products + a ga
 # bound's four data maxima in one launch (l3d_absmax4_partials, finished inside the layer's kernel) and the parameter-only terms
 # cached: 5.00 -> 5.13 ms -- closer, still not a gain; stays off.
 F16_GROUPED_STACK = False
+F16_GROUPED_MIN_ROWS = 0      # rows (S * K) per cloud from which a grouped stack takes the f16x2 chain when F16_GROUPED_STACK is on
 
 
 def _mlp_stack(x, convs, bns, module, pool=False, cl_shape=None):
@@ -135,7 +136,7 @@ def _f16_stack_ok(C1, convs, S, K, pool):
     """The layers behind a factored first layer can run as an f16x2 chain (conv_f16.hip: plane image in, plane image or
     grouped maxima out): every layer on one of its two tiles, max over K in the last layer's epilogue."""
     if not (F16_GROUPED_STACK and _fused.gemm_arith() == "f16x2" and len(convs) and pool and C1 in (64, 128, 256)
-            and K in (8, 16, 32, 64)):
+            and K in (8, 16, 32, 64) and S * K >= F16_GROUPED_MIN_ROWS):
         return False
     cin = C1
     for conv in convs:

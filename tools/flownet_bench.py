@@ -18,6 +18,14 @@ with torch.no_grad():
         t = timeit(lambda: net(pc1, pc2, f1, f2), warm=2, iters=5)
         outs[flag] = net(pc1, pc2, f1, f2)
         print(f"FlowNet3D forward B=32 N=8192, factored first layers {flag[0]!s:5} f16x2 stacks {flag[1]!s:5}: {t:8.1f} us")
+    for rows in (16384, 8192):                     # the f16x2 chain only for the largest grouped stacks (fe_layer: 256 x 64 rows per cloud; su3: 1024 x 8)
+        F3.FACTOR_FIRST_LAYER, F3.F16_GROUPED_STACK, F3.F16_GROUPED_MIN_ROWS = True, True, rows
+        for _ in range(2):
+            t = timeit(lambda: net(pc1, pc2, f1, f2), warm=2, iters=5)
+            print(f"FlowNet3D forward B=32 N=8192, f16x2 stacks from {rows} rows per cloud: {t:8.1f} us")
+        d = (net(pc1, pc2, f1, f2) - outs[(False, False)]).abs().max().item()
+        print(f"   max |difference| to the grouped-tensor route: {d:.3e}")
+    F3.F16_GROUPED_MIN_ROWS = 0
     for flag in ((True, False), (True, True)):
         d = (outs[flag] - outs[(False, False)]).abs().max().item()
         print(f"max |difference| of {flag} to the grouped-tensor route: {d:.3e} (max |flow| {outs[(False, False)].abs().max().item():.3e})")
