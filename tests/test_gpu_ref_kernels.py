@@ -230,7 +230,7 @@ def test_chamfer_equals_reference_gpu_kernels(B, N, M):
 
 
 # ------------------------------------------------------------------------------------------ K3-K6 EMD
-@pytest.mark.parametrize("B,n,m", [(2, 256, 256), (4, 1024, 1024), (32, 1024, 1024), (2, 512, 256), (2, 300, 900), (3, 1001, 777), (1, 2500, 2500)])
+@pytest.mark.parametrize("B,n,m", [(2, 256, 256), (4, 1024, 1024), (32, 1024, 1024), (2, 512, 256), (2, 300, 900), (3, 1001, 777), (1, 2500, 2500), (1, 64, 6000)])
 def test_emd_equals_reference_kernels(B, n, m):
     """EMD against the reference's own approxmatch / matchcost / matchcostgrad kernels (emd.cuh:7-323) run on this
     GPU, n = m = 1024 at B = 32 (the c2-sized case) included.  Both sides evaluate exp through v_exp_f32 (__expf)

@@ -95,6 +95,16 @@ with torch.no_grad():
         d1, d2_ = ChamferDistanceFunction.apply(dev(xyz), dev(other))
         o1, o2, _, _ = oracle.chamfer_forward(xyz, other)
         assert np.array_equal(d1.cpu().numpy(), o1) and np.array_equal(d2_.cpu().numpy(), o2), ("chamfer", B, N, M); ok("chamfer")
+        # ... and the matrix-core-ranked kernel (chamfer_mfma.hip, l3d_chamfer_forward_variant 3; the default from 2^24 pairs per cloud):
+        # distances AND indices against the oracle's strict-'<' scan (lowest index on ties)
+        from learning3d_amd._lib import check as _chk, lib as _lib, ptr as _ptr, stream_ptr as _sp
+        ta, tb = dev(xyz), dev(other)
+        m1, m2 = torch.empty((B, N), device="cuda"), torch.empty((B, M), device="cuda")
+        j1, j2 = torch.empty((B, N), dtype=torch.int32, device="cuda"), torch.empty((B, M), dtype=torch.int32, device="cuda")
+        _chk(_lib().l3d_chamfer_forward_variant(_ptr(ta), _ptr(tb), B, N, M, _ptr(m1), _ptr(m2), _ptr(j1), _ptr(j2), 3, _sp()), "chamfer mfma")
+        _, _, oi1, oi2 = oracle.chamfer_forward(xyz, other)
+        assert np.array_equal(m1.cpu().numpy(), o1) and np.array_equal(m2.cpu().numpy(), o2), ("chamfer_mfma dist", B, N, M)
+        assert np.array_equal(j1.cpu().numpy(), oi1) and np.array_equal(j2.cpu().numpy(), oi2), ("chamfer_mfma idx", B, N, M); ok("chamfer_mfma")
         # square_distance / index_points / knn_point (a3, a5, a7)
         if N * M <= 400000:
             assert np.array_equal(U.square_distance(dev(xyz), dev(other)).cpu().numpy(), oracle.square_distance(xyz, other)); ok("square_distance")
