@@ -9,9 +9,18 @@ from ..utils.transformer import Identity, Transformer
 from .dgcnn import DGCNN
 
 
+def _mm(a, b):
+    """a @ b for the head's small products: on the library's own batched GEMM (l3d_bmm_f32, differentiable) for fp32 device tensors
+    -- no rocBLAS launch in the forward trace --, torch.matmul otherwise (CPU tensors, other dtypes)."""
+    if a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape[:-2] == b.shape[:-2] and a.dim() == 3:
+        from . import _rows
+        return _rows.matmul(a, b)
+    return torch.matmul(a, b)
+
+
 def transform_point_cloud(point_cloud, rotation, translation):
     """ops/transform_functions.py:24-29 for rotation matrices."""
-    return (torch.matmul(rotation, point_cloud.permute(0, 2, 1)) + translation.unsqueeze(2)).permute(0, 2, 1)
+    return (_mm(rotation, point_cloud.permute(0, 2, 1)) + translation.unsqueeze(2)).permute(0, 2, 1)
 
 
 def convert2transformation(rotation_matrix, translation_vector):
@@ -51,7 +60,7 @@ class DCP(nn.Module):
             rotation_ba, translation_ba = self.head(template_features, source_features, template, source)
         else:
             rotation_ba = rotation_ab.transpose(2, 1).contiguous()
-            translation_ba = -torch.matmul(rotation_ba, translation_ab.unsqueeze(2)).squeeze(2)
+            translation_ba = -_mm(rotation_ba, translation_ab.unsqueeze(2)).squeeze(2)
         transformed_source = transform_point_cloud(source, rotation_ab, translation_ab)
         return {'est_R': rotation_ab, 'est_t': translation_ab, 'est_R_': rotation_ba, 'est_t_': translation_ba,
                 'est_T': convert2transformation(rotation_ab, translation_ab),
