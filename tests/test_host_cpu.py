@@ -316,6 +316,18 @@ def test_two_rank_gloo_batchnorm_statistics_bit_identical(NB, mode):
         assert m == mean.numpy().tobytes() and v == var.numpy().tobytes() and nn_ == n
 
 
+def test_emd_workspace_size_is_a_pure_host_function():
+    """l3d_emd_workspace_bytes needs no device: remainders (n + m) + ten levels of ratios (10 (n + m)) + one cost partial per
+    (512 k, 64 l) tile of the match kernel, floats, per cloud; 0 for nonsense sizes."""
+    import ctypes
+    from learning3d_amd import _lib
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    h.l3d_emd_workspace_bytes.restype = ctypes.c_size_t
+    assert h.l3d_emd_workspace_bytes(2, 100, 50) == 4 * 2 * (11 * 150 + 1)
+    assert h.l3d_emd_workspace_bytes(32, 1024, 1024) == 4 * 32 * (11 * 2048 + 2 * 16)
+    assert h.l3d_emd_workspace_bytes(0, 10, 10) == 0 and h.l3d_emd_workspace_bytes(1, -1, 10) == 0
+
+
 def test_integration_md_shims_match_the_library():
     """INTEGRATION.md is the binding a maintainer would add: its python shims must compile, call only exported entry
     points with the number of arguments the C ABI declares, and the prose must not name a symbol that does not exist."""
