@@ -607,7 +607,12 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
                 float v = acc[a][c][r] * sc + sh;
                 if (relu) v = l3d_act(v, relu);
                 if constexpr (RESID) v = rb[(size_t)co * N + n0 + wn * 128 + c * 32 + (lane & 31)] + v;
-                yb[(size_t)co * N + n0 + wn * 128 + c * 32 + (lane & 31)] = v;
+                // DGCNN's conv5 (the two-plane instantiation): 134 MB of fp32 output that nothing on the chip reads back soon.  As ordinary
+                // stores its dirty lines are still being written back while the NEXT launches run -- the step's EdgeConv kernel is
+                // 128 us behind a kNN launch and 140 us behind this kernel (tools/ec_instep_probe.py: its dependent index / coordinate
+                // gathers queue behind the write-back).  Nontemporal stores cost this kernel 1.5 us and give EdgeConv 3-5 back.
+                if constexpr (NPW == 2) __builtin_nontemporal_store(v, &yb[(size_t)co * N + n0 + wn * 128 + c * 32 + (lane & 31)]);
+                else yb[(size_t)co * N + n0 + wn * 128 + c * 32 + (lane & 31)] = v;
                 if constexpr (AMAX) acc[a][c][r] = fabsf(v);     // kept for the maximum below (the accumulator is dead)
             }
         }
