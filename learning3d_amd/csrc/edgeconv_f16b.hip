@@ -729,10 +729,15 @@ __global__ __launch_bounds__(256, 1) void EF_KERNEL(const float *__restrict__ xy
     // point to before pair 6), waited for before pair 7, where every count is known, instead of behind the loop's back edge.
     f16x8 dummy[1][2][MT];
     u32x4 X;                                                     // the 16 bytes on their way from LDS to the image
-    auto st_a = [&](int c) { *(u32x4 *)(img_pt + (size_t)((c >> 1) * 64 + (c & 1) * 16 + (lane >> 2)) * row_bytes) = X; EF_PIN(); };
+#ifdef EF_NT_OUT      // experiment (LABLOG R5.6): the pooled planes leave through nontemporal stores
+#define EF_ST16(ptr, val) __builtin_nontemporal_store(val, (u32x4 *)(ptr))
+#else
+#define EF_ST16(ptr, val) (*(u32x4 *)(ptr) = (val))
+#endif
+    auto st_a = [&](int c) { EF_ST16(img_pt + (size_t)((c >> 1) * 64 + (c & 1) * 16 + (lane >> 2)) * row_bytes, X); EF_PIN(); };
     auto st_b = [&](int m0) {                                    // chunk of pairs m0, m0 + 1: lane -> slot, plane, cell row, point
         const int row = ((lane >> 4) & 1) * 64 + (EC_C1 + EC_C2 + EC_C3) / 8 + 4 * (m0 + (lane >> 5)) + ((lane >> 2) & 3);
-        *(u32x4 *)(img_pt + (size_t)row * row_bytes) = X;
+        EF_ST16(img_pt + (size_t)row * row_bytes, X);
         EF_PIN();
     };
     auto hook = [&](auto ic) {
