@@ -78,12 +78,18 @@ __device__ __forceinline__ void fk_insert_lex(TopK<K> &t, float key, int j)
 
 template <int K>
 __global__ __launch_bounds__(256, K <= 20 ? 2 : 1) void featknn_kernel(const uint4 *__restrict__ xs, const float *__restrict__ nxx,
-                                                         int C, int N, int Np, int k, int64_t *__restrict__ idx_out)
+                                                         int C, int N, int Np, int k, int64_t *__restrict__ idx_out,
+                                                         float *__restrict__ part_v, int *__restrict__ part_i)
 {
+    // Key-range split (round 5): with B N / 128 < 512 workgroups a CU holds ONE and every unit's load -> LDS -> barrier -> MFMA chain
+    // runs exposed (LABLOG R5.4).  gridDim.z parts each rank their share of the key tiles for the same 128 queries (a second
+    // workgroup per CU to switch to) and leave their sorted K-lists in part_v / part_i; featknn_merge_kernel merges them.
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int b = blockIdx.y, q0 = blockIdx.x * 128;
-    const int nch = C / 32, nkt = Np / 128, U = nkt * nch;
+    const int nch = C / 32, nkt_all = Np / 128;
+    const int kt0 = (int)((long)nkt_all * blockIdx.z / gridDim.z), kt1 = (int)((long)nkt_all * (blockIdx.z + 1) / gridDim.z);
+    const int U = (kt1 - kt0) * nch;
     const uint4 *xsb = xs + (size_t)b * (C / 16) * 6 * Np;
     const float *nxb = nxx + (size_t)b * Np;
     float *nxl = (float *)(lds + FK_NXOFF);
@@ -149,13 +155,13 @@ __global__ __launch_bounds__(256, K <= 20 ? 2 : 1) void featknn_kernel(const uin
     top.init();
     float thr = -INFINITY, thrp = -INFINITY;
 
-    int kt = 0, ch = 0;                      // current unit
-    int ktn = 0, chn = 0;                    // next unit to fetch
-    FK_LOAD(0, 0);
-    FK_STORE(0, 0, 0);
+    int kt = kt0, ch = 0;                    // current unit
+    int ktn = kt0, chn = 0;                  // next unit to fetch
+    FK_LOAD(kt0, 0);
+    FK_STORE(0, kt0, 0);
     FK_QSWAP();
     chn = 1;
-    if (chn == nch) { chn = 0; ktn = 1; }
+    if (chn == nch) { chn = 0; ktn = kt0 + 1; }
     __syncthreads();
 
 #pragma unroll 1
@@ -273,19 +279,68 @@ __global__ __launch_bounds__(256, K <= 20 ? 2 : 1) void featknn_kernel(const uin
 #pragma unroll 1
         for (int i = 0; i < K; i++) fk_insert_lex<K>(top, mv[i * 32 + lane], mi[i * 32 + lane]);
         if (qrow < N) {
-            int64_t *dst = idx_out + ((size_t)b * N + qrow) * k;
+            if (gridDim.z == 1) {
+                int64_t *dst = idx_out + ((size_t)b * N + qrow) * k;
 #pragma unroll
-            for (int i = 0; i < K; i++)
-                if (i < k) dst[i] = top.id[i];
+                for (int i = 0; i < K; i++)
+                    if (i < k) dst[i] = top.id[i];
+            } else {
+                const size_t o = (((size_t)b * N + qrow) * gridDim.z + blockIdx.z) * K;
+#pragma unroll
+                for (int i = 0; i < K; i++) { part_v[o + i] = top.v[i]; part_i[o + i] = top.id[i]; }
+            }
         }
     }
+}
+
+// idx[q][0..k) = the k best of the parts' sorted lists (value descending, equal values: lower index first -- the order inside a list
+// and what one list over all keys would hold); one thread per query, <= 4 list heads
+template <int K>
+__global__ __launch_bounds__(256) void featknn_merge_kernel(const float *__restrict__ part_v, const int *__restrict__ part_i, long nq, int parts,
+                                                            int k, int64_t *__restrict__ idx_out)
+{
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const float *v = part_v + (size_t)q * parts * K;
+    const int *id = part_i + (size_t)q * parts * K;
+    int head[4] = {0, 0, 0, 0};
+    for (int o = 0; o < k; o++) {
+        int best = -1;
+        float bv = 0.f;
+        int bi = 0;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            if (p >= parts || head[p] >= K) continue;
+            const float pv = v[p * K + head[p]];
+            const int pi = id[p * K + head[p]];
+            if (best < 0 || pv > bv || (pv == bv && pi < bi)) { best = p; bv = pv; bi = pi; }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) head[p] += (p == best);
+        idx_out[(size_t)q * k + o] = bi;
+    }
+}
+
+// key-range parts: enough workgroups for two per CU (512), at most 4, at most one per key tile
+// (measured at k = 20, profiles/round5_featknn_bench.txt: B 32, N 1024: C 64 128 -> 134 us (the per-part epilogues cost more than the
+// overlap returns: no split), C 128 168 -> 163, C 256 244 -> 220; B 8, N 1024, k 40: 477 -> 381)
+static inline int fk_parts(int B, int Cp, int Np)
+{
+    const long wgs = (long)B * (Np / 128);
+    if (Cp < 128 && wgs > 128) return 1;
+    int p = wgs >= 512 ? 1 : (int)((512 + wgs - 1) / wgs);
+    if (p > 4) p = 4;
+    if (p > Np / 128) p = Np / 128;
+    return p < 1 ? 1 : p;
 }
 
 extern "C" size_t l3d_knn_feature_workspace_bytes(int B, int C, int N)
 {
     if (B <= 0 || C <= 0 || N <= 0) return 0;
     const size_t Np = (size_t)l3d_divup(N, 128) * 128, Cp = (size_t)l3d_divup(C, 32) * 32;
-    return (size_t)B * Cp * Np * 6 + (size_t)B * Np * 4;
+    const int parts = fk_parts(B, (int)Cp, (int)Np);
+    // split planes | -|x|^2 | (parts > 1) the parts' sorted lists, values and indices, at the longest list length (64)
+    return (size_t)B * Cp * Np * 6 + (size_t)B * Np * 4 + (parts > 1 ? (size_t)B * N * parts * 64 * 8 : 0);
 }
 
 extern "C" int l3d_knn_feature(const float *x, int B, int C, int N, int k, void *workspace, int64_t *idx,
@@ -297,12 +352,23 @@ extern "C" int l3d_knn_feature(const float *x, int B, int C, int N, int k, void 
     const int Np = l3d_divup(N, 128) * 128, Cp = l3d_divup(C, 32) * 32;      // any C: padded with zero channels
     uint4 *xs = (uint4 *)workspace;
     float *nxx = (float *)((unsigned char *)workspace + (size_t)B * Cp * Np * 6);
+    const int parts = fk_parts(B, Cp, Np);
+    float *pv = nxx + (size_t)B * Np;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(featknn_split_kernel, dim3(l3d_divup(Np, 256), B), dim3(256), 0, st, x, C, Cp, N, Np, xs, nxx);
-    dim3 grid(Np / 128, B), block(256);
+    dim3 grid(Np / 128, B, parts), block(256);
+    const long nq = (long)B * N;
+    const dim3 mgrid((unsigned)((nq + 255) / 256));
     // k <= 20: the asm insertion network; 20 < k <= 64: the generic one (list lengths 32 / 64)
-    if (k <= 20) hipLaunchKernelGGL(featknn_kernel<20>, grid, block, FK_LDS, st, (const uint4 *)xs, (const float *)nxx, Cp, N, Np, k, idx);
-    else if (k <= 32) hipLaunchKernelGGL(featknn_kernel<32>, grid, block, FK_LDS, st, (const uint4 *)xs, (const float *)nxx, Cp, N, Np, k, idx);
-    else hipLaunchKernelGGL(featknn_kernel<64>, grid, block, FK_LDS, st, (const uint4 *)xs, (const float *)nxx, Cp, N, Np, k, idx);
+#define FK_GO(KK)                                                                                                                       \
+    do {                                                                                                                                \
+        int *pi = (int *)(pv + (size_t)nq * parts * KK);                                                                                \
+        hipLaunchKernelGGL(featknn_kernel<KK>, grid, block, FK_LDS, st, (const uint4 *)xs, (const float *)nxx, Cp, N, Np, k, idx, pv, pi); \
+        if (parts > 1) hipLaunchKernelGGL(featknn_merge_kernel<KK>, mgrid, dim3(256), 0, st, (const float *)pv, (const int *)pi, nq, parts, k, idx); \
+    } while (0)
+    if (k <= 20) FK_GO(20);
+    else if (k <= 32) FK_GO(32);
+    else FK_GO(64);
+#undef FK_GO
     return l3d_check_launch();
 }
