@@ -314,6 +314,13 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
         }
     }
     auto issue_one = [&](int stage, int i) {
+#ifdef CF_ABL      // timing ablation (results are garbage): bit 0 = no W pieces after the prologue, bit 1 = no x pieces
+        {
+            int q_ = wave * NPIECE + i;
+            if (q_ >= NWP + NXP) q_ -= NXP;
+            if (((CF_ABL & 1) && q_ < NWP) || ((CF_ABL & 2) && q_ >= NWP)) return;
+        }
+#endif
         __builtin_amdgcn_global_load_lds((cf_gbl_ptr_t)src[i], (cf_lds_ptr_t)(lds + stage * STAGE + dst[i]), 16, 0, 0);
         src[i] += stride[i];
     };
