@@ -44,6 +44,10 @@ int l3d_version(void);
 const char *l3d_status_string(int status);
 /* hipError_t recorded by the last failing launch on the calling thread (0 if none) */
 int l3d_last_hip_error(void);
+/* Measurement aid (bench.py): one launch in which every SIMD issues fp16 MFMAs back to back on random operands -- 256 workgroups x
+ * 8 waves x 4 * iters instructions of 32 768 FLOP.  The caller times the launch; ticks[0] / ticks[1] * 100 MHz = the shader clock the
+ * chip held (the data-sheet peak assumes 2.4 GHz; under this load it holds ~1.5).  sink: 131 072 floats of scratch. */
+int l3d_probe_mfma_sustained(int iters, float *sink, long long *ticks, l3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused kNN graph (T1)  == utils/model_common_utils.py:3-9  knn(x, k)

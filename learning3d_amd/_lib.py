@@ -110,6 +110,7 @@ SIGNATURES = {
     "l3d_quat_transform": [_P, _P, _I, _I, _P, _P],
     "l3d_sceneflow_batch": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "l3d_emd_workspace_bytes": [_I, _I, _I],
+    "l3d_probe_mfma_sustained": [_I, _P, _P, _P],
     "l3d_emd_forward": [_P, _P, _I, _I, _I, _P, _P, _P, _I, _P],
     "l3d_emd_backward": [_P, _P, _P, _I, _I, _I, _P, _P, _P],
 }
