@@ -63,4 +63,7 @@ def test_new_entry_points_validate_arguments():
     assert l.l3d_group_concat2(None, None, None, None, None, 1, 1, 1, 1, 1, 0, 0, None, None) == -1
     assert l.l3d_add_transposed(None, None, 1, 1, 1, None, None) == -1
     assert l.l3d_three_interpolate_concat(1, 1, 1, 1, None, None, None, None, 0, None, None) == -1
-    assert l.l3d_knn_feature_workspace_bytes(2, 64, 300) == 2 * 64 * 384 * 6 + 2 * 384 * 4
+    # split planes + -|x|^2, and (round 5) the sorted K-lists of the key-range parts where a CU would otherwise hold one workgroup:
+    # 2 x 3 query tiles -> 3 parts (one per key tile), lists at the longest length (64), 8 bytes per entry
+    assert l.l3d_knn_feature_workspace_bytes(2, 64, 300) == 2 * 64 * 384 * 6 + 2 * 384 * 4 + 2 * 300 * 3 * 64 * 8
+    assert l.l3d_knn_feature_workspace_bytes(32, 64, 1024) == 32 * 64 * 1024 * 6 + 32 * 1024 * 4          # C < 128, 256 query tiles: no split
