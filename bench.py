@@ -749,9 +749,13 @@ def main():
                     help="c2: where the step's Chamfer branch (NN search + loss tail; independent of the DGCNN chain) runs: 'knn' (default) "
                          "= on a second stream beside the kNN kernel only, joined in front of EdgeConv (two branches of the replayed "
                          "hipGraph: both kernels are VALU / latency bound and the matrix kernels keep the chip to themselves; +1.3 %); "
-                         "'none' = one stream, the five kernels back to back; 'start' / 'edgeconv' / 'conv5' = leaves the main stream at "
+                         "'none' = one stream, the kernels back to back; 'start' / 'edgeconv' / 'conv5' = leaves the main stream at "
                          "the start of the step / when that stage's kernel is issued and is joined at the END of the step (measured "
                          "2 % slower than one stream: the matrix kernels lose more than the branch gains)")
+    ap.add_argument("--chamfer-tail", choices=["fused", "separate"], default="separate",
+                    help="ChamferDistanceLoss's loss tail as its own launch behind the search (default: 0.3-0.5 %% faster inside the replayed "
+                         "two-branch graph, LABLOG R6.2) or inside the search kernel's launch (l3d_chamfer_forward_loss: what the module's "
+                         "no-grad forward calls -- one launch less for an eager caller)")
     ap.add_argument("--selftest-cpu", action="store_true",
                     help="control-flow self test on CPU/gloo (launcher, sharding, collective, max-over-ranks, JSON): "
                          "NO kernels run and the printed line is not a measurement")
@@ -819,10 +823,15 @@ def main():
 
     branch = torch.cuda.Stream() if args.fork != "none" else None
 
+    from learning3d_amd.losses.chamfer_distance import chamfer_forward_loss
+
     def chamfer_branch():
+        # ChamferDistanceLoss's no-grad forward: NN search of both directions + the loss tail (N > 1: the fp64 partial sums)
         with _fused.stage("chamfer"):
-            d1, d2 = cd(a, b)
-        return chamfer_loss_local(d1, d2) if not multi else chamfer_partials(d1, d2)
+            if args.chamfer_tail == "separate":            # rounds 3-5: the search, then the loss kernel (A/B: LABLOG R6.2)
+                d1, d2 = cd(a, b)
+                return chamfer_loss_local(d1, d2) if not multi else chamfer_partials(d1, d2)
+            return chamfer_forward_loss(a, b, want="partials" if multi else "loss")
 
     def compute(fork=True):
         """the step's kernels: knn -> edgeconv -> conv5, Chamfer NN search, and the loss tail's local part.  The Chamfer pair
@@ -867,7 +876,7 @@ def main():
             main.wait_stream(branch)
         return feat, out[0]
 
-    # The six launches of a step are captured once into a hipGraph and replayed: at ~0.36 ms of GPU work per step the
+    # The five launches of a step (four with --chamfer-tail fused) are captured once into a hipGraph and replayed: at ~0.36 ms of GPU work per step the
     # Python / ctypes launch path (~13 us per launch) had become part of the step time (0.436 ms eager).  Steps that
     # carry the live kernel-timing events (<= 8 per run) are issued eagerly.
     graph = None
@@ -879,7 +888,7 @@ def main():
         else:
             feat, part = compute(fork=not eager)           # event-carrying steps stay on one stream: clean per-kernel durations
         if not multi:
-            return feat, part                              # the whole loss tail ran in one launch (l3d_chamfer_loss_local)
+            return feat, part                              # the whole loss tail ran inside the search's launch (l3d_chamfer_forward_loss)
         if sync_loss:
             loss = parallel.allgather_chamfer_loss(part)   # blocking RCCL all_gather
         else:
@@ -1072,7 +1081,7 @@ def main():
                        "untimed_precondition_steps": PRECONDITION_STEPS, "untimed_settle_probes_of_20_steps": settle_probes,
                        "settle_rule": "probes of 20 replayed steps until one is within 12 % of the kernels' own sum (max 4); for N > 1 all "
                                       "ranks probe until every rank is settled (all_reduce of the verdict)",
-                       "launch": "hipGraph replay of the step's 5 kernels" if graph is not None else "eager launches",
+                       "launch": ("hipGraph replay of the step's " + ("5 kernels" if args.chamfer_tail == "separate" else "4 kernels (Chamfer search + loss tail in one)")) if graph is not None else "eager launches",
                        "chamfer_branch": ("one stream" if branch is None else
                                           "second stream beside the kNN kernel only, joined in front of EdgeConv (two branches of the replayed hipGraph)"
                                           if args.fork == "knn" else

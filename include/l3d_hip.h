@@ -127,6 +127,14 @@ int l3d_chamfer_combine(const double *partials, int world, float *loss, l3d_stre
 size_t l3d_chamfer_loss_local_ws_bytes(void);
 int l3d_chamfer_loss_local_mb(const float *dist1, const float *dist2, int B, int N, int M, void *ws, double *partial,
                               float *loss, l3d_stream_t stream);
+/* Search AND loss tail of ChamferDistanceLoss.forward (losses/chamfer_distance.py:34-43: chamfer_distance() == cd.forward_cuda, then
+ * (mean sqrt dist1 + mean sqrt dist2) / 2) in ONE launch where the two-queries-per-lane kernel serves the search (N * M < 2^24 pairs
+ * per cloud and >= 256 workgroups: configs 2 and 3), else l3d_chamfer_forward + l3d_chamfer_loss_local_mb.  Outputs: dist / idx as
+ * l3d_chamfer_forward (bit for bit), partial[4] as l3d_chamfer_partials, loss[0] fp32.  ws: l3d_chamfer_forward_loss_ws_bytes(B, N, M)
+ * bytes of device memory, the first 16 zero before the first call (the kernel re-arms them); one ws per stream. */
+size_t l3d_chamfer_forward_loss_ws_bytes(int B, int N, int M);
+int l3d_chamfer_forward_loss(const float *xyz1, const float *xyz2, int B, int N, int M, float *dist1, float *dist2, int32_t *idx1,
+                             int32_t *idx2, void *ws, double *partial, float *loss, l3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * PointNet++ native ops  == utils/lib/src/pointnet2_api.cpp:10-25 (pybind `pointnet2_cuda`)

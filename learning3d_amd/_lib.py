@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libl3d_hip.so")
+# L3D_LIB_PATH: a library built from the same sources with other -D flags (tools/build_variant_lib.py: A/B runs of bench.py on one box)
+LIB_PATH = os.environ.get("L3D_LIB_PATH") or os.path.join(_HERE, "libl3d_hip.so")
 _lib = None
 
 _P, _I, _F, _SZ, _L, _D = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long, C.c_double
@@ -34,6 +35,8 @@ SIGNATURES = {
     "l3d_chamfer_combine": [_P, _I, _P, _P],
     "l3d_chamfer_loss_local_ws_bytes": [],
     "l3d_chamfer_loss_local_mb": [_P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "l3d_chamfer_forward_loss_ws_bytes": [_I, _I, _I],
+    "l3d_chamfer_forward_loss": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "l3d_ball_query": [_I, _I, _I, _F, _I, _P, _P, _P, _P, _P],
     "l3d_group_points": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "l3d_group_points_grad": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
@@ -116,7 +119,7 @@ SIGNATURES = {
 }
 _RESTYPE = {"l3d_status_string": C.c_char_p, "l3d_edgeconv_packed_floats": _SZ, "l3d_split_bytes": _SZ,
             "l3d_soft_correspondence_workspace_floats": _SZ, "l3d_layernorm_backward_workspace_floats": _SZ, "l3d_knn_feature_workspace_bytes": _SZ,
-            "l3d_scatter_add_det_workspace_bytes": _SZ, "l3d_chamfer_loss_local_ws_bytes": _SZ, "l3d_f16_image_bytes": _SZ,
+            "l3d_scatter_add_det_workspace_bytes": _SZ, "l3d_chamfer_loss_local_ws_bytes": _SZ, "l3d_chamfer_forward_loss_ws_bytes": _SZ, "l3d_f16_image_bytes": _SZ,
             "l3d_wgrad_workspace_bytes": _SZ, "l3d_emd_workspace_bytes": _SZ}
 
 

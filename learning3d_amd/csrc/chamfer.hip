@@ -19,6 +19,11 @@
 #define CTILE 2048      // candidates per LDS tile, shared by the 4 waves (32 KiB)
 #define CWAVES 4        // waves per workgroup: each scans 1/4 of every tile for the SAME 64*QPL queries
 #define CUNROLL 8
+#ifndef CH_SMALL_TILE
+#define CH_SMALL_TILE 0      // 1: 1024-candidate tiles when neither cloud is longer (LABLOG R6.2: co-resident with the kNN kernel, and slower)
+#endif
+#define CHAMFER_LL_BLOCKS 64                                  // l3d_chamfer_loss_local_mb's workgroups
+#define CHAMFER_LL_WS_BYTES (16 + CHAMFER_LL_BLOCKS * 16)
 
 template <int QPL>   // queries per lane
 __global__ __launch_bounds__(64 * CWAVES) void chamfer_fwd_kernel(const float *__restrict__ xyz1,
@@ -116,6 +121,40 @@ __global__ __launch_bounds__(64 * CWAVES) void chamfer_fwd_kernel(const float *_
     }
 }
 
+// The loss tail of chamfer_fwd_packed_kernel<true>, called by wave 0 of every workgroup (grid (x, B, 2): direction z's slots are
+// [z * gridDim.x * gridDim.y, ...)).  ws: 16 bytes (ticket, zero before the first launch) + one double per workgroup.
+__device__ __forceinline__ void chamfer_loss_tail(double sq, unsigned *__restrict__ ws, double *__restrict__ partial,
+                                                  float *__restrict__ loss, int N, int M)
+{
+    const int lane = threadIdx.x & 63;
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+    double *slots = (double *)(ws + 4);
+    const unsigned per_dir = gridDim.x * gridDim.y, total = 2 * per_dir;
+    const unsigned slot = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    unsigned ticket = 0;
+    if (lane == 0) {
+        __hip_atomic_store(&slots[slot], sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                       // ... and acknowledged
+        ticket = __hip_atomic_fetch_add(ws, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != total - 1) return;
+    double t[2];
+#pragma unroll
+    for (int z = 0; z < 2; z++) {                      // lane l adds slots l, l + 64, ... of the direction, then a fixed shuffle tree
+        double a = 0.0;
+        for (unsigned i = lane; i < per_dir; i += 64) a += __hip_atomic_load(&slots[z * per_dir + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+        t[z] = a;
+    }
+    if (lane == 0) {
+        const double n1 = (double)gridDim.y * N, n2 = (double)gridDim.y * M;
+        partial[0] = t[0]; partial[1] = t[1]; partial[2] = n1; partial[3] = n2;
+        loss[0] = (float)((t[0] / n1 + t[1] / n2) / 2.0);
+        __hip_atomic_store(ws, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                 // re-armed for the next launch on this stream
+    }
+}
+
 // kernel choice is an ARGUMENT of l3d_chamfer_forward_variant (0 = per-candidate kernels only, 1 = auto, 2 = packed
 // kernel always); there is no process-wide state.  l3d_chamfer_forward == variant 1.
 
@@ -128,15 +167,30 @@ __global__ __launch_bounds__(64 * CWAVES) void chamfer_fwd_kernel(const float *_
 // equals the best: exactly what one sequential strict-'<' scan returns.  Per (query, candidate): 4 packed + ~1
 // instructions instead of 11.  Same tiling / wave split / merge as chamfer_fwd_kernel.
 // ---------------------------------------------------------------------------------------------
+// LOSS (its own instantiation): the loss tail of losses/chamfer_distance.py:38-40 in the same launch.  Wave 0 of every workgroup adds
+// the square roots of its 128 final distances in fp64 and publishes the sum in its slot of `ws` with a WRITE-THROUGH store (sc1),
+// waits for it (s_waitcnt vmcnt(0)) and draws a ticket (agent-scope atomic); the workgroup that draws the last ticket adds the
+// slots in a fixed order and writes partial[4] = (sum sqrt d1, sum sqrt d2, n1, n2) and the loss, and re-arms the ticket.  Round 3
+// tried this with __threadfence() in front of the ticket and lost 4 us per step (LABLOG R3.10): an agent-scope release fence
+// writes the XCD's whole L2 back; a write-through store of the 8 bytes that matter does not.  The separate loss kernel was 7 us
+// on the Chamfer branch's critical path in front of EdgeConv (launch + L2 turn-around for ~1 us of work).
+// PTILE: candidates per LDS tile, 2048 in the product.  With 1024 (20 KB with the merge arrays; -DCH_SMALL_TILE=1) a workgroup fits on
+// a CU BESIDE two of knn_mfma_kernel's (2 x 69.6 KB at N = 1024), which the 36 KB of a 2048-candidate tile does not -- the two kernels
+// of the bench step's front, launched side by side on two streams, take turns on a CU (24.5 + 16.7 us alone, 39.5 together).  Measured
+// (LABLOG R6.2): co-resident, the step is 1.3 % SLOWER (281.5 vs 277.9 us, four interleaved pairs on one box) -- the kNN kernel is the
+// front's critical path and the Chamfer waves beside it take its issue slots.  Not the default.
+template <bool LOSS, int PTILE>
 __global__ __launch_bounds__(64 * CWAVES) void chamfer_fwd_packed_kernel(const float *__restrict__ xyz1,
                                                                          const float *__restrict__ xyz2, int N, int M,
                                                                          float *__restrict__ dist1,
                                                                          float *__restrict__ dist2,
                                                                          int32_t *__restrict__ idx1,
-                                                                         int32_t *__restrict__ idx2)
+                                                                         int32_t *__restrict__ idx2,
+                                                                         unsigned *__restrict__ ws, double *__restrict__ partial,
+                                                                         float *__restrict__ loss)
 {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    __shared__ float4 cand[CTILE];
+    __shared__ float4 cand[PTILE];
     __shared__ float rbest[CWAVES][2][64];
     __shared__ int rbesti[CWAVES][2][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -149,7 +203,11 @@ __global__ __launch_bounds__(64 * CWAVES) void chamfer_fwd_packed_kernel(const f
     float *dout = dir == 0 ? dist1 : dist2;
     int32_t *iout = dir == 0 ? idx1 : idx2;
     const int q0 = blockIdx.x * 128;
-    if (q0 >= Nq) return;
+    if (!LOSS && q0 >= Nq) return;
+    if (LOSS && q0 >= Nq) {                                // a workgroup beyond the shorter cloud still owns a slot and a ticket
+        if (wave == 0) chamfer_loss_tail(0.0, ws, partial, loss, N, M);
+        return;
+    }
 
     f32x2 qx, qy, qz;
     {
@@ -160,14 +218,14 @@ __global__ __launch_bounds__(64 * CWAVES) void chamfer_fwd_packed_kernel(const f
     float best0 = INFINITY, best1 = INFINITY;
     int base0 = 0x7fffffff, base1 = 0x7fffffff;        // first candidate index of the chunk that holds the best
     const float *cbase = cs + (size_t)b * Nc * 3;
-    for (int c0 = 0; c0 < Nc; c0 += CTILE) {
-        const int tn = min(CTILE, Nc - c0);
+    for (int c0 = 0; c0 < Nc; c0 += PTILE) {
+        const int tn = min(PTILE, Nc - c0);
         __syncthreads();
         {
             // the tile's loads all in flight before the first LDS write (a rolled load / wait / write loop is one round trip to
             // memory per 256 points: four of them in a row at N = 1024, a third of this kernel's 16 us): unconditional loads from
             // clamped indices (a uniform test around a load is still a branch with a wait at its join); only the LDS writes are predicated
-            constexpr int NS = CTILE / (64 * CWAVES);
+            constexpr int NS = PTILE / (64 * CWAVES);
             float sx[NS], sy[NS], sz[NS];
 #pragma unroll
             for (int i = 0; i < NS; i++) {
@@ -229,6 +287,7 @@ __global__ __launch_bounds__(64 * CWAVES) void chamfer_fwd_packed_kernel(const f
     rbest[wave][1][lane] = best1; rbesti[wave][1][lane] = bi1;
     __syncthreads();
     if (wave == 0) {
+        double sq = 0.0;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             float bv = rbest[0][u][lane];
@@ -245,8 +304,10 @@ __global__ __launch_bounds__(64 * CWAVES) void chamfer_fwd_packed_kernel(const f
             if (q < Nq) {
                 dout[(size_t)b * Nq + q] = bv;
                 iout[(size_t)b * Nq + q] = bi == 0x7fffffff ? 0 : bi;
+                if (LOSS) sq += (double)sqrtf(bv);
             }
         }
+        if (LOSS) chamfer_loss_tail(sq, ws, partial, loss, N, M);
     }
 }
 
@@ -271,8 +332,12 @@ extern "C" int l3d_chamfer_forward_variant(const float *xyz1, const float *xyz2,
     const long wgs2 = (long)l3d_divup(mx, 128) * B * 2;
     if (l3d_chamfer_forward_mode == 2 || (l3d_chamfer_forward_mode == 1 && wgs2 * CWAVES >= 1024)) {
         dim3 grid(l3d_divup(mx, 128), B, 2);
-        hipLaunchKernelGGL(chamfer_fwd_packed_kernel, grid, dim3(64 * CWAVES), 0, (hipStream_t)stream, xyz1, xyz2, N, M,
-                           dist1, dist2, idx1, idx2);
+        if (mx <= 1024 && CH_SMALL_TILE)
+            hipLaunchKernelGGL((chamfer_fwd_packed_kernel<false, 1024>), grid, dim3(64 * CWAVES), 0, (hipStream_t)stream, xyz1, xyz2, N, M,
+                               dist1, dist2, idx1, idx2, (unsigned *)nullptr, (double *)nullptr, (float *)nullptr);
+        else
+            hipLaunchKernelGGL((chamfer_fwd_packed_kernel<false, CTILE>), grid, dim3(64 * CWAVES), 0, (hipStream_t)stream, xyz1, xyz2, N, M,
+                               dist1, dist2, idx1, idx2, (unsigned *)nullptr, (double *)nullptr, (float *)nullptr);
     } else if (wgs2 * 2 >= 8192) {
         dim3 grid(l3d_divup(mx, 128), B, 2);
         hipLaunchKernelGGL(chamfer_fwd_kernel<2>, grid, dim3(64 * CWAVES), 0, (hipStream_t)stream, xyz1,
@@ -290,6 +355,41 @@ extern "C" int l3d_chamfer_forward(const float *xyz1, const float *xyz2, int B, 
                                    l3d_stream_t stream)
 {
     return l3d_chamfer_forward_variant(xyz1, xyz2, B, N, M, dist1, dist2, idx1, idx2, 1, stream);
+}
+
+extern "C" int l3d_chamfer_loss_local_mb(const float *dist1, const float *dist2, int B, int N, int M, void *ws, double *partial, float *loss,
+                                         l3d_stream_t stream);
+
+// Search + loss tail (losses/chamfer_distance.py:34-43 for one rank: the NN search of both directions, then
+// (mean sqrt d1 + mean sqrt d2) / 2) -- ONE launch where the packed kernel serves the search (the shapes of configs 2 / 3), the
+// search and l3d_chamfer_loss_local_mb otherwise.  partial [4] fp64 = (sum sqrt d1, sum sqrt d2, B N, B M): what a multi-GPU run
+// all-gathers.  ws: l3d_chamfer_forward_loss_ws_bytes(B, N, M) bytes, the first 16 zero before the first call (the kernel re-arms it).
+extern "C" size_t l3d_chamfer_forward_loss_ws_bytes(int B, int N, int M)
+{
+    if (B <= 0 || N <= 0 || M <= 0) return 0;
+    const size_t fused = 16 + (size_t)2 * B * l3d_divup(N > M ? N : M, 128) * sizeof(double);
+    return fused > CHAMFER_LL_WS_BYTES ? fused : CHAMFER_LL_WS_BYTES;
+}
+
+extern "C" int l3d_chamfer_forward_loss(const float *xyz1, const float *xyz2, int B, int N, int M, float *dist1, float *dist2,
+                                        int32_t *idx1, int32_t *idx2, void *ws, double *partial, float *loss, l3d_stream_t stream)
+{
+    L3D_REQUIRE(xyz1 && xyz2 && dist1 && dist2 && idx1 && idx2 && ws && partial && loss && B > 0 && N > 0 && M > 0);
+    L3D_REQUIRE(B <= 65535);
+    const int mx = N > M ? N : M;
+    const long wgs2 = (long)l3d_divup(mx, 128) * B * 2;
+    if ((long)N * M < (1L << 24) && wgs2 * CWAVES >= 1024) {
+        dim3 grid(l3d_divup(mx, 128), B, 2);
+        if (mx <= 1024 && CH_SMALL_TILE)
+            hipLaunchKernelGGL((chamfer_fwd_packed_kernel<true, 1024>), grid, dim3(64 * CWAVES), 0, (hipStream_t)stream, xyz1, xyz2, N, M, dist1,
+                               dist2, idx1, idx2, (unsigned *)ws, partial, loss);
+        else
+            hipLaunchKernelGGL((chamfer_fwd_packed_kernel<true, CTILE>), grid, dim3(64 * CWAVES), 0, (hipStream_t)stream, xyz1, xyz2, N, M, dist1,
+                               dist2, idx1, idx2, (unsigned *)ws, partial, loss);
+        return l3d_check_launch();
+    }
+    const int rc = l3d_chamfer_forward_variant(xyz1, xyz2, B, N, M, dist1, dist2, idx1, idx2, 1, stream);
+    return rc ? rc : l3d_chamfer_loss_local_mb(dist1, dist2, B, N, M, ws, partial, loss, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -536,8 +636,6 @@ extern "C" int l3d_chamfer_partials(const float *dist1, const float *dist2, int 
 // workgroup writes its two fp64 partial sums to ws, and the workgroup that draws the last ticket adds them with a
 // fixed shuffle tree (deterministic) and re-arms the ticket for the next call on the stream.
 //   ws: CHAMFER_LL_WS_BYTES bytes, the first 8 of them zero before the first call.
-#define CHAMFER_LL_BLOCKS 64
-#define CHAMFER_LL_WS_BYTES (16 + CHAMFER_LL_BLOCKS * 16)
 __global__ __launch_bounds__(256) void chamfer_loss_local_mb_kernel(const float *__restrict__ d1, size_t n1,
                                                                     const float *__restrict__ d2, size_t n2,
                                                                     unsigned *__restrict__ ws, double *__restrict__ partial,

@@ -34,6 +34,7 @@
 // 128 x 256 workgroups, two per CU, which do hide the epilogue (99 us); those with W fragments straight from L2 (110 us);
 // all 14 reads ahead of the first MFMA (105 us); first-product fragments read across the barrier (105 us); LDS bank
 // padding of the regions (worth 25 % in the bare read + MFMA loop, nothing here); non-temporal epilogue stores (-1 us).
+#include <cstdlib>
 #include "common.h"
 #include "split_bf16.h"          // f32x4 / f32x16 typedefs
 #include "split_f16.h"
@@ -629,8 +630,16 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
 #if defined(CF_ABL) && (CF_ABL & 4)     // timing ablation: no output stores (a store that never fires keeps the accumulators alive)
                 if (v == 12345.678f) yb[(size_t)co * N + n0 + wn * 128 + c * 32 + (lane & 31)] = v;
 #else
-                if constexpr (NPW == 2) __builtin_nontemporal_store(v, &yb[(size_t)co * N + n0 + wn * 128 + c * 32 + (lane & 31)]);
-                else yb[(size_t)co * N + n0 + wn * 128 + c * 32 + (lane & 31)] = v;
+#ifndef CF_STORE
+#define CF_STORE 1     // the two-plane instantiation's output stores: 0 plain, 1 nt (default), 2 sc1 (write-through, agent), 3 sc0 sc1 (system)
+#endif
+                float *dst_ = &yb[(size_t)co * N + n0 + wn * 128 + c * 32 + (lane & 31)];
+                if constexpr (NPW == 2) {
+                    if (CF_STORE == 1) __builtin_nontemporal_store(v, dst_);
+                    else if (CF_STORE == 2) __hip_atomic_store(dst_, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else if (CF_STORE == 3) __hip_atomic_store(dst_, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    else *dst_ = v;
+                } else *dst_ = v;
 #endif
                 if constexpr (AMAX) acc[a][c][r] = fabsf(v);     // kept for the maximum below (the accumulator is dead)
             }
@@ -668,6 +677,9 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
     }
 }
 
+#ifdef CF_PERSIST    // tools/experiments/conv_f16_persist.inc: persistent two-tile form with an LDS-transposed 16-byte epilogue (LABLOG R6.1; measured, slower in the step)
+#include "../../tools/experiments/conv_f16_persist.inc"
+#endif
 #ifdef CF_HALF       // tools/experiments/conv_f16_half.inc: 256-thread workgroups, two per CU (LABLOG R4.4; measured, not faster)
 #include "../../tools/experiments/conv_f16_half.inc"
 #endif
@@ -769,6 +781,22 @@ static int cf_launch(const void *x_planes, const void *w_planes, const float *sc
         }
         hipLaunchKernelGGL((conv_f16_kernel<false, false, false, 2>), grid, block, 4 * (4 * CF_TM * 16 + 4 * CF_TN * 16), st, CF_ARGS);
 #else
+#ifdef CF_PERSIST
+        {
+            // persistent form: one workgroup per CU (a multiple of 8, so that a workgroup's tiles stay on its XCD's Cout group)
+            static bool ok = [] { return hipFuncSetAttribute((const void *)conv_f16_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                             CFP_LDS) == hipSuccess; }();
+            static const bool off = [] { const char *e = getenv("L3D_CONV5_PERSIST"); return e && e[0] == '0'; }();
+            const int ntiles = (int)grid.x;
+            if (ok && !off && Cin >= 32) {
+                const int wgs = ntiles < 256 ? ntiles : 256;
+                hipLaunchKernelGGL(conv_f16_persist_kernel, dim3(wgs), block, CFP_LDS, st, (const uint4 *)xp, (const uint4 *)(xp + xpb),
+                                   (const uint4 *)wp, (const uint4 *)(wp + 2 * wpb), (const float *)(wp + 3 * wpb), (const float *)(xp + 2 * xpb),
+                                   scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, ntiles);
+                return l3d_check_launch();
+            }
+        }
+#endif
         hipLaunchKernelGGL((conv_f16_kernel<false, false, false, 2>), grid, block, 3 * (4 * CF_TM * 16 + 4 * CF_TN * 16), st, CF_ARGS);
 #endif
 #endif

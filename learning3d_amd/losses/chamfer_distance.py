@@ -90,6 +90,42 @@ def chamfer_loss_local(dist1, dist2):
     return loss
 
 
+_FL_WS = {}
+
+
+def chamfer_forward_loss(template, source, want="loss"):
+    """The no-grad forward of ChamferDistanceLoss as ONE launch (l3d_chamfer_forward_loss): NN search of both directions and the loss
+    tail.  Returns the fp32 loss scalar (want="loss"), this rank's fp64 partial sums [4] (want="partials": what a multi-GPU run
+    all-gathers, == chamfer_partials(dist1, dist2)), or (loss, partials, dist1, dist2, idx1, idx2) (want="all")."""
+    require_gpu(template, source)
+    xyz1, xyz2 = f32c(template), f32c(source)
+    B, N, _ = xyz1.shape
+    M = xyz2.shape[1]
+    dev = xyz1.device
+    from .. import _lib
+    nbytes = lib().l3d_chamfer_forward_loss_ws_bytes(B, N, M)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    hit = _FL_WS.get(key)
+    if hit is None or hit[1] != _lib.FAILED_CALLS or hit[0].numel() < nbytes:
+        # the kernel's last workgroup re-arms the ticket; after ANY failed C-ABI call the workspace is zeroed again instead of trusted
+        ws = hit[0].zero_() if hit is not None and hit[0].numel() >= nbytes else torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        _FL_WS[key] = (ws, _lib.FAILED_CALLS)
+    ws = _FL_WS[key][0]
+    dist1 = torch.empty(B, N, dtype=torch.float32, device=dev)
+    dist2 = torch.empty(B, M, dtype=torch.float32, device=dev)
+    idx1 = torch.empty(B, N, dtype=torch.int32, device=dev)
+    idx2 = torch.empty(B, M, dtype=torch.int32, device=dev)
+    part = torch.empty(4, dtype=torch.float64, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    check(lib().l3d_chamfer_forward_loss(ptr(xyz1), ptr(xyz2), B, N, M, ptr(dist1), ptr(dist2), ptr(idx1), ptr(idx2), ptr(ws),
+                                         ptr(part), ptr(loss), stream_ptr()), "l3d_chamfer_forward_loss")
+    if want == "loss":
+        return loss
+    if want == "partials":
+        return part
+    return loss, part, dist1, dist2, idx1, idx2
+
+
 def chamfer_combine(partials):
     """partials: fp64 [world,4] (or [4]) device tensor -> fp32 scalar loss tensor (on device)."""
     require_gpu(partials)
@@ -107,12 +143,12 @@ def chamfer_distance(template: torch.Tensor, source: torch.Tensor):
     over the whole batch."""
     from .._lib import on_device_of
     with on_device_of(template, source):               # tensors on a GPU other than the current one: switch for the call
-        cost_p0_p1, cost_p1_p0 = ChamferDistance()(template, source)
         if torch.is_grad_enabled() and (template.requires_grad or source.requires_grad):
+            cost_p0_p1, cost_p1_p0 = ChamferDistance()(template, source)
             cost_p0_p1 = torch.mean(torch.sqrt(cost_p0_p1))
             cost_p1_p0 = torch.mean(torch.sqrt(cost_p1_p0))
             return (cost_p0_p1 + cost_p1_p0) / 2.0
-        return chamfer_loss_local(cost_p0_p1, cost_p1_p0)      # == chamfer_combine(chamfer_partials(...)), one launch
+        return chamfer_forward_loss(template, source)           # search + loss tail, one launch (two for the large-cloud kernels)
 
 
 def chamfer(a, b):

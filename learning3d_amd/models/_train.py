@@ -29,45 +29,38 @@ from . import _fused
 
 
 _SHARD_SIZES = None      # clouds per rank, in rank order, when the shards of the global batch are NOT all equal (declare_shard_sizes)
-_SEEN_ROWS = {}          # local cloud count -> every rank's count, as discovered the first time that count was seen undeclared
 
 
 def declare_shard_sizes(sizes):
     """Tell the BatchNorm statistics exchange how many clouds every rank holds (list in rank order; None: back to discovery).
-    Equal shards are what torch's DistributedSampler hands out; parallel.shard / parallel.declare_global_batch declare the sizes
-    they cut themselves, every time they are called.  The declaration is STICKY until replaced or cleared
-    (declare_global_batch(None)); a later step whose local cloud count does not match it raises a ValueError on that rank.
-    Without a declaration the exchange DISCOVERS the sizes (gather_cloud_partials)."""
+    parallel.declare_global_batch (and parallel.shard(..., declare=True)) declare the sizes they cut.  The declaration is STICKY
+    until replaced or cleared (declare_global_batch(None)); a later step whose local cloud count does not match it raises a
+    ValueError on that rank.  Without a declaration the exchange DISCOVERS the sizes on every call (_discover_sizes)."""
     global _SHARD_SIZES
     _SHARD_SIZES = None if sizes is None else [int(v) for v in sizes]
 
 
 def _discover_sizes(rows, device):
-    """Every rank's cloud count through one all_gather of one integer and ONE host read (the cost round 4 removed from every
-    layer: ~70 stalls per FlowNet3D step).  It runs once per distinct local count (cached), on every call when
-    L3D_CHECK_SHARDS=1 (debugging an exchange that hangs), never when the declared sizes fit.  All ranks take the same branch
-    as long as their counts change together -- which DistributedSampler and parallel.shard guarantee; a loader that changes
-    one rank's count while another rank's stays the same must declare (declare_shard_sizes) or set L3D_CHECK_SHARDS=1."""
-    import os
-    if rows in _SEEN_ROWS and os.environ.get("L3D_CHECK_SHARDS") != "1":
-        return _SEEN_ROWS[rows]
+    """Every rank's cloud count through one all_gather of one integer and one host read -- on EVERY undeclared call.  Round 5
+    cached the answer per local count; that is wrong exactly where discovery matters: after steps of 4 + 4 clouds, a
+    last batch of 4 + 3 lets rank 0 hit its cache for "4" and enter the partials gather while rank 1 (3: unseen) enters this
+    exchange -- two different collectives.  No local information can tell a rank that ANOTHER rank's count changed, so there is no
+    cache: a training loop that wants the exchange without the host read declares its shards (parallel.declare_global_batch,
+    one call per step; equal shards: declare_shard_sizes([n] * world))."""
     world = dist.get_world_size()
     staged = device.type == "cuda" and dist.get_backend() == "gloo"
     mine = torch.tensor([rows], dtype=torch.int64, device="cpu" if staged else device)
     allr = torch.empty(world, dtype=torch.int64, device=mine.device)
     dist.all_gather_into_tensor(allr, mine)
-    sizes = [int(v) for v in allr.tolist()]
-    if os.environ.get("L3D_CHECK_SHARDS") != "1":
-        _SEEN_ROWS[rows] = sizes
-    return sizes
+    return [int(v) for v in allr.tolist()]
 
 
 def gather_cloud_partials(part):
     """part [B_local, C, 2] fp64 (this rank's clouds) -> [B_global, C, 2] in global cloud order (ranks hold contiguous
     shards, parallel.shard_bounds).  One collective per call: equal shards go out as they are; unequal shards are padded to
     the largest one and cut back after the gather -- same code on RCCL and gloo.  The per-rank sizes come from the
-    declaration (declare_shard_sizes; parallel.shard declares what it cuts), else from a discovery exchange that costs a host
-    read once per distinct local count -- undeclared uneven shards no longer launch a collective with mismatched sizes.
+    declaration (declare_shard_sizes / parallel.declare_global_batch), else from a discovery exchange (one integer per rank and
+    a host read, every call) -- undeclared uneven shards never launch a collective with mismatched sizes.
     Single process: returned as is."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         world, rank = dist.get_world_size(), dist.get_rank()
@@ -79,9 +72,6 @@ def gather_cloud_partials(part):
                              "declare every step (parallel.shard / parallel.declare_global_batch do) or clear it with declare_global_batch(None)")
         if sizes is None:
             sizes = _discover_sizes(int(part.shape[0]), part.device)
-            if sizes[rank] != part.shape[0]:
-                raise RuntimeError(f"shard-size discovery is stale: rank {rank} holds {part.shape[0]} clouds, the cached exchange "
-                                   f"says {sizes}; declare the sizes (parallel.declare_global_batch) or set L3D_CHECK_SHARDS=1")
         part = part.contiguous()
         # device tensors on a gloo group (two ranks sharing one GPU in tests/test_gpu_two_ranks.py; RCCL wants a device per rank):
         # the few KB go through the host for the collective only

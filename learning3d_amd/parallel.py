@@ -49,11 +49,13 @@ def declare_global_batch(global_batch, world=None):
     _train.declare_shard_sizes([hi - lo for lo, hi in spans])
 
 
-def shard(tensor, rank, world):
-    """This rank's contiguous slice of a global batch.  Also records the sizes it cut (declare_global_batch), so a train-mode
-    BatchNorm exchange behind it knows every rank's cloud count without asking."""
+def shard(tensor, rank, world, declare=False):
+    """This rank's contiguous slice of a global batch.  Pure by default (sharding an eval set or a label tensor of
+    another length must not change what later BatchNorm exchanges expect).  declare=True also records the sizes it cut
+    (declare_global_batch) -- for the training batch of a step, so that the train-mode BatchNorm exchange behind it knows every
+    rank's cloud count without asking; the declaration is sticky until the next one (declare_global_batch(None) clears it)."""
     lo, hi = shard_bounds(tensor.shape[0], rank, world)
-    if world > 1:
+    if declare and world > 1:
         declare_global_batch(tensor.shape[0], world)
     return tensor[lo:hi]
 

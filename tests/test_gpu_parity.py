@@ -236,6 +236,36 @@ def test_chamfer_loss_local_equals_partials_plus_combine():
         assert abs(a.item() - want) < 1e-6
 
 
+def test_chamfer_forward_loss_one_launch_equals_search_plus_tail():
+    """l3d_chamfer_forward_loss (round 6: the loss tail inside the search kernel's launch -- write-through slots, a ticket, the last
+    workgroup adds them): distances and indices bit for bit those of l3d_chamfer_forward, partial sums and loss those of the two-step
+    route (fp64 sums in another order), against the oracle's loss; config 2's shape, ragged and unequal clouds (workgroups beyond the
+    shorter cloud still draw a ticket), the two-launch fallback for tiny and for large clouds, repeated calls (the ticket re-arms)."""
+    from learning3d_amd.losses.chamfer_distance import (ChamferDistanceLoss, chamfer_forward_loss, chamfer_partials, chamfer_combine)
+    from learning3d_amd._lib import lib, check, ptr, stream_ptr
+    for (B, N, M, seed) in [(32, 1024, 1024, 3), (32, 1024, 700, 4), (16, 300, 2000, 5), (2, 77, 130, 1), (1, 5, 2, 6), (1, 4096, 4100, 7)]:
+        a, b = rand((B, N, 3), seed), rand((B, M, 3), seed + 50)
+        ta, tb = dev(a), dev(b)
+        d1 = torch.empty(B, N, device="cuda"); d2 = torch.empty(B, M, device="cuda")
+        i1 = torch.empty(B, N, dtype=torch.int32, device="cuda"); i2 = torch.empty(B, M, dtype=torch.int32, device="cuda")
+        check(lib().l3d_chamfer_forward(ptr(ta), ptr(tb), B, N, M, ptr(d1), ptr(d2), ptr(i1), ptr(i2), stream_ptr()), "cd")
+        part_ref = chamfer_partials(d1, d2)
+        loss_ref = chamfer_combine(part_ref)
+        for rep in range(3):
+            loss, part, e1, e2, j1, j2 = chamfer_forward_loss(ta, tb, want="all")
+            assert torch.equal(e1, d1) and torch.equal(e2, d2) and torch.equal(j1, i1) and torch.equal(j2, i2), (B, N, M, rep)
+            pr, pg = part_ref.cpu().numpy(), part.cpu().numpy()
+            assert pg[2] == B * N and pg[3] == B * M
+            np.testing.assert_allclose(pg[:2], pr[:2], rtol=1e-13, atol=0)
+            assert abs(loss.item() - loss_ref.item()) <= 1.2e-7 * max(1.0, abs(loss_ref.item())), (B, N, M, rep)
+        want = (np.sqrt(d1.cpu().numpy().astype(np.float64)).mean() + np.sqrt(d2.cpu().numpy().astype(np.float64)).mean()) / 2
+        assert abs(loss.item() - want) < 1e-6
+        with torch.no_grad():
+            assert ChamferDistanceLoss()(ta, tb).item() == loss.item()          # the module's no-grad forward IS this entry point
+    o = oracle.chamfer_forward(a[:1], b[:1])
+    assert np.array_equal(e1.cpu().numpy()[:1], o[0]) and np.array_equal(j2.cpu().numpy()[:1], o[3])
+
+
 def test_chamfer_idx_and_ragged_vs_oracle():
     from learning3d_amd._lib import lib, check, ptr, stream_ptr
     for (B, N, M, seed) in [(2, 77, 130, 1), (1, 2500, 64, 2), (32, 1024, 1024, 3)]:

@@ -273,23 +273,33 @@ def _bn_stats_rank(rank, world, port, q, NB=8, mode="declared"):
     if mode == "declared" and NB % world:
         parallel.declare_global_batch(NB, world)                              # uneven shards are declared, not asked for per layer
     elif mode == "shard":
-        assert tuple(parallel.shard(torch.from_numpy(z), rank, world).shape) == (hi - lo, 16, 300)   # shard() declares what it cuts
+        assert tuple(parallel.shard(torch.from_numpy(z[:5]), rank, world).shape[1:]) == (16, 300) and _train._SHARD_SIZES is None   # pure
+        assert tuple(parallel.shard(torch.from_numpy(z), rank, world, declare=True).shape) == (hi - lo, 16, 300)   # declares what it cuts
     zs = z[lo:hi].astype(np.float64)
     # per-cloud fp64 partial sums of this rank's shard: the stand-in for l3d_channel_stats (tested on the GPU against numpy)
     part = torch.from_numpy(np.stack([zs.sum(-1), (zs ** 2).sum(-1)], axis=-1))
+    if mode == "undeclared_after_even":
+        # two steps of 4 + 4 clouds come first, undeclared; the last batch is 4 + 3.  Rank 0's local count (4) does not
+        # change, rank 1's does: a per-count cache put the two ranks into different collectives here.
+        ze = rng.standard_normal((8, 16, 300)).astype(np.float64)
+        elo, ehi = parallel.shard_bounds(8, rank, world)
+        pe = torch.from_numpy(np.stack([ze[elo:ehi].sum(-1), (ze[elo:ehi] ** 2).sum(-1)], axis=-1))
+        for _ in range(2):
+            assert tuple(_train.gather_cloud_partials(pe).shape) == (8, 16, 2)
     pg = _train.gather_cloud_partials(part)
     mean, var, n, tot = _train.stats_from_partials(pg, z.shape[2])
     q.put((rank, pg.numpy().tobytes(), tot.numpy().tobytes(), mean.numpy().tobytes(), var.numpy().tobytes(), n))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("NB,mode", [(8, "declared"), (7, "declared"), (7, "undeclared"), (7, "shard")])
+@pytest.mark.parametrize("NB,mode", [(8, "declared"), (7, "declared"), (7, "undeclared"), (7, "shard"), (7, "undeclared_after_even")])
 def test_two_rank_gloo_batchnorm_statistics_bit_identical(NB, mode):
     """train-mode BatchNorm statistics over a batch sharded across 2 ranks (gloo) equal the
     single-process statistics BIT FOR BIT: per-cloud fp64 partial sums, all_gather, addition in global cloud order.
     NB = 7: an uneven last batch (4 + 3 clouds), padded for the gather -- declared with parallel.declare_global_batch, declared by
-    parallel.shard itself, or NOT declared at all (the exchange discovers the sizes, one host read per distinct local count:
-    ADVICE r4 -- undeclared uneven shards used to launch a collective with mismatched sizes)."""
+    parallel.shard(declare=True), or NOT declared at all (the exchange discovers the sizes on every call: ADVICE r4 -- undeclared
+    uneven shards used to launch a collective with mismatched sizes; ADVICE r5 -- also right behind even steps of the same local
+    count on rank 0, where a per-count cache sent the ranks into different collectives)."""
     import socket
     import numpy as np
     import torch
