@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, s), f"{s} declared in include/l3d_hip.h but not exported"
     assert set(syms) == set(_lib.SIGNATURES), "ctypes table and header disagree"
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "l3d_hip.h")).read(), flags=re.S)
-    assert len(set(re.findall(r"\b(l3d_[a-z0-9_]+)\s*\(", text))) <= 92, "the boundary header grew past 92 entry points (90 + l3d_emd_workspace_bytes + l3d_probe_mfma_sustained, round 5)"
+    assert len(set(re.findall(r"\b(l3d_[a-z0-9_]+)\s*\(", text))) <= 94, "the boundary header grew past 94 entry points (90 + l3d_emd_workspace_bytes + l3d_probe_mfma_sustained, round 5; + l3d_chamfer_forward_loss and its workspace size, round 6)"
     l = _lib.lib()
     assert l.l3d_version() >= 100
     assert b"invalid" in l.l3d_status_string(-1)
@@ -393,7 +393,7 @@ def test_hot_kernels_compile_without_scratch():
            "_Z19fold_mlp_f16_kernelILi5EE": 256}
     for prefix, vgpr_max in hot.items():
         ks = [k for n, k in meta.items() if n.startswith(prefix)]
-        assert len(ks) == 1, prefix
-        k = ks[0]
-        assert k.get(".private_segment_fixed_size", 0) == 0 and k.get(".vgpr_spill_count", 0) == 0, (prefix, k)
-        assert k.get(".vgpr_count", 0) <= vgpr_max, (prefix, k.get(".vgpr_count"))
+        assert len(ks) >= 1, prefix                              # every instantiation behind the prefix
+        for k in ks:
+            assert k.get(".private_segment_fixed_size", 0) == 0 and k.get(".vgpr_spill_count", 0) == 0, (prefix, k)
+            assert k.get(".vgpr_count", 0) <= vgpr_max, (prefix, k.get(".vgpr_count"))
