@@ -1,346 +1,562 @@
 // featknn.hip -- k nearest neighbours in FEATURE space: knn(x, k) of
-// utils/model_common_utils.py:3-9 for x [B,C,N] with C = 32..512 (the dynamic graphs of PRNet's DGCNN,
-// models/prnet.py:76-97), without the [B,N,N] inner-product / distance matrices:
+// utils/model_common_utils.py:3-9 for x [B,C,N] with C != 3 (the dynamic graphs of PRNet's DGCNN, models/prnet.py:76-97;
+// PointConv's knn_point, utils/pointconv_util.py:107-121; CurveNet's LPFA, utils/curvenet_util.py:260-291), without the [B,N,N]
+// inner-product / distance matrices:
 //     inner = -2 x^T x;  xx = sum_c x^2;  pd = -xx_j - inner_ij - xx_i;  idx = topk(pd, k)
-// The inner product is a real GEMM here (2*C flops per pair), so it runs on the matrix cores in the bf16x3
-// arithmetic of conv_split.hip (x = h + m + l exactly, six bf16 products, fp32 accumulate: fp32-level error),
-// with the top-k selection as the GEMM's epilogue, flash-attention style:
-//   * featknn_split_kernel: one pass over x -> the three bf16 planes in MFMA operand order
-//     [B][C/16][plane 3][kg 2][Np][8 bf16] (Np = N rounded up to 128, zero padded) and nxx = -sum_c x^2
-//     (-inf on the padding).  The SAME buffer is both GEMM operands (keys and queries).
-//   * featknn_kernel: workgroup = 4 waves = 128 queries; wave = 32 queries (MFMA columns) x 128-key tiles
-//     (MFMA rows, "swapped" orientation: a lane owns ONE query and 64 of the tile's 128 keys, its partner
-//     lane l^32 the other 64).  Key chunks of 32 channels go through a double-buffered LDS tile shared by
-//     the four waves; query fragments come straight from L2 one unit ahead.  After the last channel chunk
-//     the lane forms pd exactly in the reference's op order, keeps candidates that beat its current k-th
-//     best in a bit mask and runs the (value, index) insertion network only for those.  The two lanes of a
-//     pair merge their lists once at the end (ties -> lower index first, as knn.hip).
-// Indices cannot be bit-pinned to the reference here (its sgemm's summation order is MKL's); the parity
-// test bounds every returned neighbour by the exact k-th distance.
+//
+// Round 6 rewrite (rounds 2-5: six bf16 products per fp32 product, a sorted (value, index) list of 2 K registers per lane, one wave per
+// SIMD with every unit's load -> LDS -> barrier -> MFMA chain exposed: 125 us at B 32 / C 64 / N 1024 / k 20 against ~10 us of matrix
+// work, 151 spilled registers at K = 64; that kernel is tools/experiments/featknn_v1.hip).  Now:
+//
+//   * the inner product is an f16x2 GEMM (split_f16.h: X = x 2^T per ROW, h = f16(X), m = f16(X - h); products m h' + h m' + h h' on
+//     v_mfma_f32_32x32x16_f16, fp32 accumulate: THREE fp16 products per fp32 product, fp32-level error -- the same arithmetic as the
+//     shared-MLP kernels).  The row scale is a power of two taken from the row's own largest magnitude by the thread that splits the
+//     row: no pass for a tensor maximum, and 2^-T_i 2^-T_j comes back out exactly.
+//   * one pre-pass (featknn_split_kernel) writes the two fp16 planes in MFMA operand order [plane][C/8][Np][8 fp16] (16-byte cells:
+//     the 8 consecutive channels a lane of the MFMA consumes) and aux = (-|x_j|^2, 2^-T_j) per row; the SAME planes are both operands.
+//   * featknn_kernel: a workgroup = 128 queries x the whole cloud, EIGHT waves (two per SIMD): wave = (query block of 32) x (key half):
+//     the 64-key tiles 2t + half of every 128 keys.  Keys are the MFMA's rows and stream through a double-buffered LDS stage as
+//     global_load_lds DMA pieces (no registers, no VALU) shared by the four query blocks; queries are the MFMA's COLUMNS: a lane holds
+//     16 candidates of ONE query per 32 x 32 tile, and four lanes (two waves x two half-waves) serve a query.
+//   * selection is knn_mfma.hip's: no sorted lists in registers.  Sweep 0 keeps per-lane GROUP maxima (one v_max3 per two values);
+//     the T-th largest of a lane's 16 (K = 64: 32) group maxima, T = ceil(K / 4), minimised over the query's four lanes, is a bound thr that at
+//     least K candidates reach -- and few more (~25 for K = 20 at N = 1024).  Sweep 1 recomputes the tiles (bit-identical) and appends
+//     every candidate >= thr as a 64-bit key (order-preserving value bits << 32 | ~index) to the query's list (LDS counter, list in the
+//     workspace).  Rank: four threads per query count the keys above each key; rank r < k writes idx[q][r].  Equal values: the lower
+//     index ranks first, as l3d_knn_graph.
+//   * a list that overflows (more than CAP candidates at or above the bound: clouds of many identical points) sends its query to an
+//     exact wave-per-query selection at the end of the same kernel (plain fp32 dot products, k rounds of arg-max): slow, rare, and
+//     what guarantees an answer for every input.
+// Indices cannot be bit-pinned to the reference here (its sgemm's summation order is MKL's); the parity test bounds every returned
+// neighbour by the exact k-th distance and compares with the reference's own op sequence on the CPU (> 99.9 % identical indices).
+#include <type_traits>
 #include "common.h"
-#include "split_bf16.h"
+#include "split_bf16.h"          // f32x16
+#include "split_f16.h"
 
-#ifndef FK_PROBE
-#define FK_PROBE 0                                   // tools/probe_featknn.hip: 1 = no insertions, 2 = GEMM only
-#endif
-#ifdef FK_COUNT
-__device__ unsigned long long fk_trip_counter;
-#endif
-#define FK_REGION (128 * 16 + 64)
-#define FK_BUF (12 * FK_REGION)                      // 32 channels x 128 keys x 3 planes
-#define FK_NXOFF (2 * FK_BUF)                        // [2][128] floats
-#define FK_SCROFF (FK_NXOFF + 2 * 128 * 4)           // [4 waves][17][64] floats (row 16 = -inf)
-#define FK_LDS (FK_SCROFF + 4 * 17 * 64 * 4)
-
-// C: the tensor's channels; Cp: C rounded up to a multiple of 32 (the GEMM's K chunk) -- the pad channels are zeros,
-// which change neither the dot products nor |x|^2
-__global__ __launch_bounds__(256) void featknn_split_kernel(const float *__restrict__ x, int C, int Cp, int N, int Np,
-                                                            uint4 *__restrict__ xs, float *__restrict__ nxx)
+typedef _Float16 fk_f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned long long fk_u64;
+typedef __attribute__((address_space(3))) void *fk_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *fk_gbl_ptr_t;
+// byte offset of an LDS object inside the workgroup's allocation (what a ds_* instruction in inline asm takes)
+__device__ __forceinline__ unsigned fk_lds_off(const void *p)
 {
-    const int n = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (n >= Np) return;
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
+}
+
+#ifdef FK_TIMELINE     // tools/fk_timeline.py: s_memrealtime (100 MHz) marks of every workgroup in the (unused, K <= 20) list area of the workspace
+#define FKM(i) { if (threadIdx.x == 0) ((long long *)lists)[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define FKM(i)
+#endif
+#ifndef FK_ABL
+#define FK_ABL 0      // timing ablations (tools/build_variant_lib.py; results are garbage): 1 no rank phase, 2 nothing reaches the bound, 4 one sweep, 8 no epilogue
+#endif
+#define FK_QT 128                          // queries per workgroup (4 column blocks of 32)
+#define FK_STAGE 33792                     // 2 key halves x 2 planes x 8 octets x 64 rows x 16 B (128 keys x 64 channels) + 1 KB: the tile's aux
+#define FK_AUXT 256                        // floats of aux per 128-key tile: -|x_row|^2 x 128 | 2^-T | max |x_row| | (unused)
+#define FK_NSTAGE 2
+#define FK_DUMP_OFF (FK_NSTAGE * FK_STAGE) // [8 waves][17 rows][64 lanes] floats (row 16 = scratch for lanes without a hit)
+#define FK_DUMP_BYTES (8 * 17 * 64 * 4)
+#define FK_CNT_OFF (FK_DUMP_OFF + FK_DUMP_BYTES)           // int qcnt[128]
+#define FK_FLAG_OFF (FK_CNT_OFF + 128 * 4)                 // int flagged[1 .. 128], count at [129]
+#define FK_LIST_OFF (FK_FLAG_OFF + 132 * 4)                // LDS lists (K <= 20): float lv[128][65], unsigned short li[128][66]
+#define FK_LDS_CAP 64
+#define FK_LVS 65                                          // row strides: odd in 4-byte words, or a wave's 16 - 32 queries meet in one bank
+#define FK_LIS 66
+#define FK_LDS_LL (FK_LIST_OFF + 128 * FK_LVS * 4 + 128 * FK_LIS * 2)
+#define FK_MAXNP 16384                     // the exact fallback keeps one query's Np ranking values in the two stages
+
+__host__ __device__ constexpr int fk_cap(int KC) { return KC <= 20 ? FK_LDS_CAP : (KC <= 32 ? 96 : 192); }   // list capacity per query
+
+// x [B][C][N] fp32 -> planes [B][2][Cp/8][Np][8 fp16] (h | m of x 2^T, T per 128-ROW TILE from the tile's own largest magnitude; zero
+// rows / channels beyond N / C) and aux [B][Np/128][256] = per tile: -sum_c x^2 of its 128 rows (-inf on the padding rows), then
+// [128] = 2^-T, [129] = the tile's largest |x_row|.  A workgroup = one tile: thread (row t & 127, part t >> 7) takes a quarter of the
+// row's channels / octets.  (A scale per tile rather than per tensor: no pass for a tensor maximum in front of the split; rather
+// than per row: the epilogue then owes every value a multiplication.  A row far below its tile's maximum keeps the tile's absolute
+// resolution, 2^-22 of |x_max| |x_i| in a ranking value -- the tolerance the parity test grants is 4e-6 of the largest |x|^2.)
+__global__ __launch_bounds__(512) void featknn_split_kernel(const float *__restrict__ x, int C, int Cp, int N, int Np,
+                                                            uint4 *__restrict__ planes, float *__restrict__ aux)
+{
+    __shared__ float red[4][128];
+    __shared__ float tmax[8];
+    const int t = threadIdx.x, r = t & 127, part = t >> 7;
+    const int n = blockIdx.x * 128 + r, b = blockIdx.y;
     const float *xb = x + (size_t)b * C * N;
-    uint4 *xsb = xs + (size_t)b * (Cp / 16) * 6 * Np;
+    const int noct = Cp / 8;
+    uint4 *ph = planes + (size_t)b * 2 * noct * Np, *pm = ph + (size_t)noct * Np;
+    float big = 0.f;
+    if (n < N)
+        for (int c = part; c < C; c += 4) big = fmaxf(big, fabsf(xb[(size_t)c * N + n]));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) big = fmaxf(big, __shfl_xor(big, d, 64));
+    if ((t & 63) == 0) tmax[t >> 6] = big;
+    __syncthreads();
+    big = fmaxf(fmaxf(fmaxf(tmax[0], tmax[1]), fmaxf(tmax[2], tmax[3])), fmaxf(fmaxf(tmax[4], tmax[5]), fmaxf(tmax[6], tmax[7])));
+    int e = 0;
+    const bool fin = big > 0.f && big < INFINITY;
+    if (fin) (void)frexpf(big, &e);                                 // big = f 2^e, f in [0.5, 1): big 2^(12 - e) in [2^11, 2^12)
+    const int T = fin ? 12 - e : 0;
+    const float up = ldexpf(1.0f, T);
     float s = 0.f;
-    for (int c8 = 0; c8 < Cp / 8; c8++) {              // kc16 = c8 >> 1, kg = c8 & 1
+    for (int o = part; o < noct; o += 4) {
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = (n < N && c8 * 8 + e < C) ? xb[(size_t)(c8 * 8 + e) * N + n] : 0.f;
+        for (int u = 0; u < 8; u++) v[u] = (n < N && o * 8 + u < C) ? xb[(size_t)(o * 8 + u) * N + n] : 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; e++) s = s + v[e] * v[e];          // x ** 2 then sum: no fused multiply-add
-        uint4 h, m, l;
-        split8(v, h, m, l);
-        const size_t base = ((size_t)(c8 >> 1) * 6 + (c8 & 1)) * Np + n;
-        xsb[base] = h;
-        xsb[base + 2 * (size_t)Np] = m;
-        xsb[base + 4 * (size_t)Np] = l;
+        for (int u = 0; u < 8; u++) s = s + v[u] * v[u];           // x ** 2 then sum: no fused multiply-add
+        uint4 h, m;
+        af_split_x_unscaled(v[0], v[1], up, h.x, m.x);
+        af_split_x_unscaled(v[2], v[3], up, h.y, m.y);
+        af_split_x_unscaled(v[4], v[5], up, h.z, m.z);
+        af_split_x_unscaled(v[6], v[7], up, h.w, m.w);
+        ph[(size_t)o * Np + n] = h;
+        pm[(size_t)o * Np + n] = m;
     }
-    nxx[(size_t)b * Np + n] = n < N ? -s : -INFINITY;
+    red[part][r] = s;
+    __syncthreads();
+    float *at = aux + ((size_t)b * (Np / 128) + blockIdx.x) * FK_AUXT;
+    float xx = 0.f;
+    if (part == 0) {
+        xx = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
+        at[r] = n < N ? -xx : -INFINITY;
+        xx = n < N ? xx : 0.f;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) xx = fmaxf(xx, __shfl_xor(xx, d, 64));
+    }
+    __syncthreads();
+    if (part == 0 && (t & 63) == 0) tmax[t >> 6] = xx;
+    __syncthreads();
+    if (t == 0) {
+        at[128] = ldexpf(1.0f, -T);
+        at[129] = sqrtf(fmaxf(tmax[0], tmax[1])) * 1.000001f;
+    }
 }
 
-// (value desc, index asc) insertion: used once, to merge the two lists of a lane pair
-template <int K>
-__device__ __forceinline__ void fk_insert_lex(TopK<K> &t, float key, int j)
-{
-#define FK_BEFORE(i) (key > t.v[i] || (key == t.v[i] && j < t.id[i]))
-    bool b_prev = FK_BEFORE(K - 1);
+// T largest of the values inserted so far, descending (TopKV's v_med3 network, common.h)
+template <int T>
+struct FkTop {
+    float v[T];
+    __device__ __forceinline__ void init() {
 #pragma unroll
-    for (int i = K - 1; i > 0; i--) {
-        const bool b_up = FK_BEFORE(i - 1);
-        t.id[i] = b_up ? t.id[i - 1] : (b_prev ? j : t.id[i]);
-        t.v[i] = b_up ? t.v[i - 1] : (b_prev ? key : t.v[i]);
-        b_prev = b_up;
+        for (int i = 0; i < T; i++) v[i] = -INFINITY;
     }
-    t.id[0] = b_prev ? j : t.id[0];
-    t.v[0] = b_prev ? key : t.v[0];
-#undef FK_BEFORE
-}
+    __device__ __forceinline__ void insert(float key) {
+#pragma unroll
+        for (int i = T - 1; i > 0; i--) v[i] = __builtin_amdgcn_fmed3f(v[i - 1], v[i], key);
+        v[0] = fmaxf(v[0], key);
+    }
+};
 
-template <int K>
-__global__ __launch_bounds__(256, K <= 20 ? 2 : 1) void featknn_kernel(const uint4 *__restrict__ xs, const float *__restrict__ nxx,
-                                                         int C, int N, int Np, int k, int64_t *__restrict__ idx_out,
-                                                         float *__restrict__ part_v, int *__restrict__ part_i)
+// KC: list-length class (20, 32, 64: k <= KC).  KC = 20 keeps the queries' lists in LDS (value + 16-bit index, 64 entries), the longer
+// classes in the workspace (64-bit keys).  NCH_RES: channel chunks of 64 whose query fragments stay in registers (1 or 2: C <= 128);
+// 0: any C, the query fragments of a chunk are fetched from L2 one unit ahead.
+template <int KC, int NCH_RES>
+__global__ __launch_bounds__(512) void featknn_kernel(const uint4 *__restrict__ planes, const float *__restrict__ aux,
+                                                       const float *__restrict__ x, int C, int Cp, int N, int Np, int k,
+                                                       fk_u64 *__restrict__ lists, int64_t *__restrict__ idx_out)
 {
-    // Key-range split (round 5): with B N / 128 < 512 workgroups a CU holds ONE and every unit's load -> LDS -> barrier -> MFMA chain
-    // runs exposed (LABLOG R5.4).  gridDim.z parts each rank their share of the key tiles for the same 128 queries (a second
-    // workgroup per CU to switch to) and leave their sorted K-lists in part_v / part_i; featknn_merge_kernel merges them.
+    constexpr int CAP = fk_cap(KC), T = KC / 4 + 1;            // 4 T >= KC + 4 group maxima per query decide its bound
+    constexpr bool LL = KC <= 20;                              // lists in LDS
+    constexpr bool STREAM = NCH_RES == 0;
+    constexpr int NBF = STREAM ? 2 : NCH_RES;                 // query fragment sets held in registers
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int b = blockIdx.y, q0 = blockIdx.x * 128;
-    const int nch = C / 32, nkt_all = Np / 128;
-    const int kt0 = (int)((long)nkt_all * blockIdx.z / gridDim.z), kt1 = (int)((long)nkt_all * (blockIdx.z + 1) / gridDim.z);
-    const int U = (kt1 - kt0) * nch;
-    const uint4 *xsb = xs + (size_t)b * (C / 16) * 6 * Np;
-    const float *nxb = nxx + (size_t)b * Np;
-    float *nxl = (float *)(lds + FK_NXOFF);
-    float *scr = (float *)(lds + FK_SCROFF) + wave * 17 * 64;
-    scr[16 * 64 + lane] = -INFINITY;
+    const int qb = wave & 3, kh = wave >> 2;                  // query block, key half
+    const int col = lane & 31, hf = lane >> 5;
+    const int b = blockIdx.y, q0 = blockIdx.x * FK_QT;
+    const int ql = qb * 32 + col, q = q0 + ql;                // q < Np always
+    const int noct = Cp / 8, nch = Cp / 64, nkt = Np / 128, U = nkt * nch;
+    const uint4 *pb = planes + (size_t)b * 2 * noct * Np;
+    const float *ab = aux + (size_t)b * nkt * FK_AUXT;
+    float *dump = (float *)(lds + FK_DUMP_OFF) + wave * 17 * 64;
+    float *tv = (float *)lds;                                  // [128][4 T + 1]: the lanes' T largest group maxima (between the sweeps, in the idle stages)
+    int *qcnt = (int *)(lds + FK_CNT_OFF);
+    int *flags = (int *)(lds + FK_FLAG_OFF);
+    float *lv = (float *)(lds + FK_LIST_OFF);
+    unsigned short *li = (unsigned short *)(lds + FK_LIST_OFF + 128 * FK_LVS * 4);
+    static_assert((4 * T + 1) * 128 * 4 <= FK_NSTAGE * FK_STAGE, "the bound exchange fits the stages");
 
-    // staging: thread -> key row t & 127 of regions 2j + (t >> 7), j < 6; region r of channel chunk ch sits
-    // at ((ch * 12 + r) * Np + key) in the split buffer
-    const int srow = t & 127, shalf = t >> 7;
-    const int s_lds = shalf * FK_REGION + srow * 16;
-    // query fragments: lane (i = l & 31, kg = l >> 5) -> 8 channels of query q0 + 32 wave + i
-    const int qrow = q0 + wave * 32 + (lane & 31);
-    const size_t q_off = (size_t)(lane >> 5) * Np + qrow;
-    const int a_off = (lane >> 5) * FK_REGION + (lane & 31) * 16;
-    const float xxq = -nxb[qrow];                                  // xx_i (qrow < Np always)
+    FKM(0)
+    if (t < 128) qcnt[t] = 0;
+    if (t == 0) flags[129] = 0;
+    const float xxq = -ab[(q >> 7) * FK_AUXT + (q & 127)], sq2 = 2.0f * ab[(q >> 7) * FK_AUXT + 128];
+    // Sweep 0 ranks with ONE product (h h').  What the two dropped products can add to a ranking value is below
+    // 2 (2^-11 + 2^-11 + 2^-22) |x_i| |x_j| (+ the accumulations' own rounding) < 0x1.1p-9 |x_i| max_j |x_j|: the bound taken from the
+    // one-product group maxima is lowered by that much and stays a value that at least KC exact ranking values reach.
+    float sxmax = 0.f;
+    for (int kt_ = 0; kt_ < nkt; kt_++) sxmax = fmaxf(sxmax, ab[(size_t)kt_ * FK_AUXT + 129]);
+    const float margin = 0x1.1p-9f * sqrtf(xxq) * sxmax;
 
-    uint4 k0, k1, k2, k3, k4, k5;            // key chunk in flight
-    uint4 qn[2][3];                          // query fragments of the next unit
-    bf16x8 qc[2][3];                         // ... of the current unit
-    float nxr = 0.f;
-
-#define FK_LOAD(KT, CH)                                                                                   \
-    do {                                                                                                  \
-        const uint4 *src_ = xsb + ((size_t)(CH) * 12 + shalf) * Np + (KT) * 128 + srow;                   \
-        k0 = src_[0];                                                                                     \
-        k1 = src_[2 * (size_t)Np];                                                                        \
-        k2 = src_[4 * (size_t)Np];                                                                        \
-        k3 = src_[6 * (size_t)Np];                                                                        \
-        k4 = src_[8 * (size_t)Np];                                                                        \
-        k5 = src_[10 * (size_t)Np];                                                                       \
-        const uint4 *qs_ = xsb + (size_t)(CH) * 12 * Np + q_off;                                          \
-        _Pragma("unroll") for (int s_ = 0; s_ < 2; s_++)                                                  \
-            _Pragma("unroll") for (int p_ = 0; p_ < 3; p_++) qn[s_][p_] = qs_[(size_t)((s_ * 3 + p_) * 2) * Np]; \
-        if ((CH) == 0 && t < 128) nxr = nxb[(KT) * 128 + t];                                              \
-    } while (0)
-#define FK_STORE(BUF, KT, CH)                                                                             \
-    do {                                                                                                  \
-        unsigned char *base_ = lds + (BUF) * FK_BUF + s_lds;                                              \
-        *(uint4 *)(base_) = k0;                                                                           \
-        *(uint4 *)(base_ + 2 * FK_REGION) = k1;                                                           \
-        *(uint4 *)(base_ + 4 * FK_REGION) = k2;                                                           \
-        *(uint4 *)(base_ + 6 * FK_REGION) = k3;                                                           \
-        *(uint4 *)(base_ + 8 * FK_REGION) = k4;                                                           \
-        *(uint4 *)(base_ + 10 * FK_REGION) = k5;                                                          \
-        if ((CH) == 0 && t < 128) nxl[((KT) & 1) * 128 + t] = nxr;                                        \
-    } while (0)
-#define FK_QSWAP()                                                                                        \
-    do {                                                                                                  \
-        _Pragma("unroll") for (int s_ = 0; s_ < 2; s_++)                                                  \
-            _Pragma("unroll") for (int p_ = 0; p_ < 3; p_++) qc[s_][p_] = __builtin_bit_cast(bf16x8, qn[s_][p_]); \
-    } while (0)
-
-    f32x16 acc[4];
+    // ---- DMA pieces of a unit (64 keys per half x 64 channels): piece z = wave * 4 + i -> (half z >> 4, plane (z >> 3) & 1, octet z & 7),
+    // 64 rows of 16 B = 1 KB, one global_load_lds_dwordx4 per wave; wave 0 adds the tile's aux (1 KB) on the tile's last chunk
+    auto issue = [&](int u, int stage) {
+        const int kt = u / nch, ch = u - kt * nch;
 #pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
-    static_assert(K == 20 || K == 32 || K == 64, "instantiated list lengths");
-#ifdef FK_COUNT
-    int trips = 0;
-#endif
-    TopK<K> top;
-    top.init();
-    float thr = -INFINITY, thrp = -INFINITY;
-
-    int kt = kt0, ch = 0;                    // current unit
-    int ktn = kt0, chn = 0;                  // next unit to fetch
-    FK_LOAD(kt0, 0);
-    FK_STORE(0, kt0, 0);
-    FK_QSWAP();
-    chn = 1;
-    if (chn == nch) { chn = 0; ktn = kt0 + 1; }
-    __syncthreads();
-
-#pragma unroll 1
-    for (int u = 0; u < U; u++) {
-        const bool more = u + 1 < U;
-        if (more) FK_LOAD(ktn, chn);
-        const unsigned char *base = lds + (u & 1) * FK_BUF + a_off;
-        // six plane steps (k-step s, key plane pa = l, m, h); the fragments of step i + 1 are read while the
-        // products of step i run, and no further ahead (sched_barrier): the register budget is what matters here
-        bf16x8 A[2][4];
-#pragma unroll
-        for (int a = 0; a < 4; a++) A[0][a] = *(const bf16x8 *)(base + (2 * 2) * FK_REGION + a * 512);
-#pragma unroll
-        for (int st = 0; st < 6; st++) {
-            const int s = st / 3, pa = 2 - st % 3;
-            if (st < 5) {
-                const int sn = (st + 1) / 3, pn = 2 - (st + 1) % 3;
-#pragma unroll
-                for (int a = 0; a < 4; a++)
-                    A[(st + 1) & 1][a] = *(const bf16x8 *)(base + ((sn * 3 + pn) * 2) * FK_REGION + a * 512);
-            }
-#pragma unroll
-            for (int pb = 2; pb >= 0; pb--) {
-                if (pa + pb > 2) continue;
-#pragma unroll
-                for (int a = 0; a < 4; a++)
-                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[st & 1][a], qc[s][pb], acc[a], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < 4; i++) {
+            const int z = wave * 4 + i, half = z >> 4, p = (z >> 3) & 1, o = z & 7;
+            const uint4 *src = pb + ((size_t)(p * noct + ch * 8 + o)) * Np + kt * 128 + half * 64 + lane;
+            __builtin_amdgcn_global_load_lds((fk_gbl_ptr_t)src, (fk_lds_ptr_t)(lds + stage * FK_STAGE + z * 1024), 16, 0, 0);
         }
-        if (more) FK_STORE((u + 1) & 1, ktn, chn);
+        if (ch == nch - 1 && wave == 0)
+            __builtin_amdgcn_global_load_lds((fk_gbl_ptr_t)((const uint4 *)(ab + (size_t)kt * FK_AUXT) + lane),
+                                             (fk_lds_ptr_t)(lds + stage * FK_STAGE + 32768), 16, 0, 0);
+    };
+    // query fragments of channel chunk ch: k-step s, lane (col, hf) -> octet 2 s + hf of row q, planes h and m
+    fk_f16x8 Bh[NBF][4], Bm[NBF][4];
+    auto load_b = [&](int ch, int set) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const size_t cell = (size_t)(ch * 8 + 2 * s + hf) * Np + q;
+            Bh[set][s] = __builtin_bit_cast(fk_f16x8, pb[cell]);
+            Bm[set][s] = __builtin_bit_cast(fk_f16x8, pb[(size_t)noct * Np + cell]);
+        }
+    };
+    if constexpr (!STREAM) {
+#pragma unroll
+        for (int c_ = 0; c_ < NCH_RES; c_++)
+            if (c_ < nch) load_b(c_, c_);
+        // a use of every fragment register HERE: the compiler waits for the loads in front of it.  Left to their first use inside the
+        // unit loop, that wait (s_waitcnt vmcnt(0), every iteration) also waited for the DMA pieces issued a few instructions earlier --
+        // every unit then cost an L2 round trip (1.7 us per unit instead of 0.5: tools/fk_timeline.py)
+#pragma unroll
+        for (int c_ = 0; c_ < NCH_RES; c_++)
+#pragma unroll
+            for (int s_ = 0; s_ < 4; s_++) asm volatile("" :: "v"(Bh[c_][s_]), "v"(Bm[c_][s_]));
+    }
+    const int a_off = kh * 16384 + hf * 1024 + col * 16;      // + plane * 8192 + s * 2048 + a * 512
 
-#if FK_PROBE == 2
-        if (false) {
-#else
-        if (ch == nch - 1) {
-#endif
-            // ---- epilogue of key tile kt: pd = (-xx_j - (-2 inner_ij)) - xx_i, candidates -> top-K
-            const float *nx = nxl + (kt & 1) * 128 + 4 * (lane >> 5);
+    float thr = -INFINITY;
+    auto run_sweep = [&](auto sweep_c) {
+        constexpr int sweep = decltype(sweep_c)::value;
+        float mr[2][16];
 #pragma unroll
-            for (int a = 0; a < 4; a++) {
-                unsigned mask = 0;
+        for (int a = 0; a < 2; a++)
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const float4 n4 = *(const float4 *)(nx + a * 32 + g * 8);
-                    const float nv[4] = {n4.x, n4.y, n4.z, n4.w};
+            for (int r = 0; r < 16; r++) mr[a][r] = -INFINITY;
+        f32x16 acc[2];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const int r = g * 4 + e;
-                        const float pd = fmaf(2.0f, acc[a][r], nv[e]) - xxq;
-                        scr[r * 64 + lane] = pd;
-                        mask |= (pd > thr && pd >= thrp) ? (1u << r) : 0u;
-                        acc[a][r] = 0.f;
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
+        __syncthreads();                                       // the previous sweep's last stage reads are done (and the setup above)
+        dump[16 * 64 + lane] = 0.f;
+        // Double buffer: unit u + 1's pieces are issued at the top of unit u (right behind the barrier that retires their stage) and
+        // waited for, with everything else this wave has in flight, at the top of unit u + 1.  (A third stage with counted waits,
+        // conv_f16.hip's scheme, measured no faster and needs the 34 KB of the dump area: LABLOG R6.3.)
+        if constexpr (STREAM) load_b(0, 0);
+        issue(0, 0);
+        int kt = 0, ch = 0, stage = 0;
+        // one unit; PAR = u & 1 at compile time when the query fragments stream (their two register sets alternate: with a runtime
+        // parity the compiler made the sets an indexed private array -- scratch)
+        auto unit = [&](int u, auto par_c) {
+            constexpr int PAR = decltype(par_c)::value;
+            const int chn = ch + 1 == nch ? 0 : ch + 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                      // ... everybody's; the other stage was last read in unit u - 1
+            if constexpr (STREAM) {
+                if (u + 1 < U) load_b(chn, PAR ^ 1);
+            }
+            if (u + 1 < U) issue(u + 1, stage ^ 1);
+            const unsigned char *base = lds + stage * FK_STAGE + a_off;
+            const int set = STREAM ? PAR : ch;
+            // the fragments of k-step s + 1 are read while the products of step s run, and no further ahead (sched_barrier): the
+            // register budget decides whether two sets of query fragments fit beside them
+            auto products = [&](const fk_f16x8 (&bh)[4], const fk_f16x8 (&bm)[4]) {
+                fk_f16x8 Ah[2][2], Am[2][2];
+#pragma unroll
+                for (int a = 0; a < 2; a++) {
+                    Ah[0][a] = *(const fk_f16x8 *)(base + a * 512);
+                    if (sweep == 1) Am[0][a] = *(const fk_f16x8 *)(base + 8192 + a * 512);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    if (s < 3) {
+#pragma unroll
+                        for (int a = 0; a < 2; a++) {
+                            Ah[(s + 1) & 1][a] = *(const fk_f16x8 *)(base + (s + 1) * 2048 + a * 512);
+                            if (sweep == 1) Am[(s + 1) & 1][a] = *(const fk_f16x8 *)(base + 8192 + (s + 1) * 2048 + a * 512);
+                        }
                     }
+#pragma unroll
+                    for (int a = 0; a < 2; a++) {          // smallest first: m h', h m', h h'  (sweep 0: h h' alone, see margin)
+                        if (sweep == 1) {
+                            acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Am[s & 1][a], bh[s], acc[a], 0, 0, 0);
+                            acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s & 1][a], bm[s], acc[a], 0, 0, 0);
+                        }
+                        acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[s & 1][a], bh[s], acc[a], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                // one candidate per trip, the NEXT one's LDS read issued before the network runs.  A lane that
-                // has run out of candidates reads row 16 of its scratch column, which holds -inf (a no-op
-                // insertion): no per-lane boolean is carried around the loop -- a divergent i1 phi here made the
-                // compiler add a flow block and ~120 register copies per trip.
-                unsigned bp = min((unsigned)(__ffs((int)mask) - 1), 16u);
-                mask &= mask - 1;
-                float cv = scr[bp * 64 + lane];
-                const int rbase = kt * 128 + a * 32 + 4 * (lane >> 5);
-                // hand-rotated (if + do-while): ballot is convergent, so the compiler may not rotate a while
-                // loop itself, and the unrotated form carries every TopK register through two extra blocks
-#if FK_PROBE == 1
-                if (false) {
-#else
-                if (__builtin_amdgcn_ballot_w64(bp < 16u) != 0) {
-#endif
+            };
+            if constexpr (STREAM) products(Bh[PAR], Bm[PAR]);
+            else if (NBF == 1 || set == 0) products(Bh[0], Bm[0]);
+            else products(Bh[NBF - 1], Bm[NBF - 1]);
+
+            if (ch == nch - 1 && !(FK_ABL & 8)) {
+                // ---- epilogue of key tile kt: p0 = -xx_j + 2 <x_i, x_j> for this lane's 2 x 16 candidates (the reference's pd = p0 - xx_i is
+                // formed for the collected candidates only: x -> fl(x - xx_i) is monotone, so selecting on p0 selects the same set)
+                // The tile's aux arrived as a DMA piece; read with compiler-visible loads, the compiler orders them behind EVERY LDS DMA it has
+                // seen -- s_waitcnt vmcnt(0) right behind the pieces just issued for unit u + 1, an L2 round trip per tile.  The piece of
+                // this unit has landed (the wait and the barrier at the top): inline asm reads, waited for by hand.
+                const unsigned aux_addr = fk_lds_off(lds + stage * FK_STAGE + 32768);
+                float fsc;
+                f32x4 nq[2][4];
+                {
+                    const unsigned arow = aux_addr + (unsigned)(kh * 64 + 4 * hf) * 4u;
+                    // ONE statement, reads and wait together: between separate asm statements the compiler may move a register whose
+                    // load it cannot know is still in flight
+                    asm volatile("ds_read_b32 %0, %9 offset:512\n\t"
+                                 "ds_read_b128 %1, %10\n\tds_read_b128 %2, %10 offset:32\n\tds_read_b128 %3, %10 offset:64\n\tds_read_b128 %4, %10 offset:96\n\t"
+                                 "ds_read_b128 %5, %10 offset:128\n\tds_read_b128 %6, %10 offset:160\n\tds_read_b128 %7, %10 offset:192\n\tds_read_b128 %8, %10 offset:224\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(fsc), "=&v"(nq[0][0]), "=&v"(nq[0][1]), "=&v"(nq[0][2]), "=&v"(nq[0][3]), "=&v"(nq[1][0]), "=&v"(nq[1][1]),
+                                   "=&v"(nq[1][2]), "=&v"(nq[1][3])
+                                 : "v"(aux_addr), "v"(arow)
+                                 : "memory");
+                }
+                const int krow = kh * 64 + 4 * hf;                       // row of the 128-key tile: + 32 a + (r & 3) + 8 (r >> 2)
+                const float fkt = sq2 * fsc;                             // 2 x 2^-T_i x 2^-T_j: exact
+#pragma unroll
+                for (int a = 0; a < 2; a++) {
+                    float pd[16];
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const f32x4 n4 = nq[a][g];
+                        pd[4 * g] = fmaf(acc[a][4 * g], fkt, n4[0]);         pd[4 * g + 1] = fmaf(acc[a][4 * g + 1], fkt, n4[1]);
+                        pd[4 * g + 2] = fmaf(acc[a][4 * g + 2], fkt, n4[2]); pd[4 * g + 3] = fmaf(acc[a][4 * g + 3], fkt, n4[3]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
+                    if (sweep == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) mr[a][r] = fmaxf(mr[a][r], pd[r]);
+                    } else {
+                        unsigned m = 0;
+#pragma unroll
+                        for (int r = 0; r < 16; r++) m |= pd[r] >= thr ? (1u << r) : 0u;
+                        if (!(FK_ABL & 16) && __builtin_amdgcn_ballot_w64(m != 0) != 0) {
+#pragma unroll
+                            for (int r = 0; r < 16; r++) dump[r * 64 + lane] = pd[r];
+                            const int cand0 = kt * 128 + krow + 32 * a;
 #pragma unroll 1
-                    do {
-#ifdef FK_COUNT
-                        trips++;
-#endif
-                        const unsigned bn = min((unsigned)(__ffs((int)mask) - 1), 16u);
-                        mask &= mask - 1;
-                        const float cn = scr[bn * 64 + lane];
-                        if constexpr (K == 20) topk20_insert(top, cv, rbase + (int)((bp & 3) + 8 * (bp >> 2)));   // asm network (common.h)
-                        else top.insert(cv, rbase + (int)((bp & 3) + 8 * (bp >> 2)));
-                        bp = bn;
-                        cv = cn;
-                    } while (__builtin_amdgcn_ballot_w64(bp < 16u) != 0);
+                            do {
+                                const bool has = m != 0;
+                                const int e = has ? __builtin_ctz(m) : 16;
+                                m &= m - 1;
+                                float v = dump[e * 64 + lane] - xxq;                 // the reference's pd
+                                // (LDS atomic and list writes as inline asm for the reason the aux reads are: the compiler puts s_waitcnt vmcnt(0)
+                                // in front of any LDS access that may alias a DMA destination)
+                                int slot;
+                                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(slot) : "v"(fk_lds_off(qcnt + ql)), "v"(has ? 1 : 0) : "memory");
+                                const unsigned cand = (unsigned)(cand0 + (e & 3) + 8 * (e >> 2));
+                                if (has && slot < CAP) {           // else: the count says so (rank phase)
+                                    if constexpr (LL) {
+                                        asm volatile("ds_write_b32 %0, %1" :: "v"(fk_lds_off(lv + ql * FK_LVS + slot)), "v"(v) : "memory");
+                                        asm volatile("ds_write_b16 %0, %1" :: "v"(fk_lds_off(li + ql * FK_LIS + slot)), "v"(cand) : "memory");
+                                    } else {
+                                        const unsigned bits = __float_as_uint(v + 0.0f);                         // -0 -> +0
+                                        const unsigned sk = bits ^ ((unsigned)((int)bits >> 31) | 0x80000000u);   // unsigned order == float order
+                                        lists[((size_t)b * Np + q) * CAP + slot] = ((fk_u64)sk << 32) | (unsigned)(~cand);
+                                    }
+                                }
+                            } while (__builtin_amdgcn_ballot_w64(m != 0) != 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);         // one row block's 16 values at a time
                 }
-                // a candidate has to beat this lane's k-th best AND (at least tie) the partner lane's, which
-                // ranks the other 64 keys of each tile for the same query.  (The k-th best of the pair's UNION,
-                // max_i min(a[i-1], b[K-1-i]), cuts the insertions by a quarter but costs more than it saves.)
-                thr = top.worst();
-                thrp = __shfl_xor(thr, 32, 64);
+            }
+            ch++;
+            if (ch == nch) { ch = 0; kt++; }
+            stage ^= 1;
+        };
+        if constexpr (STREAM) {
+#pragma unroll 1
+            for (int u = 0; u < U; u += 2) {
+                unit(u, std::integral_constant<int, 0>{});
+                if (u + 1 < U) unit(u + 1, std::integral_constant<int, 1>{});
+            }
+        } else {
+#pragma unroll 1
+            for (int u = 0; u < U; u++) unit(u, std::integral_constant<int, 0>{});
+        }
+        if (sweep == 0) {
+            FKM(2)
+            // ---- the bound: the KC-th largest of the 4 T values the query's four lanes offer (each its T largest group maxima: distinct
+            // candidates, so at least KC candidates reach it)
+            FkTop<T> top;
+            top.init();
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) top.insert(mr[a][r]);
+            __syncthreads();                                   // every wave is past its last stage read
+            float *mine = tv + ql * (4 * T + 1) + (kh * 2 + hf) * T;
+#pragma unroll
+            for (int i = 0; i < T; i++) mine[i] = top.v[i];
+            __syncthreads();
+            int cnt[T];
+#pragma unroll
+            for (int i = 0; i < T; i++) cnt[i] = 0;
+            for (int f = 0; f < 4 * T; f++) {
+                const float v = tv[ql * (4 * T + 1) + f];
+#pragma unroll
+                for (int i = 0; i < T; i++) cnt[i] += v > top.v[i] ? 1 : 0;
+            }
+            // the smallest own value with fewer than KC values above it (own values descend, so the counts ascend); the query's bound is
+            // the smallest such offer of its four lanes
+            float offer = INFINITY;
+#pragma unroll
+            for (int i = 0; i < T; i++) offer = cnt[i] < KC ? top.v[i] : offer;
+            __syncthreads();
+            tv[ql * 5 + kh * 2 + hf] = offer;
+            __syncthreads();
+            const float *t4 = tv + ql * 5;
+            thr = fmaxf(fminf(fminf(t4[0], t4[1]), fminf(t4[2], t4[3])) - margin, -3.0e38f);     // -inf (fewer than KC real candidates): every finite one
+            if (FK_ABL & 2) thr = INFINITY;
+        }
+    };
+    FKM(1)
+    run_sweep(std::integral_constant<int, 0>{});
+    FKM(3)
+    if (!(FK_ABL & 4)) run_sweep(std::integral_constant<int, 1>{});
+    FKM(4)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the asm LDS writes of the collection are not the compiler's to wait for)
+    __syncthreads();
+
+    // ---- rank: four threads per query, thread part ranks keys part, part + 4, ...; a key of rank r < k gives idx[q][r]
+    if (FK_ABL & 32) return;
+    if constexpr (LL) {
+        const int rq = t >> 2, part = t & 3, gq = q0 + rq;
+        const int M = qcnt[rq];
+        if (gq < N && M <= CAP && !(FK_ABL & 1)) {
+            const float *V = lv + rq * FK_LVS;
+            const unsigned short *I = li + rq * FK_LIS;
+            int64_t *dst = idx_out + ((size_t)b * N + gq) * k;
+            // own keys part, part + 4, ... in registers (<= 16), ONE pass over the list; no branches: a compare written with && / ||
+            // became an exec-mask region and a wait per element here (52 us of a 112 us kernel)
+            constexpr int OWN = FK_LDS_CAP / 4;
+            float ov[OWN];
+            int oi[OWN], rank[OWN];
+#pragma unroll
+            for (int j = 0; j < OWN; j++) {
+                const int o = part + 4 * j;
+                ov[j] = o < M ? V[o] : INFINITY;
+                oi[j] = o < M ? (int)I[o] : -1;
+                rank[j] = 0;
+            }
+#pragma unroll 4
+            for (int f = 0; f < M; f++) {
+                const float fv = V[f];
+                const int fi = I[f];
+#pragma unroll
+                for (int j = 0; j < OWN; j++) rank[j] += (int)(fv > ov[j]) | ((int)(fv == ov[j]) & (int)(fi < oi[j]));
+            }
+#pragma unroll
+            for (int j = 0; j < OWN; j++)
+                if (part + 4 * j < M && rank[j] < k) dst[rank[j]] = oi[j];
+        } else if (gq < N && part == 0) {
+            flags[1 + atomicAdd(&flags[129], 1)] = rq;          // overflowed: the exact selection below
+        }
+    } else {
+        // lists in the workspace: staged through the (idle) key stages, 32 queries at a time, then ranked from LDS
+        fk_u64 *Ls = (fk_u64 *)lds;
+        static_assert(32 * CAP * 8 <= FK_NSTAGE * FK_STAGE, "a batch of lists fits the stages");
+        for (int bq = 0; bq < 128; bq += 32) {
+            __syncthreads();
+            for (int e = t; e < 32 * CAP; e += 512) {
+                const int rq = bq + e / CAP, o = e % CAP;
+                if (o < min(qcnt[rq], CAP))
+                    Ls[e] = __hip_atomic_load(&lists[((size_t)b * Np + q0 + rq) * CAP + o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            const int rq = bq + (t >> 4), part = t & 15, gq = q0 + rq;
+            const int M = qcnt[rq];
+            if (gq < N && M <= CAP && !(FK_ABL & 1)) {
+                const fk_u64 *L = Ls + (t >> 4) * CAP;
+                int64_t *dst = idx_out + ((size_t)b * N + gq) * k;
+                constexpr int OWN = CAP / 16;
+                fk_u64 own[OWN];
+                int rank[OWN];
+#pragma unroll
+                for (int j = 0; j < OWN; j++) {
+                    const int o = part + 16 * j;
+                    own[j] = o < M ? L[o] : ~0ull;
+                    rank[j] = 0;
+                }
+#pragma unroll 4
+                for (int f = 0; f < M; f++) {
+                    const fk_u64 kf = L[f];
+#pragma unroll
+                    for (int j = 0; j < OWN; j++) rank[j] += (int)(kf > own[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < OWN; j++)
+                    if (part + 16 * j < M && rank[j] < k) dst[rank[j]] = (int64_t)(unsigned)(~(unsigned)own[j]);
+            } else if (gq < N && part == 0) {
+                flags[1 + atomicAdd(&flags[129], 1)] = rq;
             }
         }
-        FK_QSWAP();
-        __syncthreads();
-        ch++;
-        if (ch == nch) { ch = 0; kt++; }
-        chn++;
-        if (chn == nch) { chn = 0; ktn++; }
-    }
-#undef FK_LOAD
-#undef FK_STORE
-#undef FK_QSWAP
-
-#ifdef FK_COUNT
-    if (lane == 0) atomicAdd(&fk_trip_counter, (unsigned long long)trips);
-#endif
-    // ---- merge the two half-lists of each lane pair (the key buffers are free after the last barrier)
-    float *mv = (float *)lds + wave * (2 * K * 32);
-    int *mi = (int *)mv + K * 32;
-    if (lane >= 32) {
-#pragma unroll
-        for (int i = 0; i < K; i++) { mv[i * 32 + lane - 32] = top.v[i]; mi[i * 32 + lane - 32] = top.id[i]; }
     }
     __syncthreads();
-    if (lane < 32) {
-#pragma unroll 1
-        for (int i = 0; i < K; i++) fk_insert_lex<K>(top, mv[i * 32 + lane], mi[i * 32 + lane]);
-        if (qrow < N) {
-            if (gridDim.z == 1) {
-                int64_t *dst = idx_out + ((size_t)b * N + qrow) * k;
-#pragma unroll
-                for (int i = 0; i < K; i++)
-                    if (i < k) dst[i] = top.id[i];
-            } else {
-                const size_t o = (((size_t)b * N + qrow) * gridDim.z + blockIdx.z) * K;
-#pragma unroll
-                for (int i = 0; i < K; i++) { part_v[o + i] = top.v[i]; part_i[o + i] = top.id[i]; }
+    FKM(5)
+    const int nfl = flags[129];
+    if (nfl == 0) return;
+    // ---- exact fallback: a wave per overflowed query, its Np ranking values in the wave's eighth of the (idle) stages when they fit
+    // there (Np <= 2048), else wave 0 alone with all of it
+    const bool wide = Np > 2048;
+    if (wide && wave != 0) return;
+    float *vals = (float *)lds + (wide ? 0 : wave * 2048);
+    const float *xb = x + (size_t)b * C * N;
+    for (int f = wide ? 0 : wave; f < nfl; f += wide ? 1 : 8) {
+        const int gq = q0 + flags[1 + f];
+        const float xxg = -ab[(gq >> 7) * FK_AUXT + (gq & 127)];
+        for (int j0 = 0; j0 < Np; j0 += 64) {
+            const int j = j0 + lane;
+            float dot = 0.f;
+            if (j < N)
+                for (int c = 0; c < C; c++) dot = fmaf(xb[(size_t)c * N + gq], xb[(size_t)c * N + j], dot);
+            vals[j] = j < N ? fmaf(2.0f, dot, ab[(j >> 7) * FK_AUXT + (j & 127)]) - xxg : -INFINITY;
+        }
+        int64_t *dst = idx_out + ((size_t)b * N + gq) * k;
+        for (int o = 0; o < k; o++) {
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+            for (int j = lane; j < Np; j += 64) {
+                const float v = vals[j];
+                if (v > bv) { bv = v; bi = j; }                 // ascending j: the first of equal values stays
             }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                const float ov = __shfl_xor(bv, d, 64);
+                const int oi = __shfl_xor(bi, d, 64);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (lane == 0) { dst[o] = bi; vals[bi] = -INFINITY; }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
-}
-
-// idx[q][0..k) = the k best of the parts' sorted lists (value descending, equal values: lower index first -- the order inside a list
-// and what one list over all keys would hold); one thread per query, <= 4 list heads
-template <int K>
-__global__ __launch_bounds__(256) void featknn_merge_kernel(const float *__restrict__ part_v, const int *__restrict__ part_i, long nq, int parts,
-                                                            int k, int64_t *__restrict__ idx_out)
-{
-    const long q = (long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= nq) return;
-    const float *v = part_v + (size_t)q * parts * K;
-    const int *id = part_i + (size_t)q * parts * K;
-    int head[4] = {0, 0, 0, 0};
-    for (int o = 0; o < k; o++) {
-        int best = -1;
-        float bv = 0.f;
-        int bi = 0;
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            if (p >= parts || head[p] >= K) continue;
-            const float pv = v[p * K + head[p]];
-            const int pi = id[p * K + head[p]];
-            if (best < 0 || pv > bv || (pv == bv && pi < bi)) { best = p; bv = pv; bi = pi; }
-        }
-#pragma unroll
-        for (int p = 0; p < 4; p++) head[p] += (p == best);
-        idx_out[(size_t)q * k + o] = bi;
-    }
-}
-
-// key-range parts: enough workgroups for two per CU (512), at most 4, at most one per key tile
-// (measured at k = 20, profiles/round5_featknn_bench.txt: B 32, N 1024: C 64 128 -> 134 us (the per-part epilogues cost more than the
-// overlap returns: no split), C 128 168 -> 163, C 256 244 -> 220; B 8, N 1024, k 40: 477 -> 381)
-static inline int fk_parts(int B, int Cp, int Np)
-{
-    const long wgs = (long)B * (Np / 128);
-    if (Cp < 128 && wgs > 128) return 1;
-    int p = wgs >= 512 ? 1 : (int)((512 + wgs - 1) / wgs);
-    if (p > 4) p = 4;
-    if (p > Np / 128) p = Np / 128;
-    return p < 1 ? 1 : p;
 }
 
 extern "C" size_t l3d_knn_feature_workspace_bytes(int B, int C, int N)
 {
     if (B <= 0 || C <= 0 || N <= 0) return 0;
-    const size_t Np = (size_t)l3d_divup(N, 128) * 128, Cp = (size_t)l3d_divup(C, 32) * 32;
-    const int parts = fk_parts(B, (int)Cp, (int)Np);
-    // split planes | -|x|^2 | (parts > 1) the parts' sorted lists, values and indices, at the longest list length (64)
-    return (size_t)B * Cp * Np * 6 + (size_t)B * Np * 4 + (parts > 1 ? (size_t)B * N * parts * 64 * 8 : 0);
+    const size_t Np = (size_t)l3d_divup(N, 128) * 128, Cp = (size_t)l3d_divup(C, 64) * 64;
+    // fp16 planes (h | m) | aux (-|x|^2, 2^-T) | the queries' candidate lists at the longest capacity (k > 20 only; k <= 20 keeps them in LDS)
+    return (size_t)B * Cp * Np * 4 + (size_t)B * Np * 8 + (size_t)B * Np * fk_cap(64) * 8;
+}
+
+template <int KC, int NCH_RES>
+static int fk_launch(const uint4 *planes, const float *aux, const float *x, int B, int C, int Cp, int N, int Np, int k, fk_u64 *lists,
+                     int64_t *idx, hipStream_t st)
+{
+    const size_t nlds = KC <= 20 ? FK_LDS_LL : FK_LIST_OFF;
+    static const bool ok = hipFuncSetAttribute((const void *)featknn_kernel<KC, NCH_RES>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)nlds) == hipSuccess;
+    if (!ok) return L3D_ERR_LAUNCH;
+    hipLaunchKernelGGL((featknn_kernel<KC, NCH_RES>), dim3(Np / FK_QT, B), dim3(512), nlds, st, planes, aux, x, C, Cp, N, Np, k, lists, idx);
+    return l3d_check_launch();
 }
 
 extern "C" int l3d_knn_feature(const float *x, int B, int C, int N, int k, void *workspace, int64_t *idx,
@@ -348,27 +564,21 @@ extern "C" int l3d_knn_feature(const float *x, int B, int C, int N, int k, void 
 {
     L3D_REQUIRE(x && workspace && idx && B > 0 && C > 0 && N > 0 && k > 0);
     if (k > N) return L3D_ERR_INVALID_ARG;
-    if (k > 64 || B > 65535 || (((size_t)workspace) & 15)) return L3D_ERR_UNSUPPORTED;
-    const int Np = l3d_divup(N, 128) * 128, Cp = l3d_divup(C, 32) * 32;      // any C: padded with zero channels
-    uint4 *xs = (uint4 *)workspace;
-    float *nxx = (float *)((unsigned char *)workspace + (size_t)B * Cp * Np * 6);
-    const int parts = fk_parts(B, Cp, Np);
-    float *pv = nxx + (size_t)B * Np;
+    const int Np = l3d_divup(N, 128) * 128, Cp = l3d_divup(C, 64) * 64;          // any C: padded with zero channels
+    if (k > 64 || B > 65535 || Np > FK_MAXNP || (((size_t)workspace) & 15)) return L3D_ERR_UNSUPPORTED;
+    unsigned char *ws = (unsigned char *)workspace;
+    uint4 *planes = (uint4 *)ws;
+    float *aux = (float *)(ws + (size_t)B * Cp * Np * 4);
+    fk_u64 *lists = (fk_u64 *)(ws + (size_t)B * Cp * Np * 4 + (size_t)B * Np * 8);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(featknn_split_kernel, dim3(l3d_divup(Np, 256), B), dim3(256), 0, st, x, C, Cp, N, Np, xs, nxx);
-    dim3 grid(Np / 128, B, parts), block(256);
-    const long nq = (long)B * N;
-    const dim3 mgrid((unsigned)((nq + 255) / 256));
-    // k <= 20: the asm insertion network; 20 < k <= 64: the generic one (list lengths 32 / 64)
-#define FK_GO(KK)                                                                                                                       \
-    do {                                                                                                                                \
-        int *pi = (int *)(pv + (size_t)nq * parts * KK);                                                                                \
-        hipLaunchKernelGGL(featknn_kernel<KK>, grid, block, FK_LDS, st, (const uint4 *)xs, (const float *)nxx, Cp, N, Np, k, idx, pv, pi); \
-        if (parts > 1) hipLaunchKernelGGL(featknn_merge_kernel<KK>, mgrid, dim3(256), 0, st, (const float *)pv, (const int *)pi, nq, parts, k, idx); \
-    } while (0)
-    if (k <= 20) FK_GO(20);
-    else if (k <= 32) FK_GO(32);
-    else FK_GO(64);
+    hipLaunchKernelGGL(featknn_split_kernel, dim3(Np / 128, B), dim3(512), 0, st, x, C, Cp, N, Np, planes, aux);
+    const int nch = Cp / 64;
+#define FK_GO(KK)                                                                                                        \
+    (nch == 1 ? fk_launch<KK, 1>(planes, aux, x, B, C, Cp, N, Np, k, lists, idx, st)                                     \
+              : (nch == 2 ? fk_launch<KK, 2>(planes, aux, x, B, C, Cp, N, Np, k, lists, idx, st)                         \
+                          : fk_launch<KK, 0>(planes, aux, x, B, C, Cp, N, Np, k, lists, idx, st)))
+    // list-length classes: k <= 20 (the DGCNN / PRNet graphs), <= 32, <= 64
+    const int rc = k <= 20 ? FK_GO(20) : (k <= 32 ? FK_GO(32) : FK_GO(64));
 #undef FK_GO
-    return l3d_check_launch();
+    return rc;
 }
