@@ -336,19 +336,30 @@ __global__ __launch_bounds__(512) void featknn_kernel(const uint4 *__restrict__ 
 #pragma unroll
                         for (int r = 0; r < 16; r++) m |= pd[r] >= thr ? (1u << r) : 0u;
                         if (!(FK_ABL & 16) && __builtin_amdgcn_ballot_w64(m != 0) != 0) {
-#pragma unroll
-                            for (int r = 0; r < 16; r++) dump[r * 64 + lane] = pd[r];
+                            // Every LDS access of the collection as inline asm, for the reason the aux reads are: the compiler puts
+                            // s_waitcnt vmcnt(0) in front of any LDS access that may alias a DMA destination -- here, behind the pieces just
+                            // issued for the next unit.  The 16 values go to this wave's dump rows (a lane's column), a hit's value comes
+                            // back by its register number; that read and the slot atomic are in flight together.
+                            const unsigned daddr = fk_lds_off(dump + lane);
+                            asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:256\n\tds_write_b32 %0, %3 offset:512\n\tds_write_b32 %0, %4 offset:768\n\t"
+                                         "ds_write_b32 %0, %5 offset:1024\n\tds_write_b32 %0, %6 offset:1280\n\tds_write_b32 %0, %7 offset:1536\n\t"
+                                         "ds_write_b32 %0, %8 offset:1792\n\tds_write_b32 %0, %9 offset:2048\n\tds_write_b32 %0, %10 offset:2304\n\t"
+                                         "ds_write_b32 %0, %11 offset:2560\n\tds_write_b32 %0, %12 offset:2816\n\tds_write_b32 %0, %13 offset:3072\n\t"
+                                         "ds_write_b32 %0, %14 offset:3328\n\tds_write_b32 %0, %15 offset:3584\n\tds_write_b32 %0, %16 offset:3840"
+                                         :: "v"(daddr), "v"(pd[0]), "v"(pd[1]), "v"(pd[2]), "v"(pd[3]), "v"(pd[4]), "v"(pd[5]), "v"(pd[6]), "v"(pd[7]),
+                                            "v"(pd[8]), "v"(pd[9]), "v"(pd[10]), "v"(pd[11]), "v"(pd[12]), "v"(pd[13]), "v"(pd[14]), "v"(pd[15])
+                                         : "memory");
                             const int cand0 = kt * 128 + krow + 32 * a;
 #pragma unroll 1
                             do {
                                 const bool has = m != 0;
                                 const int e = has ? __builtin_ctz(m) : 16;
                                 m &= m - 1;
-                                float v = dump[e * 64 + lane] - xxq;                 // the reference's pd
-                                // (LDS atomic and list writes as inline asm for the reason the aux reads are: the compiler puts s_waitcnt vmcnt(0)
-                                // in front of any LDS access that may alias a DMA destination)
+                                float v;
                                 int slot;
-                                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(slot) : "v"(fk_lds_off(qcnt + ql)), "v"(has ? 1 : 0) : "memory");
+                                asm volatile("ds_read_b32 %0, %2\n\tds_add_rtn_u32 %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
+                                             : "=&v"(v), "=&v"(slot) : "v"(daddr + (unsigned)e * 256u), "v"(fk_lds_off(qcnt + ql)), "v"(has ? 1 : 0) : "memory");
+                                v = v - xxq;                                           // the reference's pd
                                 const unsigned cand = (unsigned)(cand0 + (e & 3) + 8 * (e >> 2));
                                 if (has && slot < CAP) {           // else: the count says so (rank phase)
                                     if constexpr (LL) {
@@ -429,13 +440,15 @@ __global__ __launch_bounds__(512) void featknn_kernel(const uint4 *__restrict__ 
     if constexpr (LL) {
         const int rq = t >> 2, part = t & 3, gq = q0 + rq;
         const int M = qcnt[rq];
-        if (gq < N && M <= CAP && !(FK_ABL & 1)) {
+        const bool ranked = gq < N && M <= CAP && !(FK_ABL & 1);
+        int *outl = (int *)lds;                                 // [128][k] ranks -> indices, in the idle stages; written out coalesced below
+        // own keys part, part + 4, ... in registers, ONE pass over the list; no branches: a compare written with && / || became an
+        // exec-mask region and a wait per element here (52 us of a 112 us kernel).  OWN = 8 covers lists of up to 32 keys (the mean
+        // is 24, the 99th percentile 34); a wave with a longer list among its 16 queries takes the 16-key form.
+        auto rank_lists = [&](auto own_c) {
+            constexpr int OWN = decltype(own_c)::value;
             const float *V = lv + rq * FK_LVS;
             const unsigned short *I = li + rq * FK_LIS;
-            int64_t *dst = idx_out + ((size_t)b * N + gq) * k;
-            // own keys part, part + 4, ... in registers (<= 16), ONE pass over the list; no branches: a compare written with && / ||
-            // became an exec-mask region and a wait per element here (52 us of a 112 us kernel)
-            constexpr int OWN = FK_LDS_CAP / 4;
             float ov[OWN];
             int oi[OWN], rank[OWN];
 #pragma unroll
@@ -454,9 +467,21 @@ __global__ __launch_bounds__(512) void featknn_kernel(const uint4 *__restrict__ 
             }
 #pragma unroll
             for (int j = 0; j < OWN; j++)
-                if (part + 4 * j < M && rank[j] < k) dst[rank[j]] = oi[j];
-        } else if (gq < N && part == 0) {
-            flags[1 + atomicAdd(&flags[129], 1)] = rq;          // overflowed: the exact selection below
+                if (part + 4 * j < M && rank[j] < k) outl[rq * k + rank[j]] = oi[j];
+        };
+        if (__builtin_amdgcn_ballot_w64(ranked && M > 32) != 0) {
+            if (ranked) rank_lists(std::integral_constant<int, FK_LDS_CAP / 4>{});
+        } else {
+            if (ranked) rank_lists(std::integral_constant<int, 8>{});
+        }
+        if (!ranked && gq < N && part == 0) flags[1 + atomicAdd(&flags[129], 1)] = rq;     // overflowed: the exact selection below
+        __syncthreads();
+        {
+            // the workgroup's rows of idx_out are one contiguous block: 8-byte stores, 512 B per wave instruction (a row of an
+            // overflowed query carries stale values here; the fallback below overwrites it)
+            const int rows = min(FK_QT, N - q0);
+            int64_t *dst = idx_out + ((size_t)b * N + q0) * k;
+            for (int e = t; e < rows * k; e += 512) dst[e] = outl[e];
         }
     } else {
         // lists in the workspace: staged through the (idle) key stages, 32 queries at a time, then ranked from LDS
