@@ -33,7 +33,7 @@
 #define AT_NEG (-1.0e30f)
 
 template <int ND /* D / 32 */>
-__global__ __launch_bounds__(256, 2) void attention_kernel(const float *__restrict__ q, const float *__restrict__ k,
+__global__ __launch_bounds__(256) void attention_kernel(const float *__restrict__ q, const float *__restrict__ k,
                                                            const float *__restrict__ v, int H, int N, int M,
                                                            float scale, float *__restrict__ ctx, long q_bs, long k_bs,
                                                            long v_bs)

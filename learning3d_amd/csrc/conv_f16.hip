@@ -35,6 +35,7 @@
 // all 14 reads ahead of the first MFMA (105 us); first-product fragments read across the barrier (105 us); LDS bank
 // padding of the regions (worth 25 % in the bare read + MFMA loop, nothing here); non-temporal epilogue stores (-1 us).
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "split_bf16.h"          // f32x4 / f32x16 typedefs
 #include "split_f16.h"
@@ -545,9 +546,11 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
         const size_t rows = (size_t)Bn * N;
         const int half = lane >> 5, NP = N / pool;               // pool: 8, 16, 32, 64 or 128 consecutive points per maximum
         const int span = pool < 32 ? pool : 32;                  // lanes of one 32-point tile that share a maximum
-#pragma unroll
+        // (unroll(full): with a plain `unroll` the compiler kept these two loops rolled -- the body is long -- and indexed a private copy of
+        // the accumulators: 576 bytes of scratch)
+#pragma clang loop unroll(full)
         for (int a = 0; a < 2; a++)
-#pragma unroll
+#pragma clang loop unroll(full)
             for (int gq = 0; gq < 4; gq++) {
                 const int cob = co0 + wm * 64 + a * 32 + 8 * gq + 4 * half;          // this lane's 4 channels: cob .. cob + 3
                 float sc[4], sh[4], pv[4][4];
@@ -586,10 +589,10 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
                             if (pool == 128) pv[0][u] = fmaxf(pv[0][u], pv[2][u]);
                         }
                     }
-                    const int step = pool == 128 ? 4 : (pool == 64 ? 2 : 1);        // tiles per maximum
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        if (c % step) continue;
+                    // tiles per maximum: 4 (pool 128), 2 (pool 64), 1 (pool <= 32).  Written out per case: `if (c % step) continue` with a
+                    // runtime step made pv[][] an indexed private array (576 bytes of scratch)
+                    auto finish = [&](auto c_c) {
+                        constexpr int c = decltype(c_c)::value;
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
                             float m = pv[c][u];
@@ -603,14 +606,23 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
 #pragma unroll
                             for (int u = 0; u < 4; u++) ypool[((size_t)b * Cout + cob + u) * NP + n / pool] = pv[c][u];
                         }
-                    }
+                    };
+                    finish(std::integral_constant<int, 0>{});
+                    if (pool <= 64) finish(std::integral_constant<int, 2>{});
+                    if (pool <= 32) { finish(std::integral_constant<int, 1>{}); finish(std::integral_constant<int, 3>{}); }
                 }
             }
       }
         return;
     }
+    // the GROUP instantiation is only launched with pooled maxima (cf_launch): without this its fp32 epilogue is compiled too, with the
+    // loop over the accumulator blocks left rolled -- an indexed private copy of the accumulators, 576 bytes of scratch
+    if constexpr (GROUP) return;
     float *yb = y + (size_t)b * Cout * N;
     const float *rb = RESID ? obs + (size_t)b * Cout * N : nullptr;
+    float amax_nan = 0.f;
+    float amax_run = 0.f;                          // AMAX: max |y| of this lane's 128 outputs (round 6: a running maximum; parking |v| in
+                                                   // the dead accumulators for a later reduction cost the instantiation 12 - 16 spilled registers)
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -641,7 +653,11 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
                     else *dst_ = v;
                 } else *dst_ = v;
 #endif
-                if constexpr (AMAX) acc[a][c][r] = fabsf(v);     // kept for the maximum below (the accumulator is dead)
+                // (asm: left to the compiler the maxima are re-associated into ONE tree behind the last store, every v alive until then)
+                if constexpr (AMAX) {
+                    asm volatile("v_max_f32_e64 %0, %0, |%1|" : "+v"(amax_run) : "v"(v));
+                    asm volatile("v_fma_f32 %0, %1, 0, %0" : "+v"(amax_nan) : "v"(v));      // v_max drops a NaN: 0 * v keeps it (and an inf)
+                }
             }
         }
 #ifdef CF_TIMELINE
@@ -656,21 +672,16 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
         // float bits: the consumer's operand scale (attention_f16.hip takes max|q|, |k|, |v| of a fused q|k|v projection from
         // here instead of a pass over the three tensors).  One atomic per workgroup, skipped when it would not raise the value.
         float *red = (float *)lds;                 // the stages are dead: every wave is past its last fragment read ...
-        float big = 0.f;
-#pragma unroll
-        for (int a = 0; a < 2; a++)
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) big = fmaxf(big, acc[a][c][r]);
+        float big = amax_run;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) big = fmaxf(big, __shfl_xor(big, d, 64));
+        if (__builtin_amdgcn_ballot_w64(amax_nan != amax_nan) != 0) big = __builtin_nanf("");   // fmaxf would drop it
         __syncthreads();                           // ... after this barrier
         if (lane == 0) red[wave] = big;
         __syncthreads();
         if (t == 0) {
             float m = red[0];
-            for (int w = 1; w < 8; w++) m = fmaxf(m, red[w]);
+            for (int w = 1; w < 8; w++) m = (m != m || red[w] != red[w]) ? __builtin_nanf("") : fmaxf(m, red[w]);
             unsigned *dst = amax_out + co0 / amax_cdiv;
             if (!(m <= __uint_as_float(__atomic_load_n(dst, __ATOMIC_RELAXED)))) atomicMax(dst, __float_as_uint(m));   // NaN goes through too
         }

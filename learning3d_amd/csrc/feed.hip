@@ -114,13 +114,24 @@ __global__ __launch_bounds__(256) void twist_transform_kernel(const float *__res
     feed_se3_exp(w, v, R, p);
     if (blockIdx.x == 0 && threadIdx.x < 32) {
         const int which = threadIdx.x >> 4, e = threadIdx.x & 15, r = e >> 2, c = e & 3;
+        // element (r, c) of [R | p; 0 0 0 1] by compile-time indices: R[r][c] with a per-thread r, c made the matrices private arrays (scratch)
+        auto pick = [&](const double (&Rm)[3][3], const double (&pm)[3]) {
+            float val = c == 3 ? 1.f : 0.f;                   // row 3
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) val = (r == i && c == j) ? (float)Rm[i][j] : val;
+                val = (r == i && c == 3) ? (float)pm[i] : val;
+            }
+            return val;
+        };
         if (which == 0) {
-            igt[b * 16 + e] = r == 3 ? (c == 3 ? 1.f : 0.f) : (c == 3 ? (float)p[r] : (float)R[r][c]);
+            igt[b * 16 + e] = pick(R, p);
         } else {
             const double wn[3] = {-w[0], -w[1], -w[2]}, vn[3] = {-v[0], -v[1], -v[2]};
             double Rn[3][3], pn[3];
             feed_se3_exp(wn, vn, Rn, pn);
-            gt[b * 16 + e] = r == 3 ? (c == 3 ? 1.f : 0.f) : (c == 3 ? (float)pn[r] : (float)Rn[r][c]);
+            gt[b * 16 + e] = pick(Rn, pn);
         }
     }
     const int n = blockIdx.x * 256 + threadIdx.x;

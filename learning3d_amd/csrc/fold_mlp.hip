@@ -40,9 +40,9 @@ __global__ __launch_bounds__(512) void fold_mlp_kernel(const float *__restrict__
     const int xrow = t & 255;
     const int xkg = __builtin_amdgcn_readfirstlane(t >> 8);
     const int xn = min(n0 + xrow, N - 1);
-    float gv[CG];
-#pragma unroll
-    for (int c = 0; c < CG; c++) gv[c] = g[((size_t)b * N + xn) * CG + c];
+    // the point's CG grid / coarse values are re-read from L1 for every K chunk (the pointer passes through an empty asm, so the loads
+    // are not hoisted): held in registers across the loop they were the 3 registers this kernel spilled at its 256-register cap
+    const float *gp = g + ((size_t)b * N + xn) * CG;
     const float *s5b = s5 + (size_t)b * FM_C;
     const int wrow = t & 255, wkg = t >> 8;
     const int w_lds = wkg * FM_REGION + wrow * 16;
@@ -66,7 +66,9 @@ __global__ __launch_bounds__(512) void fold_mlp_kernel(const float *__restrict__
         // h5 octet of chunk KC for this thread's point -> three bf16 planes (x0, x1, x2)
 #define FM_GEN_X(KC)                                                                                  \
         do {                                                                                          \
-            float hv_[8];                                                                             \
+            float hv_[8], gv[CG];                                                                     \
+            asm volatile("" : "+v"(gp));                                                              \
+            _Pragma("unroll") for (int c = 0; c < CG; c++) gv[c] = gp[c];                             \
             _Pragma("unroll") for (int e = 0; e < 8; e++) {                                           \
                 const int k_ = (KC) * 16 + xkg * 8 + e;                 /* wave-uniform: scalar loads */ \
                 float a_ = s5b[k_];                                                                   \

@@ -30,15 +30,17 @@
 enum { METRIC_EXPANDED = 0, METRIC_DIRECT = 1, METRIC_EXPANDED_SQ = 2 };
 enum { OUT_KNN_GRAPH = 0, OUT_KNN_PAIR = 1, OUT_KNN_POINT = 2 };
 
-template <int K, int METRIC>
-__global__ __launch_bounds__(64) void topk_scan_kernel(
+// 64 < k <= 200 where the wave-per-query selection kernel (knn_select.hip) does not reach (more than 8192 candidates, or its
+// metric): one query per lane, k ROUNDS -- round r re-scans the candidates for the nearest one that ranks behind round r - 1's
+// (smaller value, or equal value and higher index).  O(k Nc) evaluations per query and five registers of state: no caller in the
+// reference's configurations comes here, and the sorted 128 / 200-slot register lists this replaces (rounds 1-5: topk_scan_kernel<128>,
+// <200>) spilled 588 - 1635 registers.
+template <int METRIC>
+__global__ __launch_bounds__(64) void topk_rounds_kernel(
     const float *__restrict__ qxyz, const float *__restrict__ cxyz, int Nq, int Nc, int k,
     int out_mode, void *__restrict__ idx_out, float *__restrict__ val_out)
 {
     __shared__ float4 cand[TILE];
-    __shared__ float qkey[QCAP][64];
-    __shared__ int qidx[QCAP][64];
-
     const int lane = threadIdx.x;
     const int b = blockIdx.y;
     const int q = blockIdx.x * 64 + lane;
@@ -48,103 +50,57 @@ __global__ __launch_bounds__(64) void topk_scan_kernel(
     const float qx = qp[0], qy = qp[1], qz = qp[2];
     const float qxx = (qx * qx + qy * qy) + qz * qz;       // torch.sum(x**2): sequential rounding
     const float *cbase = cxyz + (size_t)b * Nc * 3;
-
-    TopK<K> top;
-    top.init();
-    float thr = -INFINITY;
-    int cnt = 0;
-
-    auto flush = [&]() {
-#pragma unroll 1
-        for (int s = 0; s < QCAP; s++) {
-            const bool has = s < cnt;
-            if (!__any(has)) break;
-            const float key = has ? qkey[s][lane] : -INFINITY;
-            const int j = qidx[s][lane];
-            top.insert(key, j);
-        }
-        cnt = 0;
-        thr = top.worst();
-    };
-
-    auto eval = [&](const float4 c) -> float {
+    auto eval = [&](const float4 c) -> float {              // topk2_kernel's ranking values: larger = nearer
         if (METRIC == METRIC_EXPANDED) {
-            // inner = -2 * dot (MKL sgemm K=3: fma chain); pd = (-xx_j - inner) - xx_i
             const float dot = fmaf(qz, c.z, fmaf(qy, c.y, qx * c.x));
-            const float tt = fmaf(2.0f, dot, c.w);      // == rn(-xx_j + 2*dot): 2*dot is exact
-            return tt - qxx;
+            return fmaf(2.0f, dot, c.w) - qxx;
         } else if (METRIC == METRIC_EXPANDED_SQ) {
             const float dot = fmaf(qz, c.z, fmaf(qy, c.y, qx * c.x));
-            const float tt = fmaf(-2.0f, dot, qxx);     // == rn(-2*dot + |q|^2)
-            return -(tt + c.w);                         // c.w = +|c|^2; negated so that larger = nearer
+            return -(fmaf(-2.0f, dot, qxx) + c.w);
         } else {
             const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
             return -((dx * dx + dy * dy) + dz * dz);
         }
     };
-
-    for (int c0 = 0; c0 < Nc; c0 += TILE) {
-        const int tn = min(TILE, Nc - c0);
-        __syncthreads();
-        l3d_stage_points<8>(cbase + (size_t)c0 * 3, tn, lane, 64, [&](int t, float x, float y, float z) {
-            float w = 0.f;
-            if (METRIC == METRIC_EXPANDED) w = -((x * x + y * y) + z * z);   // -xx[j]
-            if (METRIC == METRIC_EXPANDED_SQ) w = (x * x + y * y) + z * z;
-            cand[t] = make_float4(x, y, z, w);
-        });
-        __syncthreads();
-        // main loop: CHUNK candidates between queue checks (queue has room for CHUNK more
-        // whenever every lane holds <= QCAP - CHUNK entries)
-        int t = 0;
-        for (; t + CHUNK <= tn; t += CHUNK) {
-            if (__any(cnt > QCAP - CHUNK)) flush();
-            // read the whole chunk first (independent ds_read_b128 in flight together), evaluate,
-            // THEN append: the queue stores may alias `cand` as far as the compiler knows, and
-            // interleaving them serialises every candidate behind an LDS round trip.
-            float4 c[CHUNK];
-            float key[CHUNK];
-#pragma unroll
-            for (int u = 0; u < CHUNK; u++) c[u] = cand[t + u];
-#pragma unroll
-            for (int u = 0; u < CHUNK; u++) key[u] = eval(c[u]);
-#pragma unroll
-            for (int u = 0; u < CHUNK; u++) {
-                if (key[u] > thr) {
-                    qkey[cnt][lane] = key[u];
-                    qidx[cnt][lane] = c0 + t + u;
-                    cnt++;
-                }
-            }
-        }
-        for (; t < tn; t++) {
-            if (__any(cnt >= QCAP)) flush();
-            const float key = eval(cand[t]);
-            if (key > thr) {
-                qkey[cnt][lane] = key;
-                qidx[cnt][lane] = c0 + t;
-                cnt++;
-            }
-        }
-    }
-    flush();
-
-    if (!valid) return;
+    float last_key = INFINITY;
+    int last_idx = -1;
     const size_t o = ((size_t)b * Nq + q) * k;
-    if (out_mode == OUT_KNN_GRAPH) {
-        int64_t *dst = (int64_t *)idx_out + o;
-#pragma unroll
-        for (int i = 0; i < K; i++)
-            if (i < k) dst[i] = top.id[i];
-    } else if (out_mode == OUT_KNN_PAIR) {
-        int32_t *dst = (int32_t *)idx_out + o;
-#pragma unroll
-        for (int i = 0; i < K; i++)
-            if (i < k) { dst[i] = top.id[i]; val_out[o + i] = -top.v[i]; }
-    } else {
-        int64_t *dst = (int64_t *)idx_out + o;
-#pragma unroll
-        for (int i = 0; i < K; i++)
-            if (i < k) { dst[i] = top.id[i]; val_out[o + i] = sqrtf(-top.v[i]); }
+    for (int r = 0; r < k; r++) {
+        float best_key = -INFINITY;
+        int best_idx = 0x7fffffff;
+        for (int c0 = 0; c0 < Nc; c0 += TILE) {
+            const int tn = min(TILE, Nc - c0);
+            __syncthreads();
+            l3d_stage_points<8>(cbase + (size_t)c0 * 3, tn, lane, 64, [&](int t, float x, float y, float z) {
+                float w = 0.f;
+                if (METRIC == METRIC_EXPANDED) w = -((x * x + y * y) + z * z);
+                if (METRIC == METRIC_EXPANDED_SQ) w = (x * x + y * y) + z * z;
+                cand[t] = make_float4(x, y, z, w);
+            });
+            __syncthreads();
+            for (int t = 0; t < tn; t++) {
+                const float key = eval(cand[t]);
+                const int j = c0 + t;
+                const bool behind = key < last_key || (key == last_key && j > last_idx);
+                const bool take = behind && key > best_key;           // ascending j: the first of equal values stays
+                best_key = take ? key : best_key;
+                best_idx = take ? j : best_idx;
+            }
+        }
+        if (best_idx == 0x7fffffff) { best_idx = min(last_idx + 1, Nc - 1); best_key = -INFINITY; }   // nothing left that compares (NaN rows)
+        if (valid) {
+            if (out_mode == OUT_KNN_GRAPH) {
+                ((int64_t *)idx_out)[o + r] = best_idx;
+            } else if (out_mode == OUT_KNN_PAIR) {
+                ((int32_t *)idx_out)[o + r] = best_idx;
+                val_out[o + r] = -best_key;
+            } else {
+                ((int64_t *)idx_out)[o + r] = best_idx;
+                val_out[o + r] = sqrtf(-best_key);
+            }
+        }
+        last_key = best_key;
+        last_idx = best_idx;
     }
 }
 
@@ -479,15 +435,10 @@ static int launch_topk(const float *q, const float *c, int B, int Nq, int Nc, in
     L3D_TOPK2_CASE(32, 4)
     L3D_TOPK2_CASE(64, 2)
 #undef L3D_TOPK2_CASE
-#define L3D_TOPK_CASE(KK)                                                                    \
-    if (k <= KK) {                                                                           \
-        hipLaunchKernelGGL((topk_scan_kernel<KK, METRIC>), grid, block, 0, st, q, c, Nq, Nc, \
-                           k, out_mode, idx, val);                                           \
-        return l3d_check_launch();                                                           \
+    if (k <= L3D_KNN_MAX_K) {
+        hipLaunchKernelGGL((topk_rounds_kernel<METRIC>), grid, block, 0, st, q, c, Nq, Nc, k, out_mode, idx, val);
+        return l3d_check_launch();
     }
-    L3D_TOPK_CASE(128)
-    L3D_TOPK_CASE(200)
-#undef L3D_TOPK_CASE
     return L3D_ERR_UNSUPPORTED;
 }
 

@@ -371,25 +371,41 @@ def test_integration_md_shims_match_the_library():
 
 
 def test_hot_kernels_compile_without_scratch():
-    """The kernels of the benchmark step (and the f16x2 GEMMs of PCN / DCP) must not spill: a spilled register in conv_f16_kernel
-    was a silent 35 % on its main loop (LABLOG R2.4h).  Read from the code objects inside libl3d_hip.so (tools/kernel_meta.py:
-    AMDGPU metadata notes), so it runs without a GPU."""
+    """No kernel of the library spills or indexes a private array (a spilled register in conv_f16_kernel was a silent
+    35 % on its main loop, LABLOG R2.4h): EVERY code object in libl3d_hip.so is read (tools/kernel_meta.py: AMDGPU metadata notes, no
+    GPU needed) and must show 0 bytes of scratch and 0 spilled registers -- except three named instantiations no BASELINE config
+    launches, kept at their 3-4 spilled registers.  The kernels of the benchmark step and the f16x2 GEMMs also keep a register budget."""
     import importlib.util
     from learning3d_amd import _lib
     spec = importlib.util.spec_from_file_location("kernel_meta", os.path.join(ROOT, "tools", "kernel_meta.py"))
     km = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(km)
     meta = km.kernel_metadata(_lib.LIB_PATH)
-    assert len(meta) > 100                                   # every translation unit's code object was found
+    assert len(meta) > 200                                   # every translation unit's code object was found
+    allowed = {"_Z12topk2_kernelILi64ELi1ELi2EE": 4,          # knn_point with 32 < k <= 64 in the direct metric, two waves: no caller in configs 1-5
+               "_Z15fold_mlp_kernelILi5EE": 3,                # PCN's folding decoder in the bf16x3 range-fallback arithmetic
+               "_Z17knn_select_kernelILi128EE": 3}            # 64 < k <= 128 between two clouds: no caller in the reference
+    dirty = {}
+    for name, k in meta.items():
+        sc, sp = k.get(".private_segment_fixed_size", 0), k.get(".vgpr_spill_count", 0)
+        if sc or sp:
+            dirty[name] = (sc, sp)
+    for name, (sc, sp) in dirty.items():
+        ok = [a for a in allowed if name.startswith(a)]
+        assert ok and sp <= allowed[ok[0]] and sc <= 16, f"{name}: {sc} bytes of scratch, {sp} spilled registers"
+    assert not any("rocprim" in n for n in meta), "a library kernel is linked into libl3d_hip.so"
     hot = {"_Z15conv_f16_kernelILb0ELb0ELb0ELi3ELb0EE": 224,    # Linear layers / PCN (wide tile, three weight planes): VGPR budget 218 today
            "_Z15conv_f16_kernelILb0ELb0ELb0ELi2ELb0EE": 224,    # conv5 of the benchmark step (wide tile, two weight planes)
            "_Z15conv_f16_kernelILb1ELb0ELb0ELi3ELb0EE": 224,    # narrow tile
            "_Z15conv_f16_kernelILb0ELb0ELb0ELi3ELb1EE": 224,    # residual epilogue (the pointer network's sublayers)
+           "_Z15conv_f16_kernelILb0ELb1ELb0ELi3ELb0EE": 232,    # + operand maxima (the fused q|k|v projection: 20 % of DCP's forward)
+           "_Z15conv_f16_kernelILb0ELb0ELb1ELi3ELb0EE": 232,    # + pooled maxima over a group's K neighbours
            "_Z26layernorm_planes_cf_kernelILi64ELi8EE": 128,
            "_Z20edgeconv_f16b_kernelILi5ELb1EE": 512,       # the two-plane, persistent kernel of the benchmark step
            "_Z20edgeconv_f16b_kernelILi5ELb0EE": 512,
            "_Z15knn_mfma_kernelILi8EE": 256,
            "_Z25chamfer_fwd_packed_kernel": 128,
+           "_Z14featknn_kernel": 256,                       # all nine instantiations (round 6)
            "_Z19fold_mlp_f16_kernelILi5EE": 256}
     for prefix, vgpr_max in hot.items():
         ks = [k for n, k in meta.items() if n.startswith(prefix)]
