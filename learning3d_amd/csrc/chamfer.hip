@@ -325,7 +325,9 @@ extern "C" int l3d_chamfer_forward_variant(const float *xyz1, const float *xyz2,
     const int mx = N > M ? N : M;
     // large clouds (from 4096 x 4096 pairs per cloud: 81 vs 96 us at B 16, 2.0 vs 4.9 ms at config 4; below that the per-pair kernel
     // wins, profiles/round5_chamfer_bench.txt): the matrix-core ranking + exact refinement; variant 3 forces it, 0 and 2 never use it
-    if (variant == 3 || (variant == 1 && (long)N * M >= (1L << 24)))
+    // ... and only with enough workgroups for the part: 2 ceil(max / 512) B of them, each re-scanning every candidate for its bounding
+    // box -- a single 4096 x 4096 pair is 16 workgroups on 256 CUs, where the per-pair kernel's 64 x B x 2 do better
+    if (variant == 3 || (variant == 1 && (long)N * M >= (1L << 24) && (long)2 * l3d_divup(mx, 512) * B >= 128))
         return l3d_chamfer_forward_mfma(xyz1, xyz2, B, N, M, dist1, dist2, idx1, idx2, (hipStream_t)stream);
     // two queries per lane, packed fp32 (chamfer_fwd_packed_kernel) once that still gives every SIMD a wave;
     // tiny problems keep one query per lane for the workgroup count

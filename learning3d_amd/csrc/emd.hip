@@ -426,8 +426,10 @@ extern "C" int l3d_emd_backward(const float *xyz1, const float *xyz2, const floa
     L3D_REQUIRE(B <= 65535);
     const int mpad = l3d_divup(m, 8 * EMD_G1_U) * 8 * EMD_G1_U + 4 * EMD_G1_U;
     const size_t lds = (size_t)mpad * sizeof(float4);
-    if (lds > 160 * 1024) return L3D_ERR_UNSUPPORTED;     // m <= 10 200 partner points (the reference's own kernels stop at what fits their grid)
-    if (lds > 64 * 1024) hipFuncSetAttribute((const void *)emd_grad1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 160 * 1024) return L3D_ERR_UNSUPPORTED;     // m <= 10 176 partner points (the reference's own kernels stop at what fits their grid)
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void *)emd_grad1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return L3D_ERR_LAUNCH;
     hipLaunchKernelGGL(emd_grad1_kernel, dim3(l3d_divup(n, 64), B), dim3(256), lds, st, n, m, xyz1, xyz2, match, grad1);
     hipLaunchKernelGGL(emd_grad2_kernel, dim3(l3d_divup(m, EMD_G2_ROWS), B), dim3(256), 0, st, n, m, xyz1, xyz2, match, grad2);
     return l3d_check_launch();

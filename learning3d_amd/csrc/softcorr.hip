@@ -30,7 +30,7 @@
 
 // partial state layout in the workspace: [B][N][parts][5] = (m, l, o0, o1, o2)
 template <int DUMMY>
-__global__ __launch_bounds__(256) void softcorr_kernel(const float *__restrict__ src_emb,
+__global__ __launch_bounds__(256, 2) void softcorr_kernel(const float *__restrict__ src_emb,
                                                           const float *__restrict__ tgt_emb,
                                                           const float *__restrict__ tgt, int C, int N, int M,
                                                           float scale, int ksplit, float *__restrict__ ws)

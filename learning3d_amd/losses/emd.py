@@ -11,6 +11,9 @@ import torch.nn as nn
 from .._lib import check, f32c, lib, ptr, require_gpu, stream_ptr
 
 
+EMD_BACKWARD_MAX_M = 10176      # emd.hip, l3d_emd_backward: (m rounded up to 64 points, + 32) float4 records in 160 KB of LDS
+
+
 class EMDFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz1, xyz2):
@@ -19,6 +22,10 @@ class EMDFunction(torch.autograd.Function):
         B, n, d = xyz1.shape
         m = xyz2.shape[1]
         assert d == 3 and xyz2.shape[2] == 3, "EMD kernels are built for 3-D points"
+        if m > EMD_BACKWARD_MAX_M and torch.is_grad_enabled() and (xyz1.requires_grad or xyz2.requires_grad):
+            # l3d_emd_backward keeps the partner cloud in LDS (160 KB): refuse HERE, not in a backward() that runs long after a
+            # forward that succeeded
+            raise ValueError(f"EMD backward supports partner clouds of up to {EMD_BACKWARD_MAX_M} points, got {m}")
         dev = xyz1.device
         match = torch.empty((B, n, m), dtype=torch.float32, device=dev)
         cost = torch.empty((B,), dtype=torch.float32, device=dev)

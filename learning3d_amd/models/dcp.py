@@ -12,7 +12,8 @@ from .dgcnn import DGCNN
 def _mm(a, b):
     """a @ b for the head's small products: on the library's own batched GEMM (l3d_bmm_f32, differentiable) for fp32 device tensors
     -- no rocBLAS launch in the forward trace --, torch.matmul otherwise (CPU tensors, other dtypes)."""
-    if a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape[:-2] == b.shape[:-2] and a.dim() == 3:
+    if (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape[:-2] == b.shape[:-2] and a.dim() == 3
+            and a.shape[0] <= 65535):                  # l3d_bmm_f32's grid limit: larger batches fall through to torch.matmul (ADVICE r5)
         from . import _rows
         return _rows.matmul(a, b)
     return torch.matmul(a, b)

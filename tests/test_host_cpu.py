@@ -374,7 +374,7 @@ def test_hot_kernels_compile_without_scratch():
     """No kernel of the library spills or indexes a private array (a spilled register in conv_f16_kernel was a silent
     35 % on its main loop, LABLOG R2.4h): EVERY code object in libl3d_hip.so is read (tools/kernel_meta.py: AMDGPU metadata notes, no
     GPU needed) and must show 0 bytes of scratch and 0 spilled registers -- except three named instantiations no BASELINE config
-    launches, kept at their 3-4 spilled registers.  The kernels of the benchmark step and the f16x2 GEMMs also keep a register budget."""
+    launches (3-4 spilled registers) and the SVD head's score kernel, which measured faster with its spills than without.  The kernels of the benchmark step and the f16x2 GEMMs also keep a register budget."""
     import importlib.util
     from learning3d_amd import _lib
     spec = importlib.util.spec_from_file_location("kernel_meta", os.path.join(ROOT, "tools", "kernel_meta.py"))
@@ -384,7 +384,9 @@ def test_hot_kernels_compile_without_scratch():
     assert len(meta) > 200                                   # every translation unit's code object was found
     allowed = {"_Z12topk2_kernelILi64ELi1ELi2EE": 4,          # knn_point with 32 < k <= 64 in the direct metric, two waves: no caller in configs 1-5
                "_Z15fold_mlp_kernelILi5EE": 3,                # PCN's folding decoder in the bf16x3 range-fallback arithmetic
-               "_Z17knn_select_kernelILi128EE": 3}            # 64 < k <= 128 between two clouds: no caller in the reference
+               "_Z17knn_select_kernelILi128EE": 3,            # 64 < k <= 128 between two clouds: no caller in the reference
+               "_Z15softcorr_kernelILi0EE": 27}               # SVD head's bf16x3 scores: two workgroups per CU WITH 27 spilled registers run
+                                                              # 252 us, one without 304 (round 6, profiles/round6_dcp_forward_kernels.txt)
     dirty = {}
     for name, k in meta.items():
         sc, sp = k.get(".private_segment_fixed_size", 0), k.get(".vgpr_spill_count", 0)
@@ -392,7 +394,7 @@ def test_hot_kernels_compile_without_scratch():
             dirty[name] = (sc, sp)
     for name, (sc, sp) in dirty.items():
         ok = [a for a in allowed if name.startswith(a)]
-        assert ok and sp <= allowed[ok[0]] and sc <= 16, f"{name}: {sc} bytes of scratch, {sp} spilled registers"
+        assert ok and sp <= allowed[ok[0]] and sc <= 4 * allowed[ok[0]] + 8, f"{name}: {sc} bytes of scratch, {sp} spilled registers"
     assert not any("rocprim" in n for n in meta), "a library kernel is linked into libl3d_hip.so"
     hot = {"_Z15conv_f16_kernelILb0ELb0ELb0ELi3ELb0EE": 224,    # Linear layers / PCN (wide tile, three weight planes): VGPR budget 218 today
            "_Z15conv_f16_kernelILb0ELb0ELb0ELi2ELb0EE": 224,    # conv5 of the benchmark step (wide tile, two weight planes)
