@@ -74,7 +74,7 @@ def pmc_record(tag):
     """What the committed rocprofv3 PMC passes measured for one kernel (profiles/round2_traffic.json, produced on the
     GPU box by tools/pmc.sh + tools/traffic_json.py; bench.py cannot run rocprofv3 on itself, so this is the measured
     figure of the same kernel at the same shapes).  {} if not collected."""
-    for name in ("round5_traffic.json", "round4_traffic.json", "round3_traffic.json", "round2_traffic.json", "round1_traffic.json"):
+    for name in ("round6_traffic.json", "round5_traffic.json", "round4_traffic.json", "round3_traffic.json", "round2_traffic.json", "round1_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 rec = json.load(f).get(tag)

@@ -1,17 +1,13 @@
 #!/bin/bash
-# gpurun_out/ (scratch, merged back from the GPU box by scripts/gpu_r3_final.sh) -> profiles/round3_* (tracked)
+# gpurun_out/ (scratch, merged back from the GPU box by scripts/gpu.sh tasks) -> profiles/round<N>_* (tracked).  usage: collect_profiles.sh <N>
 set -u
-R=/root/repo; cd $R
+R=/root/repo; cd $R; N=${1:?round number}
 cp_if() { [ -s "$1" ] && cp "$1" "$2" && echo "  $2"; }
-cp_if "$(find gpurun_out/prof_r3 -name '*kernel_stats.csv' | head -1)" profiles/round3_kernel_stats_bench.csv
-cp_if "$(find gpurun_out/prof_r3_c5 -name '*kernel_stats.csv' | head -1)" profiles/round3_kernel_stats_bench_c5.csv
-cp_if gpurun_out/r3_bench.json profiles/round3_bench.json
-cp_if gpurun_out/r3_bench_driver.json profiles/round3_bench_driver_args.json
-cp_if gpurun_out/r3_bench_c5.json profiles/round3_bench_c5.json
-cp_if gpurun_out/pmc_edgeconv_f16b.txt profiles/round3_pmc_edgeconv_f16b.txt
-cp_if gpurun_out/pmc_conv5_f16_2p.txt profiles/round3_pmc_conv5_f16_2p.txt
-cp_if gpurun_out/pmc_knn_mfma.txt profiles/round3_pmc_knn_mfma.txt
-cp_if gpurun_out/pmc_group_c5.txt profiles/round3_pmc_group_c5.txt
-cp_if gpurun_out/r3_kbench.txt profiles/round3_kbench.txt
-python tools/kernel_meta.py > profiles/round3_kernel_resources.txt 2>/dev/null && echo "  profiles/round3_kernel_resources.txt"
-python tools/traffic_json.py 3 > /dev/null && echo "  profiles/round3_traffic.json"
+cp_if gpurun_out/kernel_stats_bench.csv profiles/round${N}_kernel_stats_bench.csv
+cp_if gpurun_out/bench.json profiles/round${N}_bench.json
+cp_if gpurun_out/bench_driver_1.json profiles/round${N}_bench_driver_args.json
+cp_if gpurun_out/step_timeline.txt profiles/round${N}_step_timeline.txt
+for f in gpurun_out/pmc_*.txt; do t=$(basename $f .txt); case $t in pmc_*_[0-9]) ;; *) cp_if $f profiles/round${N}_$t.txt ;; esac; done
+for t in kbench featknn_bench dcp_kernels flownet_bench scatter_det_bench emd_bench attention_bench chamfer_bench fk_timeline; do cp_if gpurun_out/$t.txt profiles/round${N}_$t.txt; done
+python tools/kernel_meta.py > profiles/round${N}_kernel_resources.txt 2>/dev/null && echo "  profiles/round${N}_kernel_resources.txt"
+python tools/traffic_json.py $N > /dev/null && echo "  profiles/round${N}_traffic.json"

@@ -1,5 +1,5 @@
 """Run one kernel a few times (for rocprofv3 --pmc passes).
-usage: pmc_one.py emd|emd_sweep|knn|chamfer|edgeconv|edgeconv_split|edgeconv_f16b|conv5|conv5_split|conv5_f16|conv5_f16_2p|group_c5|sa_mlp3"""
+usage: pmc_one.py featknn|emd|emd_sweep|knn|chamfer|edgeconv|edgeconv_split|edgeconv_f16b|conv5|conv5_split|conv5_f16|conv5_f16_2p|group_c5|sa_mlp3"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,6 +18,12 @@ with torch.no_grad():
     img = _fused.edgeconv_forward(x, idx, packed, planes=True, v2=True)
     img2 = _fused.edgeconv_forward(x, idx, packed, planes=True, v2=True, unscaled=True)
     torch.cuda.synchronize()
+    if what == "featknn":                        # feature-space kNN at B 32, C 64, N 1024, k 20 (featknn.hip: split + featknn_kernel<20, 1>)
+        xf = torch.randn((32, 64, 1024), generator=g).cuda()
+        for _ in range(5):
+            U.knn(xf, 20)
+        torch.cuda.synchronize()
+        sys.exit(0)
     if what == "group_c5":                       # config 5's grouping gather (bench.py --workload c5: the HBM-bound op)
         from learning3d_amd.utils import pointnet2_utils as P
         gq = torch.Generator().manual_seed(0)

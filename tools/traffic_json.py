@@ -6,7 +6,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 out = {}
 TAGS = ("edgeconv", "edgeconv_split", "edgeconv_f16", "edgeconv_f16b", "conv5", "conv5_split", "conv5_f16", "conv5_f16_2p", "knn", "knn_mfma",
-        "chamfer", "chamfer_c4", "emd_sweep", "emd_match", "group_c5", "sa_mlp3", "bq_cells", "attention")
+        "chamfer", "chamfer_c4", "emd_sweep", "emd_match", "group_c5", "sa_mlp3", "bq_cells", "attention", "featknn")
 # from round 5 on a round's file only carries what that round measured (entries sourced from round-1 passes of kernels
 # that had changed since); earlier rounds keep the fall-back to the newest earlier file
 for tag in TAGS:
