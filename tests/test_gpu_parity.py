@@ -792,6 +792,24 @@ def test_knn_feature_space_matches_exact_topk():
     x = np.concatenate([half, half], axis=2)
     idx = knn(dev(x), 20).cpu().numpy()[0]
     assert np.all(idx[:, 0::2] + 128 == idx[:, 1::2]) and np.all(idx[:, 0::2] < 128)
+    # lists that overflow (round 6: more than 64 candidates at the bound -> the exact wave-per-query selection at the end of the kernel):
+    # a cloud of identical points (every ranking value equal: indices 0 .. k-1 for every query), and 200 copies of one point among
+    # random ones (their queries see 200 exact ties at the top; the others must not be disturbed)
+    for C, N, k in ((64, 300, 20), (128, 1024, 20), (48, 200, 33)):
+        x = np.broadcast_to(np.random.default_rng(73).standard_normal((1, C, 1)).astype(np.float32), (1, C, N)).copy()
+        idx = knn(dev(x), k).cpu().numpy()[0]
+        assert np.array_equal(idx, np.broadcast_to(np.arange(k), (N, k))), (C, N, k)
+    rng = np.random.default_rng(74)
+    x = rng.standard_normal((1, 64, 1024)).astype(np.float32)
+    x[:, :, 100:300] = x[:, :, 100:101]
+    idx = knn(dev(x), 20).cpu().numpy()[0]
+    assert np.array_equal(idx[100:300], np.broadcast_to(np.arange(100, 120), (200, 20)))            # ties: lowest indices first
+    xd = x.astype(np.float64)[0]
+    sq = (xd ** 2).sum(0)
+    d = sq[:, None] + sq[None, :] - 2 * xd.T @ xd
+    kth = np.sort(d, axis=1)[:, 19]
+    got = np.take_along_axis(d, idx, axis=1)
+    assert np.all(got.max(axis=1) <= kth + 4e-6 * sq.max())
     # the caller: get_graph_feature on a feature map
     x = np.random.default_rng(61).standard_normal((2, 64, 300)).astype(np.float32)
     feat = get_graph_feature(dev(x), k=16)
