@@ -364,6 +364,36 @@ def other_configs(dev, iters=10, warm=3):
             "backward_match_read_gbs": 2 * 4.0 * pairs / (t_b * 1e-3) / 1e9}
     except Exception as exc:
         out["emd_c2_shape"] = {"error": f"{type(exc).__name__}: {exc}"}
+    try:        # feature-space kNN (PRNet's dynamic graphs, models/prnet.py:76-97) at B 32, N 1024, k 20
+        import learning3d_amd.utils as U
+        gk = torch.Generator().manual_seed(11)
+        fk = {}
+        for C in (64, 128):
+            xf = torch.randn((32, C, 1024), generator=gk).to(dev)
+            with torch.no_grad():
+                t = ms(lambda: U.knn(xf, 20))
+            fk[f"C{C}_us"] = t * 1e3
+            # matrix work per call: 2 B N^2 C fp32-equivalent FLOP, executed as 4 fp16 products' worth (1 in the bound sweep + 3 in the collecting one)
+            fk[f"C{C}_fp32_equiv_tflops"] = 2.0 * 32 * 1024 * 1024 * C / (t * 1e-3) / 1e12
+        fk["shape"] = "B=32, N=1024, k=20; split pass + featknn_kernel (f16x2 GEMM + threshold / collect / rank selection)"
+        out["f2_feature_space_knn"] = fk
+    except Exception as exc:
+        out["f2_feature_space_knn"] = {"error": f"{type(exc).__name__}: {exc}"}
+    try:        # the deterministic backward of grouping at FlowNet3D's sa1 shape, beside the reference's atomic scatter
+        from learning3d_amd._lib import check, lib, ptr, stream_ptr
+        from learning3d_amd.utils import pointnet2_utils as P
+        gs = torch.Generator().manual_seed(12)
+        Bs, Cs, Ns, Ss, Ks = 32, 64, 8192, 1024, 16
+        xyz = torch.clamp(torch.randn((Bs, Ns, 3), generator=gs), -2, 2).to(dev)
+        idx = P.ball_query(0.5, Ks, xyz, xyz[:, :Ss].contiguous())
+        gg = torch.randn((Bs, Cs, Ss, Ks), generator=gs).to(dev)
+        outg = torch.empty((Bs, Cs, Ns), device=dev)
+        t_a = ms(lambda: check(lib().l3d_group_points_grad(Bs, Cs, Ns, Ss, Ks, ptr(gg), ptr(idx), ptr(outg), stream_ptr()), "group_points_grad"))
+        t_d = ms(lambda: P._scatter_add_det(gg.view(Bs, Cs, Ss * Ks), idx, None, Ns, 1))
+        out["f3_grouping_backward_sa1"] = {"atomic_scatter_us": t_a * 1e3, "deterministic_us": t_d * 1e3,
+                                           "shape": "B=32, C=64, N=8192, 1024 groups of 16 (group_points_grad_kernel's job, utils/lib/src/group_points_gpu.cu:8-28)"}
+    except Exception as exc:
+        out["f3_grouping_backward_sa1"] = {"error": f"{type(exc).__name__}: {exc}"}
     torch.cuda.synchronize()
     return out
 
