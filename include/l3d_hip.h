@@ -594,11 +594,15 @@ int l3d_sa_mlp3_fused(const float *xyz, const float *new_xyz, const float *feat,
  *   8 bias[m]; parts > 1: K split into `parts` ranges through `workspace` (nb1 nb2 parts M N floats), summed in ascending order
  *   (weight gradients: few output tiles, K = every row of the batch).  fp32 MFMA: an exact fma chain per element, ascending k.
  * l3d_softmax_rows: dp == NULL: y = softmax(scale x) over the last axis of [rows][cols]; dp given: y = scale p (dp - sum_j p_j dp_j)
- * with p = x (the backward through the softmax and the score scale).  y may alias x / dp.  cols <= 8192. */
+ * with p = x (the backward through the softmax and the score scale).  y may alias x / dp.  cols <= 8192.
+ * l3d_colsum_rows: out[c] = sum_r x[r row_stride + c] -- the bias gradient of an nn.Linear over rows (db = 1^T g); a fixed summation
+ * tree over chunks of 128 rows: the same bits on every run (workspace: l3d_colsum_rows_workspace_bytes). */
 int l3d_bmm_f32(const float *A, const long *a_strides, const float *B, const long *b_strides, float *C, const long *c_strides,
                 int nb1, int nb2, int M, int N, int K, float alpha, int flags, const float *bias, int parts, float *workspace,
                 l3d_stream_t stream);
 int l3d_softmax_rows(const float *x, const float *dp, long rows, int cols, float scale, float *y, l3d_stream_t stream);
+size_t l3d_colsum_rows_workspace_bytes(long rows, int cols);
+int l3d_colsum_rows(const float *x, long rows, int cols, long row_stride, void *workspace, float *out, l3d_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight gradient of a 1x1 conv / Linear over points (wgrad.hip; the autograd of nn.Conv1d / Conv2d(k=1) in

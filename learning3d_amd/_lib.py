@@ -75,6 +75,8 @@ SIGNATURES = {
     "l3d_sa_mlp3_fused": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_bmm_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _I, _P, _P],
     "l3d_softmax_rows": [_P, _P, _L, _I, _F, _P, _P],
+    "l3d_colsum_rows_workspace_bytes": [_L, _I],
+    "l3d_colsum_rows": [_P, _L, _I, _L, _P, _P, _P],
     "l3d_layernorm_planes": [_P, _P, _P, _F, _L, _I, _P, _P, _P],
     "l3d_add_transposed": [_P, _P, _I, _I, _I, _P, _P],
     "l3d_max_last": [_P, _L, _I, _P, _P, _P],
@@ -120,7 +122,7 @@ SIGNATURES = {
 _RESTYPE = {"l3d_status_string": C.c_char_p, "l3d_edgeconv_packed_floats": _SZ, "l3d_split_bytes": _SZ,
             "l3d_soft_correspondence_workspace_floats": _SZ, "l3d_layernorm_backward_workspace_floats": _SZ, "l3d_knn_feature_workspace_bytes": _SZ,
             "l3d_scatter_add_det_workspace_bytes": _SZ, "l3d_chamfer_loss_local_ws_bytes": _SZ, "l3d_chamfer_forward_loss_ws_bytes": _SZ, "l3d_f16_image_bytes": _SZ,
-            "l3d_wgrad_workspace_bytes": _SZ, "l3d_emd_workspace_bytes": _SZ}
+            "l3d_wgrad_workspace_bytes": _SZ, "l3d_emd_workspace_bytes": _SZ, "l3d_colsum_rows_workspace_bytes": _SZ}
 
 
 class L3DError(RuntimeError):

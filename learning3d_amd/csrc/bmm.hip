@@ -21,6 +21,11 @@
 #define BM_T 128
 #define BM_K 16
 #define BM_P (BM_T + 32)          // pitch 160: the two k rows a wave reads per MFMA operand fall on disjoint bank halves
+#ifndef BM_OCC
+#define BM_OCC 4                   // waves per SIMD the register allocation is bounded for: <= 128 registers, so that FOUR workgroups share a
+                                   // CU -- a Linear layer over 32768 rows x 512 channels is 1024 tiles = one round of the chip (at the three the
+                                   // 134-138 registers of a bound of 2 allowed, a second round ran on a third of the slots: 210 -> 183 us)
+#endif
 
 struct BmOperand {
     const float *p;
@@ -109,7 +114,7 @@ __device__ __forceinline__ void bm_stash(float (*__restrict__ tile)[BM_P], const
 // has passed the barrier in front of chunk i, so nobody still reads that buffer).
 // AM / BM = the fetch form of the two operands (bm_fetch)
 template <int YT, int AM, int BM>
-__global__ __launch_bounds__(256, 2) void bmm_f32_kernel(BmOperand A, BmOperand B, float *__restrict__ C, long c1, long c2, long cr, long cc,
+__global__ __launch_bounds__(256, (YT == 2 && (AM == 0 || BM == 0)) ? 2 : BM_OCC) void bmm_f32_kernel(BmOperand A, BmOperand B, float *__restrict__ C, long c1, long c2, long cr, long cc,
                                                       int nb2, int M, int N, int K, float alpha, int flags,
                                                       const float *__restrict__ bias, int parts, float *__restrict__ ws)
 {
@@ -160,18 +165,36 @@ __global__ __launch_bounds__(256, 2) void bmm_f32_kernel(BmOperand A, BmOperand 
             fa[P] = bm_fetch<8, AM>(a, A.sr, A.sc, m0, k0 + 2 * BM_K, M, kend, t);
             fb[P] = bm_fetch<VB, BM>(b, B.sc, B.sr, n0, k0 + 2 * BM_K, N, kend, t);
         }
+        // the fragments of k-step s + 1 are read before the MFMAs of k-step s are issued (left to itself the compiler read a step's four
+        // values, waited for them, issued the step's MFMAs and only then read the next: every step ended in an exposed LDS round trip)
+        float av[2][2], bv[2][YT];
+#pragma unroll
+        for (int x = 0; x < 2; x++) av[0][x] = As[P][kl][wm * 64 + 32 * x + rl];
+#pragma unroll
+        for (int y = 0; y < YT; y++) bv[0][y] = Bs[P][kl][wn * 32 * YT + 32 * y + rl];
 #pragma unroll
         for (int kk = 0; kk < BM_K; kk += 2) {
-            float av[2], bv[YT];
+            const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+            if (kk + 2 < BM_K) {
 #pragma unroll
-            for (int x = 0; x < 2; x++) av[x] = As[P][kk + kl][wm * 64 + 32 * x + rl];
+                for (int x = 0; x < 2; x++) av[nxt][x] = As[P][kk + 2 + kl][wm * 64 + 32 * x + rl];
 #pragma unroll
-            for (int y = 0; y < YT; y++) bv[y] = Bs[P][kk + kl][wn * 32 * YT + 32 * y + rl];
+                for (int y = 0; y < YT; y++) bv[nxt][y] = Bs[P][kk + 2 + kl][wn * 32 * YT + 32 * y + rl];
+            }
 #pragma unroll
             for (int x = 0; x < 2; x++)
 #pragma unroll
-                for (int y = 0; y < YT; y++) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], bv[y], acc[x][y], 0, 0, 0);
+                for (int y = 0; y < YT; y++) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][x], bv[cur][y], acc[x][y], 0, 0, 0);
         }
+        // ... and the order is pinned (the scheduler folds the two register sets back into one otherwise): two steps' reads, then
+        // [a step's MFMAs, the reads of the step after next]; a step is two LDS instructions (ds_read2_b32 pairs) and 2 YT MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int i = 0; i < BM_K / 2 - 2; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * YT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * YT, 0);
         if (k0 + BM_K < kend) {                           // chunk + 1 (register set P ^ 1, requested a chunk ago) into the other buffer
             bm_stash<8, AM>(As[P ^ 1], fa[P ^ 1], A.sr, t);
             bm_stash<VB, BM>(Bs[P ^ 1], fb[P ^ 1], B.sc, t);
@@ -374,5 +397,113 @@ extern "C" int l3d_softmax_rows(const float *x, const float *dp, long rows, int 
     if (nit <= 1) SM_GO(1); else if (nit <= 2) SM_GO(2); else if (nit <= 4) SM_GO(4); else if (nit <= 8) SM_GO(8);
     else if (nit <= 16) SM_GO(16); else SM_GO(32);
 #undef SM_GO
+    return l3d_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column sums of [rows][cols] (row stride given): the bias gradient of an nn.Linear over rows, db = 1^T g (what autograd derives for
+// utils/transformer.py:183-189).  As a GEMM with M = 1 it cost 62 us for 32768 x 512 (one MFMA row in 128 used); this is a read at
+// bandwidth.  Deterministic: a fixed summation tree -- rows in chunks of 128 (four groups of 32 in ascending order, then the groups in
+// order), the chunks' sums in four ascending quarters, then the quarters in order.
+// ---------------------------------------------------------------------------------------------
+#define CS_ROWS 128
+// one workgroup: 128 rows x 256 columns.  VEC: four row groups of 32 rows x 64 lanes of float4 (16 MB in flight over the chip at 32768 x 512),
+// the groups' sums added in order through LDS; else one thread per column over the 128 rows (any stride / alignment).
+template <bool VEC>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ x, long rows, int cols, long stride,
+                                                             float *__restrict__ ws)
+{
+    const long r0 = (long)blockIdx.y * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
+    if constexpr (VEC) {
+        __shared__ float4 part[4][64];
+        const int q = threadIdx.x & 63, grp = threadIdx.x >> 6, c = blockIdx.x * 256 + 4 * q;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < cols) {
+            const long ra = r0 + 32 * grp, rb = min(r1, ra + 32);
+            const float *p = x + ra * stride + c;
+            long r = ra;
+            for (; r + 8 <= rb; r += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = *(const float4 *)(p + (long)i * stride);
+#pragma unroll
+                for (int i = 0; i < 8; i++) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
+                p += 8 * stride;
+            }
+            for (; r < rb; r++, p += stride) {
+                const float4 v = *(const float4 *)p;
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        }
+        part[grp][q] = s;
+        __syncthreads();
+        if (grp == 0 && c < cols) {
+#pragma unroll
+            for (int g = 1; g < 4; g++) { const float4 o = part[g][q]; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+            *(float4 *)(ws + (size_t)blockIdx.y * cols + c) = s;
+        }
+    } else {
+        const int c = blockIdx.x * 256 + threadIdx.x;
+        if (c >= cols) return;
+        const float *p = x + r0 * stride + c;
+        float s = 0.f;
+        long r = r0;
+        for (; r + 8 <= r1; r += 8) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = p[(long)i * stride];
+#pragma unroll
+            for (int i = 0; i < 8; i++) s += v[i];
+            p += 8 * stride;
+        }
+        for (; r < r1; r++, p += stride) s += *p;
+        ws[(size_t)blockIdx.y * cols + c] = s;
+    }
+}
+
+// 64 columns per workgroup; four groups of threads each add a quarter of the chunks in ascending order (16 loads in flight), the four
+// quarters are added in order
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restrict__ ws, int chunks, int cols, float *__restrict__ out)
+{
+    __shared__ float part[4][64];
+    const int q = threadIdx.x & 63, grp = threadIdx.x >> 6, c = blockIdx.x * 64 + q;
+    const int per = (chunks + 3) / 4, i0 = grp * per, i1 = min(chunks, i0 + per);
+    float s = 0.f;
+    if (c < cols) {
+        int i = i0;
+        for (; i + 16 <= i1; i += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) v[u] = ws[(size_t)(i + u) * cols + c];
+#pragma unroll
+            for (int u = 0; u < 16; u++) s += v[u];
+        }
+        for (; i < i1; i++) s += ws[(size_t)i * cols + c];
+    }
+    part[grp][q] = s;
+    __syncthreads();
+    if (grp == 0 && c < cols) out[c] = ((part[0][q] + part[1][q]) + part[2][q]) + part[3][q];
+}
+
+extern "C" size_t l3d_colsum_rows_workspace_bytes(long rows, int cols)
+{
+    return rows > 0 && cols > 0 ? (size_t)l3d_divup(rows, (long)CS_ROWS) * cols * sizeof(float) : 0;
+}
+
+// out[c] = sum_r x[r * row_stride + c], r < rows, c < cols
+extern "C" int l3d_colsum_rows(const float *x, long rows, int cols, long row_stride, void *workspace, float *out, l3d_stream_t stream)
+{
+    L3D_REQUIRE(x && out && workspace && rows > 0 && cols > 0 && row_stride >= cols);
+    const long chunks = l3d_divup(rows, (long)CS_ROWS);
+    if (chunks > 65535) return L3D_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)l3d_divup(cols, 256), (unsigned)chunks);
+    if (cols % 4 == 0 && row_stride % 4 == 0 && (((size_t)x) & 15) == 0 && (((size_t)workspace) & 15) == 0)
+        hipLaunchKernelGGL(colsum_partial_kernel<true>, grid, dim3(256), 0, st, x, rows, cols, row_stride, (float *)workspace);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel<false>, grid, dim3(256), 0, st, x, rows, cols, row_stride, (float *)workspace);
+    if (l3d_check_launch() != 0) return L3D_ERR_LAUNCH;
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)l3d_divup(cols, 64)), dim3(256), 0, st, (const float *)workspace, (int)chunks,
+                       cols, out);
     return l3d_check_launch();
 }

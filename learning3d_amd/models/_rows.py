@@ -79,25 +79,37 @@ class _MatMul(torch.autograd.Function):
     """alpha a @ b for operands with equal batch shapes; da = alpha g b^T, db = alpha a^T g -- read through transposed strides"""
 
     @staticmethod
-    def forward(ctx, a, b, alpha):
+    def forward(ctx, a, b, alpha, like):
         ctx.save_for_backward(a, b)
         ctx.alpha = alpha
-        return bmm(a, b, alpha)
+        # `like`: a tensor of the product's shape whose memory layout the product takes (the head-split view of a [B, N, h d] tensor:
+        # the caller's transpose(1, 2).contiguous() behind the product is then no copy)
+        return bmm(a, b, alpha, out=torch.empty_like(like) if like is not None else None)
 
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.saved_tensors
         g = g if g.dtype == torch.float32 else g.float()
-        ga = bmm(g, b.transpose(-1, -2), ctx.alpha) if ctx.needs_input_grad[0] else None
-        gb = bmm(a.transpose(-1, -2), g, ctx.alpha) if ctx.needs_input_grad[1] else None
-        return ga, gb, None
+        # a gradient is laid out like its operand (empty_like keeps the strides of a dense view): what autograd does next -- undoing the
+        # transposes and head splits the operand came through -- then ends in a contiguous tensor instead of a strided copy
+        ga = bmm(g, b.transpose(-1, -2), ctx.alpha, out=_like(a)) if ctx.needs_input_grad[0] else None
+        gb = bmm(a.transpose(-1, -2), g, ctx.alpha, out=_like(b)) if ctx.needs_input_grad[1] else None
+        return ga, gb, None, None
 
 
-def matmul(a, b, alpha=1.0):
+def _like(t):
+    """an uninitialised tensor of t's shape in t's memory layout if t is a dense view (no overlaps, no holes), else contiguous"""
+    out = torch.empty_like(t)
+    return out if out.stride() == t.stride() else torch.empty(t.shape, dtype=t.dtype, device=t.device)
+
+
+def matmul(a, b, alpha=1.0, like=None):
     """differentiable alpha * (a @ b) on the HIP GEMM; a [..., M, K], b [..., K, N] with the same batch shape (no broadcasting)"""
     if a.shape[:-2] != b.shape[:-2]:
         raise ValueError("matmul: equal batch shapes (a broadcast operand's gradient would need a reduction)")
-    return _MatMul.apply(a.float(), b.float(), float(alpha))
+    if like is not None and (like.shape != a.shape[:-1] + b.shape[-1:] or like.dtype != torch.float32):
+        like = None
+    return _MatMul.apply(a.float(), b.float(), float(alpha), like)
 
 
 class _SoftmaxRows(torch.autograd.Function):
@@ -138,7 +150,7 @@ def attention_core(query, key, value, scale):
     """softmax(scale q k^T) v and the attention map (reference utils/transformer.py:127-132 without mask / dropout):
     q [..., N, d], k [..., M, d], v [..., M, dv] -> ([..., N, dv], p [..., N, M])"""
     p = softmax_rows(matmul(query, key.transpose(-1, -2)), scale)
-    return matmul(p, value), p
+    return matmul(p, value, like=query), p
 
 
 class _LinearRows(torch.autograd.Function):
@@ -146,7 +158,9 @@ class _LinearRows(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, relu):
-        y = bmm(x, w.t(), bias=b, bias_axis="n", relu=relu)
+        # W^T as its own [Cin, Cout] tensor (a 1 MB copy): l3d_bmm_f32 then stages it with 16-byte LDS writes; through w.t()'s strides the
+        # same product is 15 % slower (scalar LDS writes behind loads along k)
+        y = bmm(x, w.t().contiguous() if w.numel() <= (1 << 22) else w.t(), bias=b, bias_axis="n", relu=relu)
         ctx.relu = relu
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.has_bias = b is not None
@@ -164,8 +178,20 @@ class _LinearRows(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = bmm(g.t(), x, parts=_split_parts(w.shape[0], w.shape[1], R))
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = bmm(_ones(R, g.device).view(1, R), g, parts=_split_parts(1, g.shape[1], R)).view(-1)
+            gb = colsum(g)
         return gx, gw, gb, None
+
+
+def colsum(g):
+    """sum over the rows of g [R, C] (a bias gradient): l3d_colsum_rows, fixed summation order"""
+    if g.stride(1) != 1:
+        g = g.contiguous()
+    R, Cn = g.shape
+    out = torch.empty(Cn, dtype=torch.float32, device=g.device)
+    with on_device_of(g):
+        ws = torch.empty(lib().l3d_colsum_rows_workspace_bytes(R, Cn), dtype=torch.uint8, device=g.device)
+        check(lib().l3d_colsum_rows(ptr(g), R, Cn, g.stride(0), ptr(ws), ptr(out), stream_ptr()), "l3d_colsum_rows")
+    return out
 
 
 def linear(x, lin, relu=False):

@@ -222,8 +222,10 @@ def test_pointer_network_training_gradients_vs_fp64(route, monkeypatch):
     assert "l3d_layernorm_ref_backward" in log and ("l3d_wgrad" in log) == (route == "conv"), log
     assert ("l3d_bmm_f32" in log and "l3d_softmax_rows" in log) == (route == "rows"), log
     if route == "rows":
-        # 12 Linear layers x (forward, dgrad, wgrad, bias) + 3 attention cores x 2 passes x (2 forward + 4 backward products)
-        assert log.count("l3d_bmm_f32") >= 12 * 2 * 4 + 6 * 6, log.count("l3d_bmm_f32")
+        # 12 Linear layers x 2 passes x (forward, dgrad, wgrad; the bias gradient is l3d_colsum_rows) + 3 attention cores x 2 passes x
+        # (2 forward + 4 backward products)
+        assert log.count("l3d_bmm_f32") >= 12 * 2 * 3 + 6 * 6, log.count("l3d_bmm_f32")
+        assert log.count("l3d_colsum_rows") >= 12 * 2, log.count("l3d_colsum_rows")
         assert log.count("l3d_softmax_rows") >= 12, log.count("l3d_softmax_rows")      # 6 cores, forward and backward (+ a recompute)
     s64, t64 = src.detach().double().requires_grad_(), tgt.detach().double().requires_grad_()
     a64, b64 = net64(s64, t64)
@@ -293,6 +295,27 @@ def test_bmm_kernel_every_layout_vs_fp64():
     r2 = _rows.bmm(gy.t(), xx, parts=_rows._split_parts(96, 64, 5000))
     assert _rows._split_parts(96, 64, 5000) > 1 and torch.equal(r1, r2)
     assert float((r1.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+def test_colsum_rows_vs_fp64_and_repeatable():
+    """l3d_colsum_rows (the bias gradient of an nn.Linear over rows, db = 1^T g): against fp64 within the fp32 summation bound, the same
+    bits on every run, rows read through their stride (a column slice of a wider tensor), sizes off the 128-row / 256-column tiles."""
+    from learning3d_amd.models import _rows
+    g = torch.Generator().manual_seed(9)
+    for R, Cn in ((1, 1), (127, 5), (1000, 300), (32768, 512), (5001, 1024)):
+        x = torch.randn((R, Cn + 7), generator=g).cuda()
+        for v in (x[:, :Cn], x[:, 3:3 + Cn], x[:, :Cn].contiguous()):
+            got = _rows.colsum(v)
+            assert torch.equal(got, _rows.colsum(v))
+            want = v.double().sum(0)
+            bound = v.double().abs().sum(0) * (R * 2.0 ** -24) + 1e-30
+            assert bool(((got.double() - want).abs() <= bound).all()), (R, Cn)
+    lin = torch.nn.Linear(40, 24).cuda()
+    xin = torch.randn((333, 40), generator=g).cuda()
+    w = torch.randn((333, 24), generator=g).cuda()
+    (_rows.linear(xin, lin, relu=True) * w).sum().backward()
+    want = ((torch.relu(lin(xin)) > 0) * w).double().sum(0)
+    assert float((lin.bias.grad.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
 def test_softmax_rows_forward_backward_vs_fp64():

@@ -23,18 +23,19 @@ def t_us(fn, it=20):
 
 
 g = torch.Generator().manual_seed(0)
-R = 8192
+NB = int(os.environ.get("DCP_B", "8"))
+R = NB * 1024
 x, w, gy = torch.randn(R, 512, generator=g).cuda(), torch.randn(512, 512, generator=g).cuda(), torch.randn(R, 512, generator=g).cuda()
 w2 = torch.randn(1024, 512, generator=g).cuda()
-q = torch.randn(8, 1024, 4, 128, generator=g).cuda().transpose(1, 2)
-k = torch.randn(8, 1024, 4, 128, generator=g).cuda().transpose(1, 2)
-p = torch.randn(8, 4, 1024, 1024, generator=g).cuda()
+q = torch.randn(NB, 1024, 4, 128, generator=g).cuda().transpose(1, 2)
+k = torch.randn(NB, 1024, 4, 128, generator=g).cuda().transpose(1, 2)
+p = torch.randn(NB, 4, 1024, 1024, generator=g).cuda()
 cases = [
-    ("linear fwd  x W^T        8192x512x512", x, w.t(), 1),
-    ("linear fwd  x W2^T       8192x1024x512", x, w2.t(), 1),
-    ("dgrad       g W          8192x512x512", gy, w, 1),
-    ("wgrad       g^T x        512x512x8192 split", gy.t(), x, _rows._split_parts(512, 512, R)),
-    ("bias grad   1^T g        1x512x8192 split", torch.ones(1, R, device="cuda"), gy, _rows._split_parts(1, 512, R)),
+    ("linear fwd  x W^T        Rx512x512", x, w.t(), 1),
+    ("linear fwd  x W2^T       Rx1024x512", x, w2.t(), 1),
+    ("dgrad       g W          Rx512x512", gy, w, 1),
+    ("wgrad       g^T x        512x512xR split", gy.t(), x, _rows._split_parts(512, 512, R)),
+    ("bias grad   1^T g        1x512xR split", torch.ones(1, R, device="cuda"), gy, _rows._split_parts(1, 512, R)),
     ("q k^T       32 x 1024x1024x128", q, k.transpose(-1, -2), 1),
     ("p v         32 x 1024x128x1024", p, k, 1),
     ("p^T dO      32 x 1024x128x1024", p.transpose(-1, -2), q, 1),

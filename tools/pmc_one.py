@@ -24,6 +24,18 @@ with torch.no_grad():
             U.knn(xf, 20)
         torch.cuda.synchronize()
         sys.exit(0)
+    if what in ("bmm11", "bmm12", "bmm22"):     # l3d_bmm_f32 on a DCP training step's Linear shapes (R = 32768 rows, 512 -> 512): forward / dgrad / wgrad
+        from learning3d_amd.models import _rows
+        xx, ww, gg = torch.randn(32768, 512, device="cuda"), torch.randn(512, 512, device="cuda"), torch.randn(32768, 512, device="cuda")
+        for _ in range(5):
+            if what == "bmm11":
+                _rows.bmm(xx, ww.t())
+            elif what == "bmm12":
+                _rows.bmm(gg, ww)
+            else:
+                _rows.bmm(gg.t(), xx, parts=_rows._split_parts(512, 512, 32768))
+        torch.cuda.synchronize()
+        sys.exit(0)
     if what == "group_c5":                       # config 5's grouping gather (bench.py --workload c5: the HBM-bound op)
         from learning3d_amd.utils import pointnet2_utils as P
         gq = torch.Generator().manual_seed(0)

@@ -29,7 +29,7 @@ def run(name, make, step, iters=5):
     gpu = sum(k.self_device_time_total for k in ka) / iters / 1e3
     n = sum(k.count for k in ka) / iters
     print(f"== {name}: wall {wall:.2f} ms per step, GPU kernels {gpu:.2f} ms per step in {n:.0f} launches")
-    for k in sorted(ka, key=lambda k: -k.self_device_time_total)[:12]:
+    for k in sorted(ka, key=lambda k: -k.self_device_time_total)[:int(os.environ.get('TOPK', '12'))]:
         print(f"   {k.self_device_time_total / iters / 1e3:8.3f} ms  x{k.count / iters:5.1f}  {k.key[:100]}")
 
 
@@ -98,7 +98,7 @@ def extra(which):
         def make():
             net = DCP(feature_model=DGCNN(emb_dims=512), cycle=False).cuda().train()
             g = torch.Generator().manual_seed(0)
-            t = (torch.rand(8, 1024, 3, generator=g) - 0.5).cuda()
+            t = (torch.rand(int(os.environ.get("DCP_B", "8")), 1024, 3, generator=g) - 0.5).cuda()
             return net, torch.optim.Adam(net.parameters(), lr=1e-3), (t, (t + 0.05).contiguous())
 
         def step(net, opt, data):
@@ -108,7 +108,7 @@ def extra(which):
             loss = (out["est_R"] - torch.eye(3, device="cuda")).square().mean() + out["est_t"].square().mean()
             loss.backward()
             opt.step()
-        run("DCP-v2 train step (B 8, N 1024, emb 512; examples/train_dcp.py)", make, step, iters=3)
+        run(f"DCP-v2 train step (B {os.environ.get('DCP_B', '8')}, N 1024, emb 512; examples/train_dcp.py)", make, step, iters=3)
 
 
 if __name__ == "__main__":
