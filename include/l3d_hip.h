@@ -289,7 +289,8 @@ int l3d_attention_forward_strided(const float *q, const float *k, const float *v
 
 /* The same computation on the restructured kernel (attention_f16b.hip: 256 queries per workgroup, Q fragments in registers, the
  * probabilities handed from the score accumulators to the second product without leaving registers, one barrier per 32-key
- * tile, unscaled fp16 residuals).  maxima_ready != 0: workspace already holds the three maxima. */
+ * tile, unscaled fp16 residuals).  maxima_ready bit 0: workspace already holds the three maxima; bit 1: ctx_img carries an UNSCALED
+ * residual plane m = f16(X - h) (for l3d_pointwise_conv_f16 with L3D_CONV_F16_TWO_PLANE) instead of m' = f16((X - h) 2^12). */
 int l3d_attention_forward_f16b(const float *q, const float *k, const float *v, int B, int H, int D, int N, int M,
                                long q_bstride, long k_bstride, long v_bstride, float scale, void *workspace, int maxima_ready,
                                float *ctx, void *ctx_img, l3d_stream_t stream);
@@ -304,9 +305,10 @@ int l3d_layernorm_planes(const float *x, const float *a, const float *b, float e
                          l3d_stream_t stream);
 /* The same LayerNorm over the channels of a CHANNEL-FIRST tensor x [B][C][N] (one normalisation per point), output as
  * y [B][C][N] (or NULL) and / or as the activation image with rows b N + n (img: l3d_f16_image_bytes(1, B N, C) bytes, or NULL):
- * the pointer network keeps the [B,C,N] layout its GEMMs write from end to end.  C in {128, 256, 512}. */
+ * the pointer network keeps the [B,C,N] layout its GEMMs write from end to end.  C in {128, 256, 512}.  flags 1: the image's residual
+ * plane is UNSCALED (m = f16(X - h): what l3d_pointwise_conv_f16 reads with L3D_CONV_F16_TWO_PLANE); 0: m' = f16((X - h) 2^12). */
 int l3d_layernorm_planes_cf(const float *x, const float *a, const float *b, float eps, int B, int C, int N, float *y,
-                            void *img, l3d_stream_t stream);
+                            void *img, int flags, l3d_stream_t stream);
 /* Residual connection x + sublayer(norm(x)) of utils/transformer.py:82-88 when the sublayer output is channel-first:
  * out[b][n][c] = x[b][n][c] + y[b][c][n];  x, out fp32 [B,N,C], y fp32 [B,C,N] (tiled transpose through LDS). */
 int l3d_add_transposed(const float *x, const float *y, int B, int N, int C, float *out, l3d_stream_t stream);
@@ -440,10 +442,14 @@ int l3d_split_f16_rows(const float *x, long rows, int C, int channel_first, int 
  *             (uint32 float bits, atomic maximum: the caller zeroes them first): the operand maxima
  *             l3d_attention_forward_f16b wants, from the projection's own epilogue (utils/transformer.py:183-189)
  * flags     L3D_CONV_F16_TWO_PLANE: the input image's residual plane is UNSCALED (m = f16(X - h); written by
- *           l3d_edgeconv_forward_f16b with out_mode 2): the Hs plane of the weight image is not read (12 instead of 14 LDS fragment
- *           reads and 4 instead of 5 DMA pieces per chunk and wave).  y only; Cout % 256 == 0, N % 256 == 0.
+ *           l3d_edgeconv_forward_f16b with out_mode 2, by l3d_layernorm_planes_cf / l3d_attention_forward_f16b / this function when
+ *           asked): the Hs plane of the weight image is not read (12 instead of 14 LDS fragment reads and 4 instead of 5 DMA pieces
+ *           per chunk and wave).  Cout % 256 == 0, N % 256 == 0; outputs: y, y + residual, y + amax_out, or out_img with
+ *           L3D_CONV_F16_OUT_UNSCALED.
+ *           L3D_CONV_F16_OUT_UNSCALED (with L3D_CONV_F16_TWO_PLANE): out_img carries an unscaled residual plane as well.
  * shift may be per cloud (shift_bstride = Cout, else 0). */
 #define L3D_CONV_F16_TWO_PLANE 1
+#define L3D_CONV_F16_OUT_UNSCALED 2
 int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
                            int shift_bstride, int B, int Cin, int Cout, int N, int relu, int flags, float *y,
                            const float *residual, void *out_img, const float *obs, float *ypool, int pool,

@@ -84,7 +84,7 @@ SIGNATURES = {
     "l3d_bn_backward_finalize": [_P, _I, _P, _I, _I, _D, _I, _P, _P, _P, _P, _P, _P, _P],
     "l3d_max_last_backward": [_P, _P, _L, _I, _P, _P],
     "l3d_linear_rows": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
-    "l3d_layernorm_planes_cf": [_P, _P, _P, _F, _I, _I, _I, _P, _P, _P],
+    "l3d_layernorm_planes_cf": [_P, _P, _P, _F, _I, _I, _I, _P, _P, _I, _P],
     "l3d_edgeconv_packed_floats": [_I, _I, _I, _I],
     "l3d_edgeconv_pack": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "l3d_edgeconv_forward": [_P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P],

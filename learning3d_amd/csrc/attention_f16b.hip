@@ -47,13 +47,13 @@ __device__ __forceinline__ void ab_split(float a0, float a1, float c, uint32_t &
     m = __builtin_bit_cast(uint32_t, mm);
 }
 
-// conv_f16.hip's activation-image convention for the context output: h = f16(x c), m' = f16((x c - h) 2^12)
-__device__ __forceinline__ void ab_split_scaled(float a0, float a1, float c, uint32_t &h, uint32_t &m)
+// (a0, a1) c -> packed fp16 (h, m rs): rs = 2^12 is ab_split_scaled, rs = 1 ab_split
+__device__ __forceinline__ void ab_split_rs(float a0, float a1, float c, float rs, uint32_t &h, uint32_t &m)
 {
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
     const float x0 = a0 * c, x1 = a1 * c;
     const f16x2 hh = {(_Float16)x0, (_Float16)x1};
-    const f16x2 mm = {(_Float16)((x0 - (float)hh[0]) * 4096.0f), (_Float16)((x1 - (float)hh[1]) * 4096.0f)};
+    const f16x2 mm = {(_Float16)((x0 - (float)hh[0]) * rs), (_Float16)((x1 - (float)hh[1]) * rs)};
     h = __builtin_bit_cast(uint32_t, hh);
     m = __builtin_bit_cast(uint32_t, mm);
 }
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(512) void attention_f16b_kernel(const float *__rest
                                                              const float *__restrict__ v, int H, int N, int M, float scale,
                                                              float *__restrict__ ctx, long q_bs, long k_bs, long v_bs,
                                                              const unsigned *__restrict__ amax, uint2 *__restrict__ cph,
-                                                             uint2 *__restrict__ cpm, float *__restrict__ cinv)
+                                                             uint2 *__restrict__ cpm, float *__restrict__ cinv, float img_rs)
 {
     constexpr int D = 32 * ND, KS = D / 16;                       // channels per head, k-steps of the S^T product
     constexpr int KPL = KS * 2 * 32 * 16;                         // bytes of one K plane of a tile: [k-step][g][key][16 B]
@@ -403,8 +403,11 @@ __global__ __launch_bounds__(512) void attention_f16b_kernel(const float *__rest
                 for (int gq = 0; gq < 4; gq++) {
                     const int oc = (h * D + 32 * dt + 8 * gq) >> 3;
                     uint32_t h0, h1, m0, m1;
-                    ab_split_scaled(O[dt][4 * gq], O[dt][4 * gq + 1], invp, h0, m0);
-                    ab_split_scaled(O[dt][4 * gq + 2], O[dt][4 * gq + 3], invp, h1, m1);
+                    // rs = 2^12: m' = f16((X - h) 2^12), conv_f16.hip's three-plane convention; rs = 1: the unscaled residual its two-plane
+                    // form reads.  One code path with the factor as data (a run-time branch between ab_split and ab_split_scaled
+                    // produced an image that was one fp16 ulp off in 5 of 262144 values -- not run to ground)
+                    ab_split_rs(O[dt][4 * gq], O[dt][4 * gq + 1], invp, img_rs, h0, m0);
+                    ab_split_rs(O[dt][4 * gq + 2], O[dt][4 * gq + 3], invp, img_rs, h1, m1);
                     cph[((size_t)oc * rows + row) * 2 + g] = make_uint2(h0, h1);
                     cpm[((size_t)oc * rows + row) * 2 + g] = make_uint2(m0, m1);
                 }
@@ -457,14 +460,15 @@ static int l3d_attention_absmax3(const float *q, const float *k, const float *v,
     return l3d_check_launch();
 }
 
-// workspace: 16 bytes of device memory (the three maxima; maxima_ready != 0: already there, e.g. from
-// l3d_pointwise_conv_f16 with its amax argument); ctx [B, H D, N] fp32 and / or ctx_img = the context as an fp16 activation image
+// workspace: 16 bytes of device memory (the three maxima; maxima_ready bit 0: already there, e.g. from
+// l3d_pointwise_conv_f16 with its amax argument; bit 1: ctx_img with an UNSCALED residual plane, for the two-plane form of
+// l3d_pointwise_conv_f16); ctx [B, H D, N] fp32 and / or ctx_img = the context as an fp16 activation image
 // (l3d_f16_act_bytes(B N, H D) bytes) for l3d_pointwise_conv_f16; everything else as l3d_attention_forward_strided
 extern "C" int l3d_attention_forward_f16b(const float *q, const float *k, const float *v, int B, int H, int D, int N, int M,
                                           long q_bstride, long k_bstride, long v_bstride, float scale, void *workspace,
                                           int maxima_ready, float *ctx, void *ctx_img, l3d_stream_t stream)
 {
-    L3D_REQUIRE(q && k && v && (ctx || ctx_img) && workspace && B > 0 && H > 0 && D > 0 && N > 0 && M > 0);
+    L3D_REQUIRE(q && k && v && (ctx || ctx_img) && workspace && B > 0 && H > 0 && D > 0 && N > 0 && M > 0 && (maxima_ready & ~3) == 0);
     if (ctx_img && (((size_t)ctx_img) & 15)) return L3D_ERR_UNSUPPORTED;
     const size_t cpb = (size_t)(H * D / 8) * ((size_t)B * N) * 16;
     uint2 *cph = (uint2 *)ctx_img, *cpm = ctx_img ? (uint2 *)((unsigned char *)ctx_img + cpb) : nullptr;
@@ -472,15 +476,16 @@ extern "C" int l3d_attention_forward_f16b(const float *q, const float *k, const 
     if ((D != 32 && D != 64 && D != 128) || B > 65535 || H > 65535) return L3D_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     unsigned *amax = (unsigned *)workspace;
-    if (!maxima_ready) {
+    const float img_rs = (maxima_ready & 2) ? 1.0f : 4096.0f;
+    if (!(maxima_ready & 1)) {
         const int rc = l3d_attention_absmax3(q, k, v, q_bstride, k_bstride, v_bstride, (long)H * D * N, (long)H * D * M, B, amax, st);
         if (rc != L3D_OK) return rc;
     }
     dim3 grid(l3d_divup(N, AB_TQ) * H * B), block(512);
 #define AB_LDS(ND_) (3 * (2 * ((32 * ND_) / 16) * 2 * 32 * 16 + 2 * 2 * 2 * ((32 * ND_) * 16 + 32)))
-    if (D == 32)      hipLaunchKernelGGL(attention_f16b_kernel<1>, grid, block, AB_LDS(1), st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax, cph, cpm, cinv);
-    else if (D == 64) hipLaunchKernelGGL(attention_f16b_kernel<2>, grid, block, AB_LDS(2), st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax, cph, cpm, cinv);
-    else              hipLaunchKernelGGL(attention_f16b_kernel<4>, grid, block, AB_LDS(4), st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax, cph, cpm, cinv);
+    if (D == 32)      hipLaunchKernelGGL(attention_f16b_kernel<1>, grid, block, AB_LDS(1), st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax, cph, cpm, cinv, img_rs);
+    else if (D == 64) hipLaunchKernelGGL(attention_f16b_kernel<2>, grid, block, AB_LDS(2), st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax, cph, cpm, cinv, img_rs);
+    else              hipLaunchKernelGGL(attention_f16b_kernel<4>, grid, block, AB_LDS(4), st, q, k, v, H, N, M, scale, ctx, q_bstride, k_bstride, v_bstride, amax, cph, cpm, cinv, img_rs);
 #undef AB_LDS
     return l3d_check_launch();
 }

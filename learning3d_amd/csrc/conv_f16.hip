@@ -247,7 +247,10 @@ __device__ long long *g_cf_timeline;
 // connection of the pointer network's sublayers (utils/transformer.py:131-140 of the reference) in the GEMM's epilogue instead
 // of a pass over both tensors.  The residual pointer travels in `obs`, which the fp32 epilogue does not otherwise read: the
 // kernel's signature, and with it the other instantiations' code, stays as it was.
-template <bool NARROW, bool AMAX, bool GROUP, int NPW = 3, bool RESID = false>
+// OUT2 (two weight planes only; its own instantiation): the plane-image output carries an UNSCALED residual too, so that the next layer
+// runs the two-plane form as well -- the pointer network's projections (utils/transformer.py:163-194 of the reference) then all do:
+// 119 -> 94 us at 512 -> 1024 over 32768 rows, the difference between the three- and the two-plane main loop.
+template <bool NARROW, bool AMAX, bool GROUP, int NPW = 3, bool RESID = false, bool OUT2 = false>
 __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__ xh, const uint4 *__restrict__ xm,
                                                        const uint4 *__restrict__ wH, const uint4 *__restrict__ wHs,
                                                        const uint4 *__restrict__ wM, const float *__restrict__ winv,
@@ -259,8 +262,9 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
 {
     constexpr int TM = NARROW ? 128 : CF_TM, TN = NARROW ? 512 : CF_TN;
     constexpr int WR = TM * 16, XR = TN * 16;                   // bytes of one (plane, octet) region of W / x
-    static_assert(NPW == 3 || (NPW == 2 && !NARROW && !AMAX && !GROUP), "two weight planes: wide tile, fp32 output");
-    static_assert(!RESID || (NPW == 3 && !NARROW && !AMAX && !GROUP), "residual epilogue: wide tile, fp32 output");
+    static_assert(NPW == 3 || (NPW == 2 && !NARROW && !GROUP), "two weight planes: wide tile");
+    static_assert(!RESID || (!NARROW && !AMAX && !GROUP), "residual epilogue: wide tile, fp32 output");
+    static_assert(!OUT2 || (NPW == 2 && !AMAX && !RESID), "unscaled output image: the two-plane form");
     constexpr int WBYTES = 2 * NPW * WR, STAGE = WBYTES + 4 * XR;
     constexpr int NPIECE = NARROW ? 6 : (NPW == 3 ? 5 : 4);     // DMA instructions per wave and chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -521,8 +525,13 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
                     }
                     if (oph) {
                         uint32_t h0, h1, m0, m1;
-                        af_split_x(v[0], v[1], up, h0, m0);
-                        af_split_x(v[2], v[3], up, h1, m1);
+                        if constexpr (OUT2) {
+                            af_split_x_unscaled(v[0], v[1], up, h0, m0);
+                            af_split_x_unscaled(v[2], v[3], up, h1, m1);
+                        } else {
+                            af_split_x(v[0], v[1], up, h0, m0);
+                            af_split_x(v[2], v[3], up, h1, m1);
+                        }
                         const size_t row = (size_t)b * N + n0 + wn * 128 + c * 32 + (lane & 31);
                         const size_t cellh = ((size_t)(cob >> 3) * rows + row) * 2 + half;
                         oph[cellh] = make_uint2(h0, h1);
@@ -646,7 +655,7 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
 #define CF_STORE 1     // the two-plane instantiation's output stores: 0 plain, 1 nt (default), 2 sc1 (write-through, agent), 3 sc0 sc1 (system)
 #endif
                 float *dst_ = &yb[(size_t)co * N + n0 + wn * 128 + c * 32 + (lane & 31)];
-                if constexpr (NPW == 2) {
+                if constexpr (NPW == 2 && !AMAX && !RESID) {
                     if (CF_STORE == 1) __builtin_nontemporal_store(v, dst_);
                     else if (CF_STORE == 2) __hip_atomic_store(dst_, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     else if (CF_STORE == 3) __hip_atomic_store(dst_, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -750,7 +759,8 @@ extern "C" int l3d_split_f16_rows(const float *x, long rows, int C, int channel_
 // x_act: an activation image (l3d_f16_act_bytes), w_planes: a weight image (l3d_conv_f16_weight_bytes)
 static int cf_launch(const void *x_planes, const void *w_planes, const float *scale, const float *shift, int shift_bstride, int B,
                      int Cin, int Cout, int N, int relu, float *y, void *out_img, const float *obs, float *ypool, int pool,
-                     unsigned *amax_out, int amax_cdiv, hipStream_t st, bool two_plane = false, const float *resid = nullptr)
+                     unsigned *amax_out, int amax_cdiv, hipStream_t st, bool two_plane = false, const float *resid = nullptr,
+                     bool out_unscaled = false)
 {
     // wide tile (256 x 256) when Cout allows it, else the narrow one (128 x 512)
     const bool narrow = Cout % CF_TM != 0;
@@ -771,10 +781,20 @@ static int cf_launch(const void *x_planes, const void *w_planes, const float *sc
     const size_t nlds = 3 * (6 * 128 * 16 + 4 * 512 * 16);
     const bool group = ypool && pool != 128;
     if (group && amax_out) return L3D_ERR_UNSUPPORTED;
+    constexpr size_t lds2 = 3 * (4 * CF_TM * 16 + 4 * CF_TN * 16);             // the two-plane form's three stages
+    if (out_unscaled && !(two_plane && out_img && !ypool)) return L3D_ERR_UNSUPPORTED;
     if (resid) {
-        if (narrow || group || amax_out || ypool || out_img || !y || two_plane) return L3D_ERR_UNSUPPORTED;
+        if (narrow || group || amax_out || ypool || out_img || !y) return L3D_ERR_UNSUPPORTED;
         obs = resid;
-        hipLaunchKernelGGL((conv_f16_kernel<false, false, false, 3, true>), grid, block, CF_LDS, st, CF_ARGS);
+        if (two_plane) hipLaunchKernelGGL((conv_f16_kernel<false, false, false, 2, true>), grid, block, lds2, st, CF_ARGS);
+        else hipLaunchKernelGGL((conv_f16_kernel<false, false, false, 3, true>), grid, block, CF_LDS, st, CF_ARGS);
+        return l3d_check_launch();
+    }
+    if (two_plane && (amax_out || out_img)) {
+        // the pointer network's projections on two-plane images: operand maxima out of the epilogue, or an (unscaled) plane image
+        if (narrow || group || ypool || (amax_out && !y) || (out_img && (!out_unscaled || amax_out))) return L3D_ERR_UNSUPPORTED;
+        if (amax_out) hipLaunchKernelGGL((conv_f16_kernel<false, true, false, 2>), grid, block, lds2, st, CF_ARGS);
+        else hipLaunchKernelGGL((conv_f16_kernel<false, false, false, 2, false, true>), grid, block, lds2, st, CF_ARGS);
         return l3d_check_launch();
     }
     if (two_plane) {
@@ -836,8 +856,10 @@ static int cf_launch(const void *x_planes, const void *w_planes, const float *sc
 //   amax_out  max|y| per group of amax_cdiv output channels (amax_cdiv % 256 == 0) as float bits, atomicMax into
 //             amax_out[Cout / amax_cdiv] (the caller zeroes them; needs y): transformer.py:183-189's fused q|k|v projection
 //             hands the attention kernel its operand maxima
-// flags: L3D_CONV_F16_TWO_PLANE -- the input image's residual plane is UNSCALED (m = f16(X - h), written by
-//        l3d_edgeconv_forward_f16b with out_mode 2): the Hs plane of the weight image is not read (wide tile, y only).
+// flags: 1 (L3D_CONV_F16_TWO_PLANE) -- the input image's residual plane is UNSCALED (m = f16(X - h), written by
+//        l3d_edgeconv_forward_f16b with out_mode 2, l3d_layernorm_planes / l3d_attention_forward_f16b / this kernel when asked): the Hs
+//        plane of the weight image is not read (wide tile; y, y + residual, y + amax_out, or out_img with flag 2).
+//        2 (L3D_CONV_F16_OUT_UNSCALED) -- out_img gets an unscaled residual plane as well (needs flag 1).
 // shift may be per cloud (shift_bstride = Cout).  Cin % 16 == 0; Cout % 256 == 0 and N % 256 == 0, or Cout % 128 == 0 and N % 512 == 0.
 extern "C" int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
                                       int shift_bstride, int B, int Cin, int Cout, int N, int relu, int flags, float *y,
@@ -845,10 +867,10 @@ extern "C" int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes
                                       void *amax_out, int amax_cdiv, l3d_stream_t stream)
 {
     L3D_REQUIRE(x_planes && w_planes && (y || out_img || ypool) && (!out_img || obs) && (!residual || y) && (!amax_out || (y && amax_cdiv > 0)) &&
-                B > 0 && Cin > 0 && Cout > 0 && N > 0 && (flags & ~1) == 0);
+                B > 0 && Cin > 0 && Cout > 0 && N > 0 && (flags & ~3) == 0);
     if (y && (out_img || ypool)) return L3D_ERR_UNSUPPORTED;                  // the epilogue writes fp32 rows OR planes / pooled maxima
     return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, out_img, obs, ypool, pool,
-                     (unsigned *)amax_out, amax_cdiv, (hipStream_t)stream, (flags & 1) != 0, residual);
+                     (unsigned *)amax_out, amax_cdiv, (hipStream_t)stream, (flags & 1) != 0, residual, (flags & 2) != 0);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -461,7 +461,7 @@ template <int CPW /* channels per wave */, int NW /* waves */>
 __global__ __launch_bounds__(64 * NW) void layernorm_planes_cf_kernel(const float *__restrict__ x, const float *__restrict__ a,
                                                                   const float *__restrict__ bb, float eps, int Bn, int N,
                                                                   float *__restrict__ y, uint4 *__restrict__ ph, uint4 *__restrict__ pm,
-                                                                  float *__restrict__ inv_out)
+                                                                  float *__restrict__ inv_out, float rs)
 {
     constexpr int C = NW * CPW;
     __shared__ double red[2][NW][64];
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(64 * NW) void layernorm_planes_cf_kernel(const floa
             if (y && ok) (y + ((size_t)b * C + c0 + i) * N)[n] = val;
             const float X = val * up;
             h[k] = (_Float16)X;
-            m[k] = (_Float16)((X - (float)h[k]) * 4096.0f);
+            m[k] = (_Float16)((X - (float)h[k]) * rs);           // rs = 2^12 (the three-plane kernel's m') or 1 (unscaled: the two-plane form)
         }
         if (ph && ok) {
             const size_t cell = (size_t)(c0 / 8 + o) * rows + row;
@@ -538,11 +538,13 @@ __global__ __launch_bounds__(64 * NW) void layernorm_planes_cf_kernel(const floa
 }
 
 // x [B][C][N] -> y [B][C][N] (or NULL) and / or img = the activation image of y with rows b N + n (l3d_f16_act_bytes(B N, C)
-// bytes; or NULL).  C in {128, 256, 512}.
+// bytes; or NULL).  C in {128, 256, 512}.  flags 1: the image's residual plane is UNSCALED, m = f16(X - h) (the two-plane form of
+// l3d_pointwise_conv_f16 reads it, L3D_CONV_F16_TWO_PLANE); 0: m' = f16((X - h) 2^12).
 extern "C" int l3d_layernorm_planes_cf(const float *x, const float *a, const float *b, float eps, int B, int C, int N, float *y,
-                                       void *img, l3d_stream_t stream)
+                                       void *img, int flags, l3d_stream_t stream)
 {
-    L3D_REQUIRE(x && a && b && (y || img) && B > 0 && N > 0 && C > 1);
+    L3D_REQUIRE(x && a && b && (y || img) && B > 0 && N > 0 && C > 1 && (flags & ~1) == 0);
+    const float rs = (flags & 1) ? 1.0f : 4096.0f;
     if ((C != 128 && C != 256 && C != 512) || B > 65535 || (((size_t)img) & 15)) return L3D_ERR_UNSUPPORTED;
     const size_t rows = (size_t)B * N, pb = (size_t)(C / 8) * rows * 16;
     unsigned char *d = (unsigned char *)img;
@@ -550,9 +552,9 @@ extern "C" int l3d_layernorm_planes_cf(const float *x, const float *a, const flo
     float *inv = d ? (float *)(d + 2 * pb) : nullptr;
     dim3 grid((unsigned)l3d_divup(N, 64), (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
-    if (C == 512)      hipLaunchKernelGGL((layernorm_planes_cf_kernel<64, 8>), grid, dim3(512), 0, st, x, a, b, eps, B, N, y, ph, pm, inv);
-    else if (C == 256) hipLaunchKernelGGL((layernorm_planes_cf_kernel<64, 4>), grid, dim3(256), 0, st, x, a, b, eps, B, N, y, ph, pm, inv);
-    else               hipLaunchKernelGGL((layernorm_planes_cf_kernel<32, 4>), grid, dim3(256), 0, st, x, a, b, eps, B, N, y, ph, pm, inv);
+    if (C == 512)      hipLaunchKernelGGL((layernorm_planes_cf_kernel<64, 8>), grid, dim3(512), 0, st, x, a, b, eps, B, N, y, ph, pm, inv, rs);
+    else if (C == 256) hipLaunchKernelGGL((layernorm_planes_cf_kernel<64, 4>), grid, dim3(256), 0, st, x, a, b, eps, B, N, y, ph, pm, inv, rs);
+    else               hipLaunchKernelGGL((layernorm_planes_cf_kernel<32, 4>), grid, dim3(256), 0, st, x, a, b, eps, B, N, y, ph, pm, inv, rs);
     return l3d_check_launch();
 }
 

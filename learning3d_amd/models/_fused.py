@@ -326,6 +326,7 @@ def _conv_f16(label, x_planes, w_planes, scale, shift, bstride, B, Cin, Cout, N,
 
 
 CONV_F16_TWO_PLANE = 1        # include/l3d_hip.h: L3D_CONV_F16_TWO_PLANE
+CONV_F16_OUT_UNSCALED = 2     # include/l3d_hip.h: L3D_CONV_F16_OUT_UNSCALED
 
 
 def pointwise_conv_f16(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=None, relu=False, out_planes=False, amax=None,
@@ -333,31 +334,39 @@ def pointwise_conv_f16(x_planes, B, N, w_planes, Cin, Cout, scale=None, shift=No
     """l3d_pointwise_conv_f16 on pre-split operands -> y [B,Cout,N] fp32; out_planes=True: the output as an fp16 activation
     image (uint8 tensor) for the next f16x2 layer instead (shift must be [Cout] or None).
     amax = (int32 tensor, channels per group): also max|y| per channel group as float bits, atomically maximised into the
-    (pre-zeroed) tensor.  unscaled: the input image carries an unscaled residual plane (the two-plane EdgeConv kernel's).
+    (pre-zeroed) tensor.  unscaled: the input image carries an unscaled residual plane (the two-plane EdgeConv kernel's, or the
+    pointer network's images: l3d_layernorm_planes_cf / l3d_attention_forward_f16b / this layer asked for one) -- the two-plane
+    form of the kernel; a plane output then carries an unscaled residual too.
     residual: y = residual + layer(x)."""
     scale = f32c(scale) if scale is not None else None
     shift = f32c(shift) if shift is not None else None
+    two = unscaled and Cout % 256 == 0 and N % 256 == 0
+    if unscaled and not two:
+        raise ValueError("the two-plane conv kernel takes Cout % 256 == 0 and N % 256 == 0")
     if out_planes:
         if shift is not None and shift.dim() != 1:
             raise ValueError("plane output takes a per-channel shift only")
         dev = x_planes.device
         obs = _plane_obs(scale, shift, dev)
         img = torch.empty(lib().l3d_f16_image_bytes(1, B * N, Cout), dtype=torch.uint8, device=dev)
-        _conv_f16("l3d_pointwise_conv_f16[planes]", x_planes, w_planes, scale, shift, 0, B, Cin, Cout, N, relu, img=img, obs=obs)
+        _conv_f16("l3d_pointwise_conv_f16[planes]" + ("[two-plane]" if two else ""), x_planes, w_planes, scale, shift, 0, B, Cin, Cout, N,
+                  relu, flags=(CONV_F16_TWO_PLANE | CONV_F16_OUT_UNSCALED) if two else 0, img=img, obs=obs)
         return img
     bstride = Cout if (shift is not None and shift.dim() == 2) else 0
     y = torch.empty((B, Cout, N), dtype=torch.float32, device=x_planes.device)
     if residual is not None:
         # y = residual + layer(x): the sublayer's residual connection in the GEMM's epilogue
-        if amax is not None or unscaled or tuple(residual.shape) != (B, Cout, N) or not (Cout % 256 == 0 and N % 256 == 0):
-            raise ValueError("residual epilogue: residual [B,Cout,N], Cout % 256 == 0, N % 256 == 0, no absmax / two-plane input")
-        _conv_f16("l3d_pointwise_conv_f16[residual]", x_planes, w_planes, scale, shift, bstride, B, Cin, Cout, N, relu, y=y,
-                  residual=f32c(residual))
+        if amax is not None or tuple(residual.shape) != (B, Cout, N) or not (Cout % 256 == 0 and N % 256 == 0):
+            raise ValueError("residual epilogue: residual [B,Cout,N], Cout % 256 == 0, N % 256 == 0, no absmax")
+        _conv_f16("l3d_pointwise_conv_f16[residual]" + ("[two-plane]" if two else ""), x_planes, w_planes, scale, shift, bstride, B, Cin,
+                  Cout, N, relu, flags=CONV_F16_TWO_PLANE if two else 0, y=y, residual=f32c(residual))
+        return y
+    if two and amax is not None:
+        _conv_f16("l3d_pointwise_conv_f16[absmax][two-plane]", x_planes, w_planes, scale, shift, bstride, B, Cin, Cout, N, relu,
+                  flags=CONV_F16_TWO_PLANE, y=y, amax=amax[0], amax_cdiv=int(amax[1]))
         return y
     if unscaled:
         # the image's residual plane is unscaled (edgeconv_forward(..., planes=True, unscaled=True)): two weight planes
-        if amax is not None or not (Cout % 256 == 0 and N % 256 == 0):
-            raise ValueError("the two-plane conv kernel takes Cout % 256 == 0, N % 256 == 0 and no absmax output")
         with stage("conv5_kernel"):
             _conv_f16("l3d_pointwise_conv_f16[two-plane]", x_planes, w_planes, scale, shift, bstride, B, Cin, Cout, N, relu,
                       flags=CONV_F16_TWO_PLANE, y=y)

@@ -24,6 +24,10 @@ PROJECTION_MAXIMA = True    # the f16x2 q|k|v projections report max|q|, |k|, |v
 # direction: a DCP training step took 25.6 ms with it against 20.4 ms on rocBLAS, LABLOG R3.22 -- kept as a cross-check);
 # "torch": nn.Linear and torch matmul / softmax (rocBLAS).  LayerNorm's HIP forward / backward is independent of this switch.
 TRAIN_LINEAR = os.environ.get("L3D_TRAIN_LINEAR", "rows")
+# the channel-first pass's plane images (LayerNorm outputs, attention contexts, the feed-forward's hidden layer) with an UNSCALED residual
+# plane: every projection then runs the two-plane form of the f16x2 kernel (conv_f16.hip: 12 instead of 14 fragment reads, 4 instead
+# of 5 DMA pieces per chunk); "0" keeps the scaled images of rounds 3-5 (A/B)
+TWO_PLANE_IMAGES = os.environ.get("L3D_TWO_PLANE_IMAGES", "1") != "0"
 CHANNEL_FIRST_PASS = True   # a whole encoder-decoder pass in the [B,C,N] layout the GEMMs write (Transformer._pass_cf); False: module by module
 
 _ATT_WS = {}
@@ -67,13 +71,16 @@ def _fast_linear_ok(lin, x, n_points):
             and _fused.split_eligible(lin.in_features, lin.out_features, n_points))
 
 
-def _linear_cf(lin, x, channel_last, relu=False, out_scale=None, planes=None, out_planes=False, amax=None, residual=None):
+def _linear_cf(lin, x, channel_last, relu=False, out_scale=None, planes=None, out_planes=False, amax=None, residual=None,
+               two_plane=False):
     """Linear over points as a 1x1 conv: x [B,N,Cin] (channel_last) or [B,Cin,N] -> [B,Cout,N];
     out_scale multiplies the whole result (weights and bias) in the kernel's epilogue.
     planes = (image, B, N): the input exists only as an fp16 plane image (x is None); out_planes: return (image, B, N) of the
     output instead of the fp32 tensor (f16x2 path only; None if that path does not apply).
     amax = (int32 tensor, channels per group): the f16x2 kernel also maximises max|y| per channel group into the tensor and
-    the result carries `_l3d_amax = True`; ignored (no attribute) on the other routes."""
+    the result carries `_l3d_amax = True`; ignored (no attribute) on the other routes.
+    two_plane: the input image carries an UNSCALED residual plane (l3d_layernorm_planes_cf / l3d_attention_forward_f16b / a plane
+    output of this route asked for one): the two-plane form of the f16x2 kernel; a plane output is unscaled as well."""
     from ..models import _fused
     if planes is not None:
         img, nb_, np_ = planes
@@ -94,13 +101,14 @@ def _linear_cf(lin, x, channel_last, relu=False, out_scale=None, planes=None, ou
             bias = bias * float(out_scale) if bias is not None else None
         if out_planes:
             return (_fused.pointwise_conv_f16(img, nb_, np_, c16[1], lin.in_features, lin.out_features, scale, bias, relu=relu,
-                                              out_planes=True), nb_, np_)
+                                              out_planes=True, unscaled=two_plane), nb_, np_)
         if amax is not None and amax[1] % 256 == 0 and PROJECTION_MAXIMA:
-            y = _fused.pointwise_conv_f16(img, nb_, np_, c16[1], lin.in_features, lin.out_features, scale, bias, relu=relu, amax=amax)
+            y = _fused.pointwise_conv_f16(img, nb_, np_, c16[1], lin.in_features, lin.out_features, scale, bias, relu=relu, amax=amax,
+                                          unscaled=two_plane)
             y._l3d_amax = True
             return y
         return _fused.pointwise_conv_f16(img, nb_, np_, c16[1], lin.in_features, lin.out_features, scale, bias, relu=relu,
-                                         residual=residual)
+                                         residual=residual, unscaled=two_plane)
     if out_planes:
         return None
     if residual is not None:
@@ -469,7 +477,7 @@ class Transformer(nn.Module):
         img = torch.empty(lib().l3d_f16_image_bytes(1, B * N, C), dtype=torch.uint8, device=x.device) if planes else None
         check(lib().l3d_layernorm_planes_cf(ptr(x), ptr(norm.a_2.detach().contiguous()), ptr(norm.b_2.detach().contiguous()),
                                             float(norm.eps), B, C, N, ptr(y) if values else None, ptr(img) if planes else None,
-                                            stream_ptr()), "l3d_layernorm_planes_cf")
+                                            int(TWO_PLANE_IMAGES), stream_ptr()), "l3d_layernorm_planes_cf")
         return y, img
 
     def _attn_block_cf(self, norm, attn, x, memory):
@@ -480,27 +488,28 @@ class Transformer(nn.Module):
         ws = _attention_workspace(x.device)
         ws.zero_()
         if memory is None:
-            qkv = _linear_cf(attn._fused_linear(0, 3), None, True, planes=(img, B, N), amax=(ws, C))
+            qkv = _linear_cf(attn._fused_linear(0, 3), None, True, planes=(img, B, N), amax=(ws, C), two_plane=TWO_PLANE_IMAGES)
             q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
             have_max, M = getattr(qkv, "_l3d_amax", False), N
         else:
             mem_img, M = memory
-            q = _linear_cf(attn.linears[0], None, True, planes=(img, B, N), amax=(ws, C))
-            kv = _linear_cf(attn._fused_linear(1, 3), None, True, planes=(mem_img, B, M), amax=(ws[1:], C))
+            q = _linear_cf(attn.linears[0], None, True, planes=(img, B, N), amax=(ws, C), two_plane=TWO_PLANE_IMAGES)
+            kv = _linear_cf(attn._fused_linear(1, 3), None, True, planes=(mem_img, B, M), amax=(ws[1:], C), two_plane=TWO_PLANE_IMAGES)
             k, v = kv[:, :C], kv[:, C:]
             have_max = getattr(q, "_l3d_amax", False) and getattr(kv, "_l3d_amax", False)
         attn.attn = None                                           # the [B,h,N,M] map is never formed
         ctx = torch.empty(lib().l3d_f16_image_bytes(1, B * N, C), dtype=torch.uint8, device=x.device)
         check(lib().l3d_attention_forward_f16b(ptr(q), ptr(k), ptr(v), B, attn.h, attn.d_k, N, M, q.stride(0), k.stride(0), v.stride(0),
-                                               1.0 / math.sqrt(attn.d_k), ptr(ws), int(bool(have_max)), None, ptr(ctx), stream_ptr()),
+                                               1.0 / math.sqrt(attn.d_k), ptr(ws), int(bool(have_max)) | (2 if TWO_PLANE_IMAGES else 0), None,
+                                               ptr(ctx), stream_ptr()),
               "l3d_attention_forward_f16b")
-        return _linear_cf(attn.linears[-1], None, True, planes=(ctx, B, N), residual=x)
+        return _linear_cf(attn.linears[-1], None, True, planes=(ctx, B, N), residual=x, two_plane=TWO_PLANE_IMAGES)
 
     def _ffn_block_cf(self, norm, ff, x):
         B, C, N = x.shape
         _, img = self._ln_cf(norm, x)
-        hidden = _linear_cf(ff.w_1, None, True, planes=(img, B, N), relu=True, out_planes=True)      # fp16 planes, never fp32
-        return _linear_cf(ff.w_2, None, True, planes=hidden, residual=x)
+        hidden = _linear_cf(ff.w_1, None, True, planes=(img, B, N), relu=True, out_planes=True, two_plane=TWO_PLANE_IMAGES)   # fp16 planes, never fp32
+        return _linear_cf(ff.w_2, None, True, planes=hidden, residual=x, two_plane=TWO_PLANE_IMAGES)
 
     def _pass_cf(self, src, tgt):
         """self.model(src^T, tgt^T, None, None)^T for channel-first src, tgt [B,C,N]: the decoder's output [B,C,N_tgt]"""

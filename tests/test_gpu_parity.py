@@ -1143,6 +1143,14 @@ def test_flash_attention_vs_fp64():
         xinv = float(raw[2 * pb:2 * pb + 4].view(np.float32)[0])
         dec = ((ph + pm / 4096.0) * xinv).transpose(1, 0, 2).reshape(B, N, H * D).transpose(0, 2, 1).reshape(B, H, D, N)
         np.testing.assert_allclose(dec, gotb.astype(np.float64), rtol=2.0 ** -21, atol=np.abs(gotb).max() * 2.0 ** -30)
+        # ... and with an unscaled residual plane (maxima_ready bit 1: what the two-plane form of l3d_pointwise_conv_f16 reads)
+        check(lib().l3d_attention_forward_f16b(ptr(qd), ptr(kd), ptr(vd), B, H, D, N, M, H * D * N, H * D * M, H * D * M,
+                                               float(1 / np.sqrt(D)), ptr(ws), 2, None, ptr(imgb), stream_ptr()), "l3d_attention_forward_f16b")
+        raw2 = imgb.cpu().numpy()
+        assert np.array_equal(raw2[:pb], raw[:pb]) and np.array_equal(raw2[2 * pb:2 * pb + 4], raw[2 * pb:2 * pb + 4])
+        pm2 = raw2[pb:2 * pb].view(np.float16).reshape(H * D // 8, B * N, 8).astype(np.float64)
+        dec2 = ((ph + pm2) * xinv).transpose(1, 0, 2).reshape(B, N, H * D).transpose(0, 2, 1).reshape(B, H, D, N)
+        np.testing.assert_allclose(dec2, gotb.astype(np.float64), rtol=2.0 ** -21, atol=np.abs(gotb).max() * 2.0 ** -25)
     # operands far from unit scale: the per-tensor power-of-two scaling must keep fp32-level accuracy (and not overflow fp16)
     for sq, sk, sv in ((1e-4, 3e2, 1e3), (5e3, 1e-3, 1e-5)):
         B, H, D, N, M = 1, 2, 64, 256, 384
@@ -1253,7 +1261,7 @@ def test_transformer_channel_first_pass():
         want = a[None, :, None] * (x64 - x64.mean(1, keepdims=True)) / (x64.std(1, ddof=1, keepdims=True) + 1e-6) + b[None, :, None]
         y = torch.empty((B, C, N), device="cuda"); img = torch.empty(lib().l3d_f16_image_bytes(1, B * N, C), dtype=torch.uint8, device="cuda")
         tx, ta, tb = dev(x), dev(a), dev(b)                       # held: a temporary's block would be handed to the next allocation
-        check(lib().l3d_layernorm_planes_cf(ptr(tx), ptr(ta), ptr(tb), 1e-6, B, C, N, ptr(y), ptr(img), stream_ptr()), "ln cf")
+        check(lib().l3d_layernorm_planes_cf(ptr(tx), ptr(ta), ptr(tb), 1e-6, B, C, N, ptr(y), ptr(img), 0, stream_ptr()), "ln cf")
         np.testing.assert_allclose(y.cpu().numpy(), want, rtol=2e-6, atol=2e-6)
         # the image against the row kernel's image of the same values laid out [B,N,C]
         rows = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 1))).cuda()
@@ -1285,21 +1293,60 @@ def test_transformer_channel_first_pass():
     import learning3d_amd._lib as _lib
     with torch.no_grad():
         want = ref(torch.from_numpy(a_).double(), torch.from_numpy(b_).double())
-        _lib.LAUNCH_LOG = log = []
-        try:
-            got = net(dev(a_), dev(b_))
-        finally:
-            _lib.LAUNCH_LOG = None
-        assert "l3d_layernorm_planes_cf" in log and "l3d_pointwise_conv_f16[residual]" in log and "l3d_add_transposed" not in log, sorted(set(log))
         T.CHANNEL_FIRST_PASS = False
         try:
             mod = net(dev(a_), dev(b_))
         finally:
             T.CHANNEL_FIRST_PASS = True
-    for g_, m_, w_ in zip(got, mod, want):
-        assert g_.shape == w_.shape and g_.is_contiguous()
-        np.testing.assert_allclose(g_.cpu().numpy(), w_.numpy(), rtol=1e-4, atol=2e-5)
-        assert (g_ - m_).abs().max().item() <= 2e-5 * m_.abs().max().item()
+        # the pass with its plane images' residual planes unscaled (every projection on the two-plane form of the kernel: the default) and
+        # with the scaled images of rounds 3-5
+        for two in (True, False):
+            prev, T.TWO_PLANE_IMAGES = T.TWO_PLANE_IMAGES, two
+            _lib.LAUNCH_LOG = log = []
+            try:
+                got = net(dev(a_), dev(b_))
+            finally:
+                _lib.LAUNCH_LOG = None
+                T.TWO_PLANE_IMAGES = prev
+            tag = "[two-plane]" if two else ""
+            assert "l3d_layernorm_planes_cf" in log and "l3d_add_transposed" not in log, sorted(set(log))
+            for name in ("l3d_pointwise_conv_f16[residual]", "l3d_pointwise_conv_f16[planes]"):
+                assert name + tag in log and (name + "[two-plane]" in log) == two, sorted(set(log))
+            assert ("l3d_pointwise_conv_f16[absmax][two-plane]" in log) == two and ("l3d_pointwise_conv_f16[absmax]" in log) != two, sorted(set(log))
+            for g_, m_, w_ in zip(got, mod, want):
+                assert g_.shape == w_.shape and g_.is_contiguous()
+                np.testing.assert_allclose(g_.cpu().numpy(), w_.numpy(), rtol=1e-4, atol=2e-5)
+                assert (g_ - m_).abs().max().item() <= 2e-5 * m_.abs().max().item()
+    # ---- the two-plane form piece by piece: an unscaled LayerNorm image through the projection in its three output modes, against fp64
+    B, C, N, C1 = 2, 512, 512, 512
+    x = (rng.standard_normal((B, C, N)) * rng.uniform(0.1, 3.0, (B, 1, N))).astype(np.float32)
+    a = rng.uniform(0.5, 1.5, C).astype(np.float32); b = rng.uniform(-0.5, 0.5, C).astype(np.float32)
+    w = (rng.standard_normal((C1, C)) / C ** 0.5).astype(np.float32); sh = (rng.standard_normal(C1) * 0.3).astype(np.float32)
+    w2 = (rng.standard_normal((C1, C1)) / C1 ** 0.5).astype(np.float32)
+    x64 = x.astype(np.float64)
+    ln64 = a[None, :, None] * (x64 - x64.mean(1, keepdims=True)) / (x64.std(1, ddof=1, keepdims=True) + 1e-6) + b[None, :, None]
+    y64 = np.einsum("oc,bcn->bon", w.astype(np.float64), ln64) + sh[None, :, None]
+    tx, ta, tb, tsh = dev(x), dev(a), dev(b), dev(sh)
+    wimg, w2img = _fused.split_weights_f16(dev(w)), _fused.split_weights_f16(dev(w2))
+    res = dev(rng.standard_normal((B, C1, N)).astype(np.float32))
+    outs = {}
+    for flags in (1, 0):
+        img = torch.empty(lib().l3d_f16_image_bytes(1, B * N, C), dtype=torch.uint8, device="cuda")
+        check(lib().l3d_layernorm_planes_cf(ptr(tx), ptr(ta), ptr(tb), 1e-6, B, C, N, None, ptr(img), flags, stream_ptr()), "ln cf")
+        ws = torch.zeros(4, dtype=torch.int32, device="cuda")
+        y_amax = _fused.pointwise_conv_f16(img, B, N, wimg, C, C1, None, tsh, amax=(ws, 256), unscaled=bool(flags))
+        y_res = _fused.pointwise_conv_f16(img, B, N, wimg, C, C1, None, tsh, residual=res, unscaled=bool(flags))
+        him = _fused.pointwise_conv_f16(img, B, N, wimg, C, C1, None, tsh, relu=True, out_planes=True, unscaled=bool(flags))
+        y_chain = _fused.pointwise_conv_f16(him, B, N, w2img, C1, C1, None, None, unscaled=bool(flags))
+        scale = np.abs(y64).max()
+        assert np.abs(y_amax.cpu().numpy() - y64).max() <= 4e-6 * scale, flags
+        assert torch.equal(y_res, res + y_amax), flags
+        mx = ws.view(torch.float32).cpu().numpy()
+        assert mx[0] == np.abs(y_amax[:, :256].cpu().numpy()).max() and mx[1] == np.abs(y_amax[:, 256:].cpu().numpy()).max(), flags
+        c64 = np.einsum("oc,bcn->bon", w2.astype(np.float64), np.maximum(y64, 0))
+        assert np.abs(y_chain.cpu().numpy() - c64).max() <= 4e-6 * np.abs(c64).max(), flags
+        outs[flags] = (y_amax, y_chain)
+    assert (outs[1][0] - outs[0][0]).abs().max().item() <= 2e-6 * scale                 # the two residual conventions agree to fp32 level
     _fused.check_range(sync=True)
 
 

@@ -134,7 +134,7 @@ with torch.no_grad():
         want = a[None, :, None] * (x64 - x64.mean(1, keepdims=True)) / (x64.std(1, ddof=1, keepdims=True) + 1e-6) + b_[None, :, None]
         tx, ta, tb = dev(x), dev(a), dev(b_)
         y = torch.empty((B, C, N), device="cuda")
-        check(lib().l3d_layernorm_planes_cf(ptr(tx), ptr(ta), ptr(tb), 1e-6, B, C, N, ptr(y), None, stream_ptr()), "ln cf")
+        check(lib().l3d_layernorm_planes_cf(ptr(tx), ptr(ta), ptr(tb), 1e-6, B, C, N, ptr(y), None, 0, stream_ptr()), "ln cf")
         rec("layernorm cf vs fp64", y.cpu().numpy(), want, 2e-6, 4e-6)
         C1 = 256 * int(rng.integers(1, 3)); N2 = 256 * int(rng.integers(1, 4)); C0 = 16 * int(rng.integers(2, 30))
         xr = rng.standard_normal((B, N2, C0)).astype(np.float32)
