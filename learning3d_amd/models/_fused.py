@@ -11,6 +11,7 @@ launches, and the two mechanisms that decide WHICH route a model's forward takes
     wait) and an overflowing call is re-run on bf16x3 (fp32's exponent range) before anything is returned.
 Train-mode BatchNorm (batch statistics) takes the per-layer route directly (_train.py)."""
 import ctypes as C
+import os
 import threading
 
 import torch
@@ -233,6 +234,13 @@ def checkpointed(module, impl, *tensors):
         return guarded(lambda: impl(*tensors))
     if not all(t.is_cuda for t in tensors if isinstance(t, torch.Tensor)):
         return impl(*tensors)
+    if TRAIN_DIRECT and module.training and getattr(module, "_l3d_train_direct", False):
+        # module.train() with something to learn (examples/train_dcp.py), for the modules that ask for it (the pointer network, the
+        # SVD head): a backward WILL follow, so the forward runs once, under autograd, on the differentiable routes -- not once on
+        # the fused kernels and again inside the backward (the pointer network's fused forward was 4.5 of a 56 ms DCP step).
+        # eval() with grad enabled keeps the fused forward + recompute.
+        with on_device_of(*tensors):
+            return impl(*tensors)
 
     def apply():
         holder = {}
@@ -242,6 +250,10 @@ def checkpointed(module, impl, *tensors):
     with on_device_of(*tensors):
         return guarded(apply)
 
+
+# module.train() and something requires grad: run a checkpointed module's forward directly under autograd (see `checkpointed`);
+# "0": the fused forward + recompute of rounds 2-5 in every mode (A/B)
+TRAIN_DIRECT = os.environ.get("L3D_TRAIN_DIRECT", "1") != "0"
 
 # Training (module.train() with BatchNorm, or autograd through the conv stack): True = conv / dgrad / wgrad on the HIP
 # GEMMs with rank-count-independent batch statistics (_train.py); False = torch convs + torch BatchNorm.

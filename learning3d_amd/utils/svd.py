@@ -109,6 +109,8 @@ def svd3x3_rotation(H):
 
 
 class SVDHead(nn.Module):
+    _l3d_train_direct = True       # _fused.checkpointed: in train() mode the forward runs once, on the differentiable routes
+
     def __init__(self, emb_dims, input_shape="bnc"):
         super(SVDHead, self).__init__()
         self.emb_dims = emb_dims

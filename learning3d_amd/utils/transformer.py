@@ -419,6 +419,7 @@ class Identity(nn.Module):
 
 class Transformer(nn.Module):
     """reference :219-243.  forward(src [B,C,N], tgt [B,C,N]) -> (src_embedding, tgt_embedding)."""
+    _l3d_train_direct = True       # _fused.checkpointed: in train() mode the forward runs once, on the differentiable routes
 
     def __init__(self, emb_dims, n_blocks, dropout, ff_dims, n_heads):
         super().__init__()
@@ -432,8 +433,9 @@ class Transformer(nn.Module):
                                     nn.Sequential(), nn.Sequential(), nn.Sequential())
 
     def forward(self, *input):
-        """The fused pointer network serves the forward in every grad mode (dropout is None throughout, reference :163-217);
-        a backward recomputes through the reference's op sequence (_fused.checkpointed)."""
+        """The fused pointer network serves the forward of an eval() module in every grad mode (dropout is None throughout, reference
+        :163-217); a backward recomputes through the reference's op sequence (_fused.checkpointed).  A train() module with something
+        to learn runs the forward once, under autograd, on the differentiable routes (_l3d_train_direct)."""
         from ..models import _fused
         return _fused.checkpointed(self, self._forward, input[0], input[1])
 

@@ -220,6 +220,8 @@ def test_pointer_network_training_gradients_vs_fp64(route, monkeypatch):
         a, b = net(src, tgt)
         ((a * w0).sum() + (b * w1).sum()).backward()
     assert "l3d_layernorm_ref_backward" in log and ("l3d_wgrad" in log) == (route == "conv"), log
+    # a train() module runs its forward ONCE, under autograd: no fused forward in front of the backward's own (_fused.checkpointed)
+    assert "l3d_attention_forward_f16b" not in log and "l3d_layernorm_planes_cf" not in log, sorted(set(log))
     assert ("l3d_bmm_f32" in log and "l3d_softmax_rows" in log) == (route == "rows"), log
     if route == "rows":
         # 12 Linear layers x 2 passes x (forward, dgrad, wgrad; the bias gradient is l3d_colsum_rows) + 3 attention cores x 2 passes x
