@@ -4,6 +4,8 @@ The reference needs the separately built `pointnet2_cuda` extension (and raises 
 it); here the same layers run on libl3d_hip.so: FPS, gather, ball query / kNN, grouping are the HIP
 kernels of grouping.hip / knn.hip, and every Conv2d/Conv1d(k=1)+BN+ReLU stack is the fp32-MFMA GEMM
 of mlp.hip with BN folded (inference).  Parameter names match the reference."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -22,6 +24,14 @@ FACTOR_FIRST_LAYER = True    # grouped first layers as per-point products + a ga
 # cached: 5.00 -> 5.13 ms -- closer, still not a gain; stays off.
 F16_GROUPED_STACK = False
 F16_GROUPED_MIN_ROWS = 0      # rows (S * K) per cloud from which a grouped stack takes the f16x2 chain when F16_GROUPED_STACK is on
+# A per-point (ungrouped) stack over at least F16_PLAIN_MIN_ROWS points of the whole batch as an f16x2 chain (one split pass, then
+# conv_f16.hip with plane images between the layers) instead of bf16x3 / fp32-MFMA layers: feature propagation's 272 -> 256 -> 256 and
+# the head's 256 -> 128 at N = 8192 (reference models/flownet3d.py:271-286, :325-327).  Correct (1.5e-8 from the other route) and OFF:
+# the three GEMMs drop from 625 to 378 us, but the two split passes over 285 / 268 MB of fp32 input (maximum + split: 195 us each with
+# the 16-byte absmax kernel, 545 before it) take more back -- forward 4.92 ms against 4.50 (tools/flownet_plain_ab.py, three interleaved
+# pairs).  It would pay with the producers (l3d_three_interpolate_concat, the stack's own last layer) writing plane images; not built.
+F16_PLAIN_STACK = os.environ.get("L3D_F16_PLAIN_STACK", "0") != "0"
+F16_PLAIN_MIN_ROWS = 65536
 
 
 def _mlp_stack(x, convs, bns, module, pool=False, cl_shape=None):
@@ -41,6 +51,25 @@ def _mlp_stack(x, convs, bns, module, pool=False, cl_shape=None):
             shp = x.shape
             h = x.reshape(shp[0], shp[1], -1)
         last = len(convs) - 1
+        if (F16_PLAIN_STACK and cl_shape is None and not pool and len(shp) == 3 and _fused.gemm_arith() == "f16x2"
+                and shp[0] * shp[2] >= F16_PLAIN_MIN_ROWS
+                and all(_fused.f16_eligible(h.shape[1] if i == 0 else convs[i - 1].out_channels, c.out_channels, shp[2])
+                        for i, c in enumerate(convs))):
+            # a per-point stack over many points (feature propagation and the head's conv1 at N = 8192, reference :271-286, :325-327):
+            # one split pass over the input, then the f16x2 kernel layer by layer, plane images in between
+            img = _fused.split_rows_f16(h, channel_first=True)
+            cin = h.shape[1]
+            for i, (conv, bn) in enumerate(zip(convs, bns)):
+                w, sc, sh = _fused.fold_conv_bn(conv, bn)
+                hit = conv.__dict__.get("_l3d_w_f16p")
+                if hit is None or hit[0] != (w.data_ptr(), w._version, cin):
+                    wp = F.pad(w, (0, cin - w.shape[1])).contiguous() if cin > w.shape[1] else w     # zero columns for zero channels
+                    hit = ((w.data_ptr(), w._version, cin), _fused.split_weights_f16(wp))
+                    conv.__dict__["_l3d_w_f16p"] = hit
+                if i == last:
+                    return _fused.pointwise_conv_f16(img, shp[0], shp[2], hit[1], cin, w.shape[0], sc, sh, relu=True)
+                img = _fused.pointwise_conv_f16(img, shp[0], shp[2], hit[1], cin, w.shape[0], sc, sh, relu=True, out_planes=True)
+                cin = w.shape[0]
         for i, (conv, bn) in enumerate(zip(convs, bns)):
             w, sc, sh = _fused.fold_conv_bn(conv, bn)
             if i == 0 and cl_shape is None and h.shape[1] > w.shape[1]:
