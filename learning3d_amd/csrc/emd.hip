@@ -108,17 +108,29 @@ __global__ __launch_bounds__(256) void emd_sweep_kernel(const EmdSweep A)
         const int lend = min(A.ncols, l0 + EMD_TILE) - l0;
         const int lpad = (lend + 4 * S * U - 1) / (4 * S * U) * (4 * S * U);     // zero-weight phantom points: + 0.0f changes no bit
         __syncthreads();
-        for (int l = tid; l < lpad; l += 256) {
-            float x = 0.f, y = 0.f, z = 0.f, a = 0.f, bw = 0.f;
-            if (l < lend) {
-                const int gl = l0 + l;
-                x = pc[gl * 3]; y = pc[gl * 3 + 1]; z = pc[gl * 3 + 2];
-                a = wa ? wa[gl] : consta;
-                if (FUSED) bw = wb[gl];
+        {
+            // the tile's records: every thread's EMD_TILE / 256 points are loaded from clamped indices with NO condition around the
+            // loads -- all of them in flight at once, one trip to memory per tile instead of one per point (n = 1024 is one tile per
+            // sweep, and with one or two waves per SIMD nobody else covers the trip) -- then zeroed where they are padding
+            constexpr int PT = EMD_TILE / 256;
+            float x[PT], y[PT], z[PT], a[PT], bw[PT];
+#pragma unroll
+            for (int it = 0; it < PT; it++) {
+                const int gl = l0 + min(tid + 256 * it, lend - 1);
+                x[it] = pc[gl * 3]; y[it] = pc[gl * 3 + 1]; z[it] = pc[gl * 3 + 2];
+                a[it] = wa ? wa[gl] : consta;
+                bw[it] = FUSED ? wb[gl] : 0.f;
             }
-            float *f0 = (float *)r0 + (l >> 1) * 4 + (l & 1), *f1 = (float *)r1 + (l >> 1) * 4 + (l & 1);
-            f0[0] = x; f0[2] = y; f1[0] = z; f1[2] = a;
-            if (FUSED) ((float *)r2)[l] = bw;
+#pragma unroll
+            for (int it = 0; it < PT; it++) {
+                const int l = tid + 256 * it;
+                if (l < lpad) {
+                    const bool in = l < lend;
+                    float *f0 = (float *)r0 + (l >> 1) * 4 + (l & 1), *f1 = (float *)r1 + (l >> 1) * 4 + (l & 1);
+                    f0[0] = in ? x[it] : 0.f; f0[2] = in ? y[it] : 0.f; f1[0] = in ? z[it] : 0.f; f1[2] = in ? a[it] : 0.f;
+                    if (FUSED) ((float *)r2)[l] = in ? bw[it] : 0.f;
+                }
+            }
         }
         __syncthreads();
         // uniform trip count (scalar loop control, DPP sees every lane) in whole groups of 2U records per lane: a loop
