@@ -366,58 +366,6 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
     const int a_off = kgl * WR + (wm * 64 + (lane & 31)) * 16;                       // + a*512 + p*2*WR
     const int b_off = WBYTES + kgl * XR + (wn * 128 + (lane & 31)) * 16;             // + c*512 + p*2*XR
 
-#ifdef CF_PF
-    // CF_PF (two weight planes only): FOUR stages, DMA three chunks ahead, and the six fragments of a chunk's FIRST product (M, h)
-    // read one chunk early -- the barrier at the top of chunk kc publishes chunks kc AND kc+1, so the eight MFMAs of the first
-    // product start straight behind it while the other six fragments (H, m) arrive under them.  Two register sets ping-pong.
-    if constexpr (NPW == 2) {
-        issue(0);
-        if (nk > 1) issue(1);
-        if (nk > 2) issue(2);
-        f16x8 F0A[2], F0B[4], F1A[2], F1B[4];
-        auto read_first = [&](int st, f16x8 (&FA)[2], f16x8 (&FB)[4]) {
-            const unsigned char *bs = lds + st * STAGE;
-#pragma unroll
-            for (int c = 0; c < 4; c++) FB[c] = *(const f16x8 *)(bs + b_off + c * 512);                     // h plane of x
-#pragma unroll
-            for (int a = 0; a < 2; a++) FA[a] = *(const f16x8 *)(bs + a_off + a * 512 + 2 * WR);           // M plane of W
-        };
-        auto chunk = [&](int kc, f16x8 (&FA)[2], f16x8 (&FB)[4], f16x8 (&NA)[2], f16x8 (&NB)[4]) {
-            if (kc + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // chunk kc+2's four pieces may still fly
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                                          // chunks <= kc+1 visible; stage (kc+3)%4 free
-            const int st = kc & 3;
-            const unsigned char *base = lds + st * STAGE;
-            f16x8 RA[2], RB[4];
-#pragma unroll
-            for (int c = 0; c < 4; c++) RB[c] = *(const f16x8 *)(base + b_off + c * 512 + 2 * XR);          // m plane of x
-#pragma unroll
-            for (int a = 0; a < 2; a++) RA[a] = *(const f16x8 *)(base + a_off + a * 512);                   // H plane of W
-            if (kc + 1 < nk) read_first((kc + 1) & 3, NA, NB);
-            const bool more = kc + 3 < nk;
-            const int nst = (kc + 3) & 3;
-#pragma unroll
-            for (int n = 0; n < 24; n++) {
-                const int prod = n >> 3, a = (n >> 2) & 1, c = n & 3;
-                if (prod == 0) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FA[a], FB[c], acc[a][c], 0, 0, 0);        // M h
-                else if (prod == 1) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(RA[a], RB[c], acc[a][c], 0, 0, 0);   // H m
-                else acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(RA[a], FB[c], acc[a][c], 0, 0, 0);                  // H h
-                if (n % 6 == 3) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (more) issue_one(nst, n / 6);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        };
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(0) : "memory");                  // prologue: chunk 0's first-product fragments
-        __builtin_amdgcn_s_barrier();
-        read_first(0, F0A, F0B);
-        for (int kc = 0; kc < nk; kc += 2) {
-            chunk(kc, F0A, F0B, F1A, F1B);
-            if (kc + 1 < nk) chunk(kc + 1, F1A, F1B, F0A, F0B);
-        }
-    } else {
-#endif
     issue(0);
     if (nk > 1) issue(1);
     int stage = 0;
@@ -482,9 +430,6 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
         stage = stage == 2 ? 0 : stage + 1;
         CFT(3)
     }
-#ifdef CF_PF
-    }
-#endif
 #ifdef CF_TIMING
     if (lane == 0) {
         long long *o = (long long *)y + ((size_t)blockIdx.x * 8 + wave) * 8;
@@ -823,14 +768,6 @@ static int cf_launch(const void *x_planes, const void *w_planes, const float *sc
                            (const uint4 *)xp, (const uint4 *)(xp + xpb), (const uint4 *)wp, (const uint4 *)(wp + 2 * wpb),
                            (const float *)(wp + 3 * wpb), (const float *)(xp + 2 * xpb), scale, shift, shift_bstride, B, Cin, Cout, N, relu, y);
 #else
-#ifdef CF_PF
-        {
-            static bool once = [] { return hipFuncSetAttribute((const void *)conv_f16_kernel<false, false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                               4 * (4 * CF_TM * 16 + 4 * CF_TN * 16)) == hipSuccess; }();
-            (void)once;
-        }
-        hipLaunchKernelGGL((conv_f16_kernel<false, false, false, 2>), grid, block, 4 * (4 * CF_TM * 16 + 4 * CF_TN * 16), st, CF_ARGS);
-#else
 #ifdef CF_PERSIST
         {
             // persistent form: one workgroup per CU (a multiple of 8, so that a workgroup's tiles stay on its XCD's Cout group)
@@ -848,7 +785,6 @@ static int cf_launch(const void *x_planes, const void *w_planes, const float *sc
         }
 #endif
         hipLaunchKernelGGL((conv_f16_kernel<false, false, false, 2>), grid, block, 3 * (4 * CF_TM * 16 + 4 * CF_TN * 16), st, CF_ARGS);
-#endif
 #endif
         return l3d_check_launch();
     }
