@@ -31,16 +31,19 @@ q = torch.randn(NB, 1024, 4, 128, generator=g).cuda().transpose(1, 2)
 k = torch.randn(NB, 1024, 4, 128, generator=g).cuda().transpose(1, 2)
 p = torch.randn(NB, 4, 1024, 1024, generator=g).cuda()
 cases = [
-    ("linear fwd  x W^T        Rx512x512", x, w.t(), 1),
-    ("linear fwd  x W2^T       Rx1024x512", x, w2.t(), 1),
+    ("linear fwd  x W^T (w.t() view)      Rx512x512", x, w.t(), 1),
+    ("linear fwd  x W^T (own tensor: the route)  Rx512x512", x, w.t().contiguous(), 1),
+    ("linear fwd  x W2^T (own tensor)  Rx1024x512", x, w2.t().contiguous(), 1),
     ("dgrad       g W          Rx512x512", gy, w, 1),
     ("wgrad       g^T x        512x512xR split", gy.t(), x, _rows._split_parts(512, 512, R)),
-    ("bias grad   1^T g        1x512xR split", torch.ones(1, R, device="cuda"), gy, _rows._split_parts(1, 512, R)),
     ("q k^T       32 x 1024x1024x128", q, k.transpose(-1, -2), 1),
     ("p v         32 x 1024x128x1024", p, k, 1),
     ("p^T dO      32 x 1024x128x1024", p.transpose(-1, -2), q, 1),
     ("dS^T q", p.transpose(-1, -2), q, 1),
 ]
+tc = t_us(lambda: _rows.colsum(gy))
+tt = t_us(lambda: gy.sum(0))
+print(f"{'bias grad  colsum(g) (l3d_colsum_rows)  Rx512':48s} hip {tc:8.1f} us   torch sum(0) {tt:8.1f} us", flush=True)
 for name, a, b, parts in cases:
     flop = 2.0 * a.shape[-2] * a.shape[-1] * b.shape[-1] * (a.numel() // (a.shape[-2] * a.shape[-1]))
     th = t_us(lambda: _rows.bmm(a, b, parts=parts))
