@@ -125,7 +125,17 @@ __global__ __launch_bounds__(256, (YT == 2 && (AM == 0 || BM == 0)) ? 2 : BM_OCC
     const int wm = wave & 1, wn = wave >> 1;
     const int part = blockIdx.z % parts, bz = blockIdx.z / parts;
     const int i1 = bz / nb2, i2 = bz % nb2;
-    const int m0 = blockIdx.y * BM_T, n0 = blockIdx.x * TN;
+    // Tile order.  Workgroups are dispatched x fastest and workgroup L runs on XCD L % 8, each with its own L2: left alone, the column
+    // tiles of one row tile land on DIFFERENT XCDs and every one of them fetches the row tile's A rows from HBM / the memory-side cache
+    // again (133 MB fetched for 67 MB of x at 32768 x 512 x 512, profiles/round6_pmc_bmm12.txt).  Remapped so that a row tile's column
+    // tiles are consecutive slots of ONE XCD (conv_f16.hip's order).
+    int bx = blockIdx.x, by = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {
+        const int L = blockIdx.y * gridDim.x + blockIdx.x, xcd = L & 7, slot = L >> 3;
+        bx = slot % gridDim.x;
+        by = (slot / gridDim.x) * 8 + xcd;
+    }
+    const int m0 = by * BM_T, n0 = bx * TN;
     const float *__restrict__ a = A.p + (long)i1 * A.s1 + (long)i2 * A.s2;
     const float *__restrict__ b = B.p + (long)i1 * B.s1 + (long)i2 * B.s2;
     // this part's K range: chunks of 16, split evenly
