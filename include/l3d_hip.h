@@ -450,10 +450,18 @@ int l3d_split_f16_rows(const float *x, long rows, int C, int channel_first, int 
  * shift may be per cloud (shift_bstride = Cout, else 0). */
 #define L3D_CONV_F16_TWO_PLANE 1
 #define L3D_CONV_F16_OUT_UNSCALED 2
+#define L3D_CONV_F16_SHIFT_N 4      /* with TWO_PLANE, y only: shift [N] is indexed by the output column -- see l3d_split_f16_operand */
 int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
                            int shift_bstride, int B, int Cin, int Cout, int N, int relu, int flags, float *y,
                            const float *residual, void *out_img, const float *obs, float *ypool, int pool,
                            void *amax_out, int amax_cdiv, l3d_stream_t stream);
+/* One operand of a training-path product on the f16x2 kernel (an nn.Linear over rows, utils/transformer.py:183-189 of the reference, and
+ * its dgrad): x [rows][C] fp32 with row stride `row_stride` -> fp16 planes h | m of x 2^T, UNSCALED residual, T from the window's maximum.
+ * kind 0: an activation image (l3d_f16_image_bytes(1, rows, C)); kind 1: the two planes in the slots of a weight image
+ * (l3d_f16_image_bytes(2, rows, C)), i.e. the w_planes operand of l3d_pointwise_conv_f16 with L3D_CONV_F16_TWO_PLANE.  With the batch's
+ * rows as w_planes (kind 1), the layer's [Cout][Cin] matrix as x_planes (kind 0), B = 1, "Cout" = rows, "N" = Cout and
+ * L3D_CONV_F16_SHIFT_N the kernel's output is y [rows][Cout] = x W^T + b, row-major.  rows % 256 == 0 and Cout % 256 == 0 for the GEMM. */
+int l3d_split_f16_operand(const float *x, long rows, int C, long row_stride, int kind, void *dst, int *range_flag, l3d_stream_t stream);
 /* First layer of a per-point MLP (Cin <= 8; pcn.py:26-33 conv1 3 -> 128, pointnet.py:42) written straight as an activation
  * image: x [B][N][Cin] (channel_last) or [B][Cin][N], w [Cout][Cin], shift [Cout] or NULL, xmax = device float >= max|x|
  * (the plane scale follows from max_r(|shift_r| + xmax sum_c |w_rc|)); raises *range_flag if xmax was not a bound. */

@@ -75,6 +75,7 @@ SIGNATURES = {
     "l3d_sa_mlp3_fused": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "l3d_bmm_f32": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _I, _P, _P],
     "l3d_softmax_rows": [_P, _P, _L, _I, _F, _P, _P],
+    "l3d_split_f16_operand": [_P, _L, _I, _L, _I, _P, _P, _P],
     "l3d_colsum_rows_workspace_bytes": [_L, _I],
     "l3d_colsum_rows": [_P, _L, _I, _L, _P, _P, _P],
     "l3d_layernorm_planes": [_P, _P, _P, _F, _L, _I, _P, _P, _P],

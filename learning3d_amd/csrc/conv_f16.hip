@@ -82,7 +82,27 @@ __global__ __launch_bounds__(256) void cf_absmax_kernel(const float *__restrict_
     for (size_t e = gid; e < head; e += gsz) m = fmaxf(m, fabsf(src[e]));
     for (size_t e = head + 4 * n4 + gid; e < n; e += gsz) m = fmaxf(m, fabsf(src[e]));
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));          // non-negative floats order like their bits
+    // one atomic per workgroup, and only if it would raise the value: thousands of atomics on ONE address are serialised by the L2
+    // (8192 of them cost more than reading 67 MB did)
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const unsigned bits = __float_as_uint(m);                               // non-negative floats order like their bits
+        if (bits > __atomic_load_n(out, __ATOMIC_RELAXED)) atomicMax(out, bits);
+    }
+}
+
+// the same over the [R][C] window of a matrix with row stride `stride` (a column slice of a wider tensor): one workgroup per 64 rows
+__global__ __launch_bounds__(256) void cf_absmax_rows_kernel(const float *__restrict__ src, long R, int C, long stride, unsigned *__restrict__ out)
+{
+    float m = 0.f;
+    const long r0 = (long)blockIdx.x * 64, r1 = min(R, r0 + 64);
+    for (long r = r0; r < r1; r++)
+        for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, fabsf(src[r * stride + c]));
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
 
 __device__ __forceinline__ int cf_scale_exp(float wmax)
@@ -182,8 +202,9 @@ __global__ __launch_bounds__(256) void cf_split_x_kernel(const float *__restrict
 #define CFS_STRIDE (CFS_ROWS + 1)            // cells per octet line in LDS (+1: bank spread)
 __global__ __launch_bounds__(256) void cf_split_x_cl_kernel(const float *__restrict__ src, long R, int C, const unsigned *__restrict__ amax,
                                                             uint4 *__restrict__ ph, uint4 *__restrict__ pm, float *__restrict__ inv,
-                                                            int *__restrict__ range_flag)
+                                                            int *__restrict__ range_flag, long sstride = 0, float rs = 4096.0f)
 {
+    if (sstride == 0) sstride = C;                 // row stride of src in floats; rs = 2^12: m' = f16((X - h) 2^12), rs = 1: unscaled residual
     __shared__ uint4 lh[CFS_OCT * CFS_STRIDE], lm[CFS_OCT * CFS_STRIDE];
     const int T = cf_act_exp(__uint_as_float(*amax));
     const float up = ldexpf(1.0f, T);
@@ -202,8 +223,8 @@ __global__ __launch_bounds__(256) void cf_split_x_cl_kernel(const float *__restr
 #pragma unroll
             for (int e = 0; e < 8; e++) v[e] = 0.f;
             if (row < R && o * 8 < C) {
-                const float *p = src + (size_t)row * C + o * 8;
-                if (o * 8 + 8 <= C && (C & 3) == 0) {
+                const float *p = src + (size_t)row * sstride + o * 8;
+                if (o * 8 + 8 <= C && (C & 3) == 0 && (sstride & 3) == 0) {
                     const f32x4 a = *(const f32x4 *)p, b = *(const f32x4 *)(p + 4);
                     v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
                 } else {
@@ -217,7 +238,7 @@ __global__ __launch_bounds__(256) void cf_split_x_cl_kernel(const float *__restr
                 const float x = v[e] * up;
                 big = fmaxf(big, fabsf(x));
                 h[e] = (_Float16)x;
-                m[e] = (_Float16)((x - (float)h[e]) * 4096.0f);
+                m[e] = (_Float16)((x - (float)h[e]) * rs);
             }
             lh[oc * CFS_STRIDE + r] = *(const uint4 *)h;
             lm[oc * CFS_STRIDE + r] = *(const uint4 *)m;
@@ -269,7 +290,10 @@ __device__ long long *g_cf_timeline;
 // OUT2 (two weight planes only; its own instantiation): the plane-image output carries an UNSCALED residual too, so that the next layer
 // runs the two-plane form as well -- the pointer network's projections (utils/transformer.py:163-194 of the reference) then all do:
 // 119 -> 94 us at 512 -> 1024 over 32768 rows, the difference between the three- and the two-plane main loop.
-template <bool NARROW, bool AMAX, bool GROUP, int NPW = 3, bool RESID = false, bool OUT2 = false>
+// SHIFTN (two weight planes, fp32 output; its own instantiation): `shift` is indexed by the output COLUMN n instead of the row co -- the
+// bias of an nn.Linear whose rows are the "weight" operand and whose [Cout][Cin] matrix is the "activation" (l3d_split_f16_operand:
+// the training path's y [rows][Cout] = x W^T + b, models/_rows.py).
+template <bool NARROW, bool AMAX, bool GROUP, int NPW = 3, bool RESID = false, bool OUT2 = false, bool SHIFTN = false>
 __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__ xh, const uint4 *__restrict__ xm,
                                                        const uint4 *__restrict__ wH, const uint4 *__restrict__ wHs,
                                                        const uint4 *__restrict__ wM, const float *__restrict__ winv,
@@ -284,6 +308,7 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
     static_assert(NPW == 3 || (NPW == 2 && !NARROW && !GROUP), "two weight planes: wide tile");
     static_assert(!RESID || (!NARROW && !AMAX && !GROUP), "residual epilogue: wide tile, fp32 output");
     static_assert(!OUT2 || (NPW == 2 && !AMAX && !RESID), "unscaled output image: the two-plane form");
+    static_assert(!SHIFTN || (NPW == 2 && !AMAX && !RESID && !OUT2), "column-indexed shift: the plain two-plane form");
     constexpr int WBYTES = 2 * NPW * WR, STAGE = WBYTES + 4 * XR;
     constexpr int NPIECE = NARROW ? 6 : (NPW == 3 ? 5 : 4);     // DMA instructions per wave and chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -593,6 +618,13 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
     if constexpr (GROUP) return;
     float *yb = y + (size_t)b * Cout * N;
     const float *rb = RESID ? obs + (size_t)b * Cout * N : nullptr;
+    float shn[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (SHIFTN) {
+        if (shift) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) shn[c] = shift[n0 + wn * 128 + c * 32 + (lane & 31)];
+        }
+    }
     float amax_nan = 0.f;
     float amax_run = 0.f;                          // AMAX: max |y| of this lane's 128 outputs (round 6: a running maximum; parking |v| in
                                                    // the dead accumulators for a later reduction cost the instantiation 12 - 16 spilled registers)
@@ -602,10 +634,10 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
         for (int r = 0; r < 16; r++) {
             const int co = co0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const float sc = (scale ? scale[co] : 1.f) * inv;
-            const float sh = shift ? shift[(size_t)b * shift_bstride + co] : 0.f;
+            const float sh = (!SHIFTN && shift) ? shift[(size_t)b * shift_bstride + co] : 0.f;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                float v = acc[a][c][r] * sc + sh;
+                float v = acc[a][c][r] * sc + (SHIFTN ? shn[c] : sh);
                 if (relu) v = l3d_act(v, relu);
                 if constexpr (RESID) v = rb[(size_t)co * N + n0 + wn * 128 + c * 32 + (lane & 31)] + v;
                 // DGCNN's conv5 (the two-plane instantiation): 134 MB of fp32 output that nothing on the chip reads back soon.  As ordinary
@@ -619,7 +651,7 @@ __global__ __launch_bounds__(512) void conv_f16_kernel(const uint4 *__restrict__
 #define CF_STORE 1     // the two-plane instantiation's output stores: 0 plain, 1 nt (default), 2 sc1 (write-through, agent), 3 sc0 sc1 (system)
 #endif
                 float *dst_ = &yb[(size_t)co * N + n0 + wn * 128 + c * 32 + (lane & 31)];
-                if constexpr (NPW == 2 && !AMAX && !RESID) {
+                if constexpr (NPW == 2 && !AMAX && !RESID && !SHIFTN) {
                     if (CF_STORE == 1) __builtin_nontemporal_store(v, dst_);
                     else if (CF_STORE == 2) __hip_atomic_store(dst_, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     else if (CF_STORE == 3) __hip_atomic_store(dst_, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -720,11 +752,40 @@ extern "C" int l3d_split_f16_rows(const float *x, long rows, int C, int channel_
     return l3d_check_launch();
 }
 
+// One operand of a training-path GEMM (models/_rows.py: an nn.Linear over rows and its dgrad on the two-plane form of the f16x2 kernel):
+// x [rows][C] fp32 with row stride `row_stride` -> two fp16 planes h | m of x 2^T with an UNSCALED residual, T from the window's own maximum.
+//   kind 0: an activation image (l3d_f16_image_bytes(1, rows, C)): the x_planes operand of l3d_pointwise_conv_f16 with L3D_CONV_F16_TWO_PLANE
+//   kind 1: the same two planes in the slots of a WEIGHT image (l3d_f16_image_bytes(2, rows, C): H at plane 0, M at plane 2, 2^-T behind
+//           them) -- the w_planes operand of the two-plane form, which reads exactly those.  With the rows of a batch as the "weight" and
+//           the layer's [Cout][Cin] matrix as the "activation" the kernel's [B][Cout][N] output IS y [rows][Cout], row-major.
+extern "C" int l3d_split_f16_operand(const float *x, long rows, int C, long row_stride, int kind, void *dst, int *range_flag, l3d_stream_t stream)
+{
+    L3D_REQUIRE(x && dst && rows > 0 && C > 0 && row_stride >= C && (kind == 0 || kind == 1));
+    if ((((size_t)dst) & 15) || rows > 2147483647L) return L3D_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t pb = l3d_f16_plane_bytes(rows, C);
+    unsigned char *d = (unsigned char *)dst;
+    uint4 *ph = (uint4 *)d, *pm = (uint4 *)(d + (kind ? 2 : 1) * pb);
+    float *inv = (float *)(d + (kind ? 3 : 2) * pb);
+    unsigned *amax = (unsigned *)(inv + 1);
+    if (hipMemsetAsync(inv, 0, 16, st) != hipSuccess) return L3D_ERR_LAUNCH;
+    if (row_stride == C) {
+        const size_t n = (size_t)rows * C;
+        const long nblk = l3d_divup((long)n, 4096);
+        hipLaunchKernelGGL(cf_absmax_kernel, dim3((unsigned)(nblk > 2048 ? 2048 : nblk)), dim3(256), 0, st, x, n, amax);
+    } else {
+        hipLaunchKernelGGL(cf_absmax_rows_kernel, dim3((unsigned)l3d_divup(rows, 64L)), dim3(256), 0, st, x, rows, C, row_stride, amax);
+    }
+    hipLaunchKernelGGL(cf_split_x_cl_kernel, dim3((unsigned)l3d_divup(rows, (long)CFS_ROWS), (unsigned)l3d_divup((C + 7) / 8, CFS_OCT)), dim3(256), 0,
+                       st, x, rows, C, (const unsigned *)amax, ph, pm, inv, range_flag, row_stride, 1.0f);
+    return l3d_check_launch();
+}
+
 // x_act: an activation image (l3d_f16_act_bytes), w_planes: a weight image (l3d_conv_f16_weight_bytes)
 static int cf_launch(const void *x_planes, const void *w_planes, const float *scale, const float *shift, int shift_bstride, int B,
                      int Cin, int Cout, int N, int relu, float *y, void *out_img, const float *obs, float *ypool, int pool,
                      unsigned *amax_out, int amax_cdiv, hipStream_t st, bool two_plane = false, const float *resid = nullptr,
-                     bool out_unscaled = false)
+                     bool out_unscaled = false, bool shift_n = false)
 {
     // wide tile (256 x 256) when Cout allows it, else the narrow one (128 x 512)
     const bool narrow = Cout % CF_TM != 0;
@@ -747,6 +808,11 @@ static int cf_launch(const void *x_planes, const void *w_planes, const float *sc
     if (group && amax_out) return L3D_ERR_UNSUPPORTED;
     constexpr size_t lds2 = 3 * (4 * CF_TM * 16 + 4 * CF_TN * 16);             // the two-plane form's three stages
     if (out_unscaled && !(two_plane && out_img && !ypool)) return L3D_ERR_UNSUPPORTED;
+    if (shift_n) {                                 // the training path's rows-as-weights product: plain two-plane form, bias along n
+        if (!two_plane || narrow || group || amax_out || ypool || out_img || resid || !y || shift_bstride) return L3D_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL((conv_f16_kernel<false, false, false, 2, false, false, true>), grid, block, lds2, st, CF_ARGS);
+        return l3d_check_launch();
+    }
     if (resid) {
         if (narrow || group || amax_out || ypool || out_img || !y) return L3D_ERR_UNSUPPORTED;
         obs = resid;
@@ -815,6 +881,8 @@ static int cf_launch(const void *x_planes, const void *w_planes, const float *sc
 //        l3d_edgeconv_forward_f16b with out_mode 2, l3d_layernorm_planes / l3d_attention_forward_f16b / this kernel when asked): the Hs
 //        plane of the weight image is not read (wide tile; y, y + residual, y + amax_out, or out_img with flag 2).
 //        2 (L3D_CONV_F16_OUT_UNSCALED) -- out_img gets an unscaled residual plane as well (needs flag 1).
+//        4 (L3D_CONV_F16_SHIFT_N) -- shift [N] is indexed by the output column (needs flag 1; y only): with w_planes = the rows of a batch
+//        (l3d_split_f16_operand kind 1) and x_planes = a layer's [Cout][Cin] matrix (kind 0), y [1][rows][Cout] = x W^T + b.
 // shift may be per cloud (shift_bstride = Cout).  Cin % 16 == 0; Cout % 256 == 0 and N % 256 == 0, or Cout % 128 == 0 and N % 512 == 0.
 extern "C" int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes, const float *scale, const float *shift,
                                       int shift_bstride, int B, int Cin, int Cout, int N, int relu, int flags, float *y,
@@ -822,10 +890,10 @@ extern "C" int l3d_pointwise_conv_f16(const void *x_planes, const void *w_planes
                                       void *amax_out, int amax_cdiv, l3d_stream_t stream)
 {
     L3D_REQUIRE(x_planes && w_planes && (y || out_img || ypool) && (!out_img || obs) && (!residual || y) && (!amax_out || (y && amax_cdiv > 0)) &&
-                B > 0 && Cin > 0 && Cout > 0 && N > 0 && (flags & ~3) == 0);
+                B > 0 && Cin > 0 && Cout > 0 && N > 0 && (flags & ~7) == 0);
     if (y && (out_img || ypool)) return L3D_ERR_UNSUPPORTED;                  // the epilogue writes fp32 rows OR planes / pooled maxima
     return cf_launch(x_planes, w_planes, scale, shift, shift_bstride, B, Cin, Cout, N, relu, y, out_img, obs, ypool, pool,
-                     (unsigned *)amax_out, amax_cdiv, (hipStream_t)stream, (flags & 1) != 0, residual, (flags & 2) != 0);
+                     (unsigned *)amax_out, amax_cdiv, (hipStream_t)stream, (flags & 1) != 0, residual, (flags & 2) != 0, (flags & 4) != 0);
 }
 
 // ---------------------------------------------------------------------------------------------

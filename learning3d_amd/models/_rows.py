@@ -8,6 +8,7 @@ utils/svd.py:27-31 (scores -> softmax -> src_corr), utils/model_common_utils.py:
 the gradients are what torch.autograd derives for those op sequences.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -153,14 +154,61 @@ def attention_core(query, key, value, scale):
     return matmul(p, value, like=query), p
 
 
+# The Linear layers' forward and dgrad as f16x2 products (three fp16 MFMA products per fp32 product, the arithmetic of the inference path):
+# the rows of the batch are the kernel's "weight" operand, the layer's matrix its "activation" operand, so the output is [rows, Cout]
+# row-major like everything else here (l3d_split_f16_operand + l3d_pointwise_conv_f16 with TWO_PLANE | SHIFT_N).  One split pass per
+# operand (maximum + planes); the weight gradient stays the split-K fp32-MFMA product.  "fp32": every product on l3d_bmm_f32 (rounds 4-5).
+TRAIN_GEMM = os.environ.get("L3D_TRAIN_GEMM", "f16x2")
+_A_IMG = {}              # the last row operand's image: the q, k, v projections of a self-attention sublayer share their input
+
+
+def _f16_ok(rows, K, N):
+    return TRAIN_GEMM == "f16x2" and rows % 256 == 0 and N % 256 == 0 and K % 16 == 0 and K >= 32 and rows >= 4096
+
+
+def _operand(t, kind):
+    """l3d_split_f16_operand of a 2-D fp32 tensor whose rows are contiguous (row stride >= columns)"""
+    rows, Cn = t.shape
+    img = torch.empty(lib().l3d_f16_image_bytes(2 if kind else 1, rows, Cn), dtype=torch.uint8, device=t.device)
+    check(lib().l3d_split_f16_operand(ptr(t), rows, Cn, t.stride(0), kind, ptr(img), None, stream_ptr()), "l3d_split_f16_operand")
+    return img
+
+
+def _row_operand(x):
+    """the rows' image (kind 1), kept for the next call with the SAME tensor (same memory, same version): a self-attention sublayer's
+    three projections read one LayerNorm output.  The cache holds the tensor, so its memory cannot be handed to another one meanwhile."""
+    key = (x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride()), str(x.device))
+    hit = _A_IMG.get("last")
+    if hit is not None and hit[0] == key:
+        return hit[2]
+    img = _operand(x, 1)
+    _A_IMG["last"] = (key, x, img)
+    return img
+
+
+def _f16_product(a_img, rows, K, w_img, N, bias, relu):
+    """y [rows, N] = act(A B^T + bias): A = the rows' image (kind 1, [rows][K]), B = an activation-kind image of a [N][K] matrix"""
+    y = torch.empty((rows, N), dtype=torch.float32, device=a_img.device)
+    flags = 1 | (4 if bias is not None else 0)
+    check(lib().l3d_pointwise_conv_f16(ptr(w_img), ptr(a_img), None, ptr(bias), 0, 1, K, rows, N, int(bool(relu)), flags,
+                                       ptr(y), None, None, None, None, 0, None, 0, stream_ptr()), "l3d_pointwise_conv_f16[rows]")
+    return y
+
+
 class _LinearRows(torch.autograd.Function):
     """y = act(x W^T + b) over rows x [R, Cin]; dx = g W, dW = g^T x (split-K, parts summed in order), db = 1^T g"""
 
     @staticmethod
     def forward(ctx, x, w, b, relu):
-        # W^T as its own [Cin, Cout] tensor (a 1 MB copy): l3d_bmm_f32 then stages it with 16-byte LDS writes; through w.t()'s strides the
-        # same product is 15 % slower (scalar LDS writes behind loads along k)
-        y = bmm(x, w.t().contiguous() if w.numel() <= (1 << 22) else w.t(), bias=b, bias_axis="n", relu=relu)
+        R, Cin = x.shape
+        Cout = w.shape[0]
+        if x.is_cuda and x.stride(1) == 1 and w.is_contiguous() and _f16_ok(R, Cin, Cout):
+            with on_device_of(x):
+                y = _f16_product(_row_operand(x), R, Cin, _operand(w.detach(), 0), Cout, f32c(b.detach()) if b is not None else None, relu)
+        else:
+            # W^T as its own [Cin, Cout] tensor (a 1 MB copy): l3d_bmm_f32 then stages it with 16-byte LDS writes; through w.t()'s strides
+            # the same product is 15 % slower (scalar LDS writes behind loads along k)
+            y = bmm(x, w.t().contiguous() if w.numel() <= (1 << 22) else w.t(), bias=b, bias_axis="n", relu=relu)
         ctx.relu = relu
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.has_bias = b is not None
@@ -173,7 +221,14 @@ class _LinearRows(torch.autograd.Function):
         if ctx.relu:
             g = g * (y > 0)
         R = x.shape[0]
-        gx = bmm(g, w) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            Cout, Cin = w.shape
+            if g.is_cuda and g.dim() == 2 and g.stride(1) == 1 and _f16_ok(R, Cout, Cin):
+                with on_device_of(g):
+                    gx = _f16_product(_operand(g, 1), R, Cout, _operand(w.detach().t().contiguous(), 0), Cin, None, False)
+            else:
+                gx = bmm(g, w)
         gw = gb = None
         if ctx.needs_input_grad[1]:
             gw = bmm(g.t(), x, parts=_split_parts(w.shape[0], w.shape[1], R))

@@ -320,6 +320,51 @@ def test_colsum_rows_vs_fp64_and_repeatable():
     assert float((lin.bias.grad.double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
+def test_linear_rows_f16x2_route_vs_fp64():
+    """models/_rows.linear at the sizes of a DCP training step (rows % 256 == 0, Cout % 256 == 0): forward and dgrad as f16x2 products with the
+    batch's rows as the kernel's weight operand (l3d_split_f16_operand + l3d_pointwise_conv_f16 with TWO_PLANE | SHIFT_N), weight and bias
+    gradients on l3d_bmm_f32 / l3d_colsum_rows.  Outputs and all gradients against fp64 at the fp32 dot-product level; the three
+    projections of one input split it once; L3D_TRAIN_GEMM=fp32 (the module switch) takes l3d_bmm_f32 for everything."""
+    from learning3d_amd.models import _rows
+    g = torch.Generator().manual_seed(21)
+    for (R, Cin, Cout, relu, scale) in ((4096, 512, 256, False, 1.0), (8192, 256, 512, True, 1e-3), (4096, 1024, 512, True, 30.0)):
+        lin = torch.nn.Linear(Cin, Cout).cuda()
+        x = (torch.randn((R, Cin), generator=g) * scale).cuda().requires_grad_()
+        wgt = torch.randn((R, Cout), generator=g).cuda()
+        with _lib_log() as log:
+            y = _rows.linear(x, lin, relu=relu)
+            (y * wgt).sum().backward()
+        assert log.count("l3d_pointwise_conv_f16[rows]") == 2 and log.count("l3d_bmm_f32") == 1 and "l3d_colsum_rows" in log, log
+        lin64 = torch.nn.Linear(Cin, Cout).double().cuda()
+        lin64.load_state_dict({k: v.double() for k, v in lin.state_dict().items()})
+        x64 = x.detach().double().requires_grad_()
+        y64 = lin64(x64)
+        if relu:                                                   # on the fp32 run's own branches
+            y64 = y64 * (y.detach() > 0)
+        (y64 * wgt.double()).sum().backward()
+        ref = (x.detach() @ lin.weight.detach().t() + lin.bias.detach())
+        e_ref = float((ref.double() - lin64(x64).detach()).abs().max())
+        e_got = float(((y.detach().double() - y64.detach()).abs() * (y.detach() > 0 if relu else 1)).max())
+        assert e_got <= 2.0 * e_ref + 1e-6 * float(y64.abs().max()), (R, Cin, Cout, e_got, e_ref)
+        for name, got, want in (("dx", x.grad, x64.grad), ("dW", lin.weight.grad, lin64.weight.grad), ("db", lin.bias.grad, lin64.bias.grad)):
+            err = float((got.double() - want).abs().max())
+            assert err <= 2e-5 * float(want.abs().max()), (name, R, Cin, Cout, err, float(want.abs().max()))
+    # three layers on one input: one split of the rows
+    lins = [torch.nn.Linear(512, 512).cuda() for _ in range(3)]
+    x = torch.randn((4096, 512), generator=g).cuda()
+    with _lib_log() as log, torch.enable_grad():
+        outs = [_rows.linear(x.requires_grad_(), l) for l in lins]
+    assert log.count("l3d_split_f16_operand") == 1 + 3, log          # the rows once, each weight matrix once
+    prev, _rows.TRAIN_GEMM = _rows.TRAIN_GEMM, "fp32"
+    try:
+        with _lib_log() as log:
+            y32 = _rows.linear(x, lins[0])
+        assert "l3d_pointwise_conv_f16[rows]" not in log and "l3d_bmm_f32" in log
+    finally:
+        _rows.TRAIN_GEMM = prev
+    assert float((y32 - outs[0]).abs().max()) <= 1e-5 * float(y32.abs().max())
+
+
 def test_softmax_rows_forward_backward_vs_fp64():
     from learning3d_amd.models import _rows
     g = torch.Generator().manual_seed(6)

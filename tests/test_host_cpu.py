@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(handle, s), f"{s} declared in include/l3d_hip.h but not exported"
     assert set(syms) == set(_lib.SIGNATURES), "ctypes table and header disagree"
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "l3d_hip.h")).read(), flags=re.S)
-    assert len(set(re.findall(r"\b(l3d_[a-z0-9_]+)\s*\(", text))) <= 96, "the boundary header grew past 96 entry points (90 + l3d_emd_workspace_bytes + l3d_probe_mfma_sustained, round 5; + l3d_chamfer_forward_loss, l3d_colsum_rows and their workspace sizes, round 6)"
+    assert len(set(re.findall(r"\b(l3d_[a-z0-9_]+)\s*\(", text))) <= 97, "the boundary header grew past 97 entry points (90 + l3d_emd_workspace_bytes + l3d_probe_mfma_sustained, round 5; + l3d_chamfer_forward_loss, l3d_colsum_rows and their workspace sizes, l3d_split_f16_operand, round 6)"
     l = _lib.lib()
     assert l.l3d_version() >= 100
     assert b"invalid" in l.l3d_status_string(-1)
@@ -64,10 +64,13 @@ def test_argument_validation_without_gpu():
     assert l.l3d_pointwise_conv_f16(p, p, None, None, 0, 1, 128, 128, 256, 0, 0, None, None, None, None, p, 8, None, 0, None) == -2        # narrow tile wants N % 512
     assert l.l3d_pointwise_conv_f16(p, p, None, None, 0, 1, 128, 256, 256, 0, 0, p, None, None, None, None, 0, p, 100, None) == -2        # group size % 256
     assert l.l3d_pointwise_conv_f16(p, p, None, None, 0, 1, 128, 256, 256, 0, 0, p, None, p, p, None, 0, None, 0, None) == -2          # fp32 rows AND an image
-    assert l.l3d_pointwise_conv_f16(p, p, None, None, 0, 1, 128, 256, 256, 0, 4, p, None, None, None, None, 0, None, 0, None) == -1     # unknown flag
+    assert l.l3d_pointwise_conv_f16(p, p, None, None, 0, 1, 128, 256, 256, 0, 8, p, None, None, None, None, 0, None, 0, None) == -1     # unknown flag
     assert l.l3d_pointwise_conv_f16(p, p, None, None, 0, 1, 128, 256, 256, 0, 2, p, None, None, None, None, 0, None, 0, None) == -2     # unscaled OUTPUT image without the two-plane input form / an image
     assert l.l3d_layernorm_planes_cf(p, p, p, 1e-6, 1, 512, 64, p, None, 2, None) == -1                            # unknown flag
     assert l.l3d_colsum_rows(p, 4, 8, 4, p, p, None) == -1                                                        # row stride < cols
+    assert l.l3d_pointwise_conv_f16(p, p, None, None, 0, 1, 128, 256, 256, 0, 4, p, None, None, None, None, 0, None, 0, None) == -2     # column-indexed shift without the two-plane form
+    assert l.l3d_split_f16_operand(p, 8, 16, 8, 0, p, None, None) == -1                                            # row stride < cols
+    assert l.l3d_split_f16_operand(p, 8, 16, 16, 2, p, None, None) == -1                                           # no such kind
     assert l.l3d_layernorm_planes(p, p, p, 1e-6, 4, 520, None, p, None) == -2                                      # C > 512
     # round-3 entry points
     assert l.l3d_knn_variant(1, 8, 8, 4, p, p, p, p, 7, None) == -1                                                # no such variant
@@ -399,15 +402,16 @@ def test_hot_kernels_compile_without_scratch():
         ok = [a for a in allowed if name.startswith(a)]
         assert ok and sp <= allowed[ok[0]] and sc <= 4 * allowed[ok[0]] + 8, f"{name}: {sc} bytes of scratch, {sp} spilled registers"
     assert not any("rocprim" in n for n in meta), "a library kernel is linked into libl3d_hip.so"
-    hot = {"_Z15conv_f16_kernelILb0ELb0ELb0ELi3ELb0ELb0EE": 224,    # Linear layers / PCN (wide tile, three weight planes): VGPR budget 218 today
-           "_Z15conv_f16_kernelILb0ELb0ELb0ELi2ELb0ELb0EE": 224,    # conv5 of the benchmark step (wide tile, two weight planes)
-           "_Z15conv_f16_kernelILb1ELb0ELb0ELi3ELb0ELb0EE": 224,    # narrow tile
-           "_Z15conv_f16_kernelILb0ELb0ELb0ELi3ELb1ELb0EE": 224,    # residual epilogue (the pointer network's sublayers)
-           "_Z15conv_f16_kernelILb0ELb1ELb0ELi3ELb0ELb0EE": 232,    # + operand maxima (the fused q|k|v projection: 20 % of DCP's forward)
-           "_Z15conv_f16_kernelILb0ELb0ELb1ELi3ELb0ELb0EE": 232,    # + pooled maxima over a group's K neighbours
-           "_Z15conv_f16_kernelILb0ELb0ELb0ELi2ELb1ELb0EE": 224,    # round 6, the pointer network on two-plane images: residual epilogue,
-           "_Z15conv_f16_kernelILb0ELb1ELb0ELi2ELb0ELb0EE": 224,    #   operand maxima,
-           "_Z15conv_f16_kernelILb0ELb0ELb0ELi2ELb0ELb1EE": 224,    #   plane output with an unscaled residual
+    hot = {"_Z15conv_f16_kernelILb0ELb0ELb0ELi3ELb0ELb0ELb0EE": 224,    # Linear layers / PCN (wide tile, three weight planes): VGPR budget 218 today
+           "_Z15conv_f16_kernelILb0ELb0ELb0ELi2ELb0ELb0ELb0EE": 224,    # conv5 of the benchmark step (wide tile, two weight planes)
+           "_Z15conv_f16_kernelILb1ELb0ELb0ELi3ELb0ELb0ELb0EE": 224,    # narrow tile
+           "_Z15conv_f16_kernelILb0ELb0ELb0ELi3ELb1ELb0ELb0EE": 224,    # residual epilogue (the pointer network's sublayers)
+           "_Z15conv_f16_kernelILb0ELb1ELb0ELi3ELb0ELb0ELb0EE": 232,    # + operand maxima (the fused q|k|v projection: 20 % of DCP's forward)
+           "_Z15conv_f16_kernelILb0ELb0ELb1ELi3ELb0ELb0ELb0EE": 232,    # + pooled maxima over a group's K neighbours
+           "_Z15conv_f16_kernelILb0ELb0ELb0ELi2ELb1ELb0ELb0EE": 224,    # round 6, the pointer network on two-plane images: residual epilogue,
+           "_Z15conv_f16_kernelILb0ELb1ELb0ELi2ELb0ELb0ELb0EE": 224,    #   operand maxima,
+           "_Z15conv_f16_kernelILb0ELb0ELb0ELi2ELb0ELb1ELb0EE": 224,    #   plane output with an unscaled residual
+           "_Z15conv_f16_kernelILb0ELb0ELb0ELi2ELb0ELb0ELb1EE": 224,    # the training path's rows-as-weights product (bias along n)
            "_Z14bmm_f32_kernelILi2ELi1ELi1EE": 128,                 # the training GEMM's vector-fetch forms: four workgroups per CU
            "_Z14bmm_f32_kernelILi2ELi1ELi2EE": 128,
            "_Z14bmm_f32_kernelILi2ELi2ELi1EE": 128,
