@@ -449,21 +449,27 @@ __global__ __launch_bounds__(512) void featknn_kernel(const uint4 *__restrict__ 
             constexpr int OWN = decltype(own_c)::value;
             const float *V = lv + rq * FK_LVS;
             const unsigned short *I = li + rq * FK_LIS;
-            float ov[OWN];
+            // (value, index) as ONE 64-bit key -- order-preserving value bits << 32 | ~index: larger = nearer, the lower index first under
+            // equal values -- so that a comparison is v_cmp_gt_u64 + v_addc instead of three compares and two logic operations
+            auto key_of = [](float v, unsigned i) {
+                const unsigned bits = __float_as_uint(v + 0.0f);                               // -0 -> +0
+                const unsigned sk = bits ^ ((unsigned)((int)bits >> 31) | 0x80000000u);
+                return ((fk_u64)sk << 32) | (unsigned)(~i);
+            };
+            fk_u64 own[OWN];
             int oi[OWN], rank[OWN];
 #pragma unroll
             for (int j = 0; j < OWN; j++) {
                 const int o = part + 4 * j;
-                ov[j] = o < M ? V[o] : INFINITY;
                 oi[j] = o < M ? (int)I[o] : -1;
+                own[j] = o < M ? key_of(V[o], (unsigned)oi[j]) : ~(fk_u64)0;
                 rank[j] = 0;
             }
 #pragma unroll 4
             for (int f = 0; f < M; f++) {
-                const float fv = V[f];
-                const int fi = I[f];
+                const fk_u64 kf = key_of(V[f], (unsigned)I[f]);
 #pragma unroll
-                for (int j = 0; j < OWN; j++) rank[j] += (int)(fv > ov[j]) | ((int)(fv == ov[j]) & (int)(fi < oi[j]));
+                for (int j = 0; j < OWN; j++) rank[j] += (int)(kf > own[j]);
             }
 #pragma unroll
             for (int j = 0; j < OWN; j++)
