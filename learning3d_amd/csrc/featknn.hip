@@ -85,9 +85,40 @@ __global__ __launch_bounds__(512) void featknn_split_kernel(const float *__restr
     const float *xb = x + (size_t)b * C * N;
     const int noct = Cp / 8;
     uint4 *ph = planes + (size_t)b * 2 * noct * Np, *pm = ph + (size_t)noct * Np;
+    // The thread's values once, with every load in flight (round 6: the maximum was a loop of one dependent load per channel -- 16 trips
+    // to memory for C = 64, 12 us for 16 MB of traffic): up to four octets per thread (C <= 128) stay in registers for the split below;
+    // wider inputs take the maximum eight loads at a time and read the values again (L2).
+    constexpr int KEEP = 4;
+    const bool keep = noct <= 4 * KEEP;
+    float kv[KEEP][8];
     float big = 0.f;
-    if (n < N)
-        for (int c = part; c < C; c += 4) big = fmaxf(big, fabsf(xb[(size_t)c * N + n]));
+    if (keep) {
+#pragma unroll
+        for (int i = 0; i < KEEP; i++) {
+            const int o = part + 4 * i;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int c = min(o * 8 + u, C - 1);                    // clamped: no condition around the load
+                kv[i][u] = xb[(size_t)c * N + min(n, N - 1)];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < KEEP; i++)
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const bool in = n < N && (part + 4 * i) * 8 + u < C;
+                kv[i][u] = in ? kv[i][u] : 0.f;
+                big = fmaxf(big, fabsf(kv[i][u]));
+            }
+    } else if (n < N) {
+        for (int o = part; o < noct; o += 4) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = xb[(size_t)min(o * 8 + u, C - 1) * N + n];
+#pragma unroll
+            for (int u = 0; u < 8; u++) big = fmaxf(big, o * 8 + u < C ? fabsf(v[u]) : 0.f);
+        }
+    }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) big = fmaxf(big, __shfl_xor(big, d, 64));
     if ((t & 63) == 0) tmax[t >> 6] = big;
@@ -99,10 +130,7 @@ __global__ __launch_bounds__(512) void featknn_split_kernel(const float *__restr
     const int T = fin ? 12 - e : 0;
     const float up = ldexpf(1.0f, T);
     float s = 0.f;
-    for (int o = part; o < noct; o += 4) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = (n < N && o * 8 + u < C) ? xb[(size_t)(o * 8 + u) * N + n] : 0.f;
+    auto emit = [&](int o, const float (&v)[8]) {
 #pragma unroll
         for (int u = 0; u < 8; u++) s = s + v[u] * v[u];           // x ** 2 then sum: no fused multiply-add
         uint4 h, m;
@@ -112,6 +140,18 @@ __global__ __launch_bounds__(512) void featknn_split_kernel(const float *__restr
         af_split_x_unscaled(v[6], v[7], up, h.w, m.w);
         ph[(size_t)o * Np + n] = h;
         pm[(size_t)o * Np + n] = m;
+    };
+    if (keep) {
+#pragma unroll
+        for (int i = 0; i < KEEP; i++)
+            if (part + 4 * i < noct) emit(part + 4 * i, kv[i]);
+    } else {
+        for (int o = part; o < noct; o += 4) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = (n < N && o * 8 + u < C) ? xb[(size_t)(o * 8 + u) * N + n] : 0.f;
+            emit(o, v);
+        }
     }
     red[part][r] = s;
     __syncthreads();
