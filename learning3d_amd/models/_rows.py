@@ -202,7 +202,7 @@ class _LinearRows(torch.autograd.Function):
     def forward(ctx, x, w, b, relu):
         R, Cin = x.shape
         Cout = w.shape[0]
-        if x.is_cuda and x.stride(1) == 1 and w.is_contiguous() and _f16_ok(R, Cin, Cout):
+        if x.is_cuda and x.stride(1) == 1 and x.stride(0) >= Cin and w.is_contiguous() and _f16_ok(R, Cin, Cout):
             with on_device_of(x):
                 y = _f16_product(_row_operand(x), R, Cin, _operand(w.detach(), 0), Cout, f32c(b.detach()) if b is not None else None, relu)
         else:
@@ -224,7 +224,7 @@ class _LinearRows(torch.autograd.Function):
         gx = None
         if ctx.needs_input_grad[0]:
             Cout, Cin = w.shape
-            if g.is_cuda and g.dim() == 2 and g.stride(1) == 1 and _f16_ok(R, Cout, Cin):
+            if g.is_cuda and g.dim() == 2 and g.stride(1) == 1 and g.stride(0) >= Cout and _f16_ok(R, Cout, Cin):
                 with on_device_of(g):
                     gx = _f16_product(_operand(g, 1), R, Cout, _operand(w.detach().t().contiguous(), 0), Cin, None, False)
             else:
