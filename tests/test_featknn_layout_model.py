@@ -123,3 +123,28 @@ def test_lds_budget():
     for T in (6, 9, 17):                                              # the bound exchange lives in the idle stages
         assert (4 * T + 1) * 128 * 4 <= 2 * stage
     assert 32 * 192 * 8 <= 2 * stage                                  # a batch of 32 workspace lists (K = 64) staged for ranking
+
+
+def test_rows_as_weight_operand_layout():
+    # models/_rows.py, round 6: y [rows, Cout] = x W^T through l3d_pointwise_conv_f16 with the batch's rows as the kernel's WEIGHT operand.
+    # The kernel writes y[b][co][n] at (b Cout + co) N + n for weight row co and activation row n; with B = 1, "Cout" = rows and "N" = the
+    # layer's Cout that offset is row * Cout + c: row-major [rows, Cout].  The two-plane form reads the weight image's planes 0 (H) and
+    # 2 (M) and the scale behind plane 2: where l3d_split_f16_operand (kind 1) puts h, m and 2^-T.
+    rows, Cout, Cin = 512, 256, 64
+    rng = np.random.default_rng(0)
+    x, W = rng.standard_normal((rows, Cin)), rng.standard_normal((Cout, Cin))
+    y_kernel = np.empty(rows * Cout)
+    for co in range(0, rows, 37):                       # the kernel's indices: weight row co (a batch row), activation row n (an output channel)
+        for n in range(0, Cout, 11):
+            y_kernel[(0 * rows + co) * Cout + n] = x[co] @ W[n]
+            assert y_kernel[co * Cout + n] == (x @ W.T)[co, n]
+    plane = lambda r, c: ((c + 7) // 8) * r * 16           # common.h: l3d_f16_plane_bytes
+    pb = plane(rows, Cin)
+    weight_image_bytes, act_image_bytes = 3 * pb + 16, 2 * pb + 16
+    h_off, m_off, inv_off = 0, 2 * pb, 3 * pb              # kind 1: the slots the two-plane kernel reads (wH, wM = wp + 2 wpb, winv = wp + 3 wpb)
+    assert inv_off + 16 == weight_image_bytes and m_off + pb == inv_off
+    assert (0, pb, 2 * pb) == (0, pb, act_image_bytes - 16)   # kind 0: h | m | 2^-T, an ordinary activation image
+    # a cell: 8 consecutive k of one row, octet-major: [k / 8][row][8 fp16]
+    cell = lambda row, k: ((k // 8) * rows + row) * 16 + (k % 8) * 2
+    seen = {cell(r, k) for r in range(rows) for k in range(Cin)}
+    assert len(seen) == rows * Cin and max(seen) + 2 == pb
