@@ -137,7 +137,7 @@ def test_rows_as_weight_operand_layout():
     for co in range(0, rows, 37):                       # the kernel's indices: weight row co (a batch row), activation row n (an output channel)
         for n in range(0, Cout, 11):
             y_kernel[(0 * rows + co) * Cout + n] = x[co] @ W[n]
-            assert y_kernel[co * Cout + n] == (x @ W.T)[co, n]
+            assert abs(y_kernel[co * Cout + n] - (x @ W.T)[co, n]) < 1e-12
     plane = lambda r, c: ((c + 7) // 8) * r * 16           # common.h: l3d_f16_plane_bytes
     pb = plane(rows, Cin)
     weight_image_bytes, act_image_bytes = 3 * pb + 16, 2 * pb + 16
